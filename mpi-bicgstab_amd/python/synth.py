@@ -1,0 +1,191 @@
+"""Synthetic CSR matrices and the reference's row-block partition (host-side, numpy only).
+
+The reference reads its matrices from Matrix-Market files (reference src/matrix.c:268-419) and the
+real Transport.mtx is not available offline, so benchmarks and tests use the generators below
+(SURVEY.md section 8d "Synthetic inputs"):
+
+* ``transport_like``  -- Transport-*shaped*: n = 1 602 111 rows, 15 fixed diagonals
+  {0, +-1, +-117, +-118, +-13689, +-13690, +-13806, +-13807} clipped to [0, n)
+  => 23 921 209 non-zeros (Transport.mtx itself: 23 487 281, reference README.md:32-42).
+* ``banded``          -- dense band of half-bandwidth b.
+* ``stencil7``        -- 7-point stencil on an m^3 grid (tiny KAT: m = 12, nonsymmetric weights).
+
+Right-hand sides follow reference src/main.c:109-117: b = A * 1, x0 = 0.
+
+``split_blocks`` mirrors MPI_coo_load_matrix_block's partition and diag/offd split
+(reference src/matrix.c:295-308, 336-340, 380-392) for in-memory CSR input.
+"""
+from __future__ import annotations
+
+import dataclasses
+
+import numpy as np
+
+TRANSPORT_N = 1_602_111
+TRANSPORT_OFFSETS = (0, 1, -1, 117, -117, 118, -118, 13689, -13689, 13690, -13690, 13806, -13806,
+                     13807, -13807)
+
+
+@dataclasses.dataclass
+class CSR:
+    """CSR with the reference's index width (uint32, reference src/matrix.h:19-26)."""
+    rows: int
+    cols: int
+    ptr: np.ndarray   # uint32 [rows+1]
+    col: np.ndarray   # uint32 [nnz]
+    val: np.ndarray   # float64 [nnz]
+
+    @property
+    def nnz(self) -> int:
+        return int(self.ptr[-1])
+
+    def matvec(self, x: np.ndarray) -> np.ndarray:
+        """y = A x with numpy (pairwise sums; NOT the oracle -- only for building b = A*1)."""
+        prod = self.val * x[self.col]
+        ptr = self.ptr.astype(np.int64)
+        y = np.zeros(self.rows)
+        nonempty = ptr[1:] > ptr[:-1]
+        y[nonempty] = np.add.reduceat(prod, ptr[:-1][nonempty])
+        return y
+
+    def to_coo(self):
+        row = np.repeat(np.arange(self.rows, dtype=np.uint32), np.diff(self.ptr.astype(np.int64)))
+        return row, self.col.copy(), self.val.copy()
+
+
+def _uniform(idx: np.ndarray, seed: int) -> np.ndarray:
+    """Counter-based U[0,1): splitmix64 of (seed + idx), top 53 bits."""
+    with np.errstate(over="ignore"):
+        z = idx.astype(np.uint64) + np.uint64(seed) + np.uint64(0x9E3779B97F4A7C15)
+        z = (z ^ (z >> np.uint64(30))) * np.uint64(0xBF58476D1CE4E5B9)
+        z = (z ^ (z >> np.uint64(27))) * np.uint64(0x94D049BB133111EB)
+        z = z ^ (z >> np.uint64(31))
+    return (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
+
+
+def from_offsets(n: int, offsets, diag_base: float = 16.0, seed: int = 12345) -> CSR:
+    """Rows hold one entry per offset (clipped to [0, n)), ascending column order.
+
+    diagonal = diag_base + U[0,1); off-diagonal = -(0.5 + 0.5 U[0,1)).  diag_base = 16 is the
+    strongly dominant law of SURVEY.md section 8d; smaller values give harder systems.
+    """
+    offs = np.array(sorted(offsets), dtype=np.int64)
+    k = len(offs)
+    rows = np.arange(n, dtype=np.int64)
+    cols = rows[:, None] + offs[None, :]                     # [n, k]
+    ok = (cols >= 0) & (cols < n)
+    counts = ok.sum(axis=1)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(counts, out=ptr[1:])
+    eid = rows[:, None] * k + np.arange(k, dtype=np.int64)[None, :]
+    u = _uniform(eid[ok], seed)
+    is_diag = np.broadcast_to(offs[None, :] == 0, cols.shape)[ok]
+    val = np.where(is_diag, diag_base + u, -(0.5 + 0.5 * u))
+    return CSR(n, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), val)
+
+
+def transport_like(n: int = TRANSPORT_N, diag_base: float = 16.0, seed: int = 12345) -> CSR:
+    return from_offsets(n, TRANSPORT_OFFSETS, diag_base, seed)
+
+
+def banded(n: int, half_bw: int, diag_base: float | None = None, seed: int = 777) -> CSR:
+    if diag_base is None:
+        diag_base = 2.0 * half_bw + 1.0
+    return from_offsets(n, range(-half_bw, half_bw + 1), diag_base, seed)
+
+
+def stencil7(m: int, weights=(6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)) -> CSR:
+    """7-point stencil on an m^3 grid; weights = (centre, x-, x+, y-, y+, z-, z+)."""
+    n = m ** 3
+    idx = np.arange(n, dtype=np.int64)
+    ix, iy, iz = idx % m, (idx // m) % m, idx // (m * m)
+    cand = [  # (offset, mask, weight) in ascending column order
+        (-m * m, iz > 0, weights[5]), (-m, iy > 0, weights[3]), (-1, ix > 0, weights[1]),
+        (0, np.ones(n, bool), weights[0]),
+        (1, ix < m - 1, weights[2]), (m, iy < m - 1, weights[4]), (m * m, iz < m - 1, weights[6]),
+    ]
+    cols = np.stack([idx + o for o, _, _ in cand], axis=1)
+    ok = np.stack([msk for _, msk, _ in cand], axis=1)
+    vals = np.broadcast_to(np.array([w for _, _, w in cand], dtype=np.float64)[None, :], cols.shape)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ok.sum(axis=1), out=ptr[1:])
+    return CSR(n, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), vals[ok].copy())
+
+
+def random_rows(n: int, max_row: int, seed: int = 1, empty_frac: float = 0.1, long_rows=()) -> CSR:
+    """Ragged test matrix: random row lengths in [0, max_row], some empty rows, optional very long
+    rows (row index -> length); diagonal made dominant where present."""
+    rng = np.random.default_rng(seed)
+    lens = rng.integers(1, max_row + 1, size=n)
+    lens[rng.random(n) < empty_frac] = 0
+    for r, ln in dict(long_rows).items():
+        lens[r] = min(ln, n)
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(lens, out=ptr[1:])
+    col = np.empty(int(ptr[-1]), dtype=np.uint32)
+    val = rng.uniform(-1.0, 1.0, size=int(ptr[-1]))
+    for i in range(n):
+        ln = int(lens[i])
+        if ln:
+            c = rng.choice(n, size=ln, replace=False)
+            if ln < 64:
+                c[0] = i                      # keep a diagonal entry in short rows
+            c.sort()
+            col[ptr[i]:ptr[i + 1]] = c
+            seg = val[ptr[i]:ptr[i + 1]]
+            d = np.nonzero(c == i)[0]
+            if d.size:
+                seg[d[0]] = np.abs(seg).sum() + 1.0
+    return CSR(n, n, ptr.astype(np.uint32), col, val)
+
+
+def colmajor_coo(A: CSR):
+    """COO triplets in column-major order (how SuiteSparse .mtx files are written)."""
+    row, col, val = A.to_coo()
+    order = np.lexsort((row, col))
+    return row[order], col[order], val[order]
+
+
+def write_mtx(path: str, A: CSR, order: str = "colmajor") -> None:
+    """Write 'coordinate real general' (the only flavour the reference block loader handles,
+    SURVEY.md section 4 defect 2); 17 significant digits so values round-trip exactly."""
+    if order == "colmajor":
+        row, col, val = colmajor_coo(A)
+    else:
+        row, col, val = A.to_coo()
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{A.rows} {A.cols} {A.nnz}\n")
+        for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
+            f.write(f"{i + 1} {j + 1} {v!r}\n")
+
+
+def partition(n: int, nranks: int):
+    """(counts, displs) of reference src/matrix.c:295-308."""
+    base, extra = divmod(n, nranks)
+    counts = np.array([base + (1 if p < extra else 0) for p in range(nranks)], dtype=np.int32)
+    displs = np.zeros(nranks, dtype=np.int32)
+    np.cumsum(counts[:-1], out=displs[1:])
+    return counts, displs
+
+
+def split_blocks(A: CSR, nranks: int, rank: int):
+    """(diag, offd, counts, displs) for one rank: diag has LOCAL columns and cols = local rows,
+    offd keeps GLOBAL columns and cols = n (reference src/matrix.c:343-351, 380-392)."""
+    counts, displs = partition(A.rows, nranks)
+    lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+    ptr = A.ptr.astype(np.int64)
+    a, b = int(ptr[lo]), int(ptr[hi])
+    col = A.col[a:b].astype(np.int64)
+    val = A.val[a:b]
+    rowid = np.repeat(np.arange(hi - lo), np.diff(ptr[lo:hi + 1]))
+    local = (col >= lo) & (col < hi)
+
+    def build(mask, ncols, shift):
+        cnt = np.bincount(rowid[mask], minlength=hi - lo)
+        p = np.zeros(hi - lo + 1, dtype=np.int64)
+        np.cumsum(cnt, out=p[1:])
+        return CSR(hi - lo, ncols, p.astype(np.uint32), (col[mask] - shift).astype(np.uint32),
+                   val[mask].copy())
+
+    return build(local, hi - lo, lo), build(~local, A.cols, 0), counts, displs

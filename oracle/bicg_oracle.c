@@ -1,0 +1,399 @@
+/*
+ * bicg_oracle.c -- CPU ORACLE (test infrastructure, NOT product code). See bicg_oracle.h.
+ *
+ * Build: gcc -O2 -ffp-contract=off -fPIC -shared (no FMA contraction, so every a*b+c is two
+ * roundings exactly as in an -O2 x86-64 build of the reference without -march=native).
+ * Every function names the reference lines it restates.
+ */
+#include "bicg_oracle.h"
+
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+
+/* ------------------------------------------------------------------ partition */
+
+/* reference src/matrix.c:295-308: m/P rows each, the first m%P ranks get one more. */
+void orc_partition(unsigned n, int P, int *counts, int *displs)
+{
+    int base = (int)(n / (unsigned)P), extra = (int)(n % (unsigned)P);
+    for (int p = 0; p < P; ++p) {
+        int lo = p * base + (p < extra ? p : extra);
+        counts[p] = base + (p < extra ? 1 : 0);
+        displs[p] = lo;
+    }
+}
+
+static void csr_alloc(orc_csr *A, unsigned rows, unsigned cols, unsigned nz)
+{
+    A->rows = rows; A->cols = cols; A->nz = nz;
+    A->val = (double *)calloc(nz ? nz : 1, sizeof(double));
+    A->col = (unsigned *)calloc(nz ? nz : 1, sizeof(unsigned));
+    A->ptr = (unsigned *)calloc((size_t)rows + 1, sizeof(unsigned));
+}
+
+static void csr_release(orc_csr *A) { free(A->val); free(A->col); free(A->ptr); }
+
+/*
+ * reference src/matrix.c:336-340 and 380-392 classify each triplet of the file as diag (row and
+ * column inside the rank's range, column made local) or offd (row inside, column kept GLOBAL);
+ * coo2csr (206-232) then orders by row with a stable merge sort, i.e. file order inside a row.
+ * A counting sort on the row key that scans the triplets in file order produces the same CSR.
+ */
+orc_dist *orc_dist_from_coo(unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                            const double *val, int P)
+{
+    orc_dist *d = (orc_dist *)calloc(1, sizeof(orc_dist));
+    d->P = P; d->n = n;
+    d->counts = (int *)malloc(sizeof(int) * (size_t)P);
+    d->displs = (int *)malloc(sizeof(int) * (size_t)P);
+    d->diag = (orc_csr *)calloc((size_t)P, sizeof(orc_csr));
+    d->offd = (orc_csr *)calloc((size_t)P, sizeof(orc_csr));
+    orc_partition(n, P, d->counts, d->displs);
+
+    /* owner of every row */
+    int *owner = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
+    for (int p = 0; p < P; ++p)
+        for (int i = 0; i < d->counts[p]; ++i) owner[d->displs[p] + i] = p;
+
+    /* pass 1: per-row counts for both blocks (global row index) */
+    unsigned *cnt_d = (unsigned *)calloc((size_t)n + 1, sizeof(unsigned));
+    unsigned *cnt_o = (unsigned *)calloc((size_t)n + 1, sizeof(unsigned));
+    for (unsigned e = 0; e < nnz; ++e) {
+        int p = owner[row[e]];
+        unsigned lo = (unsigned)d->displs[p], hi = lo + (unsigned)d->counts[p];
+        if (col[e] >= lo && col[e] < hi) cnt_d[row[e]]++; else cnt_o[row[e]]++;
+    }
+    for (int p = 0; p < P; ++p) {
+        unsigned lo = (unsigned)d->displs[p], rows = (unsigned)d->counts[p];
+        unsigned nd = 0, no = 0;
+        for (unsigned i = 0; i < rows; ++i) { nd += cnt_d[lo + i]; no += cnt_o[lo + i]; }
+        csr_alloc(&d->diag[p], rows, rows, nd);  /* src/matrix.c:343-345: cols = local rows */
+        csr_alloc(&d->offd[p], rows, n, no);     /* src/matrix.c:350-352: cols = n (global) */
+        unsigned ad = 0, ao = 0;
+        for (unsigned i = 0; i < rows; ++i) {
+            d->diag[p].ptr[i] = ad; ad += cnt_d[lo + i];
+            d->offd[p].ptr[i] = ao; ao += cnt_o[lo + i];
+        }
+        d->diag[p].ptr[rows] = ad; d->offd[p].ptr[rows] = ao;
+    }
+    /* pass 2: scatter in file order (fill cursors reuse cnt arrays) */
+    memset(cnt_d, 0, sizeof(unsigned) * ((size_t)n + 1));
+    memset(cnt_o, 0, sizeof(unsigned) * ((size_t)n + 1));
+    for (unsigned e = 0; e < nnz; ++e) {
+        int p = owner[row[e]];
+        unsigned lo = (unsigned)d->displs[p], hi = lo + (unsigned)d->counts[p];
+        unsigned li = row[e] - lo;
+        if (col[e] >= lo && col[e] < hi) {
+            unsigned k = d->diag[p].ptr[li] + cnt_d[row[e]]++;
+            d->diag[p].val[k] = val[e]; d->diag[p].col[k] = col[e] - lo;
+        } else {
+            unsigned k = d->offd[p].ptr[li] + cnt_o[row[e]]++;
+            d->offd[p].val[k] = val[e]; d->offd[p].col[k] = col[e];
+        }
+    }
+    free(cnt_d); free(cnt_o); free(owner);
+    return d;
+}
+
+void orc_dist_free(orc_dist *d)
+{
+    if (!d) return;
+    for (int p = 0; p < d->P; ++p) { csr_release(&d->diag[p]); csr_release(&d->offd[p]); }
+    free(d->diag); free(d->offd); free(d->counts); free(d->displs); free(d);
+}
+
+/*
+ * Matrix-Market reader for the only flavour the reference's block loader handles correctly
+ * ("coordinate real general"; src/matrix.c:363-378 never assigns val for pattern/integer and
+ * never mirrors symmetric storage -- SURVEY.md section 4 defect 2). 1-based -> 0-based as in
+ * src/matrix.c:333-334.
+ */
+int orc_read_mtx(const char *path, unsigned *n_rows, unsigned *n_cols, unsigned *nnz,
+                 unsigned **row, unsigned **col, double **val)
+{
+    FILE *f = fopen(path, "r");
+    if (!f) return 1;
+    char line[1100];
+    if (!fgets(line, sizeof line, f) || strncmp(line, "%%MatrixMarket", 14) != 0) { fclose(f); return 2; }
+    if (!strstr(line, "coordinate") || !strstr(line, "real") || !strstr(line, "general")) { fclose(f); return 3; }
+    do { if (!fgets(line, sizeof line, f)) { fclose(f); return 4; } } while (line[0] == '%');
+    unsigned m, n, nz;
+    if (sscanf(line, "%u %u %u", &m, &n, &nz) != 3) { fclose(f); return 5; }
+    *row = (unsigned *)malloc(sizeof(unsigned) * (size_t)(nz ? nz : 1));
+    *col = (unsigned *)malloc(sizeof(unsigned) * (size_t)(nz ? nz : 1));
+    *val = (double *)malloc(sizeof(double) * (size_t)(nz ? nz : 1));
+    for (unsigned e = 0; e < nz; ++e) {
+        unsigned i, j; double v;
+        if (fscanf(f, "%u %u %lg", &i, &j, &v) != 3) { fclose(f); return 6; }
+        (*row)[e] = i - 1; (*col)[e] = j - 1; (*val)[e] = v;
+    }
+    fclose(f);
+    *n_rows = m; *n_cols = n; *nnz = nz;
+    return 0;
+}
+
+/* ------------------------------------------------------------------ kernels */
+
+/* reference src/matrix.c:498-516: per row a fresh accumulator summed in stored order, then
+ * ADDED to y (y is not overwritten). */
+void orc_mult(const orc_csr *A, const double *x, double *y)
+{
+    for (unsigned i = 0; i < A->rows; ++i) {
+        double acc = 0.0;
+        for (unsigned j = A->ptr[i]; j < A->ptr[i + 1]; ++j) acc += A->val[j] * x[A->col[j]];
+        y[i] += acc;
+    }
+}
+
+/* reference src/matrix.c:428-441: allgather x (here: x already is the concatenation), zero y,
+ * diag product with the rank's own slice of x, then offd product with the full x. */
+void orc_spmv(const orc_dist *d, const double *x, double *y)
+{
+    for (int p = 0; p < d->P; ++p) {
+        double *yp = y + d->displs[p];
+        for (int i = 0; i < d->counts[p]; ++i) yp[i] = 0.0;
+        orc_mult(&d->diag[p], x + d->displs[p], yp);
+        orc_mult(&d->offd[p], x, yp);
+    }
+}
+
+/* reference src/vector.c:3-7 */
+void orc_daxpy(int n, double a, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] += a * x[i]; }
+/* reference src/vector.c:9-15 */
+double orc_ddot(int n, const double *x, const double *y) { double s = 0.0; for (int i = 0; i < n; ++i) s += x[i] * y[i]; return s; }
+/* reference src/vector.c:17-21 */
+void orc_dscal(int n, double a, double *x) { for (int i = 0; i < n; ++i) x[i] *= a; }
+/* reference src/vector.c:23-27 */
+void orc_dcopy(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) y[i] = x[i]; }
+
+/* my_ddot per rank + MPI_Iallreduce(MPI_SUM) (e.g. src/solver.c:89-91). MPI leaves the
+ * association of the P partial sums unspecified; MPICH's recursive doubling gives the balanced
+ * pairwise tree ((p0+p1)+(p2+p3))+... for power-of-two P, which is what is restated here
+ * (bit-identical to the reference under conda MPICH 3.3.2 at P = 1, 2, 4 -- see
+ * tests/test_oracle_golden.py). Other P: pairs first, leftovers carried upward. */
+double orc_dist_dot(const orc_dist *d, const double *x, const double *y)
+{
+    double part[1024];
+    int m = d->P;
+    if (m > 1024) m = 1024;
+    for (int p = 0; p < m; ++p)
+        part[p] = orc_ddot(d->counts[p], x + d->displs[p], y + d->displs[p]);
+    while (m > 1) {
+        int h = 0;
+        for (int p = 0; p + 1 < m; p += 2) part[h++] = part[p] + part[p + 1];
+        if (m & 1) part[h++] = part[m - 1];
+        m = h;
+    }
+    return part[0];
+}
+
+/* ------------------------------------------------------------------ solvers */
+
+static double *vec_new(unsigned n) { return (double *)calloc(n ? n : 1, sizeof(double)); }
+
+static void trace_put(orc_opts *o, int k, double a, double w, double b, double rr)
+{
+    if (k < 1 || k > o->max_iter) return;
+    if (o->tr_alpha) o->tr_alpha[k - 1] = a;
+    if (o->tr_omega) o->tr_omega[k - 1] = w;
+    if (o->tr_beta)  o->tr_beta[k - 1]  = b;
+    if (o->tr_dotr)  o->tr_dotr[k - 1]  = rr;
+}
+
+/* u <- add + beta (u - omega v): the 3-call pattern daxpy(-omega) / dscal(beta) / daxpy(1.0)
+ * of src/solver.c:217-219, 220-222, 352-360. */
+static void recur3(int n, double omega, double beta, const double *v, const double *add, double *u)
+{
+    orc_daxpy(n, -omega, v, u);
+    orc_dscal(n, beta, u);
+    orc_daxpy(n, 1.0, add, u);
+}
+
+/* reference src/solver.c:35-146 */
+static int solve_plain(const orc_dist *d, double *x, double *r, orc_opts *o)
+{
+    int n = (int)d->n, k = 0;
+    double *Ax = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *y = vec_new(d->n), *p = vec_new(d->n);
+    double rTr, rTs, rTy, yTy, rTr_old, alpha = 0, beta = 0, omega = 0, dot_r, dot_zero;
+
+    orc_spmv(d, x, Ax);                 /* :74 */
+    orc_daxpy(n, -1.0, Ax, r);          /* :75  r = b - A x0 */
+    orc_dcopy(n, r, rh);                /* :76 */
+    orc_dcopy(n, r, p);                 /* :77 */
+    rTr = orc_dist_dot(d, r, r);        /* :78-80 */
+    dot_r = rTr; dot_zero = rTr;        /* :82-83 */
+
+    while (dot_r > o->tol * o->tol * dot_zero && k < o->max_iter) {     /* :86 */
+        orc_spmv(d, p, s);                          /* :88 */
+        rTs = orc_dist_dot(d, rh, s);               /* :89-91 */
+        alpha = rTr / rTs;                          /* :93 */
+        orc_daxpy(n, -alpha, s, r);                 /* :94  q (kept in r) */
+        orc_spmv(d, r, y);                          /* :96 */
+        rTy = orc_dist_dot(d, r, y);                /* :97 */
+        yTy = orc_dist_dot(d, y, y);                /* :99 */
+        omega = rTy / yTy;                          /* :104 */
+        orc_daxpy(n, alpha, p, x);                  /* :105 */
+        orc_daxpy(n, omega, r, x);                  /* :106 */
+        orc_daxpy(n, -omega, y, r);                 /* :107 */
+        dot_r = orc_dist_dot(d, r, r);              /* :108 */
+        rTr_old = rTr;                              /* :110 */
+        rTr = orc_dist_dot(d, rh, r);               /* :111 */
+        beta = (alpha / omega) * (rTr / rTr_old);   /* :116 */
+        orc_dscal(n, beta, p);                      /* :117 */
+        orc_daxpy(n, 1.0, r, p);                    /* :118 */
+        orc_daxpy(n, -beta * omega, s, p);          /* :119 */
+        k++;
+        trace_put(o, k, alpha, omega, beta, dot_r);
+    }
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(Ax); free(rh); free(s); free(y); free(p);
+    return k;
+}
+
+/* reference src/solver.c:160-278. p, s, z and omega are read before they are written there
+ * (SURVEY.md section 4 defect 1); they are DEFINED as zero here, which is what the reference
+ * computes whenever its malloc'ed pages are fresh. */
+static int solve_ca(const orc_dist *d, double *x, double *r, orc_opts *o)
+{
+    int n = (int)d->n, k = 0;
+    double *Ax = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *z = vec_new(d->n),
+           *w = vec_new(d->n), *p = vec_new(d->n);
+    double rTr, rTw, wTw, rTs, rTz, rTr_old, alpha, beta, omega = 0.0, dot_r, dot_zero;
+
+    orc_spmv(d, x, Ax);                 /* :200 */
+    orc_daxpy(n, -1.0, Ax, r);          /* :201 */
+    orc_dcopy(n, r, rh);                /* :202 */
+    rTr = orc_dist_dot(d, r, r);        /* :203 */
+    orc_spmv(d, r, w);                  /* :205 */
+    rTw = orc_dist_dot(d, r, w);        /* :206 */
+    alpha = rTr / rTw;                  /* :210 */
+    beta = 0;                           /* :211 */
+    dot_r = rTr; dot_zero = rTr;
+
+    while (dot_r > o->tol * o->tol * dot_zero && k < o->max_iter) {     /* :216 */
+        recur3(n, omega, beta, s, r, p);            /* :217-219 */
+        recur3(n, omega, beta, z, w, s);            /* :220-222 */
+        orc_spmv(d, s, z);                          /* :224 */
+        orc_daxpy(n, -alpha, s, r);                 /* :225 q */
+        orc_daxpy(n, -alpha, z, w);                 /* :226 y */
+        rTw = orc_dist_dot(d, r, w);                /* :227 (q,y) */
+        wTw = orc_dist_dot(d, w, w);                /* :228 (y,y) */
+        omega = rTw / wTw;                          /* :232 */
+        orc_daxpy(n, alpha, p, x);                  /* :233 */
+        orc_daxpy(n, omega, r, x);                  /* :234 */
+        orc_daxpy(n, -omega, w, r);                 /* :235 */
+        dot_r = orc_dist_dot(d, r, r);              /* :236 */
+        orc_spmv(d, r, w);                          /* :238 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);               /* :240 */
+        rTw = orc_dist_dot(d, rh, w);               /* :241 */
+        rTs = orc_dist_dot(d, rh, s);               /* :242 */
+        rTz = orc_dist_dot(d, rh, z);               /* :243 */
+        double alpha_used = alpha;
+        beta = (alpha / omega) * (rTr / rTr_old);               /* :248 */
+        alpha = rTr / (rTw + beta * (rTs - omega * rTz));       /* :249 */
+        k++;
+        trace_put(o, k, alpha_used, omega, beta, dot_r);
+    }
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(Ax); free(rh); free(s); free(z); free(w); free(p);
+    return k;
+}
+
+/* reference src/solver.c:292-417 (rr == 0) and 433-576 (rr != 0: residual replacement when
+ * k % krr == 0 && k > 0 && k <= krr*nrr, :498 and :522). Same zero definition of the
+ * uninitialised p, s, z, v, omega as solve_ca. */
+static int solve_pipe(const orc_dist *d, double *x, double *r, orc_opts *o, int rr)
+{
+    int n = (int)d->n, k = 0;
+    double *b = vec_new(d->n), *Ax = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n),
+           *z = vec_new(d->n), *w = vec_new(d->n), *p = vec_new(d->n), *v = vec_new(d->n),
+           *t = vec_new(d->n);
+    double rTr, rTw, wTw, rTs, rTz, rTr_old, alpha, beta, omega = 0.0, dot_r, dot_zero;
+
+    if (rr) orc_dcopy(n, r, b);         /* :475 */
+    orc_spmv(d, x, Ax);                 /* :333 */
+    orc_daxpy(n, -1.0, Ax, r);          /* :334 */
+    orc_dcopy(n, r, rh);                /* :335 */
+    rTr = orc_dist_dot(d, r, r);        /* :336 */
+    orc_spmv(d, r, w);                  /* :338 */
+    rTw = orc_dist_dot(d, r, w);        /* :339 */
+    orc_spmv(d, w, t);                  /* :341 */
+    alpha = rTr / rTw;                  /* :345 */
+    beta = 0;                           /* :346 */
+    dot_r = rTr; dot_zero = rTr;
+
+    while (dot_r > o->tol * o->tol * dot_zero && k < o->max_iter) {     /* :351 */
+        int replace = rr && (k % o->krr == 0) && k > 0 && k <= o->krr * o->nrr;
+        recur3(n, omega, beta, s, r, p);            /* :352-354 */
+        if (replace) {
+            orc_spmv(d, p, s);                      /* :499 */
+            orc_spmv(d, s, z);                      /* :500 */
+        } else {
+            recur3(n, omega, beta, z, w, s);        /* :355-357 */
+            recur3(n, omega, beta, v, t, z);        /* :358-360 */
+        }
+        orc_daxpy(n, -alpha, s, r);                 /* :361 q */
+        orc_daxpy(n, -alpha, z, w);                 /* :362 y */
+        rTw = orc_dist_dot(d, r, w);                /* :363 */
+        wTw = orc_dist_dot(d, w, w);                /* :364 */
+        orc_spmv(d, z, v);                          /* :365 */
+        omega = rTw / wTw;                          /* :369 */
+        orc_daxpy(n, alpha, p, x);                  /* :370 */
+        orc_daxpy(n, omega, r, x);                  /* :371 */
+        if (replace) {
+            orc_spmv(d, x, Ax);                     /* :523 */
+            orc_dcopy(n, b, r);                     /* :524 */
+            orc_daxpy(n, -1.0, Ax, r);              /* :525 */
+            orc_spmv(d, r, w);                      /* :526 */
+        } else {
+            orc_daxpy(n, -omega, w, r);             /* :372 */
+            orc_daxpy(n, -alpha, v, t);             /* :374 */
+            orc_daxpy(n, -omega, t, w);             /* :375 */
+        }
+        dot_r = orc_dist_dot(d, r, r);              /* :373 / :533 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);               /* :377 */
+        rTw = orc_dist_dot(d, rh, w);               /* :378 */
+        rTs = orc_dist_dot(d, rh, s);               /* :379 */
+        rTz = orc_dist_dot(d, rh, z);               /* :380 */
+        orc_spmv(d, w, t);                          /* :381 */
+        double alpha_used = alpha;
+        beta = (alpha / omega) * (rTr / rTr_old);               /* :387 */
+        alpha = rTr / (rTw + beta * (rTs - omega * rTz));       /* :388 */
+        k++;
+        trace_put(o, k, alpha_used, omega, beta, dot_r);
+    }
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(b); free(Ax); free(rh); free(s); free(z); free(w); free(p); free(v); free(t);
+    return k;
+}
+
+int orc_solve(int method, const orc_dist *d, double *x, double *r, orc_opts *o)
+{
+    switch (method) {
+    case ORC_BICGSTAB:         return solve_plain(d, x, r, o);
+    case ORC_CA_BICGSTAB:      return solve_ca(d, x, r, o);
+    case ORC_PIPE_BICGSTAB:    return solve_pipe(d, x, r, o, 0);
+    case ORC_PIPE_BICGSTAB_RR: return solve_pipe(d, x, r, o, 1);
+    default: return -1;
+    }
+}
+
+int orc_solve_coo(int method, int P, unsigned n, unsigned nnz, const unsigned *row,
+                  const unsigned *col, const double *val, double *x, double *r, orc_opts *o)
+{
+    orc_dist *d = orc_dist_from_coo(n, nnz, row, col, val, P);
+    int k = orc_solve(method, d, x, r, o);
+    orc_dist_free(d);
+    return k;
+}
+
+void orc_spmv_coo(int P, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                  const double *val, const double *x, double *y)
+{
+    orc_dist *d = orc_dist_from_coo(n, nnz, row, col, val, P);
+    orc_spmv(d, x, y);
+    orc_dist_free(d);
+}
