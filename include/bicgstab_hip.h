@@ -1,0 +1,187 @@
+/*
+ * bicgstab_hip.h -- C ABI of libbicgstab_hip.so: the MI355X (gfx950) BiCGStab hot path.
+ *
+ * Drop-in boundary: the four solver entry points of the reference's solver.h, byte-for-byte the
+ * same signatures and struct layouts, so that the reference's C host (main.c + matrix.c + mmio.c)
+ * links against this library instead of its own solver.c / vector.c.
+ * Everything else in this header is additive (handle-based API for callers that keep the matrix
+ * resident on the GPU, kernel-level entry points for parity tests and benchmarks, communicator
+ * bootstrap). Plain C types only.
+ *
+ * All arithmetic is fp64, all indices uint32, exactly as in the reference (src/matrix.h:19-26).
+ */
+#ifndef BICGSTAB_HIP_H
+#define BICGSTAB_HIP_H
+
+#include <stddef.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * Matrix containers. If the reference's matrix.h was included first (its include guard is
+ * MATRIX_H) its own typedefs are used; otherwise layout-identical ones are declared here.
+ *   CSR_Matrix  <- reference src/matrix.h:19-26   (sizeof 40)
+ *   INFO_Matrix <- reference src/matrix.h:28-33   (sizeof 32; MM_typecode = char[4], mmio.h:16)
+ * Per rank: diag = rows x rows block with LOCAL column indices, offd = rows x n block with
+ * GLOBAL column indices (reference src/matrix.c:343-351, 380-392); displs[p]/recvcounts[p] =
+ * first row / row count of rank p (src/matrix.c:306-307).
+ * ------------------------------------------------------------------------------------------- */
+#ifndef MATRIX_H
+typedef struct {
+    double       *val;
+    unsigned int *col;
+    unsigned int *ptr;
+    unsigned int  nz;
+    unsigned int  rows;
+    unsigned int  cols;
+} CSR_Matrix;
+
+typedef struct {
+    unsigned int nz, rows, cols;
+    char         code[4];
+    int         *recvcounts;
+    int         *displs;
+} INFO_Matrix;
+#endif
+
+/* ---------------------------------------------------------------------------------------------
+ * 1. Drop-in entry points (replace reference src/solver.c).
+ *
+ *   bicgstab          <- src/solver.h:10 (implementation src/solver.c:35-146)
+ *   ca_bicgstab       <- src/solver.h:11 (src/solver.c:160-278)
+ *   pipe_bicgstab     <- src/solver.h:12 (src/solver.c:292-417)
+ *   pipe_bicgstab_rr  <- src/solver.h:13 (src/solver.c:433-576)
+ *
+ * Semantics kept: collective over all ranks; x_loc in = x0, out = solution; r_loc in = b,
+ * out = recursive residual (src/solver.c:75); return value = iterations executed; non-square
+ * matrix prints "Error: matrix is not square." and exit(1) (src/solver.c:43-46); rank 0 prints
+ * the reference's progress and summary lines verbatim (src/solver.c:124,135-139). The matrix is
+ * never modified. Constants default to the reference's (EPS 1e-15, MAX_ITER 1000, OUT_ITER 100;
+ * src/solver.c:3-9) and can be overridden without an ABI change through the environment:
+ * BICG_TOL, BICG_MAX_ITER, BICG_OUT_ITER, BICG_CHECK_EVERY, BICG_QUIET.
+ *
+ * Rank discovery: if the process has initialised MPI (the reference's main.c does) the library
+ * picks rank/size up from MPI_COMM_WORLD through weak symbols and bootstraps RCCL with an
+ * MPI_Bcast of the unique id; otherwise it runs single-rank unless a bicg_comm_init_* call was
+ * made first. HIP / RCCL failures print to stderr and exit(EXIT_FAILURE).
+ * ------------------------------------------------------------------------------------------- */
+int bicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc, double *r_loc);
+int ca_bicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc, double *r_loc);
+int pipe_bicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc, double *r_loc);
+int pipe_bicgstab_rr(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc, double *r_loc, int krr, int nrr);
+
+/* ---------------------------------------------------------------------------------------------
+ * 2. Communicator bootstrap (process-global; one process per GPU).
+ *    The reference uses MPI_COMM_WORLD implicitly (src/solver.c:37, src/matrix.c:432); here the
+ *    transport is explicit: RCCL over xGMI for production, or a host-staged transport driven by
+ *    caller-supplied callbacks (MPI, gloo, ...) for tests and for more ranks than GPUs.
+ * ------------------------------------------------------------------------------------------- */
+#define BICG_UNIQUE_ID_BYTES 128
+
+/* rank 0: create an RCCL unique id to broadcast to the other ranks by any means */
+int bicg_comm_unique_id(void *id_out /* BICG_UNIQUE_ID_BYTES */);
+/* all ranks: join. device = HIP device ordinal for this process (-1: rank % device count) */
+int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device);
+
+/* Host-staged transport. Callbacks operate on HOST buffers and are collective.
+ *   allreduce_sum: in-place sum of n doubles over all ranks (replaces MPI_Iallreduce+MPI_Wait of
+ *                  one double each, e.g. reference src/solver.c:90-91, here packed)
+ *   alltoallv:     byte-wise personalised exchange (counts/displs in BYTES, per peer), replaces
+ *                  the full-vector MPI_Iallgatherv of reference src/matrix.c:432 with a halo */
+typedef void (*bicg_allreduce_fn)(double *buf, int n, void *user);
+typedef void (*bicg_alltoallv_fn)(const void *send, const int *scounts, const int *sdispls,
+                                  void *recv, const int *rcounts, const int *rdispls, void *user);
+int bicg_comm_init_host(int rank, int nranks, bicg_allreduce_fn allreduce, bicg_alltoallv_fn alltoallv,
+                        void *user, int device);
+/* MPI_COMM_WORLD of the calling process through weak symbols; transport "rccl" or "host".
+ * Returns non-zero when the process has no initialised MPI. */
+int bicg_comm_init_mpi(const char *transport, int device);
+int bicg_comm_init_single(int device);
+void bicg_comm_finalize(void);
+int bicg_comm_rank(void);
+int bicg_comm_size(void);
+
+/* ---------------------------------------------------------------------------------------------
+ * 3. Handle-based API: upload once, solve many times, vectors may stay resident in HBM.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct bicg_ctx bicg_ctx;
+
+enum { BICG_BICGSTAB = 0, BICG_CA_BICGSTAB = 1, BICG_PIPE_BICGSTAB = 2, BICG_PIPE_BICGSTAB_RR = 3 };
+
+typedef struct {
+    double tol;          /* relative residual tolerance, reference EPS (src/solver.c:3) */
+    int    max_iter;     /* reference MAX_ITER (src/solver.c:4) */
+    int    out_iter;     /* progress line every out_iter iterations, reference OUT_ITER (:9); 0 = never */
+    int    check_every;  /* iterations enqueued between host convergence checks (device stops itself) */
+    int    quiet;        /* 1: no stdout lines */
+    int    krr, nrr;     /* residual replacement period / count (src/solver.c:433) */
+    int    record_trace; /* 1: keep per-iteration alpha/omega/beta/(r,r) on the device */
+    int    time_kernels; /* 1: bracket every SpMV launch with HIP events (roofline measurement) */
+} bicg_options;
+
+typedef struct {
+    int    iterations;     /* k, the reference's return value */
+    double dot_r;          /* final (r,r), all ranks */
+    double dot_zero;       /* (r0,r0) */
+    double seconds;        /* wall time, init SpMV .. last iteration (the span of src/solver.c:70-131) */
+    double iter_seconds;   /* wall time of the iteration loop only (after the set-up phase) */
+    double spmv_ms_total;  /* sum of event-timed SpMV launches (time_kernels) */
+    int    spmv_launches;  /* number of SpMV (interior+boundary pairs) timed */
+} bicg_result;
+
+void bicg_default_options(bicg_options *o);
+
+/* Upload this rank's blocks and build the SpMV plan (row blocks, halo lists). Collective.
+ * Returns NULL after printing to stderr on failure. The host arrays are not referenced afterwards. */
+bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info);
+void bicg_destroy(bicg_ctx *ctx);
+
+/* Whole solve with host vectors, semantics of section 1 (x_loc/r_loc in-out). */
+int bicg_solve(bicg_ctx *ctx, int method, double *x_loc, double *r_loc, const bicg_options *opt,
+               bicg_result *res);
+
+/* Device-resident variant: load x0/b once, run, fetch. bicg_run leaves x and r on the device. */
+int bicg_load(bicg_ctx *ctx, const double *x0_loc, const double *b_loc);
+int bicg_run(bicg_ctx *ctx, int method, const bicg_options *opt, bicg_result *res);
+int bicg_fetch(bicg_ctx *ctx, double *x_loc, double *r_loc);
+/* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */
+int bicg_trace(bicg_ctx *ctx, double *alpha, double *omega, double *beta, double *dot_r);
+
+/* ---------------------------------------------------------------------------------------------
+ * 4. Kernel-level entry points (parity tests, benchmarks).
+ *   bicg_spmv        <- MPI_csr_spmv_ovlap, reference src/matrix.c:428-441 (collective)
+ *   bicg_dot         <- my_ddot + MPI_Iallreduce, reference src/vector.c:9-15, src/solver.c:89-91
+ * ------------------------------------------------------------------------------------------- */
+int bicg_spmv(bicg_ctx *ctx, const double *x_loc, double *y_loc);
+double bicg_dot(bicg_ctx *ctx, const double *x_loc, const double *y_loc);
+/* reps back-to-back SpMVs on device-resident vectors; returns average ms per SpMV (HIP events on
+ * the library's compute stream) */
+int bicg_spmv_bench(bicg_ctx *ctx, int reps, double *ms_per_spmv);
+/* plan facts: local rows, diag nnz, offd nnz, halo length, row blocks, boundary row blocks */
+int bicg_plan_info(bicg_ctx *ctx, unsigned int out[6]);
+
+/* ---------------------------------------------------------------------------------------------
+ * 5. Host-only helpers (no GPU needed; unit-tested on CPU).
+ *   bicg_partition   <- reference src/matrix.c:295-308
+ *   bicg_halo_plan   -- unique global columns referenced by an offd block, grouped by owner rank
+ * ------------------------------------------------------------------------------------------- */
+void bicg_partition(unsigned int n, int nranks, int *counts, int *displs);
+/* Returns the halo length h and fills (caller-allocated, sizes noted):
+ *   halo_cols[offd->nz upper bound]  ascending unique global columns
+ *   recv_counts[nranks]              how many of them each rank owns
+ *   renumbered[offd->nz]             offd->col mapped to local_rows + halo position */
+int bicg_halo_plan(const CSR_Matrix *offd, const INFO_Matrix *info, int nranks, unsigned int local_rows,
+                   unsigned int *halo_cols, int *recv_counts, unsigned int *renumbered);
+/* greedy row blocks of at most chunk non-zeros (whole rows); returns the number of blocks and fills
+ * rowblk[nblk+1] (caller provides rows+1 entries) */
+unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int rows, unsigned int chunk,
+                             unsigned int max_rows, unsigned int *rowblk);
+
+const char *bicg_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* BICGSTAB_HIP_H */

@@ -1,0 +1,306 @@
+// bicg_comm.cpp -- transports: single rank, RCCL over xGMI (dlopen'ed, one process per GPU),
+// host-staged callbacks. See bicg_comm.h.
+#include "bicg_comm.h"
+
+#include <dlfcn.h>
+#include <rccl/rccl.h>   // types and enums only; the functions are resolved with dlsym
+
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+namespace bicg {
+
+void die(const char *what, const char *detail)
+{
+    // the reference's loader reports errors this way (src/matrix.c:34-37)
+    fprintf(stderr, "ERROR: bicgstab_hip: %s: %s\n", what, detail ? detail : "");
+    fflush(stderr);
+    exit(EXIT_FAILURE);
+}
+
+int pick_device(int rank, int requested)
+{
+    int ndev = 0;
+    BICG_HIP(hipGetDeviceCount(&ndev));
+    if (ndev <= 0) die("hipGetDeviceCount", "no HIP device visible");
+    int dev = requested;
+    if (dev < 0) {
+        const char *lr = getenv("LOCAL_RANK");
+        dev = (lr ? atoi(lr) : rank) % ndev;
+    }
+    BICG_HIP(hipSetDevice(dev));
+    return dev;
+}
+
+// ------------------------------------------------------------------ single rank
+struct SingleComm : Comm {
+    const char *name() const override { return "single"; }
+    bool stream_ordered() const override { return true; }
+    void allreduce_sum(double *, int, hipStream_t) override {}
+    void exchange(const double *, const int *, const int *, double *, const int *, const int *, hipStream_t) override {}
+    void alltoallv_host(const void *, const int *, const int *, void *, const int *, const int *) override {}
+};
+
+Comm *make_single(int device)
+{
+    SingleComm *c = new SingleComm;
+    c->rank = 0; c->nranks = 1;
+    c->device = pick_device(0, device);
+    return c;
+}
+
+// ------------------------------------------------------------------ host staged
+struct HostComm : Comm {
+    bicg_allreduce_fn ar = nullptr;
+    bicg_alltoallv_fn a2a = nullptr;
+    void *user = nullptr;
+    std::vector<double> hs, hr;
+    std::vector<int> bs_cnt, bs_dsp, br_cnt, br_dsp;
+
+    const char *name() const override { return "host"; }
+    bool stream_ordered() const override { return false; }
+
+    void allreduce_sum(double *dev, int n, hipStream_t st) override
+    {
+        double tmp[64];
+        if (n > 64) die("allreduce_sum", "group too wide");
+        BICG_HIP(hipMemcpyAsync(tmp, dev, sizeof(double) * n, hipMemcpyDeviceToHost, st));
+        BICG_HIP(hipStreamSynchronize(st));
+        ar(tmp, n, user);
+        BICG_HIP(hipMemcpyAsync(dev, tmp, sizeof(double) * n, hipMemcpyHostToDevice, st));
+        BICG_HIP(hipStreamSynchronize(st));
+    }
+
+    void exchange(const double *send, const int *scnt, const int *sdsp, double *recv, const int *rcnt, const int *rdsp,
+                  hipStream_t st) override
+    {
+        const int P = nranks;
+        const int ns = sdsp[P - 1] + scnt[P - 1], nr = rdsp[P - 1] + rcnt[P - 1];
+        hs.resize(ns > 0 ? ns : 1); hr.resize(nr > 0 ? nr : 1);
+        bs_cnt.resize(P); bs_dsp.resize(P); br_cnt.resize(P); br_dsp.resize(P);
+        for (int p = 0; p < P; ++p) {
+            bs_cnt[p] = scnt[p] * 8; bs_dsp[p] = sdsp[p] * 8; br_cnt[p] = rcnt[p] * 8; br_dsp[p] = rdsp[p] * 8;
+        }
+        if (ns) BICG_HIP(hipMemcpyAsync(hs.data(), send, sizeof(double) * ns, hipMemcpyDeviceToHost, st));
+        BICG_HIP(hipStreamSynchronize(st));
+        a2a(hs.data(), bs_cnt.data(), bs_dsp.data(), hr.data(), br_cnt.data(), br_dsp.data(), user);
+        if (nr) BICG_HIP(hipMemcpyAsync(recv, hr.data(), sizeof(double) * nr, hipMemcpyHostToDevice, st));
+        BICG_HIP(hipStreamSynchronize(st));
+    }
+
+    void alltoallv_host(const void *send, const int *scnt, const int *sdsp, void *recv, const int *rcnt,
+                        const int *rdsp) override
+    {
+        a2a(send, scnt, sdsp, recv, rcnt, rdsp, user);
+    }
+};
+
+Comm *make_host(int rank, int nranks, bicg_allreduce_fn ar, bicg_alltoallv_fn a2a, void *user, int device)
+{
+    HostComm *c = new HostComm;
+    c->rank = rank; c->nranks = nranks; c->ar = ar; c->a2a = a2a; c->user = user;
+    c->device = pick_device(rank, device);
+    return c;
+}
+
+// ------------------------------------------------------------------ RCCL (xGMI)
+struct RcclApi {
+    void *handle = nullptr;
+    ncclResult_t (*GetUniqueId)(ncclUniqueId *) = nullptr;
+    ncclResult_t (*CommInitRank)(ncclComm_t *, int, ncclUniqueId, int) = nullptr;
+    ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
+    ncclResult_t (*AllReduce)(const void *, void *, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Send)(const void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void *, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
+    const char *(*GetErrorString)(ncclResult_t) = nullptr;
+};
+
+static RcclApi &rccl()
+{
+    static RcclApi api;
+    if (api.handle) return api;
+    // librccl.so.1 resolves to an already loaded RCCL (e.g. the one PyTorch ships) by SONAME
+    const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+    for (const char *nm : names) {
+        api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        if (api.handle) break;
+    }
+    if (!api.handle) die("dlopen(librccl)", dlerror());
+#define SYM(field, sym)                                                       \
+    do {                                                                      \
+        *(void **)(&api.field) = dlsym(api.handle, sym);                      \
+        if (!api.field) die("dlsym", sym);                                    \
+    } while (0)
+    SYM(GetUniqueId, "ncclGetUniqueId");
+    SYM(CommInitRank, "ncclCommInitRank");
+    SYM(CommDestroy, "ncclCommDestroy");
+    SYM(AllReduce, "ncclAllReduce");
+    SYM(Send, "ncclSend");
+    SYM(Recv, "ncclRecv");
+    SYM(GroupStart, "ncclGroupStart");
+    SYM(GroupEnd, "ncclGroupEnd");
+    SYM(GetErrorString, "ncclGetErrorString");
+#undef SYM
+    return api;
+}
+
+#define BICG_NCCL(call)                                                      \
+    do {                                                                     \
+        ncclResult_t r_ = (call);                                            \
+        if (r_ != ncclSuccess) die(#call, rccl().GetErrorString(r_));        \
+    } while (0)
+
+int rccl_unique_id(void *out)
+{
+    static_assert(sizeof(ncclUniqueId) == BICG_UNIQUE_ID_BYTES, "unique id size");
+    ncclUniqueId id;
+    BICG_NCCL(rccl().GetUniqueId(&id));
+    memcpy(out, &id, sizeof id);
+    return 0;
+}
+
+struct RcclComm : Comm {
+    ncclComm_t comm = nullptr;
+
+    ~RcclComm() override { if (comm) rccl().CommDestroy(comm); }
+    const char *name() const override { return "rccl"; }
+    bool stream_ordered() const override { return true; }
+
+    void allreduce_sum(double *dev, int n, hipStream_t st) override
+    {
+        BICG_NCCL(rccl().AllReduce(dev, dev, (size_t)n, ncclFloat64, ncclSum, comm, st));
+    }
+
+    // point-to-point to the actual neighbours only: on xGMI every pair of GPUs has a direct link
+    void exchange(const double *send, const int *scnt, const int *sdsp, double *recv, const int *rcnt, const int *rdsp,
+                  hipStream_t st) override
+    {
+        BICG_NCCL(rccl().GroupStart());
+        for (int p = 0; p < nranks; ++p) {
+            if (p == rank) continue;
+            if (scnt[p] > 0) BICG_NCCL(rccl().Send(send + sdsp[p], (size_t)scnt[p], ncclFloat64, p, comm, st));
+            if (rcnt[p] > 0) BICG_NCCL(rccl().Recv(recv + rdsp[p], (size_t)rcnt[p], ncclFloat64, p, comm, st));
+        }
+        BICG_NCCL(rccl().GroupEnd());
+    }
+
+    void alltoallv_host(const void *send, const int *scnt, const int *sdsp, void *recv, const int *rcnt,
+                        const int *rdsp) override
+    {
+        const int P = nranks;
+        const size_t ns = (size_t)sdsp[P - 1] + scnt[P - 1], nr = (size_t)rdsp[P - 1] + rcnt[P - 1];
+        char *ds = nullptr, *dr = nullptr;
+        BICG_HIP(hipMalloc((void **)&ds, ns ? ns : 1));
+        BICG_HIP(hipMalloc((void **)&dr, nr ? nr : 1));
+        if (ns) BICG_HIP(hipMemcpy(ds, send, ns, hipMemcpyHostToDevice));
+        // the self segment never travels
+        if (scnt[rank] > 0) memcpy((char *)recv + rdsp[rank], (const char *)send + sdsp[rank], (size_t)scnt[rank]);
+        hipStream_t st = nullptr;
+        BICG_NCCL(rccl().GroupStart());
+        for (int p = 0; p < P; ++p) {
+            if (p == rank) continue;
+            if (scnt[p] > 0) BICG_NCCL(rccl().Send(ds + sdsp[p], (size_t)scnt[p], ncclInt8, p, comm, st));
+            if (rcnt[p] > 0) BICG_NCCL(rccl().Recv(dr + rdsp[p], (size_t)rcnt[p], ncclInt8, p, comm, st));
+        }
+        BICG_NCCL(rccl().GroupEnd());
+        BICG_HIP(hipStreamSynchronize(st));
+        for (int p = 0; p < P; ++p)
+            if (p != rank && rcnt[p] > 0)
+                BICG_HIP(hipMemcpy((char *)recv + rdsp[p], dr + rdsp[p], (size_t)rcnt[p], hipMemcpyDeviceToHost));
+        BICG_HIP(hipFree(ds));
+        BICG_HIP(hipFree(dr));
+    }
+};
+
+Comm *make_rccl(int rank, int nranks, const void *id, int device)
+{
+    RcclComm *c = new RcclComm;
+    c->rank = rank; c->nranks = nranks;
+    c->device = pick_device(rank, device);
+    ncclUniqueId uid;
+    memcpy(&uid, id, sizeof uid);
+    BICG_NCCL(rccl().CommInitRank(&c->comm, nranks, uid, rank));
+    return c;
+}
+
+// ------------------------------------------------------------------ process-global communicator
+static Comm *g_comm = nullptr;
+
+void comm_set(Comm *c)
+{
+    if (g_comm) delete g_comm;
+    g_comm = c;
+}
+
+// First use without an explicit bicg_comm_init_*: adopt MPI_COMM_WORLD when the host program has
+// initialised MPI (the reference's main.c does, src/main.c:14), else run single rank.
+Comm *comm_get()
+{
+    if (g_comm) return g_comm;
+    if (bicg_mpi_active()) {
+        const char *t = getenv("BICG_TRANSPORT");
+        if (bicg_comm_init_mpi(t ? t : "auto", -1) == 0) return g_comm;
+    }
+    g_comm = make_single(-1);
+    return g_comm;
+}
+
+}  // namespace bicg
+
+using namespace bicg;
+
+extern "C" {
+
+int bicg_comm_unique_id(void *id_out) { return rccl_unique_id(id_out); }
+
+int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device)
+{
+    comm_set(nranks > 1 ? make_rccl(rank, nranks, id, device) : make_single(device));
+    return 0;
+}
+
+int bicg_comm_init_host(int rank, int nranks, bicg_allreduce_fn allreduce, bicg_alltoallv_fn alltoallv, void *user,
+                        int device)
+{
+    comm_set(nranks > 1 ? make_host(rank, nranks, allreduce, alltoallv, user, device) : make_single(device));
+    return 0;
+}
+
+int bicg_comm_init_single(int device)
+{
+    comm_set(make_single(device));
+    return 0;
+}
+
+int bicg_comm_init_mpi(const char *transport, int device)
+{
+    if (!bicg_mpi_active()) return 1;
+    int rank = 0, size = 1;
+    bicg_mpi_rank_size(&rank, &size);
+    if (size == 1) { comm_set(make_single(device)); return 0; }
+    int ndev = 0;
+    BICG_HIP(hipGetDeviceCount(&ndev));
+    bool use_rccl;
+    if (transport && strcmp(transport, "rccl") == 0) use_rccl = true;
+    else if (transport && strcmp(transport, "host") == 0) use_rccl = false;
+    else use_rccl = size <= ndev;     // RCCL needs one GPU per rank
+    if (use_rccl) {
+        char id[BICG_UNIQUE_ID_BYTES];
+        if (rank == 0) rccl_unique_id(id);
+        bicg_mpi_bcast_bytes(id, BICG_UNIQUE_ID_BYTES, 0);
+        comm_set(make_rccl(rank, size, id, device));
+    } else {
+        comm_set(make_host(rank, size, bicg_mpi_allreduce_sum, bicg_mpi_alltoallv_bytes, nullptr, device));
+    }
+    return 0;
+}
+
+void bicg_comm_finalize(void) { comm_set(nullptr); }
+int bicg_comm_rank(void) { return comm_get()->rank; }
+int bicg_comm_size(void) { return comm_get()->nranks; }
+
+}  // extern "C"

@@ -1,0 +1,58 @@
+// bicg_comm.h -- rank-to-rank transports behind the solver (one process per GPU).
+//
+// The reference communicates through MPI_COMM_WORLD only: MPI_Iallgatherv of the whole vector per
+// SpMV (src/matrix.c:432) and one 8-byte MPI_Iallreduce per dot product (e.g. src/solver.c:90).
+// Here: a halo exchange of exactly the entries the offd block references, and ONE packed
+// all-reduce per dot group, on RCCL over xGMI (device buffers, enqueued on a HIP stream) or on a
+// host-staged transport (callbacks: MPI, gloo, ...) used for tests and for ranks > GPUs.
+#pragma once
+
+#include <hip/hip_runtime.h>
+
+#include "../../include/bicgstab_hip.h"
+
+namespace bicg {
+
+struct Comm {
+    int rank = 0, nranks = 1, device = 0;
+    virtual ~Comm() {}
+    virtual const char *name() const = 0;
+    // true: collectives are enqueued on `st` and complete in stream order (RCCL);
+    // false: the call synchronises `st` and completes on return (host staged)
+    virtual bool stream_ordered() const = 0;
+    // in-place sum over ranks of n doubles in DEVICE memory
+    virtual void allreduce_sum(double *dev, int n, hipStream_t st) = 0;
+    // halo exchange, DEVICE buffers; counts/displs in doubles per peer rank
+    virtual void exchange(const double *send, const int *scnt, const int *sdsp, double *recv, const int *rcnt,
+                          const int *rdsp, hipStream_t st) = 0;
+    // set-up time personalised exchange of HOST bytes
+    virtual void alltoallv_host(const void *send, const int *scnt, const int *sdsp, void *recv, const int *rcnt,
+                                const int *rdsp) = 0;
+};
+
+Comm *comm_get();                 // process-global communicator (auto-initialised on first use)
+void comm_set(Comm *c);           // takes ownership
+Comm *make_single(int device);
+Comm *make_host(int rank, int nranks, bicg_allreduce_fn ar, bicg_alltoallv_fn a2a, void *user, int device);
+Comm *make_rccl(int rank, int nranks, const void *id, int device);
+int   rccl_unique_id(void *out);
+int   pick_device(int rank, int requested);
+
+[[noreturn]] void die(const char *what, const char *detail);
+#define BICG_HIP(call)                                                                       \
+    do {                                                                                     \
+        hipError_t e_ = (call);                                                              \
+        if (e_ != hipSuccess) ::bicg::die(#call, hipGetErrorString(e_));                     \
+    } while (0)
+
+}  // namespace bicg
+
+// MPI through weak symbols (bicg_mpi_shim.c)
+extern "C" {
+int  bicg_mpi_active(void);
+void bicg_mpi_rank_size(int *rank, int *size);
+void bicg_mpi_bcast_bytes(void *buf, int n, int root);
+void bicg_mpi_allreduce_sum(double *buf, int n, void *user);
+void bicg_mpi_alltoallv_bytes(const void *send, const int *scnt, const int *sdsp, void *recv, const int *rcnt,
+                              const int *rdsp, void *user);
+}

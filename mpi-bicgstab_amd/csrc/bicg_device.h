@@ -1,0 +1,114 @@
+// bicg_device.h -- device-side state and kernel launch interface shared by the kernels
+// (bicg_kernels.hip) and the iteration drivers (bicg_solver.cpp). gfx950 only.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+namespace bicg {
+
+constexpr int kBlock = 256;                 // 4 wavefronts of 64
+constexpr int kNnzPerThread = 8;            // SpMV: products staged per thread
+constexpr int kChunk = kBlock * kNnzPerThread;  // 2048 non-zeros (16 KiB of LDS) per row block
+constexpr int kMaxDots = 5;                 // widest dot group (pipelined phase 2)
+constexpr int kRedSlots = 8;                // packed all-reduce buffer, doubles
+constexpr int kPartialStride = 8;           // doubles per block in the partial-sum table (64 B)
+constexpr int kShards = 32;                 // arrival counters per dot group (one word saturates at ~88 atomics/us)
+constexpr int kCounterStride = 32;          // unsigneds between shard counters (128 B apart)
+constexpr int kMaxGrid = 2048;              // element-wise kernels: 256 CUs x 8 resident workgroups, grid-stride beyond
+constexpr int kSpmvMaxGrid = 1 << 18;       // SpMV: one workgroup per row block up to this many
+
+// What the single thread that completes a dot group does with the (globally reduced) sums in
+// Scal::red. One value per blocking point of the reference's loops.
+enum Phase : int {
+    PH_NONE = 0,
+    PH_INIT,        // red[0]=(r,r): rTr = dot_r = dot_zero           (src/solver.c:78-83, 203, 336)
+    PH_INIT_ALPHA,  // red[0]=(r,w): alpha = rTr/(r,w), beta=omega=0   (src/solver.c:210-211, 345-346)
+    PH_PLAIN_ALPHA, // red[0]=(r#,s): alpha = rTr/(r#,s)               (src/solver.c:93)
+    PH_OMEGA,       // red[0]=(q,y), red[1]=(y,y): omega               (src/solver.c:104, 232, 369)
+    PH_PLAIN_END,   // red[0]=(r,r), red[1]=(r#,r): beta, k++          (src/solver.c:108-120)
+    PH_RECUR_END,   // red[0..4]=(r,r),(r#,r),(r#,w),(r#,s),(r#,z): beta, alpha, k++ (src/solver.c:248-251, 387-390)
+};
+
+// Device-resident scalar state of one solve. Kernels read alpha/beta/omega/done from here, so the
+// host never has to synchronise inside an iteration.
+struct Scal {
+    double alpha, beta, omega;
+    double rTr, rTr_old;
+    double dot_r, dot_zero;
+    double tol2;                 // tol*tol (src/solver.c:86)
+    double red[kRedSlots];       // dot sums of the current group (local, then all-reduced in place)
+    int    k;                    // iterations completed
+    int    max_iter;
+    int    done;                 // sticky: set when the reference's while condition fails
+    int    pad;
+    double *tr_alpha, *tr_omega, *tr_beta, *tr_dotr;   // optional trace, [max_iter]
+};
+
+// Where a kernel's dot partial sums go and what happens when the last block has arrived.
+struct Reduce {
+    double   *partial;     // [slots][kPartialStride]
+    double   *shard_tot;   // [kShards][kPartialStride]
+    unsigned *counter;     // [(kShards + 1) * kCounterStride] arrival tickets, return to 0 after each group
+    unsigned  expected;    // workgroups contributing to this group (possibly over two launches)
+    unsigned  slot_base;   // slot of this launch's workgroup 0
+    int       red_off;     // sums land in Scal::red[red_off + d]
+    int       phase;       // Phase applied by the finishing thread when apply_now
+    int       apply_now;   // single rank: apply the phase in-kernel; multi rank: host all-reduces first
+};
+
+struct CsrDev {
+    const double   *val;
+    const uint32_t *col;
+    const uint32_t *ptr;
+};
+
+struct SpmvArgs {
+    CsrDev diag;            // local columns
+    CsrDev offd;            // columns renumbered to rows + halo position; ptr over ALL local rows
+    const uint32_t *rowblk; // [nblk+1] first row of each row block
+    const uint32_t *blist;  // row-block ids this launch processes (interior or boundary list); null = all
+    uint32_t nlist;         // number of row blocks to process (grid-stride over them)
+    const double *x;        // [rows + halo]
+    double       *y;        // [rows]
+    const double *u;        // dot operand (NDOT >= 1): d0 = sum u_i y_i ; NDOT == 2 adds d1 = sum y_i^2
+    Scal   *S;
+    Reduce  red;
+};
+
+// element-wise phase kernels: pointers to the rank-local vectors
+struct Vecs {
+    double *x, *r, *rh, *p, *s, *y, *z, *w, *v, *t, *ax, *b;
+    uint32_t n;
+};
+
+// ---- launch wrappers (bicg_kernels.hip) ----
+void launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st);
+void launch_apply(Scal *S, int phase, hipStream_t st);
+void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);
+
+// init: r = b - Ax ; rh = r ; [p = r] ; [bsave = b] ; dot (r,r)
+void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, Scal *S, Reduce red, hipStream_t st);
+// plain BiCGStab phases (src/solver.c:94, 105-111, 117-119)
+void launch_plain_q(const Vecs &v, Scal *S, hipStream_t st);
+void launch_plain_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_plain_p(const Vecs &v, Scal *S, hipStream_t st);
+// CA-BiCGStab phases (src/solver.c:217-222, 225-228, 233-236 + 240-243)
+void launch_ca_ps(const Vecs &v, Scal *S, hipStream_t st);
+void launch_qy(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_ca_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+// pipelined phases (src/solver.c:352-364, 370-380)
+void launch_pipe_f1(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_pipe_f2(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+// residual-replacement steps (src/solver.c:494-496, 519-520, 524-525, 533-538)
+void launch_p_update(const Vecs &v, Scal *S, hipStream_t st);
+void launch_x_update(const Vecs &v, Scal *S, hipStream_t st);
+void launch_true_residual(const Vecs &v, Scal *S, hipStream_t st);
+void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+// standalone dot (x,y) -> red[0]
+void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
+
+unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
+unsigned spmv_grid(uint32_t nlist);   // workgroups used by the SpMV for nlist row blocks
+
+}  // namespace bicg

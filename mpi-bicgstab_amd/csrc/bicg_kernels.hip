@@ -1,0 +1,618 @@
+// bicg_kernels.hip -- hand-written HIP kernels for the BiCGStab hot path on MI355X (gfx950, CDNA4).
+//
+// Everything here is HBM-bandwidth bound (0.15 flop/byte): no MFMA, the rules that matter are
+// coalesced streaming of val/col, LDS staging, 64-wide wavefront reductions and few launches.
+//
+//   k_spmv        CSR "row-block stream" SpMV: a 256-thread workgroup owns a block of whole rows
+//                 holding <= 2048 non-zeros, streams val/col fully coalesced (8 per thread, all
+//                 loads in flight before the first use), gathers x, stages the products in LDS
+//                 and reduces every row from LDS in stored order; fused dot-product epilogue.
+//                 Replaces mult() + MPI_csr_spmv_ovlap (reference src/matrix.c:498-516, 428-441).
+//   k_vec<...>    fused element-wise phases of the four iterations (replace the my_daxpy /
+//                 my_dscal / my_dcopy / my_ddot call sequences of reference src/solver.c).
+//   reductions    __shfl_down over the 64-lane wavefront -> LDS across the 4 wavefronts -> one
+//                 partial per workgroup -> the LAST workgroup to arrive sums the partials in a
+//                 fixed order (deterministic) and applies the scalar recurrence on the device.
+//
+// Compiled with -ffp-contract=off: every a*b+c keeps the two roundings of the reference's scalar
+// loops, so the element-wise phases and every SpMV row are bit-identical to the CPU oracle; only
+// the association of the dot-product sums differs.
+#include "bicg_device.h"
+
+namespace bicg {
+
+// ------------------------------------------------------------------------------------------
+// scalar recurrences (one thread)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void finish_iteration(Scal *S, double alpha_used)
+{
+    S->k += 1;
+    const int k = S->k;
+    if (S->tr_dotr && k <= S->max_iter) {
+        S->tr_alpha[k - 1] = alpha_used;
+        S->tr_omega[k - 1] = S->omega;
+        S->tr_beta[k - 1]  = S->beta;
+        S->tr_dotr[k - 1]  = S->dot_r;
+    }
+    // reference loop condition, src/solver.c:86 / 216 / 351
+    if (!(S->dot_r > S->tol2 * S->dot_zero && k < S->max_iter)) S->done = 1;
+}
+
+__device__ void apply_phase(Scal *S, int phase)
+{
+    const double *d = S->red;
+    switch (phase) {
+    case PH_INIT:
+        S->rTr = d[0]; S->dot_r = d[0]; S->dot_zero = d[0];
+        S->alpha = 0.0; S->beta = 0.0; S->omega = 0.0; S->rTr_old = 0.0;
+        if (!(S->dot_r > S->tol2 * S->dot_zero && 0 < S->max_iter)) S->done = 1;
+        break;
+    case PH_INIT_ALPHA:
+        S->alpha = S->rTr / d[0]; S->beta = 0.0; S->omega = 0.0;
+        break;
+    case PH_PLAIN_ALPHA:
+        S->alpha = S->rTr / d[0];
+        break;
+    case PH_OMEGA:
+        S->omega = d[0] / d[1];
+        break;
+    case PH_PLAIN_END: {
+        S->dot_r = d[0];
+        S->rTr_old = S->rTr;
+        S->rTr = d[1];
+        S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);
+        finish_iteration(S, S->alpha);
+        break;
+    }
+    case PH_RECUR_END: {
+        const double alpha_used = S->alpha;
+        S->dot_r = d[0];
+        S->rTr_old = S->rTr;
+        S->rTr = d[1];
+        const double rTw = d[2], rTs = d[3], rTz = d[4];
+        S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);
+        S->alpha = S->rTr / (rTw + S->beta * (rTs - S->omega * rTz));
+        finish_iteration(S, alpha_used);
+        break;
+    }
+    default: break;
+    }
+}
+
+__global__ void k_apply(Scal *S, int phase)
+{
+    if (S->done) return;
+    apply_phase(S, phase);
+}
+
+// ------------------------------------------------------------------------------------------
+// reductions
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ double wave_sum(double v)
+{
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+    return v;   // lane 0 holds the sum of the 64 lanes
+}
+
+// Sum ND values over the workgroup; every thread receives the totals in v[].
+template <int ND>
+__device__ __forceinline__ void block_sum(double (&v)[ND], double *sm /* [4*ND + ND] */)
+{
+    const int lane = threadIdx.x & 63, w = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) v[d] = wave_sum(v[d]);
+    __syncthreads();   // sm may still be read from a previous use
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) sm[w * ND + d] = v[d];
+    }
+    __syncthreads();
+    if (threadIdx.x < ND) {
+        double s = sm[threadIdx.x];
+#pragma unroll
+        for (int ww = 1; ww < kBlock / 64; ++ww) s += sm[ww * ND + threadIdx.x];
+        sm[4 * ND + threadIdx.x] = s;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int d = 0; d < ND; ++d) v[d] = sm[4 * ND + d];
+}
+
+// Publish this workgroup's ND partial sums into slot `slot`. Arrival is counted in kShards sharded
+// counters (a single word would serialise ~2000 simultaneous arrivals at ~12 ns each); the last
+// arriver of a shard sums that shard's partials, the last shard to finish sums the shard totals,
+// stores them in Scal::red and (single rank) applies the scalar recurrence. Membership and order
+// of every sum are fixed by the slot numbers, so the result is deterministic.
+// Cross-workgroup visibility follows the gfx950 rules for 8-byte agent-scope atomics on both
+// sides: write-through (sc1) stores drained with an explicit vmcnt(0) before the ticket, sc1
+// loads (L1 bypass) in the summing workgroup, one agent acquire fence before them.
+__device__ __forceinline__ unsigned shard_population(unsigned expected, unsigned shard)
+{
+    return shard < expected ? (expected - shard + kShards - 1) / kShards : 0u;
+}
+
+template <int ND>
+__device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const Reduce &red, unsigned slot, double *sm)
+{
+    __shared__ unsigned s_last;
+    const unsigned shard = slot % kShards;
+    block_sum<ND>(acc, sm);
+    if (threadIdx.x < ND)
+        __hip_atomic_store(&red.partial[(size_t)slot * kPartialStride + threadIdx.x], acc[threadIdx.x],
+                           __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (threadIdx.x == 0) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&red.counter[shard * kCounterStride], 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == shard_population(red.expected, shard) - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- last arriver of this shard: sum the shard's partials in slot order
+    if (threadIdx.x == 0) __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
+    __syncthreads();
+    const unsigned members = shard_population(red.expected, shard);
+    double tot[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) tot[d] = 0.0;
+    for (unsigned i = threadIdx.x; i < members; i += kBlock) {
+        const size_t sl = (size_t)shard + (size_t)i * kShards;
+#pragma unroll
+        for (int d = 0; d < ND; ++d)
+            tot[d] += __hip_atomic_load(&red.partial[sl * kPartialStride + d], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    block_sum<ND>(tot, sm);
+    if (threadIdx.x < ND)
+        __hip_atomic_store(&red.shard_tot[shard * kPartialStride + threadIdx.x], tot[threadIdx.x], __ATOMIC_RELAXED,
+                           __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned active = red.expected < (unsigned)kShards ? red.expected : (unsigned)kShards;
+    if (threadIdx.x == 0) {
+        __hip_atomic_store(&red.counter[shard * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        const unsigned t = __hip_atomic_fetch_add(&red.counter[kShards * kCounterStride], 1u, __ATOMIC_RELAXED,
+                                                  __HIP_MEMORY_SCOPE_AGENT);
+        s_last = (t == active - 1) ? 1u : 0u;
+    }
+    __syncthreads();
+    if (!s_last) return;
+
+    // ---- last shard: sum the shard totals in shard order, finish the group
+#pragma unroll
+    for (int d = 0; d < ND; ++d)
+        tot[d] = threadIdx.x < active ? __hip_atomic_load(&red.shard_tot[threadIdx.x * kPartialStride + d], __ATOMIC_RELAXED,
+                                                          __HIP_MEMORY_SCOPE_AGENT)
+                                      : 0.0;
+    block_sum<ND>(tot, sm);
+    if (threadIdx.x == 0) {
+#pragma unroll
+        for (int d = 0; d < ND; ++d) S->red[red.red_off + d] = tot[d];
+        __hip_atomic_store(&red.counter[kShards * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (red.apply_now) apply_phase(S, red.phase);
+    }
+}
+
+// ------------------------------------------------------------------------------------------
+// CSR SpMV, row-block stream
+// ------------------------------------------------------------------------------------------
+template <int NDOT, bool OFFD>
+__global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
+{
+    if (a.S->done) return;
+    __shared__ double prod[kChunk];
+    __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
+
+    const unsigned tid = threadIdx.x;
+    const double *__restrict__ x = a.x;
+
+    double acc[NDOT > 0 ? NDOT : 1];
+#pragma unroll
+    for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
+
+    // normally one row block per workgroup; consecutive workgroups sweep a contiguous window of the
+    // matrix, so the gathered part of x stays cache-resident
+    for (unsigned bi = blockIdx.x; bi < a.nlist; bi += gridDim.x) {
+        const unsigned b = a.blist ? a.blist[bi] : bi;
+        const uint32_t r0 = a.rowblk[b], r1 = a.rowblk[b + 1];
+        const uint32_t j0 = a.diag.ptr[r0], j1 = a.diag.ptr[r1];
+
+        if (j1 - j0 <= (uint32_t)kChunk) {
+            // stream: all val/col loads of the block are issued before the first gather
+            uint32_t c[kNnzPerThread];
+            double   v[kNnzPerThread];
+#pragma unroll
+            for (int i = 0; i < kNnzPerThread; ++i) {
+                const uint32_t j = j0 + tid + i * kBlock;
+                const bool ok = j < j1;
+                c[i] = ok ? a.diag.col[j] : 0u;
+                v[i] = ok ? a.diag.val[j] : 0.0;
+            }
+#pragma unroll
+            for (int i = 0; i < kNnzPerThread; ++i) prod[tid + i * kBlock] = v[i] * x[c[i]];
+            __syncthreads();
+            // one thread per row, sequential in stored order (the order of reference src/matrix.c:511-513)
+            for (uint32_t r = r0 + tid; r < r1; r += kBlock) {
+                const uint32_t a0 = a.diag.ptr[r] - j0, a1 = a.diag.ptr[r + 1] - j0;
+                double sum = 0.0;
+                for (uint32_t k = a0; k < a1; ++k) sum += prod[k];
+                double yi = 0.0 + sum;                       // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+                if (OFFD) {
+                    double so = 0.0;
+                    for (uint32_t k = a.offd.ptr[r]; k < a.offd.ptr[r + 1]; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
+                    yi += so;                                // second mult() call, src/matrix.c:440
+                }
+                a.y[r] = yi;
+                if (NDOT >= 1) acc[0] += a.u[r] * yi;
+                if (NDOT >= 2) acc[1] += yi * yi;
+            }
+        } else {
+            // a single row longer than the chunk: strided partial sums + workgroup reduction
+            double part[1] = {0.0};
+            for (uint32_t j = j0 + tid; j < j1; j += kBlock) part[0] += a.diag.val[j] * x[a.diag.col[j]];
+            block_sum<1>(part, sm);
+            if (tid == 0) {
+                double yi = 0.0 + part[0];
+                if (OFFD) {
+                    double so = 0.0;
+                    for (uint32_t k = a.offd.ptr[r0]; k < a.offd.ptr[r0 + 1]; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
+                    yi += so;
+                }
+                a.y[r0] = yi;
+                if (NDOT >= 1) acc[0] += a.u[r0] * yi;
+                if (NDOT >= 2) acc[1] += yi * yi;
+            }
+        }
+        __syncthreads();   // prod is rewritten by the next row block
+    }
+    if (NDOT > 0) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+}
+
+// One workgroup per row block: the hardware dispatcher balances the ~12k workgroups of a
+// Transport-sized matrix better than a 2048-workgroup persistent grid does (60.5 vs 67.8 us
+// measured); beyond kSpmvMaxGrid row blocks the kernel's loop strides.
+unsigned spmv_grid(uint32_t nlist)
+{
+    return nlist < (uint32_t)kSpmvMaxGrid ? nlist : (unsigned)kSpmvMaxGrid;
+}
+
+void launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st)
+{
+    if (a.nlist == 0) return;
+    dim3 g(spmv_grid(a.nlist)), b(kBlock);
+#define SPMV_CASE(ND, OF) hipLaunchKernelGGL((k_spmv<ND, OF>), g, b, 0, st, a)
+    if (with_offd) {
+        if (ndot == 0) SPMV_CASE(0, true); else if (ndot == 1) SPMV_CASE(1, true); else SPMV_CASE(2, true);
+    } else {
+        if (ndot == 0) SPMV_CASE(0, false); else if (ndot == 1) SPMV_CASE(1, false); else SPMV_CASE(2, false);
+    }
+#undef SPMV_CASE
+}
+
+void launch_apply(Scal *S, int phase, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_apply, dim3(1), dim3(1), 0, st, S, phase);
+}
+
+// gather the entries of x other ranks need into the contiguous send buffer
+__global__ void __launch_bounds__(kBlock) k_halo_pack(const double *x, const uint32_t *idx, uint32_t n, double *out, const Scal *S)
+{
+    if (S->done) return;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) out[i] = x[idx[i]];
+}
+
+void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st)
+{
+    if (nsend == 0) return;
+    unsigned g = (nsend + kBlock - 1) / kBlock;
+    if (g > 1024) g = 1024;
+    hipLaunchKernelGGL(k_halo_pack, dim3(g), dim3(kBlock), 0, st, x, send_idx, nsend, sendbuf, S);
+}
+
+// ------------------------------------------------------------------------------------------
+// fused element-wise phases
+// ------------------------------------------------------------------------------------------
+// Two-wide value so that one functor body serves the 16-byte vectorised main loop and the tail.
+struct d2 { double a, b; };
+__device__ __forceinline__ d2 operator+(d2 p, d2 q) { return {p.a + q.a, p.b + q.b}; }
+__device__ __forceinline__ d2 operator-(d2 p, d2 q) { return {p.a - q.a, p.b - q.b}; }
+__device__ __forceinline__ d2 operator*(d2 p, d2 q) { return {p.a * q.a, p.b * q.b}; }
+__device__ __forceinline__ d2 operator*(double s, d2 q) { return {s * q.a, s * q.b}; }
+__device__ __forceinline__ double hsum(d2 p) { return p.a + p.b; }
+__device__ __forceinline__ double hsum(double p) { return p; }
+
+template <class T> __device__ __forceinline__ T ld(const double *p, uint32_t i);
+template <> __device__ __forceinline__ double ld<double>(const double *p, uint32_t i) { return p[i]; }
+template <> __device__ __forceinline__ d2 ld<d2>(const double *p, uint32_t i)
+{
+    const double2 t = *reinterpret_cast<const double2 *>(p + i);
+    return {t.x, t.y};
+}
+__device__ __forceinline__ void st(double *p, uint32_t i, double v) { p[i] = v; }
+__device__ __forceinline__ void st(double *p, uint32_t i, d2 v) { *reinterpret_cast<double2 *>(p + i) = make_double2(v.a, v.b); }
+
+// F::ND dot products, F::load(S) fetches the scalars once, F::apply<T>(i, acc) handles element(s) i.
+template <class F>
+__global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce red)
+{
+    if (S->done) return;
+    constexpr int ND = F::ND > 0 ? F::ND : 1;
+    __shared__ double sm[5 * ND];
+    double acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = 0.0;
+    f.load(S);
+    const uint32_t npair = n >> 1;
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npair; i += gridDim.x * kBlock)
+        f.template apply<d2>(2 * i, acc);
+    if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
+    if (F::ND > 0) reduce_publish<ND>(acc, S, red, blockIdx.x, sm);
+}
+
+unsigned vec_grid(uint32_t n)
+{
+    unsigned g = ((n >> 1) + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > (unsigned)kMaxGrid) g = kMaxGrid;      // 256 CUs x 8 resident workgroups, grid-stride beyond
+    return g;
+}
+
+template <class F>
+static void run_vec(F f, uint32_t n, Scal *S, Reduce red, hipStream_t stream)
+{
+    const unsigned g = vec_grid(n);
+    red.expected = g;
+    red.slot_base = 0;
+    hipLaunchKernelGGL((k_vec<F>), dim3(g), dim3(kBlock), 0, stream, f, n, S, red);
+}
+
+// ---- init: r = b - Ax ; r# = r ; [p = r] ; [bsave = b] ; (r,r)     (src/solver.c:74-78, 475-479)
+struct FInit {
+    static constexpr int ND = 1;
+    double *r, *rh, *p, *bs; const double *ax;
+    __device__ void load(const Scal *) {}
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T b = ld<T>(r, i);
+        if (bs) st(bs, i, b);
+        T rr = b + (-1.0) * ld<T>(ax, i);
+        st(r, i, rr); st(rh, i, rr);
+        if (p) st(p, i, rr);
+        acc[0] += hsum(rr * rr);
+    }
+};
+void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FInit{v.r, v.rh, copy_p ? v.p : nullptr, save_b ? v.b : nullptr, v.ax}, v.n, S, red, s);
+}
+
+// ---- plain: q = r - alpha s (kept in r)                               (src/solver.c:94)
+struct FPlainQ {
+    static constexpr int ND = 0;
+    double *r; const double *s; double alpha;
+    __device__ void load(const Scal *S) { alpha = S->alpha; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        st(r, i, ld<T>(r, i) + (-alpha) * ld<T>(s, i));
+    }
+};
+void launch_plain_q(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FPlainQ{v.r, v.s, 0.0}, v.n, S, Reduce{}, s); }
+
+// ---- plain: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r)   (src/solver.c:105-111)
+struct FPlainXR {
+    static constexpr int ND = 2;
+    double *x, *r; const double *p, *y, *rh; double alpha, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T q = ld<T>(r, i);
+        T xx = ld<T>(x, i) + alpha * ld<T>(p, i);
+        xx = xx + omega * q;
+        st(x, i, xx);
+        T rr = q + (-omega) * ld<T>(y, i);
+        st(r, i, rr);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(ld<T>(rh, i) * rr);
+    }
+};
+void launch_plain_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FPlainXR{v.x, v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, S, red, s);
+}
+
+// ---- plain: p = beta p ; p += r ; p += (-beta*omega) s                (src/solver.c:117-119)
+struct FPlainP {
+    static constexpr int ND = 0;
+    double *p; const double *r, *s; double beta, c;
+    __device__ void load(const Scal *S) { beta = S->beta; c = -S->beta * S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        T pp = beta * ld<T>(p, i);
+        pp = pp + 1.0 * ld<T>(r, i);
+        pp = pp + c * ld<T>(s, i);
+        st(p, i, pp);
+    }
+};
+void launch_plain_p(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FPlainP{v.p, v.r, v.s, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+
+// u <- add + beta (u - omega w): daxpy(-omega) / dscal(beta) / daxpy(1.0)   (src/solver.c:217-219 etc.)
+template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double omega, double beta)
+{
+    T t = u + (-omega) * w;
+    t = beta * t;
+    return t + 1.0 * add;
+}
+
+// ---- CA: p = r + beta(p - omega s) ; s = w + beta(s - omega z)         (src/solver.c:217-222)
+struct FCaPS {
+    static constexpr int ND = 0;
+    double *p, *s; const double *r, *z, *w; double beta, omega;
+    __device__ void load(const Scal *S) { beta = S->beta; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        T s0 = ld<T>(s, i);
+        st(p, i, recur3<T>(ld<T>(p, i), s0, ld<T>(r, i), omega, beta));
+        st(s, i, recur3<T>(s0, ld<T>(z, i), ld<T>(w, i), omega, beta));
+    }
+};
+void launch_ca_ps(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FCaPS{v.p, v.s, v.r, v.z, v.w, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+
+// ---- q = r - alpha s (in r) ; y = w - alpha z (in w) ; (q,y), (y,y)    (src/solver.c:225-228, 361-364)
+struct FQY {
+    static constexpr int ND = 2;
+    double *r, *w; const double *s, *z; double alpha;
+    __device__ void load(const Scal *S) { alpha = S->alpha; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T q = ld<T>(r, i) + (-alpha) * ld<T>(s, i);
+        T y = ld<T>(w, i) + (-alpha) * ld<T>(z, i);
+        st(r, i, q); st(w, i, y);
+        acc[0] += hsum(q * y);
+        acc[1] += hsum(y * y);
+    }
+};
+void launch_qy(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FQY{v.r, v.w, v.s, v.z, 0.0}, v.n, S, red, s); }
+
+// ---- CA: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r), [slot 2 left for (r#,w)], (r#,s), (r#,z)
+//      (src/solver.c:233-236, 240, 242-243; (r#,w) comes from the following SpMV's epilogue)
+struct FCaXR {
+    static constexpr int ND = 5;
+    double *x, *r; const double *p, *w, *rh, *s, *z; double alpha, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T q = ld<T>(r, i);
+        T xx = ld<T>(x, i) + alpha * ld<T>(p, i);
+        xx = xx + omega * q;
+        st(x, i, xx);
+        T rr = q + (-omega) * ld<T>(w, i);
+        st(r, i, rr);
+        T h = ld<T>(rh, i);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(h * rr);
+        acc[3] += hsum(h * ld<T>(s, i));
+        acc[4] += hsum(h * ld<T>(z, i));
+    }
+};
+void launch_ca_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FCaXR{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
+}
+
+// ---- pipelined phase 1: p, s, z recurrences ; q, y ; (q,y), (y,y)       (src/solver.c:352-364)
+struct FPipe1 {
+    static constexpr int ND = 2;
+    double *p, *s, *z, *r, *w; const double *t, *v; double alpha, beta, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; beta = S->beta; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T r0 = ld<T>(r, i), w0 = ld<T>(w, i), s0 = ld<T>(s, i), z0 = ld<T>(z, i);
+        st(p, i, recur3<T>(ld<T>(p, i), s0, r0, omega, beta));
+        T s1 = recur3<T>(s0, z0, w0, omega, beta);
+        T z1 = recur3<T>(z0, ld<T>(v, i), ld<T>(t, i), omega, beta);
+        st(s, i, s1); st(z, i, z1);
+        T q = r0 + (-alpha) * s1;
+        T y = w0 + (-alpha) * z1;
+        st(r, i, q); st(w, i, y);
+        acc[0] += hsum(q * y);
+        acc[1] += hsum(y * y);
+    }
+};
+void launch_pipe_f1(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FPipe1{v.p, v.s, v.z, v.r, v.w, v.t, v.v, 0.0, 0.0, 0.0}, v.n, S, red, s);
+}
+
+// ---- pipelined phase 2: x ; r = q - omega y ; w = y - omega (t - alpha v) ; five dots  (src/solver.c:370-380)
+// t - alpha v is not written back: t is overwritten by the next SpMV (src/solver.c:381).
+struct FPipe2 {
+    static constexpr int ND = 5;
+    double *x, *r, *w; const double *p, *t, *v, *rh, *s, *z; double alpha, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T q = ld<T>(r, i), y = ld<T>(w, i);
+        T xx = ld<T>(x, i) + alpha * ld<T>(p, i);
+        xx = xx + omega * q;
+        st(x, i, xx);
+        T rr = q + (-omega) * y;
+        st(r, i, rr);
+        T tt = ld<T>(t, i) + (-alpha) * ld<T>(v, i);
+        T ww = y + (-omega) * tt;
+        st(w, i, ww);
+        T h = ld<T>(rh, i);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(h * rr);
+        acc[2] += hsum(h * ww);
+        acc[3] += hsum(h * ld<T>(s, i));
+        acc[4] += hsum(h * ld<T>(z, i));
+    }
+};
+void launch_pipe_f2(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FPipe2{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
+}
+
+// ---- residual replacement pieces
+struct FPUpdate {   // p = r + beta (p - omega s)                            (src/solver.c:494-496)
+    static constexpr int ND = 0;
+    double *p; const double *s, *r; double beta, omega;
+    __device__ void load(const Scal *S) { beta = S->beta; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        st(p, i, recur3<T>(ld<T>(p, i), ld<T>(s, i), ld<T>(r, i), omega, beta));
+    }
+};
+void launch_p_update(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FPUpdate{v.p, v.s, v.r, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+
+struct FXUpdate {   // x += alpha p ; x += omega q                           (src/solver.c:519-520)
+    static constexpr int ND = 0;
+    double *x; const double *p, *r; double alpha, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        T xx = ld<T>(x, i) + alpha * ld<T>(p, i);
+        st(x, i, xx + omega * ld<T>(r, i));
+    }
+};
+void launch_x_update(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FXUpdate{v.x, v.p, v.r, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+
+struct FTrueRes {   // r = b ; r += -1.0 * Ax                                (src/solver.c:524-525)
+    static constexpr int ND = 0;
+    double *r; const double *b, *ax;
+    __device__ void load(const Scal *) {}
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        st(r, i, ld<T>(b, i) + (-1.0) * ld<T>(ax, i));
+    }
+};
+void launch_true_residual(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FTrueRes{v.r, v.b, v.ax}, v.n, S, Reduce{}, s); }
+
+struct FDots5 {     // (r,r), (r#,r), (r#,w), (r#,s), (r#,z)                 (src/solver.c:533-538)
+    static constexpr int ND = 5;
+    const double *r, *rh, *w, *s, *z;
+    __device__ void load(const Scal *) {}
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T rr = ld<T>(r, i), h = ld<T>(rh, i);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(h * rr);
+        acc[2] += hsum(h * ld<T>(w, i));
+        acc[3] += hsum(h * ld<T>(s, i));
+        acc[4] += hsum(h * ld<T>(z, i));
+    }
+};
+void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FDots5{v.r, v.rh, v.w, v.s, v.z}, v.n, S, red, s); }
+
+struct FDot {
+    static constexpr int ND = 1;
+    const double *x, *y;
+    __device__ void load(const Scal *) {}
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { acc[0] += hsum(ld<T>(x, i) * ld<T>(y, i)); }
+};
+void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FDot{x, y}, n, S, red, s);
+}
+
+}  // namespace bicg

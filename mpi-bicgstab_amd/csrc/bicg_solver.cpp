@@ -1,0 +1,683 @@
+// bicg_solver.cpp -- GPU-resident iteration drivers and the C ABI (include/bicgstab_hip.h).
+//
+// One context per rank: the rank's diag/offd CSR blocks, the SpMV plan (row blocks, interior /
+// boundary split, halo lists), twelve vectors of rows+halo doubles, and a small device-resident
+// scalar block. An iteration is a fixed sequence of kernel launches (and, across ranks, halo
+// exchanges and packed all-reduces) with NO host synchronisation: alpha/beta/omega live on the
+// device, the convergence test of the reference's while loop (src/solver.c:86) is evaluated on the
+// device and turns every later kernel into a no-op, and the host only looks every `check_every`
+// iterations.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <vector>
+
+#include "bicg_comm.h"
+#include "bicg_device.h"
+
+using namespace bicg;
+
+namespace {
+
+constexpr int kEvRing = 16;
+constexpr int kMaxTimed = 8192;
+
+double now_sec()
+{
+    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
+}
+
+template <class T> T *dev_alloc(size_t n)
+{
+    T *p = nullptr;
+    BICG_HIP(hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)));
+    return p;
+}
+
+template <class T> T *dev_upload(const T *src, size_t n)
+{
+    T *p = dev_alloc<T>(n);
+    if (n) BICG_HIP(hipMemcpy(p, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    return p;
+}
+
+}  // namespace
+
+struct bicg_ctx {
+    Comm *comm = nullptr;
+    int nranks = 1, rank = 0;
+    uint32_t n_loc = 0, n_glob = 0, halo = 0, stride = 0, nnz_d = 0, nnz_o = 0;
+
+    // matrix + plan (device)
+    double *d_val = nullptr, *o_val = nullptr;
+    uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
+    uint32_t *rowblk = nullptr, *blist_int = nullptr, *blist_bnd = nullptr;
+    uint32_t nblk = 0, n_int = 0, n_bnd = 0;
+
+    // halo exchange
+    std::vector<int> scnt, sdsp, rcnt, rdsp;
+    uint32_t nsend = 0;
+    uint32_t *send_idx = nullptr;
+    double *sendbuf = nullptr;
+
+    // vectors and scalars
+    double *slab = nullptr;
+    Vecs v{};
+    Scal *S = nullptr;
+    Scal *hS = nullptr;          // pinned mirror
+    double *partial = nullptr, *shard_tot = nullptr;
+    unsigned *counter = nullptr;
+    unsigned nslots = 0;
+    double *trace = nullptr;     // 4 * trace_cap
+    int trace_cap = 0;
+    int last_iters = 0;
+
+    hipStream_t sc = nullptr, sm = nullptr;   // compute, communication
+    hipEvent_t ev_pack[kEvRing], ev_halo[kEvRing], ev_dots[kEvRing], ev_red[kEvRing];
+    unsigned i_pack = 0, i_halo = 0, i_dots = 0, i_red = 0;
+
+    // deferred dot group (pipelined variant: all-reduce overlaps the next SpMV)
+    bool pend = false;
+    int pend_n = 0, pend_phase = 0;
+    hipEvent_t pend_ev = nullptr;
+
+    // per-SpMV timing
+    bool time_kernels = false;
+    std::vector<hipEvent_t> tev;
+    int tev_used = 0;
+
+    bool single() const { return nranks == 1; }
+    Reduce red(int off, int phase, bool apply_single = true) const
+    {
+        Reduce r;
+        r.partial = partial; r.shard_tot = shard_tot; r.counter = counter; r.expected = 0; r.slot_base = 0;
+        r.red_off = off; r.phase = phase;
+        r.apply_now = (single() && apply_single) ? 1 : 0;
+        return r;
+    }
+};
+
+namespace {
+
+// ---------------------------------------------------------------- dot groups across ranks
+void group_enqueue(bicg_ctx *c, int n, int phase, hipEvent_t after)
+{
+    if (c->comm->stream_ordered()) {
+        BICG_HIP(hipStreamWaitEvent(c->sm, after, 0));
+        c->comm->allreduce_sum(c->S->red, n, c->sm);
+        launch_apply(c->S, phase, c->sm);
+        hipEvent_t e = c->ev_red[c->i_red++ % kEvRing];
+        BICG_HIP(hipEventRecord(e, c->sm));
+        c->pend_ev = e;
+    } else {
+        c->comm->allreduce_sum(c->S->red, n, c->sc);   // synchronises sc
+        launch_apply(c->S, phase, c->sc);
+        c->pend_ev = nullptr;
+    }
+}
+
+// all-reduce the n sums in Scal::red and apply `phase`, blocking the compute stream on the result
+void group_now(bicg_ctx *c, int n, int phase)
+{
+    if (c->single()) return;   // applied in-kernel by the finishing workgroup
+    hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
+    BICG_HIP(hipEventRecord(e, c->sc));
+    group_enqueue(c, n, phase, e);
+    if (c->pend_ev) BICG_HIP(hipStreamWaitEvent(c->sc, c->pend_ev, 0));
+    c->pend_ev = nullptr;
+}
+
+// same, but the all-reduce is started by the NEXT spmv() after its halo exchange is in flight and
+// joined after that SpMV: the overlap of reference src/solver.c:363-367 and 377-385
+void group_defer(bicg_ctx *c, int n, int phase)
+{
+    if (c->single()) return;
+    hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
+    BICG_HIP(hipEventRecord(e, c->sc));
+    c->pend = true; c->pend_n = n; c->pend_phase = phase; c->pend_ev = e;
+}
+
+// ---------------------------------------------------------------- distributed SpMV
+// y = A x (+ fused dots). Replaces MPI_csr_spmv_ovlap (reference src/matrix.c:428-441): the halo
+// exchange runs on the communication stream while the interior row blocks are multiplied; row
+// blocks that touch the halo run after it has landed. Every row is produced by exactly one
+// workgroup as (0 + sum_diag) + sum_offd, the reference's order.
+void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red)
+{
+    SpmvArgs a;
+    a.diag = {c->d_val, c->d_col, c->d_ptr};
+    a.offd = {c->o_val, c->o_col, c->o_ptr};
+    a.rowblk = c->rowblk;
+    a.x = xin; a.y = yout; a.u = u; a.S = c->S;
+    // dot partials: one slot per workgroup, interior launch first, boundary launch after it
+    const unsigned g_int = c->single() ? spmv_grid(c->nblk) : spmv_grid(c->n_int);
+    const unsigned g_bnd = c->single() ? 0u : spmv_grid(c->n_bnd);
+    red.expected = g_int + g_bnd;
+    red.slot_base = 0;
+    a.red = red;
+
+    hipEvent_t t0 = nullptr, t1 = nullptr;
+    if (c->time_kernels && c->tev_used + 2 <= (int)c->tev.size()) {
+        t0 = c->tev[c->tev_used++]; t1 = c->tev[c->tev_used++];
+        BICG_HIP(hipEventRecord(t0, c->sc));
+    }
+
+    if (c->single()) {
+        a.blist = nullptr; a.nlist = c->nblk;
+        launch_spmv(a, ndot, false, c->sc);
+    } else {
+        launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
+        hipEvent_t eh = nullptr;
+        if (c->comm->stream_ordered()) {
+            hipEvent_t ep = c->ev_pack[c->i_pack++ % kEvRing];
+            BICG_HIP(hipEventRecord(ep, c->sc));
+            BICG_HIP(hipStreamWaitEvent(c->sm, ep, 0));
+            c->comm->exchange(c->sendbuf, c->scnt.data(), c->sdsp.data(), xin + c->n_loc, c->rcnt.data(), c->rdsp.data(), c->sm);
+            eh = c->ev_halo[c->i_halo++ % kEvRing];
+            BICG_HIP(hipEventRecord(eh, c->sm));
+        } else {
+            c->comm->exchange(c->sendbuf, c->scnt.data(), c->sdsp.data(), xin + c->n_loc, c->rcnt.data(), c->rdsp.data(), c->sc);
+        }
+        bool joined_pending = false;
+        if (c->pend) {   // start the deferred all-reduce behind the halo traffic
+            hipEvent_t after = c->pend_ev;
+            c->pend = false;
+            group_enqueue(c, c->pend_n, c->pend_phase, after);
+            joined_pending = true;
+        }
+        a.blist = c->blist_int; a.nlist = c->n_int;
+        launch_spmv(a, ndot, false, c->sc);
+        if (eh) BICG_HIP(hipStreamWaitEvent(c->sc, eh, 0));
+        a.blist = c->blist_bnd; a.nlist = c->n_bnd;
+        a.red.slot_base = g_int;
+        launch_spmv(a, ndot, true, c->sc);
+        if (joined_pending && c->pend_ev) {
+            BICG_HIP(hipStreamWaitEvent(c->sc, c->pend_ev, 0));
+            c->pend_ev = nullptr;
+        }
+    }
+    if (t1) BICG_HIP(hipEventRecord(t1, c->sc));
+}
+
+// a deferred group that no SpMV picked up (defensive)
+void group_flush(bicg_ctx *c)
+{
+    if (!c->pend) return;
+    hipEvent_t after = c->pend_ev;
+    c->pend = false;
+    group_enqueue(c, c->pend_n, c->pend_phase, after);
+    if (c->pend_ev) BICG_HIP(hipStreamWaitEvent(c->sc, c->pend_ev, 0));
+    c->pend_ev = nullptr;
+}
+
+// ---------------------------------------------------------------- the four iterations
+struct Driver {
+    bicg_ctx *c;
+    int method;
+    int krr, nrr;
+    hipStream_t sc;
+    Vecs &v;
+    Scal *S;
+
+    Driver(bicg_ctx *ctx, int m, int kr, int nr) : c(ctx), method(m), krr(kr), nrr(nr), sc(ctx->sc), v(ctx->v), S(ctx->S) {}
+
+    void init()
+    {
+        const bool plain = method == BICG_BICGSTAB;
+        const bool rr = method == BICG_PIPE_BICGSTAB_RR;
+        spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));                       // Ax = A x0
+        launch_init_residual(v, plain, rr, S, c->red(0, PH_INIT), sc);             // r = b - Ax, r# = r, (r,r)
+        group_now(c, 1, PH_INIT);
+        if (plain) return;
+        spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_INIT_ALPHA));                        // w = A r, (r,w)
+        if (method == BICG_CA_BICGSTAB) {
+            group_now(c, 1, PH_INIT_ALPHA);
+        } else {
+            group_defer(c, 1, PH_INIT_ALPHA);                                       // overlaps t = A w (src/solver.c:339-343)
+            spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));
+            group_flush(c);
+        }
+    }
+
+    void iter_plain()   // reference src/solver.c:88-119
+    {
+        spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA));   // s = A p, (r#,s) -> alpha
+        group_now(c, 1, PH_PLAIN_ALPHA);
+        launch_plain_q(v, S, sc);                                // q = r - alpha s
+        spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA));          // y = A q, (q,y), (y,y) -> omega
+        group_now(c, 2, PH_OMEGA);
+        launch_plain_xr(v, S, c->red(0, PH_PLAIN_END), sc);      // x, r, (r,r), (r#,r) -> beta, k++
+        group_now(c, 2, PH_PLAIN_END);
+        launch_plain_p(v, S, sc);                                // p = r + beta (p - omega s)
+    }
+
+    void iter_ca()      // reference src/solver.c:217-251
+    {
+        launch_ca_ps(v, S, sc);                                  // p, s recurrences
+        spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
+        launch_qy(v, S, c->red(0, PH_OMEGA), sc);                // q, y, (q,y), (y,y) -> omega
+        group_now(c, 2, PH_OMEGA);
+        launch_ca_xr(v, S, c->red(0, PH_NONE, false), sc);       // x, r, (r,r), (r#,r), (r#,s), (r#,z)
+        spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END));     // w = A r, (r#,w) -> beta, alpha, k++
+        group_now(c, 5, PH_RECUR_END);
+    }
+
+    void iter_pipe(int it)   // reference src/solver.c:352-390 and 494-548
+    {
+        const bool replace = method == BICG_PIPE_BICGSTAB_RR && krr > 0 && (it % krr == 0) && it > 0 && it <= krr * nrr;
+        if (!replace) {
+            launch_pipe_f1(v, S, c->red(0, PH_OMEGA), sc);           // p, s, z, q, y, (q,y), (y,y)
+            group_defer(c, 2, PH_OMEGA);
+            spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));       // v = A z   || all-reduce
+            launch_pipe_f2(v, S, c->red(0, PH_RECUR_END), sc);       // x, r, w, five dots
+            group_defer(c, 5, PH_RECUR_END);
+            spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));       // t = A w   || all-reduce
+        } else {
+            launch_p_update(v, S, sc);
+            spmv(c, v.p, v.s, 0, nullptr, c->red(0, PH_NONE));       // s = A p
+            spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
+            launch_qy(v, S, c->red(0, PH_OMEGA), sc);
+            group_defer(c, 2, PH_OMEGA);
+            spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));       // v = A z
+            launch_x_update(v, S, sc);
+            spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));      // Ax = A x
+            launch_true_residual(v, S, sc);                          // r = b - Ax
+            spmv(c, v.r, v.w, 0, nullptr, c->red(0, PH_NONE));       // w = A r
+            launch_dots5(v, S, c->red(0, PH_RECUR_END), sc);
+            group_defer(c, 5, PH_RECUR_END);
+            spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));       // t = A w
+        }
+        group_flush(c);
+    }
+
+    void iterate(int it)
+    {
+        switch (method) {
+        case BICG_BICGSTAB: iter_plain(); break;
+        case BICG_CA_BICGSTAB: iter_ca(); break;
+        default: iter_pipe(it); break;
+        }
+    }
+};
+
+void fetch_scal(bicg_ctx *c)
+{
+    BICG_HIP(hipMemcpyAsync(c->hS, c->S, sizeof(Scal), hipMemcpyDeviceToHost, c->sc));
+    BICG_HIP(hipStreamSynchronize(c->sc));
+    if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
+}
+
+int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result *res)
+{
+    bicg_options o;
+    if (opt_in) o = *opt_in; else bicg_default_options(&o);
+    if (method < BICG_BICGSTAB || method > BICG_PIPE_BICGSTAB_RR) die("bicg_run", "unknown method");
+    if (o.max_iter < 0) o.max_iter = 0;
+    if (o.check_every < 1) o.check_every = 1;
+    BICG_HIP(hipSetDevice(c->comm->device));
+
+    // trace storage: the (r,r) history is always kept (progress lines), 4 arrays of max_iter
+    if (c->trace_cap < o.max_iter) {
+        if (c->trace) BICG_HIP(hipFree(c->trace));
+        c->trace_cap = o.max_iter > 0 ? o.max_iter : 1;
+        c->trace = dev_alloc<double>(4 * (size_t)c->trace_cap);
+    }
+    Scal h;
+    memset(&h, 0, sizeof h);
+    h.tol2 = o.tol * o.tol;
+    h.max_iter = o.max_iter;
+    h.tr_alpha = c->trace;
+    h.tr_omega = c->trace + c->trace_cap;
+    h.tr_beta = c->trace + 2 * (size_t)c->trace_cap;
+    h.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
+    BICG_HIP(hipMemcpyAsync(c->S, &h, sizeof h, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
+    // every work vector starts at zero: defines the reads of p, s, z, v that the reference makes
+    // before writing them (src/solver.c:217-222, 352-360) and keeps halo tails finite
+    const size_t st = c->stride;
+    BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
+    c->time_kernels = o.time_kernels != 0;
+    c->tev_used = 0;
+    if (c->time_kernels && c->tev.empty()) {
+        c->tev.resize(kMaxTimed);
+        for (auto &e : c->tev) BICG_HIP(hipEventCreate(&e));
+    }
+    BICG_HIP(hipStreamSynchronize(c->sc));
+
+    Driver d(c, method, o.krr, o.nrr);
+    const bool talk = c->rank == 0 && !o.quiet;
+
+    const double t0 = now_sec();
+    d.init();
+    fetch_scal(c);
+    const double t1 = now_sec();
+
+    int it = 0, printed = 0;
+    std::vector<double> hist;
+    while (!c->hS->done && it < o.max_iter) {
+        const int chunk = std::min(o.check_every, o.max_iter - it);
+        for (int j = 0; j < chunk; ++j) d.iterate(it + j);
+        it += chunk;
+        fetch_scal(c);
+        if (talk && o.out_iter > 0) {   // reference src/solver.c:122-126
+            const int k = c->hS->k;
+            const int upto = (k / o.out_iter) * o.out_iter;
+            if (upto > printed) {
+                hist.resize(k);
+                BICG_HIP(hipMemcpy(hist.data(), h.tr_dotr, sizeof(double) * k, hipMemcpyDeviceToHost));
+                for (int q = printed + o.out_iter; q <= upto; q += o.out_iter)
+                    printf("Iteration: %d, Residual: %e\n", q, sqrt(hist[q - 1] / c->hS->dot_zero));
+                printed = upto;
+            }
+        }
+    }
+    const double t2 = now_sec();
+
+    const int k = c->hS->k;
+    c->last_iters = k;
+    double spmv_ms = 0.0;
+    int spmv_n = 0;
+    if (c->time_kernels) {
+        for (int i = 0; i + 1 < c->tev_used; i += 2) {
+            float ms = 0.f;
+            if (hipEventElapsedTime(&ms, c->tev[i], c->tev[i + 1]) == hipSuccess) { spmv_ms += ms; ++spmv_n; }
+        }
+    }
+    if (res) {
+        res->iterations = k;
+        res->dot_r = c->hS->dot_r;
+        res->dot_zero = c->hS->dot_zero;
+        res->seconds = t2 - t0;
+        res->iter_seconds = t2 - t1;
+        res->spmv_ms_total = spmv_ms;
+        res->spmv_launches = spmv_n;
+    }
+    if (talk) {   // reference src/solver.c:134-141, verbatim
+        printf("Total iter   : %d\n", k);
+        printf("Final r      : %e\n", sqrt(c->hS->dot_r / c->hS->dot_zero));
+        printf("Total time   : %e [sec.] \n", t2 - t0);
+        printf("Avg time/iter: %e [sec.] \n", (t2 - t0) / k);
+        fflush(stdout);
+    }
+    return k;
+}
+
+void check_square(const INFO_Matrix *info)
+{
+    if (info->cols != info->rows) {   // reference src/solver.c:43-46
+        printf("Error: matrix is not square.\n");
+        exit(1);
+    }
+}
+
+void env_options(bicg_options *o)
+{
+    bicg_default_options(o);
+    if (const char *s = getenv("BICG_TOL")) o->tol = atof(s);
+    if (const char *s = getenv("BICG_MAX_ITER")) o->max_iter = atoi(s);
+    if (const char *s = getenv("BICG_OUT_ITER")) o->out_iter = atoi(s);
+    if (const char *s = getenv("BICG_CHECK_EVERY")) o->check_every = atoi(s);
+    if (const char *s = getenv("BICG_QUIET")) o->quiet = atoi(s);
+}
+
+int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, double *x, double *r, int krr, int nrr)
+{
+    check_square(info);
+    bicg_options o;
+    env_options(&o);
+    o.krr = krr; o.nrr = nrr;
+    bicg_ctx *c = bicg_create(diag, offd, info);
+    if (!c) die("bicg_create", "failed");
+    bicg_result res;
+    const int k = bicg_solve(c, method, x, r, &o, &res);
+    bicg_destroy(c);
+    return k;
+}
+
+}  // namespace
+
+// =====================================================================================  C ABI
+extern "C" {
+
+const char *bicg_version(void) { return "bicgstab_hip 0.1 (gfx950)"; }
+
+void bicg_default_options(bicg_options *o)
+{
+    memset(o, 0, sizeof *o);
+    o->tol = 1.0e-15;      // reference EPS       (src/solver.c:3)
+    o->max_iter = 1000;    // reference MAX_ITER  (src/solver.c:4)
+    o->out_iter = 100;     // reference OUT_ITER  (src/solver.c:9)
+    o->check_every = 16;
+}
+
+bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
+{
+    Comm *comm = comm_get();
+    BICG_HIP(hipSetDevice(comm->device));
+    if (info->rows != info->cols) { fprintf(stderr, "ERROR: bicg_create: matrix is not square\n"); return nullptr; }
+    if (diag->rows == 0) { fprintf(stderr, "ERROR: bicg_create: a rank without rows is not supported\n"); return nullptr; }
+
+    bicg_ctx *c = new bicg_ctx;
+    c->comm = comm; c->nranks = comm->nranks; c->rank = comm->rank;
+    c->n_loc = diag->rows; c->n_glob = info->rows;
+    c->nnz_d = diag->ptr[diag->rows];
+    const int P = c->nranks;
+
+    // ---- SpMV plan: row blocks over the diag block
+    std::vector<uint32_t> rowblk(c->n_loc + 1);
+    c->nblk = bicg_row_blocks(diag->ptr, c->n_loc, kChunk, 1024, rowblk.data());
+    rowblk.resize(c->nblk + 1);
+
+    // ---- halo plan (multi rank): which of x's remote entries this rank needs, who needs ours
+    std::vector<uint32_t> ocol, optr(c->n_loc + 1, 0u);
+    std::vector<double> oval;
+    std::vector<uint32_t> send_idx;
+    c->scnt.assign(P, 0); c->sdsp.assign(P, 0); c->rcnt.assign(P, 0); c->rdsp.assign(P, 0);
+    if (P > 1) {
+        if (offd->rows != c->n_loc) die("bicg_create", "offd block row count differs from diag block");
+        c->nnz_o = offd->ptr[offd->rows];
+        std::vector<uint32_t> halo_cols(c->nnz_o ? c->nnz_o : 1);
+        ocol.resize(c->nnz_o ? c->nnz_o : 1);
+        c->halo = (uint32_t)bicg_halo_plan(offd, info, P, c->n_loc, halo_cols.data(), c->rcnt.data(), ocol.data());
+        optr.assign(offd->ptr, offd->ptr + c->n_loc + 1);
+        oval.assign(offd->val, offd->val + c->nnz_o);
+        for (int p = 1; p < P; ++p) c->rdsp[p] = c->rdsp[p - 1] + c->rcnt[p - 1];
+        // tell every owner how many / which of its rows we need
+        std::vector<int> one(P, (int)sizeof(int)), off(P), need_from_me(P, 0);
+        for (int p = 0; p < P; ++p) off[p] = p * (int)sizeof(int);
+        comm->alltoallv_host(c->rcnt.data(), one.data(), off.data(), need_from_me.data(), one.data(), off.data());
+        c->scnt = need_from_me;
+        for (int p = 1; p < P; ++p) c->sdsp[p] = c->sdsp[p - 1] + c->scnt[p - 1];
+        c->nsend = (uint32_t)(c->sdsp[P - 1] + c->scnt[P - 1]);
+        std::vector<int> sb(P), sd(P), rb(P), rd(P);
+        for (int p = 0; p < P; ++p) {
+            sb[p] = c->rcnt[p] * 4; sd[p] = c->rdsp[p] * 4;     // we SEND the index lists we want to receive values for
+            rb[p] = c->scnt[p] * 4; rd[p] = c->sdsp[p] * 4;
+        }
+        send_idx.resize(c->nsend ? c->nsend : 1);
+        comm->alltoallv_host(halo_cols.data(), sb.data(), sd.data(), send_idx.data(), rb.data(), rd.data());
+        const uint32_t lo = (uint32_t)info->displs[c->rank];
+        for (uint32_t i = 0; i < c->nsend; ++i) {
+            if (send_idx[i] < lo || send_idx[i] - lo >= c->n_loc) die("bicg_create", "halo request outside the owner's rows");
+            send_idx[i] -= lo;
+        }
+    }
+
+    // ---- interior / boundary row blocks
+    std::vector<uint32_t> bint, bbnd;
+    for (uint32_t b = 0; b < c->nblk; ++b) {
+        const bool touches_halo = P > 1 && optr[rowblk[b + 1]] > optr[rowblk[b]];
+        (touches_halo ? bbnd : bint).push_back(b);
+    }
+    c->n_int = (uint32_t)bint.size(); c->n_bnd = (uint32_t)bbnd.size();
+
+    // ---- upload
+    c->d_val = dev_upload(diag->val, c->nnz_d);
+    c->d_col = dev_upload(diag->col, c->nnz_d);
+    c->d_ptr = dev_upload(diag->ptr, (size_t)c->n_loc + 1);
+    c->o_val = dev_upload(oval.data(), c->nnz_o);
+    c->o_col = dev_upload(ocol.data(), c->nnz_o);
+    c->o_ptr = dev_upload(optr.data(), (size_t)c->n_loc + 1);
+    c->rowblk = dev_upload(rowblk.data(), rowblk.size());
+    c->blist_int = dev_upload(bint.data(), bint.size());
+    c->blist_bnd = dev_upload(bbnd.data(), bbnd.size());
+    c->send_idx = dev_upload(send_idx.data(), c->nsend);
+    c->sendbuf = dev_alloc<double>(c->nsend);
+
+    // ---- vectors: 12 x (rows + halo), each 256-byte aligned; order x r | rh p s y z w v t ax b
+    c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
+    c->slab = dev_alloc<double>(12 * (size_t)c->stride);
+    BICG_HIP(hipMemset(c->slab, 0, sizeof(double) * 12 * (size_t)c->stride));
+    double *base = c->slab;
+    double **slots[12] = {&c->v.x, &c->v.r, &c->v.rh, &c->v.p, &c->v.s, &c->v.y, &c->v.z, &c->v.w, &c->v.v, &c->v.t, &c->v.ax, &c->v.b};
+    for (int i = 0; i < 12; ++i) *slots[i] = base + (size_t)i * c->stride;
+    c->v.n = c->n_loc;
+
+    c->nslots = std::max<unsigned>(2 * kSpmvMaxGrid, kMaxGrid) + 2;
+    if (c->nblk + 2 < c->nslots) c->nslots = std::max<unsigned>(c->nblk, kMaxGrid) + 2;
+    c->partial = dev_alloc<double>((size_t)c->nslots * kPartialStride);
+    c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
+    c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
+    BICG_HIP(hipMemset(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride));
+    c->S = dev_alloc<Scal>(1);
+    BICG_HIP(hipMemset(c->S, 0, sizeof(Scal)));
+    BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
+    memset(c->hS, 0, sizeof(Scal));
+
+    BICG_HIP(hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking));
+    if (P > 1) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
+    for (int i = 0; i < kEvRing; ++i) {
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_pack[i], hipEventDisableTiming));
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_halo[i], hipEventDisableTiming));
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_dots[i], hipEventDisableTiming));
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming));
+    }
+    return c;
+}
+
+void bicg_destroy(bicg_ctx *c)
+{
+    if (!c) return;
+    (void)hipSetDevice(c->comm->device);
+    (void)hipDeviceSynchronize();
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->rowblk, c->blist_int, c->blist_bnd,
+                    c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace};
+    for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->hS) (void)hipHostFree(c->hS);
+    for (int i = 0; i < kEvRing; ++i) {
+        (void)hipEventDestroy(c->ev_pack[i]); (void)hipEventDestroy(c->ev_halo[i]); (void)hipEventDestroy(c->ev_dots[i]); (void)hipEventDestroy(c->ev_red[i]);
+    }
+    for (auto &e : c->tev) (void)hipEventDestroy(e);
+    if (c->sc) (void)hipStreamDestroy(c->sc);
+    if (c->sm) (void)hipStreamDestroy(c->sm);
+    delete c;
+}
+
+int bicg_load(bicg_ctx *c, const double *x0, const double *b)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    BICG_HIP(hipMemcpy(c->v.x, x0, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemcpy(c->v.r, b, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
+    return 0;
+}
+
+int bicg_fetch(bicg_ctx *c, double *x, double *r)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    BICG_HIP(hipStreamSynchronize(c->sc));
+    if (x) BICG_HIP(hipMemcpy(x, c->v.x, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
+    if (r) BICG_HIP(hipMemcpy(r, c->v.r, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
+    return 0;
+}
+
+int bicg_run(bicg_ctx *c, int method, const bicg_options *opt, bicg_result *res) { return run_solver(c, method, opt, res); }
+
+int bicg_solve(bicg_ctx *c, int method, double *x, double *r, const bicg_options *opt, bicg_result *res)
+{
+    bicg_load(c, x, r);
+    const int k = run_solver(c, method, opt, res);
+    bicg_fetch(c, x, r);
+    return k;
+}
+
+int bicg_trace(bicg_ctx *c, double *alpha, double *omega, double *beta, double *dot_r)
+{
+    const int k = c->last_iters;
+    if (k <= 0 || !c->trace) return 0;
+    double *dst[4] = {alpha, omega, beta, dot_r};
+    for (int i = 0; i < 4; ++i)
+        if (dst[i]) BICG_HIP(hipMemcpy(dst[i], c->trace + (size_t)i * c->trace_cap, sizeof(double) * k, hipMemcpyDeviceToHost));
+    return k;
+}
+
+static void reset_scal(bicg_ctx *c)
+{
+    BICG_HIP(hipMemsetAsync(c->S, 0, sizeof(Scal), c->sc));
+    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
+}
+
+int bicg_spmv(bicg_ctx *c, const double *x, double *y)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    reset_scal(c);
+    BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
+    c->time_kernels = false;
+    spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
+    BICG_HIP(hipMemcpyAsync(y, c->v.s, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost, c->sc));
+    BICG_HIP(hipStreamSynchronize(c->sc));
+    return 0;
+}
+
+double bicg_dot(bicg_ctx *c, const double *x, const double *y)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    reset_scal(c);
+    BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipMemcpyAsync(c->v.s, y, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
+    launch_dot(c->v.p, c->v.s, c->n_loc, c->S, c->red(0, PH_NONE), c->sc);
+    group_now(c, 1, PH_NONE);
+    fetch_scal(c);
+    return c->hS->red[0];
+}
+
+int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    reset_scal(c);
+    std::vector<double> ones(c->n_loc, 1.0);
+    BICG_HIP(hipMemcpyAsync(c->v.p, ones.data(), sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipStreamSynchronize(c->sc));
+    c->time_kernels = false;
+    for (int i = 0; i < 3; ++i) spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
+    hipEvent_t a, b;
+    BICG_HIP(hipEventCreate(&a)); BICG_HIP(hipEventCreate(&b));
+    BICG_HIP(hipEventRecord(a, c->sc));
+    for (int i = 0; i < reps; ++i) spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
+    BICG_HIP(hipEventRecord(b, c->sc));
+    BICG_HIP(hipEventSynchronize(b));
+    float ms = 0.f;
+    BICG_HIP(hipEventElapsedTime(&ms, a, b));
+    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    *ms_per_spmv = (double)ms / (reps > 0 ? reps : 1);
+    return 0;
+}
+
+int bicg_plan_info(bicg_ctx *c, unsigned int out[6])
+{
+    out[0] = c->n_loc; out[1] = c->nnz_d; out[2] = c->nnz_o; out[3] = c->halo; out[4] = c->nblk; out[5] = c->n_bnd;
+    return 0;
+}
+
+// ---- drop-in entry points: reference src/solver.h:10-13
+int bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_BICGSTAB, d, o, i, x, r, 0, 0); }
+int ca_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_CA_BICGSTAB, d, o, i, x, r, 0, 0); }
+int pipe_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_PIPE_BICGSTAB, d, o, i, x, r, 0, 0); }
+int pipe_bicgstab_rr(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, int krr, int nrr)
+{
+    return dropin(BICG_PIPE_BICGSTAB_RR, d, o, i, x, r, krr, nrr);
+}
+
+}  // extern "C"

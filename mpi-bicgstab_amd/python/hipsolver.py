@@ -1,0 +1,241 @@
+"""ctypes binding of libbicgstab_hip.so (include/bicgstab_hip.h) -- the host-side mirror used by
+tests/ and bench.py. The reference's host is C (src/main.c); the equivalent C host lives in
+``mpi-bicgstab_amd/host/``. Function names follow the reference's solver.h.
+
+There is NO fallback: if the HIP library is missing or no GPU is visible the calls fail loudly.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+
+from .synth import CSR
+
+PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LIB_PATH = os.path.join(PKG_DIR, "libbicgstab_hip.so")
+
+METHODS = {"bicgstab": 0, "ca_bicgstab": 1, "pipe_bicgstab": 2, "pipe_bicgstab_rr": 3}
+
+_dp = C.POINTER(C.c_double)
+_up = C.POINTER(C.c_uint)
+_ip = C.POINTER(C.c_int)
+
+
+class CSRMatrix(C.Structure):      # include/bicgstab_hip.h (reference src/matrix.h:19-26)
+    _fields_ = [("val", _dp), ("col", _up), ("ptr", _up), ("nz", C.c_uint), ("rows", C.c_uint), ("cols", C.c_uint)]
+
+
+class InfoMatrix(C.Structure):     # include/bicgstab_hip.h (reference src/matrix.h:28-33)
+    _fields_ = [("nz", C.c_uint), ("rows", C.c_uint), ("cols", C.c_uint), ("code", C.c_char * 4),
+                ("recvcounts", _ip), ("displs", _ip)]
+
+
+class Options(C.Structure):
+    _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("out_iter", C.c_int), ("check_every", C.c_int),
+                ("quiet", C.c_int), ("krr", C.c_int), ("nrr", C.c_int), ("record_trace", C.c_int),
+                ("time_kernels", C.c_int)]
+
+
+class Result(C.Structure):
+    _fields_ = [("iterations", C.c_int), ("dot_r", C.c_double), ("dot_zero", C.c_double), ("seconds", C.c_double),
+                ("iter_seconds", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int)]
+
+
+ALLREDUCE_FN = C.CFUNCTYPE(None, _dp, C.c_int, C.c_void_p)
+ALLTOALLV_FN = C.CFUNCTYPE(None, C.c_void_p, _ip, _ip, C.c_void_p, _ip, _ip, C.c_void_p)
+
+EXPORTS = [
+    "bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr",
+    "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
+    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_rank", "bicg_comm_size",
+    "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
+    "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info",
+    "bicg_partition", "bicg_halo_plan", "bicg_row_blocks", "bicg_version",
+]
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(f"{LIB_PATH} is missing: build it with `make -C mpi-bicgstab_amd lib` "
+                               "(python -c 'import __graft_entry__ as g; g.build()')")
+        L = C.CDLL(LIB_PATH, mode=C.RTLD_GLOBAL)
+        L.bicg_create.restype = C.c_void_p
+        L.bicg_create.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix)]
+        L.bicg_destroy.argtypes = [C.c_void_p]
+        L.bicg_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(Options), C.POINTER(Result)]
+        L.bicg_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Result)]
+        L.bicg_load.argtypes = [C.c_void_p, _dp, _dp]
+        L.bicg_fetch.argtypes = [C.c_void_p, _dp, _dp]
+        L.bicg_trace.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
+        L.bicg_spmv.argtypes = [C.c_void_p, _dp, _dp]
+        L.bicg_dot.argtypes = [C.c_void_p, _dp, _dp]
+        L.bicg_dot.restype = C.c_double
+        L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.bicg_plan_info.argtypes = [C.c_void_p, _up]
+        L.bicg_default_options.argtypes = [C.POINTER(Options)]
+        L.bicg_comm_unique_id.argtypes = [C.c_void_p]
+        L.bicg_comm_init_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
+        L.bicg_comm_init_host.argtypes = [C.c_int, C.c_int, ALLREDUCE_FN, ALLTOALLV_FN, C.c_void_p, C.c_int]
+        L.bicg_comm_init_single.argtypes = [C.c_int]
+        L.bicg_comm_init_mpi.argtypes = [C.c_char_p, C.c_int]
+        L.bicg_partition.argtypes = [C.c_uint, C.c_int, _ip, _ip]
+        L.bicg_halo_plan.argtypes = [C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), C.c_int, C.c_uint, _up, _ip, _up]
+        L.bicg_row_blocks.argtypes = [_up, C.c_uint, C.c_uint, C.c_uint, _up]
+        L.bicg_row_blocks.restype = C.c_uint
+        L.bicg_version.restype = C.c_char_p
+        for name in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
+            getattr(L, name).argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp]
+        L.pipe_bicgstab_rr.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp,
+                                       C.c_int, C.c_int]
+        _lib = L
+    return _lib
+
+
+def _d(a):
+    return a.ctypes.data_as(_dp)
+
+
+class HostBlocks:
+    """One rank's diag/offd blocks + INFO in the reference's struct layout (keeps numpy buffers alive)."""
+
+    def __init__(self, diag: CSR, offd: CSR | None, n_global: int, counts, displs):
+        if offd is None:
+            offd = CSR(diag.rows, n_global, np.zeros(diag.rows + 1, dtype=np.uint32), np.zeros(1, dtype=np.uint32),
+                       np.zeros(1))
+        self._keep = []
+
+        def mk(A: CSR):
+            v = np.ascontiguousarray(A.val, dtype=np.float64)
+            c = np.ascontiguousarray(A.col, dtype=np.uint32)
+            p = np.ascontiguousarray(A.ptr, dtype=np.uint32)
+            if v.size == 0:
+                v = np.zeros(1)
+            if c.size == 0:
+                c = np.zeros(1, dtype=np.uint32)
+            self._keep += [v, c, p]
+            return CSRMatrix(_d(v), c.ctypes.data_as(_up), p.ctypes.data_as(_up), int(p[-1]), A.rows, A.cols)
+
+        self.diag, self.offd = mk(diag), mk(offd)
+        cnt = np.ascontiguousarray(counts, dtype=np.int32)
+        dsp = np.ascontiguousarray(displs, dtype=np.int32)
+        self._keep += [cnt, dsp]
+        self.info = InfoMatrix(0, n_global, n_global, b"MCRG", cnt.ctypes.data_as(_ip), dsp.ctypes.data_as(_ip))
+        self.n_loc = diag.rows
+
+
+def single_rank_blocks(A: CSR) -> HostBlocks:
+    return HostBlocks(A, None, A.rows, [A.rows], [0])
+
+
+class Context:
+    """bicg_ctx wrapper: matrix resident on the GPU; solves, SpMV, dot."""
+
+    def __init__(self, blocks: HostBlocks):
+        self.blocks = blocks
+        self.n = blocks.n_loc
+        self.h = lib().bicg_create(C.byref(blocks.diag), C.byref(blocks.offd), C.byref(blocks.info))
+        if not self.h:
+            raise RuntimeError("bicg_create failed")
+
+    def close(self):
+        if self.h:
+            lib().bicg_destroy(self.h)
+            self.h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def options(self, **kw) -> Options:
+        o = Options()
+        lib().bicg_default_options(C.byref(o))
+        for k, val in kw.items():
+            setattr(o, k, val)
+        return o
+
+    def solve(self, method: str, b, x0=None, **kw):
+        """Semantics of the reference solver call: returns dict(k, x, r, result)."""
+        x = np.zeros(self.n) if x0 is None else np.array(x0, dtype=np.float64)
+        r = np.array(b, dtype=np.float64)
+        kw.setdefault("quiet", 1)
+        o = self.options(**kw)
+        res = Result()
+        k = lib().bicg_solve(self.h, METHODS[method], _d(x), _d(r), C.byref(o), C.byref(res))
+        return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res)
+
+    def load(self, x0, b):
+        x0 = np.ascontiguousarray(x0, dtype=np.float64)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        lib().bicg_load(self.h, _d(x0), _d(b))
+
+    def run(self, method: str, **kw) -> Result:
+        kw.setdefault("quiet", 1)
+        o = self.options(**kw)
+        res = Result()
+        lib().bicg_run(self.h, METHODS[method], C.byref(o), C.byref(res))
+        return res
+
+    def fetch(self):
+        x, r = np.zeros(self.n), np.zeros(self.n)
+        lib().bicg_fetch(self.h, _d(x), _d(r))
+        return x, r
+
+    def trace(self, k: int):
+        arrs = [np.zeros(max(k, 1)) for _ in range(4)]
+        got = lib().bicg_trace(self.h, *[_d(a) for a in arrs])
+        return dict(zip(("alpha", "omega", "beta", "dotr"), [a[:got] for a in arrs]))
+
+    def spmv(self, x):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.zeros(self.n)
+        lib().bicg_spmv(self.h, _d(x), _d(y))
+        return y
+
+    def dot(self, x, y):
+        x = np.ascontiguousarray(x, dtype=np.float64)
+        y = np.ascontiguousarray(y, dtype=np.float64)
+        return lib().bicg_dot(self.h, _d(x), _d(y))
+
+    def spmv_bench(self, reps: int) -> float:
+        ms = C.c_double(0.0)
+        lib().bicg_spmv_bench(self.h, reps, C.byref(ms))
+        return ms.value
+
+    def plan_info(self):
+        out = (C.c_uint * 6)()
+        lib().bicg_plan_info(self.h, out)
+        return dict(zip(("rows", "nnz_diag", "nnz_offd", "halo", "row_blocks", "boundary_blocks"), list(out)))
+
+
+# ---- host-only helpers (no GPU) ----------------------------------------------------------------
+def partition(n: int, nranks: int):
+    cnt = np.zeros(nranks, dtype=np.int32)
+    dsp = np.zeros(nranks, dtype=np.int32)
+    lib().bicg_partition(n, nranks, cnt.ctypes.data_as(_ip), dsp.ctypes.data_as(_ip))
+    return cnt, dsp
+
+
+def halo_plan(blocks: HostBlocks, nranks: int):
+    nz = max(int(blocks.offd.nz), 1)
+    cols = np.zeros(nz, dtype=np.uint32)
+    ren = np.zeros(nz, dtype=np.uint32)
+    rc = np.zeros(nranks, dtype=np.int32)
+    h = lib().bicg_halo_plan(C.byref(blocks.offd), C.byref(blocks.info), nranks, blocks.n_loc,
+                             cols.ctypes.data_as(_up), rc.ctypes.data_as(_ip), ren.ctypes.data_as(_up))
+    return h, cols[:h], rc, ren[:int(blocks.offd.nz)]
+
+
+def row_blocks(ptr, chunk=2048, max_rows=1024):
+    ptr = np.ascontiguousarray(ptr, dtype=np.uint32)
+    rows = len(ptr) - 1
+    out = np.zeros(rows + 1, dtype=np.uint32)
+    nb = lib().bicg_row_blocks(ptr.ctypes.data_as(_up), rows, chunk, max_rows, out.ctypes.data_as(_up))
+    return out[:nb + 1]

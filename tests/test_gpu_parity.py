@@ -1,0 +1,143 @@
+"""GPU parity tests (run with -m gpu on an MI355X): the HIP path, called through the C ABI of
+libbicgstab_hip.so, against (a) golden vectors produced by the REAL reference (tests/golden) and
+(b) the CPU oracle (oracle/liboracle.so) on seeded inputs.
+
+Bars (fp64 throughout):
+* SpMV rows and every element-wise phase keep the reference's operation order and rounding
+  (-ffp-contract=off, one thread sums a row in stored order): SpMV is compared BIT-EXACTLY.
+* Dot products are summed in a different association (wavefront shuffles) -> 1e-13 relative.
+* Solver scalars (alpha, omega, beta, (r,r)) over a short horizon (k <= 10): relative error
+  <= 1e-9 + 1e3 x the reference's own P=1 vs P=2 drift at that iteration (BiCGStab is chaotic on
+  the harder fixtures); end state: iteration count within +-2
+  of the reference for the non-stagnating solvers and |x - 1|_inf <= 1e-9 (manufactured solution
+  x* = 1, reference src/main.c:109-117).
+"""
+import glob
+import os
+
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from mpi_bicgstab_amd import hipsolver as H
+from mpi_bicgstab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = sorted(glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz")))
+SOLVERS = [("bicgstab", (0, 0)), ("ca_bicgstab", (0, 0)), ("pipe_bicgstab", (0, 0)), ("pipe_bicgstab_rr", (10, 3))]
+
+
+def _csr(g):
+    n = int(g["n"])
+    return synth.CSR(n, n, g["ptr"], g["col"], g["val"])
+
+
+@pytest.fixture(scope="module", autouse=True)
+def _single_rank():
+    H.lib().bicg_comm_init_single(0)
+    yield
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: os.path.basename(p)[:-4])
+def test_spmv_golden_bitexact(path):
+    g = np.load(path)
+    ctx = H.Context(H.single_rank_blocks(_csr(g)))
+    assert np.array_equal(ctx.spmv(g["spmv_x"]), g["spmv_y_P1"])
+    assert np.array_equal(ctx.spmv(np.ones(int(g["n"]))), g["b_P1"])
+    d = ctx.dot(g["b"], g["b"])
+    assert abs(d - float(g["dot_b_b"])) <= 1e-13 * abs(float(g["dot_b_b"]))
+    ctx.close()
+
+
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: os.path.basename(p)[:-4])
+@pytest.mark.parametrize("method,rr", SOLVERS, ids=[s for s, _ in SOLVERS])
+def test_solver_vs_golden(path, method, rr):
+    g = np.load(path)
+    A = _csr(g)
+    ctx = H.Context(H.single_rank_blocks(A))
+    ref_k = int(g[f"{method}_P1_k"])
+    res = ctx.solve(method, g["b_P1"], krr=rr[0], nrr=rr[1], record_trace=1)
+    # short-horizon scalars against the oracle's trace (the oracle is bit-identical to the reference)
+    row, col, val = A.to_coo()
+    orc = O.solve(method, A.rows, row, col, val, g["b_P1"], krr=rr[0], nrr=rr[1])
+    assert orc["k"] == ref_k
+    tr = ctx.trace(res["k"])
+    # BiCGStab trajectories are chaotic on the harder fixtures: the reference itself drifts with
+    # the rank count (summation order only). Per-iteration bar = 1e-9 + 1e3 x the reference's own
+    # P=1 vs P=2 drift so far; stop comparing once that bar would exceed 1e-4.
+    orc2 = O.solve(method, A.rows, row, col, val, g["b_P1"], nranks=2, krr=rr[0], nrr=rr[1])
+    h = min(10, res["k"], orc["k"], orc2["k"])
+    assert h >= 1, (res["k"], orc["k"], orc2["k"])
+    drift = np.zeros(h)
+    for key in ("alpha", "omega", "beta", "dotr"):
+        with np.errstate(divide="ignore", invalid="ignore"):
+            drift = np.maximum(drift, np.nan_to_num(np.abs(orc2[key][:h] / orc[key][:h] - 1.0), nan=0.0, posinf=1.0))
+    bar = 1e-9 + 1e3 * np.maximum.accumulate(drift)
+    for key in ("alpha", "omega", "beta", "dotr"):
+        for i in range(h):
+            if bar[i] > 1e-4:
+                break
+            assert abs(tr[key][i] - orc[key][i]) <= bar[i] * abs(orc[key][i]), (key, i, tr[key][i], orc[key][i], bar[i])
+    chaotic = ref_k >= 300        # hard fixture: the reference's own count moves by +-10 % with P
+    if method == "pipe_bicgstab":
+        # Without residual replacement the pipelined recurrence cannot reach the reference's
+        # EPS = 1e-15: the reference itself stagnates for 1000 iterations or breaks down to NaN
+        # depending on the rank count. Its end state is compared at an
+        # attainable tolerance instead, oracle and HIP path run with the same setting.
+        orc9 = O.solve(method, A.rows, row, col, val, g["b_P1"], tol=1e-9)
+        res9 = ctx.solve(method, g["b_P1"], tol=1e-9)
+        if not chaotic:
+            assert abs(res9["k"] - orc9["k"]) <= 2
+            assert np.abs(res9["x"] - 1.0).max() <= 1e-6
+    elif not chaotic:
+        assert abs(res["k"] - ref_k) <= 2
+        assert np.abs(res["x"] - 1.0).max() <= 1e-9
+        assert res["k"] == 1000 or np.sqrt(res["dot_r"] / res["dot_zero"]) <= 1e-15
+    else:
+        ref_err = np.abs(g[f"{method}_P1_x"] - 1.0).max()
+        assert np.isfinite(res["x"]).all()
+        assert np.abs(res["x"] - 1.0).max() <= max(100 * ref_err, 1e-9)
+    ctx.close()
+
+
+def test_spmv_ragged_vs_oracle():
+    """empty rows, rows longer than one 2048-entry chunk, single-entry rows"""
+    A = synth.random_rows(3000, 40, seed=11, empty_frac=0.15, long_rows={5: 2500, 1777: 2999, 2999: 2100})
+    x = np.random.default_rng(3).standard_normal(A.rows)
+    row, col, val = A.to_coo()
+    y_orc = O.spmv(A.rows, row, col, val, x)
+    ctx = H.Context(H.single_rank_blocks(A))
+    y = ctx.spmv(x)
+    lens = np.diff(A.ptr.astype(np.int64))
+    short = lens <= 2048
+    assert np.array_equal(y[short], y_orc[short])                 # sequential rows: bit-exact
+    scale = np.abs(A.val).max() * np.abs(x).max() * lens.max()
+    assert np.abs(y - y_orc).max() <= 1e-13 * scale               # long rows: re-associated
+    assert np.all(y[lens == 0] == 0.0)
+    ctx.close()
+
+
+def test_dot_vs_oracle():
+    rng = np.random.default_rng(5)
+    A = synth.banded(100003, 2)
+    ctx = H.Context(H.single_rank_blocks(A))
+    x, y = rng.standard_normal(A.rows), rng.standard_normal(A.rows)
+    ref = O.ddot(x, y)
+    assert abs(ctx.dot(x, y) - ref) <= 1e-12 * np.abs(x * y).sum()
+    ctx.close()
+
+
+def test_transport_shaped_medium():
+    """Transport-shaped offsets at 1/8 scale: plain BiCGStab end state vs the oracle."""
+    A = synth.transport_like(n=200_000)
+    b = A.matvec(np.ones(A.rows))
+    row, col, val = A.to_coo()
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert np.array_equal(ctx.spmv(np.ones(A.rows)), O.spmv(A.rows, row, col, val, np.ones(A.rows)))
+    for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab_rr"):
+        orc = O.solve(method, A.rows, row, col, val, b, krr=10, nrr=3)
+        res = ctx.solve(method, b, krr=10, nrr=3)
+        assert abs(res["k"] - orc["k"]) <= 2, method
+        assert np.abs(res["x"] - 1.0).max() <= 1e-9
+    ctx.close()
