@@ -1,0 +1,207 @@
+#!/usr/bin/env python3
+"""bench.py -- ms/iteration and achieved HBM GB/s of the BiCGStab hot path on MI355X.
+
+    python bench.py [--gpus N] [--steps K] [--warmup W] [--method bicgstab]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE solver iteration (2 SpMV + the fused vector phases + the dot groups). Workload =
+BASELINE.json configs[1]: plain BiCGStab on the Transport matrix on 1 GPU; Transport.mtx itself is
+not available offline, so the matrix is the Transport-SHAPED synthetic of SURVEY.md section 8d
+(n = 1 602 111, 15 diagonals, nnz = 23 921 209), symmetrically scaled over two decades so that the
+W+K timed iterations are genuine unconverged iterations (the real Transport needs ~2700). Right-hand
+side b = A*1, x0 = 0 (reference src/main.c:109-117). With N GPUs the SAME matrix is row-partitioned
+exactly like the reference does (src/matrix.c:295-308): strong scaling; halo exchange and packed
+dot all-reduces go over RCCL inside libbicgstab_hip.so, torch.distributed (gloo) is only the
+bootstrap and the timing barrier.
+
+Matrix and vectors are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+"""
+from __future__ import annotations
+
+import argparse
+import ctypes as C
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+import numpy as np  # noqa: E402
+
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured copy)
+
+
+def spmv_bytes(nnz, rows, halo=0):
+    """val + col + ptr + x read once + y written once (+ halo in/out)."""
+    return 12 * nnz + 4 * (rows + 1) + 8 * rows + 8 * rows + 16 * halo
+
+
+ITER_VECTOR_BYTES_PER_ROW = {"bicgstab": 120, "ca_bicgstab": 184, "pipe_bicgstab": 192, "pipe_bicgstab_rr": 192}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=200)
+    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--method", default="bicgstab", choices=list(ITER_VECTOR_BYTES_PER_ROW))
+    ap.add_argument("--n", type=int, default=0, help="rows (default: Transport's 1602111)")
+    ap.add_argument("--scale-decades", type=float, default=2.0)
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--cpu-iters", type=int, default=100)
+    a = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:
+        if rank == 0:
+            print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
+        if world == 1 and a.gpus > 1:
+            sys.exit(2)
+
+    import torch
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the HIP path)")
+    torch.cuda.set_device(local_rank)
+
+    from mpi_bicgstab_amd import hipsolver as H
+    from mpi_bicgstab_amd import synth
+    L = H.lib()
+
+    dist = None
+    if world > 1:
+        import torch.distributed as dist
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo", rank=rank, world_size=world)
+        ident = torch.zeros(H_UNIQUE, dtype=torch.uint8)
+        if rank == 0:
+            buf = (C.c_char * H_UNIQUE)()
+            L.bicg_comm_unique_id(buf)
+            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        dist.broadcast(ident, src=0)
+        raw = bytes(ident.numpy().tobytes())
+        L.bicg_comm_init_rccl(rank, world, raw, local_rank)
+    else:
+        L.bicg_comm_init_single(local_rank)
+
+    def barrier():
+        if dist is not None:
+            dist.barrier()
+
+    # ---- workload: this rank's row slab of the global matrix
+    n = a.n or synth.TRANSPORT_N
+    counts, displs = synth.partition(n, world)
+    lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+    slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
+    diag, offd = synth.split_row_slab(slab, lo)
+    nnz_global = synth.transport_nnz(n)
+    blocks = H.HostBlocks(diag, offd if world > 1 else None, n, counts, displs)
+    ctx = H.Context(blocks)
+    plan = ctx.plan_info()
+    ones = np.ones(hi - lo)
+    b = ctx.spmv(ones)                       # b = A*1 (reference src/main.c:109-113), collective
+    x0 = np.zeros(hi - lo)
+
+    K, W = a.steps, a.warmup
+
+    def timed_run(method, kernel_events):
+        ctx.load(x0, b)
+        ctx.run_begin(method, tol=0.0, max_iter=W + K, check_every=max(W, K, 1), krr=50, nrr=2,
+                      time_kernels=1 if kernel_events else 0)
+        if W:
+            ctx.run_iterate(W)
+        barrier(); ctx.sync(); torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        ctx.run_iterate(K)
+        ctx.sync(); torch.cuda.synchronize(); barrier()
+        dt = time.perf_counter() - t0
+        res = ctx.run_end()
+        if dist is not None:
+            t = torch.tensor([dt], dtype=torch.float64)
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            dt = float(t[0])
+        return dt, res
+
+    # main timed region: exactly K iterations, no per-kernel instrumentation
+    dt, res = timed_run(a.method, kernel_events=False)
+    ms_step = 1e3 * dt / K
+    relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
+    genuine = res.iterations == W + K and np.isfinite(relres)
+
+    # roofline leg: the same K iterations with every SpMV bracketed by HIP events on the compute stream
+    dt_ev, res_ev = timed_run(a.method, kernel_events=True)
+    spmv_ms = res_ev.spmv_ms_total / max(res_ev.spmv_launches, 1)
+    b_spmv = spmv_bytes(plan["nnz_diag"] + plan["nnz_offd"], plan["rows"], plan["halo"])
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    traffic = None
+    pmc = os.path.join(ROOT, "profiles", "pmc_spmv.json")
+    if os.path.exists(pmc):
+        try:
+            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
+        except Exception:
+            traffic = None
+
+    variants = {}
+    if not a.no_variants:
+        for m in ITER_VECTOR_BYTES_PER_ROW:
+            if m == a.method:
+                variants[m] = ms_step
+                continue
+            dtv, resv = timed_run(m, kernel_events=False)
+            variants[m] = 1e3 * dtv / K
+    spmv_alone_ms = ctx.spmv_bench(200)
+
+    cpu = None
+    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+        try:
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--n", str(n),
+                                  "--scale-decades", str(a.scale_decades), "--iters", str(a.cpu_iters),
+                                  "--method", a.method], capture_output=True, text=True, timeout=900)
+            cpu = json.loads(out.stdout.strip().splitlines()[-1])
+        except Exception as e:  # the baseline is reported, never required
+            cpu = {"error": repr(e)}
+
+    if rank == 0:
+        iter_bytes = 2 * spmv_bytes(nnz_global, n) + ITER_VECTOR_BYTES_PER_ROW[a.method] * n
+        line = {
+            "metric": f"ms/iteration, {a.method}, Transport-shaped CSR ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
+            "value": ms_step, "unit": "ms/iteration", "n_gpus": world, "steps": K, "warmup": W,
+            "ms_per_step": ms_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
+            "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "BASELINE.json configs[1]: plain BiCGStab, Transport-shaped synthetic "
+                                   "(Transport.mtx unavailable offline), b = A*1, x0 = 0",
+                       "rows": n, "nnz": nnz_global, "scale_decades": a.scale_decades, "method": a.method,
+                       "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
+                       "transport": "rccl" if world > 1 else "none",
+                       "iterations_genuine": bool(genuine), "relres_after_timed_region": relres},
+            "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,
+            "iteration_algorithmic_bytes": iter_bytes,
+            "roofline": {"kernel": "k_spmv (row-block-stream CSR SpMV), rank 0 share", "bound": "hbm",
+                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                         "traffic": traffic, "algorithmic_bytes_per_launch": b_spmv,
+                         "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,
+                         "ms_per_step_with_events": 1e3 * dt_ev / K,
+                         "back_to_back_spmv_ms": spmv_alone_ms,
+                         "frac_of_measured_copy_6290": achieved / 6290.0},
+            "cpu_baseline": cpu,
+            "variants_ms_per_iteration": variants,
+        }
+        print(json.dumps(line), flush=True)
+
+    ctx.close()
+    if dist is not None:
+        dist.barrier()
+        L.bicg_comm_finalize()
+        dist.destroy_process_group()
+
+
+H_UNIQUE = 128
+
+if __name__ == "__main__":
+    main()

@@ -100,6 +100,8 @@ int bicg_comm_init_host(int rank, int nranks, bicg_allreduce_fn allreduce, bicg_
 int bicg_comm_init_mpi(const char *transport, int device);
 int bicg_comm_init_single(int device);
 void bicg_comm_finalize(void);
+/* one-rank RCCL round trip (library load, communicator, all-reduce); 0 = ok. Needs a GPU. */
+int bicg_comm_selftest_rccl(int device);
 int bicg_comm_rank(void);
 int bicg_comm_size(void);
 
@@ -146,6 +148,15 @@ int bicg_solve(bicg_ctx *ctx, int method, double *x_loc, double *r_loc, const bi
 int bicg_load(bicg_ctx *ctx, const double *x0_loc, const double *b_loc);
 int bicg_run(bicg_ctx *ctx, int method, const bicg_options *opt, bicg_result *res);
 int bicg_fetch(bicg_ctx *ctx, double *x_loc, double *r_loc);
+/* The same solve in three steps (benchmarks time exactly K iterations this way):
+ *   begin   = the reference's set-up phase (src/solver.c:74-83, 200-213, 333-348), synchronised
+ *   iterate = up to nsteps further passes of its while loop (stops early on convergence or
+ *             max_iter); returns k so far; synchronised on return
+ *   end     = summary lines (src/solver.c:134-141) and result */
+int bicg_run_begin(bicg_ctx *ctx, int method, const bicg_options *opt);
+int bicg_run_iterate(bicg_ctx *ctx, int nsteps);
+int bicg_run_end(bicg_ctx *ctx, bicg_result *res);
+int bicg_sync(bicg_ctx *ctx);
 /* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */
 int bicg_trace(bicg_ctx *ctx, double *alpha, double *omega, double *beta, double *dot_r);
 
@@ -174,6 +185,17 @@ void bicg_partition(unsigned int n, int nranks, int *counts, int *displs);
  *   renumbered[offd->nz]             offd->col mapped to local_rows + halo position */
 int bicg_halo_plan(const CSR_Matrix *offd, const INFO_Matrix *info, int nranks, unsigned int local_rows,
                    unsigned int *halo_cols, int *recv_counts, unsigned int *renumbered);
+/* Collective (through the caller's alltoallv): the SEND side of the halo exchange, in two steps.
+ * Given this rank's halo_cols/recv_counts from bicg_halo_plan:
+ *   bicg_halo_send_counts fills send_counts[nranks] (how many of OUR rows each rank needs) and
+ *                         returns their sum;
+ *   bicg_halo_send_lists  fills send_idx[sum] with the local row indices, grouped by destination
+ *                         rank; returns the sum, or -1 if a peer asked for a row we do not own. */
+int bicg_halo_send_counts(int nranks, const int *recv_counts, bicg_alltoallv_fn alltoallv, void *user,
+                          int *send_counts);
+int bicg_halo_send_lists(int rank, int nranks, const INFO_Matrix *info, unsigned int local_rows,
+                         const unsigned int *halo_cols, const int *recv_counts, const int *send_counts,
+                         bicg_alltoallv_fn alltoallv, void *user, unsigned int *send_idx);
 /* greedy row blocks of at most chunk non-zeros (whole rows); returns the number of blocks and fills
  * rowblk[nblk+1] (caller provides rows+1 entries) */
 unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int rows, unsigned int chunk,

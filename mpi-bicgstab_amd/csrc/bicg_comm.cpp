@@ -299,6 +299,32 @@ int bicg_comm_init_mpi(const char *transport, int device)
     return 0;
 }
 
+// One-rank RCCL round trip on the current device: dlopen + symbol resolution, the by-value
+// ncclUniqueId ABI, communicator creation, an in-place fp64 all-reduce and a grouped (empty)
+// exchange on a non-default stream. Returns 0 when the reduced values come back unchanged.
+int bicg_comm_selftest_rccl(int device)
+{
+    char id[BICG_UNIQUE_ID_BYTES];
+    rccl_unique_id(id);
+    Comm *c = make_rccl(0, 1, id, device);
+    hipStream_t st;
+    BICG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
+    double h[5] = {1.5, -2.0, 3.25, 0.0, 1e300}, back[5] = {0, 0, 0, 0, 0};
+    double *d = nullptr;
+    BICG_HIP(hipMalloc((void **)&d, sizeof h));
+    BICG_HIP(hipMemcpy(d, h, sizeof h, hipMemcpyHostToDevice));
+    c->allreduce_sum(d, 5, st);
+    int zero = 0;
+    c->exchange(d, &zero, &zero, d, &zero, &zero, st);
+    BICG_HIP(hipStreamSynchronize(st));
+    BICG_HIP(hipMemcpy(back, d, sizeof h, hipMemcpyDeviceToHost));
+    BICG_HIP(hipFree(d));
+    BICG_HIP(hipStreamDestroy(st));
+    delete c;
+    for (int i = 0; i < 5; ++i) if (back[i] != h[i]) return 1 + i;
+    return 0;
+}
+
 void bicg_comm_finalize(void) { comm_set(nullptr); }
 int bicg_comm_rank(void) { return comm_get()->rank; }
 int bicg_comm_size(void) { return comm_get()->nranks; }

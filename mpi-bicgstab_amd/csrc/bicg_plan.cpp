@@ -43,6 +43,44 @@ extern "C" int bicg_halo_plan(const CSR_Matrix *offd, const INFO_Matrix *info, i
     return h;
 }
 
+// Collective, in two steps so that every rank can size its buffers between them: each rank learns
+// which of ITS rows the other ranks need (the send side of the halo exchange) by sending every
+// owner first the count, then the list, of the global columns it wants from it. Both steps are
+// personalised exchanges through the caller's alltoallv (counts/displacements in bytes).
+extern "C" int bicg_halo_send_counts(int nranks, const int *recv_counts, bicg_alltoallv_fn a2a, void *user,
+                                     int *send_counts)
+{
+    const int P = nranks;
+    std::vector<int> one(P, (int)sizeof(int)), off(P);
+    for (int p = 0; p < P; ++p) off[p] = p * (int)sizeof(int);
+    a2a(recv_counts, one.data(), off.data(), send_counts, one.data(), off.data(), user);
+    int total = 0;
+    for (int p = 0; p < P; ++p) total += send_counts[p];
+    return total;
+}
+
+extern "C" int bicg_halo_send_lists(int rank, int nranks, const INFO_Matrix *info, unsigned int local_rows,
+                                    const unsigned int *halo_cols, const int *recv_counts, const int *send_counts,
+                                    bicg_alltoallv_fn a2a, void *user, unsigned int *send_idx)
+{
+    const int P = nranks;
+    std::vector<int> sb(P), sd(P), rb(P), rd(P);
+    int racc = 0, sacc = 0;
+    for (int p = 0; p < P; ++p) {
+        sb[p] = recv_counts[p] * 4; sd[p] = racc * 4; racc += recv_counts[p];   // we send the lists we want values for
+        rb[p] = send_counts[p] * 4; rd[p] = sacc * 4; sacc += send_counts[p];
+    }
+    uint32_t none = 0;
+    a2a(racc ? (const void *)halo_cols : (const void *)&none, sb.data(), sd.data(),
+        sacc ? (void *)send_idx : (void *)&none, rb.data(), rd.data(), user);
+    const uint32_t lo = (uint32_t)info->displs[rank];
+    for (int i = 0; i < sacc; ++i) {
+        if (send_idx[i] < lo || send_idx[i] - lo >= local_rows) return -1;   // request outside our rows
+        send_idx[i] -= lo;
+    }
+    return sacc;
+}
+
 extern "C" unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int rows, unsigned int chunk,
                                         unsigned int max_rows, unsigned int *rowblk)
 {

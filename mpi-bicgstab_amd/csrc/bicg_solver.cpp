@@ -84,6 +84,11 @@ struct bicg_ctx {
     int pend_n = 0, pend_phase = 0;
     hipEvent_t pend_ev = nullptr;
 
+    // state of the solve in progress (run_begin / run_iterate / run_end)
+    bicg_options opt{};
+    int method = 0, it = 0, printed = 0;
+    double t_begin = 0.0, t_init = 0.0, t_iter = 0.0;
+
     // per-SpMV timing
     bool time_kernels = false;
     std::vector<hipEvent_t> tev;
@@ -310,13 +315,17 @@ void fetch_scal(bicg_ctx *c)
     if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
 }
 
-int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result *res)
+// A solve in three steps so that callers (and bench.py) can time exactly K iterations:
+// run_begin = set-up phase of the reference (src/solver.c:74-83 etc.), run_iterate = up to n more
+// iterations of its while loop, run_end = summary lines and result.
+void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
 {
-    bicg_options o;
+    bicg_options &o = c->opt;
     if (opt_in) o = *opt_in; else bicg_default_options(&o);
     if (method < BICG_BICGSTAB || method > BICG_PIPE_BICGSTAB_RR) die("bicg_run", "unknown method");
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.check_every < 1) o.check_every = 1;
+    c->method = method;
     BICG_HIP(hipSetDevice(c->comm->device));
 
     // trace storage: the (r,r) history is always kept (progress lines), 4 arrays of max_iter
@@ -347,35 +356,47 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
     }
     BICG_HIP(hipStreamSynchronize(c->sc));
 
+    c->it = 0; c->printed = 0; c->t_iter = 0.0;
+    c->t_begin = now_sec();
     Driver d(c, method, o.krr, o.nrr);
-    const bool talk = c->rank == 0 && !o.quiet;
-
-    const double t0 = now_sec();
     d.init();
     fetch_scal(c);
-    const double t1 = now_sec();
+    c->t_init = now_sec() - c->t_begin;
+}
 
-    int it = 0, printed = 0;
-    std::vector<double> hist;
-    while (!c->hS->done && it < o.max_iter) {
-        const int chunk = std::min(o.check_every, o.max_iter - it);
-        for (int j = 0; j < chunk; ++j) d.iterate(it + j);
-        it += chunk;
+int run_iterate(bicg_ctx *c, int nsteps)
+{
+    const bicg_options &o = c->opt;
+    BICG_HIP(hipSetDevice(c->comm->device));
+    Driver d(c, c->method, o.krr, o.nrr);
+    const bool talk = c->rank == 0 && !o.quiet;
+    const double t0 = now_sec();
+    const int stop = std::min(o.max_iter, c->it + std::max(nsteps, 0));
+    while (!c->hS->done && c->it < stop) {
+        const int chunk = std::min(o.check_every, stop - c->it);
+        for (int j = 0; j < chunk; ++j) d.iterate(c->it + j);
+        c->it += chunk;
         fetch_scal(c);
         if (talk && o.out_iter > 0) {   // reference src/solver.c:122-126
             const int k = c->hS->k;
             const int upto = (k / o.out_iter) * o.out_iter;
-            if (upto > printed) {
-                hist.resize(k);
-                BICG_HIP(hipMemcpy(hist.data(), h.tr_dotr, sizeof(double) * k, hipMemcpyDeviceToHost));
-                for (int q = printed + o.out_iter; q <= upto; q += o.out_iter)
+            if (upto > c->printed) {
+                std::vector<double> hist(k);
+                BICG_HIP(hipMemcpy(hist.data(), c->trace + 3 * (size_t)c->trace_cap, sizeof(double) * k, hipMemcpyDeviceToHost));
+                for (int q = c->printed + o.out_iter; q <= upto; q += o.out_iter)
                     printf("Iteration: %d, Residual: %e\n", q, sqrt(hist[q - 1] / c->hS->dot_zero));
-                printed = upto;
+                c->printed = upto;
             }
         }
     }
-    const double t2 = now_sec();
+    c->t_iter += now_sec() - t0;
+    return c->hS->k;
+}
 
+int run_end(bicg_ctx *c, bicg_result *res)
+{
+    const bicg_options &o = c->opt;
+    const bool talk = c->rank == 0 && !o.quiet;
     const int k = c->hS->k;
     c->last_iters = k;
     double spmv_ms = 0.0;
@@ -386,23 +407,31 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
             if (hipEventElapsedTime(&ms, c->tev[i], c->tev[i + 1]) == hipSuccess) { spmv_ms += ms; ++spmv_n; }
         }
     }
+    const double total = c->t_init + c->t_iter;
     if (res) {
         res->iterations = k;
         res->dot_r = c->hS->dot_r;
         res->dot_zero = c->hS->dot_zero;
-        res->seconds = t2 - t0;
-        res->iter_seconds = t2 - t1;
+        res->seconds = total;
+        res->iter_seconds = c->t_iter;
         res->spmv_ms_total = spmv_ms;
         res->spmv_launches = spmv_n;
     }
     if (talk) {   // reference src/solver.c:134-141, verbatim
         printf("Total iter   : %d\n", k);
         printf("Final r      : %e\n", sqrt(c->hS->dot_r / c->hS->dot_zero));
-        printf("Total time   : %e [sec.] \n", t2 - t0);
-        printf("Avg time/iter: %e [sec.] \n", (t2 - t0) / k);
+        printf("Total time   : %e [sec.] \n", total);
+        printf("Avg time/iter: %e [sec.] \n", total / k);
         fflush(stdout);
     }
     return k;
+}
+
+int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result *res)
+{
+    run_begin(c, method, opt_in);
+    run_iterate(c, c->opt.max_iter);
+    return run_end(c, res);
 }
 
 void check_square(const INFO_Matrix *info)
@@ -485,25 +514,17 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         optr.assign(offd->ptr, offd->ptr + c->n_loc + 1);
         oval.assign(offd->val, offd->val + c->nnz_o);
         for (int p = 1; p < P; ++p) c->rdsp[p] = c->rdsp[p - 1] + c->rcnt[p - 1];
-        // tell every owner how many / which of its rows we need
-        std::vector<int> one(P, (int)sizeof(int)), off(P), need_from_me(P, 0);
-        for (int p = 0; p < P; ++p) off[p] = p * (int)sizeof(int);
-        comm->alltoallv_host(c->rcnt.data(), one.data(), off.data(), need_from_me.data(), one.data(), off.data());
-        c->scnt = need_from_me;
+        // tell every owner which of its rows we need; learn which of ours the others need
+        auto tramp = [](const void *sbuf, const int *sc, const int *sd, void *rbuf, const int *rc, const int *rd, void *user) {
+            static_cast<Comm *>(user)->alltoallv_host(sbuf, sc, sd, rbuf, rc, rd);
+        };
+        const int total = bicg_halo_send_counts(P, c->rcnt.data(), tramp, comm, c->scnt.data());
+        send_idx.resize(total > 0 ? total : 1);
+        const int got = bicg_halo_send_lists(c->rank, P, info, c->n_loc, halo_cols.data(), c->rcnt.data(), c->scnt.data(),
+                                             tramp, comm, send_idx.data());
+        if (got < 0) die("bicg_create", "halo request outside the owner's rows");
+        c->nsend = (uint32_t)got;
         for (int p = 1; p < P; ++p) c->sdsp[p] = c->sdsp[p - 1] + c->scnt[p - 1];
-        c->nsend = (uint32_t)(c->sdsp[P - 1] + c->scnt[P - 1]);
-        std::vector<int> sb(P), sd(P), rb(P), rd(P);
-        for (int p = 0; p < P; ++p) {
-            sb[p] = c->rcnt[p] * 4; sd[p] = c->rdsp[p] * 4;     // we SEND the index lists we want to receive values for
-            rb[p] = c->scnt[p] * 4; rd[p] = c->sdsp[p] * 4;
-        }
-        send_idx.resize(c->nsend ? c->nsend : 1);
-        comm->alltoallv_host(halo_cols.data(), sb.data(), sd.data(), send_idx.data(), rb.data(), rd.data());
-        const uint32_t lo = (uint32_t)info->displs[c->rank];
-        for (uint32_t i = 0; i < c->nsend; ++i) {
-            if (send_idx[i] < lo || send_idx[i] - lo >= c->n_loc) die("bicg_create", "halo request outside the owner's rows");
-            send_idx[i] -= lo;
-        }
     }
 
     // ---- interior / boundary row blocks
@@ -594,6 +615,16 @@ int bicg_fetch(bicg_ctx *c, double *x, double *r)
 }
 
 int bicg_run(bicg_ctx *c, int method, const bicg_options *opt, bicg_result *res) { return run_solver(c, method, opt, res); }
+int bicg_run_begin(bicg_ctx *c, int method, const bicg_options *opt) { run_begin(c, method, opt); return 0; }
+int bicg_run_iterate(bicg_ctx *c, int nsteps) { return run_iterate(c, nsteps); }
+int bicg_run_end(bicg_ctx *c, bicg_result *res) { return run_end(c, res); }
+int bicg_sync(bicg_ctx *c)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    BICG_HIP(hipStreamSynchronize(c->sc));
+    if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
+    return 0;
+}
 
 int bicg_solve(bicg_ctx *c, int method, double *x, double *r, const bicg_options *opt, bicg_result *res)
 {

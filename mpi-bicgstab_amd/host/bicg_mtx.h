@@ -1,0 +1,20 @@
+/*
+ * bicg_mtx.h -- Matrix-Market block loader of the C host.
+ *
+ * Produces what MPI_csr_load_matrix_block produces (reference src/matrix.c:402-419): per rank the
+ * diag block (local columns) and the offd block (global columns) in CSR, entries of a row in FILE
+ * order (the reference's stable row sort, src/matrix.c:135-183), and the equal-rows partition of
+ * src/matrix.c:295-308. Unlike the reference it reads and tokenises the file ONCE per rank
+ * (the reference fscanf()s it twice, src/matrix.c:315-341 and 357-393).
+ */
+#ifndef BICG_MTX_H
+#define BICG_MTX_H
+
+#include "bicgstab_hip.h"
+
+/* Returns 0 on success; on failure prints to stderr and returns non-zero.
+ * Arrays inside diag/offd/info are malloc'ed; release with bicg_mtx_free. */
+int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+void bicg_mtx_free(CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+
+#endif

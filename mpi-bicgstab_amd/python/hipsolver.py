@@ -49,10 +49,10 @@ ALLTOALLV_FN = C.CFUNCTYPE(None, C.c_void_p, _ip, _ip, C.c_void_p, _ip, _ip, C.c
 EXPORTS = [
     "bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
-    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_rank", "bicg_comm_size",
+    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info",
-    "bicg_partition", "bicg_halo_plan", "bicg_row_blocks", "bicg_version",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info",
+    "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_version",
 ]
 
 _lib = None
@@ -70,6 +70,10 @@ def lib():
         L.bicg_destroy.argtypes = [C.c_void_p]
         L.bicg_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(Options), C.POINTER(Result)]
         L.bicg_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Result)]
+        L.bicg_run_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
+        L.bicg_run_iterate.argtypes = [C.c_void_p, C.c_int]
+        L.bicg_run_end.argtypes = [C.c_void_p, C.POINTER(Result)]
+        L.bicg_sync.argtypes = [C.c_void_p]
         L.bicg_load.argtypes = [C.c_void_p, _dp, _dp]
         L.bicg_fetch.argtypes = [C.c_void_p, _dp, _dp]
         L.bicg_trace.argtypes = [C.c_void_p, _dp, _dp, _dp, _dp]
@@ -86,6 +90,9 @@ def lib():
         L.bicg_comm_init_mpi.argtypes = [C.c_char_p, C.c_int]
         L.bicg_partition.argtypes = [C.c_uint, C.c_int, _ip, _ip]
         L.bicg_halo_plan.argtypes = [C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), C.c_int, C.c_uint, _up, _ip, _up]
+        L.bicg_halo_send_counts.argtypes = [C.c_int, _ip, ALLTOALLV_FN, C.c_void_p, _ip]
+        L.bicg_halo_send_lists.argtypes = [C.c_int, C.c_int, C.POINTER(InfoMatrix), C.c_uint, _up, _ip, _ip, ALLTOALLV_FN,
+                                           C.c_void_p, _up]
         L.bicg_row_blocks.argtypes = [_up, C.c_uint, C.c_uint, C.c_uint, _up]
         L.bicg_row_blocks.restype = C.c_uint
         L.bicg_version.restype = C.c_char_p
@@ -182,6 +189,22 @@ class Context:
         res = Result()
         lib().bicg_run(self.h, METHODS[method], C.byref(o), C.byref(res))
         return res
+
+    def run_begin(self, method: str, **kw):
+        kw.setdefault("quiet", 1)
+        self._opt = self.options(**kw)
+        lib().bicg_run_begin(self.h, METHODS[method], C.byref(self._opt))
+
+    def run_iterate(self, nsteps: int) -> int:
+        return lib().bicg_run_iterate(self.h, nsteps)
+
+    def run_end(self) -> Result:
+        res = Result()
+        lib().bicg_run_end(self.h, C.byref(res))
+        return res
+
+    def sync(self):
+        lib().bicg_sync(self.h)
 
     def fetch(self):
         x, r = np.zeros(self.n), np.zeros(self.n)

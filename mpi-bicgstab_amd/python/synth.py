@@ -63,29 +63,66 @@ def _uniform(idx: np.ndarray, seed: int) -> np.ndarray:
     return (z >> np.uint64(11)).astype(np.float64) * (1.0 / (1 << 53))
 
 
-def from_offsets(n: int, offsets, diag_base: float = 16.0, seed: int = 12345) -> CSR:
+def row_scale(idx: np.ndarray, decades: float, seed: int = 99) -> np.ndarray:
+    """d_i = 10^(decades * (U_i - 0.5)): the symmetric diagonal scaling D A D used to make the
+    synthetic systems as badly scaled as real FEM matrices (Transport.mtx needs ~2700 BiCGStab
+    iterations, reference README.md:44-45; the unscaled synthetic converges in ~20)."""
+    return 10.0 ** (decades * (_uniform(idx.astype(np.int64) + 7_000_000_000, seed) - 0.5))
+
+
+def from_offsets(n: int, offsets, diag_base: float = 16.0, seed: int = 12345, rows=None,
+                 scale_decades: float = 0.0) -> CSR:
     """Rows hold one entry per offset (clipped to [0, n)), ascending column order.
 
     diagonal = diag_base + U[0,1); off-diagonal = -(0.5 + 0.5 U[0,1)).  diag_base = 16 is the
     strongly dominant law of SURVEY.md section 8d; smaller values give harder systems.
+    rows=(lo, hi) builds only that row range of the same global matrix (GLOBAL columns, cols = n).
+    scale_decades > 0 applies A <- D A D with D = row_scale (harder, same sparsity pattern).
     """
     offs = np.array(sorted(offsets), dtype=np.int64)
     k = len(offs)
-    rows = np.arange(n, dtype=np.int64)
+    lo, hi = (0, n) if rows is None else rows
+    rows = np.arange(lo, hi, dtype=np.int64)
     cols = rows[:, None] + offs[None, :]                     # [n, k]
     ok = (cols >= 0) & (cols < n)
     counts = ok.sum(axis=1)
-    ptr = np.zeros(n + 1, dtype=np.int64)
+    ptr = np.zeros(hi - lo + 1, dtype=np.int64)
     np.cumsum(counts, out=ptr[1:])
     eid = rows[:, None] * k + np.arange(k, dtype=np.int64)[None, :]
     u = _uniform(eid[ok], seed)
     is_diag = np.broadcast_to(offs[None, :] == 0, cols.shape)[ok]
     val = np.where(is_diag, diag_base + u, -(0.5 + 0.5 * u))
-    return CSR(n, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), val)
+    if scale_decades > 0.0:
+        rid = np.broadcast_to(rows[:, None], cols.shape)[ok]
+        val = val * row_scale(rid, scale_decades) * row_scale(cols[ok], scale_decades)
+    return CSR(hi - lo, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), val)
 
 
-def transport_like(n: int = TRANSPORT_N, diag_base: float = 16.0, seed: int = 12345) -> CSR:
-    return from_offsets(n, TRANSPORT_OFFSETS, diag_base, seed)
+def transport_like(n: int = TRANSPORT_N, diag_base: float = 16.0, seed: int = 12345, rows=None,
+                   scale_decades: float = 0.0) -> CSR:
+    return from_offsets(n, TRANSPORT_OFFSETS, diag_base, seed, rows, scale_decades)
+
+
+def transport_nnz(n: int = TRANSPORT_N) -> int:
+    """non-zeros of transport_like(n) without building it"""
+    return sum(max(n - abs(o), 0) for o in TRANSPORT_OFFSETS)
+
+
+def split_row_slab(slab: CSR, lo: int):
+    """diag/offd blocks of a row slab that starts at global row `lo` (slab has GLOBAL columns):
+    what MPI_coo_load_matrix_block gives one rank (reference src/matrix.c:336-340, 380-392)."""
+    hi = lo + slab.rows
+    ptr = slab.ptr.astype(np.int64)
+    col = slab.col.astype(np.int64)
+    rowid = np.repeat(np.arange(slab.rows), np.diff(ptr))
+    local = (col >= lo) & (col < hi)
+
+    def build(mask, ncols, shift):
+        p = np.zeros(slab.rows + 1, dtype=np.int64)
+        np.cumsum(np.bincount(rowid[mask], minlength=slab.rows), out=p[1:])
+        return CSR(slab.rows, ncols, p.astype(np.uint32), (col[mask] - shift).astype(np.uint32), slab.val[mask].copy())
+
+    return build(local, slab.rows, lo), build(~local, slab.cols, 0)
 
 
 def banded(n: int, half_bw: int, diag_base: float | None = None, seed: int = 777) -> CSR:

@@ -1,0 +1,135 @@
+"""Worker functions for the world_size-2 tests (spawned processes, gloo rendezvous on 127.0.0.1)."""
+from __future__ import annotations
+
+import os
+import sys
+import traceback
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def _init(rank, world, port):
+    import torch.distributed as dist
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    return dist
+
+
+def test_matrix(kind):
+    from mpi_bicgstab_amd import synth
+    if kind == "offsets":
+        return synth.from_offsets(4001, (0, 1, -1, 7, -7, 300, -300, 1999, -1999), diag_base=12.0, seed=3)
+    if kind == "stencil":
+        return synth.stencil7(14)
+    if kind == "ragged":
+        return synth.random_rows(900, 9, seed=21, empty_frac=0.05, long_rows={40: 700})
+    raise ValueError(kind)
+
+
+def plan_worker(rank, world, port, kind, outdir):
+    """CPU only: halo plan + send lists through the library's host code and gloo callbacks, then a
+    numpy emulation of the halo SpMV compared with the oracle's distributed SpMV."""
+    try:
+        import ctypes as C
+        import numpy as np
+        dist = _init(rank, world, port)
+        import oracle_lib as O
+        from mpi_bicgstab_amd import hipsolver as H, synth
+        from mpi_bicgstab_amd import dist_transport as T
+
+        A = test_matrix(kind)
+        diag, offd, counts, displs = synth.split_blocks(A, world, rank)
+        blk = H.HostBlocks(diag, offd, A.rows, counts, displs)
+        h, halo_cols, rc, ren = H.halo_plan(blk, world)
+        ar, a2a = T.callbacks()
+        L = H.lib()
+        sc = np.zeros(world, dtype=np.int32)
+        ip = C.POINTER(C.c_int)
+        up = C.POINTER(C.c_uint)
+        hc = np.ascontiguousarray(halo_cols if h else np.zeros(1, dtype=np.uint32))
+        total = L.bicg_halo_send_counts(world, rc.ctypes.data_as(ip), a2a, None, sc.ctypes.data_as(ip))
+        send_idx = np.zeros(max(total, 1), dtype=np.uint32)
+        got = L.bicg_halo_send_lists(rank, world, C.byref(blk.info), blk.n_loc, hc.ctypes.data_as(up),
+                                     rc.ctypes.data_as(ip), sc.ctypes.data_as(ip), a2a, None, send_idx.ctypes.data_as(up))
+        assert got == total >= 0
+        assert rc[rank] == 0 and sc[rank] == 0            # own columns never travel
+        # value exchange with the same callback the library would use (counts in bytes)
+        x = np.random.default_rng(1234).standard_normal(A.rows)
+        lo = int(displs[rank])
+        x_loc = x[lo:lo + blk.n_loc]
+        sendbuf = np.ascontiguousarray(x_loc[send_idx[:total]])
+        recvbuf = np.zeros(max(h, 1))
+        sdsp = np.concatenate(([0], np.cumsum(sc)[:-1])).astype(np.int32)
+        rdsp = np.concatenate(([0], np.cumsum(rc)[:-1])).astype(np.int32)
+        i32 = lambda a: np.ascontiguousarray(a, dtype=np.int32)
+        a2a(sendbuf.ctypes.data, i32(sc * 8).ctypes.data_as(ip), i32(sdsp * 8).ctypes.data_as(ip),
+            recvbuf.ctypes.data, i32(rc * 8).ctypes.data_as(ip), i32(rdsp * 8).ctypes.data_as(ip), None)
+        assert np.array_equal(recvbuf[:h], x[halo_cols])   # the halo holds exactly the requested entries
+        x_ext = np.concatenate((x_loc, recvbuf[:h]))
+        off_r = synth.CSR(offd.rows, blk.n_loc + h, offd.ptr, ren.astype(np.uint32) if offd.nnz else offd.col, offd.val)
+        y = diag.matvec(x_loc) + (off_r.matvec(x_ext) if offd.nnz else 0.0)
+        row, col, val = A.to_coo()
+        y_orc = O.spmv(A.rows, row, col, val, x, nranks=world)[lo:lo + blk.n_loc]
+        scale = np.abs(A.val).max() * np.abs(x).max() * 64
+        assert np.abs(y - y_orc).max() <= 1e-13 * scale
+        # packed all-reduce callback
+        v = np.arange(5, dtype=np.float64) + rank
+        ar(v.ctypes.data_as(C.POINTER(C.c_double)), 5, None)
+        assert np.array_equal(v, world * np.arange(5) + sum(range(world)))
+        dist.barrier()
+        dist.destroy_process_group()
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    except Exception:
+        open(os.path.join(outdir, f"fail{rank}"), "w").write(traceback.format_exc())
+        raise
+
+
+def gpu_worker(rank, world, port, kind, outdir):
+    """GPU box: `world` ranks share cuda:0 through the host-staged transport; the full multi-rank
+    path (halo plan, interior/boundary SpMV, packed dot groups, all four solvers) vs the oracle."""
+    try:
+        import numpy as np
+        dist = _init(rank, world, port)
+        import oracle_lib as O
+        from mpi_bicgstab_amd import hipsolver as H, synth
+        from mpi_bicgstab_amd import dist_transport as T
+
+        T.init_host_transport(0)
+        A = test_matrix(kind)
+        diag, offd, counts, displs = synth.split_blocks(A, world, rank)
+        lo, nl = int(displs[rank]), int(counts[rank])
+        ctx = H.Context(H.HostBlocks(diag, offd, A.rows, counts, displs))
+        info = ctx.plan_info()
+        assert info["halo"] > 0 and info["boundary_blocks"] > 0
+        row, col, val = A.to_coo()
+        x = np.random.default_rng(99).standard_normal(A.rows)
+        y = ctx.spmv(x[lo:lo + nl])
+        y_orc = O.spmv(A.rows, row, col, val, x, nranks=world)[lo:lo + nl]
+        lens = np.diff(A.ptr.astype(np.int64))[lo:lo + nl]
+        assert np.array_equal(y[lens <= 2048], y_orc[lens <= 2048]), "distributed SpMV is not bit-exact"
+        d = ctx.dot(x[lo:lo + nl], y_orc)
+        d_ref = float(np.dot(x, O.spmv(A.rows, row, col, val, x, nranks=world)))
+        assert abs(d - d_ref) <= 1e-11 * abs(d_ref) + 1e-9
+        b_full = O.spmv(A.rows, row, col, val, np.ones(A.rows), nranks=world)
+        b = ctx.spmv(np.ones(nl))
+        assert np.array_equal(b, b_full[lo:lo + nl])
+        for method, tol in (("bicgstab", 1e-15), ("ca_bicgstab", 1e-15), ("pipe_bicgstab", 1e-9), ("pipe_bicgstab_rr", 1e-15)):
+            orc = O.solve(method, A.rows, row, col, val, b_full, nranks=world, tol=tol, krr=10, nrr=3)
+            got = ctx.solve(method, b, tol=tol, krr=10, nrr=3, check_every=4)
+            assert abs(got["k"] - orc["k"]) <= 2, (method, got["k"], orc["k"])
+            assert np.abs(got["x"] - 1.0).max() <= (1e-6 if tol > 1e-12 else 1e-9), method
+            tr = ctx.trace(got["k"])
+            h = min(5, got["k"], orc["k"])
+            np.testing.assert_allclose(tr["dotr"][:h], orc["dotr"][:h], rtol=1e-7)
+        ctx.close()
+        dist.barrier()
+        H.lib().bicg_comm_finalize()
+        dist.destroy_process_group()
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    except Exception:
+        open(os.path.join(outdir, f"fail{rank}"), "w").write(traceback.format_exc())
+        raise

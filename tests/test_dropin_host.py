@@ -1,0 +1,77 @@
+"""Drop-in boundary on the GPU box (`-m gpu`), through real SPMD MPI launches:
+
+* oracle/_ref/solver_dropin = the reference's UNMODIFIED main.c + matrix.c + mmio.c linked against
+  libbicgstab_hip.so instead of the reference's solver.c / vector.c (built by oracle/Makefile where
+  /root/reference is mounted; travels to the GPU box as a binary);
+* mpi-bicgstab_amd/host/bicg_solver_host = our own C host with the same command line;
+* oracle/_ref/solver_ref = the reference itself (CPU), the yardstick.
+
+The summary lines the reference prints (src/solver.c:135-139) must match: identical iteration count
++-2 and a final relative residual below EPS. With 2 ranks on the single GPU the library falls back
+to its host-staged MPI transport (more ranks than GPUs), i.e. the full N>1 code path."""
+import os
+import re
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpi_bicgstab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+REF = os.path.join(ROOT, "oracle", "_ref")
+HOST = os.path.join(ROOT, "mpi-bicgstab_amd", "host", "bicg_solver_host")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+
+def _run(binary, np_, mtx, method, extra=()):
+    env = dict(os.environ, BICG_CHECK_EVERY="4")
+    out = subprocess.run([MPIEXEC, "-n", str(np_), binary, mtx, method, *map(str, extra)], capture_output=True,
+                         text=True, timeout=300, env=env)
+    assert out.returncode == 0, out.stdout + out.stderr
+    k = int(re.search(r"Total iter\s*:\s*(\d+)", out.stdout).group(1))
+    r = float(re.search(r"Final r\s*:\s*(\S+)", out.stdout).group(1))
+    return k, r, out.stdout
+
+
+@pytest.fixture(scope="module")
+def mtx(tmp_path_factory):
+    path = str(tmp_path_factory.mktemp("mtx") / "offsets.mtx")
+    synth.write_mtx(path, synth.from_offsets(6007, (0, 1, -1, 50, -50, 51, -51, 2000, -2000), diag_base=12.0, seed=8))
+    return path
+
+
+need = pytest.mark.skipif(not (os.path.exists(MPIEXEC) and os.path.exists(os.path.join(REF, "solver_ref"))),
+                          reason="oracle/_ref or MPI not present")
+
+
+@need
+@pytest.mark.parametrize("np_", [1, 2])
+@pytest.mark.parametrize("method,extra", [("bicgstab", ()), ("ca_bicgstab", ()), ("pipe_bicgstab_rr", (10, 3))])
+def test_reference_main_linked_against_hip_library(mtx, method, extra, np_):
+    dropin = os.path.join(REF, "solver_dropin")
+    if not os.path.exists(dropin):
+        pytest.skip("solver_dropin not built")
+    k_ref, r_ref, _ = _run(os.path.join(REF, "solver_ref"), np_, mtx, method, extra)
+    k, r, out = _run(dropin, np_, mtx, method, extra)
+    assert abs(k - k_ref) <= 2, out
+    assert r <= 1e-15 and r_ref <= 1e-15
+    assert "Avg time/iter" in out and f"Proc: {np_}" in out
+
+
+@need
+@pytest.mark.parametrize("np_", [1, 2])
+def test_c_host_matches_reference(mtx, np_, tmp_path):
+    k_ref, r_ref, _ = _run(os.path.join(REF, "solver_ref"), np_, mtx, "bicgstab")
+    prefix = str(tmp_path / "x")
+    k, r, out = _run(HOST, np_, mtx, "bicgstab", ("--dump", prefix))
+    assert abs(k - k_ref) <= 2, out
+    assert r <= 1e-15
+    xs = []
+    for p in range(np_):
+        raw = open(f"{prefix}.rank{p}.bin", "rb").read()
+        nl = int(np.frombuffer(raw[4:8], dtype=np.int32)[0])
+        xs.append(np.frombuffer(raw[8:8 + 8 * nl], dtype=np.float64))
+    assert np.abs(np.concatenate(xs) - 1.0).max() <= 1e-9     # manufactured solution (src/main.c:109-117)
