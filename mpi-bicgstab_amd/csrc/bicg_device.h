@@ -9,7 +9,10 @@ namespace bicg {
 
 constexpr int kBlock = 256;                 // 4 wavefronts of 64
 constexpr int kNnzPerThread = 8;            // SpMV: products staged per thread
-constexpr int kChunk = kBlock * kNnzPerThread;  // 2048 non-zeros (16 KiB of LDS) per row block
+constexpr int kChunk = kBlock * kNnzPerThread;  // 2048 products (16 KiB of LDS) staged per row block
+constexpr int kRowBlockNnz = kChunk - 4;        // row blocks hold at most this many non-zeros: the staged
+                                                // window starts at a multiple of 4 entries (16-byte loads)
+constexpr int kPadEntries = 4;                  // val/col device arrays are padded by this many entries
 constexpr int kMaxDots = 5;                 // widest dot group (pipelined phase 2)
 constexpr int kRedSlots = 8;                // packed all-reduce buffer, doubles
 constexpr int kPartialStride = 8;           // doubles per block in the partial-sum table (64 B)
@@ -66,14 +69,14 @@ struct CsrDev {
 struct SpmvArgs {
     CsrDev diag;            // local columns
     CsrDev offd;            // columns renumbered to rows + halo position; ptr over ALL local rows
-    const uint32_t *rowblk; // [nblk+1] first row of each row block
-    const uint32_t *blist;  // row-block ids this launch processes (interior or boundary list); null = all
-    uint32_t nlist;         // number of row blocks to process (grid-stride over them)
+    const uint4 *desc;      // row blocks of this launch: {first row, end row, first nnz, end nnz}
+    uint32_t nlist;         // number of row blocks to process
     const double *x;        // [rows + halo]
     double       *y;        // [rows]
     const double *u;        // dot operand (NDOT >= 1): d0 = sum u_i y_i ; NDOT == 2 adds d1 = sum y_i^2
     Scal   *S;
     Reduce  red;
+    int     variant;        // SpMV kernel variant bits (see k_spmv)
 };
 
 // element-wise phase kernels: pointers to the rank-local vectors
@@ -109,6 +112,6 @@ void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 
 unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
-unsigned spmv_grid(uint32_t nlist);   // workgroups used by the SpMV for nlist row blocks
+unsigned spmv_grid(uint32_t nlist, int variant);   // workgroups used by the SpMV for nlist row blocks
 
 }  // namespace bicg

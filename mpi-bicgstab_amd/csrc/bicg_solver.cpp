@@ -44,6 +44,15 @@ template <class T> T *dev_upload(const T *src, size_t n)
     return p;
 }
 
+// n entries followed by `pad` zero entries (16-byte loads may run past the last non-zero)
+template <class T> T *dev_upload_padded(const T *src, size_t n, size_t pad)
+{
+    T *p = dev_alloc<T>(n + pad);
+    BICG_HIP(hipMemset(p + n, 0, sizeof(T) * pad));
+    if (n) BICG_HIP(hipMemcpy(p, src, sizeof(T) * n, hipMemcpyHostToDevice));
+    return p;
+}
+
 }  // namespace
 
 struct bicg_ctx {
@@ -54,8 +63,9 @@ struct bicg_ctx {
     // matrix + plan (device)
     double *d_val = nullptr, *o_val = nullptr;
     uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
-    uint32_t *rowblk = nullptr, *blist_int = nullptr, *blist_bnd = nullptr;
+    uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // row-block descriptors: interior / halo-touching
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
+    int spmv_variant = 0;
 
     // halo exchange
     std::vector<int> scnt, sdsp, rcnt, rdsp;
@@ -155,11 +165,11 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     SpmvArgs a;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
     a.offd = {c->o_val, c->o_col, c->o_ptr};
-    a.rowblk = c->rowblk;
     a.x = xin; a.y = yout; a.u = u; a.S = c->S;
+    a.variant = c->spmv_variant;
     // dot partials: one slot per workgroup, interior launch first, boundary launch after it
-    const unsigned g_int = c->single() ? spmv_grid(c->nblk) : spmv_grid(c->n_int);
-    const unsigned g_bnd = c->single() ? 0u : spmv_grid(c->n_bnd);
+    const unsigned g_int = spmv_grid(c->n_int, c->spmv_variant);
+    const unsigned g_bnd = c->single() ? 0u : spmv_grid(c->n_bnd, c->spmv_variant);
     red.expected = g_int + g_bnd;
     red.slot_base = 0;
     a.red = red;
@@ -171,7 +181,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     }
 
     if (c->single()) {
-        a.blist = nullptr; a.nlist = c->nblk;
+        a.desc = c->desc_int; a.nlist = c->n_int;
         launch_spmv(a, ndot, false, c->sc);
     } else {
         launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
@@ -193,10 +203,10 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             group_enqueue(c, c->pend_n, c->pend_phase, after);
             joined_pending = true;
         }
-        a.blist = c->blist_int; a.nlist = c->n_int;
+        a.desc = c->desc_int; a.nlist = c->n_int;
         launch_spmv(a, ndot, false, c->sc);
         if (eh) BICG_HIP(hipStreamWaitEvent(c->sc, eh, 0));
-        a.blist = c->blist_bnd; a.nlist = c->n_bnd;
+        a.desc = c->desc_bnd; a.nlist = c->n_bnd;
         a.red.slot_base = g_int;
         launch_spmv(a, ndot, true, c->sc);
         if (joined_pending && c->pend_ev) {
@@ -497,7 +507,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
 
     // ---- SpMV plan: row blocks over the diag block
     std::vector<uint32_t> rowblk(c->n_loc + 1);
-    c->nblk = bicg_row_blocks(diag->ptr, c->n_loc, kChunk, 1024, rowblk.data());
+    c->nblk = bicg_row_blocks(diag->ptr, c->n_loc, kRowBlockNnz, 1024, rowblk.data());
+    if (const char *sv = getenv("BICG_SPMV_VARIANT")) c->spmv_variant = atoi(sv);
     rowblk.resize(c->nblk + 1);
 
     // ---- halo plan (multi rank): which of x's remote entries this rank needs, who needs ours
@@ -528,23 +539,23 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     }
 
     // ---- interior / boundary row blocks
-    std::vector<uint32_t> bint, bbnd;
+    std::vector<uint4> bint, bbnd;
     for (uint32_t b = 0; b < c->nblk; ++b) {
         const bool touches_halo = P > 1 && optr[rowblk[b + 1]] > optr[rowblk[b]];
-        (touches_halo ? bbnd : bint).push_back(b);
+        const uint4 d = make_uint4(rowblk[b], rowblk[b + 1], diag->ptr[rowblk[b]], diag->ptr[rowblk[b + 1]]);
+        (touches_halo ? bbnd : bint).push_back(d);
     }
     c->n_int = (uint32_t)bint.size(); c->n_bnd = (uint32_t)bbnd.size();
 
     // ---- upload
-    c->d_val = dev_upload(diag->val, c->nnz_d);
-    c->d_col = dev_upload(diag->col, c->nnz_d);
+    c->d_val = dev_upload_padded(diag->val, c->nnz_d, kPadEntries);
+    c->d_col = dev_upload_padded(diag->col, c->nnz_d, kPadEntries);
     c->d_ptr = dev_upload(diag->ptr, (size_t)c->n_loc + 1);
     c->o_val = dev_upload(oval.data(), c->nnz_o);
     c->o_col = dev_upload(ocol.data(), c->nnz_o);
     c->o_ptr = dev_upload(optr.data(), (size_t)c->n_loc + 1);
-    c->rowblk = dev_upload(rowblk.data(), rowblk.size());
-    c->blist_int = dev_upload(bint.data(), bint.size());
-    c->blist_bnd = dev_upload(bbnd.data(), bbnd.size());
+    c->desc_int = dev_upload(bint.data(), bint.size());
+    c->desc_bnd = dev_upload(bbnd.data(), bbnd.size());
     c->send_idx = dev_upload(send_idx.data(), c->nsend);
     c->sendbuf = dev_alloc<double>(c->nsend);
 
@@ -584,7 +595,7 @@ void bicg_destroy(bicg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->comm->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->rowblk, c->blist_int, c->blist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->hS) (void)hipHostFree(c->hS);
