@@ -134,7 +134,8 @@ def main():
     relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
     genuine = res.iterations == W + K and np.isfinite(relres)
 
-    # roofline leg: the same K iterations with every SpMV bracketed by HIP events on the compute stream
+    # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
+    # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps
     dt_ev, res_ev = timed_run(a.method, kernel_events=True)
     spmv_ms = res_ev.spmv_ms_total / max(res_ev.spmv_launches, 1)
     b_spmv = spmv_bytes(plan["nnz_diag"] + plan["nnz_offd"], plan["rows"], plan["halo"])
@@ -182,7 +183,7 @@ def main():
                        "iterations_genuine": bool(genuine), "relres_after_timed_region": relres},
             "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,
             "iteration_algorithmic_bytes": iter_bytes,
-            "roofline": {"kernel": "k_spmv (row-block-stream CSR SpMV), rank 0 share", "bound": "hbm",
+            "roofline": {"kernel": "k_spmv_sell (sliced-ELL SpMV with fused dot epilogue), rank 0 share", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "algorithmic_bytes_per_launch": b_spmv,
                          "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,

@@ -120,7 +120,7 @@ typedef struct {
     int    quiet;        /* 1: no stdout lines */
     int    krr, nrr;     /* residual replacement period / count (src/solver.c:433) */
     int    record_trace; /* 1: keep per-iteration alpha/omega/beta/(r,r) on the device */
-    int    time_kernels; /* 1: bracket every SpMV launch with HIP events (roofline measurement) */
+    int    time_kernels; /* 1: give every SpMV kernel its own start/stop HIP events (roofline measurement) */
 } bicg_options;
 
 typedef struct {
@@ -129,8 +129,8 @@ typedef struct {
     double dot_zero;       /* (r0,r0) */
     double seconds;        /* wall time, init SpMV .. last iteration (the span of src/solver.c:70-131) */
     double iter_seconds;   /* wall time of the iteration loop only (after the set-up phase) */
-    double spmv_ms_total;  /* sum of event-timed SpMV launches (time_kernels) */
-    int    spmv_launches;  /* number of SpMV (interior+boundary pairs) timed */
+    double spmv_ms_total;  /* sum of the kernel durations of all timed SpMVs (time_kernels) */
+    int    spmv_launches;  /* number of SpMVs timed (an SpMV may consist of up to 4 kernels) */
 } bicg_result;
 
 void bicg_default_options(bicg_options *o);
@@ -170,8 +170,9 @@ double bicg_dot(bicg_ctx *ctx, const double *x_loc, const double *y_loc);
 /* reps back-to-back SpMVs on device-resident vectors; returns average ms per SpMV (HIP events on
  * the library's compute stream) */
 int bicg_spmv_bench(bicg_ctx *ctx, int reps, double *ms_per_spmv);
-/* plan facts: local rows, diag nnz, offd nnz, halo length, row blocks, boundary row blocks */
-int bicg_plan_info(bicg_ctx *ctx, unsigned int out[6]);
+/* plan facts: local rows, diag nnz, offd nnz, halo length, workgroups per SpMV, halo-touching
+ * workgroups, rows on the sliced-ELL path, sliced-ELL padding entries */
+int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);
 
 /* ---------------------------------------------------------------------------------------------
  * 5. Host-only helpers (no GPU needed; unit-tested on CPU).

@@ -66,7 +66,28 @@ struct CsrDev {
     const uint32_t *ptr;
 };
 
+// Sliced-ELL copy of the diag block: slices of 64 consecutive rows (one wavefront), entries stored
+// slice by slice COLUMN-major -- entry k of row r sits at slice_base + k*64 + (r % 64) -- padded to
+// the longest row of the slice with (val 0, col 0). Lane = row: val/col loads AND the x gather of
+// a banded matrix are coalesced across the wavefront, each lane adds ITS row in stored order.
+constexpr int kSliceRows = 64;
+constexpr int kGroupRows = kBlock;          // one workgroup = 4 slices = 256 consecutive rows
+struct SellDev {
+    const double   *val;
+    const uint32_t *col;
+    const uint32_t *slice_base;   // [nslices] first entry of the slice
+    const uint32_t *slice_len;    // [nslices] padded row length of the slice
+    // optional 16-bit column offsets (col - row), slice by slice in quads: the four offsets of
+    // entries 4q..4q+3 of a lane are contiguous -> element (q*64 + lane)*4 + (k % 4) from
+    // slice_base16; null when some |col - row| >= 32768
+    const short    *col16;
+    const uint32_t *slice_base16;
+};
+
 struct SpmvArgs {
+    SellDev sell;
+    const uint32_t *glist;  // SELL launch: 256-row groups to process (null = groups 0..nlist-1)
+    uint32_t nrows;         // local rows
     CsrDev diag;            // local columns
     CsrDev offd;            // columns renumbered to rows + halo position; ptr over ALL local rows
     const uint4 *desc;      // row blocks of this launch: {first row, end row, first nnz, end nnz}
@@ -76,7 +97,8 @@ struct SpmvArgs {
     const double *u;        // dot operand (NDOT >= 1): d0 = sum u_i y_i ; NDOT == 2 adds d1 = sum y_i^2
     Scal   *S;
     Reduce  red;
-    int     variant;        // SpMV kernel variant bits (see k_spmv)
+    int     variant;        // CSR SpMV kernel variant bits (see k_spmv)
+    int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
 };
 
 // element-wise phase kernels: pointers to the rank-local vectors
@@ -86,7 +108,10 @@ struct Vecs {
 };
 
 // ---- launch wrappers (bicg_kernels.hip) ----
-void launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st);
+// Both return false when there was nothing to launch. e0/e1 (optional): start/stop events bound to
+// this one kernel (hipExtLaunchKernelGGL) -- the per-kernel durations bench.py's roofline uses.
+bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);        // CSR row-block stream
+bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // sliced ELL
 void launch_apply(Scal *S, int phase, hipStream_t st);
 void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);
 
@@ -111,6 +136,7 @@ void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
 // standalone dot (x,y) -> red[0]
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 
+unsigned sell_grid(uint32_t ngroups, int per_wg); // workgroups launched for ngroups 256-row groups
 unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
 unsigned spmv_grid(uint32_t nlist, int variant);   // workgroups used by the SpMV for nlist row blocks
 

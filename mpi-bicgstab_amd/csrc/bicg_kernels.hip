@@ -19,7 +19,17 @@
 // the association of the dot-product sums differs.
 #include "bicg_device.h"
 
+#include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events bound to ONE kernel (roofline timing)
+
 namespace bicg {
+
+// launch with optional per-kernel timing events (kernel-accurate, unlike events recorded around a launch)
+template <class K, class... Args>
+static void launch_timed(K kernel, dim3 g, dim3 b, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args)
+{
+    if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, 0, st, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, g, b, 0, st, args...);
+}
 
 // ------------------------------------------------------------------------------------------
 // scalar recurrences (one thread)
@@ -498,25 +508,156 @@ unsigned spmv_grid(uint32_t nlist, int variant)
 }
 
 template <int NDOT, bool OFFD>
-static void launch_spmv_var(const SpmvArgs &a, hipStream_t st)
+static void launch_spmv_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     dim3 g(spmv_grid(a.nlist, a.variant)), b(kBlock);
-    if (a.variant & 8) { hipLaunchKernelGGL((k_spmv_pipe<NDOT, OFFD>), g, b, 0, st, a); return; }
+    if (a.variant & 8) { launch_timed(k_spmv_pipe<NDOT, OFFD>, g, b, st, e0, e1, a); return; }
     switch (a.variant & 7) {
-#define V(n) case n: hipLaunchKernelGGL((k_spmv<NDOT, OFFD, n>), g, b, 0, st, a); break
+#define V(n) case n: launch_timed(k_spmv<NDOT, OFFD, n>, g, b, st, e0, e1, a); break
         V(0); V(1); V(2); V(3); V(4); V(5); V(6); V(7);
 #undef V
     }
 }
 
-void launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st)
+bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
-    if (a.nlist == 0) return;
+    if (a.nlist == 0) return false;
     if (with_offd) {
-        if (ndot == 0) launch_spmv_var<0, true>(a, st); else if (ndot == 1) launch_spmv_var<1, true>(a, st); else launch_spmv_var<2, true>(a, st);
+        if (ndot == 0) launch_spmv_var<0, true>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, true>(a, st, e0, e1); else launch_spmv_var<2, true>(a, st, e0, e1);
     } else {
-        if (ndot == 0) launch_spmv_var<0, false>(a, st); else if (ndot == 1) launch_spmv_var<1, false>(a, st); else launch_spmv_var<2, false>(a, st);
+        if (ndot == 0) launch_spmv_var<0, false>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, false>(a, st, e0, e1); else launch_spmv_var<2, false>(a, st, e0, e1);
     }
+    return true;
+}
+
+// ------------------------------------------------------------------------------------------
+// Sliced-ELL SpMV (the default path for rows whose slice pads by < 25 %)
+//
+// Why: the CSR row-block kernel above is limited by the vector L1 (TCP), not by HBM: with lanes
+// walking the non-zeros row-major, the x gather of a wavefront touches ~20 different cache lines
+// per instruction; rocprofv3 shows 26 M TCP tag accesses per SpMV (1.1 per non-zero), the TCP
+// clock-enabled 85 % of the kernel, and the time does not react to fabric traffic or occupancy.
+// With lane = row (SELL-64) consecutive lanes read consecutive entries of val/col AND, for banded
+// matrices, consecutive entries of x: ~0.35 tag accesses per non-zero, no LDS, no barrier.
+// Each lane accumulates its own row in stored order -> bit-identical to mult() (reference
+// src/matrix.c:506-515) for every row. Padding entries are loaded (coalescing) but never added.
+// ------------------------------------------------------------------------------------------
+typedef short i16x4 __attribute__((ext_vector_type(4)));
+
+// C16: column indices are read as 16-bit offsets from the row (col = row + delta), four
+// consecutive entries of a lane packed in one 8-byte word: 10 instead of 12 bytes per non-zero.
+// Used when every entry of the sliced-ELL copy satisfies |col - row| < 32768 (banded matrices).
+template <int NDOT, bool OFFD, bool NT, bool C16>
+__global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
+{
+    const int done = a.S->done;       // consumed at the stores only (see k_spmv)
+    __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
+    constexpr int U = 8;              // entries per lane in flight (4, 8, 16 measured identical)
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const double *__restrict__ x = a.x;
+
+    double acc[NDOT > 0 ? NDOT : 1];
+#pragma unroll
+    for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
+
+    // A workgroup handles groups blockIdx.x, blockIdx.x + gridDim.x, ...: with one group per
+    // workgroup the fused dot epilogue (one partial + one arrival ticket per workgroup) costs
+    // 10 us per SpMV on Transport; a few groups per workgroup amortise it. Round-robin placement
+    // over the XCDs is kept: an XCD-contiguous mapping cuts the fabric reads from 386 to 309 MB
+    // (x is then fetched by one L2 instead of eight) but is 3-5 % SLOWER in wall time.
+    for (unsigned gi = blockIdx.x; gi < a.nlist; gi += gridDim.x) {
+        const unsigned g = a.glist ? a.glist[gi] : gi;
+        const uint32_t row = g * kGroupRows + tid;                 // = slice * 64 + lane
+        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
+        const bool live = row < a.nrows;
+
+        uint32_t base = 0u, len = 0u, base16 = 0u;
+        if (slice * kSliceRows < a.nrows) {
+            base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
+            if (C16) base16 = a.sell.slice_base16[slice];
+        }
+        uint32_t mylen = 0u, oa = 0u, ob = 0u;
+        double ume = 0.0;
+        if (live) {
+            mylen = a.diag.ptr[row + 1] - a.diag.ptr[row];
+            if (OFFD) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
+            if (NDOT >= 1) ume = a.u[row];
+        }
+
+        double sum = 0.0;
+        for (uint32_t k0 = 0; k0 < len; k0 += U) {
+            uint32_t c[U];
+            double   v[U];
+            if (C16) {
+                static_assert(U % 4 == 0, "packed 16-bit columns come four at a time");
+#pragma unroll
+                for (int q = 0; q < U / 4; ++q) {
+                    const bool ok = k0 + 4 * q < len;             // wave-uniform; the quad is padded
+                    const i16x4 *p = reinterpret_cast<const i16x4 *>(a.sell.col16) +
+                                     ((size_t)base16 / 4 + (size_t)((k0 / 4) + q) * kSliceRows + lane);
+                    i16x4 dq = (i16x4)(0);
+                    if (ok) dq = NT ? __builtin_nontemporal_load(p) : *p;
+                    c[4 * q + 0] = row + (int)dq.x; c[4 * q + 1] = row + (int)dq.y;
+                    c[4 * q + 2] = row + (int)dq.z; c[4 * q + 3] = row + (int)dq.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const bool ok = k0 + e < len;                     // wave-uniform
+                const uint32_t j = base + (k0 + e) * kSliceRows + lane;
+                if (!C16) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
+                v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
+            }
+            double xv[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) xv[e] = x[c[e]];
+#pragma unroll
+            for (int e = 0; e < U; ++e)
+                if (k0 + e < mylen) sum += v[e] * xv[e];          // stored order; padding never added
+        }
+        double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+        if (OFFD) {
+            double so = 0.0;
+            for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
+            yi += so;                                             // second mult() call, src/matrix.c:440
+        }
+        if (live && !done) a.y[row] = yi;
+        if (NDOT >= 1 && live) acc[0] += ume * yi;
+        if (NDOT >= 2 && live) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+    }
+    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+}
+
+// workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
+unsigned sell_grid(uint32_t ngroups, int per_wg)
+{
+    if (ngroups == 0) return 0;
+    if (per_wg < 1) per_wg = 1;
+    const unsigned per = (unsigned)per_wg;
+    const unsigned grid0 = (ngroups + per - 1) / per;             // upper bound on workgroups
+    const unsigned each = (ngroups + grid0 - 1) / grid0;
+    return (ngroups + each - 1) / each;
+}
+
+bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
+{
+    if (a.nlist == 0) return false;
+    dim3 g(sell_grid(a.nlist, a.groups_per_wg)), b(kBlock);
+#define SELL_CASE(ND, OF)                                                                          \
+    do {                                                                                           \
+        const bool nt = !(a.variant & 16), c16 = a.sell.col16 != nullptr;                          \
+        if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true>, g, b, st, e0, e1, a);         \
+        else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false>, g, b, st, e0, e1, a);          \
+        else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true>, g, b, st, e0, e1, a);         \
+        else launch_timed(k_spmv_sell<ND, OF, false, false>, g, b, st, e0, e1, a);                 \
+    } while (0)
+    if (with_offd) {
+        if (ndot == 0) SELL_CASE(0, true); else if (ndot == 1) SELL_CASE(1, true); else SELL_CASE(2, true);
+    } else {
+        if (ndot == 0) SELL_CASE(0, false); else if (ndot == 1) SELL_CASE(1, false); else SELL_CASE(2, false);
+    }
+#undef SELL_CASE
+    return true;
 }
 
 void launch_apply(Scal *S, int phase, hipStream_t st)

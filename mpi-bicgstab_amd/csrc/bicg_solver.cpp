@@ -63,9 +63,21 @@ struct bicg_ctx {
     // matrix + plan (device)
     double *d_val = nullptr, *o_val = nullptr;
     uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
-    uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // row-block descriptors: interior / halo-touching
+    uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // CSR row-block descriptors: interior / halo-touching
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
     int spmv_variant = 0;
+    int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
+    int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
+    bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
+    uint64_t matrix_bytes = 0;             // bytes one SpMV streams from the matrix arrays
+    // sliced-ELL copy of the diag block (rows whose 256-row group pads by < 25 %)
+    double *s_val = nullptr;
+    uint32_t *s_col = nullptr, *s_base = nullptr, *s_len = nullptr, *s_base16 = nullptr;
+    short *s_col16 = nullptr;
+    uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
+    uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
+    uint64_t sell_entries = 0, sell_nnz = 0;
+    bool glist_int_identity = false;
 
     // halo exchange
     std::vector<int> scnt, sdsp, rcnt, rdsp;
@@ -102,7 +114,7 @@ struct bicg_ctx {
     // per-SpMV timing
     bool time_kernels = false;
     std::vector<hipEvent_t> tev;
-    int tev_used = 0;
+    int tev_used = 0, spmv_calls_timed = 0;
 
     bool single() const { return nranks == 1; }
     Reduce red(int off, int phase, bool apply_single = true) const
@@ -163,26 +175,44 @@ void group_defer(bicg_ctx *c, int n, int phase)
 void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red)
 {
     SpmvArgs a;
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16};
+    a.glist = nullptr;
+    a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
     a.offd = {c->o_val, c->o_col, c->o_ptr};
+    a.desc = nullptr; a.nlist = 0;
     a.x = xin; a.y = yout; a.u = u; a.S = c->S;
-    a.variant = c->spmv_variant;
-    // dot partials: one slot per workgroup, interior launch first, boundary launch after it
-    const unsigned g_int = spmv_grid(c->n_int, c->spmv_variant);
-    const unsigned g_bnd = c->single() ? 0u : spmv_grid(c->n_bnd, c->spmv_variant);
-    red.expected = g_int + g_bnd;
+    a.variant = (c->spmv_variant & ~16) | (c->sell_nt ? 0 : 16);
+    // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
+    // order): {sliced-ELL groups, CSR row blocks} x {interior, halo-touching}.
+    a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
+    const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int, c->spmv_variant);
+    const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd, c->spmv_variant);
+    red.expected = g_si + g_ci + g_sb + g_cb;
     red.slot_base = 0;
     a.red = red;
 
-    hipEvent_t t0 = nullptr, t1 = nullptr;
-    if (c->time_kernels && c->tev_used + 2 <= (int)c->tev.size()) {
-        t0 = c->tev[c->tev_used++]; t1 = c->tev[c->tev_used++];
-        BICG_HIP(hipEventRecord(t0, c->sc));
-    }
+    // per-kernel timing: every SpMV kernel of this call gets its own start/stop event pair
+    const bool timed = c->time_kernels && c->tev_used + 8 <= (int)c->tev.size();
+    bool any_timed = false;
+    auto ev = [&](int i) -> hipEvent_t { return timed ? c->tev[c->tev_used + i] : nullptr; };
+    auto took = [&](bool launched) { if (launched && timed) { c->tev_used += 2; any_timed = true; } };
+
+    auto interior = [&]() {
+        a.glist = c->glist_int_identity ? nullptr : c->glist_int; a.nlist = c->ng_int; a.red.slot_base = 0;
+        took(launch_spmv_sell(a, ndot, false, c->sc, ev(0), ev(1)));
+        a.desc = c->desc_int; a.nlist = c->n_int; a.red.slot_base = g_si;
+        took(launch_spmv(a, ndot, false, c->sc, ev(0), ev(1)));
+    };
+    auto boundary = [&]() {
+        a.glist = c->glist_bnd; a.nlist = c->ng_bnd; a.red.slot_base = g_si + g_ci;
+        took(launch_spmv_sell(a, ndot, true, c->sc, ev(0), ev(1)));
+        a.desc = c->desc_bnd; a.nlist = c->n_bnd; a.red.slot_base = g_si + g_ci + g_sb;
+        took(launch_spmv(a, ndot, true, c->sc, ev(0), ev(1)));
+    };
 
     if (c->single()) {
-        a.desc = c->desc_int; a.nlist = c->n_int;
-        launch_spmv(a, ndot, false, c->sc);
+        interior();
     } else {
         launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
         hipEvent_t eh = nullptr;
@@ -203,18 +233,15 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             group_enqueue(c, c->pend_n, c->pend_phase, after);
             joined_pending = true;
         }
-        a.desc = c->desc_int; a.nlist = c->n_int;
-        launch_spmv(a, ndot, false, c->sc);
+        interior();
         if (eh) BICG_HIP(hipStreamWaitEvent(c->sc, eh, 0));
-        a.desc = c->desc_bnd; a.nlist = c->n_bnd;
-        a.red.slot_base = g_int;
-        launch_spmv(a, ndot, true, c->sc);
+        boundary();
         if (joined_pending && c->pend_ev) {
             BICG_HIP(hipStreamWaitEvent(c->sc, c->pend_ev, 0));
             c->pend_ev = nullptr;
         }
     }
-    if (t1) BICG_HIP(hipEventRecord(t1, c->sc));
+    if (any_timed) c->spmv_calls_timed++;
 }
 
 // a deferred group that no SpMV picked up (defensive)
@@ -337,6 +364,17 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     if (o.check_every < 1) o.check_every = 1;
     c->method = method;
     BICG_HIP(hipSetDevice(c->comm->device));
+    // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
+    // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
+    // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
+    // per iteration). Beyond that the matrix only evicts the vectors and is streamed with
+    // non-temporal loads instead (Transport, pipelined, 10 vectors: 167.3 vs 173.8 us).
+    {
+        static const int nvec[4] = {6, 8, 10, 11};
+        const double ws = (double)c->matrix_bytes + 8.0 * c->stride * nvec[method];
+        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
+        if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
+    }
 
     // trace storage: the (r,r) history is always kept (progress lines), 4 arrays of max_iter
     if (c->trace_cap < o.max_iter) {
@@ -359,7 +397,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     const size_t st = c->stride;
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = o.time_kernels != 0;
-    c->tev_used = 0;
+    c->tev_used = 0; c->spmv_calls_timed = 0;
     if (c->time_kernels && c->tev.empty()) {
         c->tev.resize(kMaxTimed);
         for (auto &e : c->tev) BICG_HIP(hipEventCreate(&e));
@@ -414,8 +452,9 @@ int run_end(bicg_ctx *c, bicg_result *res)
     if (c->time_kernels) {
         for (int i = 0; i + 1 < c->tev_used; i += 2) {
             float ms = 0.f;
-            if (hipEventElapsedTime(&ms, c->tev[i], c->tev[i + 1]) == hipSuccess) { spmv_ms += ms; ++spmv_n; }
+            if (hipEventElapsedTime(&ms, c->tev[i], c->tev[i + 1]) == hipSuccess) spmv_ms += ms;
         }
+        spmv_n = c->spmv_calls_timed;
     }
     const double total = c->t_init + c->t_iter;
     if (res) {
@@ -505,11 +544,11 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->nnz_d = diag->ptr[diag->rows];
     const int P = c->nranks;
 
-    // ---- SpMV plan: row blocks over the diag block
-    std::vector<uint32_t> rowblk(c->n_loc + 1);
-    c->nblk = bicg_row_blocks(diag->ptr, c->n_loc, kRowBlockNnz, 1024, rowblk.data());
     if (const char *sv = getenv("BICG_SPMV_VARIANT")) c->spmv_variant = atoi(sv);
-    rowblk.resize(c->nblk + 1);
+    const bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
+    if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
+    if (const char *sv = getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = atoi(sv);
 
     // ---- halo plan (multi rank): which of x's remote entries this rank needs, who needs ours
     std::vector<uint32_t> ocol, optr(c->n_loc + 1, 0u);
@@ -538,14 +577,87 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         for (int p = 1; p < P; ++p) c->sdsp[p] = c->sdsp[p - 1] + c->scnt[p - 1];
     }
 
-    // ---- interior / boundary row blocks
+    // ---- SpMV plan. Rows are cut into groups of 256 (4 slices of 64 = one workgroup). A group goes
+    // to the sliced-ELL kernel when padding its slices to their longest row costs < 25 % extra
+    // entries; the other groups (ragged or very long rows) are covered by CSR row blocks of whole
+    // rows with <= kRowBlockNnz non-zeros. Either kind is "boundary" when one of its rows has offd
+    // entries (it then runs after the halo has landed).
+    const uint32_t nrows = c->n_loc;
+    const uint32_t nslices = (nrows + kSliceRows - 1) / kSliceRows, ngroups = (nrows + kGroupRows - 1) / kGroupRows;
+    std::vector<uint32_t> slice_len(nslices, 0u), slice_base(nslices, 0u);
+    for (uint32_t r = 0; r < nrows; ++r)
+        slice_len[r / kSliceRows] = std::max(slice_len[r / kSliceRows], diag->ptr[r + 1] - diag->ptr[r]);
+    std::vector<uint32_t> gl_int, gl_bnd;
     std::vector<uint4> bint, bbnd;
-    for (uint32_t b = 0; b < c->nblk; ++b) {
-        const bool touches_halo = P > 1 && optr[rowblk[b + 1]] > optr[rowblk[b]];
-        const uint4 d = make_uint4(rowblk[b], rowblk[b + 1], diag->ptr[rowblk[b]], diag->ptr[rowblk[b + 1]]);
-        (touches_halo ? bbnd : bint).push_back(d);
+    std::vector<char> group_is_sell(ngroups, 0);
+    uint64_t sell_entries = 0;
+    for (uint32_t g = 0; g < ngroups; ++g) {
+        const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
+        const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
+        uint64_t padded = 0;
+        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) padded += (uint64_t)slice_len[sl] * kSliceRows;
+        const bool sell = use_sell && padded <= nnz_g + nnz_g / 4 + 2 * kSliceRows && sell_entries + padded < 0xFFFFFF00ull;
+        group_is_sell[g] = sell;
+        if (!sell) continue;
+        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) {
+            slice_base[sl] = (uint32_t)sell_entries;
+            sell_entries += (uint64_t)slice_len[sl] * kSliceRows;
+        }
+        c->sell_nnz += nnz_g; c->sell_rows += r1 - r0;
+        const bool touches_halo = P > 1 && optr[r1] > optr[r0];
+        (touches_halo ? gl_bnd : gl_int).push_back(g);
+    }
+    c->sell_entries = sell_entries;
+    std::vector<double> sval(sell_entries ? sell_entries : 1, 0.0);
+    std::vector<uint32_t> scol(sell_entries ? sell_entries : 1, 0u);
+    for (uint32_t r = 0; r < nrows; ++r) {
+        if (!group_is_sell[r / kGroupRows]) continue;
+        const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
+        for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
+            const size_t e = (size_t)slice_base[sl] + (size_t)k * kSliceRows + lane;
+            sval[e] = diag->val[j]; scol[e] = diag->col[j];
+        }
+    }
+    // 16-bit column offsets when every sliced-ELL entry is within +-32767 of its row
+    bool c16 = sell_entries > 0 && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
+    std::vector<uint32_t> slice_base16(nslices, 0u);
+    uint64_t n16 = 0;
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        slice_base16[sl] = (uint32_t)n16;
+        if (group_is_sell[sl / (kGroupRows / kSliceRows)]) n16 += (uint64_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows;
+    }
+    if (n16 >= 0xFFFFFF00ull) c16 = false;
+    std::vector<short> scol16(c16 ? n16 : 1, 0);
+    for (uint32_t r = 0; c16 && r < nrows; ++r) {
+        if (!group_is_sell[r / kGroupRows]) continue;
+        const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
+        for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
+            const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
+            if (dlt < -32767 || dlt > 32767) { c16 = false; break; }
+            scol16[(size_t)slice_base16[sl] + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] = (short)dlt;
+        }
+    }
+
+    // CSR row blocks over the maximal runs of non-SELL groups
+    std::vector<uint32_t> rb(nrows + 1);
+    for (uint32_t g = 0; g < ngroups;) {
+        if (group_is_sell[g]) { ++g; continue; }
+        uint32_t g1 = g;
+        while (g1 < ngroups && !group_is_sell[g1]) ++g1;
+        const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, g1 * kGroupRows);
+        // bicg_row_blocks works on a ptr array that starts at the run's first row
+        const uint32_t nb = bicg_row_blocks(diag->ptr + r0, r1 - r0, kRowBlockNnz, 1024, rb.data());
+        for (uint32_t b = 0; b < nb; ++b) {
+            const uint32_t a0 = r0 + rb[b], a1 = r0 + rb[b + 1];
+            const bool touches_halo = P > 1 && optr[a1] > optr[a0];
+            (touches_halo ? bbnd : bint).push_back(make_uint4(a0, a1, diag->ptr[a0], diag->ptr[a1]));
+        }
+        g = g1;
     }
     c->n_int = (uint32_t)bint.size(); c->n_bnd = (uint32_t)bbnd.size();
+    c->nblk = c->n_int + c->n_bnd;
+    c->ng_int = (uint32_t)gl_int.size(); c->ng_bnd = (uint32_t)gl_bnd.size();
+    c->glist_int_identity = c->ng_int == ngroups;     // every group, in order: index directly
 
     // ---- upload
     c->d_val = dev_upload_padded(diag->val, c->nnz_d, kPadEntries);
@@ -556,6 +668,18 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->o_ptr = dev_upload(optr.data(), (size_t)c->n_loc + 1);
     c->desc_int = dev_upload(bint.data(), bint.size());
     c->desc_bnd = dev_upload(bbnd.data(), bbnd.size());
+    c->s_val = dev_upload(sval.data(), (size_t)sell_entries);
+    c->s_col = dev_upload(scol.data(), (size_t)sell_entries);
+    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) + 8ull * nslices + 4ull * (nrows + 1) +
+                      (uint64_t)(c->nnz_d - c->sell_nnz) * 12 + (uint64_t)c->nnz_o * 12;
+    if (c16) {
+        c->s_col16 = dev_upload(scol16.data(), scol16.size());
+        c->s_base16 = dev_upload(slice_base16.data(), slice_base16.size());
+    }
+    c->s_base = dev_upload(slice_base.data(), slice_base.size());
+    c->s_len = dev_upload(slice_len.data(), slice_len.size());
+    c->glist_int = dev_upload(gl_int.data(), gl_int.size());
+    c->glist_bnd = dev_upload(gl_bnd.data(), gl_bnd.size());
     c->send_idx = dev_upload(send_idx.data(), c->nsend);
     c->sendbuf = dev_alloc<double>(c->nsend);
 
@@ -568,8 +692,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     for (int i = 0; i < 12; ++i) *slots[i] = base + (size_t)i * c->stride;
     c->v.n = c->n_loc;
 
-    c->nslots = std::max<unsigned>(2 * kSpmvMaxGrid, kMaxGrid) + 2;
-    if (c->nblk + 2 < c->nslots) c->nslots = std::max<unsigned>(c->nblk, kMaxGrid) + 2;
+    c->nslots = std::max<unsigned>(ngroups + c->nblk, kMaxGrid) + 64;
     c->partial = dev_alloc<double>((size_t)c->nslots * kPartialStride);
     c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
     c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
@@ -595,7 +718,7 @@ void bicg_destroy(bicg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->comm->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->hS) (void)hipHostFree(c->hS);
@@ -707,9 +830,13 @@ int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
     return 0;
 }
 
-int bicg_plan_info(bicg_ctx *c, unsigned int out[6])
+int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
 {
-    out[0] = c->n_loc; out[1] = c->nnz_d; out[2] = c->nnz_o; out[3] = c->halo; out[4] = c->nblk; out[5] = c->n_bnd;
+    out[0] = c->n_loc; out[1] = c->nnz_d; out[2] = c->nnz_o; out[3] = c->halo;
+    out[4] = c->nblk + c->ng_int + c->ng_bnd;       // workgroups per SpMV
+    out[5] = c->n_bnd + c->ng_bnd;                  // of which halo-touching
+    out[6] = c->sell_rows;                          // rows on the sliced-ELL path
+    out[7] = (unsigned)(c->sell_entries > c->sell_nnz ? c->sell_entries - c->sell_nnz : 0);   // padding entries
     return 0;
 }
 

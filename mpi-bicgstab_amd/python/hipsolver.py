@@ -233,9 +233,10 @@ class Context:
         return ms.value
 
     def plan_info(self):
-        out = (C.c_uint * 6)()
+        out = (C.c_uint * 8)()
         lib().bicg_plan_info(self.h, out)
-        return dict(zip(("rows", "nnz_diag", "nnz_offd", "halo", "row_blocks", "boundary_blocks"), list(out)))
+        return dict(zip(("rows", "nnz_diag", "nnz_offd", "halo", "row_blocks", "boundary_blocks", "sell_rows",
+                         "sell_padding"), list(out)))
 
 
 # ---- host-only helpers (no GPU) ----------------------------------------------------------------

@@ -37,6 +37,8 @@ known = {  # algorithmic bytes (read, written) per launch
     "FPlainQ": (2 * 8 * N, 8 * N), "FPlainXR": (5 * 8 * N, 2 * 8 * N), "FPlainP": (3 * 8 * N, 8 * N),
     "k_spmv<0": (12 * NNZ + 4 * (N + 1) + 8 * N, 8 * N), "k_spmv<1": (12 * NNZ + 4 * (N + 1) + 16 * N, 8 * N),
     "k_spmv<2": (12 * NNZ + 4 * (N + 1) + 8 * N, 8 * N),
+    "k_spmv_sell<0": (12 * NNZ + 4 * (N + 1) + 8 * N, 8 * N), "k_spmv_sell<1": (12 * NNZ + 4 * (N + 1) + 16 * N, 8 * N),
+    "k_spmv_sell<2": (12 * NNZ + 4 * (N + 1) + 8 * N, 8 * N),
 }
 rows = []
 spmv_bytes, spmv_calls = 0.0, 0
@@ -65,10 +67,7 @@ with open(os.path.join(dst, "pmc_summary.md"), "w") as out:
         a = f"{alg[0] / 1e6:.1f} / {alg[1] / 1e6:.1f}" if alg else "-"
         ratio = f"{(fb + wb) / (alg[0] + alg[1]):.2f}" if alg else "-"
         out.write(f"| `{short}` | {calls} | {us:.1f} | {fb / 1e6:.1f} | {wb / 1e6:.1f} | {a} | {ratio} |\n")
-    out.write("\nThe SpMV reads ~80 MB more than its algorithmic bytes: with one workgroup per row block and the "
-              "dispatcher's round-robin placement every XCD's private L2 ends up fetching all of x (8 x 12.8 MB instead of 1 x). "
-              "The XCD-aware mapping (BICG_SPMV_VARIANT=1) removes exactly that (2.41 M instead of 3.03 M 128-B read requests "
-              "= 308.6 MB, the algorithmic figure) but is 3-5 % slower in wall time, so it is not the default; see DESIGN.md.\n")
+    out.write("\n" + open(os.path.join(ROOT, "profiles", "NOTES.md")).read() if os.path.exists(os.path.join(ROOT, "profiles", "NOTES.md")) else "")
 
 json.dump({"kernel": "k_spmv (all instantiations, call-weighted)", "hbm_bytes_per_launch": spmv_bytes / max(spmv_calls, 1),
            "method": "rocprofv3 --pmc FETCH_SIZE (x2 on gfx950) and --pmc WRITE_SIZE in separate passes, KiB x 1024",
