@@ -259,7 +259,8 @@ int bicg_comm_unique_id(void *id_out) { return rccl_unique_id(id_out); }
 
 int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device)
 {
-    comm_set(nranks > 1 ? make_rccl(rank, nranks, id, device) : make_single(device));
+    const char *force = getenv("BICG_FORCE_COMM");     // tests: a real 1-rank RCCL communicator
+    comm_set(nranks > 1 || (force && atoi(force)) ? make_rccl(rank, nranks, id, device) : make_single(device));
     return 0;
 }
 

@@ -116,7 +116,23 @@ struct bicg_ctx {
     std::vector<hipEvent_t> tev;
     int tev_used = 0, spmv_calls_timed = 0;
 
-    bool single() const { return nranks == 1; }
+    // BICG_FORCE_COMM=1 (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
+    // apply kernels, two streams) even with one rank, so that it can be exercised on a one-GPU box
+    bool force_comm = false;
+    bool single() const { return nranks == 1 && !force_comm; }
+
+    // Use the second (communication) stream to overlap the halo exchange with the interior rows and
+    // the pipelined variant's all-reduces with the next SpMV (reference src/matrix.c:432-440,
+    // src/solver.c:363-367). A cross-stream hand-off costs ~7 us each way, the interior SpMV of a
+    // 200 k-row rank only ~6 us, so below ~6 M local non-zeros everything is enqueued in order on
+    // the compute stream instead. BICG_OVERLAP=0/1 overrides.
+    bool overlap = false;
+
+    // hipGraph replay of the iteration body (BICG_GRAPH): one captured iteration per method
+    int graph_mode = -1;                 // -1 auto, 0 off, 1 on
+    hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
+    int graph_warm[4] = {0, 0, 0, 0};    // eager iterations done since the context was created
+    bool graph_nt[4] = {false, false, false, false};
     Reduce red(int off, int phase, bool apply_single = true) const
     {
         Reduce r;
@@ -146,15 +162,14 @@ void group_enqueue(bicg_ctx *c, int n, int phase, hipEvent_t after)
     }
 }
 
-// all-reduce the n sums in Scal::red and apply `phase`, blocking the compute stream on the result
+// all-reduce the n sums in Scal::red and apply `phase` before anything else runs on the compute
+// stream: nothing can overlap, so both are enqueued on the compute stream itself (a round trip
+// through the communication stream costs two cross-stream event hand-offs, ~10 us eager)
 void group_now(bicg_ctx *c, int n, int phase)
 {
     if (c->single()) return;   // applied in-kernel by the finishing workgroup
-    hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
-    BICG_HIP(hipEventRecord(e, c->sc));
-    group_enqueue(c, n, phase, e);
-    if (c->pend_ev) BICG_HIP(hipStreamWaitEvent(c->sc, c->pend_ev, 0));
-    c->pend_ev = nullptr;
+    c->comm->allreduce_sum(c->S->red, n, c->sc);
+    launch_apply(c->S, phase, c->sc);
 }
 
 // same, but the all-reduce is started by the NEXT spmv() after its halo exchange is in flight and
@@ -162,6 +177,7 @@ void group_now(bicg_ctx *c, int n, int phase)
 void group_defer(bicg_ctx *c, int n, int phase)
 {
     if (c->single()) return;
+    if (!c->overlap || !c->comm->stream_ordered()) { group_now(c, n, phase); return; }
     hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
     BICG_HIP(hipEventRecord(e, c->sc));
     c->pend = true; c->pend_n = n; c->pend_phase = phase; c->pend_ev = e;
@@ -216,7 +232,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     } else {
         launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
         hipEvent_t eh = nullptr;
-        if (c->comm->stream_ordered()) {
+        if (c->comm->stream_ordered() && c->overlap) {
             hipEvent_t ep = c->ev_pack[c->i_pack++ % kEvRing];
             BICG_HIP(hipEventRecord(ep, c->sc));
             BICG_HIP(hipStreamWaitEvent(c->sm, ep, 0));
@@ -412,6 +428,47 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     c->t_init = now_sec() - c->t_begin;
 }
 
+// hipGraph replay of one iteration. The iteration body is a fixed sequence of launches (and, across
+// ranks, RCCL calls on the communication stream joined back by events), identical from one
+// iteration to the next except for pipe_bicgstab_rr's replacement steps, so it is captured once
+// per method and replayed: one graph launch instead of 5-17 enqueue calls per iteration. This is
+// what keeps an 8-GPU run (20-25 us of GPU work per iteration) from being bound by the host's
+// ~3-4 us per launch. Two eager iterations come first so that every lazy initialisation (RCCL
+// connections, kernel loading) happens outside the capture. Returns false when the caller has to
+// run the iteration eagerly.
+bool graph_iteration(bicg_ctx *c, Driver &d)
+{
+    const int m = c->method;
+    // Off unless BICG_GRAPH=1: measured on one MI355X, eager in-order enqueueing already keeps the
+    // GPU busy (54 us vs 60 us replayed per 17-op iteration of a 200 k-row rank); replay only pays
+    // when the two-stream overlap mode is on (80 vs 105 us).
+    const bool want = c->graph_mode == 1;
+    if (!want || m == BICG_PIPE_BICGSTAB_RR || c->time_kernels || !c->comm->stream_ordered()) return false;
+    if (c->graph_exec[m] && c->graph_nt[m] != c->sell_nt) {     // captured with the other streaming policy
+        (void)hipGraphExecDestroy(c->graph_exec[m]);
+        c->graph_exec[m] = nullptr;
+    }
+    if (!c->graph_exec[m]) {
+        if (c->graph_warm[m] < 2) { c->graph_warm[m]++; return false; }
+        hipGraph_t g = nullptr;
+        if (hipStreamBeginCapture(c->sc, hipStreamCaptureModeThreadLocal) != hipSuccess) { c->graph_mode = 0; return false; }
+        d.iterate(c->it);
+        const hipError_t e = hipStreamEndCapture(c->sc, &g);
+        if (e != hipSuccess || !g) {
+            fprintf(stderr, "bicgstab_hip: graph capture failed (%s); continuing with eager launches\n", hipGetErrorString(e));
+            (void)hipGetLastError();
+            c->graph_mode = 0;
+            return false;   // nothing was executed during the failed capture
+        }
+        const hipError_t e2 = hipGraphInstantiate(&c->graph_exec[m], g, nullptr, nullptr, 0);
+        (void)hipGraphDestroy(g);
+        if (e2 != hipSuccess) { c->graph_exec[m] = nullptr; c->graph_mode = 0; return false; }
+        c->graph_nt[m] = c->sell_nt;
+    }
+    BICG_HIP(hipGraphLaunch(c->graph_exec[m], c->sc));
+    return true;
+}
+
 int run_iterate(bicg_ctx *c, int nsteps)
 {
     const bicg_options &o = c->opt;
@@ -422,7 +479,9 @@ int run_iterate(bicg_ctx *c, int nsteps)
     const int stop = std::min(o.max_iter, c->it + std::max(nsteps, 0));
     while (!c->hS->done && c->it < stop) {
         const int chunk = std::min(o.check_every, stop - c->it);
-        for (int j = 0; j < chunk; ++j) d.iterate(c->it + j);
+        for (int j = 0; j < chunk; ++j) {
+            if (!graph_iteration(c, d)) d.iterate(c->it + j);
+        }
         c->it += chunk;
         fetch_scal(c);
         if (talk && o.out_iter > 0) {   // reference src/solver.c:122-126
@@ -547,6 +606,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (const char *sv = getenv("BICG_SPMV_VARIANT")) c->spmv_variant = atoi(sv);
     const bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
+    if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
+    c->overlap = c->nnz_d >= 6000000u;
+    if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = atoi(sv);
 
@@ -703,7 +766,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     memset(c->hS, 0, sizeof(Scal));
 
     BICG_HIP(hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking));
-    if (P > 1) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
+    if (P > 1 || c->force_comm) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
     for (int i = 0; i < kEvRing; ++i) {
         BICG_HIP(hipEventCreateWithFlags(&c->ev_pack[i], hipEventDisableTiming));
         BICG_HIP(hipEventCreateWithFlags(&c->ev_halo[i], hipEventDisableTiming));
@@ -726,6 +789,7 @@ void bicg_destroy(bicg_ctx *c)
         (void)hipEventDestroy(c->ev_pack[i]); (void)hipEventDestroy(c->ev_halo[i]); (void)hipEventDestroy(c->ev_dots[i]); (void)hipEventDestroy(c->ev_red[i]);
     }
     for (auto &e : c->tev) (void)hipEventDestroy(e);
+    for (auto &ge : c->graph_exec) if (ge) (void)hipGraphExecDestroy(ge);
     if (c->sc) (void)hipStreamDestroy(c->sc);
     if (c->sm) (void)hipStreamDestroy(c->sm);
     delete c;

@@ -1,0 +1,79 @@
+"""The multi-rank machinery on ONE GPU (`-m gpu`): BICG_FORCE_COMM=1 makes a single rank take the
+N>1 code path -- halo pack/exchange calls, packed all-reduce of every dot group on the
+communication stream, 1-thread apply kernels, event joins -- with either the trivial transport or a
+REAL one-rank RCCL communicator, eagerly and as a replayed hipGraph. Every combination must
+reproduce the plain single-rank result bit for bit (the arithmetic is the same; only where the
+scalar recurrences run changes)."""
+import ctypes as C
+
+import numpy as np
+import pytest
+
+from mpi_bicgstab_amd import hipsolver as H
+from mpi_bicgstab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+METHODS = [("bicgstab", 1e-15), ("ca_bicgstab", 1e-15), ("pipe_bicgstab", 1e-9), ("pipe_bicgstab_rr", 1e-15)]
+
+
+def _solve_all(A, b, **env):
+    import os
+    saved = {k: os.environ.get(k) for k in env}
+    os.environ.update({k: str(v) for k, v in env.items()})
+    try:
+        ctx = H.Context(H.single_rank_blocks(A))
+        out = {}
+        for m, tol in METHODS:
+            r = ctx.solve(m, b, tol=tol, krr=10, nrr=3, check_every=5)
+            out[m] = (r["k"], r["x"].copy(), r["r"].copy())
+        ctx.close()
+        return out
+    finally:
+        for k, v in saved.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+
+
+@pytest.fixture(scope="module")
+def problem():
+    H.lib().bicg_comm_init_single(0)
+    A = synth.from_offsets(20011, (0, 1, -1, 60, -60, 61, -61, 3000, -3000), diag_base=11.0, seed=4)
+    ctx = H.Context(H.single_rank_blocks(A))
+    b = ctx.spmv(np.ones(A.rows))
+    ctx.close()
+    return A, b, _solve_all(A, b, BICG_GRAPH=0)
+
+
+def _same(got, ref):
+    for m, _ in METHODS:
+        assert got[m][0] == ref[m][0], m
+        assert np.array_equal(got[m][1], ref[m][1]) and np.array_equal(got[m][2], ref[m][2]), m
+
+
+def test_graph_replay_single_rank(problem):
+    A, b, ref = problem
+    _same(_solve_all(A, b, BICG_GRAPH=1), ref)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_forced_comm_trivial_transport(problem, graph):
+    A, b, ref = problem
+    H.lib().bicg_comm_init_single(0)
+    _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph), ref)
+
+
+@pytest.mark.parametrize("graph", [0, 1])
+def test_forced_comm_one_rank_rccl(problem, graph, monkeypatch):
+    A, b, ref = problem
+    monkeypatch.setenv("BICG_FORCE_COMM", "1")
+    buf = (C.c_char * 128)()
+    H.lib().bicg_comm_unique_id(buf)
+    H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
+    try:
+        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph), ref)
+    finally:
+        monkeypatch.delenv("BICG_FORCE_COMM")
+        H.lib().bicg_comm_init_single(0)
