@@ -51,6 +51,10 @@ def main():
     ap.add_argument("--method", default="bicgstab", choices=list(ITER_VECTOR_BYTES_PER_ROW))
     ap.add_argument("--n", type=int, default=0, help="rows (default: Transport's 1602111)")
     ap.add_argument("--scale-decades", type=float, default=2.0)
+    ap.add_argument("--workload", default="transport", choices=["transport", "laplace7"],
+                    help="transport: BASELINE configs[1] (default). laplace7: 7-point Laplacian on an m^3 grid "
+                         "(configs[3] is m = 512 over 8 GPUs = 64 planes of 512^2 per GPU)")
+    ap.add_argument("--m", type=int, default=256, help="grid edge for --workload laplace7")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100)
@@ -95,12 +99,19 @@ def main():
             dist.barrier()
 
     # ---- workload: this rank's row slab of the global matrix
-    n = a.n or synth.TRANSPORT_N
+    if a.workload == "laplace7":
+        n = a.m ** 3
+        nnz_global = synth.stencil7_nnz(a.m)
+    else:
+        n = a.n or synth.TRANSPORT_N
+        nnz_global = synth.transport_nnz(n)
     counts, displs = synth.partition(n, world)
     lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
-    slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
+    if a.workload == "laplace7":
+        slab = synth.stencil7(a.m, synth.LAPLACE_WEIGHTS, rows=(lo, hi))
+    else:
+        slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
     diag, offd = synth.split_row_slab(slab, lo)
-    nnz_global = synth.transport_nnz(n)
     blocks = H.HostBlocks(diag, offd if world > 1 else None, n, counts, displs)
     ctx = H.Context(blocks)
     plan = ctx.plan_info()
@@ -142,7 +153,7 @@ def main():
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_spmv.json")
-    if os.path.exists(pmc):
+    if os.path.exists(pmc) and a.workload == "transport" and not a.n and world == 1:
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
@@ -156,10 +167,18 @@ def main():
                 continue
             dtv, resv = timed_run(m, kernel_events=False)
             variants[m] = 1e3 * dtv / K
+    if not a.no_variants and a.workload == "transport":
+        # BASELINE.json configs[4] family: 16 shifts, seed 7, sigma_j = (j+1) 0.01/16 (reference
+        # src/main_shifted.c:99 pattern); 2 SpMV + one batched update over all shifts per iteration
+        nsh, seed = 16, 7
+        sigma = (np.arange(nsh) + 1.0) * 0.01 / nsh
+        ks = min(K, 100)
+        rs = ctx.solve_shifted(b + sigma[seed] * ones, sigma, seed, tol=0.0, max_iter=ks, check_every=ks)
+        variants[f"shifted_lopbicgstab_{nsh}shifts"] = 1e3 * rs["result"].seconds / max(rs["k"], 1)
     spmv_alone_ms = ctx.spmv_bench(200)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "transport":
         try:
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--n", str(n),
                                   "--scale-decades", str(a.scale_decades), "--iters", str(a.cpu_iters),
@@ -171,12 +190,14 @@ def main():
     if rank == 0:
         iter_bytes = 2 * spmv_bytes(nnz_global, n) + ITER_VECTOR_BYTES_PER_ROW[a.method] * n
         line = {
-            "metric": f"ms/iteration, {a.method}, Transport-shaped CSR ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
+            "metric": f"ms/iteration, {a.method}, " + ("Transport-shaped CSR" if a.workload == "transport" else f"7-point Laplacian {a.m}^3")
+                      + f" ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
             "value": ms_step, "unit": "ms/iteration", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
             "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "BASELINE.json configs[1]: plain BiCGStab, Transport-shaped synthetic "
-                                   "(Transport.mtx unavailable offline), b = A*1, x0 = 0",
+            "config": {"workload": ("BASELINE.json configs[1]: plain BiCGStab, Transport-shaped synthetic "
+                                    "(Transport.mtx unavailable offline), b = A*1, x0 = 0") if a.workload == "transport" else
+                                   f"BASELINE.json configs[3] family: 7-point 3-D Laplacian {a.m}^3 generated in memory, b = A*1, x0 = 0",
                        "rows": n, "nnz": nnz_global, "scale_decades": a.scale_decades, "method": a.method,
                        "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
                        "transport": "rccl" if world > 1 else "none",

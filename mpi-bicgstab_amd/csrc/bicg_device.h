@@ -31,6 +31,24 @@ enum Phase : int {
     PH_OMEGA,       // red[0]=(q,y), red[1]=(y,y): omega               (src/solver.c:104, 232, 369)
     PH_PLAIN_END,   // red[0]=(r,r), red[1]=(r#,r): beta, k++          (src/solver.c:108-120)
     PH_RECUR_END,   // red[0..4]=(r,r),(r#,r),(r#,w),(r#,s),(r#,z): beta, alpha, k++ (src/solver.c:248-251, 387-390)
+    // shifted BiCGStab (reference src/shifted_solver.c:182-354): applied by a whole workgroup,
+    // one thread per shift for the per-shift scalar recurrences
+    PH_SH_INIT,     // red[0]=(r,r): rTr = dot_r = dot_zero, per-shift scalars reset            (:238-255)
+    PH_SH_ALPHA,    // red[0]=(r#,s): alpha[seed]; beta[j], pi, eta, alpha[j]                    (:264-287)
+    PH_SH_OMEGA,    // red[0]=(q,y), red[1]=(q,q): omega[seed]; omega[j], x/p coefficients, zeta (:291-301)
+    PH_SH_END,      // red[0]=(r,r), red[1]=(r#,r): beta[seed], max|1/(zeta pi)|, k++            (:304-320)
+};
+
+// Per-shift scalar state of the shifted solver, device resident (arrays of nsig doubles).
+struct ShiftDev {
+    int     nsig, seed;
+    double  alpha_old, beta_old, max_zeta_pi;
+    double *sigma, *alpha, *beta, *omega, *eta, *zeta, *pi_old, *pi_new;
+    // coefficients the batched update kernel reads for shift j (valid for one iteration)
+    double *cp;   // 1 / (pi_new zeta)              p_j <- beta_j p_j + cp_j r_old      (:265-266)
+    double *cx;   // omega_j / (pi_new zeta)        x_j += cx_j q                        (:296)
+    double *c1;   // omega_j / (alpha_j zeta pi_new)        p_j += c1_j q                (:298)
+    double *c2;   // -omega_j / (alpha_j zeta pi_old)       p_j += c2_j r_old            (:299)
 };
 
 // Device-resident scalar state of one solve. Kernels read alpha/beta/omega/done from here, so the
@@ -46,6 +64,7 @@ struct Scal {
     int    done;                 // sticky: set when the reference's while condition fails
     int    pad;
     double *tr_alpha, *tr_omega, *tr_beta, *tr_dotr;   // optional trace, [max_iter]
+    ShiftDev *sh;                // shifted solver only
 };
 
 // Where a kernel's dot partial sums go and what happens when the last block has arrived.
@@ -94,7 +113,10 @@ struct SpmvArgs {
     uint32_t nlist;         // number of row blocks to process
     const double *x;        // [rows + halo]
     double       *y;        // [rows]
-    const double *u;        // dot operand (NDOT >= 1): d0 = sum u_i y_i ; NDOT == 2 adds d1 = sum y_i^2
+    const double *u;        // dot operand (NDOT >= 1): d0 = sum u_i y_i ; NDOT == 2 adds d1 = sum y_i^2 ;
+                            // NDOT == 3: d0 = sum u_i y_i, d1 = sum u_i^2
+    double  shift;          // y = A x + shift * x (shifted solver: A + sigma[seed] I, src/shifted_solver.c:259-260)
+    int     has_shift;
     Scal   *S;
     Reduce  red;
     int     variant;        // CSR SpMV kernel variant bits (see k_spmv)
@@ -103,7 +125,7 @@ struct SpmvArgs {
 
 // element-wise phase kernels: pointers to the rank-local vectors
 struct Vecs {
-    double *x, *r, *rh, *p, *s, *y, *z, *w, *v, *t, *ax, *b;
+    double *x, *r, *rh, *p, *s, *y, *z, *w, *v, *t, *ax, *b;   // shifted solver: ax doubles as r_old
     uint32_t n;
 };
 
@@ -133,6 +155,13 @@ void launch_p_update(const Vecs &v, Scal *S, hipStream_t st);
 void launch_x_update(const Vecs &v, Scal *S, hipStream_t st);
 void launch_true_residual(const Vecs &v, Scal *S, hipStream_t st);
 void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+// shifted BiCGStab (reference src/shifted_solver.c:182-354)
+void launch_shift_init(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t st);      // r# = r, p[seed] = r, (r,r)
+void launch_shift_q(const Vecs &v, Scal *S, hipStream_t st);                                     // r_old = r ; q = r - alpha s
+// x[seed], r, the two dots, and for every other shift j: p_j and x_j (one pass over both sets)
+void launch_shift_update(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
+                         Scal *S, Reduce red, hipStream_t st);
+void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t st);                 // p[seed] = r + beta (p[seed] - omega s)
 // standalone dot (x,y) -> red[0]
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 

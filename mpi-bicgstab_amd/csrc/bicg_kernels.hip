@@ -89,10 +89,103 @@ __device__ void apply_phase(Scal *S, int phase)
     }
 }
 
-__global__ void k_apply(Scal *S, int phase)
+// ---- shifted solver: per-shift scalar recurrences, one thread per shift (whole workgroup calls)
+__device__ void apply_phase_shifted(Scal *S, int phase)
+{
+    ShiftDev *H = S->sh;
+    const double *d = S->red;
+    const int nsig = H->nsig, seed = H->seed;
+    __shared__ double s_max[kBlock];
+    if (threadIdx.x == 0) {
+        if (phase == PH_SH_INIT) {
+            S->rTr = d[0]; S->dot_r = d[0]; S->dot_zero = d[0];
+            S->alpha = 1.0; S->beta = 0.0; S->omega = 0.0; S->rTr_old = 0.0;
+            H->max_zeta_pi = 1.0; H->alpha_old = 1.0; H->beta_old = 0.0;
+            if (!(1.0 * 1.0 * S->dot_r > S->tol2 * S->dot_zero && 0 < S->max_iter)) S->done = 1;
+        } else if (phase == PH_SH_ALPHA) {
+            H->alpha_old = S->alpha;                  // alpha_old <- alpha[seed]   (:270)
+            H->beta_old = S->beta;                    // beta_old  <- beta[seed]    (:271)
+            S->alpha = S->rTr / d[0];                 // alpha[seed] <- (r#,r)/(r#,s)  (:274)
+        } else if (phase == PH_SH_OMEGA) {
+            S->omega = d[1] / d[0];                   // omega[seed] <- (q,q)/(q,y)    (:291)
+        } else if (phase == PH_SH_END) {
+            S->dot_r = d[0];
+            S->rTr_old = S->rTr;
+            S->rTr = d[1];
+            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);      // (:310)
+        }
+    }
+    __syncthreads();
+    const double a_seed = S->alpha, b_seed = S->beta, w_seed = S->omega, sg_seed = H->sigma[seed];
+    double local_max = 1.0;
+    for (int j = threadIdx.x; j < nsig; j += kBlock) {
+        if (phase == PH_SH_INIT) {
+            H->beta[j] = 0.0; H->alpha[j] = 1.0; H->eta[j] = 0.0; H->pi_old[j] = 1.0; H->pi_new[j] = 1.0; H->zeta[j] = 1.0;
+            H->cp[j] = 0.0; H->cx[j] = 0.0; H->c1[j] = 0.0; H->c2[j] = 0.0; H->omega[j] = 0.0;
+            continue;
+        }
+        if (j == seed) {
+            if (phase == PH_SH_ALPHA) H->pi_old[j] = H->pi_new[j];      // my_dcopy copies every entry (:268)
+            continue;
+        }
+        if (phase == PH_SH_ALPHA) {
+            const double po = H->pi_old[j], pn = H->pi_new[j];
+            H->beta[j] = (po / pn) * (po / pn) * H->beta_old;            // uses beta[seed] of the previous iteration (:264)
+            H->cp[j] = 1.0 / (pn * H->zeta[j]);                          // (:266)
+            H->pi_old[j] = pn;                                           // (:268)
+            const double e = (H->beta_old / H->alpha_old) * a_seed * H->eta[j] - (sg_seed - H->sigma[j]) * a_seed * pn;   // (:283)
+            H->eta[j] = e;
+            const double pnew = e + pn;                                  // (:285)
+            H->pi_new[j] = pnew;
+            H->alpha[j] = (pn / pnew) * a_seed;                          // (:286)
+        } else if (phase == PH_SH_OMEGA) {
+            const double dsg = sg_seed - H->sigma[j];
+            const double wj = w_seed / (1.0 - w_seed * dsg);             // (:295)
+            H->omega[j] = wj;
+            const double pn = H->pi_new[j], po = H->pi_old[j], z = H->zeta[j], aj = H->alpha[j];
+            H->cx[j] = wj / (pn * z);                                    // (:296)
+            H->c1[j] = wj / (aj * z * pn);                               // (:298)
+            H->c2[j] = -wj / (aj * z * po);                              // (:299)
+            H->zeta[j] = (1.0 - w_seed * dsg) * z;                       // (:300)
+        } else if (phase == PH_SH_END) {
+            double a = 1.0 / (H->zeta[j] * H->pi_new[j]);                // (:314)
+            if (a < 0.0) a = -a;
+            if (a > local_max) local_max = a;
+        }
+    }
+    (void)b_seed;
+    if (phase == PH_SH_END) {
+        s_max[threadIdx.x] = local_max;
+        __syncthreads();
+        for (int w = kBlock / 2; w > 0; w >>= 1) {
+            if ((int)threadIdx.x < w && s_max[threadIdx.x + w] > s_max[threadIdx.x]) s_max[threadIdx.x] = s_max[threadIdx.x + w];
+            __syncthreads();
+        }
+        if (threadIdx.x == 0) {
+            const double m = s_max[0];
+            H->max_zeta_pi = m;
+            S->k += 1;
+            const int k = S->k;
+            if (S->tr_dotr && k <= S->max_iter) {
+                S->tr_alpha[k - 1] = S->alpha; S->tr_omega[k - 1] = S->omega; S->tr_beta[k - 1] = S->beta; S->tr_dotr[k - 1] = S->dot_r;
+            }
+            // reference loop condition, src/shifted_solver.c:257
+            if (!(m * m * S->dot_r > S->tol2 * S->dot_zero && k < S->max_iter)) S->done = 1;
+        }
+    }
+}
+
+// whole-workgroup entry: scalar phases run on thread 0, shifted phases on all threads
+__device__ __forceinline__ void apply_phase_block(Scal *S, int phase)
+{
+    if (phase >= PH_SH_INIT) apply_phase_shifted(S, phase);
+    else if (threadIdx.x == 0) apply_phase(S, phase);
+}
+
+__global__ void __launch_bounds__(kBlock) k_apply(Scal *S, int phase)
 {
     if (S->done) return;
-    apply_phase(S, phase);
+    apply_phase_block(S, phase);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -199,7 +292,10 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
 #pragma unroll
         for (int d = 0; d < ND; ++d) S->red[red.red_off + d] = tot[d];
         __hip_atomic_store(&red.counter[kShards * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if (red.apply_now) apply_phase(S, red.phase);
+    }
+    if (red.apply_now) {
+        __syncthreads();            // Scal::red written by thread 0 above
+        apply_phase_block(S, red.phase);
     }
 }
 
@@ -292,9 +388,11 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
                 for (uint32_t k = o0; k < o1; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
                 yi += so;                                    // second mult() call, src/matrix.c:440
             }
+            if (a.has_shift) yi += a.shift * x[r];           // (A + sigma I) x, src/shifted_solver.c:260
             if (!done) a.y[r] = yi;
             if (NDOT >= 1) acc[0] += ur * yi;
-            if (NDOT >= 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+            if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+            if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ur * ur;
         };
 
         if (j1 - jw <= (uint32_t)kChunk) {
@@ -356,9 +454,11 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
                     for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
                     yi += so;
                 }
+                if (a.has_shift) yi += a.shift * x[r0];
                 if (!done) a.y[r0] = yi;
                 if (NDOT >= 1) acc[0] += ume * yi;
-                if (NDOT >= 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+                if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+                if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
             }
         }
         __syncthreads();   // prod is rewritten by the next row block
@@ -477,9 +577,11 @@ __global__ void __launch_bounds__(kBlock) k_spmv_pipe(SpmvArgs a)
                     for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
                     yi += so;
                 }
+                if (a.has_shift) yi += a.shift * x[r0];
                 a.y[r0] = yi;
                 if (NDOT >= 1) acc[0] += ume * yi;
-                if (NDOT >= 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+                if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+                if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
             }
         }
         __syncthreads();   // prod is rewritten by the next row block
@@ -523,9 +625,11 @@ bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hi
 {
     if (a.nlist == 0) return false;
     if (with_offd) {
-        if (ndot == 0) launch_spmv_var<0, true>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, true>(a, st, e0, e1); else launch_spmv_var<2, true>(a, st, e0, e1);
+        if (ndot == 0) launch_spmv_var<0, true>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, true>(a, st, e0, e1);
+        else if (ndot == 2) launch_spmv_var<2, true>(a, st, e0, e1); else launch_spmv_var<3, true>(a, st, e0, e1);
     } else {
-        if (ndot == 0) launch_spmv_var<0, false>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, false>(a, st, e0, e1); else launch_spmv_var<2, false>(a, st, e0, e1);
+        if (ndot == 0) launch_spmv_var<0, false>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, false>(a, st, e0, e1);
+        else if (ndot == 2) launch_spmv_var<2, false>(a, st, e0, e1); else launch_spmv_var<3, false>(a, st, e0, e1);
     }
     return true;
 }
@@ -621,9 +725,11 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
             for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
             yi += so;                                             // second mult() call, src/matrix.c:440
         }
+        if (a.has_shift && live) yi += a.shift * x[row];          // (A + sigma I) x, src/shifted_solver.c:260
         if (live && !done) a.y[row] = yi;
         if (NDOT >= 1 && live) acc[0] += ume * yi;
-        if (NDOT >= 2 && live) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+        if (NDOT == 2 && live) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+        if (NDOT == 3 && live) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
     }
     if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
 }
@@ -652,9 +758,9 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
         else launch_timed(k_spmv_sell<ND, OF, false, false>, g, b, st, e0, e1, a);                 \
     } while (0)
     if (with_offd) {
-        if (ndot == 0) SELL_CASE(0, true); else if (ndot == 1) SELL_CASE(1, true); else SELL_CASE(2, true);
+        if (ndot == 0) SELL_CASE(0, true); else if (ndot == 1) SELL_CASE(1, true); else if (ndot == 2) SELL_CASE(2, true); else SELL_CASE(3, true);
     } else {
-        if (ndot == 0) SELL_CASE(0, false); else if (ndot == 1) SELL_CASE(1, false); else SELL_CASE(2, false);
+        if (ndot == 0) SELL_CASE(0, false); else if (ndot == 1) SELL_CASE(1, false); else if (ndot == 2) SELL_CASE(2, false); else SELL_CASE(3, false);
     }
 #undef SELL_CASE
     return true;
@@ -662,7 +768,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 
 void launch_apply(Scal *S, int phase, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_apply, dim3(1), dim3(1), 0, st, S, phase);
+    hipLaunchKernelGGL(k_apply, dim3(1), dim3(phase >= PH_SH_INIT ? kBlock : 1), 0, st, S, phase);
 }
 
 // gather the entries of x other ranks need into the contiguous send buffer
@@ -974,6 +1080,101 @@ struct FDots5 {     // (r,r), (r#,r), (r#,w), (r#,s), (r#,z)                 (sr
     }
 };
 void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FDots5{v.r, v.rh, v.w, v.s, v.z}, v.n, S, red, s); }
+
+// ---- shifted BiCGStab (reference src/shifted_solver.c:182-354) ---------------------------------
+struct FShiftInit {   // r# = r ; p[seed] = r ; (r,r)                                  (:238-250)
+    static constexpr int ND = 1;
+    const double *r; double *rh, *ps;
+    __device__ void load(const Scal *) {}
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T rr = ld<T>(r, i);
+        st(rh, i, rr); st(ps, i, rr);
+        acc[0] += hsum(rr * rr);
+    }
+};
+void launch_shift_init(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FShiftInit{v.r, v.rh, p_seed}, v.n, S, red, s);
+}
+
+struct FShiftQ {      // r_old = r ; q = r - alpha[seed] s (kept in r)                  (:269, 275)
+    static constexpr int ND = 0;
+    double *r, *rold; const double *s; double alpha;
+    __device__ void load(const Scal *S) { alpha = S->alpha; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        T r0 = ld<T>(r, i);
+        st(rold, i, r0);
+        st(r, i, r0 + (-alpha) * ld<T>(s, i));
+    }
+};
+void launch_shift_q(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FShiftQ{v.r, v.ax, v.s, 0.0}, v.n, S, Reduce{}, s); }
+
+// One pass over BOTH vector sets: the seed's x and r, the two dots, and for every other shift j the
+// p_j update that the reference does at the top of the iteration (:264-266, with r = r_old), the
+// x_j update (:296-297) and the second p_j update (:298-299) -- the same operations on every
+// element in the same order, but p_j and x_j are read and written ONCE per iteration
+// (32 n bytes per shift instead of the reference's 136 n).
+struct FShiftUpdate {
+    static constexpr int ND = 2;
+    double *xs, *r, *pset, *xset; const double *ps, *y, *rh, *rold; const ShiftDev *H; uint32_t stride;
+    double alpha, omega; int nsig, seed;
+    const double *beta_j, *alpha_j, *cp, *cx, *c1, *c2;
+    __device__ void load(const Scal *S)
+    {
+        alpha = S->alpha; omega = S->omega;
+        nsig = H->nsig; seed = H->seed;
+        beta_j = H->beta; alpha_j = H->alpha; cp = H->cp; cx = H->cx; c1 = H->c1; c2 = H->c2;
+    }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        const T q = ld<T>(r, i), ro = ld<T>(rold, i);
+        T xx = ld<T>(xs, i) + alpha * ld<T>(ps, i);             // x[seed] += alpha p[seed] ; += omega q   (:292-293)
+        st(xs, i, xx + omega * q);
+        for (int j = 0; j < nsig; ++j) {
+            if (j == seed) continue;
+            double *pj = pset + (size_t)j * stride, *xj = xset + (size_t)j * stride;
+            T p = beta_j[j] * ld<T>(pj, i);                      // my_dscal(beta[j])                       (:265)
+            p = p + cp[j] * ro;                                  // += 1/(pi zeta) r   (r == r_old here)    (:266)
+            T x = ld<T>(xj, i) + cx[j] * q;                      // (:296)
+            x = x + alpha_j[j] * p;                              // (:297)
+            st(xj, i, x);
+            p = p + c1[j] * q;                                   // (:298)
+            p = p + c2[j] * ro;                                  // (:299)
+            st(pj, i, p);
+        }
+        const T rr = q + (-omega) * ld<T>(y, i);                // r = q - omega y                         (:303)
+        st(r, i, rr);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(ld<T>(rh, i) * rr);
+    }
+};
+void launch_shift_update(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
+                         Scal *S, Reduce red, hipStream_t s)
+{
+    FShiftUpdate f{};
+    f.xs = x_set + (size_t)seed * set_stride; f.ps = p_set + (size_t)seed * set_stride;
+    f.r = v.r; f.pset = p_set; f.xset = x_set; f.y = v.y; f.rh = v.rh; f.rold = v.ax; f.H = H; f.stride = set_stride;
+    run_vec(f, v.n, S, red, s);
+}
+
+struct FShiftPSeed {  // p[seed] = beta p[seed] ; += r ; += (-beta omega) s                (:317-319)
+    static constexpr int ND = 0;
+    double *p; const double *r, *s; double beta, c;
+    __device__ void load(const Scal *S) { beta = S->beta; c = -S->beta * S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        T pp = beta * ld<T>(p, i);
+        pp = pp + 1.0 * ld<T>(r, i);
+        pp = pp + c * ld<T>(s, i);
+        st(p, i, pp);
+    }
+};
+void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t s)
+{
+    run_vec(FShiftPSeed{p_seed, v.r, v.s, 0.0, 0.0}, v.n, S, Reduce{}, s);
+}
 
 struct FDot {
     static constexpr int ND = 1;

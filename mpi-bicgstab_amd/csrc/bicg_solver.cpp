@@ -106,6 +106,13 @@ struct bicg_ctx {
     int pend_n = 0, pend_phase = 0;
     hipEvent_t pend_ev = nullptr;
 
+    // shifted solver (bicg_solve_shifted): per-shift scalar state and the two vector sets
+    ShiftDev *sh_dev = nullptr;
+    double *sh_arrays = nullptr, *p_set = nullptr, *x_set = nullptr;
+    int sh_cap = 0;
+    double cur_shift = 0.0;
+    bool cur_has_shift = false;
+
     // state of the solve in progress (run_begin / run_iterate / run_end)
     bicg_options opt{};
     int method = 0, it = 0, printed = 0;
@@ -199,6 +206,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.desc = nullptr; a.nlist = 0;
     a.x = xin; a.y = yout; a.u = u; a.S = c->S;
     a.variant = (c->spmv_variant & ~16) | (c->sell_nt ? 0 : 16);
+    a.shift = c->cur_shift; a.has_shift = c->cur_has_shift ? 1 : 0;
     // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
     // order): {sliced-ELL groups, CSR row blocks} x {interior, halo-touching}.
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
@@ -542,6 +550,114 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
     return run_end(c, res);
 }
 
+// ---------------------------------------------------------------- shifted BiCGStab
+// (A + sigma_j I) x_j = b for all j from ONE Krylov recurrence on the seed system: 2 SpMV per
+// iteration whatever the number of shifts (reference src/shifted_solver.c:182-354). Per iteration:
+// SpMV(+sigma_seed) with (r#,s) | q, r_old | SpMV(+sigma_seed) with (q,y),(q,q) | ONE batched kernel
+// over all shifts (x_seed, r, every p_j and x_j, two dots) | p_seed.  The per-shift scalar
+// recurrences (beta_j, pi_j, eta_j, alpha_j, omega_j, zeta_j) run on the device, one thread per shift.
+int run_shifted(bicg_ctx *c, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
+                const bicg_options *opt_in, bicg_result *res)
+{
+    bicg_options o;
+    if (opt_in) o = *opt_in; else { bicg_default_options(&o); o.tol = 1.0e-12; }   // EPS of src/shifted_solver.c:5
+    if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
+    if (o.max_iter < 0) o.max_iter = 0;
+    if (o.check_every < 1) o.check_every = 1;
+    BICG_HIP(hipSetDevice(c->comm->device));
+    const size_t st = c->stride, n = c->n_loc;
+
+    if (c->sh_cap < nsig) {
+        for (void *p : {(void *)c->sh_dev, (void *)c->sh_arrays, (void *)c->p_set, (void *)c->x_set}) if (p) BICG_HIP(hipFree(p));
+        c->sh_dev = dev_alloc<ShiftDev>(1);
+        c->sh_arrays = dev_alloc<double>(12 * (size_t)nsig);
+        c->p_set = dev_alloc<double>((size_t)nsig * st);
+        c->x_set = dev_alloc<double>((size_t)nsig * st);
+        c->sh_cap = nsig;
+    }
+    ShiftDev h;
+    memset(&h, 0, sizeof h);
+    h.nsig = nsig; h.seed = seed;
+    double **arr[12] = {&h.sigma, &h.alpha, &h.beta, &h.omega, &h.eta, &h.zeta, &h.pi_old, &h.pi_new, &h.cp, &h.cx, &h.c1, &h.c2};
+    for (int i = 0; i < 12; ++i) *arr[i] = c->sh_arrays + (size_t)i * nsig;
+    BICG_HIP(hipMemcpy(c->sh_dev, &h, sizeof h, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemset(c->sh_arrays, 0, sizeof(double) * 12 * (size_t)nsig));
+    BICG_HIP(hipMemcpy(h.sigma, sigma, sizeof(double) * nsig, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemset(c->p_set, 0, sizeof(double) * (size_t)nsig * st));        // calloc, src/shifted_solver.c:223
+    BICG_HIP(hipMemset(c->x_set, 0, sizeof(double) * (size_t)nsig * st));
+    for (int j = 0; j < nsig; ++j)
+        BICG_HIP(hipMemcpy(c->x_set + (size_t)j * st, x_set_host + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemcpy(c->v.r, r_host, sizeof(double) * n, hipMemcpyHostToDevice));
+
+    if (c->trace_cap < o.max_iter) {
+        if (c->trace) BICG_HIP(hipFree(c->trace));
+        c->trace_cap = o.max_iter > 0 ? o.max_iter : 1;
+        c->trace = dev_alloc<double>(4 * (size_t)c->trace_cap);
+    }
+    Scal hs;
+    memset(&hs, 0, sizeof hs);
+    hs.tol2 = o.tol * o.tol; hs.max_iter = o.max_iter;
+    hs.tr_alpha = c->trace; hs.tr_omega = c->trace + c->trace_cap;
+    hs.tr_beta = c->trace + 2 * (size_t)c->trace_cap; hs.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
+    hs.sh = c->sh_dev;
+    BICG_HIP(hipMemcpyAsync(c->S, &hs, sizeof hs, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
+    BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
+    c->time_kernels = false;
+    {   // streaming policy: matrix + 6 work vectors + the two sets
+        const double ws = (double)c->matrix_bytes + 8.0 * st * (6 + 2.0 * nsig);
+        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
+        if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
+    }
+    BICG_HIP(hipStreamSynchronize(c->sc));
+
+    double *p_seed = c->p_set + (size_t)seed * st;
+    Vecs &v = c->v;
+    const double t0 = now_sec();
+    c->cur_has_shift = false;
+    launch_shift_init(v, p_seed, c->S, c->red(0, PH_SH_INIT), c->sc);
+    group_now(c, 1, PH_SH_INIT);
+    fetch_scal(c);
+    int it = 0;
+    c->cur_shift = sigma[seed]; c->cur_has_shift = true;
+    while (!c->hS->done && it < o.max_iter) {
+        const int chunk = std::min(o.check_every, o.max_iter - it);
+        for (int j = 0; j < chunk; ++j) {
+            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SH_ALPHA));          // s = (A + sigma I) p[seed], (r#,s)
+            group_now(c, 1, PH_SH_ALPHA);
+            launch_shift_q(v, c->S, c->sc);                                 // r_old = r, q = r - alpha s
+            spmv(c, v.r, v.y, 3, v.r, c->red(0, PH_SH_OMEGA));              // y = (A + sigma I) q, (q,y), (q,q)
+            group_now(c, 2, PH_SH_OMEGA);
+            launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END), c->sc);
+            group_now(c, 2, PH_SH_END);
+            launch_shift_pseed(v, p_seed, c->S, c->sc);                     // p[seed] = r + beta (p[seed] - omega s)
+        }
+        it += chunk;
+        fetch_scal(c);
+    }
+    c->cur_has_shift = false; c->cur_shift = 0.0;
+    const double t1 = now_sec();
+
+    const int k = c->hS->k;
+    c->last_iters = k;
+    for (int j = 0; j < nsig; ++j)
+        BICG_HIP(hipMemcpy(x_set_host + (size_t)j * n, c->x_set + (size_t)j * st, sizeof(double) * n, hipMemcpyDeviceToHost));
+    BICG_HIP(hipMemcpy(r_host, c->v.r, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->iterations = k; res->dot_r = c->hS->dot_r; res->dot_zero = c->hS->dot_zero;
+        res->seconds = t1 - t0; res->iter_seconds = t1 - t0;
+    }
+    if (c->rank == 0 && !o.quiet) {   // reference src/shifted_solver.c:336-343
+        printf("Total iter   : %d\n", k);
+        printf("Final r      : %e\n", sqrt(c->hS->dot_r / c->hS->dot_zero));
+        printf("Total time   : %e [sec.] \n", t1 - t0);
+        printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / k);
+        fflush(stdout);
+    }
+    return k;
+}
+
 void check_square(const INFO_Matrix *info)
 {
     if (info->cols != info->rows) {   // reference src/solver.c:43-46
@@ -781,7 +897,7 @@ void bicg_destroy(bicg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->comm->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->hS) (void)hipHostFree(c->hS);
@@ -903,6 +1019,32 @@ int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
     out[7] = (unsigned)(c->sell_entries > c->sell_nnz ? c->sell_entries - c->sell_nnz : 0);   // padding entries
     return 0;
 }
+
+int bicg_solve_shifted(bicg_ctx *c, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len, int seed,
+                       const bicg_options *opt, bicg_result *res)
+{
+    return run_shifted(c, x_loc_set, r_loc, sigma, sigma_len, seed, opt, res);
+}
+
+static int dropin_shifted(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x_set, double *r, double *sigma, int nsig, int seed)
+{
+    check_square(i);
+    bicg_options opt;
+    env_options(&opt);
+    if (!getenv("BICG_TOL")) opt.tol = 1.0e-12;      // EPS of reference src/shifted_solver.c:5
+    bicg_ctx *c = bicg_create(d, o, i);
+    if (!c) die("bicg_create", "failed");
+    bicg_result res;
+    const int k = run_shifted(c, x_set, r, sigma, nsig, seed, &opt, &res);
+    bicg_destroy(c);
+    return k;
+}
+
+// ---- shifted drop-ins: reference src/shifted_solver.h:17-19. The three reference functions perform
+// the same arithmetic in a different order (their outputs are bit-identical to each other).
+int shifted_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicgstab_v2(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(d, o, i, x, r, sigma, n, seed); }
 
 // ---- drop-in entry points: reference src/solver.h:10-13
 int bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_BICGSTAB, d, o, i, x, r, 0, 0); }

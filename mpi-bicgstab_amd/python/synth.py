@@ -131,22 +131,32 @@ def banded(n: int, half_bw: int, diag_base: float | None = None, seed: int = 777
     return from_offsets(n, range(-half_bw, half_bw + 1), diag_base, seed)
 
 
-def stencil7(m: int, weights=(6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)) -> CSR:
-    """7-point stencil on an m^3 grid; weights = (centre, x-, x+, y-, y+, z-, z+)."""
+LAPLACE_WEIGHTS = (6.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0)
+
+
+def stencil7(m: int, weights=(6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0), rows=None) -> CSR:
+    """7-point stencil on an m^3 grid; weights = (centre, x-, x+, y-, y+, z-, z+).
+    rows=(lo, hi) builds only that row range (GLOBAL columns, cols = m^3): one GPU's slab of
+    BASELINE.json configs[3] (512^3 Laplacian: 8 slabs of 64 planes)."""
     n = m ** 3
-    idx = np.arange(n, dtype=np.int64)
+    lo, hi = (0, n) if rows is None else rows
+    idx = np.arange(lo, hi, dtype=np.int64)
     ix, iy, iz = idx % m, (idx // m) % m, idx // (m * m)
     cand = [  # (offset, mask, weight) in ascending column order
         (-m * m, iz > 0, weights[5]), (-m, iy > 0, weights[3]), (-1, ix > 0, weights[1]),
-        (0, np.ones(n, bool), weights[0]),
+        (0, np.ones(hi - lo, bool), weights[0]),
         (1, ix < m - 1, weights[2]), (m, iy < m - 1, weights[4]), (m * m, iz < m - 1, weights[6]),
     ]
     cols = np.stack([idx + o for o, _, _ in cand], axis=1)
     ok = np.stack([msk for _, msk, _ in cand], axis=1)
     vals = np.broadcast_to(np.array([w for _, _, w in cand], dtype=np.float64)[None, :], cols.shape)
-    ptr = np.zeros(n + 1, dtype=np.int64)
+    ptr = np.zeros(hi - lo + 1, dtype=np.int64)
     np.cumsum(ok.sum(axis=1), out=ptr[1:])
-    return CSR(n, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), vals[ok].copy())
+    return CSR(hi - lo, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), vals[ok].copy())
+
+
+def stencil7_nnz(m: int) -> int:
+    return 7 * m ** 3 - 6 * m * m
 
 
 def random_rows(n: int, max_row: int, seed: int = 1, empty_frac: float = 0.1, long_rows=()) -> CSR:

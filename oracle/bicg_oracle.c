@@ -370,6 +370,106 @@ static int solve_pipe(const orc_dist *d, double *x, double *r, orc_opts *o, int 
     return k;
 }
 
+/* y = (A + sigma I) x : MPI_csr_spmv_ovlap followed by my_daxpy(sigma, x, y), e.g. src/shifted_solver.c:261-262 */
+static void spmv_shift(const orc_dist *d, double sigma, const double *x, double *y)
+{
+    orc_spmv(d, x, y);
+    orc_daxpy((int)d->n, sigma, x, y);
+}
+
+/* reference src/shifted_solver.c:182-354 */
+int orc_shifted_lop(const orc_dist *d, double *x_set, double *r, const double *sigma, int nsig, int seed, orc_opts *o)
+{
+    const int n = (int)d->n;
+    int k = 0;
+    double *r_old = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *y = vec_new(d->n);
+    double *p_set = (double *)calloc((size_t)n * (size_t)nsig + 1, sizeof(double));      /* :223 calloc */
+    double *alpha = vec_new(nsig), *beta = vec_new(nsig), *omega = vec_new(nsig), *eta = vec_new(nsig),
+           *zeta = vec_new(nsig), *pi_new = vec_new(nsig), *pi_old = vec_new(nsig);
+    double alpha_old, beta_old, dot_r, dot_zero, rTr, rTs, qTq, qTy, rTr_old, max_zeta_pi;
+#define P_(j) (p_set + (size_t)(j) * (size_t)n)
+#define X_(j) (x_set + (size_t)(j) * (size_t)n)
+
+    rTr = orc_dist_dot(d, r, r);                    /* :238 */
+    orc_dcopy(n, r, rh);                            /* :240 */
+    for (int i = 0; i < nsig; ++i) {                /* :241-249 */
+        beta[i] = 0.0; alpha[i] = 1.0; eta[i] = 0.0; pi_old[i] = 1.0; pi_new[i] = 1.0; zeta[i] = 1.0;
+    }
+    orc_dcopy(n, r, P_(seed));                      /* :250 */
+    dot_r = rTr; dot_zero = rTr; max_zeta_pi = 1.0; /* :253-255 */
+
+    while (max_zeta_pi * max_zeta_pi * dot_r > o->tol * o->tol * dot_zero && k < o->max_iter) {   /* :257 */
+        spmv_shift(d, sigma[seed], P_(seed), s);            /* :259-260 */
+        rTs = orc_dist_dot(d, rh, s);                       /* :261 */
+        for (int j = 0; j < nsig; ++j) {                    /* :262-267 */
+            if (j == seed) continue;
+            beta[j] = (pi_old[j] / pi_new[j]) * (pi_old[j] / pi_new[j]) * beta[seed];
+            orc_dscal(n, beta[j], P_(j));
+            orc_daxpy(n, 1.0 / (pi_new[j] * zeta[j]), r, P_(j));
+        }
+        orc_dcopy(nsig, pi_new, pi_old);                    /* :268 */
+        orc_dcopy(n, r, r_old);                             /* :269 */
+        alpha_old = alpha[seed]; beta_old = beta[seed];     /* :270-271 */
+
+        alpha[seed] = rTr / rTs;                            /* :274 */
+        orc_daxpy(n, -alpha[seed], s, r);                   /* :275  q */
+        spmv_shift(d, sigma[seed], r, y);                   /* :276-277 */
+        qTq = orc_dist_dot(d, r, r);                        /* :279 */
+        qTy = orc_dist_dot(d, r, y);                        /* :280 */
+        for (int j = 0; j < nsig; ++j) {                    /* :281-287 */
+            if (j == seed) continue;
+            eta[j] = (beta_old / alpha_old) * alpha[seed] * eta[j] - (sigma[seed] - sigma[j]) * alpha[seed] * pi_old[j];
+            pi_new[j] = eta[j] + pi_old[j];
+            alpha[j] = (pi_old[j] / pi_new[j]) * alpha[seed];
+        }
+        omega[seed] = qTq / qTy;                            /* :291 */
+        orc_daxpy(n, alpha[seed], P_(seed), X_(seed));      /* :292 */
+        orc_daxpy(n, omega[seed], r, X_(seed));             /* :293 */
+        for (int j = 0; j < nsig; ++j) {                    /* :294-302 */
+            if (j == seed) continue;
+            omega[j] = omega[seed] / (1.0 - omega[seed] * (sigma[seed] - sigma[j]));
+            orc_daxpy(n, omega[j] / (pi_new[j] * zeta[j]), r, X_(j));
+            orc_daxpy(n, alpha[j], P_(j), X_(j));
+            orc_daxpy(n, omega[j] / (alpha[j] * zeta[j] * pi_new[j]), r, P_(j));
+            orc_daxpy(n, -omega[j] / (alpha[j] * zeta[j] * pi_old[j]), r_old, P_(j));
+            zeta[j] = (1.0 - omega[seed] * (sigma[seed] - sigma[j])) * zeta[j];
+        }
+        orc_daxpy(n, -omega[seed], y, r);                   /* :303 */
+        dot_r = orc_dist_dot(d, r, r);                      /* :304 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);                       /* :306 */
+        beta[seed] = (alpha[seed] / omega[seed]) * (rTr / rTr_old);   /* :310 */
+        max_zeta_pi = 1.0;                                  /* :311-316 */
+        for (int j = 0; j < nsig; ++j) {
+            if (j == seed) continue;
+            double a = 1.0 / (zeta[j] * pi_new[j]);
+            if (a < 0) a = -a;
+            if (a > max_zeta_pi) max_zeta_pi = a;
+        }
+        orc_dscal(n, beta[seed], P_(seed));                 /* :317 */
+        orc_daxpy(n, 1.0, r, P_(seed));                     /* :318 */
+        orc_daxpy(n, -beta[seed] * omega[seed], s, P_(seed));   /* :319 */
+        k++;
+        trace_put(o, k, alpha[seed], omega[seed], beta[seed], dot_r);
+    }
+#undef P_
+#undef X_
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(r_old); free(rh); free(s); free(y); free(p_set);
+    free(alpha); free(beta); free(omega); free(eta); free(zeta); free(pi_new); free(pi_old);
+    return k;
+}
+
+int orc_shifted_lop_coo(int P, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                        const double *val, double *x_set, double *r, const double *sigma, int nsig, int seed,
+                        orc_opts *o)
+{
+    orc_dist *d = orc_dist_from_coo(n, nnz, row, col, val, P);
+    int k = orc_shifted_lop(d, x_set, r, sigma, nsig, seed, o);
+    orc_dist_free(d);
+    return k;
+}
+
 int orc_solve(int method, const orc_dist *d, double *x, double *r, orc_opts *o)
 {
     switch (method) {

@@ -126,6 +126,13 @@ def gpu_worker(rank, world, port, kind, outdir):
             tr = ctx.trace(got["k"])
             h = min(5, got["k"], orc["k"])
             np.testing.assert_allclose(tr["dotr"][:h], orc["dotr"][:h], rtol=1e-7)
+        # shifted systems, 5 shifts, seed 2 (reference src/test_shifted.c:95-111 set-up)
+        sigma, seed = 0.01 * (np.arange(5) + 1.0), 2
+        bs_full = b_full + sigma[seed] * np.ones(A.rows)
+        orc = O.solve_shifted(A.rows, row, col, val, bs_full, sigma, seed, nranks=world)
+        got = ctx.solve_shifted(bs_full[lo:lo + nl], sigma, seed, check_every=4)
+        assert abs(got["k"] - orc["k"]) <= 2, (got["k"], orc["k"])
+        assert np.abs(got["x"] - orc["x"][:, lo:lo + nl]).max() <= 1e-8 * max(1.0, np.abs(orc["x"]).max())
         ctx.close()
         dist.barrier()
         H.lib().bicg_comm_finalize()

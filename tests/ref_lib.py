@@ -48,8 +48,37 @@ def lib():
         _lib = C.CDLL(LIBREF)
         _lib.my_ddot.restype = C.c_double
         for name in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
-            getattr(_lib, name).restype = C.c_int
+            if hasattr(_lib, name):
+                getattr(_lib, name).restype = C.c_int
     return _lib
+
+
+LIBREF_SHIFTED = os.path.join(REF_DIR, "libref_shifted.so")
+_shifted = None
+
+
+def shifted_lib():
+    """reference src/shifted_solver.c (EPS 1e-12, MAX_ITER 1000 compiled in, :5-6)"""
+    global _shifted
+    if _shifted is None:
+        lib()                                    # MPI singleton init
+        _shifted = C.CDLL(LIBREF_SHIFTED)
+    return _shifted
+
+
+def solve_shifted(fname, M: RefMatrix, b, sigma, seed):
+    """x_set [nsig][n] shift-major (reference src/shifted_solver.c:118-123), r: seed residual."""
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    x = np.zeros(len(sigma) * M.n)
+    r = np.array(b, dtype=np.float64)
+    fn = getattr(shifted_lib(), fname)
+    fn.restype = C.c_int
+    args = [C.byref(M.diag), C.byref(M.offd), C.byref(M.info), x.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+            sigma.ctypes.data_as(_dp), C.c_int(len(sigma))]
+    if fname != "shifted_bicgstab":
+        args.append(C.c_int(seed))
+    k = fn(*args)
+    return dict(k=k, x=x.reshape(len(sigma), M.n), r=r)
 
 
 class RefMatrix:
