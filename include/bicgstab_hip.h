@@ -148,6 +148,8 @@ typedef struct {
     double iter_seconds;   /* wall time of the iteration loop only (after the set-up phase) */
     double spmv_ms_total;  /* sum of the kernel durations of all timed SpMVs (time_kernels) */
     int    spmv_launches;  /* number of SpMVs timed (an SpMV may consist of up to 4 kernels) */
+    int    breakdown_iteration; /* first iteration with a non-finite alpha/beta/omega/(r,r); 0 = none.
+                              The reference does not detect breakdown (it iterates on NaNs). */
 } bicg_result;
 
 void bicg_default_options(bicg_options *o);

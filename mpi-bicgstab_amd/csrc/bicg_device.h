@@ -62,7 +62,7 @@ struct Scal {
     int    k;                    // iterations completed
     int    max_iter;
     int    done;                 // sticky: set when the reference's while condition fails
-    int    pad;
+    int    breakdown_k;          // first iteration whose recurrence scalars were not finite (0 = none)
     double *tr_alpha, *tr_omega, *tr_beta, *tr_dotr;   // optional trace, [max_iter]
     ShiftDev *sh;                // shifted solver only
 };
@@ -119,7 +119,7 @@ struct SpmvArgs {
     int     has_shift;
     Scal   *S;
     Reduce  red;
-    int     variant;        // CSR SpMV kernel variant bits (see k_spmv)
+    int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
 };
 
@@ -166,7 +166,8 @@ void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t st);
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 
 unsigned sell_grid(uint32_t ngroups, int per_wg); // workgroups launched for ngroups 256-row groups
+void set_vec_nt(int on);               // experiment: non-temporal vector traffic in the element-wise kernels
 unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
-unsigned spmv_grid(uint32_t nlist, int variant);   // workgroups used by the SpMV for nlist row blocks
+unsigned spmv_grid(uint32_t nlist);   // workgroups used by the CSR SpMV for nlist row blocks
 
 }  // namespace bicg

@@ -46,6 +46,13 @@ __device__ __forceinline__ void finish_iteration(Scal *S, double alpha_used)
     }
     // reference loop condition, src/solver.c:86 / 216 / 351
     if (!(S->dot_r > S->tol2 * S->dot_zero && k < S->max_iter)) S->done = 1;
+    // Breakdown guard: the reference keeps iterating on NaNs until
+    // MAX_ITER (its loop condition is false for NaN only by accident of the comparison); here a
+    // non-finite recurrence scalar is recorded -- the iteration count and vectors are left as the
+    // reference would leave them at this k.
+    if (!(isfinite(S->alpha) && isfinite(S->beta) && isfinite(S->omega) && isfinite(S->dot_r))) {
+        if (!S->breakdown_k) S->breakdown_k = k;
+    }
 }
 
 __device__ void apply_phase(Scal *S, int phase)
@@ -302,14 +309,13 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
 // ------------------------------------------------------------------------------------------
 // CSR SpMV, row-block stream
 // ------------------------------------------------------------------------------------------
-// VAR bit 0: XCD-aware mapping -- workgroup w runs on XCD w % 8 (observed dispatch order), so XCD k
-//            is given the k-th contiguous eighth of the row blocks and its private L2 only ever
-//            fetches that eighth of x (round-robin mapping made all 8 L2s fetch all of x: measured
-//            386 MB of fabric reads per SpMV against 306 MB algorithmic).
-// VAR bit 1: 16-byte loads -- the block's window starts at a multiple of 4 entries and every thread
-//            loads 2 x (uint4 col + 2 double2 val) instead of 8 x (dword + dwordx2).
-// VAR bit 2: non-temporal val/col loads (read exactly once; keep the L2 for x).
-constexpr int kXcds = 8;
+// CSR row-block stream kernel (ragged / long-row groups; the whole matrix when BICG_NO_SELL=1).
+// Variants that were measured on Transport and dropped (profiles/r01_csr_baseline): an XCD-aware
+// block mapping (fabric reads 386 -> 309 MB, wall time +3-5 %), 16-byte val/col loads (+2 us), a
+// 2048-workgroup persistent grid-stride form (67.8 vs 60.5 us) and a software-pipelined persistent
+// form that prefetches the next block's stream (67 us, flat in the number of resident workgroups):
+// the kernel is bound by the vector L1's tag rate on the row-major x gather, which is what the
+// sliced-ELL kernel below removes.
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef double   f64x2 __attribute__((ext_vector_type(2)));
 
@@ -319,14 +325,13 @@ template <bool NT, class T> __device__ __forceinline__ T stream_load(const T *p)
     return *p;
 }
 
-template <int NDOT, bool OFFD, int VAR>
+template <int NDOT, bool OFFD, bool NT>
 __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 {
     // The sticky convergence flag is requested here but only consumed where state would be
     // modified (y stores, dot publication): an early `if (done) return` would put one more
     // dependent global load in front of every workgroup's stream.
     const int done = a.S->done;
-    constexpr bool XCD = (VAR & 1) != 0, WIDE = (VAR & 2) != 0, NT = (VAR & 4) != 0;
     __shared__ __attribute__((aligned(16))) double prod[kChunk];
     __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
 
@@ -337,24 +342,14 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 #pragma unroll
     for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
 
-    // which row blocks this workgroup handles: [first, last) with stride `step`
-    unsigned first, last, step;
-    if (XCD) {
-        const unsigned per = (a.nlist + kXcds - 1) / kXcds;          // row blocks per XCD
-        const unsigned xcd = blockIdx.x % kXcds, lane = blockIdx.x / kXcds;
-        first = xcd * per + lane;
-        last = (xcd + 1) * per < a.nlist ? (xcd + 1) * per : a.nlist;
-        step = gridDim.x / kXcds;
-    } else {
-        first = blockIdx.x; last = a.nlist; step = gridDim.x;
-    }
+    const unsigned first = blockIdx.x, last = a.nlist, step = gridDim.x;
 
     for (unsigned bi = first; bi < last; bi += step) {
         // one 16-byte descriptor per row block {first row, end row, first nnz, end nnz}: a single
         // wave-uniform load instead of the dependent chain rowblk -> ptr -> val/col
         const uint4 d = a.desc[bi];
         const uint32_t r0 = d.x, r1 = d.y, j0 = d.z, j1 = d.w;
-        const uint32_t jw = WIDE ? (j0 & ~3u) : j0;                  // start of the staged window
+        const uint32_t jw = j0;                                      // start of the staged window
 
         // this thread's (first) row: its pointers and dot operand are requested now, together with
         // the val/col stream, not after the barrier
@@ -397,33 +392,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 
         if (j1 - jw <= (uint32_t)kChunk) {
             // stream: all val/col loads of the block are issued before the first gather
-            if (WIDE) {
-                u32x4 c[2];
-                f64x2 v[2][2];
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    const uint32_t j = jw + 4u * (tid + i * kBlock);
-                    if (j < j1) {   // arrays are padded by 4 entries: the group may straddle j1
-                        c[i] = stream_load<NT>(reinterpret_cast<const u32x4 *>(a.diag.col + j));
-                        v[i][0] = stream_load<NT>(reinterpret_cast<const f64x2 *>(a.diag.val + j));
-                        v[i][1] = stream_load<NT>(reinterpret_cast<const f64x2 *>(a.diag.val + j + 2));
-                        if (j + 1 >= j1) c[i].y = 0u;
-                        if (j + 2 >= j1) c[i].z = 0u;
-                        if (j + 3 >= j1) c[i].w = 0u;
-                    } else {
-                        c[i] = (u32x4)(0u);
-                        v[i][0] = (f64x2)(0.0); v[i][1] = (f64x2)(0.0);
-                    }
-                }
-#pragma unroll
-                for (int i = 0; i < 2; ++i) {
-                    f64x2 p0, p1;
-                    p0.x = v[i][0].x * x[c[i].x]; p0.y = v[i][0].y * x[c[i].y];
-                    p1.x = v[i][1].x * x[c[i].z]; p1.y = v[i][1].y * x[c[i].w];
-                    f64x2 *dst = reinterpret_cast<f64x2 *>(prod + 4u * (tid + i * kBlock));
-                    dst[0] = p0; dst[1] = p1;
-                }
-            } else {
+            {
                 uint32_t c[kNnzPerThread];
                 double   v[kNnzPerThread];
 #pragma unroll
@@ -466,159 +435,21 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
     if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
 }
 
-// ------------------------------------------------------------------------------------------
-// Software-pipelined variant (VAR bit 3): a persistent workgroup walks its row blocks and issues
-// the NEXT block's val/col/ptr loads as soon as the current block's products are in LDS, so HBM
-// streaming continues underneath the LDS row reduction, the barriers and the y stores. With one
-// row block per workgroup the stream is only in flight for ~40 % of a workgroup's lifetime and the
-// 8 resident workgroups per CU cannot cover the HBM latency (measured 62 us against a 40 us
-// pure-read floor for the same bytes).
-// ------------------------------------------------------------------------------------------
-struct RowBlockLoads {
-    uint32_t c[kNnzPerThread];
-    double   v[kNnzPerThread];
-    uint32_t pa, pb, oa, ob;
-    double   u;
-    bool     mine;
-};
-
-template <int NDOT, bool OFFD>
-__device__ __forceinline__ void issue_block_loads(const SpmvArgs &a, const uint4 d, unsigned tid, RowBlockLoads &L)
-{
-    const uint32_t j0 = d.z, j1 = d.w;
-    if (j1 - j0 <= (uint32_t)kChunk) {
-#pragma unroll
-        for (int i = 0; i < kNnzPerThread; ++i) {
-            const uint32_t j = j0 + tid + i * kBlock;
-            const bool ok = j < j1;
-            L.c[i] = ok ? a.diag.col[j] : 0u;
-            L.v[i] = ok ? a.diag.val[j] : 0.0;
-        }
-    }
-    const uint32_t rme = d.x + tid;
-    L.mine = rme < d.y;
-    L.pa = L.mine ? a.diag.ptr[rme] : 0u;
-    L.pb = L.mine ? a.diag.ptr[rme + 1] : 0u;
-    L.oa = 0u; L.ob = 0u; L.u = 0.0;
-    if (OFFD && L.mine) { L.oa = a.offd.ptr[rme]; L.ob = a.offd.ptr[rme + 1]; }
-    if (NDOT >= 1 && L.mine) L.u = a.u[rme];
-}
-
-template <int NDOT, bool OFFD>
-__global__ void __launch_bounds__(kBlock) k_spmv_pipe(SpmvArgs a)
-{
-    if (a.S->done) return;
-    __shared__ __attribute__((aligned(16))) double prod[kChunk];
-    __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
-
-    const unsigned tid = threadIdx.x;
-    const double *__restrict__ x = a.x;
-    double acc[NDOT > 0 ? NDOT : 1];
-#pragma unroll
-    for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
-
-    auto finish_row = [&](uint32_t r, uint32_t a0, uint32_t a1, uint32_t o0, uint32_t o1, double ur) {
-        double sum = 0.0;
-        for (uint32_t k = a0; k < a1; k += 8) {      // see k_spmv: stored order, +0.0 padding is exact
-            double t[8];
-#pragma unroll
-            for (int e = 0; e < 8; ++e) {
-                const uint32_t kk = k + e < a1 ? k + e : a1 - 1;
-                t[e] = prod[kk];
-            }
-#pragma unroll
-            for (int e = 0; e < 8; ++e) sum += (k + e < a1) ? t[e] : 0.0;
-        }
-        double yi = 0.0 + sum;
-        if (OFFD) {
-            double so = 0.0;
-            for (uint32_t k = o0; k < o1; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
-            yi += so;
-        }
-        a.y[r] = yi;
-        if (NDOT >= 1) acc[0] += ur * yi;
-        if (NDOT >= 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
-    };
-
-    const unsigned step = gridDim.x;
-    unsigned bi = blockIdx.x;
-    RowBlockLoads L;
-    uint4 d = make_uint4(0u, 0u, 0u, 0u);
-    if (bi < a.nlist) { d = a.desc[bi]; issue_block_loads<NDOT, OFFD>(a, d, tid, L); }
-
-    while (bi < a.nlist) {
-        const unsigned nbi = bi + step;
-        const bool more = nbi < a.nlist;
-        const uint4 dn = more ? a.desc[nbi] : make_uint4(0u, 0u, 0u, 0u);
-        const uint32_t r0 = d.x, r1 = d.y, j0 = d.z, j1 = d.w;
-        // what the row phase needs from this block's loads, before L is reused for the next block
-        const bool mine = L.mine;
-        const uint32_t pa = L.pa, pb = L.pb, oa = L.oa, ob = L.ob;
-        const double ume = L.u;
-
-        if (j1 - j0 <= (uint32_t)kChunk) {
-#pragma unroll
-            for (int i = 0; i < kNnzPerThread; ++i) prod[tid + i * kBlock] = L.v[i] * x[L.c[i]];
-            if (more) issue_block_loads<NDOT, OFFD>(a, dn, tid, L);     // next block streams from here on
-            __syncthreads();
-            if (mine) finish_row(r0 + tid, pa - j0, pb - j0, oa, ob, ume);
-            for (uint32_t r = r0 + tid + kBlock; r < r1; r += kBlock)
-                finish_row(r, a.diag.ptr[r] - j0, a.diag.ptr[r + 1] - j0, OFFD ? a.offd.ptr[r] : 0u,
-                           OFFD ? a.offd.ptr[r + 1] : 0u, NDOT >= 1 ? a.u[r] : 0.0);
-        } else {
-            if (more) issue_block_loads<NDOT, OFFD>(a, dn, tid, L);
-            double part[1] = {0.0};
-            for (uint32_t j = j0 + tid; j < j1; j += kBlock) part[0] += a.diag.val[j] * x[a.diag.col[j]];
-            block_sum<1>(part, sm);
-            if (tid == 0) {
-                double yi = 0.0 + part[0];
-                if (OFFD) {
-                    double so = 0.0;
-                    for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
-                    yi += so;
-                }
-                if (a.has_shift) yi += a.shift * x[r0];
-                a.y[r0] = yi;
-                if (NDOT >= 1) acc[0] += ume * yi;
-                if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
-                if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
-            }
-        }
-        __syncthreads();   // prod is rewritten by the next row block
-        bi = nbi; d = dn;
-    }
-    if (NDOT > 0) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
-}
-
-// persistent grid for the pipelined variant: every workgroup gets the same number of row blocks (+-1)
-static unsigned spmv_grid_pipe(uint32_t nlist, unsigned maxgrid)
+// One workgroup per row block: the hardware dispatcher balances the ~12k workgroups of a
+// Transport-sized matrix better than a persistent grid; beyond kSpmvMaxGrid row blocks the kernel's
+// loop strides.
+unsigned spmv_grid(uint32_t nlist)
 {
     if (nlist == 0) return 0;
-    const unsigned per = (nlist + maxgrid - 1) / maxgrid;
-    return (nlist + per - 1) / per;
-}
-
-// One workgroup per row block (rounded up to a multiple of the 8 XCDs): the hardware dispatcher
-// balances the ~12k workgroups of a Transport-sized matrix better than a 2048-workgroup persistent
-// grid does (60.5 vs 67.8 us measured); beyond kSpmvMaxGrid row blocks the kernel's loop strides.
-unsigned spmv_grid(uint32_t nlist, int variant)
-{
-    if (nlist == 0) return 0;
-    if (variant & 8) return spmv_grid_pipe(nlist, (variant >> 4) > 0 ? (unsigned)(variant >> 4) * 256u : (unsigned)kMaxGrid);
-    unsigned g = ((nlist + kXcds - 1) / kXcds) * kXcds;
-    return g < (unsigned)kSpmvMaxGrid ? g : (unsigned)kSpmvMaxGrid;
+    return nlist < (uint32_t)kSpmvMaxGrid ? nlist : (unsigned)kSpmvMaxGrid;
 }
 
 template <int NDOT, bool OFFD>
 static void launch_spmv_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
-    dim3 g(spmv_grid(a.nlist, a.variant)), b(kBlock);
-    if (a.variant & 8) { launch_timed(k_spmv_pipe<NDOT, OFFD>, g, b, st, e0, e1, a); return; }
-    switch (a.variant & 7) {
-#define V(n) case n: launch_timed(k_spmv<NDOT, OFFD, n>, g, b, st, e0, e1, a); break
-        V(0); V(1); V(2); V(3); V(4); V(5); V(6); V(7);
-#undef V
-    }
+    dim3 g(spmv_grid(a.nlist)), b(kBlock);
+    if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true>, g, b, st, e0, e1, a);
+    else launch_timed(k_spmv<NDOT, OFFD, false>, g, b, st, e0, e1, a);
 }
 
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
@@ -751,7 +582,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     dim3 g(sell_grid(a.nlist, a.groups_per_wg)), b(kBlock);
 #define SELL_CASE(ND, OF)                                                                          \
     do {                                                                                           \
-        const bool nt = !(a.variant & 16), c16 = a.sell.col16 != nullptr;                          \
+        const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;                                  \
         if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true>, g, b, st, e0, e1, a);         \
         else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false>, g, b, st, e0, e1, a);          \
         else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true>, g, b, st, e0, e1, a);         \
@@ -798,15 +629,25 @@ __device__ __forceinline__ d2 operator*(double s, d2 q) { return {s * q.a, s * q
 __device__ __forceinline__ double hsum(d2 p) { return p.a + p.b; }
 __device__ __forceinline__ double hsum(double p) { return p; }
 
+// experiment switch (BICG_VEC_NT): non-temporal vector traffic in the element-wise kernels
+__device__ int g_vec_nt = 0;
+void set_vec_nt(int on) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vec_nt), &on, sizeof(int)); }
+
 template <class T> __device__ __forceinline__ T ld(const double *p, uint32_t i);
 template <> __device__ __forceinline__ double ld<double>(const double *p, uint32_t i) { return p[i]; }
 template <> __device__ __forceinline__ d2 ld<d2>(const double *p, uint32_t i)
 {
-    const double2 t = *reinterpret_cast<const double2 *>(p + i);
+    const f64x2 *q = reinterpret_cast<const f64x2 *>(p + i);
+    const f64x2 t = g_vec_nt ? __builtin_nontemporal_load(q) : *q;
     return {t.x, t.y};
 }
 __device__ __forceinline__ void st(double *p, uint32_t i, double v) { p[i] = v; }
-__device__ __forceinline__ void st(double *p, uint32_t i, d2 v) { *reinterpret_cast<double2 *>(p + i) = make_double2(v.a, v.b); }
+__device__ __forceinline__ void st(double *p, uint32_t i, d2 v)
+{
+    f64x2 t; t.x = v.a; t.y = v.b;
+    f64x2 *q = reinterpret_cast<f64x2 *>(p + i);
+    if (g_vec_nt) __builtin_nontemporal_store(t, q); else *q = t;
+}
 
 // F::ND dot products, F::load(S) fetches the scalars once, F::apply<T>(i, acc) handles element(s) i.
 template <class F>

@@ -65,7 +65,6 @@ struct bicg_ctx {
     uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
     uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // CSR row-block descriptors: interior / halo-touching
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
-    int spmv_variant = 0;
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
     bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
@@ -126,6 +125,7 @@ struct bicg_ctx {
     // BICG_FORCE_COMM=1 (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
     // apply kernels, two streams) even with one rank, so that it can be exercised on a one-GPU box
     bool force_comm = false;
+    int vec_nt = 0;
     bool single() const { return nranks == 1 && !force_comm; }
 
     // Use the second (communication) stream to overlap the halo exchange with the interior rows and
@@ -205,13 +205,13 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.desc = nullptr; a.nlist = 0;
     a.x = xin; a.y = yout; a.u = u; a.S = c->S;
-    a.variant = (c->spmv_variant & ~16) | (c->sell_nt ? 0 : 16);
+    a.nt = c->sell_nt ? 1 : 0;
     a.shift = c->cur_shift; a.has_shift = c->cur_has_shift ? 1 : 0;
     // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
     // order): {sliced-ELL groups, CSR row blocks} x {interior, halo-touching}.
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
-    const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int, c->spmv_variant);
-    const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd, c->spmv_variant);
+    const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
+    const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
     red.expected = g_si + g_ci + g_sb + g_cb;
     red.slot_base = 0;
     a.red = red;
@@ -388,6 +388,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     if (o.check_every < 1) o.check_every = 1;
     c->method = method;
     BICG_HIP(hipSetDevice(c->comm->device));
+    set_vec_nt(c->vec_nt);
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -532,7 +533,10 @@ int run_end(bicg_ctx *c, bicg_result *res)
         res->iter_seconds = c->t_iter;
         res->spmv_ms_total = spmv_ms;
         res->spmv_launches = spmv_n;
+        res->breakdown_iteration = c->hS->breakdown_k;
     }
+    if (c->hS->breakdown_k && c->rank == 0 && !o.quiet)
+        fprintf(stderr, "bicgstab_hip: recurrence broke down (non-finite scalar) at iteration %d\n", c->hS->breakdown_k);
     if (talk) {   // reference src/solver.c:134-141, verbatim
         printf("Total iter   : %d\n", k);
         printf("Final r      : %e\n", sqrt(c->hS->dot_r / c->hS->dot_zero));
@@ -719,10 +723,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->nnz_d = diag->ptr[diag->rows];
     const int P = c->nranks;
 
-    if (const char *sv = getenv("BICG_SPMV_VARIANT")) c->spmv_variant = atoi(sv);
     const bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
+    if (const char *sv = getenv("BICG_VEC_NT")) c->vec_nt = atoi(sv);
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     c->overlap = c->nnz_d >= 6000000u;
     if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;

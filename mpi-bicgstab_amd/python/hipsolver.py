@@ -40,7 +40,8 @@ class Options(C.Structure):
 
 class Result(C.Structure):
     _fields_ = [("iterations", C.c_int), ("dot_r", C.c_double), ("dot_zero", C.c_double), ("seconds", C.c_double),
-                ("iter_seconds", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int)]
+                ("iter_seconds", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int),
+                ("breakdown_iteration", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, _dp, C.c_int, C.c_void_p)

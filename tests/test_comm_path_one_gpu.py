@@ -58,22 +58,24 @@ def test_graph_replay_single_rank(problem):
     _same(_solve_all(A, b, BICG_GRAPH=1), ref)
 
 
+@pytest.mark.parametrize("overlap", [0, 1])
 @pytest.mark.parametrize("graph", [0, 1])
-def test_forced_comm_trivial_transport(problem, graph):
+def test_forced_comm_trivial_transport(problem, graph, overlap):
     A, b, ref = problem
     H.lib().bicg_comm_init_single(0)
-    _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph), ref)
+    _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph, BICG_OVERLAP=overlap), ref)
 
 
+@pytest.mark.parametrize("overlap", [0, 1])      # 1 = two-stream mode: halo / all-reduce on the communication stream
 @pytest.mark.parametrize("graph", [0, 1])
-def test_forced_comm_one_rank_rccl(problem, graph, monkeypatch):
+def test_forced_comm_one_rank_rccl(problem, graph, overlap, monkeypatch):
     A, b, ref = problem
     monkeypatch.setenv("BICG_FORCE_COMM", "1")
     buf = (C.c_char * 128)()
     H.lib().bicg_comm_unique_id(buf)
     H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
     try:
-        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph), ref)
+        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph, BICG_OVERLAP=overlap), ref)
     finally:
         monkeypatch.delenv("BICG_FORCE_COMM")
         H.lib().bicg_comm_init_single(0)

@@ -1,0 +1,88 @@
+"""BASELINE.json's full size on the GPU (`-m gpu`): the Transport-shaped matrix (1 602 111 rows,
+23 921 209 non-zeros) -- SpMV bit-exact against the oracle, size-independent properties (linearity,
+true vs recursive residual), and the first iterations of every solver against the oracle."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from mpi_bicgstab_amd import hipsolver as H
+from mpi_bicgstab_amd import synth
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def big():
+    H.lib().bicg_comm_init_single(0)
+    A = synth.transport_like(scale_decades=2.0)
+    row, col, val = A.to_coo()
+    ctx = H.Context(H.single_rank_blocks(A))
+    yield A, (row, col, val), ctx
+    ctx.close()
+
+
+def test_plan_is_sliced_ell(big):
+    A, _, ctx = big
+    info = ctx.plan_info()
+    assert info["sell_rows"] == A.rows                   # banded: every group on the sliced-ELL path
+    assert info["sell_padding"] <= 0.01 * A.nnz
+
+
+def test_spmv_bitexact_and_linear(big):
+    A, (row, col, val), ctx = big
+    rng = np.random.default_rng(0)
+    x, z = rng.standard_normal(A.rows), rng.standard_normal(A.rows)
+    y = ctx.spmv(x)
+    assert np.array_equal(y, O.spmv(A.rows, row, col, val, x))          # 1.6 M rows, bit for bit
+    lhs = ctx.spmv(2.5 * x - 0.75 * z)
+    rhs = 2.5 * y - 0.75 * ctx.spmv(z)
+    scale = np.abs(A.val).max() * 15 * (np.abs(x).max() + np.abs(z).max())
+    assert np.abs(lhs - rhs).max() <= 1e-13 * scale
+    d = ctx.dot(x, y)
+    assert abs(d - float(np.dot(x, y))) <= 1e-11 * float(np.abs(x * y).sum())
+
+
+@pytest.mark.parametrize("method", ["bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"])
+def test_first_iterations_and_residual_identity(big, method):
+    A, (row, col, val), ctx = big
+    b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+    k_fix = 12
+    orc = O.solve(method, A.rows, row, col, val, b, tol=0.0, max_iter=k_fix, krr=5, nrr=1)
+    got = ctx.solve(method, b, tol=0.0, max_iter=k_fix, krr=5, nrr=1, check_every=k_fix)
+    assert got["k"] == orc["k"] == k_fix
+    tr = ctx.trace(k_fix)
+    for key in ("alpha", "omega", "beta", "dotr"):
+        np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=key)
+    # the recursive residual the solver returns is the true residual b - A x (to rounding)
+    true_r = b - O.spmv(A.rows, row, col, val, got["x"])
+    assert np.linalg.norm(true_r - got["r"]) <= 1e-9 * np.linalg.norm(b)
+    assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
+
+
+def test_hybrid_plan_with_ragged_rows():
+    """long / ragged rows push their 256-row groups to the CSR kernel, the rest stays sliced-ELL"""
+    H.lib().bicg_comm_init_single(0)
+    A = synth.from_offsets(60000, (0, 1, -1, 200, -200), diag_base=8.0, seed=2)
+    # make rows 1000..1009 dense-ish (3000 entries each) by rebuilding those rows
+    ptr = A.ptr.astype(np.int64)
+    cols, vals, lens = [], [], []
+    rng = np.random.default_rng(7)
+    for r in range(A.rows):
+        if 1000 <= r < 1010:
+            c = np.sort(rng.choice(A.rows, size=3000, replace=False)); v = rng.uniform(-1e-3, 1e-3, size=3000)
+            v[np.searchsorted(c, r) % 3000] += 0.0
+        else:
+            c, v = A.col[ptr[r]:ptr[r + 1]], A.val[ptr[r]:ptr[r + 1]]
+        cols.append(c); vals.append(v); lens.append(len(c))
+    p2 = np.zeros(A.rows + 1, dtype=np.int64); np.cumsum(lens, out=p2[1:])
+    B = synth.CSR(A.rows, A.rows, p2.astype(np.uint32), np.concatenate(cols).astype(np.uint32), np.concatenate(vals))
+    ctx = H.Context(H.single_rank_blocks(B))
+    info = ctx.plan_info()
+    assert 0 < info["sell_rows"] < B.rows
+    x = rng.standard_normal(B.rows)
+    row, col, val = B.to_coo()
+    y, y_orc = ctx.spmv(x), O.spmv(B.rows, row, col, val, x)
+    short = np.diff(p2) <= 2044
+    assert np.array_equal(y[short], y_orc[short])
+    assert np.abs(y - y_orc).max() <= 1e-12 * np.abs(y_orc).max()
+    ctx.close()
