@@ -173,8 +173,9 @@ def main():
         nsh, seed = 16, 7
         sigma = (np.arange(nsh) + 1.0) * 0.01 / nsh
         ks = min(K, 100)
-        rs = ctx.solve_shifted(b + sigma[seed] * ones, sigma, seed, tol=0.0, max_iter=ks, check_every=ks)
-        variants[f"shifted_lopbicgstab_{nsh}shifts"] = 1e3 * rs["result"].seconds / max(rs["k"], 1)
+        for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab"):
+            rs = ctx.solve_shifted(b + sigma[seed] * ones, sigma, seed, tol=0.0, max_iter=ks, check_every=ks, which=which)
+            variants[f"{which}_{nsh}shifts"] = 1e3 * rs["result"].seconds / max(rs["k"], 1)
     spmv_alone_ms = ctx.spmv_bench(200)
 
     cpu = None

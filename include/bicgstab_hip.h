@@ -73,21 +73,27 @@ int pipe_bicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A
 int pipe_bicgstab_rr(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc, double *r_loc, int krr, int nrr);
 
 /* Shifted systems (A + sigma_j I) x_j = b, j = 0..sigma_len-1, solved with ONE Krylov recurrence on
- * the seed system A + sigma[seed] I (2 SpMV per iteration whatever the number of shifts):
+ * the seed system (2 SpMV per iteration whatever the number of shifts) -- all six entry points of
+ * reference src/shifted_solver.h:16-21:
  *
- *   shifted_lopbicgstab            <- src/shifted_solver.h:17 (implementation src/shifted_solver.c:182-354)
- *   shifted_lopbicgstab_v2         <- src/shifted_solver.h:18 (:357-529)
- *   shifted_lopbicgstab_nooverlap  <- src/shifted_solver.h:19 (:531-701)
+ *   shifted_bicgstab                    <- :16 (src/shifted_solver.c:13-180)   seed = A, xi/tau recurrences
+ *   shifted_lopbicgstab                 <- :17 (:182-354)   seed = A + sigma[seed] I
+ *   shifted_lopbicgstab_v2              <- :18 (:357-529)   same arithmetic as :17, re-ordered
+ *   shifted_lopbicgstab_nooverlap       <- :19 (:531-701)   same arithmetic as :17, re-ordered
+ *   shifted_pipe_lopbicgstab            <- :20 (:703-895)   pipelined recurrence
+ *   shifted_pipe_lopbicgstab_nooverlap  <- :21 (:897-1086)  same arithmetic as :20, re-ordered
  *
- * The three reference functions order the same arithmetic differently (their outputs are
- * bit-identical); all three symbols resolve to one implementation here. x_loc_set is shift-major,
- * x_loc_set[j * local_rows + i] (src/shifted_solver.c:118-123), in = initial guess (the reference's
- * drivers pass 0), out = the sigma_len solutions; r_loc in = b, out = seed residual. Convergence:
- * max_j |1/(zeta_j pi_j)|^2 (r,r) <= EPS^2 (b,b), EPS 1e-12, MAX_ITER 1000 (src/shifted_solver.c:5-6,
- * 257). Not built yet: shifted_bicgstab (:13-180) and the two pipelined variants (:703-1086). */
+ * (the re-ordered reference functions are bit-identical to their base function; each group resolves
+ * to one implementation here). x_loc_set is shift-major, x_loc_set[j * local_rows + i]
+ * (src/shifted_solver.c:118-123), in = initial guess (the reference's drivers pass 0), out = the
+ * sigma_len solutions; r_loc in = b, out = seed residual. Convergence: max_j |1/(zeta_j pi_j)|^2 (r,r)
+ * <= EPS^2 (b,b) (xi/tau form: max_j |xi_j tau_j|), EPS 1e-12, MAX_ITER 1000 (src/shifted_solver.c:5-6). */
+int shifted_bicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len);
 int shifted_lopbicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
 int shifted_lopbicgstab_v2(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
 int shifted_lopbicgstab_nooverlap(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
+int shifted_pipe_lopbicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
+int shifted_pipe_lopbicgstab_nooverlap(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
 
 /* ---------------------------------------------------------------------------------------------
  * 2. Communicator bootstrap (process-global; one process per GPU).
@@ -176,10 +182,12 @@ int bicg_run_begin(bicg_ctx *ctx, int method, const bicg_options *opt);
 int bicg_run_iterate(bicg_ctx *ctx, int nsteps);
 int bicg_run_end(bicg_ctx *ctx, bicg_result *res);
 int bicg_sync(bicg_ctx *ctx);
-/* shifted solve on a resident matrix (semantics of shifted_lopbicgstab above; opt NULL = reference
- * defaults with EPS 1e-12); the trace holds the SEED system's alpha, omega, beta, (r,r) */
-int bicg_solve_shifted(bicg_ctx *ctx, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len, int seed,
-                       const bicg_options *opt, bicg_result *res);
+/* shifted solve on a resident matrix; variant = BICG_SHIFTED_LOP / _PIPE / _XI (semantics of the
+ * drop-in functions above; opt NULL = reference defaults with EPS 1e-12); the trace holds the SEED
+ * system's alpha, omega, beta, (r,r) */
+enum { BICG_SHIFTED_LOP = 0, BICG_SHIFTED_PIPE = 1, BICG_SHIFTED_XI = 2 };
+int bicg_solve_shifted(bicg_ctx *ctx, int variant, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len,
+                       int seed, const bicg_options *opt, bicg_result *res);
 /* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */
 int bicg_trace(bicg_ctx *ctx, double *alpha, double *omega, double *beta, double *dot_r);
 

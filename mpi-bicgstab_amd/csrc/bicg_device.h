@@ -37,12 +37,23 @@ enum Phase : int {
     PH_SH_ALPHA,    // red[0]=(r#,s): alpha[seed]; beta[j], pi, eta, alpha[j]                    (:264-287)
     PH_SH_OMEGA,    // red[0]=(q,y), red[1]=(q,q): omega[seed]; omega[j], x/p coefficients, zeta (:291-301)
     PH_SH_END,      // red[0]=(r,r), red[1]=(r#,r): beta[seed], max|1/(zeta pi)|, k++            (:304-320)
+    // pipelined shifted variant (src/shifted_solver.c:703-895)
+    PH_SHP_INIT_ALPHA, // red[0]=(r,w): alpha[seed] = rTr/(r,w), alpha_old = 1                   (:785-786)
+    PH_SHP_OMEGA,      // red[0]=(q,y), red[1]=(y,y): omega[seed] and ALL per-shift scalars      (:803-839)
+    PH_SHP_END,        // red[0..4]=(r,r),(r#,r),(r#,w),(r#,s),(r#,z): beta, alpha, max, k++     (:856-866)
+};
+
+enum ShiftMode : int {
+    SH_LOP = 0,      // shifted_lopbicgstab (+_v2, _nooverlap)       src/shifted_solver.c:182-701
+    SH_PIPE = 1,     // shifted_pipe_lopbicgstab (+_nooverlap)       src/shifted_solver.c:703-1086
+    SH_XI = 2,       // shifted_bicgstab, seed 0, xi/tau recurrences src/shifted_solver.c:13-180
 };
 
 // Per-shift scalar state of the shifted solver, device resident (arrays of nsig doubles).
 struct ShiftDev {
-    int     nsig, seed;
+    int     nsig, seed, mode, pad;
     double  alpha_old, beta_old, max_zeta_pi;
+    // SH_XI reuses the arrays: pi_old = xi_old, pi_new = xi_curr, eta = xi_new, zeta = tau
     double *sigma, *alpha, *beta, *omega, *eta, *zeta, *pi_old, *pi_new;
     // coefficients the batched update kernel reads for shift j (valid for one iteration)
     double *cp;   // 1 / (pi_new zeta)              p_j <- beta_j p_j + cp_j r_old      (:265-266)
@@ -162,6 +173,11 @@ void launch_shift_q(const Vecs &v, Scal *S, hipStream_t st);                    
 void launch_shift_update(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
                          Scal *S, Reduce red, hipStream_t st);
 void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t st);                 // p[seed] = r + beta (p[seed] - omega s)
+// pipelined shifted variant: phase 1 (p[seed], s, z recurrences, r_old, q, y, 2 dots) and phase 2
+// (x[seed], every p_j / x_j, r, w, 5 dots)
+void launch_shift_pipe1(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t st);
+void launch_shift_pipe2(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
+                        Scal *S, Reduce red, hipStream_t st);
 // standalone dot (x,y) -> red[0]
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 

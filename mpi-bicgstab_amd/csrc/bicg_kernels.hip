@@ -96,34 +96,87 @@ __device__ void apply_phase(Scal *S, int phase)
     }
 }
 
-// ---- shifted solver: per-shift scalar recurrences, one thread per shift (whole workgroup calls)
+// ---- shifted solvers: per-shift scalar recurrences, one thread per shift (whole workgroup calls)
+// lop / pipe: the per-shift block of reference src/shifted_solver.c:264-301 (= :803-839)
+__device__ __forceinline__ void shift_beta_cp(ShiftDev *H, int j, double beta_seed)
+{
+    const double po = H->pi_old[j], pn = H->pi_new[j];
+    H->beta[j] = (po / pn) * (po / pn) * beta_seed;                  // (:264)
+    H->cp[j] = 1.0 / (pn * H->zeta[j]);                              // (:266)
+    H->pi_old[j] = pn;                                               // (:268)
+}
+__device__ __forceinline__ void shift_eta_alpha(ShiftDev *H, int j, double a_seed, double sg_seed)
+{
+    const double pn = H->pi_old[j];                                  // already copied
+    const double e = (H->beta_old / H->alpha_old) * a_seed * H->eta[j] - (sg_seed - H->sigma[j]) * a_seed * pn;   // (:283)
+    H->eta[j] = e;
+    const double pnew = e + pn;                                      // (:285)
+    H->pi_new[j] = pnew;
+    H->alpha[j] = (pn / pnew) * a_seed;                              // (:286)
+}
+__device__ __forceinline__ void shift_omega_coeffs(ShiftDev *H, int j, double w_seed, double sg_seed)
+{
+    const double dsg = sg_seed - H->sigma[j];
+    const double wj = w_seed / (1.0 - w_seed * dsg);                 // (:295)
+    H->omega[j] = wj;
+    const double pn = H->pi_new[j], po = H->pi_old[j], z = H->zeta[j], aj = H->alpha[j];
+    H->cx[j] = wj / (pn * z);                                        // (:296)
+    H->c1[j] = wj / (aj * z * pn);                                   // (:298)
+    H->c2[j] = -wj / (aj * z * po);                                  // (:299)
+    H->zeta[j] = (1.0 - w_seed * dsg) * z;                           // (:300)
+}
+
 __device__ void apply_phase_shifted(Scal *S, int phase)
 {
     ShiftDev *H = S->sh;
     const double *d = S->red;
-    const int nsig = H->nsig, seed = H->seed;
+    const int nsig = H->nsig, seed = H->seed, mode = H->mode;
     __shared__ double s_max[kBlock];
     if (threadIdx.x == 0) {
-        if (phase == PH_SH_INIT) {
+        switch (phase) {
+        case PH_SH_INIT:
             S->rTr = d[0]; S->dot_r = d[0]; S->dot_zero = d[0];
             S->alpha = 1.0; S->beta = 0.0; S->omega = 0.0; S->rTr_old = 0.0;
             H->max_zeta_pi = 1.0; H->alpha_old = 1.0; H->beta_old = 0.0;
             if (!(1.0 * 1.0 * S->dot_r > S->tol2 * S->dot_zero && 0 < S->max_iter)) S->done = 1;
-        } else if (phase == PH_SH_ALPHA) {
-            H->alpha_old = S->alpha;                  // alpha_old <- alpha[seed]   (:270)
-            H->beta_old = S->beta;                    // beta_old  <- beta[seed]    (:271)
-            S->alpha = S->rTr / d[0];                 // alpha[seed] <- (r#,r)/(r#,s)  (:274)
-        } else if (phase == PH_SH_OMEGA) {
-            S->omega = d[1] / d[0];                   // omega[seed] <- (q,q)/(q,y)    (:291)
-        } else if (phase == PH_SH_END) {
+            break;
+        case PH_SH_ALPHA:
+            H->alpha_old = S->alpha;                  // alpha_old <- alpha[seed]   (:270 / :96)
+            H->beta_old = S->beta;                    // beta_old  <- beta[seed]    (:271 / :97)
+            S->alpha = S->rTr / d[0];                 // alpha[seed] <- (r#,r)/(r#,s)  (:274 / :100)
+            break;
+        case PH_SH_OMEGA:
+            S->omega = mode == SH_XI ? d[0] / d[1]    // (q,y)/(y,y)                (:115)
+                                     : d[1] / d[0];   // (q,q)/(q,y)                (:291)
+            break;
+        case PH_SH_END:
             S->dot_r = d[0];
             S->rTr_old = S->rTr;
             S->rTr = d[1];
-            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);      // (:310)
+            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);      // (:310 / :135)
+            break;
+        case PH_SHP_INIT_ALPHA:
+            H->alpha_old = 1.0;                       // (:785)
+            S->alpha = S->rTr / d[0];                 // (:786)
+            break;
+        case PH_SHP_OMEGA:
+            H->beta_old = S->beta;                    // (:817)
+            S->omega = d[0] / d[1];                   // (q,y)/(y,y)                (:828)
+            break;
+        case PH_SHP_END: {
+            S->dot_r = d[0];
+            S->rTr_old = S->rTr;
+            S->rTr = d[1];
+            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);      // (:856)
+            H->alpha_old = S->alpha;                                      // (:857)
+            S->alpha = S->rTr / (d[2] + S->beta * (d[3] - S->omega * d[4]));   // (:858)
+            break;
+        }
+        default: break;
         }
     }
     __syncthreads();
-    const double a_seed = S->alpha, b_seed = S->beta, w_seed = S->omega, sg_seed = H->sigma[seed];
+    const double a_seed = S->alpha, w_seed = S->omega, sg_seed = H->sigma[seed];
     double local_max = 1.0;
     for (int j = threadIdx.x; j < nsig; j += kBlock) {
         if (phase == PH_SH_INIT) {
@@ -132,36 +185,53 @@ __device__ void apply_phase_shifted(Scal *S, int phase)
             continue;
         }
         if (j == seed) {
-            if (phase == PH_SH_ALPHA) H->pi_old[j] = H->pi_new[j];      // my_dcopy copies every entry (:268)
+            if (mode != SH_XI && (phase == PH_SH_ALPHA || phase == PH_SHP_OMEGA)) H->pi_old[j] = H->pi_new[j];   // my_dcopy copies every entry
+            continue;
+        }
+        if (mode == SH_XI) {
+            // xi_old = pi_old, xi_curr = pi_new, xi_new = eta, tau = zeta      (src/shifted_solver.c:90-142)
+            const double xo = H->pi_old[j], xc = H->pi_new[j], tau = H->zeta[j], sg = H->sigma[j];
+            if (phase == PH_SH_ALPHA) {
+                H->beta[j] = (xc / xo) * (xc / xo) * H->beta_old;                        // (:91)
+                H->cp[j] = tau * xc;                                                     // (:93)
+            } else if (phase == PH_SH_OMEGA) {
+                const double xn = (xc * xo * H->alpha_old) /
+                                  (a_seed * H->beta_old * (xo - xc) + xo * H->alpha_old * (1.0 + a_seed * sg));   // (:108)
+                H->eta[j] = xn;
+                const double aj = (xn / xc) * a_seed;                                    // (:110)
+                H->alpha[j] = aj;
+                const double wj = w_seed / (1.0 + w_seed * sg);                          // (:119)
+                H->omega[j] = wj;
+                H->cx[j] = wj * tau * xn;                                                // (:120)
+                H->c1[j] = wj * tau * xn / aj;                                           // (:122)
+                H->c2[j] = -wj * tau * xc / aj;                                          // (:123)
+            } else if (phase == PH_SH_END) {
+                const double tn = tau / (1.0 + w_seed * sg);                             // (:130)
+                H->zeta[j] = tn;
+                double a = xc * tn;                                                      // (:138)
+                if (a < 0.0) a = -a;
+                if (a > local_max) local_max = a;
+                H->pi_old[j] = xc;                                                       // (:141)
+                H->pi_new[j] = H->eta[j];                                                // (:142)
+            }
             continue;
         }
         if (phase == PH_SH_ALPHA) {
-            const double po = H->pi_old[j], pn = H->pi_new[j];
-            H->beta[j] = (po / pn) * (po / pn) * H->beta_old;            // uses beta[seed] of the previous iteration (:264)
-            H->cp[j] = 1.0 / (pn * H->zeta[j]);                          // (:266)
-            H->pi_old[j] = pn;                                           // (:268)
-            const double e = (H->beta_old / H->alpha_old) * a_seed * H->eta[j] - (sg_seed - H->sigma[j]) * a_seed * pn;   // (:283)
-            H->eta[j] = e;
-            const double pnew = e + pn;                                  // (:285)
-            H->pi_new[j] = pnew;
-            H->alpha[j] = (pn / pnew) * a_seed;                          // (:286)
+            shift_beta_cp(H, j, H->beta_old);        // beta[seed] of the previous iteration
+            shift_eta_alpha(H, j, a_seed, sg_seed);
         } else if (phase == PH_SH_OMEGA) {
-            const double dsg = sg_seed - H->sigma[j];
-            const double wj = w_seed / (1.0 - w_seed * dsg);             // (:295)
-            H->omega[j] = wj;
-            const double pn = H->pi_new[j], po = H->pi_old[j], z = H->zeta[j], aj = H->alpha[j];
-            H->cx[j] = wj / (pn * z);                                    // (:296)
-            H->c1[j] = wj / (aj * z * pn);                               // (:298)
-            H->c2[j] = -wj / (aj * z * po);                              // (:299)
-            H->zeta[j] = (1.0 - w_seed * dsg) * z;                       // (:300)
-        } else if (phase == PH_SH_END) {
-            double a = 1.0 / (H->zeta[j] * H->pi_new[j]);                // (:314)
+            shift_omega_coeffs(H, j, w_seed, sg_seed);
+        } else if (phase == PH_SHP_OMEGA) {
+            shift_beta_cp(H, j, H->beta_old);        // (:805-807), beta_old == beta[seed] here
+            shift_eta_alpha(H, j, a_seed, sg_seed);  // (:820-823)
+            shift_omega_coeffs(H, j, w_seed, sg_seed);   // (:833-838)
+        } else if (phase == PH_SH_END || phase == PH_SHP_END) {
+            double a = 1.0 / (H->zeta[j] * H->pi_new[j]);                // (:314 / :862)
             if (a < 0.0) a = -a;
             if (a > local_max) local_max = a;
         }
     }
-    (void)b_seed;
-    if (phase == PH_SH_END) {
+    if (phase == PH_SH_END || phase == PH_SHP_END) {
         s_max[threadIdx.x] = local_max;
         __syncthreads();
         for (int w = kBlock / 2; w > 0; w >>= 1) {
@@ -174,10 +244,13 @@ __device__ void apply_phase_shifted(Scal *S, int phase)
             S->k += 1;
             const int k = S->k;
             if (S->tr_dotr && k <= S->max_iter) {
-                S->tr_alpha[k - 1] = S->alpha; S->tr_omega[k - 1] = S->omega; S->tr_beta[k - 1] = S->beta; S->tr_dotr[k - 1] = S->dot_r;
+                S->tr_alpha[k - 1] = phase == PH_SHP_END ? H->alpha_old : S->alpha;
+                S->tr_omega[k - 1] = S->omega; S->tr_beta[k - 1] = S->beta; S->tr_dotr[k - 1] = S->dot_r;
             }
-            // reference loop condition, src/shifted_solver.c:257
+            // reference loop condition, src/shifted_solver.c:86 / 257 / 792
             if (!(m * m * S->dot_r > S->tol2 * S->dot_zero && k < S->max_iter)) S->done = 1;
+            if (!(isfinite(S->alpha) && isfinite(S->beta) && isfinite(S->omega) && isfinite(S->dot_r)) && !S->breakdown_k)
+                S->breakdown_k = k;
         }
     }
 }
@@ -997,6 +1070,82 @@ void launch_shift_update(const Vecs &v, double *p_set, double *x_set, uint32_t s
     FShiftUpdate f{};
     f.xs = x_set + (size_t)seed * set_stride; f.ps = p_set + (size_t)seed * set_stride;
     f.r = v.r; f.pset = p_set; f.xset = x_set; f.y = v.y; f.rh = v.rh; f.rold = v.ax; f.H = H; f.stride = set_stride;
+    run_vec(f, v.n, S, red, s);
+}
+
+// ---- pipelined shifted variant (reference src/shifted_solver.c:794-843)
+struct FShPipe1 {   // p[seed], s, z recurrences ; r_old = r ; q, y ; (q,y), (y,y)          (:794-813)
+    static constexpr int ND = 2;
+    double *p, *s, *z, *r, *w, *rold; const double *t, *v; double alpha, beta, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; beta = S->beta; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        T r0 = ld<T>(r, i), w0 = ld<T>(w, i), s0 = ld<T>(s, i), z0 = ld<T>(z, i);
+        st(p, i, recur3<T>(ld<T>(p, i), s0, r0, omega, beta));
+        T s1 = recur3<T>(s0, z0, w0, omega, beta);
+        T z1 = recur3<T>(z0, ld<T>(v, i), ld<T>(t, i), omega, beta);
+        st(s, i, s1); st(z, i, z1);
+        st(rold, i, r0);
+        T q = r0 + (-alpha) * s1;
+        T y = w0 + (-alpha) * z1;
+        st(r, i, q); st(w, i, y);
+        acc[0] += hsum(q * y);
+        acc[1] += hsum(y * y);
+    }
+};
+void launch_shift_pipe1(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FShPipe1{p_seed, v.s, v.z, v.r, v.w, v.ax, v.t, v.v, 0.0, 0.0, 0.0}, v.n, S, red, s);
+}
+
+struct FShPipe2 {   // x[seed] ; every p_j, x_j ; r ; w = y - omega (t - alpha v) ; five dots   (:829-848)
+    static constexpr int ND = 5;
+    double *xs, *r, *w, *pset, *xset; const double *ps, *t, *v, *rh, *s, *z, *rold; const ShiftDev *H; uint32_t stride;
+    double alpha, omega; int nsig, seed;
+    const double *beta_j, *alpha_j, *cp, *cx, *c1, *c2;
+    __device__ void load(const Scal *S)
+    {
+        alpha = S->alpha; omega = S->omega;
+        nsig = H->nsig; seed = H->seed;
+        beta_j = H->beta; alpha_j = H->alpha; cp = H->cp; cx = H->cx; c1 = H->c1; c2 = H->c2;
+    }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        const T q = ld<T>(r, i), y = ld<T>(w, i), ro = ld<T>(rold, i);
+        T xx = ld<T>(xs, i) + alpha * ld<T>(ps, i);
+        st(xs, i, xx + omega * q);
+        for (int j = 0; j < nsig; ++j) {
+            if (j == seed) continue;
+            double *pj = pset + (size_t)j * stride, *xj = xset + (size_t)j * stride;
+            T p = beta_j[j] * ld<T>(pj, i);                      // (:806)
+            p = p + cp[j] * ro;                                  // (:807)
+            T x = ld<T>(xj, i) + cx[j] * q;                      // (:834)
+            x = x + alpha_j[j] * p;                              // (:835)
+            st(xj, i, x);
+            p = p + c1[j] * q;                                   // (:836)
+            p = p + c2[j] * ro;                                  // (:837)
+            st(pj, i, p);
+        }
+        const T rr = q + (-omega) * y;                           // (:840)
+        st(r, i, rr);
+        const T tt = ld<T>(t, i) + (-alpha) * ld<T>(v, i);       // (:842)
+        const T ww = y + (-omega) * tt;                          // (:843)
+        st(w, i, ww);
+        const T h = ld<T>(rh, i);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(h * rr);
+        acc[2] += hsum(h * ww);
+        acc[3] += hsum(h * ld<T>(s, i));
+        acc[4] += hsum(h * ld<T>(z, i));
+    }
+};
+void launch_shift_pipe2(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
+                        Scal *S, Reduce red, hipStream_t s)
+{
+    FShPipe2 f{};
+    f.xs = x_set + (size_t)seed * set_stride; f.ps = p_set + (size_t)seed * set_stride;
+    f.r = v.r; f.w = v.w; f.pset = p_set; f.xset = x_set; f.t = v.t; f.v = v.v; f.rh = v.rh; f.s = v.s; f.z = v.z;
+    f.rold = v.ax; f.H = H; f.stride = set_stride;
     run_vec(f, v.n, S, red, s);
 }
 

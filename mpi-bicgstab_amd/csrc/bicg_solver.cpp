@@ -560,9 +560,11 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
 // SpMV(+sigma_seed) with (r#,s) | q, r_old | SpMV(+sigma_seed) with (q,y),(q,q) | ONE batched kernel
 // over all shifts (x_seed, r, every p_j and x_j, two dots) | p_seed.  The per-shift scalar
 // recurrences (beta_j, pi_j, eta_j, alpha_j, omega_j, zeta_j) run on the device, one thread per shift.
-int run_shifted(bicg_ctx *c, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
+int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
                 const bicg_options *opt_in, bicg_result *res)
 {
+    if (mode < SH_LOP || mode > SH_XI) die("bicg_solve_shifted", "unknown variant");
+    if (mode == SH_XI) seed = 0;          // shifted_bicgstab: the seed system is A itself, shift index 0
     bicg_options o;
     if (opt_in) o = *opt_in; else { bicg_default_options(&o); o.tol = 1.0e-12; }   // EPS of src/shifted_solver.c:5
     if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
@@ -581,7 +583,7 @@ int run_shifted(bicg_ctx *c, double *x_set_host, double *r_host, const double *s
     }
     ShiftDev h;
     memset(&h, 0, sizeof h);
-    h.nsig = nsig; h.seed = seed;
+    h.nsig = nsig; h.seed = seed; h.mode = mode;
     double **arr[12] = {&h.sigma, &h.alpha, &h.beta, &h.omega, &h.eta, &h.zeta, &h.pi_old, &h.pi_new, &h.cp, &h.cx, &h.c1, &h.c2};
     for (int i = 0; i < 12; ++i) *arr[i] = c->sh_arrays + (size_t)i * nsig;
     BICG_HIP(hipMemcpy(c->sh_dev, &h, sizeof h, hipMemcpyHostToDevice));
@@ -592,6 +594,7 @@ int run_shifted(bicg_ctx *c, double *x_set_host, double *r_host, const double *s
     for (int j = 0; j < nsig; ++j)
         BICG_HIP(hipMemcpy(c->x_set + (size_t)j * st, x_set_host + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice));
     BICG_HIP(hipMemcpy(c->v.r, r_host, sizeof(double) * n, hipMemcpyHostToDevice));
+    BICG_HIP(hipDeviceSynchronize());       // the memsets above ran on the null stream; sc does not wait for it
 
     if (c->trace_cap < o.max_iter) {
         if (c->trace) BICG_HIP(hipFree(c->trace));
@@ -608,8 +611,11 @@ int run_shifted(bicg_ctx *c, double *x_set_host, double *r_host, const double *s
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = false;
+    if (mode == SH_XI)                      // p[sigma] <- b for every shift, src/shifted_solver.c:72
+        for (int j = 0; j < nsig; ++j)
+            BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
     {   // streaming policy: matrix + 6 work vectors + the two sets
-        const double ws = (double)c->matrix_bytes + 8.0 * st * (6 + 2.0 * nsig);
+        const double ws = (double)c->matrix_bytes + 8.0 * st * ((mode == SH_PIPE ? 10 : 6) + 2.0 * nsig);
         c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
         if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
     }
@@ -617,20 +623,38 @@ int run_shifted(bicg_ctx *c, double *x_set_host, double *r_host, const double *s
 
     double *p_seed = c->p_set + (size_t)seed * st;
     Vecs &v = c->v;
+    const bool shifted_A = mode != SH_XI;       // lop / pipe iterate on A + sigma[seed] I, shifted_bicgstab on A
     const double t0 = now_sec();
     c->cur_has_shift = false;
     launch_shift_init(v, p_seed, c->S, c->red(0, PH_SH_INIT), c->sc);
     group_now(c, 1, PH_SH_INIT);
+    c->cur_shift = sigma[seed]; c->cur_has_shift = shifted_A;
+    if (mode == SH_PIPE) {                                                   // src/shifted_solver.c:764-769, 785-786
+        spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_SHP_INIT_ALPHA));             // w = (A + sigma I) r, (r,w)
+        group_defer(c, 1, PH_SHP_INIT_ALPHA);
+        spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));                   // t = (A + sigma I) w
+        group_flush(c);
+    }
     fetch_scal(c);
     int it = 0;
-    c->cur_shift = sigma[seed]; c->cur_has_shift = true;
     while (!c->hS->done && it < o.max_iter) {
         const int chunk = std::min(o.check_every, o.max_iter - it);
         for (int j = 0; j < chunk; ++j) {
-            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SH_ALPHA));          // s = (A + sigma I) p[seed], (r#,s)
+            if (mode == SH_PIPE) {
+                launch_shift_pipe1(v, p_seed, c->S, c->red(0, PH_SHP_OMEGA), c->sc);    // p, s, z, r_old, q, y, 2 dots
+                group_defer(c, 2, PH_SHP_OMEGA);
+                spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));                      // v = (A + sigma I) z
+                launch_shift_pipe2(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SHP_END), c->sc);
+                group_defer(c, 5, PH_SHP_END);
+                spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));                      // t = (A + sigma I) w
+                group_flush(c);
+                continue;
+            }
+            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SH_ALPHA));          // s = (A [+ sigma I]) p[seed], (r#,s)
             group_now(c, 1, PH_SH_ALPHA);
             launch_shift_q(v, c->S, c->sc);                                 // r_old = r, q = r - alpha s
-            spmv(c, v.r, v.y, 3, v.r, c->red(0, PH_SH_OMEGA));              // y = (A + sigma I) q, (q,y), (q,q)
+            // lop: (q,y), (q,q) ; shifted_bicgstab: (q,y), (y,y)
+            spmv(c, v.r, v.y, mode == SH_XI ? 2 : 3, v.r, c->red(0, PH_SH_OMEGA));
             group_now(c, 2, PH_SH_OMEGA);
             launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END), c->sc);
             group_now(c, 2, PH_SH_END);
@@ -893,6 +917,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         BICG_HIP(hipEventCreateWithFlags(&c->ev_dots[i], hipEventDisableTiming));
         BICG_HIP(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming));
     }
+    BICG_HIP(hipDeviceSynchronize());       // uploads and memsets above used the null stream
     return c;
 }
 
@@ -1024,13 +1049,13 @@ int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
     return 0;
 }
 
-int bicg_solve_shifted(bicg_ctx *c, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len, int seed,
-                       const bicg_options *opt, bicg_result *res)
+int bicg_solve_shifted(bicg_ctx *c, int variant, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len,
+                       int seed, const bicg_options *opt, bicg_result *res)
 {
-    return run_shifted(c, x_loc_set, r_loc, sigma, sigma_len, seed, opt, res);
+    return run_shifted(c, variant, x_loc_set, r_loc, sigma, sigma_len, seed, opt, res);
 }
 
-static int dropin_shifted(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x_set, double *r, double *sigma, int nsig, int seed)
+static int dropin_shifted(int mode, CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x_set, double *r, double *sigma, int nsig, int seed)
 {
     check_square(i);
     bicg_options opt;
@@ -1039,16 +1064,21 @@ static int dropin_shifted(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *
     bicg_ctx *c = bicg_create(d, o, i);
     if (!c) die("bicg_create", "failed");
     bicg_result res;
-    const int k = run_shifted(c, x_set, r, sigma, nsig, seed, &opt, &res);
+    const int k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
     bicg_destroy(c);
     return k;
 }
 
 // ---- shifted drop-ins: reference src/shifted_solver.h:17-19. The three reference functions perform
 // the same arithmetic in a different order (their outputs are bit-identical to each other).
-int shifted_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(d, o, i, x, r, sigma, n, seed); }
-int shifted_lopbicgstab_v2(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(d, o, i, x, r, sigma, n, seed); }
-int shifted_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_LOP, d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicgstab_v2(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_LOP, d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_LOP, d, o, i, x, r, sigma, n, seed); }
+// src/shifted_solver.h:20-21 (the two reference functions are bit-identical to each other)
+int shifted_pipe_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_PIPE, d, o, i, x, r, sigma, n, seed); }
+int shifted_pipe_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_PIPE, d, o, i, x, r, sigma, n, seed); }
+// src/shifted_solver.h:16 (seed system = A, shift index 0)
+int shifted_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n) { return dropin_shifted(SH_XI, d, o, i, x, r, sigma, n, 0); }
 
 // ---- drop-in entry points: reference src/solver.h:10-13
 int bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_BICGSTAB, d, o, i, x, r, 0, 0); }

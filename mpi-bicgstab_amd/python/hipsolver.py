@@ -49,7 +49,8 @@ ALLTOALLV_FN = C.CFUNCTYPE(None, C.c_void_p, _ip, _ip, C.c_void_p, _ip, _ip, C.c
 
 EXPORTS = [
     "bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr",
-    "shifted_lopbicgstab", "shifted_lopbicgstab_v2", "shifted_lopbicgstab_nooverlap", "bicg_solve_shifted",
+    "shifted_bicgstab", "shifted_lopbicgstab", "shifted_lopbicgstab_v2", "shifted_lopbicgstab_nooverlap",
+    "shifted_pipe_lopbicgstab", "shifted_pipe_lopbicgstab_nooverlap", "bicg_solve_shifted",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
@@ -72,7 +73,8 @@ def lib():
         L.bicg_destroy.argtypes = [C.c_void_p]
         L.bicg_solve.argtypes = [C.c_void_p, C.c_int, _dp, _dp, C.POINTER(Options), C.POINTER(Result)]
         L.bicg_run.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options), C.POINTER(Result)]
-        L.bicg_solve_shifted.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, C.c_int, C.POINTER(Options), C.POINTER(Result)]
+        L.bicg_solve_shifted.argtypes = [C.c_void_p, C.c_int, _dp, _dp, _dp, C.c_int, C.c_int, C.POINTER(Options),
+                                         C.POINTER(Result)]
         L.bicg_run_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
         L.bicg_run_iterate.argtypes = [C.c_void_p, C.c_int]
         L.bicg_run_end.argtypes = [C.c_void_p, C.POINTER(Result)]
@@ -181,8 +183,10 @@ class Context:
         k = lib().bicg_solve(self.h, METHODS[method], _d(x), _d(r), C.byref(o), C.byref(res))
         return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res)
 
-    def solve_shifted(self, b, sigma, seed, x0_set=None, **kw):
-        """(A + sigma_j I) x_j = b for all j (reference shifted_lopbicgstab): dict(k, x [nsig][n], r, result)."""
+    SHIFTED = {"shifted_lopbicgstab": 0, "shifted_pipe_lopbicgstab": 1, "shifted_bicgstab": 2}
+
+    def solve_shifted(self, b, sigma, seed, x0_set=None, which="shifted_lopbicgstab", **kw):
+        """(A + sigma_j I) x_j = b for all j (reference src/shifted_solver.c): dict(k, x [nsig][n], r, result)."""
         sigma = np.ascontiguousarray(sigma, dtype=np.float64)
         x = np.zeros((len(sigma), self.n)) if x0_set is None else np.array(x0_set, dtype=np.float64).reshape(len(sigma), self.n)
         r = np.array(b, dtype=np.float64)
@@ -190,7 +194,8 @@ class Context:
         kw.setdefault("tol", 1e-12)
         o = self.options(**kw)
         res = Result()
-        k = lib().bicg_solve_shifted(self.h, _d(x), _d(r), _d(sigma), len(sigma), seed, C.byref(o), C.byref(res))
+        k = lib().bicg_solve_shifted(self.h, self.SHIFTED[which], _d(x), _d(r), _d(sigma), len(sigma), seed, C.byref(o),
+                                     C.byref(res))
         return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res)
 
     def load(self, x0, b):

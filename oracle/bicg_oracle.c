@@ -460,6 +460,190 @@ int orc_shifted_lop(const orc_dist *d, double *x_set, double *r, const double *s
     return k;
 }
 
+/* reference src/shifted_solver.c:703-895. omega[seed], s, z, v are read before they are written
+ * there (:790-798, malloc'ed); defined as zero here like in the unshifted pipelined solver. */
+int orc_shifted_pipe_lop(const orc_dist *d, double *x_set, double *r, const double *sigma, int nsig, int seed, orc_opts *o)
+{
+    const int n = (int)d->n;
+    int k = 0;
+    double *r_old = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *z = vec_new(d->n), *w = vec_new(d->n),
+           *v = vec_new(d->n), *t = vec_new(d->n);
+    double *p_set = (double *)calloc((size_t)n * (size_t)nsig + 1, sizeof(double));
+    double *alpha = vec_new(nsig), *beta = vec_new(nsig), *omega = vec_new(nsig), *eta = vec_new(nsig),
+           *zeta = vec_new(nsig), *pi_new = vec_new(nsig), *pi_old = vec_new(nsig);
+    double alpha_old, beta_old, dot_r, dot_zero, rTr, rTw, wTw, rTs, rTz, rTr_old, max_zeta_pi;
+#define P_(j) (p_set + (size_t)(j) * (size_t)n)
+#define X_(j) (x_set + (size_t)(j) * (size_t)n)
+    const double sg = sigma[seed];
+
+    rTr = orc_dist_dot(d, r, r);                            /* :762 */
+    spmv_shift(d, sg, r, w);                                /* :764-765 */
+    rTw = orc_dist_dot(d, r, w);                            /* :766 */
+    spmv_shift(d, sg, w, t);                                /* :768-769 */
+    orc_dcopy(n, r, rh);                                    /* :771 */
+    for (int i = 0; i < nsig; ++i) { beta[i] = 0.0; alpha[i] = 1.0; eta[i] = 0.0; pi_old[i] = 1.0; pi_new[i] = 1.0; zeta[i] = 1.0; }
+    orc_dcopy(n, r, P_(seed));                              /* :781 */
+    alpha_old = 1.0;                                        /* :785 */
+    alpha[seed] = rTr / rTw;                                /* :786 */
+    dot_r = rTr; dot_zero = rTr; max_zeta_pi = 1.0;
+
+    while (max_zeta_pi * max_zeta_pi * dot_r > o->tol * o->tol * dot_zero && k < o->max_iter) {   /* :792 */
+        recur3(n, omega[seed], beta[seed], s, r, P_(seed));         /* :794-796 */
+        recur3(n, omega[seed], beta[seed], z, w, s);                /* :797-799 */
+        recur3(n, omega[seed], beta[seed], v, t, z);                /* :800-802 */
+        for (int j = 0; j < nsig; ++j) {                            /* :803-808 */
+            if (j == seed) continue;
+            beta[j] = (pi_old[j] / pi_new[j]) * (pi_old[j] / pi_new[j]) * beta[seed];
+            orc_dscal(n, beta[j], P_(j));
+            orc_daxpy(n, 1.0 / (pi_new[j] * zeta[j]), r, P_(j));
+        }
+        orc_dcopy(n, r, r_old);                                     /* :809 */
+        orc_daxpy(n, -alpha[seed], s, r);                           /* :810 q */
+        orc_daxpy(n, -alpha[seed], z, w);                           /* :811 y */
+        rTw = orc_dist_dot(d, r, w);                                /* :812 (q,y) */
+        wTw = orc_dist_dot(d, w, w);                                /* :813 (y,y) */
+        spmv_shift(d, sg, z, v);                                    /* :814-815 */
+        orc_dcopy(nsig, pi_new, pi_old);                            /* :816 */
+        beta_old = beta[seed];                                      /* :817 */
+        for (int j = 0; j < nsig; ++j) {                            /* :818-824 */
+            if (j == seed) continue;
+            eta[j] = (beta_old / alpha_old) * alpha[seed] * eta[j] - (sg - sigma[j]) * alpha[seed] * pi_old[j];
+            pi_new[j] = eta[j] + pi_old[j];
+            alpha[j] = (pi_old[j] / pi_new[j]) * alpha[seed];
+        }
+        omega[seed] = rTw / wTw;                                    /* :828 */
+        orc_daxpy(n, alpha[seed], P_(seed), X_(seed));              /* :829 */
+        orc_daxpy(n, omega[seed], r, X_(seed));                     /* :830 */
+        for (int j = 0; j < nsig; ++j) {                            /* :831-839 */
+            if (j == seed) continue;
+            omega[j] = omega[seed] / (1.0 - omega[seed] * (sg - sigma[j]));
+            orc_daxpy(n, omega[j] / (pi_new[j] * zeta[j]), r, X_(j));
+            orc_daxpy(n, alpha[j], P_(j), X_(j));
+            orc_daxpy(n, omega[j] / (alpha[j] * zeta[j] * pi_new[j]), r, P_(j));
+            orc_daxpy(n, -omega[j] / (alpha[j] * zeta[j] * pi_old[j]), r_old, P_(j));
+            zeta[j] = (1.0 - omega[seed] * (sg - sigma[j])) * zeta[j];
+        }
+        orc_daxpy(n, -omega[seed], w, r);                           /* :840 */
+        dot_r = orc_dist_dot(d, r, r);                              /* :841 */
+        orc_daxpy(n, -alpha[seed], v, t);                           /* :842 */
+        orc_daxpy(n, -omega[seed], t, w);                           /* :843 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);                               /* :845 */
+        rTw = orc_dist_dot(d, rh, w);                               /* :846 */
+        rTs = orc_dist_dot(d, rh, s);                               /* :847 */
+        rTz = orc_dist_dot(d, rh, z);                               /* :848 */
+        spmv_shift(d, sg, w, t);                                    /* :849-850 */
+        beta[seed] = (alpha[seed] / omega[seed]) * (rTr / rTr_old); /* :856 */
+        alpha_old = alpha[seed];                                    /* :857 */
+        alpha[seed] = rTr / (rTw + beta[seed] * (rTs - omega[seed] * rTz));   /* :858 */
+        max_zeta_pi = 1.0;                                          /* :859-864 */
+        for (int j = 0; j < nsig; ++j) {
+            if (j == seed) continue;
+            double a = 1.0 / (zeta[j] * pi_new[j]);
+            if (a < 0) a = -a;
+            if (a > max_zeta_pi) max_zeta_pi = a;
+        }
+        k++;
+        trace_put(o, k, alpha_old, omega[seed], beta[seed], dot_r);
+    }
+#undef P_
+#undef X_
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(r_old); free(rh); free(s); free(z); free(w); free(v); free(t); free(p_set);
+    free(alpha); free(beta); free(omega); free(eta); free(zeta); free(pi_new); free(pi_old);
+    return k;
+}
+
+/* reference src/shifted_solver.c:13-180 */
+int orc_shifted_bicgstab(const orc_dist *d, double *x_set, double *r, const double *sigma, int nsig, orc_opts *o)
+{
+    const int n = (int)d->n;
+    int k = 0;
+    double *r_old = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *y = vec_new(d->n);
+    double *p_set = (double *)calloc((size_t)n * (size_t)nsig + 1, sizeof(double));
+    double *alpha = vec_new(nsig), *beta = vec_new(nsig), *omega = vec_new(nsig), *tau = vec_new(nsig),
+           *xi_old = vec_new(nsig), *xi_curr = vec_new(nsig), *xi_new = vec_new(nsig);
+    double alpha_old, beta_old, dot_r, dot_zero, rTr, rTs, rTy, yTy, rTr_old, max_xi;
+#define P_(j) (p_set + (size_t)(j) * (size_t)n)
+#define X_(j) (x_set + (size_t)(j) * (size_t)n)
+
+    rTr = orc_dist_dot(d, r, r);                            /* :68 */
+    orc_dcopy(n, r, rh);                                    /* :70 */
+    for (int i = 0; i < nsig; ++i) {                        /* :71-78 */
+        orc_dcopy(n, r, P_(i));
+        beta[i] = 0.0; alpha[i] = 1.0; xi_old[i] = 1.0; xi_curr[i] = 1.0; tau[i] = 1.0;
+    }
+    dot_r = rTr; dot_zero = rTr; max_xi = 1.0;              /* :82-84 */
+
+    while (max_xi * max_xi * dot_r > o->tol * o->tol * dot_zero && k < o->max_iter) {     /* :86 */
+        orc_spmv(d, P_(0), s);                              /* :88 */
+        rTs = orc_dist_dot(d, rh, s);                       /* :89 */
+        for (int j = 1; j < nsig; ++j) {                    /* :90-94 */
+            beta[j] = (xi_curr[j] / xi_old[j]) * (xi_curr[j] / xi_old[j]) * beta[0];
+            orc_dscal(n, beta[j], P_(j));
+            orc_daxpy(n, tau[j] * xi_curr[j], r, P_(j));
+        }
+        orc_dcopy(n, r, r_old);                             /* :95 */
+        alpha_old = alpha[0]; beta_old = beta[0];           /* :96-97 */
+        alpha[0] = rTr / rTs;                               /* :100 */
+        orc_daxpy(n, -alpha[0], s, r);                      /* :102 */
+        orc_spmv(d, r, y);                                  /* :103 */
+        rTy = orc_dist_dot(d, r, y);                        /* :105 */
+        yTy = orc_dist_dot(d, y, y);                        /* :106 */
+        for (int j = 1; j < nsig; ++j) {                    /* :107-111 */
+            xi_new[j] = (xi_curr[j] * xi_old[j] * alpha_old) /
+                        (alpha[0] * beta_old * (xi_old[j] - xi_curr[j]) + xi_old[j] * alpha_old * (1.0 + alpha[0] * sigma[j]));
+            alpha[j] = (xi_new[j] / xi_curr[j]) * alpha[0];
+        }
+        omega[0] = rTy / yTy;                               /* :115 */
+        orc_daxpy(n, alpha[0], P_(0), X_(0));               /* :116 */
+        orc_daxpy(n, omega[0], r, X_(0));                   /* :117 */
+        for (int j = 1; j < nsig; ++j) {                    /* :118-124 */
+            omega[j] = omega[0] / (1.0 + omega[0] * sigma[j]);
+            orc_daxpy(n, omega[j] * tau[j] * xi_new[j], r, X_(j));
+            orc_daxpy(n, alpha[j], P_(j), X_(j));
+            orc_daxpy(n, omega[j] * tau[j] * xi_new[j] / alpha[j], r, P_(j));
+            orc_daxpy(n, -omega[j] * tau[j] * xi_curr[j] / alpha[j], r_old, P_(j));
+        }
+        orc_daxpy(n, -omega[0], y, r);                      /* :125 */
+        dot_r = orc_dist_dot(d, r, r);                      /* :126 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);                       /* :128 */
+        for (int j = 1; j < nsig; ++j) tau[j] = tau[j] / (1.0 + omega[0] * sigma[j]);     /* :129-131 */
+        beta[0] = (alpha[0] / omega[0]) * (rTr / rTr_old);  /* :135 */
+        max_xi = 1.0;                                       /* :136-140 */
+        for (int j = 1; j < nsig; ++j) {
+            double a = xi_curr[j] * tau[j];
+            if (a < 0) a = -a;
+            if (a > max_xi) max_xi = a;
+        }
+        orc_dcopy(nsig, xi_curr, xi_old);                   /* :141 */
+        orc_dcopy(nsig, xi_new, xi_curr);                   /* :142 */
+        orc_dscal(n, beta[0], P_(0));                       /* :143 */
+        orc_daxpy(n, 1.0, r, P_(0));                        /* :144 */
+        orc_daxpy(n, -beta[0] * omega[0], s, P_(0));        /* :145 */
+        k++;
+        trace_put(o, k, alpha[0], omega[0], beta[0], dot_r);
+    }
+#undef P_
+#undef X_
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(r_old); free(rh); free(s); free(y); free(p_set);
+    free(alpha); free(beta); free(omega); free(tau); free(xi_old); free(xi_curr); free(xi_new);
+    return k;
+}
+
+int orc_shifted_coo(int which, int P, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                    const double *val, double *x_set, double *r, const double *sigma, int nsig, int seed, orc_opts *o)
+{
+    orc_dist *d = orc_dist_from_coo(n, nnz, row, col, val, P);
+    int k = which == 0 ? orc_shifted_lop(d, x_set, r, sigma, nsig, seed, o)
+          : which == 1 ? orc_shifted_pipe_lop(d, x_set, r, sigma, nsig, seed, o)
+                       : orc_shifted_bicgstab(d, x_set, r, sigma, nsig, o);
+    orc_dist_free(d);
+    return k;
+}
+
 int orc_shifted_lop_coo(int P, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
                         const double *val, double *x_set, double *r, const double *sigma, int nsig, int seed,
                         orc_opts *o)

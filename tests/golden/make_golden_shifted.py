@@ -32,9 +32,15 @@ def main():
         ref = R.solve_shifted("shifted_lopbicgstab", M, b, sigma, seed)
         same = all(np.array_equal(R.solve_shifted(f, M, b, sigma, seed)["x"], ref["x"])
                    for f in ("shifted_lopbicgstab_v2", "shifted_lopbicgstab_nooverlap"))
+        pipe = R.solve_shifted("shifted_pipe_lopbicgstab", M, b, sigma, seed)
+        pipe_same = np.array_equal(R.solve_shifted("shifted_pipe_lopbicgstab_nooverlap", M, b, sigma, seed)["x"], pipe["x"])
+        b0 = R.spmv(M, np.ones(A.rows))                        # shifted_bicgstab: the seed system is A itself
+        xi = R.solve_shifted("shifted_bicgstab", M, b0, sigma, 0)
         np.savez_compressed(os.path.join(HERE, name + ".npz"), n=A.rows, ptr=A.ptr, col=A.col, val=A.val, sigma=sigma,
-                            seed=seed, b=b, k=ref["k"], x=ref["x"], r=ref["r"], variants_bit_identical=same)
-        print(name, "k =", ref["k"], "variants identical:", same)
+                            seed=seed, b=b, k=ref["k"], x=ref["x"], r=ref["r"], variants_bit_identical=same,
+                            pipe_k=pipe["k"], pipe_x=pipe["x"], pipe_r=pipe["r"], pipe_variants_bit_identical=pipe_same,
+                            xi_b=b0, xi_k=xi["k"], xi_x=xi["x"], xi_r=xi["r"])
+        print(name, "k =", ref["k"], pipe["k"], xi["k"], "variants identical:", same, pipe_same)
 
 
 if __name__ == "__main__":

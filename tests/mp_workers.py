@@ -129,10 +129,11 @@ def gpu_worker(rank, world, port, kind, outdir):
         # shifted systems, 5 shifts, seed 2 (reference src/test_shifted.c:95-111 set-up)
         sigma, seed = 0.01 * (np.arange(5) + 1.0), 2
         bs_full = b_full + sigma[seed] * np.ones(A.rows)
-        orc = O.solve_shifted(A.rows, row, col, val, bs_full, sigma, seed, nranks=world)
-        got = ctx.solve_shifted(bs_full[lo:lo + nl], sigma, seed, check_every=4)
-        assert abs(got["k"] - orc["k"]) <= 2, (got["k"], orc["k"])
-        assert np.abs(got["x"] - orc["x"][:, lo:lo + nl]).max() <= 1e-8 * max(1.0, np.abs(orc["x"]).max())
+        for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab"):
+            orc = O.solve_shifted(A.rows, row, col, val, bs_full, sigma, seed, nranks=world, which=which)
+            got = ctx.solve_shifted(bs_full[lo:lo + nl], sigma, seed, check_every=4, which=which)
+            assert abs(got["k"] - orc["k"]) <= 2, (which, got["k"], orc["k"])
+            assert np.abs(got["x"] - orc["x"][:, lo:lo + nl]).max() <= 1e-8 * max(1.0, np.abs(orc["x"]).max()), which
         ctx.close()
         dist.barrier()
         H.lib().bicg_comm_finalize()

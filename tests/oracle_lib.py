@@ -46,6 +46,9 @@ def lib():
         _lib.orc_dscal.restype = None
         _lib.orc_dscal.argtypes = [C.c_int, C.c_double, _dp]
         _lib.orc_read_mtx.restype = C.c_int
+        _lib.orc_shifted_coo.restype = C.c_int
+        _lib.orc_shifted_coo.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_uint, _up, _up, _dp, _dp, _dp, _dp, C.c_int, C.c_int,
+                                         C.POINTER(OrcOpts)]
         _lib.orc_shifted_lop_coo.restype = C.c_int
         _lib.orc_shifted_lop_coo.argtypes = [C.c_int, C.c_uint, C.c_uint, _up, _up, _dp, _dp, _dp, _dp, C.c_int, C.c_int,
                                              C.POINTER(OrcOpts)]
@@ -93,15 +96,18 @@ def solve(method, n, row, col, val, b, x0=None, nranks=1, tol=1e-15, max_iter=10
                 beta=tr[2][:k], dotr=tr[3][:k])
 
 
-def solve_shifted(n, row, col, val, b, sigma, seed, nranks=1, tol=1e-12, max_iter=1000):
-    """orc_shifted_lop: returns dict(k, x [nsig][n], r, dot_r, dot_zero, alpha, omega, beta, dotr) (seed scalars)."""
+SHIFTED = {"shifted_lopbicgstab": 0, "shifted_pipe_lopbicgstab": 1, "shifted_bicgstab": 2}
+
+
+def solve_shifted(n, row, col, val, b, sigma, seed, nranks=1, tol=1e-12, max_iter=1000, which="shifted_lopbicgstab"):
+    """shifted oracle: returns dict(k, x [nsig][n], r, dot_r, dot_zero, alpha, omega, beta, dotr) (seed scalars)."""
     row, col, val = _coo(row, col, val)
     sigma = np.ascontiguousarray(sigma, dtype=np.float64)
     x = np.zeros(len(sigma) * n)
     r = np.array(b, dtype=np.float64)
     tr = [np.zeros(max(max_iter, 1)) for _ in range(4)]
     o = OrcOpts(tol, max_iter, 0, 0, _d(tr[0]), _d(tr[1]), _d(tr[2]), _d(tr[3]), 0.0, 0.0)
-    k = lib().orc_shifted_lop_coo(nranks, n, len(val), _u(row), _u(col), _d(val), _d(x), _d(r), _d(sigma), len(sigma),
-                                  seed, C.byref(o))
+    k = lib().orc_shifted_coo(SHIFTED[which], nranks, n, len(val), _u(row), _u(col), _d(val), _d(x), _d(r), _d(sigma),
+                              len(sigma), seed, C.byref(o))
     return dict(k=k, x=x.reshape(len(sigma), n), r=r, dot_r=o.dot_r, dot_zero=o.dot_zero, alpha=tr[0][:k],
                 omega=tr[1][:k], beta=tr[2][:k], dotr=tr[3][:k])

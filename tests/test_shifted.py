@@ -27,6 +27,13 @@ def test_oracle_bitexact_vs_reference(path):
     o = O.solve_shifted(A.rows, row, col, val, g["b"], g["sigma"], int(g["seed"]))
     assert o["k"] == int(g["k"])
     assert np.array_equal(o["x"], g["x"]) and np.array_equal(o["r"], g["r"])
+    assert bool(g["pipe_variants_bit_identical"])
+    o = O.solve_shifted(A.rows, row, col, val, g["b"], g["sigma"], int(g["seed"]), which="shifted_pipe_lopbicgstab")
+    assert o["k"] == int(g["pipe_k"])
+    assert np.array_equal(o["x"], g["pipe_x"]) and np.array_equal(o["r"], g["pipe_r"])
+    o = O.solve_shifted(A.rows, row, col, val, g["xi_b"], g["sigma"], 0, which="shifted_bicgstab")
+    assert o["k"] == int(g["xi_k"])
+    assert np.array_equal(o["x"], g["xi_x"]) and np.array_equal(o["r"], g["xi_r"])
 
 
 @pytest.mark.gpu
@@ -50,6 +57,37 @@ def test_hip_shifted_vs_golden(path):
     assert np.abs(res["x"] - g["x"]).max() <= 1e-9
     # first iterations of the seed recurrence against the oracle
     o = O.solve_shifted(A.rows, row, col, val, g["b"], sigma, seed)
+    tr = ctx.trace(res["k"])
+    h = min(6, res["k"], o["k"])
+    for key in ("alpha", "omega", "beta", "dotr"):
+        np.testing.assert_allclose(tr[key][:h], o[key][:h], rtol=1e-8, err_msg=key)
+    ctx.close()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("which", ["shifted_pipe_lopbicgstab", "shifted_bicgstab"])
+@pytest.mark.parametrize("path", GOLDEN, ids=lambda p: os.path.basename(p)[:-4])
+def test_hip_shifted_variants_vs_golden(path, which):
+    from mpi_bicgstab_amd import hipsolver as H
+    H.lib().bicg_comm_init_single(0)
+    g, A = _load(path)
+    sigma = g["sigma"]
+    pre = "pipe_" if which == "shifted_pipe_lopbicgstab" else "xi_"
+    seed = int(g["seed"]) if which == "shifted_pipe_lopbicgstab" else 0
+    b = g["b"] if which == "shifted_pipe_lopbicgstab" else g["xi_b"]
+    ctx = H.Context(H.single_rank_blocks(A))
+    res = ctx.solve_shifted(b, sigma, seed, which=which)
+    assert abs(res["k"] - int(g[pre + "k"])) <= 2
+    assert np.abs(res["x"] - g[pre + "x"]).max() <= 1e-8 * max(1.0, np.abs(g[pre + "x"]).max())
+    row, col, val = A.to_coo()
+    shift0 = 0.0 if which == "shifted_bicgstab" else None
+    for j in range(len(sigma)):
+        sg = sigma[j] if not (which == "shifted_bicgstab" and j == 0) else 0.0     # seed system of shifted_bicgstab is A
+        resid = O.spmv(A.rows, row, col, val, res["x"][j]) + sg * res["x"][j] - b
+        ref_resid = O.spmv(A.rows, row, col, val, g[pre + "x"][j]) + sg * g[pre + "x"][j] - b
+        rel, rel_ref = np.linalg.norm(resid) / np.linalg.norm(b), np.linalg.norm(ref_resid) / np.linalg.norm(b)
+        assert rel <= max(10 * rel_ref, 1e-10), (j, rel, rel_ref)
+    o = O.solve_shifted(A.rows, row, col, val, b, sigma, seed, which=which)
     tr = ctx.trace(res["k"])
     h = min(6, res["k"], o["k"])
     for key in ("alpha", "omega", "beta", "dotr"):
