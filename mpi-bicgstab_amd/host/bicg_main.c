@@ -55,7 +55,14 @@ int main(int argc, char **argv)
     CSR_Matrix diag, offd;
     INFO_Matrix info;
     double t0 = wall();
+#ifdef BICG_HAVE_MPI
+    /* every rank tokenises 1/P of the file, triplets are exchanged (the reference has every rank
+     * fscanf the whole file twice, src/matrix.c:315-341, 357-393) */
+    if ((np > 1 ? bicg_mtx_load_block_mpi(argv[1], &diag, &offd, &info)
+                : bicg_mtx_load_block(argv[1], me, np, &diag, &offd, &info)) != 0) exit(EXIT_FAILURE);
+#else
     if (bicg_mtx_load_block(argv[1], me, np, &diag, &offd, &info) != 0) exit(EXIT_FAILURE);
+#endif
     if (me == 0) printf("IO time      : %e [sec.]\n", wall() - t0);
     if (info.cols != info.rows) { printf("Error: matrix is not square.\n"); exit(1); }
 

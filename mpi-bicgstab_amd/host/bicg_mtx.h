@@ -13,8 +13,17 @@
 #include "bicgstab_hip.h"
 
 /* Returns 0 on success; on failure prints to stderr and returns non-zero.
- * Arrays inside diag/offd/info are malloc'ed; release with bicg_mtx_free. */
+ * Arrays inside diag/offd/info are malloc'ed; release with bicg_mtx_free.
+ * Every rank reads and tokenises the whole file (no communication). */
 int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+
+#ifdef BICG_HAVE_MPI
+/* Collective over MPI_COMM_WORLD: every rank tokenises only ITS 1/P byte range of the file (cut at
+ * line boundaries), bins the triplets by owning rank and exchanges them with MPI_Alltoallv; triplets
+ * arrive in source-rank order = file order, so rows keep the reference's stored order. Parse time
+ * drops from T to ~T/P (the reference parses the whole file twice per rank). */
+int bicg_mtx_load_block_mpi(const char *path, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+#endif
 void bicg_mtx_free(CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 
 #endif

@@ -1,0 +1,92 @@
+"""The C host's Matrix-Market block loader (mpi-bicgstab_amd/host/bicg_mtx.c), CPU only.
+
+Serial mode (every rank reads the file) and MPI mode (every rank tokenises 1/P of the bytes, then
+MPI_Alltoallv) must both give what the reference's MPI_csr_load_matrix_block gives: the equal-rows
+partition, diag block with local columns, offd block with global columns, and inside a row the
+FILE order (reference src/matrix.c:135-183, 295-308, 336-392)."""
+import os
+import struct
+import subprocess
+
+import numpy as np
+import pytest
+
+from mpi_bicgstab_amd import synth
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+DUMP = os.path.join(ROOT, "mpi-bicgstab_amd", "host", "bicg_mtx_dump")
+MPIEXEC = "/opt/conda/bin/mpiexec"
+
+pytestmark = pytest.mark.skipif(not (os.path.exists(DUMP) and os.path.exists(MPIEXEC)), reason="host tools / MPI not built")
+
+
+def _read(prefix, rank):
+    raw = open(f"{prefix}.rank{rank}.bin", "rb").read()
+    rows, ncols, nd, no = struct.unpack("4I", raw[:16])
+    off = 16
+
+    def take(dtype, n):
+        nonlocal off
+        a = np.frombuffer(raw, dtype=dtype, count=n, offset=off)
+        off += a.nbytes
+        return a
+    d = (take(np.uint32, rows + 1), take(np.uint32, nd), take(np.float64, nd))
+    o = (take(np.uint32, rows + 1), take(np.uint32, no), take(np.float64, no))
+    return rows, ncols, d, o
+
+
+def _expected(n, row, col, val, world, rank):
+    """stable sort of the file-order triplets by row, then the reference's diag/offd split"""
+    order = np.argsort(row, kind="stable")
+    r, c, v = row[order], col[order], val[order]
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.add.at(ptr, r.astype(np.int64) + 1, 1)
+    ptr = np.cumsum(ptr)
+    A = synth.CSR(n, n, ptr.astype(np.uint32), c.astype(np.uint32), v)
+    return synth.split_blocks(A, world, rank)
+
+
+@pytest.mark.parametrize("order", ["colmajor", "shuffled"])
+@pytest.mark.parametrize("world,mode", [(1, "serial"), (3, "serial"), (2, "mpi"), (3, "mpi"), (5, "mpi")])
+def test_loader_blocks(tmp_path, world, mode, order):
+    A = synth.from_offsets(997, (0, 1, -1, 30, -30, 400, -400), diag_base=7.0, seed=3)
+    row, col, val = synth.colmajor_coo(A)
+    if order == "shuffled":
+        perm = np.random.default_rng(5).permutation(len(val))
+        row, col, val = row[perm], col[perm], val[perm]
+    mtx = str(tmp_path / "m.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% a comment line\n")
+        f.write(f"{A.rows} {A.cols} {A.nnz}\n")
+        for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
+            f.write(f"{i + 1} {j + 1} {v!r}\n")
+    prefix = str(tmp_path / "out")
+    subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode], check=True, timeout=120)
+    for rank in range(world):
+        rows, ncols, d, o = _read(prefix, rank)
+        ed, eo, counts, _ = _expected(A.rows, row, col, val, world, rank)
+        assert rows == counts[rank] and ncols == A.cols
+        assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[1], ed.col) and np.array_equal(d[2], ed.val)
+        assert np.array_equal(o[0], eo.ptr) and np.array_equal(o[1], eo.col) and np.array_equal(o[2], eo.val)
+
+
+def test_loader_symmetric_and_pattern(tmp_path):
+    """beyond the reference: symmetric storage is mirrored, pattern entries become 1.0
+    (the reference's block loader does neither, SURVEY.md section 4 defect 2)"""
+    mtx = str(tmp_path / "s.mtx")
+    open(mtx, "w").write("%%MatrixMarket matrix coordinate pattern symmetric\n4 4 5\n1 1\n2 1\n3 2\n4 4\n4 1\n")
+    prefix = str(tmp_path / "o")
+    subprocess.run([MPIEXEC, "-n", "2", DUMP, mtx, prefix, "mpi"], check=True, timeout=60)
+    dense = np.zeros((4, 4))
+    for rank, lo in ((0, 0), (1, 2)):
+        rows, ncols, d, o = _read(prefix, rank)
+        for i in range(rows):
+            for k in range(d[0][i], d[0][i + 1]):
+                dense[lo + i, lo + d[1][k]] += d[2][k]
+            for k in range(o[0][i], o[0][i + 1]):
+                dense[lo + i, o[1][k]] += o[2][k]
+    want = np.zeros((4, 4))
+    for i, j in ((0, 0), (1, 0), (2, 1), (3, 3), (3, 0)):
+        want[i, j] = 1.0
+        want[j, i] = 1.0
+    assert np.array_equal(dense, want)
