@@ -49,20 +49,42 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--method", default="bicgstab", choices=list(ITER_VECTOR_BYTES_PER_ROW))
-    ap.add_argument("--n", type=int, default=0, help="rows (default: Transport's 1602111)")
+    ap.add_argument("--rows", dest="n", type=int, default=0, help="rows (default: 1602111)")
     ap.add_argument("--scale-decades", type=float, default=2.0)
     ap.add_argument("--workload", default="transport", choices=["transport", "laplace7"],
                     help="transport: BASELINE configs[1] (default). laplace7: 7-point Laplacian on an m^3 grid "
                          "(configs[3] is m = 512 over 8 GPUs = 64 planes of 512^2 per GPU)")
-    ap.add_argument("--m", type=int, default=256, help="grid edge for --workload laplace7")
+    ap.add_argument("--grid", dest="m", type=int, default=256, help="grid edge for --workload laplace7")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100)
+    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
+                    help="rccl (default): RCCL over xGMI, one GPU per rank. host: gloo-staged exchanges, ranks may "
+                         "share a GPU -- only for exercising the multi-rank plumbing on a one-GPU box")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+
+    def note(msg):
+        if rank == 0:
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+    # A hung collective must not hang the driver: after BENCH_WATCHDOG_S seconds every rank gives up.
+    import threading
+
+    def _give_up():
+        if rank == 0:
+            print(json.dumps({"metric": "ms/iteration", "value": None, "unit": "ms/iteration", "n_gpus": world,
+                              "error": f"watchdog: no result after {watchdog_s} s (stage: {stage[0]})"}), flush=True)
+        os._exit(3)
+
+    watchdog_s = int(os.environ.get("BENCH_WATCHDOG_S", "1500"))
+    stage = ["start"]
+    dog = threading.Timer(watchdog_s, _give_up)
+    dog.daemon = True
+    dog.start()
     if world != a.gpus:
         if rank == 0:
             print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}; launch with torch.distributed.run", file=sys.stderr)
@@ -72,13 +94,15 @@ def main():
     import torch
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU (no CPU fallback exists for the HIP path)")
-    torch.cuda.set_device(local_rank)
+    device = local_rank % torch.cuda.device_count()
+    torch.cuda.set_device(device)
 
     from mpi_bicgstab_amd import hipsolver as H
     from mpi_bicgstab_amd import synth
     L = H.lib()
 
     dist = None
+    stage[0] = "communicator bootstrap"
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -90,14 +114,20 @@ def main():
             ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
         dist.broadcast(ident, src=0)
         raw = bytes(ident.numpy().tobytes())
-        L.bicg_comm_init_rccl(rank, world, raw, local_rank)
+        if a.transport == "rccl":
+            L.bicg_comm_init_rccl(rank, world, raw, device)
+        else:
+            from mpi_bicgstab_amd import dist_transport
+            dist_transport.init_host_transport(device)
     else:
-        L.bicg_comm_init_single(local_rank)
+        L.bicg_comm_init_single(device)
 
     def barrier():
         if dist is not None:
             dist.barrier()
 
+    note(f"communicator ready: {world} rank(s)")
+    stage[0] = "matrix generation / upload"
     # ---- workload: this rank's row slab of the global matrix
     if a.workload == "laplace7":
         n = a.m ** 3
@@ -120,6 +150,8 @@ def main():
     x0 = np.zeros(hi - lo)
 
     K, W = a.steps, a.warmup
+    note(f"matrix resident: {plan}")
+    stage[0] = "timed iterations"
 
     def timed_run(method, kernel_events):
         ctx.load(x0, b)
@@ -145,6 +177,8 @@ def main():
     relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
     genuine = res.iterations == W + K and np.isfinite(relres)
 
+    note(f"{a.method}: {ms_step:.4f} ms/iteration")
+    stage[0] = "roofline / variant legs"
     # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
     # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps
     dt_ev, res_ev = timed_run(a.method, kernel_events=True)
@@ -201,7 +235,7 @@ def main():
                                    f"BASELINE.json configs[3] family: 7-point 3-D Laplacian {a.m}^3 generated in memory, b = A*1, x0 = 0",
                        "rows": n, "nnz": nnz_global, "scale_decades": a.scale_decades, "method": a.method,
                        "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
-                       "transport": "rccl" if world > 1 else "none",
+                       "transport": a.transport if world > 1 else "none",
                        "iterations_genuine": bool(genuine), "relres_after_timed_region": relres},
             "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,
             "iteration_algorithmic_bytes": iter_bytes,
@@ -217,6 +251,7 @@ def main():
         }
         print(json.dumps(line), flush=True)
 
+    dog.cancel()
     ctx.close()
     if dist is not None:
         dist.barrier()
