@@ -182,7 +182,6 @@ void launch_shift_pipe2(const Vecs &v, double *p_set, double *x_set, uint32_t se
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 
 unsigned sell_grid(uint32_t ngroups, int per_wg); // workgroups launched for ngroups 256-row groups
-void set_vec_nt(int on);               // experiment: non-temporal vector traffic in the element-wise kernels
 unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
 unsigned spmv_grid(uint32_t nlist);   // workgroups used by the CSR SpMV for nlist row blocks
 

@@ -702,24 +702,18 @@ __device__ __forceinline__ d2 operator*(double s, d2 q) { return {s * q.a, s * q
 __device__ __forceinline__ double hsum(d2 p) { return p.a + p.b; }
 __device__ __forceinline__ double hsum(double p) { return p; }
 
-// experiment switch (BICG_VEC_NT): non-temporal vector traffic in the element-wise kernels
-__device__ int g_vec_nt = 0;
-void set_vec_nt(int on) { (void)hipMemcpyToSymbol(HIP_SYMBOL(g_vec_nt), &on, sizeof(int)); }
-
 template <class T> __device__ __forceinline__ T ld(const double *p, uint32_t i);
 template <> __device__ __forceinline__ double ld<double>(const double *p, uint32_t i) { return p[i]; }
 template <> __device__ __forceinline__ d2 ld<d2>(const double *p, uint32_t i)
 {
-    const f64x2 *q = reinterpret_cast<const f64x2 *>(p + i);
-    const f64x2 t = g_vec_nt ? __builtin_nontemporal_load(q) : *q;
+    const f64x2 t = *reinterpret_cast<const f64x2 *>(p + i);
     return {t.x, t.y};
 }
 __device__ __forceinline__ void st(double *p, uint32_t i, double v) { p[i] = v; }
 __device__ __forceinline__ void st(double *p, uint32_t i, d2 v)
 {
     f64x2 t; t.x = v.a; t.y = v.b;
-    f64x2 *q = reinterpret_cast<f64x2 *>(p + i);
-    if (g_vec_nt) __builtin_nontemporal_store(t, q); else *q = t;
+    *reinterpret_cast<f64x2 *>(p + i) = t;
 }
 
 // F::ND dot products, F::load(S) fetches the scalars once, F::apply<T>(i, acc) handles element(s) i.

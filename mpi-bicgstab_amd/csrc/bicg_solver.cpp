@@ -125,7 +125,6 @@ struct bicg_ctx {
     // BICG_FORCE_COMM=1 (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
     // apply kernels, two streams) even with one rank, so that it can be exercised on a one-GPU box
     bool force_comm = false;
-    int vec_nt = 0;
     bool single() const { return nranks == 1 && !force_comm; }
 
     // Use the second (communication) stream to overlap the halo exchange with the interior rows and
@@ -388,7 +387,6 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     if (o.check_every < 1) o.check_every = 1;
     c->method = method;
     BICG_HIP(hipSetDevice(c->comm->device));
-    set_vec_nt(c->vec_nt);
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -750,7 +748,6 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     const bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
-    if (const char *sv = getenv("BICG_VEC_NT")) c->vec_nt = atoi(sv);
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     c->overlap = c->nnz_d >= 6000000u;
     if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;

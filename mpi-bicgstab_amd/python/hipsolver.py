@@ -14,7 +14,7 @@ import numpy as np
 from .synth import CSR
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-LIB_PATH = os.path.join(PKG_DIR, "libbicgstab_hip.so")
+LIB_PATH = os.environ.get("BICG_HIP_LIB") or os.path.join(PKG_DIR, "libbicgstab_hip.so")
 
 METHODS = {"bicgstab": 0, "ca_bicgstab": 1, "pipe_bicgstab": 2, "pipe_bicgstab_rr": 3}
 

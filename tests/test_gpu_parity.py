@@ -142,3 +142,56 @@ def test_transport_shaped_medium():
         assert abs(res["k"] - orc["k"]) <= 2, method
         assert np.abs(res["x"] - 1.0).max() <= 1e-9
     ctx.close()
+
+
+@pytest.mark.parametrize("n", [1, 2, 5, 63, 64, 65, 255, 256, 257, 1000])
+def test_tiny_and_odd_sizes(n):
+    """rows not a multiple of the slice (64) / group (256) / vector width (2); single-row systems"""
+    A = synth.from_offsets(n, (0, 1, -1, 3, -3), diag_base=5.0, seed=n)
+    row, col, val = A.to_coo()
+    ctx = H.Context(H.single_rank_blocks(A))
+    x = np.random.default_rng(n).standard_normal(n)
+    assert np.array_equal(ctx.spmv(x), O.spmv(n, row, col, val, x))
+    b = O.spmv(n, row, col, val, np.ones(n))
+    for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab_rr"):
+        orc = O.solve(method, n, row, col, val, b, krr=5, nrr=2, tol=1e-13)
+        got = ctx.solve(method, b, krr=5, nrr=2, tol=1e-13)
+        assert abs(got["k"] - orc["k"]) <= 2, (method, n, got["k"], orc["k"])
+        if np.isfinite(orc["x"]).all():
+            assert np.abs(got["x"] - 1.0).max() <= 1e-9, (method, n)
+        else:
+            # e.g. n = 1: q = r - alpha s is exactly 0 after one step, omega = 0/0 -- the reference
+            # returns NaN there (its recurrence has no breakdown test); same k, same NaNs here
+            assert got["k"] == orc["k"] and np.array_equal(np.isnan(got["x"]), np.isnan(orc["x"])), (method, n)
+    ctx.close()
+
+
+def test_zero_rhs_nonzero_guess_and_zero_iterations():
+    A = synth.stencil7(6)
+    row, col, val = A.to_coo()
+    ctx = H.Context(H.single_rank_blocks(A))
+    # b = 0: (r0,r0) = 0, the reference's loop condition 0 > 0 is false -> k = 0, x untouched
+    res = ctx.solve("bicgstab", np.zeros(A.rows))
+    assert res["k"] == 0 and np.all(res["x"] == 0.0)
+    # MAX_ITER = 0: set-up only; r = b - A x0 (reference src/solver.c:74-75)
+    b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+    x0 = np.linspace(-1.0, 1.0, A.rows)
+    res = ctx.solve("bicgstab", b, x0=x0, max_iter=0)
+    assert res["k"] == 0 and np.array_equal(res["x"], x0)
+    assert np.array_equal(res["r"], b - O.spmv(A.rows, row, col, val, x0))
+    # non-zero initial guess converges to the same solution, same count as the oracle
+    orc = O.solve("bicgstab", A.rows, row, col, val, b, x0=x0)
+    res = ctx.solve("bicgstab", b, x0=x0)
+    assert abs(res["k"] - orc["k"]) <= 2 and np.abs(res["x"] - 1.0).max() <= 1e-9
+    ctx.close()
+
+
+def test_breakdown_is_reported():
+    """a singular system makes the recurrence produce non-finite scalars; the reference iterates on
+    NaNs silently, the library flags the first such iteration"""
+    n = 64
+    A = synth.CSR(n, n, np.arange(n + 1, dtype=np.uint32), np.arange(n, dtype=np.uint32), np.zeros(n))   # A = 0
+    ctx = H.Context(H.single_rank_blocks(A))
+    res = ctx.solve("bicgstab", np.ones(n), max_iter=5)
+    assert res["result"].breakdown_iteration >= 1
+    ctx.close()
