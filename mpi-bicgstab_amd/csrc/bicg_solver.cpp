@@ -794,13 +794,32 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     std::vector<uint32_t> gl_int, gl_bnd;
     std::vector<uint4> bint, bbnd;
     std::vector<char> group_is_sell(ngroups, 0);
+    auto group_fits = [&](uint32_t g, uint64_t *padded_out) {
+        const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
+        const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
+        uint64_t padded = 0;
+        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) padded += (uint64_t)slice_len[sl] * kSliceRows;
+        *padded_out = padded;
+        return padded <= nnz_g + nnz_g / 4 + 2 * kSliceRows;
+    };
+    // Ragged matrices (unstructured FEM: row lengths 3..26) leave only a few groups under the
+    // padding limit; two kernels per SpMV are then slower than the CSR kernel alone (measured on
+    // synth.fem_like: 70 vs 63 us), and sorting rows by length inside the groups (SELL-C-sigma)
+    // removes the padding but also the coalesced x gather (66.9 us). So: sliced ELL only when at
+    // least half of the rows qualify.
+    bool sell_worthwhile = use_sell;
+    if (use_sell) {
+        uint64_t rows_fit = 0, dummy;
+        for (uint32_t g = 0; g < ngroups; ++g)
+            if (group_fits(g, &dummy)) rows_fit += std::min(nrows, (g + 1) * (uint32_t)kGroupRows) - g * kGroupRows;
+        sell_worthwhile = 2 * rows_fit >= nrows;
+    }
     uint64_t sell_entries = 0;
     for (uint32_t g = 0; g < ngroups; ++g) {
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
         const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
         uint64_t padded = 0;
-        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) padded += (uint64_t)slice_len[sl] * kSliceRows;
-        const bool sell = use_sell && padded <= nnz_g + nnz_g / 4 + 2 * kSliceRows && sell_entries + padded < 0xFFFFFF00ull;
+        const bool sell = sell_worthwhile && group_fits(g, &padded) && sell_entries + padded < 0xFFFFFF00ull;
         group_is_sell[g] = sell;
         if (!sell) continue;
         for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) {

@@ -103,6 +103,24 @@ def transport_like(n: int = TRANSPORT_N, diag_base: float = 16.0, seed: int = 12
     return from_offsets(n, TRANSPORT_OFFSETS, diag_base, seed, rows, scale_decades)
 
 
+def fem_like(n: int = TRANSPORT_N, seed: int = 4242, keep: float = 0.55) -> CSR:
+    """Irregular rows like an unstructured FEM matrix: a 27-offset 3-D stencil (117 x 117 x ~117
+    node numbering) from which every off-diagonal entry is kept with probability `keep`, so row
+    lengths vary between ~6 and 27 (mean ~15.3 at keep = 0.55; Transport.mtx: 14.66). Used to
+    exercise the sliced-ELL / CSR hybrid on ragged rows; values follow from_offsets' law."""
+    nx = 117
+    offs = sorted({dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)})
+    A = from_offsets(n, offs, diag_base=32.0, seed=seed)
+    ptr = A.ptr.astype(np.int64)
+    rowid = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
+    is_diag = A.col.astype(np.int64) == rowid
+    keep_mask = is_diag | (_uniform(np.arange(A.nnz, dtype=np.int64), seed + 1) < keep)
+    cnt = np.bincount(rowid[keep_mask], minlength=n)
+    p2 = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(cnt, out=p2[1:])
+    return CSR(n, n, p2.astype(np.uint32), A.col[keep_mask], A.val[keep_mask])
+
+
 def transport_nnz(n: int = TRANSPORT_N) -> int:
     """non-zeros of transport_like(n) without building it"""
     return sum(max(n - abs(o), 0) for o in TRANSPORT_OFFSETS)
