@@ -55,6 +55,8 @@ def main():
                     help="transport: BASELINE configs[1] (default). laplace7: 7-point Laplacian on an m^3 grid "
                          "(configs[3] is m = 512 over 8 GPUs = 64 planes of 512^2 per GPU)")
     ap.add_argument("--grid", dest="m", type=int, default=256, help="grid edge for --workload laplace7")
+    ap.add_argument("--matrix", default=None, help="Matrix-Market file (coordinate real general) instead of the "
+                    "synthetic; data/Transport.mtx is picked up automatically when it exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100)
@@ -129,20 +131,28 @@ def main():
     note(f"communicator ready: {world} rank(s)")
     stage[0] = "matrix generation / upload"
     # ---- workload: this rank's row slab of the global matrix
-    if a.workload == "laplace7":
+    mtx = a.matrix or (os.path.join(ROOT, "data", "Transport.mtx") if a.workload == "transport" and not a.n and
+                       os.path.exists(os.path.join(ROOT, "data", "Transport.mtx")) else None)
+    if mtx:
+        blocks = H.load_mtx_blocks(mtx, rank, world)
+        n, nnz_global = int(blocks.info.rows), blocks.nnz_global
+        counts, displs = synth.partition(n, world)
+        lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+    elif a.workload == "laplace7":
         n = a.m ** 3
         nnz_global = synth.stencil7_nnz(a.m)
     else:
         n = a.n or synth.TRANSPORT_N
         nnz_global = synth.transport_nnz(n)
-    counts, displs = synth.partition(n, world)
-    lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
-    if a.workload == "laplace7":
-        slab = synth.stencil7(a.m, synth.LAPLACE_WEIGHTS, rows=(lo, hi))
-    else:
-        slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
-    diag, offd = synth.split_row_slab(slab, lo)
-    blocks = H.HostBlocks(diag, offd if world > 1 else None, n, counts, displs)
+    if not mtx:
+        counts, displs = synth.partition(n, world)
+        lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+        if a.workload == "laplace7":
+            slab = synth.stencil7(a.m, synth.LAPLACE_WEIGHTS, rows=(lo, hi))
+        else:
+            slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
+        diag, offd = synth.split_row_slab(slab, lo)
+        blocks = H.HostBlocks(diag, offd if world > 1 else None, n, counts, displs)
     ctx = H.Context(blocks)
     plan = ctx.plan_info()
     ones = np.ones(hi - lo)
@@ -187,7 +197,7 @@ def main():
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     traffic = None
     pmc = os.path.join(ROOT, "profiles", "pmc_spmv.json")
-    if os.path.exists(pmc) and a.workload == "transport" and not a.n and world == 1:
+    if os.path.exists(pmc) and a.workload == "transport" and not a.n and world == 1 and not mtx:
         try:
             traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
         except Exception:
@@ -213,7 +223,7 @@ def main():
     spmv_alone_ms = ctx.spmv_bench(200)
 
     cpu = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "transport":
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "transport" and not mtx:
         try:
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--n", str(n),
                                   "--scale-decades", str(a.scale_decades), "--iters", str(a.cpu_iters),

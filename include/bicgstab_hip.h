@@ -233,6 +233,14 @@ int bicg_halo_send_lists(int rank, int nranks, const INFO_Matrix *info, unsigned
 unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int rows, unsigned int chunk,
                              unsigned int max_rows, unsigned int *rowblk);
 
+/* Matrix-Market block loader (host only): what MPI_csr_load_matrix_block produces for `rank` of
+ * `nranks` (reference src/matrix.c:402-419) -- diag block with local columns, offd block with global
+ * columns, file order inside a row, equal-rows partition -- reading the file once. Arrays are
+ * malloc'ed; release with bicg_mtx_free. Returns 0 on success. (The C host additionally has an MPI
+ * variant in which every rank tokenises 1/P of the file, mpi-bicgstab_amd/host/bicg_mtx.h.) */
+int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+void bicg_mtx_free(CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+
 const char *bicg_version(void);
 
 #ifdef __cplusplus

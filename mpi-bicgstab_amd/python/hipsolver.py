@@ -55,7 +55,7 @@ EXPORTS = [
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info",
-    "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_version",
+    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_version",
 ]
 
 _lib = None
@@ -139,6 +139,29 @@ class HostBlocks:
         self._keep += [cnt, dsp]
         self.info = InfoMatrix(0, n_global, n_global, b"MCRG", cnt.ctypes.data_as(_ip), dsp.ctypes.data_as(_ip))
         self.n_loc = diag.rows
+
+
+def load_mtx_blocks(path: str, rank: int = 0, nranks: int = 1) -> HostBlocks:
+    """This rank's blocks of a Matrix-Market file through the library's loader (C, reads the file once)."""
+    d, o, info = CSRMatrix(), CSRMatrix(), InfoMatrix()
+    L = lib()
+    L.bicg_mtx_load_block.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix)]
+    if L.bicg_mtx_load_block(path.encode(), rank, nranks, C.byref(d), C.byref(o), C.byref(info)) != 0:
+        raise RuntimeError(f"cannot load {path}")
+
+    def to_csr(m, ncols):
+        nz = int(m.ptr[m.rows])
+        return CSR(m.rows, ncols, np.ctypeslib.as_array(m.ptr, shape=(m.rows + 1,)).copy(),
+                   np.ctypeslib.as_array(m.col, shape=(max(nz, 1),))[:nz].copy(),
+                   np.ctypeslib.as_array(m.val, shape=(max(nz, 1),))[:nz].copy())
+    diag, offd = to_csr(d, d.rows), to_csr(o, info.cols)
+    counts = np.ctypeslib.as_array(info.recvcounts, shape=(nranks,)).copy()
+    displs = np.ctypeslib.as_array(info.displs, shape=(nranks,)).copy()
+    n = int(info.rows)
+    L.bicg_mtx_free(C.byref(d), C.byref(o), C.byref(info))
+    blk = HostBlocks(diag, offd if nranks > 1 else None, n, counts, displs)
+    blk.nnz_global = int(info.nz)
+    return blk
 
 
 def single_rank_blocks(A: CSR) -> HostBlocks:
