@@ -239,7 +239,7 @@ def main():
                       + f" ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
             "value": ms_step, "unit": "ms/iteration", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": "synthetic",
+            "dtype": "f64", "data": ("synthetic" if not mtx else "file:" + os.path.basename(mtx)),
             "config": {"workload": ("BASELINE.json configs[1]: plain BiCGStab, Transport-shaped synthetic "
                                     "(Transport.mtx unavailable offline), b = A*1, x0 = 0") if a.workload == "transport" else
                                    f"BASELINE.json configs[3] family: 7-point 3-D Laplacian {a.m}^3 generated in memory, b = A*1, x0 = 0",
