@@ -195,3 +195,22 @@ def test_breakdown_is_reported():
     res = ctx.solve("bicgstab", np.ones(n), max_iter=5)
     assert res["result"].breakdown_iteration >= 1
     ctx.close()
+
+
+def test_contexts_do_not_leak_device_memory():
+    import torch
+    A = synth.transport_like(n=100_000)
+    b = A.matvec(np.ones(A.rows))
+
+    def cycle():
+        ctx = H.Context(H.single_rank_blocks(A))
+        ctx.solve("pipe_bicgstab_rr", b, krr=5, nrr=2, tol=1e-10)
+        ctx.solve_shifted(b, np.array([0.0, 0.01, 0.02]), 1, tol=1e-10)
+        ctx.close()
+    cycle()
+    torch.cuda.synchronize()
+    free0 = torch.cuda.mem_get_info()[0]
+    for _ in range(5):
+        cycle()
+    torch.cuda.synchronize()
+    assert abs(torch.cuda.mem_get_info()[0] - free0) < 8 * 1024 * 1024
