@@ -107,3 +107,23 @@ def test_synth_matches_oracle_partition():
     y3 = O.spmv(A.rows, row, col, val, x, nranks=3)
     assert np.abs(y1 - y3).max() <= 1e-13 * np.abs(y1).max()
     assert np.abs(A.matvec(x) - y1).max() <= 1e-13 * np.abs(y1).max()
+
+
+def test_header_is_plain_c_and_coexists_with_reference_headers(tmp_path):
+    """include/bicgstab_hip.h compiles as C99 on its own, and after the reference's solver.h (whose
+    matrix.h typedefs it then reuses) when /root/reference is mounted"""
+    import subprocess
+    inc = os.path.join(ROOT, "include")
+    src = tmp_path / "a.c"
+    src.write_text('#include "bicgstab_hip.h"\n'
+                   'typedef int (*solver_fn)(CSR_Matrix *, CSR_Matrix *, INFO_Matrix *, double *, double *);\n'
+                   'solver_fn pick(int i) { bicg_options o; bicg_default_options(&o); return i ? bicgstab : pipe_bicgstab; }\n'
+                   'int sizes(void) { return (int)sizeof(CSR_Matrix) + (int)sizeof(INFO_Matrix); }\n')
+    subprocess.run(["gcc", "-std=c99", "-Wall", "-Werror", "-fsyntax-only", f"-I{inc}", str(src)], check=True)
+    ref = "/root/reference/src"
+    if os.path.exists(os.path.join(ref, "solver.h")) and os.path.exists("/opt/conda/include/mpi.h"):
+        src2 = tmp_path / "b.c"
+        src2.write_text('#include "solver.h"\n#include "bicgstab_hip.h"\n'
+                        'int g(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return bicgstab(d, o, i, x, r); }\n')
+        subprocess.run(["gcc", "-std=gnu99", "-w", "-fsyntax-only", f"-I{ref}", "-I/opt/conda/include", f"-I{inc}", str(src2)],
+                       check=True)
