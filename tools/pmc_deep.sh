@@ -4,12 +4,11 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/pmcd
 rm -rf $OUT; mkdir -p $OUT
-V=${1:-0}
 i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  BICG_SPMV_VARIANT=$V timeout 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p --output-format csv -- python $R/tools/spmv_only.py > $OUT/p$i.log 2>&1
+  timeout 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p --output-format csv -- python $R/tools/spmv_only.py > $OUT/p$i.log 2>&1
 done <<SETS
 SQ_WAVES SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VMEM SQ_INST_LEVEL_VMEM
 SQ_INSTS_VMEM_RD SQ_INSTS_LDS SQ_INSTS_VALU SQ_INSTS_SMEM SQ_INST_CYCLES_VMEM_RD SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS

@@ -7,4 +7,4 @@ from mpi_bicgstab_amd import hipsolver as H, synth
 H.lib().bicg_comm_init_single(0)
 A = synth.transport_like(n=int(os.environ.get("SPMV_N", synth.TRANSPORT_N)), scale_decades=2.0)
 ctx = H.Context(H.single_rank_blocks(A))
-print("variant", os.environ.get("BICG_SPMV_VARIANT"), "ms", ctx.spmv_bench(20))
+print(ctx.plan_info(), "ms per SpMV", ctx.spmv_bench(20))
