@@ -60,7 +60,8 @@ typedef struct {
  * the reference's progress and summary lines verbatim (src/solver.c:124,135-139). The matrix is
  * never modified. Constants default to the reference's (EPS 1e-15, MAX_ITER 1000, OUT_ITER 100;
  * src/solver.c:3-9) and can be overridden without an ABI change through the environment:
- * BICG_TOL, BICG_MAX_ITER, BICG_OUT_ITER, BICG_CHECK_EVERY, BICG_QUIET.
+ * BICG_TOL, BICG_MAX_ITER, BICG_OUT_ITER, BICG_CHECK_EVERY, BICG_QUIET, BICG_RR_DRIFT (adaptive
+ * residual replacement for the pipelined solvers, off by default).
  *
  * Rank discovery: if the process has initialised MPI (the reference's main.c does) the library
  * picks rank/size up from MPI_COMM_WORLD through weak symbols and bootstraps RCCL with an
@@ -144,6 +145,10 @@ typedef struct {
     int    krr, nrr;     /* residual replacement period / count (src/solver.c:433) */
     int    record_trace; /* 1: keep per-iteration alpha/omega/beta/(r,r) on the device */
     int    time_kernels; /* 1: give every SpMV kernel its own start/stop HIP events (roofline measurement) */
+    double rr_drift;     /* pipelined solvers, additive: > 0 enables ADAPTIVE residual
+                            replacement -- at every host check the true residual b - A x is computed and, when
+                            ||(b - A x) - r|| > rr_drift * ||r||, the next iteration is a replacement step
+                            (the step of src/solver.c:498-508, 522-531). 0 = the reference's fixed krr/nrr policy only. */
 } bicg_options;
 
 typedef struct {
@@ -156,6 +161,7 @@ typedef struct {
     int    spmv_launches;  /* number of SpMVs timed (an SpMV may consist of up to 4 kernels) */
     int    breakdown_iteration; /* first iteration with a non-finite alpha/beta/omega/(r,r); 0 = none.
                               The reference does not detect breakdown (it iterates on NaNs). */
+    int    adaptive_replacements; /* replacement steps triggered by rr_drift */
 } bicg_result;
 
 void bicg_default_options(bicg_options *o);

@@ -178,6 +178,8 @@ void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t st);
 void launch_shift_pipe1(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t st);
 void launch_shift_pipe2(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
                         Scal *S, Reduce red, hipStream_t st);
+// adaptive residual replacement: red[0] = ||(b - Ax) - r||^2, red[1] = ||r||^2
+void launch_drift(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
 // standalone dot (x,y) -> red[0]
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 

@@ -1160,6 +1160,20 @@ void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t s)
     run_vec(FShiftPSeed{p_seed, v.r, v.s, 0.0, 0.0}, v.n, S, Reduce{}, s);
 }
 
+struct FDrift {     // how far the recursive residual has drifted from the true one (adaptive replacement)
+    static constexpr int ND = 2;
+    const double *b, *ax, *r;
+    __device__ void load(const Scal *) {}
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        const T rr = ld<T>(r, i);
+        const T dlt = (ld<T>(b, i) + (-1.0) * ld<T>(ax, i)) - rr;
+        acc[0] += hsum(dlt * dlt);
+        acc[1] += hsum(rr * rr);
+    }
+};
+void launch_drift(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FDrift{v.b, v.ax, v.r}, v.n, S, red, s); }
+
 struct FDot {
     static constexpr int ND = 1;
     const double *x, *y;

@@ -115,7 +115,7 @@ struct bicg_ctx {
 
     // state of the solve in progress (run_begin / run_iterate / run_end)
     bicg_options opt{};
-    int method = 0, it = 0, printed = 0;
+    int method = 0, it = 0, printed = 0, adaptive_rr = 0;
     double t_begin = 0.0, t_init = 0.0, t_iter = 0.0;
 
     // per-SpMV timing
@@ -293,6 +293,8 @@ void group_flush(bicg_ctx *c)
     c->pend_ev = nullptr;
 }
 
+void fetch_scal(bicg_ctx *c);
+
 // ---------------------------------------------------------------- the four iterations
 struct Driver {
     bicg_ctx *c;
@@ -307,7 +309,7 @@ struct Driver {
     void init()
     {
         const bool plain = method == BICG_BICGSTAB;
-        const bool rr = method == BICG_PIPE_BICGSTAB_RR;
+        const bool rr = method == BICG_PIPE_BICGSTAB_RR || (method == BICG_PIPE_BICGSTAB && c->opt.rr_drift > 0.0);
         spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));                       // Ax = A x0
         launch_init_residual(v, plain, rr, S, c->red(0, PH_INIT), sc);             // r = b - Ax, r# = r, (r,r)
         group_now(c, 1, PH_INIT);
@@ -345,9 +347,10 @@ struct Driver {
         group_now(c, 5, PH_RECUR_END);
     }
 
-    void iter_pipe(int it)   // reference src/solver.c:352-390 and 494-548
+    void iter_pipe(int it, bool force_replace)   // reference src/solver.c:352-390 and 494-548
     {
-        const bool replace = method == BICG_PIPE_BICGSTAB_RR && krr > 0 && (it % krr == 0) && it > 0 && it <= krr * nrr;
+        const bool replace = force_replace ||
+                             (method == BICG_PIPE_BICGSTAB_RR && krr > 0 && (it % krr == 0) && it > 0 && it <= krr * nrr);
         if (!replace) {
             launch_pipe_f1(v, S, c->red(0, PH_OMEGA), sc);           // p, s, z, q, y, (q,y), (y,y)
             group_defer(c, 2, PH_OMEGA);
@@ -373,13 +376,23 @@ struct Driver {
         group_flush(c);
     }
 
-    void iterate(int it)
+    void iterate(int it, bool force_replace = false)
     {
         switch (method) {
         case BICG_BICGSTAB: iter_plain(); break;
         case BICG_CA_BICGSTAB: iter_ca(); break;
-        default: iter_pipe(it); break;
+        default: iter_pipe(it, force_replace); break;
         }
+    }
+
+    // adaptive residual replacement (additive): true residual vs recursive one
+    double drift()
+    {
+        spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));
+        launch_drift(v, S, c->red(0, PH_NONE), sc);
+        group_now(c, 2, PH_NONE);
+        fetch_scal(c);
+        return c->hS->red[1] > 0.0 ? sqrt(c->hS->red[0] / c->hS->red[1]) : 0.0;
     }
 };
 
@@ -442,7 +455,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     }
     BICG_HIP(hipStreamSynchronize(c->sc));
 
-    c->it = 0; c->printed = 0; c->t_iter = 0.0;
+    c->it = 0; c->printed = 0; c->t_iter = 0.0; c->adaptive_rr = 0;
     c->t_begin = now_sec();
     Driver d(c, method, o.krr, o.nrr);
     d.init();
@@ -465,7 +478,7 @@ bool graph_iteration(bicg_ctx *c, Driver &d)
     // GPU busy (54 us vs 60 us replayed per 17-op iteration of a 200 k-row rank); replay only pays
     // when the two-stream overlap mode is on (80 vs 105 us).
     const bool want = c->graph_mode == 1;
-    if (!want || m == BICG_PIPE_BICGSTAB_RR || c->time_kernels || !c->comm->stream_ordered()) return false;
+    if (!want || m == BICG_PIPE_BICGSTAB_RR || c->opt.rr_drift > 0.0 || c->time_kernels || !c->comm->stream_ordered()) return false;
     if (c->graph_exec[m] && c->graph_nt[m] != c->sell_nt) {     // captured with the other streaming policy
         (void)hipGraphExecDestroy(c->graph_exec[m]);
         c->graph_exec[m] = nullptr;
@@ -501,7 +514,13 @@ int run_iterate(bicg_ctx *c, int nsteps)
     const int stop = std::min(o.max_iter, c->it + std::max(nsteps, 0));
     while (!c->hS->done && c->it < stop) {
         const int chunk = std::min(o.check_every, stop - c->it);
+        bool force = false;
+        if (o.rr_drift > 0.0 && c->method >= BICG_PIPE_BICGSTAB && c->it > 0 && d.drift() > o.rr_drift) {
+            force = true;
+            c->adaptive_rr++;
+        }
         for (int j = 0; j < chunk; ++j) {
+            if (j == 0 && force) { d.iterate(c->it, true); continue; }
             if (!graph_iteration(c, d)) d.iterate(c->it + j);
         }
         c->it += chunk;
@@ -547,6 +566,7 @@ int run_end(bicg_ctx *c, bicg_result *res)
         res->spmv_ms_total = spmv_ms;
         res->spmv_launches = spmv_n;
         res->breakdown_iteration = c->hS->breakdown_k;
+        res->adaptive_replacements = c->adaptive_rr;
     }
     if (c->hS->breakdown_k && c->rank == 0 && !o.quiet)
         fprintf(stderr, "bicgstab_hip: recurrence broke down (non-finite scalar) at iteration %d\n", c->hS->breakdown_k);
@@ -715,6 +735,7 @@ void env_options(bicg_options *o)
     if (const char *s = getenv("BICG_OUT_ITER")) o->out_iter = atoi(s);
     if (const char *s = getenv("BICG_CHECK_EVERY")) o->check_every = atoi(s);
     if (const char *s = getenv("BICG_QUIET")) o->quiet = atoi(s);
+    if (const char *s = getenv("BICG_RR_DRIFT")) o->rr_drift = atof(s);
 }
 
 int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, double *x, double *r, int krr, int nrr)

@@ -35,13 +35,13 @@ class InfoMatrix(C.Structure):     # include/bicgstab_hip.h (reference src/matri
 class Options(C.Structure):
     _fields_ = [("tol", C.c_double), ("max_iter", C.c_int), ("out_iter", C.c_int), ("check_every", C.c_int),
                 ("quiet", C.c_int), ("krr", C.c_int), ("nrr", C.c_int), ("record_trace", C.c_int),
-                ("time_kernels", C.c_int)]
+                ("time_kernels", C.c_int), ("rr_drift", C.c_double)]
 
 
 class Result(C.Structure):
     _fields_ = [("iterations", C.c_int), ("dot_r", C.c_double), ("dot_zero", C.c_double), ("seconds", C.c_double),
                 ("iter_seconds", C.c_double), ("spmv_ms_total", C.c_double), ("spmv_launches", C.c_int),
-                ("breakdown_iteration", C.c_int)]
+                ("breakdown_iteration", C.c_int), ("adaptive_replacements", C.c_int)]
 
 
 ALLREDUCE_FN = C.CFUNCTYPE(None, _dp, C.c_int, C.c_void_p)

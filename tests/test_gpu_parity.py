@@ -214,3 +214,21 @@ def test_contexts_do_not_leak_device_memory():
         cycle()
     torch.cuda.synchronize()
     assert abs(torch.cuda.mem_get_info()[0] - free0) < 8 * 1024 * 1024
+
+
+def test_adaptive_residual_replacement():
+    """with rr_drift > 0 the pipelined solver replaces the residual
+    when the recursive one has drifted from b - A x. On the 12^3 KAT matrix the reference's
+    pipe_bicgstab never reaches EPS = 1e-15 (stagnates for 1000 iterations or breaks down, SURVEY
+    section 4); with adaptive replacement it converges like the other solvers."""
+    g = np.load([p for p in GOLDEN if p.endswith("stencil7_m12.npz")][0])
+    A = _csr(g)
+    assert int(g["pipe_bicgstab_P1_k"]) == 1000                 # the reference runs into MAX_ITER
+    ctx = H.Context(H.single_rank_blocks(A))
+    plain = ctx.solve("bicgstab", g["b_P1"])
+    res = ctx.solve("pipe_bicgstab", g["b_P1"], rr_drift=1e-3, check_every=8)
+    assert res["result"].adaptive_replacements >= 1
+    assert res["k"] <= plain["k"] + 24                          # converged, close to the plain solver's count
+    assert np.sqrt(res["dot_r"] / res["dot_zero"]) <= 1e-15
+    assert np.abs(res["x"] - 1.0).max() <= 1e-9
+    ctx.close()
