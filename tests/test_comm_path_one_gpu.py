@@ -15,6 +15,7 @@ from mpi_bicgstab_amd import synth
 pytestmark = pytest.mark.gpu
 
 METHODS = [("bicgstab", 1e-15), ("ca_bicgstab", 1e-15), ("pipe_bicgstab", 1e-9), ("pipe_bicgstab_rr", 1e-15)]
+SHIFTED = ["shifted_lopbicgstab", "shifted_pipe_lopbicgstab", "shifted_bicgstab"]
 
 
 def _solve_all(A, b, **env):
@@ -27,6 +28,10 @@ def _solve_all(A, b, **env):
         for m, tol in METHODS:
             r = ctx.solve(m, b, tol=tol, krr=10, nrr=3, check_every=5)
             out[m] = (r["k"], r["x"].copy(), r["r"].copy())
+        sigma = 0.01 * (np.arange(4) + 1.0)
+        for which in SHIFTED:      # b doubles as the right-hand side of the seed system here
+            r = ctx.solve_shifted(b, sigma, 1, which=which, tol=1e-11, check_every=5)
+            out[which] = (r["k"], r["x"].copy(), r["r"].copy())
         ctx.close()
         return out
     finally:
@@ -48,7 +53,7 @@ def problem():
 
 
 def _same(got, ref):
-    for m, _ in METHODS:
+    for m in [m for m, _ in METHODS] + SHIFTED:
         assert got[m][0] == ref[m][0], m
         assert np.array_equal(got[m][1], ref[m][1]) and np.array_equal(got[m][2], ref[m][2]), m
 
