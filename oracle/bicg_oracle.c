@@ -170,7 +170,7 @@ void orc_dcopy(int n, const double *x, double *y) { for (int i = 0; i < n; ++i) 
 /* my_ddot per rank + MPI_Iallreduce(MPI_SUM) (e.g. src/solver.c:89-91). MPI leaves the
  * association of the P partial sums unspecified; MPICH's recursive doubling gives the balanced
  * pairwise tree ((p0+p1)+(p2+p3))+... for power-of-two P, which is what is restated here
- * (bit-identical to the reference under conda MPICH 3.3.2 at P = 1, 2, 4 -- see
+ * (bit-identical to the reference under conda MPICH 3.3.2 at P = 1, 2, 4, 8 -- see
  * tests/test_oracle_golden.py). Other P: pairs first, leftovers carried upward. */
 double orc_dist_dot(const orc_dist *d, const double *x, const double *y)
 {

@@ -10,7 +10,7 @@ from a column-major .mtx file after its stable row sort, reference src/matrix.c:
 b = A*1 computed BY THE REFERENCE at each rank count (b_P1, b_P2, b_P4: the diag-then-offd
 summation of src/matrix.c:437-440 makes b depend on P in the last bits; src/main.c:109-117), and for every solver x P combination the
 reference's outputs: iteration count k, solution x, recursive residual r (concatenated rank
-blocks). P = 1 goes through libref.so in-process; P = 2, 4 run oracle/_ref/ref_dump under mpiexec
+blocks). P = 1 goes through libref.so in-process; P = 2, 4, 8 run oracle/_ref/ref_dump under mpiexec
 on a .mtx file written with 17 significant digits.
 
 The reference constants are compiled in: EPS = 1e-15, MAX_ITER = 1000 (src/solver.c:3-4).
@@ -77,7 +77,7 @@ def main():
         with tempfile.TemporaryDirectory() as td:
             mtx = os.path.join(td, name + ".mtx")
             synth.write_mtx(mtx, A)
-            for P in (2, 4):
+            for P in (2, 4, 8):
                 _, y, _ = run_ref_dump(mtx, "spmv", (), P, A.rows)
                 out[f"spmv_y_P{P}"] = y
                 _, _, bP = run_ref_dump(mtx, "rhs", (), P, A.rows)
@@ -85,12 +85,12 @@ def main():
             for method, extra in SOLVERS:
                 res = R.solve(method, M, out["b"], *(extra or (0, 0)))
                 out[f"{method}_P1_k"], out[f"{method}_P1_x"], out[f"{method}_P1_r"] = res["k"], res["x"], res["r"]
-                for P in (2, 4):
+                for P in (2, 4, 8):
                     k, x, r = run_ref_dump(mtx, method, extra, P, A.rows)
                     out[f"{method}_P{P}_k"], out[f"{method}_P{P}_x"], out[f"{method}_P{P}_r"] = k, x, r
         np.savez_compressed(os.path.join(HERE, name + ".npz"), **out)
         print(name, "n =", A.rows, "nnz =", A.nnz,
-              {m: [int(out[f"{m}_P{P}_k"]) for P in (1, 2, 4)] for m, _ in SOLVERS})
+              {m: [int(out[f"{m}_P{P}_k"]) for P in (1, 2, 4, 8)] for m, _ in SOLVERS})
 
 
 if __name__ == "__main__":
