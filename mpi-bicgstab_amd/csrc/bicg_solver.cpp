@@ -785,7 +785,19 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
-    c->overlap = c->nnz_d >= 6000000u;
+    {   // the enqueue mode changes the ORDER of RCCL calls, so every rank must take the same decision:
+        // it is based on the average number of local non-zeros over all ranks
+        uint64_t total = c->nnz_d;
+        if (P > 1) {
+            std::vector<int> one(P, (int)sizeof(uint32_t)), off(P);
+            std::vector<uint32_t> mine(P, c->nnz_d), all(P, 0u);
+            for (int p = 0; p < P; ++p) off[p] = p * (int)sizeof(uint32_t);
+            comm->alltoallv_host(mine.data(), one.data(), off.data(), all.data(), one.data(), off.data());
+            total = 0;
+            for (int p = 0; p < P; ++p) total += all[p];
+        }
+        c->overlap = total / (uint64_t)P >= 6000000u;
+    }
     if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = atoi(sv);
