@@ -11,9 +11,11 @@ not available offline, so the matrix is the Transport-SHAPED synthetic of SURVEY
 (n = 1 602 111, 15 diagonals, nnz = 23 921 209), symmetrically scaled over two decades so that the
 W+K timed iterations are genuine unconverged iterations (the real Transport needs ~2700). Right-hand
 side b = A*1, x0 = 0 (reference src/main.c:109-117). With N GPUs the SAME matrix is row-partitioned
-exactly like the reference does (src/matrix.c:295-308): strong scaling; halo exchange and packed
-dot all-reduces go over RCCL inside libbicgstab_hip.so, torch.distributed (gloo) is only the
-bootstrap and the timing barrier.
+exactly like the reference does (src/matrix.c:295-308): strong scaling; halo values and packed dot
+sums are stored by the producing kernels straight into the other GPUs' memory over xGMI (HIP-IPC
+mapped mailboxes, libbicgstab_hip.so's bicg_p2p.cpp) once that path's self-test has passed on every
+rank, otherwise they go through RCCL; torch.distributed (gloo) is only the bootstrap and the timing
+barrier.
 
 Matrix and vectors are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
 """
@@ -60,14 +62,24 @@ def main():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100)
-    ap.add_argument("--transport", default="rccl", choices=["rccl", "host"],
-                    help="rccl (default): RCCL over xGMI, one GPU per rank. host: gloo-staged exchanges, ranks may "
-                         "share a GPU -- only for exercising the multi-rank plumbing on a one-GPU box")
+    ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host", "host-p2p"],
+                    help="auto (default): RCCL communicator, one GPU per rank, data path switched to direct "
+                         "peer-to-peer stores over xGMI when the library's self-test passes on every rank. rccl: RCCL "
+                         "collectives only. host: gloo-staged exchanges, ranks may share a GPU -- only for exercising "
+                         "the multi-rank plumbing on a one-GPU box. host-p2p: the same with the peer-to-peer data path")
+    ap.add_argument("--force-comm", action="store_true",
+                    help="one rank only: run the multi-rank code path anyway (1-rank RCCL communicator) -- measures what "
+                         "the transport adds to an iteration")
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    # stdout carries exactly ONE line, the JSON result: everything else this process or its libraries
+    # print (gloo's connection report, RCCL's banner) is sent to stderr
+    sys.stdout.flush()
+    result_out = os.fdopen(os.dup(1), "w")
+    os.dup2(2, 1)
 
     def note(msg):
         if rank == 0:
@@ -79,7 +91,8 @@ def main():
     def _give_up():
         if rank == 0:
             print(json.dumps({"metric": "ms/iteration", "value": None, "unit": "ms/iteration", "n_gpus": world,
-                              "error": f"watchdog: no result after {watchdog_s} s (stage: {stage[0]})"}), flush=True)
+                              "error": f"watchdog: no result after {watchdog_s} s (stage: {stage[0]})"}), file=result_out,
+                  flush=True)
         os._exit(3)
 
     watchdog_s = int(os.environ.get("BENCH_WATCHDOG_S", "1500"))
@@ -105,24 +118,48 @@ def main():
 
     dist = None
     stage[0] = "communicator bootstrap"
+    os.environ.setdefault("BICG_P2P_SOFT_FAIL", "1")     # a peer-to-peer time-out becomes a fallback, not an exit
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
-        ident = torch.zeros(H_UNIQUE, dtype=torch.uint8)
-        if rank == 0:
+
+    def comm_setup(use_p2p):
+        """(Re)create the library's communicator; returns a description of the data path in use."""
+        if world > 1:
+            ident = torch.zeros(H_UNIQUE, dtype=torch.uint8)
+            if rank == 0:
+                buf = (C.c_char * H_UNIQUE)()
+                L.bicg_comm_unique_id(buf)
+                ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+            dist.broadcast(ident, src=0)
+            raw = bytes(ident.numpy().tobytes())
+            if a.transport in ("auto", "rccl"):
+                L.bicg_comm_init_rccl(rank, world, raw, device)
+            else:
+                from mpi_bicgstab_amd import dist_transport
+                dist_transport.init_host_transport(device)
+            if use_p2p:
+                L.bicg_comm_enable_p2p()      # collective; leaves the transport as it is when the self-test fails
+        elif a.force_comm:
+            os.environ["BICG_FORCE_COMM"] = "1"
             buf = (C.c_char * H_UNIQUE)()
             L.bicg_comm_unique_id(buf)
-            ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-        dist.broadcast(ident, src=0)
-        raw = bytes(ident.numpy().tobytes())
-        if a.transport == "rccl":
-            L.bicg_comm_init_rccl(rank, world, raw, device)
+            L.bicg_comm_init_rccl(0, 1, buf.raw, device)
+            if use_p2p:
+                L.bicg_comm_enable_p2p()
         else:
-            from mpi_bicgstab_amd import dist_transport
-            dist_transport.init_host_transport(device)
-    else:
-        L.bicg_comm_init_single(device)
+            L.bicg_comm_init_single(device)
+        mode = int(L.bicg_comm_p2p_active())
+        base = "rccl" if a.transport in ("auto", "rccl") else "gloo-staged"
+        if world == 1 and not a.force_comm:
+            return 0, "none"
+        if mode:
+            return mode, (f"peer-to-peer LL stores over xGMI (HIP IPC, {'uncached' if mode == 2 else 'device'} memory; "
+                          f"bootstrap {base})")
+        return 0, base
+
+    p2p_mode, transport_name = comm_setup(a.transport in ("auto", "host-p2p"))
 
     def barrier():
         if dist is not None:
@@ -153,11 +190,11 @@ def main():
             slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
         diag, offd = synth.split_row_slab(slab, lo)
         blocks = H.HostBlocks(diag, offd if world > 1 else None, n, counts, displs)
+    ones = np.ones(hi - lo)
+    x0 = np.zeros(hi - lo)
     ctx = H.Context(blocks)
     plan = ctx.plan_info()
-    ones = np.ones(hi - lo)
     b = ctx.spmv(ones)                       # b = A*1 (reference src/main.c:109-113), collective
-    x0 = np.zeros(hi - lo)
 
     K, W = a.steps, a.warmup
     note(f"matrix resident: {plan}")
@@ -181,11 +218,41 @@ def main():
             dt = float(t[0])
         return dt, res
 
+    def transport_check(res):
+        """Did the exchanges deliver? The TRUE residual b - A x, recomputed with one more distributed
+        SpMV, must agree with the recursive residual the iterations carried (plain BiCGStab keeps them
+        within a small factor over a few hundred iterations). All ranks get the same answer."""
+        x, r = ctx.fetch()
+        tr = b - ctx.spmv(x)
+        sums = torch.tensor([float(tr @ tr), float(r @ r), float(b @ b), 1.0 if ctx.comm_failed() else 0.0], dtype=torch.float64)
+        if dist is not None:
+            dist.all_reduce(sums)
+        true_rel = float(np.sqrt(sums[0] / sums[2])) if sums[2] > 0 else float("nan")
+        rec_rel = float(np.sqrt(sums[1] / sums[2])) if sums[2] > 0 else float("nan")
+        ok = sums[3] == 0 and np.isfinite(true_rel) and np.isfinite(rec_rel) and true_rel <= 100.0 * rec_rel + 1e-12
+        return bool(ok), true_rel
+
     # main timed region: exactly K iterations, no per-kernel instrumentation
     dt, res = timed_run(a.method, kernel_events=False)
+    ok, true_relres = transport_check(res)
+    if not ok and p2p_mode:
+        # the peer-to-peer data path passed its self-test but not this check: measure with RCCL instead
+        note(f"peer-to-peer data path failed the residual check (true relres {true_relres:.3e}); falling back")
+        stage[0] = "fallback to the transport's collectives"
+        failed_name = transport_name
+        ctx.close()
+        barrier()
+        L.bicg_comm_finalize()
+        p2p_mode, transport_name = comm_setup(False)
+        transport_name += f" (fallback: '{failed_name}' failed the residual check)"
+        ctx = H.Context(blocks)
+        plan = ctx.plan_info()
+        b = ctx.spmv(ones)
+        dt, res = timed_run(a.method, kernel_events=False)
+        ok, true_relres = transport_check(res)
     ms_step = 1e3 * dt / K
     relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
-    genuine = res.iterations == W + K and np.isfinite(relres)
+    genuine = res.iterations == W + K and np.isfinite(relres) and ok
 
     note(f"{a.method}: {ms_step:.4f} ms/iteration")
     stage[0] = "roofline / variant legs"
@@ -245,8 +312,9 @@ def main():
                                    f"BASELINE.json configs[3] family: 7-point 3-D Laplacian {a.m}^3 generated in memory, b = A*1, x0 = 0",
                        "rows": n, "nnz": nnz_global, "scale_decades": a.scale_decades, "method": a.method,
                        "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
-                       "transport": a.transport if world > 1 else "none",
-                       "iterations_genuine": bool(genuine), "relres_after_timed_region": relres},
+                       "transport": transport_name,
+                       "iterations_genuine": bool(genuine), "relres_after_timed_region": relres,
+                       "true_relres_after_timed_region": true_relres},
             "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,
             "iteration_algorithmic_bytes": iter_bytes,
             "roofline": {"kernel": "k_spmv_sell (sliced-ELL SpMV with fused dot epilogue), rank 0 share", "bound": "hbm",
@@ -259,7 +327,7 @@ def main():
             "cpu_baseline": cpu,
             "variants_ms_per_iteration": variants,
         }
-        print(json.dumps(line), flush=True)
+        print(json.dumps(line), file=result_out, flush=True)
 
     dog.cancel()
     ctx.close()

@@ -123,6 +123,16 @@ int bicg_comm_init_host(int rank, int nranks, bicg_allreduce_fn allreduce, bicg_
  * Returns non-zero when the process has no initialised MPI. */
 int bicg_comm_init_mpi(const char *transport, int device);
 int bicg_comm_init_single(int device);
+/* Collective, after one of the init calls above: switch the DATA path (halo values, dot sums) to direct
+ * peer-to-peer stores between the GPUs of one node -- mailboxes mapped through HIP IPC, written by the
+ * producing kernels, no library collective per exchange (the replacement for the MPI_Iallgatherv /
+ * MPI_Iallreduce pair of reference src/matrix.c:432, src/solver.c:90 that a 20 us iteration can afford).
+ * Ends with a self-test over the real links; returns 0 when it passed on EVERY rank, otherwise nothing
+ * changes and the transport's own collectives stay in use. bicg_comm_init_mpi("auto") tries it itself.
+ * BICG_P2P=0 disables it. */
+int bicg_comm_enable_p2p(void);
+/* 0: not active; 1: active, mailboxes in ordinary device memory; 2: active, uncached device memory */
+int bicg_comm_p2p_active(void);
 void bicg_comm_finalize(void);
 /* one-rank RCCL round trip (library load, communicator, all-reduce); 0 = ok. Needs a GPU. */
 int bicg_comm_selftest_rccl(int device);
@@ -207,6 +217,9 @@ double bicg_dot(bicg_ctx *ctx, const double *x_loc, const double *y_loc);
 /* reps back-to-back SpMVs on device-resident vectors; returns average ms per SpMV (HIP events on
  * the library's compute stream) */
 int bicg_spmv_bench(bicg_ctx *ctx, int reps, double *ms_per_spmv);
+/* 1 after a peer-to-peer wait of this context timed out (only reachable with BICG_P2P_SOFT_FAIL=1; the
+ * default is to print the error and exit like any other HIP/RCCL failure). The solve in progress stops. */
+int bicg_comm_failed(bicg_ctx *ctx);
 /* plan facts: local rows, diag nnz, offd nnz, halo length, workgroups per SpMV, halo-touching
  * workgroups, rows on the sliced-ELL path, sliced-ELL padding entries */
 int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);

@@ -20,6 +20,8 @@ void die(const char *what, const char *detail)
     exit(EXIT_FAILURE);
 }
 
+Comm::~Comm() { delete p2p; }
+
 int pick_device(int rank, int requested)
 {
     int ndev = 0;
@@ -285,10 +287,15 @@ int bicg_comm_init_mpi(const char *transport, int device)
     if (size == 1) { comm_set(make_single(device)); return 0; }
     int ndev = 0;
     BICG_HIP(hipGetDeviceCount(&ndev));
+    // "auto": RCCL needs one GPU per rank, otherwise the exchanges are staged through MPI on the host;
+    //         with one GPU per rank the data path then moves to direct peer-to-peer stores when the
+    //         self-test passes (bicg_p2p.cpp). "rccl" / "host": exactly that transport.
+    //         "p2p": peer-to-peer on top of whatever transport fits, also when ranks share a GPU.
+    const bool want_p2p = transport && strcmp(transport, "p2p") == 0;
     bool use_rccl;
     if (transport && strcmp(transport, "rccl") == 0) use_rccl = true;
     else if (transport && strcmp(transport, "host") == 0) use_rccl = false;
-    else use_rccl = size <= ndev;     // RCCL needs one GPU per rank
+    else use_rccl = size <= ndev;
     if (use_rccl) {
         char id[BICG_UNIQUE_ID_BYTES];
         if (rank == 0) rccl_unique_id(id);
@@ -296,6 +303,12 @@ int bicg_comm_init_mpi(const char *transport, int device)
         comm_set(make_rccl(rank, size, id, device));
     } else {
         comm_set(make_host(rank, size, bicg_mpi_allreduce_sum, bicg_mpi_alltoallv_bytes, nullptr, device));
+    }
+    const bool automatic = !transport || strcmp(transport, "auto") == 0;
+    if (want_p2p || (automatic && use_rccl)) {
+        const int rc = p2p_enable(g_comm);
+        if (rc != 0 && want_p2p && rank == 0)
+            fprintf(stderr, "bicgstab_hip: peer-to-peer transport not available (code %d), using %s\n", rc, g_comm->name());
     }
     return 0;
 }

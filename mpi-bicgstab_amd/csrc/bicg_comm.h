@@ -9,13 +9,22 @@
 
 #include <hip/hip_runtime.h>
 
+#include <vector>
+
 #include "../../include/bicgstab_hip.h"
+#include "bicg_device.h"
 
 namespace bicg {
 
+struct P2p;
+
 struct Comm {
     int rank = 0, nranks = 1, device = 0;
-    virtual ~Comm() {}
+    // Direct peer-to-peer data path (bicg_p2p.cpp), layered on top of any transport once
+    // p2p_enable() has succeeded on every rank: halo values and dot sums are then stored straight
+    // into the other GPUs' memory by the producing kernels; the transport below only bootstraps.
+    P2p *p2p = nullptr;
+    virtual ~Comm();
     virtual const char *name() const = 0;
     // true: collectives are enqueued on `st` and complete in stream order (RCCL);
     // false: the call synchronises `st` and completes on return (host staged)
@@ -29,6 +38,38 @@ struct Comm {
     virtual void alltoallv_host(const void *send, const int *scnt, const int *sdsp, void *recv, const int *rcnt,
                                 const int *rdsp) = 0;
 };
+
+// Peer-to-peer transport over xGMI (or within one GPU for tests): every rank maps the other
+// ranks' mailboxes through HIP IPC.
+struct P2p {
+    Comm *comm = nullptr;
+    int rank = 0, nranks = 1;
+    bool uncached = false;                 // mailboxes live in uncached (fine-grained) device memory
+    bool plain_memory = false;             // uncached allocations could not be exported: use hipMalloc
+    llword *mail = nullptr;                // this rank's all-reduce mailbox
+    llword **mail_dev = nullptr;           // device array [nranks]: all mailboxes as mapped here
+    std::vector<void *> mapped;            // IPC mappings of the mailboxes
+    unsigned red_seq = 1;                  // sequence number of the next all-reduce group (0 is never used)
+    unsigned bar_seq = 1;                  // ... of the next barrier token
+    unsigned long long timeout_ticks = 0;  // 100 MHz ticks a kernel waits for a peer before giving up
+
+    P2pRed red_desc(unsigned seq, unsigned mask = 0xffu) const
+    {
+        P2pRed r;
+        r.mail = mail_dev; r.seq = seq; r.mask = mask; r.rank = rank; r.nranks = nranks;
+        return r;
+    }
+    void *alloc(size_t bytes);             // zero-filled device memory other ranks may map
+    void release(void *p);
+    // Collective. Maps `local` of every rank into this process: peers[p] (peers[rank] = local);
+    // the mappings of the other ranks are appended to `opened`. 0 when it worked on EVERY rank.
+    int share(void *local, std::vector<void *> &peers, std::vector<void *> &opened);
+    void unmap(std::vector<void *> &opened);
+    ~P2p();
+};
+// Collective: set up and self-test the peer-to-peer path on communicator c. 0 = enabled on every
+// rank; otherwise nothing changed and the transport keeps working as before.
+int p2p_enable(Comm *c);
 
 Comm *comm_get();                 // process-global communicator (auto-initialised on first use)
 void comm_set(Comm *c);           // takes ownership

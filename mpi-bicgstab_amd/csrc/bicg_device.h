@@ -20,6 +20,9 @@ constexpr int kShards = 32;                 // arrival counters per dot group (o
 constexpr int kCounterStride = 32;          // unsigneds between shard counters (128 B apart)
 constexpr int kMaxGrid = 2048;              // element-wise kernels: 256 CUs x 8 resident workgroups, grid-stride beyond
 constexpr int kSpmvMaxGrid = 1 << 18;       // SpMV: one workgroup per row block up to this many
+constexpr int kMailRing = 8;                // peer-to-peer all-reduce mailboxes: groups in flight before a slot is reused
+constexpr int kHaloRing = 8;                // peer-to-peer halo landing zones: exchanges in flight before reuse
+constexpr int kMaxRanksP2p = 64;            // ranks the peer-to-peer transport supports (one node)
 
 // What the single thread that completes a dot group does with the (globally reduced) sums in
 // Scal::red. One value per blocking point of the reference's loops.
@@ -76,7 +79,30 @@ struct Scal {
     int    breakdown_k;          // first iteration whose recurrence scalars were not finite (0 = none)
     double *tr_alpha, *tr_omega, *tr_beta, *tr_dotr;   // optional trace, [max_iter]
     ShiftDev *sh;                // shifted solver only
+    int    comm_error;           // peer-to-peer transport: a wait for a peer timed out (sets done as well)
 };
+
+// Direct peer-to-peer transport (bicg_p2p.cpp). Values travel as "LL" words -- 8 bytes holding 32
+// payload bits and the 32-bit sequence number of the operation, written with ONE store into
+// memory of the receiving GPU (mapped through HIP IPC, uncached): a reader that sees the expected
+// sequence number in a word has its payload too, so neither fences nor separate flags are needed.
+// A double takes two words.
+typedef unsigned long long llword;
+
+// All-reduce of a dot group: the workgroup that completes the group's local sums stores them into
+// the mailbox of EVERY rank (its own included); the apply kernel of the group waits for the P
+// contributions and adds them in a fixed order, so all ranks obtain bit-identical sums.
+// Mailbox layout: [kMailRing][nranks (source)][kRedSlots][2] words.
+struct P2pRed {
+    llword *const *mail;   // [nranks] every rank's mailbox as mapped in this process (device array)
+    unsigned seq;          // sequence number of the group; 0 = no peer-to-peer publication
+    unsigned mask;         // bit d set: this kernel publishes its sum d
+    int rank, nranks;
+};
+__host__ __device__ inline size_t mail_index(unsigned seq, int nranks, int src, int d)
+{
+    return ((((size_t)(seq % kMailRing) * nranks + src) * kRedSlots) + d) * 2;
+}
 
 // Where a kernel's dot partial sums go and what happens when the last block has arrived.
 struct Reduce {
@@ -88,6 +114,7 @@ struct Reduce {
     int       red_off;     // sums land in Scal::red[red_off + d]
     int       phase;       // Phase applied by the finishing thread when apply_now
     int       apply_now;   // single rank: apply the phase in-kernel; multi rank: host all-reduces first
+    P2pRed    p2p;         // peer-to-peer transport: where the finished sums are published
 };
 
 struct CsrDev {
@@ -147,6 +174,21 @@ bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hi
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // sliced ELL
 void launch_apply(Scal *S, int phase, hipStream_t st);
 void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);
+// peer-to-peer transport: wait for the P contributions of group pr.seq, sum n values, apply `phase`
+void launch_apply_p2p(Scal *S, int phase, int n, const P2pRed &pr, unsigned long long timeout_ticks, hipStream_t st);
+// halo exchange: entry i of the send list goes to dst0[i] + (seq % kHaloRing) * dst_stride[i] bytes
+// (a word pair in the landing ring of the rank that needs it); the receiver decodes its ring slot
+// into the halo tail of the vector
+void launch_halo_push(const double *x, const uint32_t *send_idx, uint32_t nsend, const unsigned long long *dst0,
+                      const unsigned long long *dst_stride, unsigned seq, Scal *S, hipStream_t st);
+void launch_halo_unpack(const llword *ring, uint32_t halo, unsigned seq, double *tail, Scal *S,
+                        unsigned long long timeout_ticks, hipStream_t st);
+// barrier token pr.seq (own sequence space) among all ranks
+void launch_p2p_barrier(const P2pRed &pr, unsigned long long timeout_ticks, Scal *S, hipStream_t st);
+// transport self-test: `rounds` all-reduces of known values starting at sequence seq0; status[0]
+// counts mismatches, status[1] time-outs
+void launch_p2p_selftest(const P2pRed &pr, unsigned seq0, int rounds, unsigned long long timeout_ticks, int *status,
+                         hipStream_t st);
 
 // init: r = b - Ax ; rh = r ; [p = r] ; [bsave = b] ; dot (r,r)
 void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, Scal *S, Reduce red, hipStream_t st);

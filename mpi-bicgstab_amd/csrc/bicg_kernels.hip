@@ -270,6 +270,122 @@ __global__ void __launch_bounds__(kBlock) k_apply(Scal *S, int phase)
 }
 
 // ------------------------------------------------------------------------------------------
+// peer-to-peer transport: LL words (see bicg_device.h)
+// ------------------------------------------------------------------------------------------
+__device__ __forceinline__ void ll_store(llword *dst, double v, unsigned seq)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    __hip_atomic_store(dst, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+
+// Spin until both words carry `seq`; false after timeout_ticks of the 100 MHz wall clock (a peer
+// that died or diverged must not hang the GPU).
+__device__ __forceinline__ bool ll_wait(const llword *src, unsigned seq, unsigned long long timeout_ticks, double *out)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        const unsigned long long w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+        if ((unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq) {
+            *out = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+            return true;
+        }
+        if ((spin & 63u) == 63u) {
+            if (wall_clock64() - t0 > timeout_ticks) { *out = 0.0; return false; }
+            __builtin_amdgcn_s_sleep(2);
+        }
+    }
+}
+
+// Sum the P contributions of every value the way a recursive-doubling all-reduce associates them
+// ((v0+v1)+(v2+v3))+... : fixed order => every rank computes bit-identical sums.
+__device__ __forceinline__ double rank_tree_sum(double *v /* [nranks], stride kRedSlots */, int nranks)
+{
+    for (int stride = 1; stride < nranks; stride <<= 1)
+        for (int i = 0; i + stride < nranks; i += 2 * stride) v[i * kRedSlots] += v[(i + stride) * kRedSlots];
+    return v[0];
+}
+
+// Collect group pr.seq from this rank's mailbox (all P sources), leave the sums in Scal::red and
+// apply the phase. Returns false (and raises comm_error/done) on a time-out.
+__device__ __forceinline__ bool p2p_collect(Scal *S, int n, const P2pRed &pr, unsigned long long timeout_ticks, double *vals,
+                                            int *s_fail)
+{
+    if (threadIdx.x == 0) *s_fail = 0;
+    __syncthreads();
+    const llword *mine = pr.mail[pr.rank];
+    for (int t = threadIdx.x; t < n * pr.nranks; t += kBlock) {
+        const int p = t / n, d = t % n;
+        double v;
+        if (!ll_wait(mine + mail_index(pr.seq, pr.nranks, p, d), pr.seq, timeout_ticks, &v)) *s_fail = 1;
+        vals[p * kRedSlots + d] = v;
+    }
+    __syncthreads();
+    if (*s_fail) {
+        if (threadIdx.x == 0) { S->comm_error = 1; S->done = 1; }
+        return false;
+    }
+    if ((int)threadIdx.x < n) S->red[threadIdx.x] = rank_tree_sum(vals + threadIdx.x, pr.nranks);
+    __syncthreads();
+    return true;
+}
+
+__global__ void __launch_bounds__(kBlock) k_apply_p2p(Scal *S, int phase, int n, P2pRed pr, unsigned long long timeout_ticks)
+{
+    if (S->done) return;
+    __shared__ double vals[kRedSlots * kMaxRanksP2p];
+    __shared__ int s_fail;
+    if (!p2p_collect(S, n, pr, timeout_ticks, vals, &s_fail)) return;
+    if (phase != PH_NONE) apply_phase_block(S, phase);
+}
+
+// Self-test of the transport: `rounds` all-reduces of five values that depend on (rank, round,
+// slot), each checked against the sum recomputed locally. One workgroup; status[0] counts wrong
+// sums, status[1] time-outs.
+__device__ __forceinline__ double selftest_value(int rank, unsigned seq, int d)
+{
+    return (double)(rank * 131 + d * 17 + 1) * 1.000000119 + (double)seq * 0.333333333333;
+}
+
+__global__ void __launch_bounds__(kBlock) k_p2p_selftest(P2pRed pr, unsigned seq0, int rounds, unsigned long long timeout_ticks,
+                                                         int *status)
+{
+    __shared__ double vals[kRedSlots * kMaxRanksP2p];
+    __shared__ double expect[kRedSlots * kMaxRanksP2p];
+    __shared__ int s_timeout;
+    constexpr int n = kMaxDots;
+    if (threadIdx.x == 0) s_timeout = 0;
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned seq = seq0 + (unsigned)r;
+        for (int t = threadIdx.x; t < n * pr.nranks; t += kBlock) {
+            const int p = t / n, d = t % n;
+            ll_store(pr.mail[p] + mail_index(seq, pr.nranks, pr.rank, d), selftest_value(pr.rank, seq, d), seq);
+        }
+        for (int t = threadIdx.x; t < n * pr.nranks; t += kBlock) {
+            const int p = t / n, d = t % n;
+            double v;
+            if (!ll_wait(pr.mail[pr.rank] + mail_index(seq, pr.nranks, p, d), seq, timeout_ticks, &v)) s_timeout = 1;
+            vals[p * kRedSlots + d] = v;
+            expect[p * kRedSlots + d] = selftest_value(p, seq, d);
+        }
+        __syncthreads();
+        if (s_timeout) {                 // a peer is not answering: do not wait `rounds` time-outs
+            if (threadIdx.x == 0) atomicAdd(&status[1], 1);
+            return;
+        }
+        if ((int)threadIdx.x < n) {
+            const double got = rank_tree_sum(vals + threadIdx.x, pr.nranks);
+            const double want = rank_tree_sum(expect + threadIdx.x, pr.nranks);
+            if (!(got == want)) atomicAdd(&status[0], 1);
+        }
+        __syncthreads();
+    }
+}
+
+// ------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------
 __device__ __forceinline__ double wave_sum(double v)
@@ -373,6 +489,16 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
 #pragma unroll
         for (int d = 0; d < ND; ++d) S->red[red.red_off + d] = tot[d];
         __hip_atomic_store(&red.counter[kShards * kCounterStride], 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    }
+    if (red.p2p.seq) {
+        // peer-to-peer all-reduce: hand the finished local sums to every rank's mailbox (block_sum
+        // left them in sm[4*ND + d])
+        for (int t = threadIdx.x; t < ND * red.p2p.nranks; t += kBlock) {
+            const int d = t % ND, p = t / ND;
+            if ((red.p2p.mask >> d) & 1u)
+                ll_store(red.p2p.mail[p] + mail_index(red.p2p.seq, red.p2p.nranks, red.p2p.rank, red.red_off + d),
+                         sm[4 * ND + d], red.p2p.seq);
+        }
     }
     if (red.apply_now) {
         __syncthreads();            // Scal::red written by thread 0 above
@@ -691,6 +817,81 @@ void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend,
     hipLaunchKernelGGL(k_halo_pack, dim3(g), dim3(kBlock), 0, st, x, send_idx, nsend, sendbuf, S);
 }
 
+void launch_apply_p2p(Scal *S, int phase, int n, const P2pRed &pr, unsigned long long timeout_ticks, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_apply_p2p, dim3(1), dim3(kBlock), 0, st, S, phase, n, pr, timeout_ticks);
+}
+
+__global__ void __launch_bounds__(kBlock) k_halo_push(const double *x, const uint32_t *idx, uint32_t n,
+                                                      const unsigned long long *dst0, const unsigned long long *dst_stride,
+                                                      unsigned seq, const Scal *S)
+{
+    if (S->done) return;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    llword *dst = reinterpret_cast<llword *>(dst0[i] + (unsigned long long)(seq % kHaloRing) * dst_stride[i]);
+    ll_store(dst, x[idx[i]], seq);
+}
+
+void launch_halo_push(const double *x, const uint32_t *send_idx, uint32_t nsend, const unsigned long long *dst0,
+                      const unsigned long long *dst_stride, unsigned seq, Scal *S, hipStream_t st)
+{
+    if (nsend == 0) return;
+    hipLaunchKernelGGL(k_halo_push, dim3((nsend + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, send_idx, nsend, dst0,
+                       dst_stride, seq, (const Scal *)S);
+}
+
+__global__ void __launch_bounds__(kBlock) k_halo_unpack(const llword *ring, uint32_t halo, unsigned seq, double *tail, Scal *S,
+                                                        unsigned long long timeout_ticks)
+{
+    if (S->done) return;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= halo) return;
+    double v;
+    if (ll_wait(ring + ((size_t)(seq % kHaloRing) * halo + i) * 2, seq, timeout_ticks, &v)) {
+        tail[i] = v;
+    } else {
+        S->comm_error = 1;
+        S->done = 1;
+    }
+}
+
+void launch_halo_unpack(const llword *ring, uint32_t halo, unsigned seq, double *tail, Scal *S,
+                        unsigned long long timeout_ticks, hipStream_t st)
+{
+    if (halo == 0) return;
+    hipLaunchKernelGGL(k_halo_unpack, dim3((halo + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ring, halo, seq, tail, S,
+                       timeout_ticks);
+}
+
+// Flow control for halo exchanges that are not separated by an all-reduce: every rank posts a token
+// to every rank (slot kRedSlots-1 of the mailbox, its own sequence numbers) and waits for all P.
+__global__ void __launch_bounds__(64) k_p2p_barrier(P2pRed pr, unsigned long long timeout_ticks, Scal *S)
+{
+    if (S->done) return;
+    constexpr int d = kRedSlots - 1;
+    for (int p = threadIdx.x; p < pr.nranks; p += 64)
+        ll_store(pr.mail[p] + mail_index(pr.seq, pr.nranks, pr.rank, d), 0.0, pr.seq);
+    for (int p = threadIdx.x; p < pr.nranks; p += 64) {
+        double v;
+        if (!ll_wait(pr.mail[pr.rank] + mail_index(pr.seq, pr.nranks, p, d), pr.seq, timeout_ticks, &v)) {
+            S->comm_error = 1;
+            S->done = 1;
+        }
+    }
+}
+
+void launch_p2p_barrier(const P2pRed &pr, unsigned long long timeout_ticks, Scal *S, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, st, pr, timeout_ticks, S);
+}
+
+void launch_p2p_selftest(const P2pRed &pr, unsigned seq0, int rounds, unsigned long long timeout_ticks, int *status,
+                         hipStream_t st)
+{
+    hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(kBlock), 0, st, pr, seq0, rounds, timeout_ticks, status);
+}
+
 // ------------------------------------------------------------------------------------------
 // fused element-wise phases
 // ------------------------------------------------------------------------------------------
@@ -911,6 +1112,7 @@ template <bool XNT> struct FCaXR {
 };
 void launch_ca_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
 {
+    red.p2p.mask &= ~4u;    // slot 2 belongs to the following SpMV's epilogue
     if (stream_x()) run_vec(FCaXR<true>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
     else run_vec(FCaXR<false>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
 }

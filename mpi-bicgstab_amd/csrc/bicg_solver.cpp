@@ -84,6 +84,17 @@ struct bicg_ctx {
     uint32_t nsend = 0;
     uint32_t *send_idx = nullptr;
     double *sendbuf = nullptr;
+    // peer-to-peer transport (comm->p2p): landing ring for incoming halo values and, per entry of
+    // the send list, where it goes in the ring of the rank that needs it
+    P2p *p2p = nullptr;
+    llword *halo_ring = nullptr;                              // [kHaloRing][halo][2]
+    unsigned long long *push_dst0 = nullptr, *push_stride = nullptr;
+    std::vector<void *> ring_mapped;
+    unsigned halo_seq = 0;          // exchanges started (sequence number of the last one)
+    int halo_unsynced = 0;          // exchanges since the last all-reduce or barrier (flow control)
+    unsigned pend_seq = 0;
+    bool comm_failed = false;       // a peer-to-peer wait timed out (BICG_P2P_SOFT_FAIL)
+    int fault_after = 0;            // BICG_P2P_FAULT_AFTER=n (tests): from the n-th exchange on this rank sends nothing
 
     // vectors and scalars
     double *slab = nullptr;
@@ -146,6 +157,8 @@ struct bicg_ctx {
         r.partial = partial; r.shard_tot = shard_tot; r.counter = counter; r.expected = 0; r.slot_base = 0;
         r.red_off = off; r.phase = phase;
         r.apply_now = (single() && apply_single) ? 1 : 0;
+        r.p2p = P2pRed{};
+        if (p2p) r.p2p = p2p->red_desc(p2p->red_seq);   // the group being produced; closed by group_now/defer
         return r;
     }
 };
@@ -175,6 +188,11 @@ void group_enqueue(bicg_ctx *c, int n, int phase, hipEvent_t after)
 void group_now(bicg_ctx *c, int n, int phase)
 {
     if (c->single()) return;   // applied in-kernel by the finishing workgroup
+    if (c->p2p) {              // the producers stored their sums into every rank's mailbox already
+        launch_apply_p2p(c->S, phase, n, c->p2p->red_desc(c->p2p->red_seq++), c->p2p->timeout_ticks, c->sc);
+        c->halo_unsynced = 0;
+        return;
+    }
     c->comm->allreduce_sum(c->S->red, n, c->sc);
     launch_apply(c->S, phase, c->sc);
 }
@@ -184,6 +202,10 @@ void group_now(bicg_ctx *c, int n, int phase)
 void group_defer(bicg_ctx *c, int n, int phase)
 {
     if (c->single()) return;
+    if (c->p2p) {   // collected after the next SpMV: the sums cross the links while it runs
+        c->pend = true; c->pend_n = n; c->pend_phase = phase; c->pend_seq = c->p2p->red_seq++;
+        return;
+    }
     if (!c->overlap || !c->comm->stream_ordered()) { group_now(c, n, phase); return; }
     hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
     BICG_HIP(hipEventRecord(e, c->sc));
@@ -212,7 +234,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
-    const bool merged = !c->single() && !(c->comm->stream_ordered() && c->overlap) && c->glist_all;
+    const bool merged = !c->single() && !c->p2p && !(c->comm->stream_ordered() && c->overlap) && c->glist_all;
     const unsigned g_sall = sell_grid(c->ng_int + c->ng_bnd, a.groups_per_wg);
     red.expected = merged ? g_sall + g_ci + g_cb : g_si + g_ci + g_sb + g_cb;
     red.slot_base = 0;
@@ -239,6 +261,26 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 
     if (c->single()) {
         interior();
+    } else if (c->p2p) {
+        // peer-to-peer: the send list is stored straight into the landing rings of the ranks that
+        // need it, the interior rows run while the values cross the links, one kernel decodes the
+        // ring slot into the halo tail of x, then the rows that touch the halo run
+        if (c->halo_unsynced >= kHaloRing - 2) {   // nothing has throttled the senders for a while
+            launch_p2p_barrier(c->p2p->red_desc(c->p2p->bar_seq++), c->p2p->timeout_ticks, c->S, c->sc);
+            c->halo_unsynced = 0;
+        }
+        const unsigned seq = ++c->halo_seq;
+        c->halo_unsynced++;
+        if (!(c->fault_after > 0 && seq >= (unsigned)c->fault_after))   // BICG_P2P_FAULT_AFTER (tests): values get lost
+            launch_halo_push(xin, c->send_idx, c->nsend, c->push_dst0, c->push_stride, seq, c->S, c->sc);
+        interior();
+        launch_halo_unpack(c->halo_ring, c->halo, seq, xin + c->n_loc, c->S, c->p2p->timeout_ticks, c->sc);
+        boundary();
+        if (c->pend) {
+            c->pend = false;
+            launch_apply_p2p(c->S, c->pend_phase, c->pend_n, c->p2p->red_desc(c->pend_seq), c->p2p->timeout_ticks, c->sc);
+            c->halo_unsynced = 0;
+        }
     } else {
         launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
         const bool two_streams = c->comm->stream_ordered() && c->overlap;
@@ -286,6 +328,12 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 void group_flush(bicg_ctx *c)
 {
     if (!c->pend) return;
+    if (c->p2p) {
+        c->pend = false;
+        launch_apply_p2p(c->S, c->pend_phase, c->pend_n, c->p2p->red_desc(c->pend_seq), c->p2p->timeout_ticks, c->sc);
+        c->halo_unsynced = 0;
+        return;
+    }
     hipEvent_t after = c->pend_ev;
     c->pend = false;
     group_enqueue(c, c->pend_n, c->pend_phase, after);
@@ -401,6 +449,16 @@ void fetch_scal(bicg_ctx *c)
     BICG_HIP(hipMemcpyAsync(c->hS, c->S, sizeof(Scal), hipMemcpyDeviceToHost, c->sc));
     BICG_HIP(hipStreamSynchronize(c->sc));
     if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
+    if (c->hS->comm_error) {
+        // BICG_P2P_SOFT_FAIL=1: report through bicg_comm_failed() and stop iterating instead of
+        // exiting (bench.py then falls back to the RCCL collectives)
+        const char *soft = getenv("BICG_P2P_SOFT_FAIL");
+        if (!soft || atoi(soft) == 0)
+            die("peer-to-peer transport", "timed out waiting for another rank (BICG_P2P_TIMEOUT_MS)");
+        if (!c->comm_failed)
+            fprintf(stderr, "bicgstab_hip: rank %d: peer-to-peer transport timed out waiting for another rank\n", c->rank);
+        c->comm_failed = true;
+    }
 }
 
 // A solve in three steps so that callers (and bench.py) can time exactly K iterations:
@@ -478,7 +536,7 @@ bool graph_iteration(bicg_ctx *c, Driver &d)
     // GPU busy (54 us vs 60 us replayed per 17-op iteration of a 200 k-row rank); replay only pays
     // when the two-stream overlap mode is on (80 vs 105 us).
     const bool want = c->graph_mode == 1;
-    if (!want || m == BICG_PIPE_BICGSTAB_RR || c->opt.rr_drift > 0.0 || c->time_kernels || !c->comm->stream_ordered()) return false;
+    if (!want || c->p2p || m == BICG_PIPE_BICGSTAB_RR || c->opt.rr_drift > 0.0 || c->time_kernels || !c->comm->stream_ordered()) return false;
     if (c->graph_exec[m] && c->graph_nt[m] != c->sell_nt) {     // captured with the other streaming policy
         (void)hipGraphExecDestroy(c->graph_exec[m]);
         c->graph_exec[m] = nullptr;
@@ -955,6 +1013,35 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->send_idx = dev_upload(send_idx.data(), c->nsend);
     c->sendbuf = dev_alloc<double>(c->nsend);
 
+    // ---- peer-to-peer transport: publish this rank's halo landing ring, learn where every entry
+    // of the send list lands in the ring of the rank that needs it (collective)
+    c->p2p = comm->p2p;
+    if (const char *sv = getenv("BICG_P2P_FAULT_AFTER")) c->fault_after = atoi(sv);
+    if (c->p2p && !c->single()) {
+        c->halo_ring = (llword *)c->p2p->alloc(sizeof(llword) * 2 * (size_t)kHaloRing * c->halo);
+        std::vector<void *> rings;
+        if (c->p2p->share(c->halo_ring, rings, c->ring_mapped) != 0)
+            die("bicg_create", "could not map the halo rings of the other ranks (peer-to-peer transport)");
+        // to rank p: where ITS values land in my ring, and my ring's slot size
+        std::vector<int> mine(2 * (size_t)P), theirs(2 * (size_t)P, 0), cnt(P, 2 * (int)sizeof(int)), dsp(P);
+        for (int p = 0; p < P; ++p) {
+            mine[2 * p] = c->rdsp[p]; mine[2 * p + 1] = (int)c->halo;
+            dsp[p] = 2 * p * (int)sizeof(int);
+        }
+        comm->alltoallv_host(mine.data(), cnt.data(), dsp.data(), theirs.data(), cnt.data(), dsp.data());
+        std::vector<unsigned long long> dst0(c->nsend ? c->nsend : 1, 0ull), dstride(c->nsend ? c->nsend : 1, 0ull);
+        for (int p = 0; p < P; ++p)
+            for (int j = 0; j < c->scnt[p]; ++j) {
+                const size_t i = (size_t)c->sdsp[p] + j;
+                dst0[i] = (unsigned long long)(uintptr_t)rings[p] + 16ull * ((unsigned long long)theirs[2 * p] + j);
+                dstride[i] = 16ull * (unsigned long long)theirs[2 * p + 1];
+            }
+        c->push_dst0 = dev_upload(dst0.data(), dst0.size());
+        c->push_stride = dev_upload(dstride.data(), dstride.size());
+    } else {
+        c->p2p = nullptr;
+    }
+
     // ---- vectors: 12 x (rows + halo), each 256-byte aligned; order x r | rh p s y z w v t ax b
     c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
     c->slab = dev_alloc<double>(12 * (size_t)c->stride);
@@ -994,6 +1081,11 @@ void bicg_destroy(bicg_ctx *c)
     void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    if (c->p2p) {
+        c->p2p->unmap(c->ring_mapped);
+        c->p2p->release(c->halo_ring);
+        (void)hipFree(c->push_dst0); (void)hipFree(c->push_stride);
+    }
     if (c->hS) (void)hipHostFree(c->hS);
     for (int i = 0; i < kEvRing; ++i) {
         (void)hipEventDestroy(c->ev_pack[i]); (void)hipEventDestroy(c->ev_halo[i]); (void)hipEventDestroy(c->ev_dots[i]); (void)hipEventDestroy(c->ev_red[i]);
@@ -1066,7 +1158,8 @@ int bicg_spmv(bicg_ctx *c, const double *x, double *y)
     c->time_kernels = false;
     spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
     BICG_HIP(hipMemcpyAsync(y, c->v.s, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost, c->sc));
-    BICG_HIP(hipStreamSynchronize(c->sc));
+    if (c->p2p) fetch_scal(c);      // also reports a peer that never delivered its halo values
+    else BICG_HIP(hipStreamSynchronize(c->sc));
     return 0;
 }
 
@@ -1100,9 +1193,12 @@ int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
     float ms = 0.f;
     BICG_HIP(hipEventElapsedTime(&ms, a, b));
     (void)hipEventDestroy(a); (void)hipEventDestroy(b);
+    if (c->p2p) fetch_scal(c);
     *ms_per_spmv = (double)ms / (reps > 0 ? reps : 1);
     return 0;
 }
+
+int bicg_comm_failed(bicg_ctx *c) { return c->comm_failed ? 1 : 0; }
 
 int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
 {

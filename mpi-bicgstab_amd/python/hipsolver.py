@@ -87,6 +87,7 @@ def lib():
         L.bicg_dot.restype = C.c_double
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
+        L.bicg_comm_failed.argtypes = [C.c_void_p]
         L.bicg_default_options.argtypes = [C.POINTER(Options)]
         L.bicg_comm_unique_id.argtypes = [C.c_void_p]
         L.bicg_comm_init_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -274,6 +275,9 @@ class Context:
         ms = C.c_double(0.0)
         lib().bicg_spmv_bench(self.h, reps, C.byref(ms))
         return ms.value
+
+    def comm_failed(self) -> bool:
+        return bool(lib().bicg_comm_failed(self.h))
 
     def plan_info(self):
         out = (C.c_uint * 8)()

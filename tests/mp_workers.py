@@ -99,6 +99,12 @@ def gpu_worker(rank, world, port, kind, outdir):
         from mpi_bicgstab_amd import dist_transport as T
 
         T.init_host_transport(0)
+        p2p = kind.endswith("+p2p")
+        kind = kind.replace("+p2p", "")
+        if p2p:
+            # data path through IPC-mapped mailboxes (bicg_p2p.cpp); gloo only bootstraps
+            assert H.lib().bicg_comm_enable_p2p() == 0, "peer-to-peer transport did not come up"
+            assert H.lib().bicg_comm_p2p_active() > 0
         A = test_matrix(kind)
         diag, offd, counts, displs = synth.split_blocks(A, world, rank)
         lo, nl = int(displs[rank]), int(counts[rank])
@@ -106,6 +112,16 @@ def gpu_worker(rank, world, port, kind, outdir):
         info = ctx.plan_info()
         assert info["halo"] > 0 and info["boundary_blocks"] > 0
         row, col, val = A.to_coo()
+        if p2p:
+            # more back-to-back exchanges than the landing ring has slots: wrap-around + flow control
+            rng = np.random.default_rng(5)
+            lens = np.diff(A.ptr.astype(np.int64))[lo:lo + nl]
+            for rep in range(2 * 8 + 3):
+                xs = rng.standard_normal(A.rows)
+                ys = ctx.spmv(xs[lo:lo + nl])
+                ys_orc = O.spmv(A.rows, row, col, val, xs, nranks=world)[lo:lo + nl]
+                assert np.array_equal(ys[lens <= 2048], ys_orc[lens <= 2048]), f"exchange {rep} delivered stale or wrong halo values"
+            ctx.spmv_bench(40)
         x = np.random.default_rng(99).standard_normal(A.rows)
         y = ctx.spmv(x[lo:lo + nl])
         y_orc = O.spmv(A.rows, row, col, val, x, nranks=world)[lo:lo + nl]

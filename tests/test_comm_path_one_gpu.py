@@ -84,3 +84,20 @@ def test_forced_comm_one_rank_rccl(problem, graph, overlap, monkeypatch):
     finally:
         monkeypatch.delenv("BICG_FORCE_COMM")
         H.lib().bicg_comm_init_single(0)
+
+
+def test_forced_comm_peer_to_peer_one_rank(problem, monkeypatch):
+    """The peer-to-peer data path (bicg_p2p.cpp) with one rank: dot groups go through the LL mailbox
+    and k_apply_p2p, SpMVs through the (empty) push / unpack kernels -- same bits as single rank."""
+    A, b, ref = problem
+    monkeypatch.setenv("BICG_FORCE_COMM", "1")
+    buf = (C.c_char * 128)()
+    H.lib().bicg_comm_unique_id(buf)
+    H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
+    try:
+        assert H.lib().bicg_comm_enable_p2p() == 0
+        assert H.lib().bicg_comm_p2p_active() > 0
+        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=0), ref)
+    finally:
+        monkeypatch.delenv("BICG_FORCE_COMM")
+        H.lib().bicg_comm_init_single(0)

@@ -45,6 +45,14 @@ def test_multirank_solver_on_one_gpu(kind, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind,world", [("offsets+p2p", 2), ("stencil+p2p", 2), ("ragged+p2p", 3)])
+def test_multirank_solver_peer_to_peer(kind, world):
+    """Same checks with the peer-to-peer data path: the ranks map each other's mailboxes and halo
+    rings through HIP IPC (here inside one GPU) and the kernels exchange LL words directly."""
+    _run(W.gpu_worker, world, kind)
+
+
+@pytest.mark.gpu
 def test_rccl_single_rank_roundtrip():
     from mpi_bicgstab_amd import hipsolver as H
     assert H.lib().bicg_comm_selftest_rccl(0) == 0
