@@ -119,6 +119,7 @@ def main():
     dist = None
     stage[0] = "communicator bootstrap"
     os.environ.setdefault("BICG_P2P_SOFT_FAIL", "1")     # a peer-to-peer time-out becomes a fallback, not an exit
+    os.environ.setdefault("BICG_P2P_TIMEOUT_MS", "20000")  # ranks are aligned by barriers here: 20 s means a lost peer
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
