@@ -141,6 +141,22 @@ struct SellDev {
     const uint32_t *slice_base16;
 };
 
+// Peer-to-peer halo exchange folded into the sliced-ELL SpMV launch: the first `npush` workgroups
+// store this rank's send list into the landing rings of the ranks that need it, the others
+// multiply; offd entries read their x value straight from this rank's landing ring (LL words of
+// exchange `seq`), spinning until it has arrived.
+struct HaloLL {
+    const llword *ring;                 // this rank's landing ring [kHaloRing][halo][2]
+    uint32_t halo;
+    unsigned seq;
+    unsigned npush;                     // leading workgroups that push instead of multiplying
+    uint32_t nsend;
+    const uint32_t *send_idx;           // [nsend] local rows to send
+    const unsigned long long *dst0;     // [nsend] address of the word pair in slot 0 of the receiver's ring
+    const unsigned long long *dstride;  // [nsend] bytes per slot of the receiver's ring
+    unsigned long long timeout_ticks;
+};
+
 struct SpmvArgs {
     SellDev sell;
     const uint32_t *glist;  // SELL launch: 256-row groups to process (null = groups 0..nlist-1)
@@ -159,6 +175,7 @@ struct SpmvArgs {
     Reduce  red;
     int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
+    HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only
 };
 
 // element-wise phase kernels: pointers to the rank-local vectors
@@ -171,7 +188,8 @@ struct Vecs {
 // Both return false when there was nothing to launch. e0/e1 (optional): start/stop events bound to
 // this one kernel (hipExtLaunchKernelGGL) -- the per-kernel durations bench.py's roofline uses.
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);        // CSR row-block stream
-bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // sliced ELL
+bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                      bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
 void launch_apply(Scal *S, int phase, hipStream_t st);
 void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);
 // peer-to-peer transport: wait for the P contributions of group pr.seq, sum n values, apply `phase`

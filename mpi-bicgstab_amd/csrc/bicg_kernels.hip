@@ -682,7 +682,7 @@ typedef short i16x4 __attribute__((ext_vector_type(4)));
 // C16: column indices are read as 16-bit offsets from the row (col = row + delta), four
 // consecutive entries of a lane packed in one 8-byte word: 10 instead of 12 bytes per non-zero.
 // Used when every entry of the sliced-ELL copy satisfies |col - row| < 32768 (banded matrices).
-template <int NDOT, bool OFFD, bool NT, bool C16>
+template <int NDOT, bool OFFD, bool NT, bool C16, bool LL>
 __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
@@ -690,6 +690,20 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
     constexpr int U = 8;              // entries per lane in flight (4, 8, 16 measured identical)
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const double *__restrict__ x = a.x;
+    unsigned bid = blockIdx.x, nblocks = gridDim.x;
+    bool ll_failed = false;
+    if (LL) {
+        // peer-to-peer exchange inside the launch: the leading workgroups are scheduled first and
+        // send; x is complete (it was written by earlier kernels), so nothing has to be waited for
+        if (bid < a.ll.npush) {
+            if (!done)
+                for (uint32_t i = bid * kBlock + tid; i < a.ll.nsend; i += a.ll.npush * kBlock)
+                    ll_store(reinterpret_cast<llword *>(a.ll.dst0[i] + (unsigned long long)(a.ll.seq % kHaloRing) * a.ll.dstride[i]),
+                             x[a.ll.send_idx[i]], a.ll.seq);
+            return;
+        }
+        bid -= a.ll.npush; nblocks -= a.ll.npush;
+    }
 
     double acc[NDOT > 0 ? NDOT : 1];
 #pragma unroll
@@ -700,7 +714,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
     // 10 us per SpMV on Transport; a few groups per workgroup amortise it. Round-robin placement
     // over the XCDs is kept: an XCD-contiguous mapping cuts the fabric reads from 386 to 309 MB
     // (x is then fetched by one L2 instead of eight) but is 3-5 % SLOWER in wall time.
-    for (unsigned gi = blockIdx.x; gi < a.nlist; gi += gridDim.x) {
+    for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
         const unsigned g = a.glist ? a.glist[gi] : gi;
         const uint32_t row = g * kGroupRows + tid;                 // = slice * 64 + lane
         const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
@@ -753,7 +767,19 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
         double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
         if (OFFD) {
             double so = 0.0;
-            for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
+            for (uint32_t k = oa; k < ob; ++k) {
+                double xh;
+                if (LL) {
+                    // the value comes straight from the landing ring; the diag part above ran while it travelled
+                    xh = 0.0;
+                    if (!done && !ll_wait(a.ll.ring + ((size_t)(a.ll.seq % kHaloRing) * a.ll.halo + (a.offd.col[k] - a.nrows)) * 2,
+                                          a.ll.seq, a.ll.timeout_ticks, &xh))
+                        ll_failed = true;
+                } else {
+                    xh = x[a.offd.col[k]];
+                }
+                so += a.offd.val[k] * xh;
+            }
             yi += so;                                             // second mult() call, src/matrix.c:440
         }
         if (a.has_shift && live) yi += a.shift * x[row];          // (A + sigma I) x, src/shifted_solver.c:260
@@ -762,7 +788,8 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
         if (NDOT == 2 && live) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
         if (NDOT == 3 && live) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
     }
-    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+    if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
+    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + bid, sm);
 }
 
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
@@ -776,22 +803,24 @@ unsigned sell_grid(uint32_t ngroups, int per_wg)
     return (ngroups + each - 1) / each;
 }
 
-bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
+bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
 {
-    if (a.nlist == 0) return false;
-    dim3 g(sell_grid(a.nlist, a.groups_per_wg)), b(kBlock);
-#define SELL_CASE(ND, OF)                                                                          \
+    if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
+    dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u)), b(kBlock);
+#define SELL_CASE(ND, OF, LLV)                                                                     \
     do {                                                                                           \
         const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;                                  \
-        if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true>, g, b, st, e0, e1, a);         \
-        else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false>, g, b, st, e0, e1, a);          \
-        else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true>, g, b, st, e0, e1, a);         \
-        else launch_timed(k_spmv_sell<ND, OF, false, false>, g, b, st, e0, e1, a);                 \
+        if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV>, g, b, st, e0, e1, a);    \
+        else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV>, g, b, st, e0, e1, a);     \
+        else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV>, g, b, st, e0, e1, a);    \
+        else launch_timed(k_spmv_sell<ND, OF, false, false, LLV>, g, b, st, e0, e1, a);            \
     } while (0)
-    if (with_offd) {
-        if (ndot == 0) SELL_CASE(0, true); else if (ndot == 1) SELL_CASE(1, true); else if (ndot == 2) SELL_CASE(2, true); else SELL_CASE(3, true);
+    if (fused_halo) {
+        if (ndot == 0) SELL_CASE(0, true, true); else if (ndot == 1) SELL_CASE(1, true, true); else if (ndot == 2) SELL_CASE(2, true, true); else SELL_CASE(3, true, true);
+    } else if (with_offd) {
+        if (ndot == 0) SELL_CASE(0, true, false); else if (ndot == 1) SELL_CASE(1, true, false); else if (ndot == 2) SELL_CASE(2, true, false); else SELL_CASE(3, true, false);
     } else {
-        if (ndot == 0) SELL_CASE(0, false); else if (ndot == 1) SELL_CASE(1, false); else if (ndot == 2) SELL_CASE(2, false); else SELL_CASE(3, false);
+        if (ndot == 0) SELL_CASE(0, false, false); else if (ndot == 1) SELL_CASE(1, false, false); else if (ndot == 2) SELL_CASE(2, false, false); else SELL_CASE(3, false, false);
     }
 #undef SELL_CASE
     return true;

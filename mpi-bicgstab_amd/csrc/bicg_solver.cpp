@@ -94,6 +94,10 @@ struct bicg_ctx {
     int halo_unsynced = 0;          // exchanges since the last all-reduce or barrier (flow control)
     unsigned pend_seq = 0;
     bool comm_failed = false;       // a peer-to-peer wait timed out (BICG_P2P_SOFT_FAIL)
+    // Exchange folded into the SpMV launch (HaloLL): possible when every halo-touching row is on the
+    // sliced-ELL path. One launch covers push + interior + halo-touching groups (listed in that order).
+    bool ll_fused = false;
+    uint32_t *glist_ll = nullptr;
     int fault_after = 0;            // BICG_P2P_FAULT_AFTER=n (tests): from the n-th exchange on this rank sends nothing
 
     // vectors and scalars
@@ -234,7 +238,8 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
-    const bool merged = !c->single() && !c->p2p && !(c->comm->stream_ordered() && c->overlap) && c->glist_all;
+    const bool fused = c->p2p && c->ll_fused;
+    const bool merged = !c->single() && (fused || (!c->p2p && !(c->comm->stream_ordered() && c->overlap) && c->glist_all));
     const unsigned g_sall = sell_grid(c->ng_int + c->ng_bnd, a.groups_per_wg);
     red.expected = merged ? g_sall + g_ci + g_cb : g_si + g_ci + g_sb + g_cb;
     red.slot_base = 0;
@@ -271,11 +276,26 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         }
         const unsigned seq = ++c->halo_seq;
         c->halo_unsynced++;
-        if (!(c->fault_after > 0 && seq >= (unsigned)c->fault_after))   // BICG_P2P_FAULT_AFTER (tests): values get lost
-            launch_halo_push(xin, c->send_idx, c->nsend, c->push_dst0, c->push_stride, seq, c->S, c->sc);
-        interior();
-        launch_halo_unpack(c->halo_ring, c->halo, seq, xin + c->n_loc, c->S, c->p2p->timeout_ticks, c->sc);
-        boundary();
+        const bool lose = c->fault_after > 0 && seq >= (unsigned)c->fault_after;   // BICG_P2P_FAULT_AFTER (tests)
+        if (fused) {
+            // ONE launch: leading workgroups push, the others multiply; halo-touching groups come last
+            // and read the landing ring directly
+            a.ll.ring = c->halo_ring; a.ll.halo = c->halo; a.ll.seq = seq;
+            a.ll.nsend = lose ? 0u : c->nsend;
+            a.ll.npush = c->nsend ? std::min<unsigned>((c->nsend + kBlock - 1) / kBlock, 64u) : 0u;
+            a.ll.send_idx = c->send_idx; a.ll.dst0 = c->push_dst0; a.ll.dstride = c->push_stride;
+            a.ll.timeout_ticks = c->p2p->timeout_ticks;
+            a.glist = c->glist_ll; a.nlist = c->ng_int + c->ng_bnd; a.red.slot_base = 0;
+            took(launch_spmv_sell(a, ndot, true, c->sc, ev(0), ev(1), true));
+            a.glist = nullptr;
+            a.desc = c->desc_int; a.nlist = c->n_int; a.red.slot_base = g_sall;
+            took(launch_spmv(a, ndot, false, c->sc, ev(0), ev(1)));
+        } else {
+            if (!lose) launch_halo_push(xin, c->send_idx, c->nsend, c->push_dst0, c->push_stride, seq, c->S, c->sc);
+            interior();
+            launch_halo_unpack(c->halo_ring, c->halo, seq, xin + c->n_loc, c->S, c->p2p->timeout_ticks, c->sc);
+            boundary();
+        }
         if (c->pend) {
             c->pend = false;
             launch_apply_p2p(c->S, c->pend_phase, c->pend_n, c->p2p->red_desc(c->pend_seq), c->p2p->timeout_ticks, c->sc);
@@ -903,10 +923,16 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     auto group_fits = [&](uint32_t g, uint64_t *padded_out) {
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
         const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
-        uint64_t padded = 0;
-        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) padded += (uint64_t)slice_len[sl] * kSliceRows;
+        // storage always covers 64 lanes per slice; the criterion only counts lanes that hold a row, so
+        // that the last, partly filled group of a block does not fall to the CSR kernel (an extra
+        // launch per SpMV for a few dozen rows)
+        uint64_t padded = 0, padded_rows = 0;
+        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) {
+            padded += (uint64_t)slice_len[sl] * kSliceRows;
+            padded_rows += (uint64_t)slice_len[sl] * std::min<uint32_t>(kSliceRows, r1 - sl * kSliceRows);
+        }
         *padded_out = padded;
-        return padded <= nnz_g + nnz_g / 4 + 2 * kSliceRows;
+        return padded_rows <= nnz_g + nnz_g / 4 + 2 * kSliceRows;
     };
     // Ragged matrices (unstructured FEM: row lengths 3..26) leave only a few groups under the
     // padding limit; two kernels per SpMV are then slower than the CSR kernel alone (measured on
@@ -1038,6 +1064,13 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             }
         c->push_dst0 = dev_upload(dst0.data(), dst0.size());
         c->push_stride = dev_upload(dstride.data(), dstride.size());
+        c->ll_fused = c->n_bnd == 0 && c->ng_int + c->ng_bnd > 0;
+        if (const char *sv = getenv("BICG_P2P_FUSED")) c->ll_fused = c->ll_fused && atoi(sv) != 0;
+        if (c->ll_fused) {
+            std::vector<uint32_t> order(gl_int);
+            order.insert(order.end(), gl_bnd.begin(), gl_bnd.end());
+            c->glist_ll = dev_upload(order.data(), order.size());
+        }
     } else {
         c->p2p = nullptr;
     }
@@ -1085,6 +1118,7 @@ void bicg_destroy(bicg_ctx *c)
         c->p2p->unmap(c->ring_mapped);
         c->p2p->release(c->halo_ring);
         (void)hipFree(c->push_dst0); (void)hipFree(c->push_stride);
+        if (c->glist_ll) (void)hipFree(c->glist_ll);
     }
     if (c->hS) (void)hipHostFree(c->hS);
     for (int i = 0; i < kEvRing; ++i) {
