@@ -258,6 +258,21 @@ unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int rows, unsigne
  * malloc'ed; release with bicg_mtx_free. Returns 0 on success. (The C host additionally has an MPI
  * variant in which every rank tokenises 1/P of the file, mpi-bicgstab_amd/host/bicg_mtx.h.) */
 int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+/* The "next" pieces of the ingest path, host only:
+ *   bicg_partition_nnz        contiguous row blocks with equal non-zero counts (idea of the reference's
+ *                             abandoned DYNAMIC_ROWS branch, archive/matrix.c:407-446); the solver accepts
+ *                             any contiguous partition through INFO_Matrix.recvcounts/displs
+ *   bicg_mtx_load_block_part  the loader above with part = BICG_PART_ROWS | BICG_PART_NNZ
+ *   bicg_mtx_cache_save/load  checksummed binary copy of one rank's parsed blocks; load returns 0 on a
+ *                             valid hit for exactly this (rank, nranks, part) and unchanged source file */
+enum { BICG_PART_ROWS = 0, BICG_PART_NNZ = 1 };
+void bicg_partition_nnz(const unsigned int *row_nnz, unsigned int n, int nranks, int *counts, int *displs);
+int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, CSR_Matrix *diag, CSR_Matrix *offd,
+                             INFO_Matrix *info);
+int bicg_mtx_cache_save(const char *cache_path, const char *src_path, int rank, int nranks, int part,
+                        const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info);
+int bicg_mtx_cache_load(const char *cache_path, const char *src_path, int rank, int nranks, int part,
+                        CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 void bicg_mtx_free(CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 
 const char *bicg_version(void);

@@ -150,6 +150,7 @@ struct HaloLL {
     uint32_t halo;
     unsigned seq;
     unsigned npush;                     // leading workgroups that push instead of multiplying
+    uint32_t first_bnd;                 // list positions >= first_bnd hold halo-touching groups (only they have offd entries)
     uint32_t nsend;
     const uint32_t *send_idx;           // [nsend] local rows to send
     const unsigned long long *dst0;     // [nsend] address of the word pair in slot 0 of the receiver's ring

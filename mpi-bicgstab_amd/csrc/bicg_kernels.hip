@@ -729,7 +729,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
         double ume = 0.0;
         if (live) {
             mylen = a.diag.ptr[row + 1] - a.diag.ptr[row];
-            if (OFFD) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
+            if (OFFD && (!LL || gi >= a.ll.first_bnd)) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
             if (NDOT >= 1) ume = a.u[row];
         }
 

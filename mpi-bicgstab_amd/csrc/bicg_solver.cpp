@@ -283,6 +283,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             a.ll.ring = c->halo_ring; a.ll.halo = c->halo; a.ll.seq = seq;
             a.ll.nsend = lose ? 0u : c->nsend;
             a.ll.npush = c->nsend ? std::min<unsigned>((c->nsend + kBlock - 1) / kBlock, 64u) : 0u;
+            a.ll.first_bnd = c->ng_int;
             a.ll.send_idx = c->send_idx; a.ll.dst0 = c->push_dst0; a.ll.dstride = c->push_stride;
             a.ll.timeout_ticks = c->p2p->timeout_ticks;
             a.glist = c->glist_ll; a.nlist = c->ng_int + c->ng_bnd; a.red.slot_base = 0;

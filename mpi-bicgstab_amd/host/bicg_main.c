@@ -55,14 +55,37 @@ int main(int argc, char **argv)
     CSR_Matrix diag, offd;
     INFO_Matrix info;
     double t0 = wall();
+    /* BICG_PARTITION=nnz: non-zero balanced row blocks instead of the reference's equal rows.
+     * BICG_MTX_CACHE=<dir>: keep / reuse a binary copy of this rank's parsed blocks in <dir>. */
+    const char *pm = getenv("BICG_PARTITION"), *cdir = getenv("BICG_MTX_CACHE");
+    const int part = (pm && strcmp(pm, "nnz") == 0) ? BICG_PART_NNZ : BICG_PART_ROWS;
+    char cpath[4096];
+    int hit = 0;
+    if (cdir && *cdir) {
+        const char *base = strrchr(argv[1], '/');
+        snprintf(cpath, sizeof cpath, "%s/%s.P%d.r%d.%s.bicgblk", cdir, base ? base + 1 : argv[1], np, me,
+                 part == BICG_PART_NNZ ? "nnz" : "rows");
+        hit = bicg_mtx_cache_load(cpath, argv[1], me, np, part, &diag, &offd, &info) == 0;
 #ifdef BICG_HAVE_MPI
-    /* every rank tokenises 1/P of the file, triplets are exchanged (the reference has every rank
-     * fscanf the whole file twice, src/matrix.c:315-341, 357-393) */
-    if ((np > 1 ? bicg_mtx_load_block_mpi(argv[1], &diag, &offd, &info)
-                : bicg_mtx_load_block(argv[1], me, np, &diag, &offd, &info)) != 0) exit(EXIT_FAILURE);
-#else
-    if (bicg_mtx_load_block(argv[1], me, np, &diag, &offd, &info) != 0) exit(EXIT_FAILURE);
+        int all = hit;                      /* the parse below is collective: all ranks or none */
+        MPI_Allreduce(&hit, &all, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+        if (hit && !all) bicg_mtx_free(&diag, &offd, &info);
+        hit = all;
 #endif
+    }
+    if (!hit) {
+#ifdef BICG_HAVE_MPI
+        /* every rank tokenises 1/P of the file, triplets are exchanged (the reference has every rank
+         * fscanf the whole file twice, src/matrix.c:315-341, 357-393) */
+        if ((np > 1 ? bicg_mtx_load_block_mpi_part(argv[1], part, &diag, &offd, &info)
+                    : bicg_mtx_load_block_part(argv[1], me, np, part, &diag, &offd, &info)) != 0) exit(EXIT_FAILURE);
+#else
+        if (bicg_mtx_load_block_part(argv[1], me, np, part, &diag, &offd, &info) != 0) exit(EXIT_FAILURE);
+#endif
+        if (cdir && *cdir && bicg_mtx_cache_save(cpath, argv[1], me, np, part, &diag, &offd, &info) != 0 && me == 0)
+            fprintf(stderr, "bicg_solver_host: could not write the block cache %s\n", cpath);
+    }
+    if (me == 0 && cdir && *cdir) printf("Block cache  : %s\n", hit ? "hit" : "miss (written)");
     if (me == 0) printf("IO time      : %e [sec.]\n", wall() - t0);
     if (info.cols != info.rows) { printf("Error: matrix is not square.\n"); exit(1); }
 

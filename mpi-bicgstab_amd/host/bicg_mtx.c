@@ -2,9 +2,11 @@
 #include "bicg_mtx.h"
 
 #include <ctype.h>
+#include <stdint.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <sys/stat.h>
 
 #ifdef BICG_HAVE_MPI
 #include <mpi.h>
@@ -34,6 +36,44 @@ static int owner_of(unsigned long row, unsigned long m, int nranks)
     const unsigned long base = m / (unsigned long)nranks, extra = m % (unsigned long)nranks;
     const unsigned long cut = extra * (base + 1);
     return (int)(row < cut ? row / (base + 1) : extra + (row - cut) / (base ? base : 1));
+}
+
+/* owner under an arbitrary contiguous partition: the rank p with displs[p] <= row < displs[p] + counts[p] */
+static int owner_in(unsigned long row, const int *counts, const int *displs, int nranks)
+{
+    int lo = 0, hi = nranks - 1;
+    while (lo < hi) {
+        const int mid = (lo + hi + 1) / 2;
+        if ((unsigned long)displs[mid] <= row) lo = mid; else hi = mid - 1;
+    }
+    while (lo > 0 && counts[lo] == 0) --lo;      /* empty ranks share a displacement with their successor */
+    while ((unsigned long)displs[lo] + (unsigned long)counts[lo] <= row && lo + 1 < nranks) ++lo;
+    return lo;
+}
+
+/* Contiguous row blocks with (nearly) equal numbers of NON-ZEROS: cut k is placed where the running
+ * count is closest to k/P of the total. The idea is the reference's abandoned DYNAMIC_ROWS branch
+ * (archive/matrix.c:407-446: each rank takes rows until it holds nz/P entries, the last rank takes
+ * the rest); cutting against the cumulative targets instead keeps the error from piling up on the
+ * last rank, and every rank gets at least one row when n >= P. */
+void bicg_partition_nnz(const unsigned int *row_nnz, unsigned int n, int nranks, int *counts, int *displs)
+{
+    unsigned long long total = 0, run = 0;
+    for (unsigned i = 0; i < n; ++i) total += row_nnz[i];
+    unsigned row = 0;
+    displs[0] = 0;
+    for (int k = 1; k < nranks; ++k) {
+        const unsigned long long target = total * (unsigned long long)k / (unsigned long long)nranks;
+        const unsigned min_row = (unsigned)displs[k - 1] + (n >= (unsigned)nranks ? 1u : 0u);
+        const unsigned max_row = n >= (unsigned)nranks ? n - (unsigned)(nranks - k) : n;
+        while (row < n && run + row_nnz[row] <= target) run += row_nnz[row++];
+        /* row = first row whose inclusion would exceed the target: take it if that is closer */
+        if (row < n && run < target && (run + row_nnz[row]) - target < target - run) run += row_nnz[row++];
+        while (row < min_row && row < n) run += row_nnz[row++];
+        while (row > max_row) run -= row_nnz[--row];
+        displs[k] = (int)row;
+    }
+    for (int k = 0; k < nranks; ++k) counts[k] = (k + 1 < nranks ? displs[k + 1] : (int)n) - displs[k];
 }
 
 static char *slurp_range(const char *path, size_t off, size_t len, size_t *got)
@@ -144,7 +184,7 @@ static void csr_from_triplets(const triplet *t, size_t nt, unsigned rows, unsign
 }
 
 static void fill_info(const mtx_header *h, int nranks, INFO_Matrix *info)
-{
+{   /* equal-rows partition; the nnz-balanced loaders overwrite recvcounts/displs afterwards */
     info->rows = (unsigned)h->m; info->cols = (unsigned)h->n; info->nz = (unsigned)h->nz;
     memcpy(info->code, h->pattern ? "MCPG" : (h->integer ? "MCIG" : "MCRG"), 4);
     if (h->symmetric) info->code[3] = 'S';
@@ -173,7 +213,14 @@ static void emit_serial(void *c, unsigned long i, unsigned long j, double v)
     if (i >= s->lo && i < s->hi) tpush(&s->mine, (unsigned)i, (unsigned)j, v);
 }
 
-int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
+static void emit_count(void *c, unsigned long i, unsigned long j, double v)
+{
+    (void)j; (void)v;
+    ((unsigned *)c)[i]++;
+}
+
+int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, CSR_Matrix *diag, CSR_Matrix *offd,
+                             INFO_Matrix *info)
 {
     size_t len = 0;
     char *buf = slurp_range(path, 0, (size_t)-1, &len);
@@ -182,6 +229,13 @@ int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag
     int rc = parse_header(buf, &h);
     if (rc) { free(buf); return rc; }
     fill_info(&h, nranks, info);
+    if (part == BICG_PART_NNZ) {             /* one more pass over the text: non-zeros per row */
+        unsigned *cnt = (unsigned *)calloc(h.m ? h.m : 1, sizeof(unsigned));
+        rc = parse_entries(buf + h.data_off, buf + len, &h, h.nz, emit_count, cnt);
+        if (rc) { free(cnt); free(buf); return rc; }
+        bicg_partition_nnz(cnt, (unsigned)h.m, nranks, info->recvcounts, info->displs);
+        free(cnt);
+    }
     serial_ctx s = {{0, 0, 0}, (unsigned)info->displs[rank], (unsigned)(info->displs[rank] + info->recvcounts[rank])};
     rc = parse_entries(buf + h.data_off, buf + len, &h, h.nz, emit_serial, &s);
     free(buf);
@@ -191,15 +245,144 @@ int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag
     return 0;
 }
 
+int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
+{
+    return bicg_mtx_load_block_part(path, rank, nranks, BICG_PART_ROWS, diag, offd, info);
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Binary block cache: the parsed blocks of one rank, so that the next run skips the text file.
+ *   header | recvcounts[P] | displs[P] | diag ptr,col,val | offd ptr,col,val | FNV-1a of all of it
+ * A cache entry is only used when it was written for the same (rank, nranks, partition mode) and the
+ * source file still has the size and modification time recorded in the header.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    char     magic[8];              /* "BICGBLK1" */
+    uint32_t version, nranks, rank, part;
+    uint32_t rows, cols, nz;        /* global, as in the banner */
+    char     code[4];
+    uint32_t local_rows, nnz_d, nnz_o, offd_cols;
+    uint64_t src_size;
+    int64_t  src_mtime;
+} cache_header;
+
+static uint64_t fnv1a(uint64_t h, const void *data, size_t n)
+{
+    const unsigned char *p = (const unsigned char *)data;
+    for (size_t i = 0; i < n; ++i) h = (h ^ p[i]) * 1099511628211ull;
+    return h;
+}
+
+static int src_stamp(const char *src, uint64_t *size, int64_t *mtime)
+{
+    struct stat st;
+    if (!src || stat(src, &st) != 0) { *size = 0; *mtime = 0; return 1; }
+    *size = (uint64_t)st.st_size; *mtime = (int64_t)st.st_mtime;
+    return 0;
+}
+
+int bicg_mtx_cache_save(const char *cache_path, const char *src_path, int rank, int nranks, int part,
+                        const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
+{
+    cache_header h;
+    memset(&h, 0, sizeof h);
+    memcpy(h.magic, "BICGBLK1", 8);
+    h.version = 1; h.nranks = (uint32_t)nranks; h.rank = (uint32_t)rank; h.part = (uint32_t)part;
+    h.rows = info->rows; h.cols = info->cols; h.nz = info->nz;
+    memcpy(h.code, info->code, 4);
+    h.local_rows = diag->rows; h.nnz_d = diag->ptr[diag->rows]; h.nnz_o = offd->ptr ? offd->ptr[offd->rows] : 0u;
+    h.offd_cols = offd->cols;
+    (void)src_stamp(src_path, &h.src_size, &h.src_mtime);
+    char tmp[4096];
+    snprintf(tmp, sizeof tmp, "%s.tmp%d", cache_path, rank);
+    FILE *f = fopen(tmp, "wb");
+    if (!f) return 1;
+    uint64_t sum = 1469598103934665603ull;
+    int bad = 0;
+#define PUT(ptr, bytes) do { const size_t nb_ = (bytes); if (nb_ && fwrite((ptr), 1, nb_, f) != nb_) bad = 1; sum = fnv1a(sum, (ptr), nb_); } while (0)
+    PUT(&h, sizeof h);
+    PUT(info->recvcounts, sizeof(int) * (size_t)nranks);
+    PUT(info->displs, sizeof(int) * (size_t)nranks);
+    PUT(diag->ptr, sizeof(unsigned) * ((size_t)h.local_rows + 1));
+    PUT(diag->col, sizeof(unsigned) * (size_t)h.nnz_d);
+    PUT(diag->val, sizeof(double) * (size_t)h.nnz_d);
+    PUT(offd->ptr, sizeof(unsigned) * ((size_t)h.local_rows + 1));
+    PUT(offd->col, sizeof(unsigned) * (size_t)h.nnz_o);
+    PUT(offd->val, sizeof(double) * (size_t)h.nnz_o);
+#undef PUT
+    if (fwrite(&sum, 1, sizeof sum, f) != sizeof sum) bad = 1;
+    if (fclose(f) != 0) bad = 1;
+    if (bad || rename(tmp, cache_path) != 0) { remove(tmp); return 1; }   /* readers never see a half-written file */
+    return 0;
+}
+
+int bicg_mtx_cache_load(const char *cache_path, const char *src_path, int rank, int nranks, int part,
+                        CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
+{
+    FILE *f = fopen(cache_path, "rb");
+    if (!f) return 1;
+    cache_header h;
+    uint64_t sum = 1469598103934665603ull, want = 0, ssize = 0;
+    int64_t smtime = 0;
+    int rc = 2;
+    memset(diag, 0, sizeof *diag); memset(offd, 0, sizeof *offd); memset(info, 0, sizeof *info);
+    if (fread(&h, 1, sizeof h, f) != sizeof h) goto out;
+    if (memcmp(h.magic, "BICGBLK1", 8) != 0 || h.version != 1) goto out;
+    if ((int)h.nranks != nranks || (int)h.rank != rank || (int)h.part != part) goto out;
+    if (src_path && (src_stamp(src_path, &ssize, &smtime) != 0 || ssize != h.src_size || smtime != h.src_mtime)) goto out;
+    sum = fnv1a(sum, &h, sizeof h);
+    info->rows = h.rows; info->cols = h.cols; info->nz = h.nz;
+    memcpy(info->code, h.code, 4);
+    info->recvcounts = (int *)malloc(sizeof(int) * (size_t)nranks);
+    info->displs = (int *)malloc(sizeof(int) * (size_t)nranks);
+    diag->rows = h.local_rows; diag->cols = h.local_rows; diag->nz = h.nnz_d;
+    offd->rows = h.local_rows; offd->cols = h.offd_cols; offd->nz = h.nnz_o;
+    diag->ptr = (unsigned *)malloc(sizeof(unsigned) * ((size_t)h.local_rows + 1));
+    diag->col = (unsigned *)malloc(sizeof(unsigned) * (h.nnz_d ? h.nnz_d : 1));
+    diag->val = (double *)malloc(sizeof(double) * (h.nnz_d ? h.nnz_d : 1));
+    offd->ptr = (unsigned *)malloc(sizeof(unsigned) * ((size_t)h.local_rows + 1));
+    offd->col = (unsigned *)malloc(sizeof(unsigned) * (h.nnz_o ? h.nnz_o : 1));
+    offd->val = (double *)malloc(sizeof(double) * (h.nnz_o ? h.nnz_o : 1));
+    rc = 3;
+#define GET(ptr, bytes) do { const size_t nb_ = (bytes); if (nb_ && fread((ptr), 1, nb_, f) != nb_) goto out; sum = fnv1a(sum, (ptr), nb_); } while (0)
+    GET(info->recvcounts, sizeof(int) * (size_t)nranks);
+    GET(info->displs, sizeof(int) * (size_t)nranks);
+    GET(diag->ptr, sizeof(unsigned) * ((size_t)h.local_rows + 1));
+    GET(diag->col, sizeof(unsigned) * (size_t)h.nnz_d);
+    GET(diag->val, sizeof(double) * (size_t)h.nnz_d);
+    GET(offd->ptr, sizeof(unsigned) * ((size_t)h.local_rows + 1));
+    GET(offd->col, sizeof(unsigned) * (size_t)h.nnz_o);
+    GET(offd->val, sizeof(double) * (size_t)h.nnz_o);
+#undef GET
+    if (fread(&want, 1, sizeof want, f) != sizeof want || want != sum) goto out;
+    if (diag->ptr[h.local_rows] != h.nnz_d || offd->ptr[h.local_rows] != h.nnz_o) goto out;
+    rc = 0;
+out:
+    fclose(f);
+    if (rc != 0 && rc != 1) {          /* partial read: release whatever was allocated */
+        free(diag->ptr); free(diag->col); free(diag->val);
+        free(offd->ptr); free(offd->col); free(offd->val);
+        free(info->recvcounts); free(info->displs);
+        memset(diag, 0, sizeof *diag); memset(offd, 0, sizeof *offd); memset(info, 0, sizeof *info);
+    }
+    return rc;
+}
+
 #ifdef BICG_HAVE_MPI
-typedef struct { tvec *bins; unsigned long m; int np; } par_ctx;
+typedef struct { tvec *bins; unsigned long m; int np; const int *counts, *displs; } par_ctx;
 static void emit_par(void *c, unsigned long i, unsigned long j, double v)
 {
     par_ctx *p = (par_ctx *)c;
-    tpush(&p->bins[owner_of(i, p->m, p->np)], (unsigned)i, (unsigned)j, v);
+    const int owner = p->counts ? owner_in(i, p->counts, p->displs, p->np) : owner_of(i, p->m, p->np);
+    tpush(&p->bins[owner], (unsigned)i, (unsigned)j, v);
 }
 
 int bicg_mtx_load_block_mpi(const char *path, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
+{
+    return bicg_mtx_load_block_mpi_part(path, BICG_PART_ROWS, diag, offd, info);
+}
+
+int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
 {
     int np = 1, me = 0;
     MPI_Comm_size(MPI_COMM_WORLD, &np);
@@ -231,8 +414,17 @@ int bicg_mtx_load_block_mpi(const char *path, CSR_Matrix *diag, CSR_Matrix *offd
     const char *q = stop;
     if (q > buf && q[-1] != '\n') { while (q < buf + len && *q != '\n') ++q; }
     par_ctx pc;
-    pc.bins = (tvec *)calloc((size_t)np, sizeof(tvec)); pc.m = h.m; pc.np = np;
-    if (p < q) rc = parse_entries(p, q, &h, (unsigned long)-1, emit_par, &pc);
+    pc.bins = (tvec *)calloc((size_t)np, sizeof(tvec)); pc.m = h.m; pc.np = np; pc.counts = NULL; pc.displs = NULL;
+    if (part == BICG_PART_NNZ) {
+        /* non-zeros per row: every rank counts its byte range, one all-reduce, same cuts everywhere */
+        unsigned *cnt = (unsigned *)calloc(h.m ? h.m : 1, sizeof(unsigned));
+        if (p < q) rc = parse_entries(p, q, &h, (unsigned long)-1, emit_count, cnt);
+        MPI_Allreduce(MPI_IN_PLACE, cnt, (int)h.m, MPI_UNSIGNED, MPI_SUM, MPI_COMM_WORLD);
+        bicg_partition_nnz(cnt, (unsigned)h.m, np, info->recvcounts, info->displs);
+        free(cnt);
+        pc.counts = info->recvcounts; pc.displs = info->displs;
+    }
+    if (!rc && p < q) rc = parse_entries(p, q, &h, (unsigned long)-1, emit_par, &pc);
     free(buf);
     if (rc) return rc;
 

@@ -17,7 +17,24 @@
  * Every rank reads and tokenises the whole file (no communication). */
 int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 
+/* Row partitions. BICG_PART_ROWS: the reference's equal-rows blocks (src/matrix.c:295-308).
+ * BICG_PART_NNZ: contiguous blocks with equal non-zero counts (the reference's abandoned DYNAMIC_ROWS
+ * idea, archive/matrix.c:407-446) -- the solver takes any contiguous partition through
+ * INFO_Matrix.recvcounts/displs. */
+int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, CSR_Matrix *diag, CSR_Matrix *offd,
+                             INFO_Matrix *info);
+
+/* Binary cache of one rank's parsed blocks: bicg_mtx_cache_load returns 0
+ * and fills diag/offd/info when `cache_path` holds the blocks of exactly this (rank, nranks,
+ * partition) and `src_path` (may be NULL: no staleness check) still has the recorded size and
+ * modification time; any other value means "parse the text file". Checksummed; written atomically. */
+int bicg_mtx_cache_save(const char *cache_path, const char *src_path, int rank, int nranks, int part,
+                        const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info);
+int bicg_mtx_cache_load(const char *cache_path, const char *src_path, int rank, int nranks, int part,
+                        CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+
 #ifdef BICG_HAVE_MPI
+int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 /* Collective over MPI_COMM_WORLD: every rank tokenises only ITS 1/P byte range of the file (cut at
  * line boundaries), bins the triplets by owning rank and exchanges them with MPI_Alltoallv; triplets
  * arrive in source-rank order = file order, so rows keep the reference's stored order. Parse time

@@ -234,10 +234,24 @@ def partition(n: int, nranks: int):
     return counts, displs
 
 
-def split_blocks(A: CSR, nranks: int, rank: int):
+def partition_nnz(A: CSR, nranks: int):
+    """non-zero balanced contiguous row blocks through the library's bicg_partition_nnz"""
+    import ctypes as C
+    from . import hipsolver as H
+    lens = np.ascontiguousarray(np.diff(A.ptr.astype(np.int64)), dtype=np.uint32)
+    counts = np.zeros(nranks, dtype=np.int32)
+    displs = np.zeros(nranks, dtype=np.int32)
+    ip = C.POINTER(C.c_int)
+    H.lib().bicg_partition_nnz(lens.ctypes.data_as(C.POINTER(C.c_uint)), C.c_uint(A.rows), C.c_int(nranks),
+                               counts.ctypes.data_as(ip), displs.ctypes.data_as(ip))
+    return counts, displs
+
+
+def split_blocks(A: CSR, nranks: int, rank: int, part=None):
     """(diag, offd, counts, displs) for one rank: diag has LOCAL columns and cols = local rows,
-    offd keeps GLOBAL columns and cols = n (reference src/matrix.c:343-351, 380-392)."""
-    counts, displs = partition(A.rows, nranks)
+    offd keeps GLOBAL columns and cols = n (reference src/matrix.c:343-351, 380-392).
+    part = (counts, displs) overrides the reference's equal-rows partition."""
+    counts, displs = part if part is not None else partition(A.rows, nranks)
     lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
     ptr = A.ptr.astype(np.int64)
     a, b = int(ptr[lo]), int(ptr[hi])

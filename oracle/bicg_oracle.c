@@ -43,13 +43,28 @@ static void csr_release(orc_csr *A) { free(A->val); free(A->col); free(A->ptr); 
 orc_dist *orc_dist_from_coo(unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
                             const double *val, int P)
 {
+    return orc_dist_from_coo_part(n, nnz, row, col, val, P, NULL);
+}
+
+/* Same with a caller-supplied contiguous partition (rows per rank); counts == NULL = the reference's
+ * equal-rows partition. The reference's live code has no other partition (its nnz-balanced
+ * DYNAMIC_ROWS branch sits unused in archive/matrix.c:407-446), so this entry is an extension: the
+ * per-rank arithmetic is the same mult()/ddot restatement, only the cuts move. */
+orc_dist *orc_dist_from_coo_part(unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                                 const double *val, int P, const int *counts)
+{
     orc_dist *d = (orc_dist *)calloc(1, sizeof(orc_dist));
     d->P = P; d->n = n;
     d->counts = (int *)malloc(sizeof(int) * (size_t)P);
     d->displs = (int *)malloc(sizeof(int) * (size_t)P);
     d->diag = (orc_csr *)calloc((size_t)P, sizeof(orc_csr));
     d->offd = (orc_csr *)calloc((size_t)P, sizeof(orc_csr));
-    orc_partition(n, P, d->counts, d->displs);
+    if (counts) {
+        int at = 0;
+        for (int p = 0; p < P; ++p) { d->counts[p] = counts[p]; d->displs[p] = at; at += counts[p]; }
+    } else {
+        orc_partition(n, P, d->counts, d->displs);
+    }
 
     /* owner of every row */
     int *owner = (int *)malloc(sizeof(int) * (size_t)(n ? n : 1));
@@ -672,6 +687,23 @@ int orc_solve_coo(int method, int P, unsigned n, unsigned nnz, const unsigned *r
     int k = orc_solve(method, d, x, r, o);
     orc_dist_free(d);
     return k;
+}
+
+int orc_solve_coo_part(int method, int P, const int *counts, unsigned n, unsigned nnz, const unsigned *row,
+                       const unsigned *col, const double *val, double *x, double *r, orc_opts *o)
+{
+    orc_dist *d = orc_dist_from_coo_part(n, nnz, row, col, val, P, counts);
+    int k = orc_solve(method, d, x, r, o);
+    orc_dist_free(d);
+    return k;
+}
+
+void orc_spmv_coo_part(int P, const int *counts, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                       const double *val, const double *x, double *y)
+{
+    orc_dist *d = orc_dist_from_coo_part(n, nnz, row, col, val, P, counts);
+    orc_spmv(d, x, y);
+    orc_dist_free(d);
 }
 
 void orc_spmv_coo(int P, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,

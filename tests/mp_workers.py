@@ -105,9 +105,17 @@ def gpu_worker(rank, world, port, kind, outdir):
             # data path through IPC-mapped mailboxes (bicg_p2p.cpp); gloo only bootstraps
             assert H.lib().bicg_comm_enable_p2p() == 0, "peer-to-peer transport did not come up"
             assert H.lib().bicg_comm_p2p_active() > 0
+        balanced = kind.endswith("+nnz")
+        kind = kind.replace("+nnz", "")
         A = test_matrix(kind)
-        diag, offd, counts, displs = synth.split_blocks(A, world, rank)
+        part = synth.partition_nnz(A, world) if balanced else None     # non-zero balanced cuts
+        diag, offd, counts, displs = synth.split_blocks(A, world, rank, part=part)
         lo, nl = int(displs[rank]), int(counts[rank])
+        if balanced:
+            assert not np.array_equal(counts, synth.partition(A.rows, world)[0]), "test matrix does not move the cuts"
+            O_spmv, O_solve = O.spmv, O.solve
+            O.spmv = lambda *a, **k: O_spmv(*a, counts=counts, **k)
+            O.solve = lambda *a, **k: O_solve(*a, counts=counts, **k)
         ctx = H.Context(H.HostBlocks(diag, offd, A.rows, counts, displs))
         info = ctx.plan_info()
         assert info["halo"] > 0 and info["boundary_blocks"] > 0
@@ -145,7 +153,7 @@ def gpu_worker(rank, world, port, kind, outdir):
         # shifted systems, 5 shifts, seed 2 (reference src/test_shifted.c:95-111 set-up)
         sigma, seed = 0.01 * (np.arange(5) + 1.0), 2
         bs_full = b_full + sigma[seed] * np.ones(A.rows)
-        for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab"):
+        for which in (() if balanced else ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab")):
             orc = O.solve_shifted(A.rows, row, col, val, bs_full, sigma, seed, nranks=world, which=which)
             got = ctx.solve_shifted(bs_full[lo:lo + nl], sigma, seed, check_every=4, which=which)
             assert abs(got["k"] - orc["k"]) <= 2, (which, got["k"], orc["k"])

@@ -39,6 +39,12 @@ def lib():
                                        C.POINTER(OrcOpts)]
         _lib.orc_spmv_coo.restype = None
         _lib.orc_spmv_coo.argtypes = [C.c_int, C.c_uint, C.c_uint, _up, _up, _dp, _dp, _dp]
+        _ip = C.POINTER(C.c_int)
+        _lib.orc_solve_coo_part.restype = C.c_int
+        _lib.orc_solve_coo_part.argtypes = [C.c_int, C.c_int, _ip, C.c_uint, C.c_uint, _up, _up, _dp, _dp, _dp,
+                                            C.POINTER(OrcOpts)]
+        _lib.orc_spmv_coo_part.restype = None
+        _lib.orc_spmv_coo_part.argtypes = [C.c_int, _ip, C.c_uint, C.c_uint, _up, _up, _dp, _dp, _dp]
         _lib.orc_ddot.restype = C.c_double
         _lib.orc_ddot.argtypes = [C.c_int, _dp, _dp]
         _lib.orc_daxpy.restype = None
@@ -68,12 +74,23 @@ def _coo(row, col, val):
             np.ascontiguousarray(val, dtype=np.float64))
 
 
-def spmv(n, row, col, val, x, nranks=1):
-    """y = A x through the oracle's distributed SpMV over `nranks` virtual ranks (file-order COO)."""
+def _counts(counts, nranks):
+    c = np.ascontiguousarray(counts, dtype=np.int32)
+    assert len(c) == nranks
+    return c, c.ctypes.data_as(C.POINTER(C.c_int))
+
+
+def spmv(n, row, col, val, x, nranks=1, counts=None):
+    """y = A x through the oracle's distributed SpMV over `nranks` virtual ranks (file-order COO);
+    counts = rows per rank for a non-default contiguous partition."""
     row, col, val = _coo(row, col, val)
     x = np.ascontiguousarray(x, dtype=np.float64)
     y = np.zeros(n)
-    lib().orc_spmv_coo(nranks, n, len(val), _u(row), _u(col), _d(val), _d(x), _d(y))
+    if counts is not None:
+        keep, cp = _counts(counts, nranks)
+        lib().orc_spmv_coo_part(nranks, cp, n, len(val), _u(row), _u(col), _d(val), _d(x), _d(y))
+    else:
+        lib().orc_spmv_coo(nranks, n, len(val), _u(row), _u(col), _d(val), _d(x), _d(y))
     return y
 
 
@@ -83,15 +100,20 @@ def ddot(x, y):
     return lib().orc_ddot(len(x), _d(x), _d(y))
 
 
-def solve(method, n, row, col, val, b, x0=None, nranks=1, tol=1e-15, max_iter=1000, krr=0, nrr=0):
+def solve(method, n, row, col, val, b, x0=None, nranks=1, tol=1e-15, max_iter=1000, krr=0, nrr=0, counts=None):
     """Returns dict(k, x, r, dot_r, dot_zero, alpha, omega, beta, dotr) -- traces have length k."""
     row, col, val = _coo(row, col, val)
     x = np.zeros(n) if x0 is None else np.array(x0, dtype=np.float64)
     r = np.array(b, dtype=np.float64)
     tr = [np.zeros(max(max_iter, 1)) for _ in range(4)]
     o = OrcOpts(tol, max_iter, krr, nrr, _d(tr[0]), _d(tr[1]), _d(tr[2]), _d(tr[3]), 0.0, 0.0)
-    k = lib().orc_solve_coo(METHODS[method], nranks, n, len(val), _u(row), _u(col), _d(val), _d(x),
-                            _d(r), C.byref(o))
+    if counts is not None:
+        keep, cp = _counts(counts, nranks)
+        k = lib().orc_solve_coo_part(METHODS[method], nranks, cp, n, len(val), _u(row), _u(col), _d(val), _d(x),
+                                     _d(r), C.byref(o))
+    else:
+        k = lib().orc_solve_coo(METHODS[method], nranks, n, len(val), _u(row), _u(col), _d(val), _d(x),
+                                _d(r), C.byref(o))
     return dict(k=k, x=x, r=r, dot_r=o.dot_r, dot_zero=o.dot_zero, alpha=tr[0][:k], omega=tr[1][:k],
                 beta=tr[2][:k], dotr=tr[3][:k])
 

@@ -35,6 +35,12 @@ def _read(prefix, rank):
     return rows, ncols, d, o
 
 
+def _read_partition(prefix, rank, world):
+    raw = open(f"{prefix}.rank{rank}.bin", "rb").read()
+    tail = np.frombuffer(raw[-8 * world:], dtype=np.int32)
+    return tail[:world].copy(), tail[world:].copy()      # displs, counts
+
+
 def _expected(n, row, col, val, world, rank):
     """stable sort of the file-order triplets by row, then the reference's diag/offd split"""
     order = np.argsort(row, kind="stable")
@@ -90,3 +96,89 @@ def test_loader_symmetric_and_pattern(tmp_path):
         want[i, j] = 1.0
         want[j, i] = 1.0
     assert np.array_equal(dense, want)
+
+
+def _write_mtx(path, A, row, col, val):
+    with open(path, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{A.rows} {A.cols} {len(val)}\n")
+        for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
+            f.write(f"{i + 1} {j + 1} {v!r}\n")
+
+
+def _blocks_for(A, displs, counts, rank):
+    """diag/offd split of CSR A (file order inside rows already) for an arbitrary contiguous partition"""
+    lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+    ptr = A.ptr.astype(np.int64)
+    dptr, optr, dcol, ocol, dval, oval = [0], [0], [], [], [], []
+    for r in range(lo, hi):
+        for k in range(ptr[r], ptr[r + 1]):
+            c = int(A.col[k])
+            if lo <= c < hi:
+                dcol.append(c - lo); dval.append(A.val[k])
+            else:
+                ocol.append(c); oval.append(A.val[k])
+        dptr.append(len(dcol)); optr.append(len(ocol))
+    return (np.array(dptr), np.array(dcol, dtype=np.int64), np.array(dval)), (np.array(optr), np.array(ocol, dtype=np.int64), np.array(oval))
+
+
+@pytest.mark.parametrize("world,mode", [(1, "serial"), (3, "serial"), (2, "mpi"), (4, "mpi")])
+def test_loader_nnz_balanced_partition_and_cache(tmp_path, world, mode):
+    """non-zero balanced row blocks (the reference's abandoned DYNAMIC_ROWS idea,
+    archive/matrix.c:407-446) and the binary block cache round trip. A ragged matrix (row lengths
+    0..60 plus one row of 400) makes equal-rows blocks badly unbalanced."""
+    A = synth.random_rows(1500, 60, seed=12, long_rows={700: 400})
+    row, col, val = A.to_coo()
+    mtx = str(tmp_path / "r.mtx")
+    _write_mtx(mtx, A, row, col, val)
+    prefix = str(tmp_path / "out")
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode, "nnz", str(cache)], check=True, timeout=120)
+    lens = np.diff(A.ptr.astype(np.int64))
+    displs, counts = _read_partition(prefix, 0, world)
+    assert displs[0] == 0 and np.array_equal(displs[1:], np.cumsum(counts)[:-1]) and counts.sum() == A.rows
+    per_rank = np.array([lens[displs[p]:displs[p] + counts[p]].sum() for p in range(world)])
+    # every block within one (longest) row of the ideal share
+    assert np.abs(per_rank - lens.sum() / world).max() <= lens.max(), (per_rank, lens.sum() / world)
+    for rank in range(world):
+        d2, c2 = _read_partition(prefix, rank, world)
+        assert np.array_equal(d2, displs) and np.array_equal(c2, counts)        # same cuts on every rank
+        rows, ncols, d, o = _read(prefix, rank)                                   # (after the cache round trip)
+        ed, eo = _blocks_for(A, displs, counts, rank)
+        assert rows == counts[rank]
+        assert np.array_equal(d[0], ed[0]) and np.array_equal(d[1], ed[1]) and np.array_equal(d[2], ed[2])
+        assert np.array_equal(o[0], eo[0]) and np.array_equal(o[1], eo[1]) and np.array_equal(o[2], eo[2])
+    assert len(list(cache.iterdir())) == world
+
+
+def test_cache_rejects_stale_and_corrupt(tmp_path):
+    import ctypes as C
+    from mpi_bicgstab_amd import hipsolver as H
+    L = H.lib()
+    A = synth.from_offsets(300, (0, 1, -1, 17, -17), diag_base=5.0, seed=1)
+    row, col, val = synth.colmajor_coo(A)
+    mtx = str(tmp_path / "m.mtx")
+    _write_mtx(mtx, A, row, col, val)
+    d, o, info = H.CSRMatrix(), H.CSRMatrix(), H.InfoMatrix()
+    L.bicg_mtx_load_block_part.argtypes = [C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(H.CSRMatrix), C.POINTER(H.CSRMatrix), C.POINTER(H.InfoMatrix)]
+    args6 = [C.c_char_p, C.c_char_p, C.c_int, C.c_int, C.c_int, C.POINTER(H.CSRMatrix), C.POINTER(H.CSRMatrix), C.POINTER(H.InfoMatrix)]
+    L.bicg_mtx_cache_save.argtypes = args6
+    L.bicg_mtx_cache_load.argtypes = args6
+    assert L.bicg_mtx_load_block_part(mtx.encode(), 1, 2, 0, C.byref(d), C.byref(o), C.byref(info)) == 0
+    cpath = str(tmp_path / "c.bicgblk").encode()
+    assert L.bicg_mtx_cache_save(cpath, mtx.encode(), 1, 2, 0, C.byref(d), C.byref(o), C.byref(info)) == 0
+    d2, o2, i2 = H.CSRMatrix(), H.CSRMatrix(), H.InfoMatrix()
+    assert L.bicg_mtx_cache_load(cpath, mtx.encode(), 1, 2, 0, C.byref(d2), C.byref(o2), C.byref(i2)) == 0
+    assert d2.rows == d.rows and d2.ptr[d2.rows] == d.ptr[d.rows]
+    assert L.bicg_mtx_cache_load(cpath, mtx.encode(), 0, 2, 0, C.byref(d2), C.byref(o2), C.byref(i2)) != 0     # other rank
+    # a flipped byte in the payload fails the checksum
+    raw = bytearray(open(cpath.decode(), "rb").read())
+    raw[len(raw) // 2] ^= 0x40
+    open(cpath.decode(), "wb").write(bytes(raw))
+    assert L.bicg_mtx_cache_load(cpath, mtx.encode(), 1, 2, 0, C.byref(d2), C.byref(o2), C.byref(i2)) != 0
+    # source file changed after the cache was written
+    assert L.bicg_mtx_cache_save(cpath, mtx.encode(), 1, 2, 0, C.byref(d), C.byref(o), C.byref(info)) == 0
+    with open(mtx, "a") as f:
+        f.write("% touched\n")
+    assert L.bicg_mtx_cache_load(cpath, mtx.encode(), 1, 2, 0, C.byref(d2), C.byref(o2), C.byref(i2)) != 0

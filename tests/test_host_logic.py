@@ -127,3 +127,37 @@ def test_header_is_plain_c_and_coexists_with_reference_headers(tmp_path):
                         'int g(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return bicgstab(d, o, i, x, r); }\n')
         subprocess.run(["gcc", "-std=gnu99", "-w", "-fsyntax-only", f"-I{ref}", "-I/opt/conda/include", f"-I{inc}", str(src2)],
                        check=True)
+
+
+def test_partition_nnz_edge_cases():
+    """bicg_partition_nnz: contiguous, covers every row once, >= 1 row per rank when n >= P, and no
+    block further than one (longest) row from the ideal share."""
+    import ctypes as C
+    from mpi_bicgstab_amd import hipsolver as H
+    L = H.lib()
+    ip, upp = C.POINTER(C.c_int), C.POINTER(C.c_uint)
+
+    def cut(lens, P):
+        lens = np.ascontiguousarray(lens, dtype=np.uint32)
+        counts, displs = np.zeros(P, dtype=np.int32), np.zeros(P, dtype=np.int32)
+        L.bicg_partition_nnz(lens.ctypes.data_as(upp), C.c_uint(len(lens)), C.c_int(P), counts.ctypes.data_as(ip),
+                             displs.ctypes.data_as(ip))
+        assert displs[0] == 0 and counts.sum() == len(lens) and (counts >= 0).all()
+        assert np.array_equal(displs[1:], np.cumsum(counts)[:-1])
+        return counts, displs
+
+    rng = np.random.default_rng(0)
+    for n, P in ((1000, 7), (64, 8), (5, 5), (3, 8), (1, 1), (200, 3)):
+        lens = rng.integers(0, 40, size=n)
+        counts, displs = cut(lens, P)
+        if n >= P:
+            assert (counts >= 1).all()
+            share = np.array([lens[displs[p]:displs[p] + counts[p]].sum() for p in range(P)])
+            assert np.abs(share - lens.sum() / P).max() <= max(lens.max(), 1) * (2 if n < 4 * P else 1) + 1
+    counts, _ = cut(np.zeros(50), 4)                       # no non-zeros at all
+    assert (counts >= 1).all()
+    lens = np.ones(100); lens[10] = 10000                  # one dominant row
+    counts, displs = cut(lens, 4)
+    assert (counts >= 1).all()
+    uniform, _ = cut(np.full(1000, 15), 8)                 # uniform rows: the equal-rows partition
+    assert np.array_equal(uniform, np.full(8, 125))

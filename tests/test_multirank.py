@@ -39,13 +39,13 @@ def test_halo_plan_gloo(world, kind):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,world", [("offsets", 2), ("stencil", 2), ("ragged", 2), ("offsets", 3)])
+@pytest.mark.parametrize("kind,world", [("offsets", 2), ("stencil", 2), ("ragged", 2), ("offsets", 3), ("ragged+nnz", 3)])
 def test_multirank_solver_on_one_gpu(kind, world):
     _run(W.gpu_worker, world, kind)
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,world", [("offsets+p2p", 2), ("stencil+p2p", 2), ("ragged+p2p", 3)])
+@pytest.mark.parametrize("kind,world", [("offsets+p2p", 2), ("stencil+p2p", 2), ("ragged+p2p", 3), ("ragged+nnz+p2p", 2)])
 def test_multirank_solver_peer_to_peer(kind, world):
     """Same checks with the peer-to-peer data path: the ranks map each other's mailboxes and halo
     rings through HIP IPC (here inside one GPU) and the kernels exchange LL words directly."""
