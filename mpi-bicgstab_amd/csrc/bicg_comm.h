@@ -57,6 +57,7 @@ struct P2p {
     {
         P2pRed r;
         r.mail = mail_dev; r.seq = seq; r.mask = mask; r.rank = rank; r.nranks = nranks;
+        r.n_collect = 0; r.timeout_ticks = timeout_ticks;
         return r;
     }
     void *alloc(size_t bytes);             // zero-filled device memory other ranks may map

@@ -98,6 +98,9 @@ struct P2pRed {
     unsigned seq;          // sequence number of the group; 0 = no peer-to-peer publication
     unsigned mask;         // bit d set: this kernel publishes its sum d
     int rank, nranks;
+    int n_collect;         // > 0 (with Reduce::apply_now): the finishing workgroup also waits for the n_collect
+                           // sums of all ranks and applies the phase itself -- no separate apply kernel
+    unsigned long long timeout_ticks;
 };
 __host__ __device__ inline size_t mail_index(unsigned seq, int nranks, int src, int d)
 {

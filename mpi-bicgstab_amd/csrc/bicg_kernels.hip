@@ -501,7 +501,16 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
         }
     }
     if (red.apply_now) {
-        __syncthreads();            // Scal::red written by thread 0 above
+        if (red.p2p.seq) {
+            // peer-to-peer, group not deferred: this workgroup is the last of the launch anyway, so it
+            // waits for the other ranks' sums and applies the phase right here instead of leaving
+            // that to a separate one-workgroup kernel (3-4 us per dot group on a small rank)
+            __shared__ double p2p_vals[kRedSlots * kMaxRanksP2p];
+            __shared__ int p2p_fail;
+            if (!p2p_collect(S, red.p2p.n_collect, red.p2p, red.p2p.timeout_ticks, p2p_vals, &p2p_fail)) return;
+        } else {
+            __syncthreads();        // Scal::red written by thread 0 above
+        }
         apply_phase_block(S, red.phase);
     }
 }

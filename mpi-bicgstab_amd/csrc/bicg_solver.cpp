@@ -98,6 +98,7 @@ struct bicg_ctx {
     // sliced-ELL path. One launch covers push + interior + halo-touching groups (listed in that order).
     bool ll_fused = false;
     uint32_t *glist_ll = nullptr;
+    bool inline_apply = true;       // BICG_P2P_INLINE_APPLY=0: always use the separate apply kernel
     int fault_after = 0;            // BICG_P2P_FAULT_AFTER=n (tests): from the n-th exchange on this rank sends nothing
 
     // vectors and scalars
@@ -155,14 +156,24 @@ struct bicg_ctx {
     hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
     int graph_warm[4] = {0, 0, 0, 0};    // eager iterations done since the context was created
     bool graph_nt[4] = {false, false, false, false};
-    Reduce red(int off, int phase, bool apply_single = true) const
+    // now_n > 0: the group is closed by group_now(now_n, phase) right after this producer (not
+    // deferred); with the peer-to-peer transport the producer's finishing workgroup then collects
+    // and applies it in-kernel and group_now launches nothing.
+    mutable bool open_inline = false;
+    Reduce red(int off, int phase, bool apply_single = true, int now_n = 0) const
     {
         Reduce r;
         r.partial = partial; r.shard_tot = shard_tot; r.counter = counter; r.expected = 0; r.slot_base = 0;
         r.red_off = off; r.phase = phase;
         r.apply_now = (single() && apply_single) ? 1 : 0;
         r.p2p = P2pRed{};
-        if (p2p) r.p2p = p2p->red_desc(p2p->red_seq);   // the group being produced; closed by group_now/defer
+        if (p2p) {
+            r.p2p = p2p->red_desc(p2p->red_seq);   // the group being produced; closed by group_now/defer
+            if (apply_single && now_n > 0 && inline_apply) {
+                r.apply_now = 1; r.p2p.n_collect = now_n;
+                open_inline = true;
+            }
+        }
         return r;
     }
 };
@@ -193,7 +204,12 @@ void group_now(bicg_ctx *c, int n, int phase)
 {
     if (c->single()) return;   // applied in-kernel by the finishing workgroup
     if (c->p2p) {              // the producers stored their sums into every rank's mailbox already
-        launch_apply_p2p(c->S, phase, n, c->p2p->red_desc(c->p2p->red_seq++), c->p2p->timeout_ticks, c->sc);
+        if (c->open_inline) {  // ... and the last of them collects and applies (Reduce::p2p.n_collect)
+            c->open_inline = false;
+            c->p2p->red_seq++;
+        } else {
+            launch_apply_p2p(c->S, phase, n, c->p2p->red_desc(c->p2p->red_seq++), c->p2p->timeout_ticks, c->sc);
+        }
         c->halo_unsynced = 0;
         return;
     }
@@ -380,11 +396,12 @@ struct Driver {
         const bool plain = method == BICG_BICGSTAB;
         const bool rr = method == BICG_PIPE_BICGSTAB_RR || (method == BICG_PIPE_BICGSTAB && c->opt.rr_drift > 0.0);
         spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));                       // Ax = A x0
-        launch_init_residual(v, plain, rr, S, c->red(0, PH_INIT), sc);             // r = b - Ax, r# = r, (r,r)
+        launch_init_residual(v, plain, rr, S, c->red(0, PH_INIT, true, 1), sc);             // r = b - Ax, r# = r, (r,r)
         group_now(c, 1, PH_INIT);
         if (plain) return;
-        spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_INIT_ALPHA));                        // w = A r, (r,w)
-        if (method == BICG_CA_BICGSTAB) {
+        const bool ca = method == BICG_CA_BICGSTAB;
+        spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_INIT_ALPHA, true, ca ? 1 : 0));       // w = A r, (r,w)
+        if (ca) {
             group_now(c, 1, PH_INIT_ALPHA);
         } else {
             group_defer(c, 1, PH_INIT_ALPHA);                                       // overlaps t = A w (src/solver.c:339-343)
@@ -395,12 +412,12 @@ struct Driver {
 
     void iter_plain()   // reference src/solver.c:88-119
     {
-        spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA));   // s = A p, (r#,s) -> alpha
+        spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
         launch_plain_q(v, S, sc);                                // q = r - alpha s
-        spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA));          // y = A q, (q,y), (y,y) -> omega
+        spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA, true, 2));          // y = A q, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_plain_xr(v, S, c->red(0, PH_PLAIN_END), sc);      // x, r, (r,r), (r#,r) -> beta, k++
+        launch_plain_xr(v, S, c->red(0, PH_PLAIN_END, true, 2), sc);      // x, r, (r,r), (r#,r) -> beta, k++
         group_now(c, 2, PH_PLAIN_END);
         launch_plain_p(v, S, sc);                                // p = r + beta (p - omega s)
     }
@@ -409,10 +426,10 @@ struct Driver {
     {
         launch_ca_ps(v, S, sc);                                  // p, s recurrences
         spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
-        launch_qy(v, S, c->red(0, PH_OMEGA), sc);                // q, y, (q,y), (y,y) -> omega
+        launch_qy(v, S, c->red(0, PH_OMEGA, true, 2), sc);       // q, y, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
         launch_ca_xr(v, S, c->red(0, PH_NONE, false), sc);       // x, r, (r,r), (r#,r), (r#,s), (r#,z)
-        spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END));     // w = A r, (r#,w) -> beta, alpha, k++
+        spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END, true, 5));     // w = A r, (r#,w) -> beta, alpha, k++
         group_now(c, 5, PH_RECUR_END);
     }
 
@@ -458,7 +475,7 @@ struct Driver {
     double drift()
     {
         spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));
-        launch_drift(v, S, c->red(0, PH_NONE), sc);
+        launch_drift(v, S, c->red(0, PH_NONE, true, 2), sc);
         group_now(c, 2, PH_NONE);
         fetch_scal(c);
         return c->hS->red[1] > 0.0 ? sqrt(c->hS->red[0] / c->hS->red[1]) : 0.0;
@@ -738,7 +755,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     const bool shifted_A = mode != SH_XI;       // lop / pipe iterate on A + sigma[seed] I, shifted_bicgstab on A
     const double t0 = now_sec();
     c->cur_has_shift = false;
-    launch_shift_init(v, p_seed, c->S, c->red(0, PH_SH_INIT), c->sc);
+    launch_shift_init(v, p_seed, c->S, c->red(0, PH_SH_INIT, true, 1), c->sc);
     group_now(c, 1, PH_SH_INIT);
     c->cur_shift = sigma[seed]; c->cur_has_shift = shifted_A;
     if (mode == SH_PIPE) {                                                   // src/shifted_solver.c:764-769, 785-786
@@ -762,13 +779,13 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
                 group_flush(c);
                 continue;
             }
-            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SH_ALPHA));          // s = (A [+ sigma I]) p[seed], (r#,s)
+            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SH_ALPHA, true, 1));          // s = (A [+ sigma I]) p[seed], (r#,s)
             group_now(c, 1, PH_SH_ALPHA);
             launch_shift_q(v, c->S, c->sc);                                 // r_old = r, q = r - alpha s
             // lop: (q,y), (q,q) ; shifted_bicgstab: (q,y), (y,y)
-            spmv(c, v.r, v.y, mode == SH_XI ? 2 : 3, v.r, c->red(0, PH_SH_OMEGA));
+            spmv(c, v.r, v.y, mode == SH_XI ? 2 : 3, v.r, c->red(0, PH_SH_OMEGA, true, 2));
             group_now(c, 2, PH_SH_OMEGA);
-            launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END), c->sc);
+            launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END, true, 2), c->sc);
             group_now(c, 2, PH_SH_END);
             launch_shift_pseed(v, p_seed, c->S, c->sc);                     // p[seed] = r + beta (p[seed] - omega s)
         }
@@ -1044,6 +1061,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // of the send list lands in the ring of the rank that needs it (collective)
     c->p2p = comm->p2p;
     if (const char *sv = getenv("BICG_P2P_FAULT_AFTER")) c->fault_after = atoi(sv);
+    if (const char *sv = getenv("BICG_P2P_INLINE_APPLY")) c->inline_apply = atoi(sv) != 0;
     if (c->p2p && !c->single()) {
         c->halo_ring = (llword *)c->p2p->alloc(sizeof(llword) * 2 * (size_t)kHaloRing * c->halo);
         std::vector<void *> rings;
@@ -1204,7 +1222,7 @@ double bicg_dot(bicg_ctx *c, const double *x, const double *y)
     reset_scal(c);
     BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemcpyAsync(c->v.s, y, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
-    launch_dot(c->v.p, c->v.s, c->n_loc, c->S, c->red(0, PH_NONE), c->sc);
+    launch_dot(c->v.p, c->v.s, c->n_loc, c->S, c->red(0, PH_NONE, true, 1), c->sc);
     group_now(c, 1, PH_NONE);
     fetch_scal(c);
     return c->hS->red[0];
