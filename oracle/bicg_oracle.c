@@ -9,6 +9,7 @@
 
 #include <stdio.h>
 #include <stdlib.h>
+#include <math.h>
 #include <string.h>
 
 /* ------------------------------------------------------------------ partition */
@@ -645,6 +646,226 @@ int orc_shifted_bicgstab(const orc_dist *d, double *x_set, double *r, const doub
     o->dot_r = dot_r; o->dot_zero = dot_zero;
     free(r_old); free(rh); free(s); free(y); free(p_set);
     free(alpha); free(beta); free(omega); free(tau); free(xi_old); free(xi_curr); free(xi_new);
+    return k;
+}
+
+/* ------------------------------------------------------------------------------------------
+ * Shifted solvers with per-shift convergence flags and SEED SWITCHING
+ * (reference src/shifted_switching_solver.c).
+ * ------------------------------------------------------------------------------------------ */
+
+/* shifted_lopbicg, reference src/shifted_switching_solver.c:20-257: the "lop" recurrence in which a
+ * shift whose residual bound |1/(zeta pi)| ||r|| has reached the tolerance is frozen (stop_flag);
+ * the loop ends when every system has converged. stop_out[nsig] (optional) receives the flags. */
+int orc_shifted_lopbicg(const orc_dist *d, double *x_set, double *r, const double *sigma, int nsig, int seed,
+                        orc_opts *o, int *stop_out)
+{
+    const int n = (int)d->n;
+    int k = 0, stop_count = 0;
+    double *r_old = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *y = vec_new(d->n);
+    double *p_set = (double *)calloc((size_t)n * (size_t)nsig + 1, sizeof(double));      /* :59 */
+    double *alpha = vec_new(nsig), *beta = vec_new(nsig), *omega = vec_new(nsig), *eta = vec_new(nsig),
+           *zeta = vec_new(nsig), *pi_new = vec_new(nsig), *pi_old = vec_new(nsig);
+    int *stop = (int *)calloc((size_t)nsig + 1, sizeof(int));                             /* :69 */
+    double alpha_old, beta_old, dot_r, dot_zero, rTr, rTs, qTq, qTy, rTr_old;
+#define P_(j) (p_set + (size_t)(j) * (size_t)n)
+#define X_(j) (x_set + (size_t)(j) * (size_t)n)
+
+    rTr = orc_dist_dot(d, r, r);                                /* :77 */
+    orc_dcopy(n, r, rh);                                        /* :79 */
+    for (int i = 0; i < nsig; ++i) {                            /* :80-88: EVERY p[sigma] starts as b */
+        orc_dcopy(n, r, P_(i));
+        alpha[i] = 1.0; beta[i] = 0.0; eta[i] = 0.0; pi_old[i] = 1.0; pi_new[i] = 1.0; zeta[i] = 1.0;
+    }
+    orc_dcopy(n, r, P_(seed));                                  /* :89 */
+    dot_r = rTr; dot_zero = rTr;                                /* :92-93 */
+
+    while (stop_count < nsig && k < o->max_iter) {              /* :100 */
+        orc_dcopy(n, r, r_old);                                 /* :102 */
+        orc_dcopy(nsig, pi_new, pi_old);                        /* :103 */
+        alpha_old = alpha[seed]; beta_old = beta[seed];         /* :104-105 */
+        spmv_shift(d, sigma[seed], P_(seed), s);                /* :107-108 */
+        rTs = orc_dist_dot(d, rh, s);                           /* :110 */
+        alpha[seed] = rTr / rTs;                                /* :113 */
+        orc_daxpy(n, -alpha[seed], s, r);                       /* :114  q */
+        spmv_shift(d, sigma[seed], r, y);                       /* :115-116 */
+        qTq = orc_dist_dot(d, r, r);                            /* :117 */
+        qTy = orc_dist_dot(d, r, y);                            /* :118 */
+        omega[seed] = qTq / qTy;                                /* :122 */
+        orc_daxpy(n, alpha[seed], P_(seed), X_(seed));          /* :123 */
+        orc_daxpy(n, omega[seed], r, X_(seed));                 /* :124 */
+        for (int j = 0; j < nsig; ++j) {                        /* :130-145 */
+            if (j == seed || stop[j]) continue;
+            eta[j] = (beta_old / alpha_old) * alpha[seed] * eta[j] - (sigma[seed] - sigma[j]) * alpha[seed] * pi_old[j];
+            pi_new[j] = eta[j] + pi_old[j];
+            alpha[j] = (pi_old[j] / pi_new[j]) * alpha[seed];
+            omega[j] = omega[seed] / (1.0 - omega[seed] * (sigma[seed] - sigma[j]));
+            orc_daxpy(n, omega[j] / (pi_new[j] * zeta[j]), r, X_(j));
+            orc_daxpy(n, alpha[j], P_(j), X_(j));
+            orc_daxpy(n, omega[j] / (alpha[j] * zeta[j] * pi_new[j]), r, P_(j));
+            orc_daxpy(n, -omega[j] / (alpha[j] * zeta[j] * pi_old[j]), r_old, P_(j));
+            zeta[j] = (1.0 - omega[seed] * (sigma[seed] - sigma[j])) * zeta[j];
+        }
+        orc_daxpy(n, -omega[seed], y, r);                       /* :152 */
+        dot_r = orc_dist_dot(d, r, r);                          /* :153 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);                           /* :155 */
+        beta[seed] = (alpha[seed] / omega[seed]) * (rTr / rTr_old);     /* :159 */
+        orc_dscal(n, beta[seed], P_(seed));                     /* :160 */
+        orc_daxpy(n, 1.0, r, P_(seed));                         /* :161 */
+        orc_daxpy(n, -beta[seed] * omega[seed], s, P_(seed));   /* :162 */
+        for (int j = 0; j < nsig; ++j) {                        /* :164-170 */
+            if (j == seed || stop[j]) continue;
+            beta[j] = (pi_old[j] / pi_new[j]) * (pi_old[j] / pi_new[j]) * beta[seed];
+            orc_dscal(n, beta[j], P_(j));
+            orc_daxpy(n, 1.0 / (pi_new[j] * zeta[j]), r, P_(j));
+        }
+        for (int j = 0; j < nsig; ++j) {                        /* :180-199 */
+            if (stop[j]) continue;
+            const double a = j == seed ? 1.0 : fabs(1.0 / (zeta[j] * pi_new[j]));
+            if (a * a * dot_r <= o->tol * o->tol * dot_zero) { stop[j] = 1; stop_count++; }
+        }
+        k++;                                                    /* :210 */
+        trace_put(o, k, alpha[seed], omega[seed], beta[seed], dot_r);
+    }
+    if (stop_out) memcpy(stop_out, stop, sizeof(int) * (size_t)nsig);
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(r_old); free(rh); free(s); free(y); free(p_set); free(stop);
+    free(alpha); free(beta); free(omega); free(eta); free(zeta); free(pi_new); free(pi_old);
+    return k;
+}
+
+/* shifted_lopbicg_switching (reference src/shifted_switching_solver.c:260-608) and its _noovlp twin
+ * (:611-1016, same arithmetic, only the MPI_Wait placement and the section timers differ).
+ * The seed system's alpha/beta/omega and every shift's pi are ARCHIVED per iteration; when the
+ * seed converges first, the unconverged shift with the largest |1/(zeta pi)| becomes the new seed:
+ * r is rescaled to its residual, the archives are rewritten for it and eta/pi/zeta of the
+ * remaining shifts are re-derived from the rewritten history (:490-527).
+ * k starts at 1 and the loop runs while k < max_iter + 1; the return value is k (iterations + 1).
+ * Kept as written: (r#,r) is NOT rescaled together with r at a switch (:499, rTr keeps its value),
+ * and `max_sigma` is read uninitialised when no unconverged shift has |1/(zeta pi)| > 1 (:462-467)
+ * -- defined as 0 here, which is what the pinned reference build (zero-initialised locals) does.
+ * final_seed / nswitch / stop_out are optional outputs for the tests. */
+int orc_shifted_lopbicg_switching(const orc_dist *d, double *x_set, double *r, const double *sigma, int nsig, int seed,
+                                  orc_opts *o, int *final_seed, int *nswitch, int *stop_out)
+{
+    const int n = (int)d->n;
+    const int max_iter = o->max_iter + 1;                        /* :297 */
+    int k = 1, stop_count = 0, max_sigma = 0, switches = 0;      /* :295 */
+    double *r_old = vec_new(d->n), *rh = vec_new(d->n), *s = vec_new(d->n), *y = vec_new(d->n), *qc = vec_new(d->n);
+    double *p_set = (double *)calloc((size_t)n * (size_t)nsig + 1, sizeof(double));
+    double *alpha = vec_new(nsig), *beta = vec_new(nsig), *omega = vec_new(nsig), *eta = vec_new(nsig), *zeta = vec_new(nsig);
+    double *a_arc = vec_new(max_iter + 1), *b_arc = vec_new(max_iter + 1), *w_arc = vec_new(max_iter + 1);
+    double *pi = (double *)calloc((size_t)max_iter * (size_t)nsig + 1, sizeof(double));
+    int *stop = (int *)calloc((size_t)nsig + 1, sizeof(int));
+    double dot_r, dot_zero, rTr, rTs, qTq, qTy, rTr_old, max_zeta_pi;
+#define PI_(j, i) pi[(size_t)(j) * (size_t)max_iter + (size_t)(i)]
+
+    rTr = orc_dist_dot(d, r, r);                                /* :344 */
+    orc_dcopy(n, r, rh);                                        /* :346 */
+    for (int i = 0; i < nsig; ++i) {                            /* :347-355 */
+        orc_dcopy(n, r, P_(i));
+        alpha[i] = 1.0; beta[i] = 0.0; eta[i] = 0.0; PI_(i, 0) = 1.0; PI_(i, 1) = 1.0; zeta[i] = 1.0;
+    }
+    orc_dcopy(n, r, P_(seed));                                  /* :356 */
+    dot_r = rTr; dot_zero = rTr;                                /* :359-360 */
+    a_arc[0] = 1.0; b_arc[0] = 0.0;                             /* :363-364 */
+
+    while (stop_count < nsig && k < max_iter) {                 /* :374 */
+        orc_dcopy(n, r, r_old);                                 /* :376 */
+        spmv_shift(d, sigma[seed], P_(seed), s);                /* :379-388 (spelled-out MPI_csr_spmv_ovlap) */
+        rTs = orc_dist_dot(d, rh, s);                           /* :389 */
+        a_arc[k] = rTr / rTs;                                   /* :392 */
+        orc_daxpy(n, -a_arc[k], s, r);                          /* :393  q */
+        orc_dcopy(n, r, qc);                                    /* :394  q_copy */
+        spmv_shift(d, sigma[seed], r, y);                       /* :397-406 */
+        qTq = orc_dist_dot(d, r, r);                            /* :407 */
+        qTy = orc_dist_dot(d, r, y);                            /* :408 */
+        w_arc[k] = qTq / qTy;                                   /* :412 */
+        orc_daxpy(n, a_arc[k], P_(seed), X_(seed));             /* :413 */
+        orc_daxpy(n, w_arc[k], r, X_(seed));                    /* :414 */
+        orc_daxpy(n, -w_arc[k], y, r);                          /* :415 */
+        dot_r = orc_dist_dot(d, r, r);                          /* :416 */
+        rTr_old = rTr;
+        rTr = orc_dist_dot(d, rh, r);                           /* :418 */
+        b_arc[k] = (a_arc[k] / w_arc[k]) * (rTr / rTr_old);     /* :422 */
+        orc_dscal(n, b_arc[k], P_(seed));                       /* :423 */
+        orc_daxpy(n, 1.0, r, P_(seed));                         /* :424 */
+        orc_daxpy(n, -b_arc[k] * w_arc[k], s, P_(seed));        /* :425 */
+
+        for (int j = 0; j < nsig; ++j) {                        /* :431-446 */
+            if (j == seed || stop[j]) continue;
+            eta[j] = (b_arc[k - 1] / a_arc[k - 1]) * a_arc[k] * eta[j] - (sigma[seed] - sigma[j]) * a_arc[k] * PI_(j, k - 1);
+            PI_(j, k) = eta[j] + PI_(j, k - 1);
+            alpha[j] = (PI_(j, k - 1) / PI_(j, k)) * a_arc[k];
+            omega[j] = w_arc[k] / (1.0 - w_arc[k] * (sigma[seed] - sigma[j]));
+            orc_daxpy(n, omega[j] / (PI_(j, k) * zeta[j]), qc, X_(j));
+            orc_daxpy(n, alpha[j], P_(j), X_(j));
+            orc_daxpy(n, omega[j] / (alpha[j] * zeta[j] * PI_(j, k)), qc, P_(j));
+            orc_daxpy(n, -omega[j] / (alpha[j] * zeta[j] * PI_(j, k - 1)), r_old, P_(j));
+            zeta[j] = (1.0 - w_arc[k] * (sigma[seed] - sigma[j])) * zeta[j];
+            beta[j] = (PI_(j, k - 1) / PI_(j, k)) * (PI_(j, k - 1) / PI_(j, k)) * b_arc[k];
+            orc_dscal(n, beta[j], P_(j));
+            orc_daxpy(n, 1.0 / (PI_(j, k) * zeta[j]), r, P_(j));
+        }
+
+        max_zeta_pi = 1.0;                                      /* :451-475 */
+        for (int j = 0; j < nsig; ++j) {
+            if (stop[j]) continue;
+            const double a = j == seed ? 1.0 : fabs(1.0 / (zeta[j] * PI_(j, k)));
+            if (a * a * dot_r <= o->tol * o->tol * dot_zero) {
+                stop[j] = 1; stop_count++;
+            } else if (a > max_zeta_pi) {
+                max_zeta_pi = a; max_sigma = j;
+            }
+        }
+
+        if (stop[seed] && stop_count < nsig) {                  /* :490-527 seed switching */
+            const int ms = max_sigma;
+            for (int i = 1; i <= k; ++i) {
+                a_arc[i] = (PI_(ms, i - 1) / PI_(ms, i)) * a_arc[i];
+                b_arc[i] = (PI_(ms, i - 1) / PI_(ms, i)) * (PI_(ms, i - 1) / PI_(ms, i)) * b_arc[i];
+                w_arc[i] = w_arc[i] / (1.0 - w_arc[i] * (sigma[seed] - sigma[ms]));
+            }
+            orc_dscal(n, 1.0 / (zeta[ms] * PI_(ms, k)), r);     /* :499 */
+            for (int j = 0; j < nsig; ++j) { eta[j] = 0.0; zeta[j] = 1.0; }
+            for (int i = 1; i <= k; ++i)
+                for (int j = 0; j < nsig; ++j) {
+                    if (stop[j] || j == ms) continue;
+                    eta[j] = (b_arc[i - 1] / a_arc[i - 1]) * a_arc[i] * eta[j] - (sigma[ms] - sigma[j]) * a_arc[i] * PI_(j, i - 1);
+                    PI_(j, i) = eta[j] + PI_(j, i - 1);
+                    zeta[j] = (1.0 - w_arc[i] * (sigma[ms] - sigma[j])) * zeta[j];
+                }
+            seed = ms;
+            switches++;
+        }
+        trace_put(o, k, a_arc[k], w_arc[k], b_arc[k], dot_r);
+        k++;                                                    /* :536 */
+    }
+#undef PI_
+#undef P_
+#undef X_
+    if (final_seed) *final_seed = seed;
+    if (nswitch) *nswitch = switches;
+    if (stop_out) memcpy(stop_out, stop, sizeof(int) * (size_t)nsig);
+    o->dot_r = dot_r; o->dot_zero = dot_zero;
+    free(r_old); free(rh); free(s); free(y); free(qc); free(p_set); free(stop); free(pi);
+    free(alpha); free(beta); free(omega); free(eta); free(zeta); free(a_arc); free(b_arc); free(w_arc);
+    return k;
+}
+
+/* which: 0 = shifted_lopbicg, 1 = shifted_lopbicg_switching (and _noovlp). info[0] = final seed,
+ * info[1] = number of seed switches, info[2 .. 2+nsig) = stop flags. */
+int orc_switching_coo(int which, int P, unsigned n, unsigned nnz, const unsigned *row, const unsigned *col,
+                      const double *val, double *x_set, double *r, const double *sigma, int nsig, int seed, orc_opts *o,
+                      int *info)
+{
+    orc_dist *d = orc_dist_from_coo(n, nnz, row, col, val, P);
+    int k;
+    info[0] = seed; info[1] = 0;
+    if (which == 0) k = orc_shifted_lopbicg(d, x_set, r, sigma, nsig, seed, o, info + 2);
+    else k = orc_shifted_lopbicg_switching(d, x_set, r, sigma, nsig, seed, o, &info[0], &info[1], info + 2);
+    orc_dist_free(d);
     return k;
 }
 

@@ -133,3 +133,26 @@ def solve_shifted(n, row, col, val, b, sigma, seed, nranks=1, tol=1e-12, max_ite
                               len(sigma), seed, C.byref(o))
     return dict(k=k, x=x.reshape(len(sigma), n), r=r, dot_r=o.dot_r, dot_zero=o.dot_zero, alpha=tr[0][:k],
                 omega=tr[1][:k], beta=tr[2][:k], dotr=tr[3][:k])
+
+
+def solve_switching(n, row, col, val, b, sigma, seed, nranks=1, tol=1e-12, max_iter=1000, which="shifted_lopbicg_switching"):
+    """Oracle restatement of reference src/shifted_switching_solver.c: shifted_lopbicg (per-shift stop
+    flags) or shifted_lopbicg_switching / _noovlp (seed switching). k as the reference returns it."""
+    row, col, val = _coo(row, col, val)
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    nsig = len(sigma)
+    x = np.zeros(nsig * n)
+    r = np.array(b, dtype=np.float64)
+    tr = [np.zeros(max(max_iter, 1)) for _ in range(4)]
+    o = OrcOpts(tol, max_iter, 0, 0, _d(tr[0]), _d(tr[1]), _d(tr[2]), _d(tr[3]), 0.0, 0.0)
+    info = np.zeros(2 + nsig, dtype=np.int32)
+    fn = lib().orc_switching_coo
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_int, C.c_int, C.c_uint, C.c_uint, _up, _up, _dp, _dp, _dp, _dp, C.c_int, C.c_int,
+                   C.POINTER(OrcOpts), C.POINTER(C.c_int)]
+    k = fn(0 if which == "shifted_lopbicg" else 1, nranks, n, len(val), _u(row), _u(col), _d(val), _d(x), _d(r), _d(sigma),
+           nsig, seed, C.byref(o), info.ctypes.data_as(C.POINTER(C.c_int)))
+    its = k if which == "shifted_lopbicg" else k - 1
+    return dict(k=k, x=x.reshape(nsig, n), r=r, dot_r=o.dot_r, dot_zero=o.dot_zero, final_seed=int(info[0]),
+                switches=int(info[1]), stop=info[2:].astype(bool), alpha=tr[0][:its], omega=tr[1][:its], beta=tr[2][:its],
+                dotr=tr[3][:its])

@@ -81,6 +81,32 @@ def solve_shifted(fname, M: RefMatrix, b, sigma, seed):
     return dict(k=k, x=x.reshape(len(sigma), M.n), r=r)
 
 
+LIBREF_SWITCHING = os.path.join(REF_DIR, "libref_switching.so")
+_switching = None
+
+
+def switching_lib():
+    """reference src/shifted_switching_solver.c (EPS 1e-12, MAX_ITER 1000 compiled in, :5-6)"""
+    global _switching
+    if _switching is None:
+        lib()                                    # MPI singleton init
+        _switching = C.CDLL(LIBREF_SWITCHING)
+    return _switching
+
+
+def solve_switching(fname, M: "RefMatrix", b, sigma, seed):
+    """shifted_lopbicg / shifted_lopbicg_switching / shifted_lopbicg_switching_noovlp; returns k as the
+    reference does (the switching variants count from 1)."""
+    sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+    x = np.zeros(len(sigma) * M.n)
+    r = np.array(b, dtype=np.float64)
+    fn = getattr(switching_lib(), fname)
+    fn.restype = C.c_int
+    k = fn(C.byref(M.diag), C.byref(M.offd), C.byref(M.info), x.ctypes.data_as(_dp), r.ctypes.data_as(_dp),
+           sigma.ctypes.data_as(_dp), C.c_int(len(sigma)), C.c_int(seed))
+    return dict(k=k, x=x.reshape(len(sigma), M.n), r=r)
+
+
 class RefMatrix:
     """Single-rank blocks: diag = whole matrix, offd empty (what the loader yields at P = 1)."""
 
