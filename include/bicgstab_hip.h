@@ -95,6 +95,18 @@ int shifted_lopbicgstab_v2(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_
 int shifted_lopbicgstab_nooverlap(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
 int shifted_pipe_lopbicgstab(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
 int shifted_pipe_lopbicgstab_nooverlap(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
+/* Shifted solvers with per-shift convergence flags and SEED SWITCHING, reference
+ * src/shifted_switching_solver.h:10-12:
+ *   shifted_lopbicg                   <- :10 (src/shifted_switching_solver.c:20-257)   a shift whose residual bound
+ *                                        |1/(zeta pi)| ||r|| has reached EPS is frozen; ends when all have converged
+ *   shifted_lopbicg_switching         <- :11 (:260-608)   as above; when the seed converges first, the slowest
+ *                                        remaining shift becomes the seed (history of alpha/beta/omega/pi re-derived)
+ *   shifted_lopbicg_switching_noovlp  <- :12 (:611-1016)  same arithmetic, different MPI_Wait placement
+ * Same arguments as shifted_lopbicgstab. r_loc returns the (rescaled) residual of the final seed. Return value as
+ * in the reference: iterations for shifted_lopbicg, iterations + 1 for the switching variants (k starts at 1). */
+int shifted_lopbicg(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
+int shifted_lopbicg_switching(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
+int shifted_lopbicg_switching_noovlp(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_offd, INFO_Matrix *A_info, double *x_loc_set, double *r_loc, double *sigma, int sigma_len, int seed);
 
 /* ---------------------------------------------------------------------------------------------
  * 2. Communicator bootstrap (process-global; one process per GPU).
@@ -198,10 +210,12 @@ int bicg_run_begin(bicg_ctx *ctx, int method, const bicg_options *opt);
 int bicg_run_iterate(bicg_ctx *ctx, int nsteps);
 int bicg_run_end(bicg_ctx *ctx, bicg_result *res);
 int bicg_sync(bicg_ctx *ctx);
-/* shifted solve on a resident matrix; variant = BICG_SHIFTED_LOP / _PIPE / _XI (semantics of the
- * drop-in functions above; opt NULL = reference defaults with EPS 1e-12); the trace holds the SEED
- * system's alpha, omega, beta, (r,r) */
-enum { BICG_SHIFTED_LOP = 0, BICG_SHIFTED_PIPE = 1, BICG_SHIFTED_XI = 2 };
+/* shifted solve on a resident matrix; variant = BICG_SHIFTED_LOP / _PIPE / _XI / _FLAG / _SWITCH (semantics
+ * of the drop-in functions above; opt NULL = reference defaults with EPS 1e-12); the trace holds the SEED
+ * system's alpha, omega, beta, (r,r). _FLAG / _SWITCH (shifted_lopbicg / shifted_lopbicg_switching): the
+ * return value follows the reference (the switching variants count from 1), bicg_result.iterations is the
+ * number of iterations and bicg_result.adaptive_replacements the number of seed switches. */
+enum { BICG_SHIFTED_LOP = 0, BICG_SHIFTED_PIPE = 1, BICG_SHIFTED_XI = 2, BICG_SHIFTED_FLAG = 3, BICG_SHIFTED_SWITCH = 4 };
 int bicg_solve_shifted(bicg_ctx *ctx, int variant, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len,
                        int seed, const bicg_options *opt, bicg_result *res);
 /* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */

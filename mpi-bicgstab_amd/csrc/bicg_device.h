@@ -44,12 +44,22 @@ enum Phase : int {
     PH_SHP_INIT_ALPHA, // red[0]=(r,w): alpha[seed] = rTr/(r,w), alpha_old = 1                   (:785-786)
     PH_SHP_OMEGA,      // red[0]=(q,y), red[1]=(y,y): omega[seed] and ALL per-shift scalars      (:803-839)
     PH_SHP_END,        // red[0..4]=(r,r),(r#,r),(r#,w),(r#,s),(r#,z): beta, alpha, max, k++     (:856-866)
+    // shifted solvers with per-shift stop flags and seed switching
+    // (reference src/shifted_switching_solver.c:20-257 and :260-608)
+    PH_SW_INIT,     // red[0]=(r,r): rTr = dot_r = dot_zero, archives and per-shift state reset       (:344-364)
+    PH_SW_ALPHA,    // red[0]=(r#,s): alpha archive[k]                                               (:389-392)
+    PH_SW_OMEGA,    // red[0]=(q,y), red[1]=(q,q): omega archive[k]                                  (:407-412)
+    PH_SW_END,      // red[0]=(r,r), red[1]=(r#,r): beta archive[k]; eta, pi, alpha_j, omega_j, the
+                    // update coefficients, zeta, beta_j of every active shift                       (:416-446)
+    PH_SW_STOP,     // no sums: stop flags, largest |1/(zeta pi)|, k++, seed switching (pauses)      (:451-536)
 };
 
 enum ShiftMode : int {
     SH_LOP = 0,      // shifted_lopbicgstab (+_v2, _nooverlap)       src/shifted_solver.c:182-701
     SH_PIPE = 1,     // shifted_pipe_lopbicgstab (+_nooverlap)       src/shifted_solver.c:703-1086
     SH_XI = 2,       // shifted_bicgstab, seed 0, xi/tau recurrences src/shifted_solver.c:13-180
+    SH_FLAG = 3,     // shifted_lopbicg: per-shift stop flags        src/shifted_switching_solver.c:20-257
+    SH_SWITCH = 4,   // shifted_lopbicg_switching (+_noovlp)          src/shifted_switching_solver.c:260-1016
 };
 
 // Per-shift scalar state of the shifted solver, device resident (arrays of nsig doubles).
@@ -63,6 +73,14 @@ struct ShiftDev {
     double *cx;   // omega_j / (pi_new zeta)        x_j += cx_j q                        (:296)
     double *c1;   // omega_j / (alpha_j zeta pi_new)        p_j += c1_j q                (:298)
     double *c2;   // -omega_j / (alpha_j zeta pi_old)       p_j += c2_j r_old            (:299)
+    // SH_FLAG / SH_SWITCH (src/shifted_switching_solver.c): history of the seed's alpha/beta/omega
+    // and of every shift's pi (index 0 = initial values, iteration k at index k), stop flags
+    double *a_arc, *b_arc, *w_arc;   // [arc_len]
+    double *pi_arc;                  // [nsig][arc_len]
+    int    *stop;                    // [nsig] converged shifts (frozen)
+    int    *skip;                    // [nsig] shifts the batched update of THIS iteration leaves alone
+    int     arc_len, stop_count, max_sigma, switches;
+    double  r_scale;                 // seed switch: r <- r_scale * r, applied by the host while paused  (:499)
 };
 
 // Device-resident scalar state of one solve. Kernels read alpha/beta/omega/done from here, so the
@@ -80,6 +98,7 @@ struct Scal {
     double *tr_alpha, *tr_omega, *tr_beta, *tr_dotr;   // optional trace, [max_iter]
     ShiftDev *sh;                // shifted solver only
     int    comm_error;           // peer-to-peer transport: a wait for a peer timed out (sets done as well)
+    int    paused;               // seed switching: done was raised only to hand control to the host (new seed pointers)
 };
 
 // Direct peer-to-peer transport (bicg_p2p.cpp). Values travel as "LL" words -- 8 bytes holding 32
@@ -242,6 +261,14 @@ void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t st);
 void launch_shift_pipe1(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t st);
 void launch_shift_pipe2(const Vecs &v, double *p_set, double *x_set, uint32_t set_stride, int seed, const ShiftDev *H,
                         Scal *S, Reduce red, hipStream_t st);
+// seed-switching shifted solvers (reference src/shifted_switching_solver.c)
+void launch_sw_q(const Vecs &v, double *qcopy, Scal *S, hipStream_t st);                  // r_old = r ; q = r - alpha s -> r, q_copy
+// x[seed] += alpha p[seed] + omega q ; r = q - omega y ; (r,r), (r#,r)
+void launch_sw_seed(const Vecs &v, double *x_seed, const double *p_seed, Scal *S, Reduce red, hipStream_t st);
+// p[seed] = beta p[seed] + r - beta omega s, and for every active shift the x_j / p_j updates of the iteration
+void launch_sw_shifts(const Vecs &v, const double *qcopy, double *p_set, double *x_set, uint32_t set_stride, int seed,
+                      const ShiftDev *H, Scal *S, hipStream_t st);
+void launch_scale(double *x, uint32_t n, double a, hipStream_t st);                        // x <- a x (my_dscal)
 // adaptive residual replacement: red[0] = ||(b - Ax) - r||^2, red[1] = ||r||^2
 void launch_drift(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
 // standalone dot (x,y) -> red[0]

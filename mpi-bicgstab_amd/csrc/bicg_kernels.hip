@@ -256,10 +256,166 @@ __device__ void apply_phase_shifted(Scal *S, int phase)
     }
 }
 
+
+// ---- shifted solvers with stop flags and seed switching (reference src/shifted_switching_solver.c).
+// One implementation serves shifted_lopbicg (:20-257, SH_FLAG) and shifted_lopbicg_switching
+// (:260-608, SH_SWITCH; _noovlp :611-1016 is an arithmetic twin): the per-shift recurrences are the
+// same expressions, written in the archive form of the switching variant -- alpha/beta/omega of
+// the seed and pi of every shift are kept per iteration, index kk = completed iterations + 1 (the
+// reference's k of the switching variant), index 0 = the initial values.
+__device__ void apply_phase_switching(Scal *S, int phase)
+{
+    ShiftDev *H = S->sh;
+    const double *d = S->red;
+    const int nsig = H->nsig, L = H->arc_len;
+    const int kk = S->k + 1;
+    const int tid = threadIdx.x;
+#define PI_(j, i) H->pi_arc[(size_t)(j) * (size_t)L + (size_t)(i)]
+    if (phase == PH_SW_INIT) {
+        if (tid == 0) {
+            S->rTr = d[0]; S->dot_r = d[0]; S->dot_zero = d[0];                      // (:344, 359-360)
+            S->alpha = 1.0; S->beta = 0.0; S->omega = 0.0; S->rTr_old = 0.0; S->paused = 0;
+            H->a_arc[0] = 1.0; H->b_arc[0] = 0.0;                                    // (:363-364)
+            H->stop_count = 0; H->max_sigma = 0; H->switches = 0; H->r_scale = 1.0;
+            if (!(0 < nsig && 0 < S->max_iter)) S->done = 1;
+        }
+        for (int j = tid; j < nsig; j += kBlock) {                                   // (:347-355)
+            H->alpha[j] = 1.0; H->beta[j] = 0.0; H->eta[j] = 0.0; H->zeta[j] = 1.0; H->omega[j] = 0.0;
+            PI_(j, 0) = 1.0; PI_(j, 1) = 1.0;
+            H->cp[j] = 0.0; H->cx[j] = 0.0; H->c1[j] = 0.0; H->c2[j] = 0.0;
+            H->stop[j] = 0; H->skip[j] = 0;
+        }
+        return;
+    }
+    if (phase == PH_SW_ALPHA) {
+        if (tid == 0) { S->alpha = S->rTr / d[0]; H->a_arc[kk] = S->alpha; }        // (:392)
+        return;
+    }
+    if (phase == PH_SW_OMEGA) {
+        if (tid == 0) { S->omega = d[1] / d[0]; H->w_arc[kk] = S->omega; }          // (q,q)/(q,y)  (:412)
+        return;
+    }
+    if (phase == PH_SW_END) {
+        if (tid == 0) {
+            S->dot_r = d[0];                                                         // (:416)
+            S->rTr_old = S->rTr;
+            S->rTr = d[1];                                                           // (:418)
+            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);                 // (:422)
+            H->b_arc[kk] = S->beta;
+        }
+        __syncthreads();
+        const int seed = H->seed;
+        const double a = H->a_arc[kk], w = H->w_arc[kk], b = H->b_arc[kk];
+        const double ratio = H->b_arc[kk - 1] / H->a_arc[kk - 1];
+        const double sgs = H->sigma[seed];
+        for (int j = tid; j < nsig; j += kBlock) {                                   // (:431-446)
+            if (j == seed || H->stop[j]) { H->skip[j] = 1; continue; }
+            const double dsg = sgs - H->sigma[j];
+            const double po = PI_(j, kk - 1);
+            const double e = ratio * a * H->eta[j] - dsg * a * po;                   // (:433)
+            H->eta[j] = e;
+            const double pn = e + po;                                                // (:435)
+            PI_(j, kk) = pn;
+            const double aj = (po / pn) * a;                                         // (:436)
+            H->alpha[j] = aj;
+            const double wj = w / (1.0 - w * dsg);                                   // (:437)
+            H->omega[j] = wj;
+            const double z = H->zeta[j];
+            H->cx[j] = wj / (pn * z);                                                // (:438)
+            H->c1[j] = wj / (aj * z * pn);                                           // (:440)
+            H->c2[j] = -wj / (aj * z * po);                                          // (:441)
+            const double zn = (1.0 - w * dsg) * z;                                   // (:442)
+            H->zeta[j] = zn;
+            H->beta[j] = (po / pn) * (po / pn) * b;                                  // (:443)
+            H->cp[j] = 1.0 / (pn * zn);                                              // (:445)
+            H->skip[j] = 0;
+        }
+        return;
+    }
+    if (phase != PH_SW_STOP) return;
+
+    // ---- stop flags, largest |1/(zeta pi)| among the shifts still running                    (:451-475)
+    __shared__ double s_val[kBlock];
+    __shared__ int s_idx[kBlock], s_cnt[kBlock];
+    __shared__ int s_switch;
+    const int seed = H->seed;
+    double best = 1.0;              // max_zeta_pi starts at 1.0: only larger values move max_sigma
+    int best_j = 0x7fffffff, newly = 0;
+    for (int j = tid; j < nsig; j += kBlock) {
+        if (H->stop[j]) continue;
+        const double av = j == seed ? 1.0 : fabs(1.0 / (H->zeta[j] * PI_(j, kk)));
+        if (av * av * S->dot_r <= S->tol2 * S->dot_zero) { H->stop[j] = 1; ++newly; }
+        else if (av > best) { best = av; best_j = j; }
+    }
+    s_val[tid] = best; s_idx[tid] = best_j; s_cnt[tid] = newly;
+    __syncthreads();
+    for (int wdt = kBlock / 2; wdt > 0; wdt >>= 1) {
+        if (tid < wdt) {
+            s_cnt[tid] += s_cnt[tid + wdt];
+            const double ov = s_val[tid + wdt];
+            const int oj = s_idx[tid + wdt];
+            if (ov > s_val[tid] || (ov == s_val[tid] && oj < s_idx[tid])) { s_val[tid] = ov; s_idx[tid] = oj; }   // first j wins ties
+        }
+        __syncthreads();
+    }
+    if (tid == 0) {
+        H->stop_count += s_cnt[0];
+        if (s_val[0] > 1.0) H->max_sigma = s_idx[0];     // otherwise it keeps its previous value, as in the reference
+        S->k += 1;                                       // (:536)
+        const int k = S->k;
+        if (S->tr_dotr && k <= S->max_iter) {
+            S->tr_alpha[k - 1] = S->alpha; S->tr_omega[k - 1] = S->omega; S->tr_beta[k - 1] = S->beta; S->tr_dotr[k - 1] = S->dot_r;
+        }
+        const bool more = H->stop_count < nsig && k < S->max_iter;                   // (:374 / :100)
+        if (!more) S->done = 1;
+        if (!(isfinite(S->alpha) && isfinite(S->beta) && isfinite(S->omega) && isfinite(S->dot_r)) && !S->breakdown_k)
+            S->breakdown_k = k;
+        s_switch = (H->mode == SH_SWITCH && H->stop[seed] && H->stop_count < nsig) ? 1 : 0;   // (:490)
+        if (s_switch) {
+            // the host has to rescale r and re-point the seed vectors: stop the device here
+            S->done = 1;
+            S->paused = more ? 1 : 2;
+            const int ms = H->max_sigma;
+            H->r_scale = 1.0 / (H->zeta[ms] * PI_(ms, kk));                          // (:499)
+        }
+    }
+    __syncthreads();
+    if (!s_switch) return;
+
+    // ---- seed switching: rewrite the history for the new seed ms                             (:494-521)
+    const int ms = H->max_sigma;
+    const double dss = H->sigma[seed] - H->sigma[ms];
+    for (int i = 1 + tid; i <= kk; i += kBlock) {                                    // (:494-498) entries are independent
+        const double qn = PI_(ms, i - 1) / PI_(ms, i);
+        H->a_arc[i] = qn * H->a_arc[i];
+        H->b_arc[i] = qn * qn * H->b_arc[i];
+        H->w_arc[i] = H->w_arc[i] / (1.0 - H->w_arc[i] * dss);
+    }
+    for (int j = tid; j < nsig; j += kBlock) { H->eta[j] = 0.0; H->zeta[j] = 1.0; }  // (:501-505)
+    __syncthreads();
+    const double sgm = H->sigma[ms];
+    for (int j = tid; j < nsig; j += kBlock) {                                       // (:509-518) one shift per thread
+        if (H->stop[j] || j == ms) continue;
+        double e = 0.0, z = 1.0;
+        const double dsg = sgm - H->sigma[j];
+        for (int i = 1; i <= kk; ++i) {
+            const double ai = H->a_arc[i];
+            e = (H->b_arc[i - 1] / H->a_arc[i - 1]) * ai * e - dsg * ai * PI_(j, i - 1);
+            PI_(j, i) = e + PI_(j, i - 1);
+            z = (1.0 - H->w_arc[i] * dsg) * z;
+        }
+        H->eta[j] = e; H->zeta[j] = z;
+    }
+    __syncthreads();
+    if (tid == 0) { H->seed = ms; H->switches += 1; }                                // (:525)
+#undef PI_
+}
+
 // whole-workgroup entry: scalar phases run on thread 0, shifted phases on all threads
 __device__ __forceinline__ void apply_phase_block(Scal *S, int phase)
 {
-    if (phase >= PH_SH_INIT) apply_phase_shifted(S, phase);
+    if (phase >= PH_SW_INIT) apply_phase_switching(S, phase);
+    else if (phase >= PH_SH_INIT) apply_phase_shifted(S, phase);
     else if (threadIdx.x == 0) apply_phase(S, phase);
 }
 
@@ -1339,6 +1495,100 @@ void launch_shift_update(const Vecs &v, double *p_set, double *x_set, uint32_t s
         run_vec(f, v.n, S, red, s);
     };
     if (stream_sets()) go(FShiftUpdate<true>{}); else go(FShiftUpdate<false>{});
+}
+
+// ---- seed-switching shifted solvers (reference src/shifted_switching_solver.c:376-446) -----------
+struct FSwQ {         // r_old = r ; q = r - alpha s -> r and q_copy                       (:376, 393-394)
+    static constexpr int ND = 0;
+    double *r, *rold, *qc; const double *s; double alpha;
+    __device__ void load(const Scal *S) { alpha = S->alpha; }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        T r0 = ld<T>(r, i);
+        st(rold, i, r0);
+        T q = r0 + (-alpha) * ld<T>(s, i);
+        st(r, i, q); st(qc, i, q);
+    }
+};
+void launch_sw_q(const Vecs &v, double *qcopy, Scal *S, hipStream_t s) { run_vec(FSwQ{v.r, v.ax, qcopy, v.s, 0.0}, v.n, S, Reduce{}, s); }
+
+struct FSwSeed {      // x[seed] += alpha p[seed] ; += omega q ; r = q - omega y ; (r,r), (r#,r)   (:413-418)
+    static constexpr int ND = 2;
+    double *xs, *r; const double *ps, *y, *rh; double alpha, omega;
+    __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    {
+        const T q = ld<T>(r, i);
+        T xx = ld<T>(xs, i) + alpha * ld<T>(ps, i);
+        st(xs, i, xx + omega * q);
+        const T rr = q + (-omega) * ld<T>(y, i);
+        st(r, i, rr);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(ld<T>(rh, i) * rr);
+    }
+};
+void launch_sw_seed(const Vecs &v, double *x_seed, const double *p_seed, Scal *S, Reduce red, hipStream_t s)
+{
+    run_vec(FSwSeed{x_seed, v.r, p_seed, v.y, v.rh, 0.0, 0.0}, v.n, S, red, s);
+}
+
+// p[seed] = beta p[seed] + r - beta omega s (:423-425) and, for every shift that is neither the seed
+// nor frozen, the six updates of :438-446 in the reference's order; each p_j and x_j is read and
+// written once.
+template <bool SNT> struct FSwShifts {
+    static constexpr int ND = 0;
+    double *ps, *pset, *xset; const double *r, *s, *qc, *rold; const ShiftDev *H; uint32_t stride;
+    double beta, omega; int nsig;
+    const int *skip; const double *beta_j, *alpha_j, *cp, *cx, *c1, *c2;
+    __device__ void load(const Scal *S)
+    {
+        beta = S->beta; omega = S->omega; nsig = H->nsig;
+        skip = H->skip; beta_j = H->beta; alpha_j = H->alpha; cp = H->cp; cx = H->cx; c1 = H->c1; c2 = H->c2;
+    }
+    template <class T> __device__ void apply(uint32_t i, double *) const
+    {
+        const T rr = ld<T>(r, i), q = ld<T>(qc, i), ro = ld<T>(rold, i);
+        T p = beta * ld<T>(ps, i);                               // my_dscal(beta)            (:423)
+        p = p + 1.0 * rr;                                        // += 1.0 r                  (:424)
+        p = p + (-beta * omega) * ld<T>(s, i);                   // += (-beta omega) s        (:425)
+        st(ps, i, p);
+        for (int j = 0; j < nsig; ++j) {
+            if (skip[j]) continue;
+            double *pj = pset + (size_t)j * stride, *xj = xset + (size_t)j * stride;
+            T pp = SNT ? ldnt<T>(pj, i) : ld<T>(pj, i);
+            T x = (SNT ? ldnt<T>(xj, i) : ld<T>(xj, i)) + cx[j] * q;     // (:438)
+            x = x + alpha_j[j] * pp;                                 // (:439)
+            if (SNT) stnt(xj, i, x); else st(xj, i, x);
+            pp = pp + c1[j] * q;                                     // (:440)
+            pp = pp + c2[j] * ro;                                    // (:441)
+            pp = beta_j[j] * pp;                                     // my_dscal(beta_j)      (:444)
+            pp = pp + cp[j] * rr;                                    // (:445)
+            if (SNT) stnt(pj, i, pp); else st(pj, i, pp);
+        }
+    }
+};
+void launch_sw_shifts(const Vecs &v, const double *qcopy, double *p_set, double *x_set, uint32_t set_stride, int seed,
+                      const ShiftDev *H, Scal *S, hipStream_t s)
+{
+    auto go = [&](auto f) {
+        f.ps = p_set + (size_t)seed * set_stride; f.pset = p_set; f.xset = x_set; f.r = v.r; f.s = v.s; f.qc = qcopy;
+        f.rold = v.ax; f.H = H; f.stride = set_stride;
+        run_vec(f, v.n, S, Reduce{}, s);
+    };
+    if (stream_sets()) go(FSwShifts<true>{}); else go(FSwShifts<false>{});
+}
+
+// x <- a x (my_dscal, src/vector.c:17-21); runs while the device is paused at a seed switch
+__global__ void __launch_bounds__(kBlock) k_scale(double *x, uint32_t n, double a)
+{
+    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < n; i += gridDim.x * kBlock) x[i] = a * x[i];
+}
+void launch_scale(double *x, uint32_t n, double a, hipStream_t s)
+{
+    if (n == 0) return;
+    unsigned g = (n + kBlock - 1) / kBlock;
+    if (g > (unsigned)kMaxGrid) g = kMaxGrid;
+    hipLaunchKernelGGL(k_scale, dim3(g), dim3(kBlock), 0, s, x, n, a);
 }
 
 // ---- pipelined shifted variant (reference src/shifted_solver.c:794-843)

@@ -123,6 +123,8 @@ struct bicg_ctx {
     hipEvent_t pend_ev = nullptr;
 
     // shifted solver (bicg_solve_shifted): per-shift scalar state and the two vector sets
+    double *sw_buf = nullptr;        // seed-switching variants: archives (doubles) followed by the flag arrays
+    size_t sw_cap = 0;
     ShiftDev *sh_dev = nullptr;
     double *sh_arrays = nullptr, *p_set = nullptr, *x_set = nullptr;
     int sh_cap = 0;
@@ -689,9 +691,150 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
 // SpMV(+sigma_seed) with (r#,s) | q, r_old | SpMV(+sigma_seed) with (q,y),(q,q) | ONE batched kernel
 // over all shifts (x_seed, r, every p_j and x_j, two dots) | p_seed.  The per-shift scalar
 // recurrences (beta_j, pi_j, eta_j, alpha_j, omega_j, zeta_j) run on the device, one thread per shift.
+// shifted_lopbicg / shifted_lopbicg_switching (+_noovlp), reference src/shifted_switching_solver.c.
+// Per iteration: SpMV (+alpha) ; q ; SpMV (+omega) ; seed update with the (r,r), (r#,r) dots (+beta
+// and every active shift's coefficients) ; ONE batched kernel over all shifts ; a one-workgroup
+// kernel for the stop flags. A seed switch needs new vector pointers and a rescaled r from the
+// host, so the device raises done/paused, the launches already queued fall through, and the host
+// resumes with the new seed (switches are rare: at most one per shift).
+int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
+                  const bicg_options *opt_in, bicg_result *res)
+{
+    bicg_options o;
+    if (opt_in) o = *opt_in; else { bicg_default_options(&o); o.tol = 1.0e-12; }   // EPS of src/shifted_switching_solver.c:5
+    if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
+    if (o.max_iter < 0) o.max_iter = 0;
+    if (o.check_every < 1) o.check_every = 1;
+    BICG_HIP(hipSetDevice(c->comm->device));
+    const size_t st = c->stride, n = c->n_loc;
+
+    if (c->sh_cap < nsig) {
+        for (void *p : {(void *)c->sh_dev, (void *)c->sh_arrays, (void *)c->p_set, (void *)c->x_set}) if (p) BICG_HIP(hipFree(p));
+        c->sh_dev = dev_alloc<ShiftDev>(1);
+        c->sh_arrays = dev_alloc<double>(12 * (size_t)nsig);
+        c->p_set = dev_alloc<double>((size_t)nsig * st);
+        c->x_set = dev_alloc<double>((size_t)nsig * st);
+        c->sh_cap = nsig;
+    }
+    const int L = o.max_iter + 2;                                    // archive entries 0 .. max_iter + 1
+    const size_t nd = 3 * (size_t)L + (size_t)nsig * L, ni = 2 * (size_t)nsig;
+    const size_t need = nd * sizeof(double) + ni * sizeof(int);
+    if (c->sw_cap < need) {
+        if (c->sw_buf) BICG_HIP(hipFree(c->sw_buf));
+        BICG_HIP(hipMalloc((void **)&c->sw_buf, need));
+        c->sw_cap = need;
+    }
+    ShiftDev h;
+    memset(&h, 0, sizeof h);
+    h.nsig = nsig; h.seed = seed; h.mode = mode; h.arc_len = L;
+    double **arr[12] = {&h.sigma, &h.alpha, &h.beta, &h.omega, &h.eta, &h.zeta, &h.pi_old, &h.pi_new, &h.cp, &h.cx, &h.c1, &h.c2};
+    for (int i = 0; i < 12; ++i) *arr[i] = c->sh_arrays + (size_t)i * nsig;
+    h.a_arc = c->sw_buf; h.b_arc = h.a_arc + L; h.w_arc = h.b_arc + L; h.pi_arc = h.w_arc + L;
+    h.stop = (int *)(c->sw_buf + nd); h.skip = h.stop + nsig;
+    BICG_HIP(hipMemcpy(c->sh_dev, &h, sizeof h, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemset(c->sh_arrays, 0, sizeof(double) * 12 * (size_t)nsig));
+    BICG_HIP(hipMemset(c->sw_buf, 0, need));
+    BICG_HIP(hipMemcpy(h.sigma, sigma, sizeof(double) * nsig, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemset(c->p_set, 0, sizeof(double) * (size_t)nsig * st));
+    BICG_HIP(hipMemset(c->x_set, 0, sizeof(double) * (size_t)nsig * st));
+    for (int j = 0; j < nsig; ++j)
+        BICG_HIP(hipMemcpy(c->x_set + (size_t)j * st, x_set_host + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice));
+    BICG_HIP(hipMemcpy(c->v.r, r_host, sizeof(double) * n, hipMemcpyHostToDevice));
+    BICG_HIP(hipDeviceSynchronize());
+
+    if (c->trace_cap < o.max_iter) {
+        if (c->trace) BICG_HIP(hipFree(c->trace));
+        c->trace_cap = o.max_iter > 0 ? o.max_iter : 1;
+        c->trace = dev_alloc<double>(4 * (size_t)c->trace_cap);
+    }
+    Scal hs;
+    memset(&hs, 0, sizeof hs);
+    hs.tol2 = o.tol * o.tol; hs.max_iter = o.max_iter;
+    hs.tr_alpha = c->trace; hs.tr_omega = c->trace + c->trace_cap;
+    hs.tr_beta = c->trace + 2 * (size_t)c->trace_cap; hs.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
+    hs.sh = c->sh_dev;
+    BICG_HIP(hipMemcpyAsync(c->S, &hs, sizeof hs, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
+    BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
+    c->time_kernels = false;
+    for (int j = 0; j < nsig; ++j)          // p[sigma] <- b for EVERY shift, src/shifted_switching_solver.c:348
+        BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
+    {   // streaming policy: matrix + 7 work vectors + the two sets
+        const double ws = (double)c->matrix_bytes + 8.0 * st * (7 + 2.0 * nsig);
+        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
+        if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
+    }
+    BICG_HIP(hipStreamSynchronize(c->sc));
+
+    Vecs &v = c->v;
+    double *qc = v.z;                               // q_copy (:394)
+    const double t0 = now_sec();
+    c->cur_has_shift = false;
+    launch_shift_init(v, c->p_set + (size_t)seed * st, c->S, c->red(0, PH_SW_INIT, true, 1), c->sc);   // r# = r, (r,r)
+    group_now(c, 1, PH_SW_INIT);
+    c->cur_has_shift = true;
+    int switches = 0;
+    for (;;) {
+        fetch_scal(c);
+        if (c->hS->paused) {                        // a seed switch happened at the end of iteration hS->k
+            ShiftDev now;
+            BICG_HIP(hipMemcpy(&now, c->sh_dev, sizeof now, hipMemcpyDeviceToHost));
+            launch_scale(v.r, (uint32_t)n, now.r_scale, c->sc);                       // (:499)
+            seed = now.seed;
+            ++switches;
+            const bool finished = c->hS->paused == 2;
+            const int zero2[2] = {0, 0};
+            if (!finished) BICG_HIP(hipMemcpyAsync(&c->S->done, &zero2[0], sizeof(int), hipMemcpyHostToDevice, c->sc));
+            BICG_HIP(hipMemcpyAsync(&c->S->paused, &zero2[1], sizeof(int), hipMemcpyHostToDevice, c->sc));
+            BICG_HIP(hipStreamSynchronize(c->sc));
+            if (finished) { c->hS->paused = 0; break; }
+            continue;
+        }
+        if (c->hS->done || c->hS->k >= o.max_iter) break;
+        double *p_seed = c->p_set + (size_t)seed * st, *x_seed = c->x_set + (size_t)seed * st;
+        c->cur_shift = sigma[seed];
+        const int chunk = std::min(o.check_every, o.max_iter - c->hS->k);
+        for (int j = 0; j < chunk; ++j) {
+            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SW_ALPHA, true, 1));           // s = (A + sigma I) p[seed], (r#,s)
+            group_now(c, 1, PH_SW_ALPHA);
+            launch_sw_q(v, qc, c->S, c->sc);                                          // r_old, q
+            spmv(c, v.r, v.y, 3, v.r, c->red(0, PH_SW_OMEGA, true, 2));               // y = (A + sigma I) q, (q,y), (q,q)
+            group_now(c, 2, PH_SW_OMEGA);
+            launch_sw_seed(v, x_seed, p_seed, c->S, c->red(0, PH_SW_END, true, 2), c->sc);   // x[seed], r, (r,r), (r#,r)
+            group_now(c, 2, PH_SW_END);
+            launch_sw_shifts(v, qc, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->sc);
+            launch_apply(c->S, PH_SW_STOP, c->sc);                                    // identical on every rank: no sums
+        }
+    }
+    c->cur_has_shift = false; c->cur_shift = 0.0;
+    const double t1 = now_sec();
+
+    const int its = c->hS->k;
+    c->last_iters = its;
+    for (int j = 0; j < nsig; ++j)
+        BICG_HIP(hipMemcpy(x_set_host + (size_t)j * n, c->x_set + (size_t)j * st, sizeof(double) * n, hipMemcpyDeviceToHost));
+    BICG_HIP(hipMemcpy(r_host, c->v.r, sizeof(double) * n, hipMemcpyDeviceToHost));
+    if (res) {
+        memset(res, 0, sizeof *res);
+        res->iterations = its; res->dot_r = c->hS->dot_r; res->dot_zero = c->hS->dot_zero;
+        res->seconds = t1 - t0; res->iter_seconds = t1 - t0;
+        res->breakdown_iteration = c->hS->breakdown_k;
+        res->adaptive_replacements = switches;      // reused: number of seed switches
+    }
+    const int k_ref = mode == SH_SWITCH ? its + 1 : its;   // the switching variants count from 1 (:295, 536)
+    if (c->rank == 0 && !o.quiet) {   // reference src/shifted_switching_solver.c:228-233 / :556-560
+        if (mode == SH_SWITCH) printf("Total iter   : %d\n", k_ref - 1);
+        printf("Total time   : %e [sec.] \n", t1 - t0);
+        printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / (k_ref > 0 ? k_ref : 1));
+        fflush(stdout);
+    }
+    return k_ref;
+}
+
 int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
                 const bicg_options *opt_in, bicg_result *res)
 {
+    if (mode == SH_FLAG || mode == SH_SWITCH) return run_switching(c, mode, x_set_host, r_host, sigma, nsig, seed, opt_in, res);
     if (mode < SH_LOP || mode > SH_XI) die("bicg_solve_shifted", "unknown variant");
     if (mode == SH_XI) seed = 0;          // shifted_bicgstab: the seed system is A itself, shift index 0
     bicg_options o;
@@ -1131,7 +1274,7 @@ void bicg_destroy(bicg_ctx *c)
     (void)hipSetDevice(c->comm->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
-                    c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace};
+                    c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace, c->sw_buf};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->p2p) {
         c->p2p->unmap(c->ring_mapped);
@@ -1293,6 +1436,10 @@ int shifted_pipe_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, doubl
 int shifted_pipe_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_PIPE, d, o, i, x, r, sigma, n, seed); }
 // src/shifted_solver.h:16 (seed system = A, shift index 0)
 int shifted_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n) { return dropin_shifted(SH_XI, d, o, i, x, r, sigma, n, 0); }
+// reference src/shifted_switching_solver.h:10-12
+int shifted_lopbicg(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_FLAG, d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicg_switching(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_SWITCH, d, o, i, x, r, sigma, n, seed); }
+int shifted_lopbicg_switching_noovlp(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_SWITCH, d, o, i, x, r, sigma, n, seed); }
 
 // ---- drop-in entry points: reference src/solver.h:10-13
 int bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_BICGSTAB, d, o, i, x, r, 0, 0); }

@@ -51,6 +51,9 @@ EXPORTS = [
     "bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr",
     "shifted_bicgstab", "shifted_lopbicgstab", "shifted_lopbicgstab_v2", "shifted_lopbicgstab_nooverlap",
     "shifted_pipe_lopbicgstab", "shifted_pipe_lopbicgstab_nooverlap", "bicg_solve_shifted",
+    "shifted_lopbicg", "shifted_lopbicg_switching", "shifted_lopbicg_switching_noovlp",
+    "bicg_comm_enable_p2p", "bicg_comm_p2p_active", "bicg_comm_failed",
+    "bicg_partition_nnz", "bicg_mtx_load_block_part", "bicg_mtx_cache_save", "bicg_mtx_cache_load",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
@@ -207,7 +210,8 @@ class Context:
         k = lib().bicg_solve(self.h, METHODS[method], _d(x), _d(r), C.byref(o), C.byref(res))
         return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res)
 
-    SHIFTED = {"shifted_lopbicgstab": 0, "shifted_pipe_lopbicgstab": 1, "shifted_bicgstab": 2}
+    SHIFTED = {"shifted_lopbicgstab": 0, "shifted_pipe_lopbicgstab": 1, "shifted_bicgstab": 2,
+               "shifted_lopbicg": 3, "shifted_lopbicg_switching": 4}
 
     def solve_shifted(self, b, sigma, seed, x0_set=None, which="shifted_lopbicgstab", **kw):
         """(A + sigma_j I) x_j = b for all j (reference src/shifted_solver.c): dict(k, x [nsig][n], r, result)."""
@@ -220,7 +224,8 @@ class Context:
         res = Result()
         k = lib().bicg_solve_shifted(self.h, self.SHIFTED[which], _d(x), _d(r), _d(sigma), len(sigma), seed, C.byref(o),
                                      C.byref(res))
-        return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res)
+        return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res,
+                    iterations=res.iterations, switches=res.adaptive_replacements)
 
     def load(self, x0, b):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)

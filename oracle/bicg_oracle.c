@@ -820,6 +820,7 @@ int orc_shifted_lopbicg_switching(const orc_dist *d, double *x_set, double *r, c
             }
         }
 
+        trace_put(o, k, a_arc[k], w_arc[k], b_arc[k], dot_r);   /* before a switch rewrites the archives */
         if (stop[seed] && stop_count < nsig) {                  /* :490-527 seed switching */
             const int ms = max_sigma;
             for (int i = 1; i <= k; ++i) {
@@ -839,7 +840,6 @@ int orc_shifted_lopbicg_switching(const orc_dist *d, double *x_set, double *r, c
             seed = ms;
             switches++;
         }
-        trace_put(o, k, a_arc[k], w_arc[k], b_arc[k], dot_r);
         k++;                                                    /* :536 */
     }
 #undef PI_

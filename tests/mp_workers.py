@@ -158,6 +158,18 @@ def gpu_worker(rank, world, port, kind, outdir):
             got = ctx.solve_shifted(bs_full[lo:lo + nl], sigma, seed, check_every=4, which=which)
             assert abs(got["k"] - orc["k"]) <= 2, (which, got["k"], orc["k"])
             assert np.abs(got["x"] - orc["x"][:, lo:lo + nl]).max() <= 1e-8 * max(1.0, np.abs(orc["x"]).max()), which
+        # seed-switching variants (reference src/shifted_switching_solver.c): the seed (largest shift)
+        # converges first, the device pauses, every rank re-points to the same new seed
+        if not balanced and kind != "ragged":
+            sg8, sd8 = 0.02 * 2.0 ** np.arange(8), 7
+            b8 = b_full + sg8[sd8] * np.ones(A.rows)
+            for which in ("shifted_lopbicg", "shifted_lopbicg_switching"):
+                orc = O.solve_switching(A.rows, row, col, val, b8, sg8, sd8, nranks=world, which=which)
+                got = ctx.solve_shifted(b8[lo:lo + nl], sg8, sd8, check_every=5, which=which)
+                assert abs(got["k"] - orc["k"]) <= 3, (which, got["k"], orc["k"])
+                assert got["switches"] == orc["switches"], (which, got["switches"], orc["switches"])
+                assert np.abs(got["x"] - orc["x"][:, lo:lo + nl]).max() <= 1e-8 * max(1.0, np.abs(orc["x"]).max()), which
+            assert orc["switches"] >= 1, "test set-up: no seed switch happened"
         ctx.close()
         dist.barrier()
         H.lib().bicg_comm_finalize()
