@@ -291,6 +291,7 @@ def main():
     spmv_alone_ms = ctx.spmv_bench(200)
 
     cpu = None
+    cpu_all = None
     if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "transport" and not mtx:
         try:
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--n", str(n),
@@ -299,6 +300,19 @@ def main():
             cpu = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # the baseline is reported, never required
             cpu = {"error": repr(e)}
+        # SURVEY.md section 8d config 1 also asks for the reference on the host's cores. More ranks are not
+        # faster for it: every rank gathers the WHOLE vector per SpMV (src/matrix.c:432), and on the GPU box's
+        # 2 x EPYC 9575F it is fastest at 8 ranks (ms/iteration at 4/8/16/32/64 ranks: 15.5 / 11.7 / 13.1 /
+        # 53.4 / 135, profiles/r01/cpu_reference_scaling.txt) -- so 8 ranks is what is timed here
+        try:
+            ranks = max(2, min(8, os.cpu_count() or 2))
+            out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--n", str(n),
+                                  "--scale-decades", str(a.scale_decades), "--iters", str(a.cpu_iters),
+                                  "--method", a.method, "--ranks", str(ranks)], capture_output=True, text=True, timeout=600)
+            cpu_all = json.loads(out.stdout.strip().splitlines()[-1])
+            cpu_all["note"] = "rank count at which the reference is fastest on this host; see profiles/r01/cpu_reference_scaling.txt"
+        except Exception as e:
+            cpu_all = {"error": repr(e)}
 
     if rank == 0:
         iter_bytes = 2 * spmv_bytes(nnz_global, n) + ITER_VECTOR_BYTES_PER_ROW[a.method] * n
@@ -326,6 +340,7 @@ def main():
                          "back_to_back_spmv_ms": spmv_alone_ms,
                          "frac_of_measured_copy_6290": achieved / 6290.0},
             "cpu_baseline": cpu,
+            "cpu_baseline_multicore": cpu_all,
             "variants_ms_per_iteration": variants,
         }
         print(json.dumps(line), file=result_out, flush=True)

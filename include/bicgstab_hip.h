@@ -218,6 +218,10 @@ int bicg_sync(bicg_ctx *ctx);
 enum { BICG_SHIFTED_LOP = 0, BICG_SHIFTED_PIPE = 1, BICG_SHIFTED_XI = 2, BICG_SHIFTED_FLAG = 3, BICG_SHIFTED_SWITCH = 4 };
 int bicg_solve_shifted(bicg_ctx *ctx, int variant, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len,
                        int seed, const bicg_options *opt, bicg_result *res);
+/* The check of the reference's shifted driver (src/test_shifted.c:129-154) on the device: relres_out[j] =
+ * || (A + sigma_j I) x_j - b || / || b || for every shift (x_loc_set shift-major as above). Collective. */
+int bicg_shifted_residuals(bicg_ctx *ctx, const double *x_loc_set, const double *b_loc, const double *sigma, int sigma_len,
+                           double *relres_out);
 /* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */
 int bicg_trace(bicg_ctx *ctx, double *alpha, double *omega, double *beta, double *dot_r);
 

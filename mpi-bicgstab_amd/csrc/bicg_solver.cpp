@@ -1371,6 +1371,37 @@ double bicg_dot(bicg_ctx *c, const double *x, const double *y)
     return c->hS->red[0];
 }
 
+// Verification loop of the reference's shifted driver (src/test_shifted.c:129-154): for every shift the
+// relative residual || (A + sigma_j I) x_j - b || / || b ||, computed on the device (SpMV with the
+// shift folded into its epilogue + one fused difference/norm kernel per shift). Collective.
+int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b_loc, const double *sigma, int nsig,
+                           double *relres_out)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    reset_scal(c);
+    const size_t n = c->n_loc;
+    BICG_HIP(hipMemcpyAsync(c->v.b, b_loc, sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipMemsetAsync(c->v.t, 0, sizeof(double) * c->stride, c->sc));
+    c->time_kernels = false;
+    launch_dot(c->v.b, c->v.b, c->n_loc, c->S, c->red(0, PH_NONE, true, 1), c->sc);
+    group_now(c, 1, PH_NONE);
+    fetch_scal(c);
+    const double bb = c->hS->red[0];
+    Vecs w = c->v;
+    w.r = c->v.t;                               // zero vector: FDrift then yields || b - A x ||^2
+    for (int j = 0; j < nsig; ++j) {
+        BICG_HIP(hipMemcpyAsync(c->v.p, x_loc_set + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
+        c->cur_shift = sigma[j]; c->cur_has_shift = true;
+        spmv(c, c->v.p, c->v.ax, 0, nullptr, c->red(0, PH_NONE));
+        c->cur_has_shift = false; c->cur_shift = 0.0;
+        launch_drift(w, c->S, c->red(0, PH_NONE, true, 2), c->sc);
+        group_now(c, 2, PH_NONE);
+        fetch_scal(c);
+        relres_out[j] = bb > 0.0 ? sqrt(c->hS->red[0] / bb) : sqrt(c->hS->red[0]);
+    }
+    return 0;
+}
+
 int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
 {
     BICG_HIP(hipSetDevice(c->comm->device));

@@ -51,7 +51,7 @@ EXPORTS = [
     "bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr",
     "shifted_bicgstab", "shifted_lopbicgstab", "shifted_lopbicgstab_v2", "shifted_lopbicgstab_nooverlap",
     "shifted_pipe_lopbicgstab", "shifted_pipe_lopbicgstab_nooverlap", "bicg_solve_shifted",
-    "shifted_lopbicg", "shifted_lopbicg_switching", "shifted_lopbicg_switching_noovlp",
+    "shifted_lopbicg", "shifted_lopbicg_switching", "shifted_lopbicg_switching_noovlp", "bicg_shifted_residuals",
     "bicg_comm_enable_p2p", "bicg_comm_p2p_active", "bicg_comm_failed",
     "bicg_partition_nnz", "bicg_mtx_load_block_part", "bicg_mtx_cache_save", "bicg_mtx_cache_load",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
@@ -91,6 +91,7 @@ def lib():
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
         L.bicg_comm_failed.argtypes = [C.c_void_p]
+        L.bicg_shifted_residuals.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, _dp]
         L.bicg_default_options.argtypes = [C.POINTER(Options)]
         L.bicg_comm_unique_id.argtypes = [C.c_void_p]
         L.bicg_comm_init_rccl.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int]
@@ -226,6 +227,15 @@ class Context:
                                      C.byref(res))
         return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res,
                     iterations=res.iterations, switches=res.adaptive_replacements)
+
+    def shifted_residuals(self, x_set, b, sigma):
+        """|| (A + sigma_j I) x_j - b || / || b || for every shift (reference src/test_shifted.c:129-154)"""
+        sigma = np.ascontiguousarray(sigma, dtype=np.float64)
+        x = np.ascontiguousarray(x_set, dtype=np.float64).reshape(len(sigma), self.n)
+        b = np.ascontiguousarray(b, dtype=np.float64)
+        out = np.zeros(len(sigma))
+        lib().bicg_shifted_residuals(self.h, _d(x), _d(b), _d(sigma), len(sigma), _d(out))
+        return out
 
     def load(self, x0, b):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)
