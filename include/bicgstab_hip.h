@@ -292,6 +292,18 @@ int bicg_mtx_cache_save(const char *cache_path, const char *src_path, int rank, 
 int bicg_mtx_cache_load(const char *cache_path, const char *src_path, int rank, int nranks, int part,
                         CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 void bicg_mtx_free(CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
+/* Device-side COO -> CSR (needs a GPU): the triplets this rank owns -- FILE order, global row and column
+ * indices, rows in [lo, hi) -- become the diag block (local columns) and the offd block (global columns,
+ * cols = ncols) that MPI_csr_load_matrix_block yields (reference src/matrix.c:336-392), file order kept inside
+ * every row (a stable sort on the row key, like the reference's merge sort, src/matrix.c:135-183).
+ * Arrays are malloc'ed; release with free() / bicg_mtx_free. bicg_mtx_set_block_builder(fn) makes the
+ * Matrix-Market loaders above use fn for that step (NULL = host counting sort); the C host does so with
+ * BICG_INGEST=device. */
+typedef int (*bicg_block_builder_fn)(const unsigned int *row, const unsigned int *col, const double *val, unsigned long nnz,
+                                     unsigned int lo, unsigned int hi, unsigned int ncols, CSR_Matrix *diag, CSR_Matrix *offd);
+int bicg_coo_to_blocks_device(const unsigned int *row, const unsigned int *col, const double *val, unsigned long nnz,
+                              unsigned int lo, unsigned int hi, unsigned int ncols, CSR_Matrix *diag, CSR_Matrix *offd);
+void bicg_mtx_set_block_builder(bicg_block_builder_fn fn);
 
 const char *bicg_version(void);
 

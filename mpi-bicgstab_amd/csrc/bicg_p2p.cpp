@@ -106,6 +106,9 @@ int P2p::share(void *local, std::vector<void *> &peers, std::vector<void *> &ope
         if (p == rank) continue;
         if (!in[p].ok || in[p].host != mine.host) { bad = 1; break; }
         if (in[p].pid == mine.pid) { bad = 1; break; }      // one process per rank
+        int ndev = 0, can = 1;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && in[p].device != mine.device && in[p].device < ndev &&
+            hipDeviceCanAccessPeer(&can, mine.device, in[p].device) == hipSuccess && !can) { bad = 1; break; }   // no link to that GPU
         void *ptr = nullptr;
         if (hipIpcOpenMemHandle(&ptr, in[p].handle, hipIpcMemLazyEnablePeerAccess) != hipSuccess || !ptr) {
             (void)hipGetLastError();

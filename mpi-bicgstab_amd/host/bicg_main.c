@@ -73,6 +73,8 @@ int main(int argc, char **argv)
         hit = all;
 #endif
     }
+    const char *ing = getenv("BICG_INGEST");                 /* device: COO -> CSR on the GPU */
+    if (ing && strcmp(ing, "device") == 0) bicg_mtx_set_block_builder(bicg_coo_to_blocks_device);
     if (!hit) {
 #ifdef BICG_HAVE_MPI
         /* every rank tokenises 1/P of the file, triplets are exchanged (the reference has every rank

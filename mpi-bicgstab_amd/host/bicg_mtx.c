@@ -193,9 +193,21 @@ static void fill_info(const mtx_header *h, int nranks, INFO_Matrix *info)
     partition((unsigned)h->m, nranks, info->recvcounts, info->displs);
 }
 
+static bicg_block_builder_fn g_builder = NULL;
+void bicg_mtx_set_block_builder(bicg_block_builder_fn fn) { g_builder = fn; }
+
 /* split this rank's triplets (global row/col) into the diag (local columns) and offd (global columns) blocks */
 static void build_blocks(const triplet *t, size_t nt, unsigned lo, unsigned hi, unsigned ncols, CSR_Matrix *diag, CSR_Matrix *offd)
 {
+    if (g_builder) {            /* e.g. bicg_coo_to_blocks_device: sort / scan / scatter on the GPU */
+        unsigned *r = (unsigned *)malloc(sizeof(unsigned) * (nt ? nt : 1)), *c = (unsigned *)malloc(sizeof(unsigned) * (nt ? nt : 1));
+        double *v = (double *)malloc(sizeof(double) * (nt ? nt : 1));
+        for (size_t e = 0; e < nt; ++e) { r[e] = t[e].r; c[e] = t[e].c; v[e] = t[e].v; }
+        const int rc = g_builder(r, c, v, (unsigned long)nt, lo, hi, ncols, diag, offd);
+        free(r); free(c); free(v);
+        if (rc == 0) return;
+        fprintf(stderr, "bicg_mtx: block builder failed (%d), using the host path\n", rc);
+    }
     tvec d = {0, 0, 0}, o = {0, 0, 0};
     for (size_t e = 0; e < nt; ++e) {
         if (t[e].c >= lo && t[e].c < hi) tpush(&d, t[e].r - lo, t[e].c - lo, t[e].v);

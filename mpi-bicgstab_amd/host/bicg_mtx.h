@@ -33,6 +33,9 @@ int bicg_mtx_cache_save(const char *cache_path, const char *src_path, int rank, 
 int bicg_mtx_cache_load(const char *cache_path, const char *src_path, int rank, int nranks, int part,
                         CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 
+/* bicg_mtx_set_block_builder (bicgstab_hip.h): replace the host counting sort that turns a rank's triplets into
+ * its two CSR blocks, e.g. by bicg_coo_to_blocks_device. */
+
 #ifdef BICG_HAVE_MPI
 int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info);
 /* Collective over MPI_COMM_WORLD: every rank tokenises only ITS 1/P byte range of the file (cut at

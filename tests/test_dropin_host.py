@@ -75,3 +75,35 @@ def test_c_host_matches_reference(mtx, np_, tmp_path):
         nl = int(np.frombuffer(raw[4:8], dtype=np.int32)[0])
         xs.append(np.frombuffer(raw[8:8 + 8 * nl], dtype=np.float64))
     assert np.abs(np.concatenate(xs) - 1.0).max() <= 1e-9     # manufactured solution (src/main.c:109-117)
+
+
+@need
+@pytest.mark.parametrize("np_", [1, 2])
+def test_c_host_ingest_options(mtx, np_, tmp_path):
+    """SURVEY.md section 8f N1 through the C host: COO -> CSR on the GPU (BICG_INGEST=device), the binary
+    block cache (miss, then hit) and the non-zero balanced partition give the same solve as the plain
+    host path -- bit-identical x for the first two (same blocks), converged for the third."""
+    def run(env_extra, tag):
+        env = dict(os.environ, BICG_CHECK_EVERY="4", **env_extra)
+        prefix = str(tmp_path / tag)
+        out = subprocess.run([MPIEXEC, "-n", str(np_), HOST, mtx, "bicgstab", "--dump", prefix], capture_output=True, text=True,
+                             timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        xs = []
+        for p in range(np_):
+            raw = open(f"{prefix}.rank{p}.bin", "rb").read()
+            nl = int(np.frombuffer(raw[4:8], dtype=np.int32)[0])
+            xs.append(np.frombuffer(raw[8:8 + 8 * nl], dtype=np.float64))
+        return np.concatenate(xs), out.stdout
+
+    base, _ = run({}, "base")
+    dev, _ = run({"BICG_INGEST": "device"}, "dev")
+    assert np.array_equal(dev, base)
+    cache = tmp_path / "cache"
+    cache.mkdir()
+    miss, out1 = run({"BICG_MTX_CACHE": str(cache)}, "miss")
+    hit, out2 = run({"BICG_MTX_CACHE": str(cache)}, "hit")
+    assert "miss (written)" in out1 and "Block cache  : hit" in out2
+    assert np.array_equal(miss, base) and np.array_equal(hit, base)
+    bal, out3 = run({"BICG_PARTITION": "nnz"}, "nnz")
+    assert np.abs(bal - 1.0).max() <= 1e-9

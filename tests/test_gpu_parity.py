@@ -232,3 +232,40 @@ def test_adaptive_residual_replacement():
     assert np.sqrt(res["dot_r"] / res["dot_zero"]) <= 1e-15
     assert np.abs(res["x"] - 1.0).max() <= 1e-9
     ctx.close()
+
+
+def test_device_ingest_matches_host():
+    """bicg_coo_to_blocks_device: a rank's triplets in shuffled FILE order become
+    the same diag / offd CSR blocks -- file order inside every row -- as the reference's stable row
+    sort + split (src/matrix.c:135-183, 336-392), bit for bit."""
+    import ctypes as C
+    H.lib().bicg_comm_init_single(0)
+    A = synth.random_rows(3000, 40, seed=3, empty_frac=0.1, long_rows={17: 900})
+    row, col, val = A.to_coo()
+    perm = np.random.default_rng(2).permutation(len(val))
+    row, col, val = row[perm].astype(np.uint32), col[perm].astype(np.uint32), val[perm]
+    order = np.argsort(row, kind="stable")               # what the reference's merge sort yields
+    r, c, v = row[order], col[order], val[order]
+    ptr = np.zeros(A.rows + 1, dtype=np.int64)
+    np.add.at(ptr, r.astype(np.int64) + 1, 1)
+    B = synth.CSR(A.rows, A.cols, np.cumsum(ptr).astype(np.uint32), c, v)
+    fn = H.lib().bicg_coo_to_blocks_device
+    up, dp = C.POINTER(C.c_uint), C.POINTER(C.c_double)
+    fn.argtypes = [up, up, dp, C.c_ulong, C.c_uint, C.c_uint, C.c_uint, C.POINTER(H.CSRMatrix), C.POINTER(H.CSRMatrix)]
+    for world, rank in ((1, 0), (3, 1), (3, 2)):
+        ed, eo, counts, displs = synth.split_blocks(B, world, rank)
+        lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+        mine = (row >= lo) & (row < hi)
+        rr, cc, vv = np.ascontiguousarray(row[mine]), np.ascontiguousarray(col[mine]), np.ascontiguousarray(val[mine])
+        d, o = H.CSRMatrix(), H.CSRMatrix()
+        assert fn(rr.ctypes.data_as(up), cc.ctypes.data_as(up), vv.ctypes.data_as(dp), len(vv), lo, hi, A.cols, C.byref(d), C.byref(o)) == 0
+        for got, exp in ((d, ed), (o, eo)):
+            n = hi - lo
+            gp = np.ctypeslib.as_array(got.ptr, shape=(n + 1,))
+            assert np.array_equal(gp, exp.ptr)
+            nz = int(gp[-1])
+            assert nz == exp.nnz
+            if nz:
+                assert np.array_equal(np.ctypeslib.as_array(got.col, shape=(nz,)), exp.col)
+                assert np.array_equal(np.ctypeslib.as_array(got.val, shape=(nz,)), exp.val)
+        assert d.cols == hi - lo and o.cols == A.cols
