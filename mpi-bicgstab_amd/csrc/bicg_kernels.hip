@@ -56,7 +56,7 @@ __device__ __forceinline__ void finish_iteration(Scal *S, double alpha_used)
     }
 }
 
-__device__ void apply_phase(Scal *S, int phase)
+__device__ __forceinline__ void apply_phase(Scal *S, int phase)
 {
     const double *d = S->red;
     switch (phase) {
@@ -127,7 +127,7 @@ __device__ __forceinline__ void shift_omega_coeffs(ShiftDev *H, int j, double w_
     H->zeta[j] = (1.0 - w_seed * dsg) * z;                           // (:300)
 }
 
-__device__ void apply_phase_shifted(Scal *S, int phase)
+__device__ __forceinline__ void apply_phase_shifted(Scal *S, int phase)
 {
     ShiftDev *H = S->sh;
     const double *d = S->red;
@@ -263,7 +263,7 @@ __device__ void apply_phase_shifted(Scal *S, int phase)
 // same expressions, written in the archive form of the switching variant -- alpha/beta/omega of
 // the seed and pi of every shift are kept per iteration, index kk = completed iterations + 1 (the
 // reference's k of the switching variant), index 0 = the initial values.
-__device__ void apply_phase_switching(Scal *S, int phase)
+__device__ __forceinline__ void apply_phase_switching(Scal *S, int phase)
 {
     ShiftDev *H = S->sh;
     const double *d = S->red;
@@ -411,18 +411,28 @@ __device__ void apply_phase_switching(Scal *S, int phase)
 #undef PI_
 }
 
-// whole-workgroup entry: scalar phases run on thread 0, shifted phases on all threads
+// whole-workgroup entry: scalar phases run on thread 0, shifted phases on all threads.
+// HEAVY = false leaves out the seed-switching phases (and, in reduce_publish, the peer-to-peer
+// in-kernel collect): inlined into every dot-producing kernel they cost the hot single-GPU kernels
+// 26 VGPRs and 8 KB of LDS (occupancy 8 -> 5 waves per SIMD, +2-3 % per iteration on Transport), so
+// the launch wrappers pick the HEAVY instantiation only for launches that need it (heavy_needed).
+template <bool HEAVY>
 __device__ __forceinline__ void apply_phase_block(Scal *S, int phase)
 {
-    if (phase >= PH_SW_INIT) apply_phase_switching(S, phase);
-    else if (phase >= PH_SH_INIT) apply_phase_shifted(S, phase);
-    else if (threadIdx.x == 0) apply_phase(S, phase);
+    if (HEAVY && phase >= PH_SW_INIT) apply_phase_switching(S, phase);
+    else if (phase >= PH_SH_INIT && phase < PH_SW_INIT) apply_phase_shifted(S, phase);
+    else if (phase < PH_SH_INIT && threadIdx.x == 0) apply_phase(S, phase);
+}
+
+static inline bool heavy_needed(const Reduce &red)
+{
+    return red.apply_now && (red.p2p.seq != 0 || red.phase >= PH_SW_INIT);
 }
 
 __global__ void __launch_bounds__(kBlock) k_apply(Scal *S, int phase)
 {
     if (S->done) return;
-    apply_phase_block(S, phase);
+    apply_phase_block<true>(S, phase);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -494,7 +504,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_p2p(Scal *S, int phase, int n,
     __shared__ double vals[kRedSlots * kMaxRanksP2p];
     __shared__ int s_fail;
     if (!p2p_collect(S, n, pr, timeout_ticks, vals, &s_fail)) return;
-    if (phase != PH_NONE) apply_phase_block(S, phase);
+    if (phase != PH_NONE) apply_phase_block<true>(S, phase);
 }
 
 // Self-test of the transport: `rounds` all-reduces of five values that depend on (rank, round,
@@ -588,7 +598,7 @@ __device__ __forceinline__ unsigned shard_population(unsigned expected, unsigned
     return shard < expected ? (expected - shard + kShards - 1) / kShards : 0u;
 }
 
-template <int ND>
+template <int ND, bool HEAVY>
 __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const Reduce &red, unsigned slot, double *sm)
 {
     __shared__ unsigned s_last;
@@ -657,7 +667,7 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
         }
     }
     if (red.apply_now) {
-        if (red.p2p.seq) {
+        if (HEAVY && red.p2p.seq) {
             // peer-to-peer, group not deferred: this workgroup is the last of the launch anyway, so it
             // waits for the other ranks' sums and applies the phase right here instead of leaving
             // that to a separate one-workgroup kernel (3-4 us per dot group on a small rank)
@@ -667,7 +677,7 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
         } else {
             __syncthreads();        // Scal::red written by thread 0 above
         }
-        apply_phase_block(S, red.phase);
+        apply_phase_block<HEAVY>(S, red.phase);
     }
 }
 
@@ -690,7 +700,7 @@ template <bool NT, class T> __device__ __forceinline__ T stream_load(const T *p)
     return *p;
 }
 
-template <int NDOT, bool OFFD, bool NT>
+template <int NDOT, bool OFFD, bool NT, bool HEAVY>
 __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 {
     // The sticky convergence flag is requested here but only consumed where state would be
@@ -797,7 +807,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
         }
         __syncthreads();   // prod is rewritten by the next row block
     }
-    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1), HEAVY>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
 }
 
 // One workgroup per row block: the hardware dispatcher balances the ~12k workgroups of a
@@ -813,8 +823,14 @@ template <int NDOT, bool OFFD>
 static void launch_spmv_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     dim3 g(spmv_grid(a.nlist)), b(kBlock);
-    if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true>, g, b, st, e0, e1, a);
-    else launch_timed(k_spmv<NDOT, OFFD, false>, g, b, st, e0, e1, a);
+    constexpr bool HV = NDOT > 0;        // without dots there is no epilogue to be heavy
+    if (HV && heavy_needed(a.red)) {
+        if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true, HV>, g, b, st, e0, e1, a);
+        else launch_timed(k_spmv<NDOT, OFFD, false, HV>, g, b, st, e0, e1, a);
+    } else {
+        if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true, false>, g, b, st, e0, e1, a);
+        else launch_timed(k_spmv<NDOT, OFFD, false, false>, g, b, st, e0, e1, a);
+    }
 }
 
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
@@ -847,7 +863,7 @@ typedef short i16x4 __attribute__((ext_vector_type(4)));
 // C16: column indices are read as 16-bit offsets from the row (col = row + delta), four
 // consecutive entries of a lane packed in one 8-byte word: 10 instead of 12 bytes per non-zero.
 // Used when every entry of the sliced-ELL copy satisfies |col - row| < 32768 (banded matrices).
-template <int NDOT, bool OFFD, bool NT, bool C16, bool LL>
+template <int NDOT, bool OFFD, bool NT, bool C16, bool LL, bool HEAVY>
 __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
@@ -954,7 +970,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
         if (NDOT == 3 && live) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
     }
     if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
-    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.S, a.red, a.red.slot_base + bid, sm);
+    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1), HEAVY>(acc, a.S, a.red, a.red.slot_base + bid, sm);
 }
 
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
@@ -975,10 +991,18 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 #define SELL_CASE(ND, OF, LLV)                                                                     \
     do {                                                                                           \
         const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;                                  \
-        if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV>, g, b, st, e0, e1, a);    \
-        else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV>, g, b, st, e0, e1, a);     \
-        else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV>, g, b, st, e0, e1, a);    \
-        else launch_timed(k_spmv_sell<ND, OF, false, false, LLV>, g, b, st, e0, e1, a);            \
+        constexpr bool HV = (ND) > 0;                                                              \
+        if (HV && heavy_needed(a.red)) {                                                           \
+            if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV, HV>, g, b, st, e0, e1, a);     \
+            else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV, HV>, g, b, st, e0, e1, a);      \
+            else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV, HV>, g, b, st, e0, e1, a);     \
+            else launch_timed(k_spmv_sell<ND, OF, false, false, LLV, HV>, g, b, st, e0, e1, a);             \
+        } else {                                                                                   \
+            if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV, false>, g, b, st, e0, e1, a);  \
+            else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV, false>, g, b, st, e0, e1, a);   \
+            else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV, false>, g, b, st, e0, e1, a);  \
+            else launch_timed(k_spmv_sell<ND, OF, false, false, LLV, false>, g, b, st, e0, e1, a);          \
+        }                                                                                          \
     } while (0)
     if (fused_halo) {
         if (ndot == 0) SELL_CASE(0, true, true); else if (ndot == 1) SELL_CASE(1, true, true); else if (ndot == 2) SELL_CASE(2, true, true); else SELL_CASE(3, true, true);
@@ -1141,7 +1165,7 @@ __device__ __forceinline__ void st(double *p, uint32_t i, d2 v)
 }
 
 // F::ND dot products, F::load(S) fetches the scalars once, F::apply<T>(i, acc) handles element(s) i.
-template <class F>
+template <class F, bool HEAVY>
 __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce red)
 {
     if (S->done) return;
@@ -1155,7 +1179,7 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
     for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npair; i += gridDim.x * kBlock)
         f.template apply<d2>(2 * i, acc);
     if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
-    if (F::ND > 0) reduce_publish<ND>(acc, S, red, blockIdx.x, sm);
+    if (F::ND > 0) reduce_publish<ND, HEAVY>(acc, S, red, blockIdx.x, sm);
 }
 
 unsigned vec_grid(uint32_t n)
@@ -1172,7 +1196,9 @@ static void run_vec(F f, uint32_t n, Scal *S, Reduce red, hipStream_t stream)
     const unsigned g = vec_grid(n);
     red.expected = g;
     red.slot_base = 0;
-    hipLaunchKernelGGL((k_vec<F>), dim3(g), dim3(kBlock), 0, stream, f, n, S, red);
+    constexpr bool HV = F::ND > 0;
+    if (HV && heavy_needed(red)) hipLaunchKernelGGL((k_vec<F, HV>), dim3(g), dim3(kBlock), 0, stream, f, n, S, red);
+    else hipLaunchKernelGGL((k_vec<F, false>), dim3(g), dim3(kBlock), 0, stream, f, n, S, red);
 }
 
 // ---- init: r = b - Ax ; r# = r ; [p = r] ; [bsave = b] ; (r,r)     (src/solver.c:74-78, 475-479)

@@ -1204,6 +1204,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // of the send list lands in the ring of the rank that needs it (collective)
     c->p2p = comm->p2p;
     if (const char *sv = getenv("BICG_P2P_FAULT_AFTER")) c->fault_after = atoi(sv);
+    // in-kernel collect needs the HEAVY kernel instantiations (occupancy 5 instead of 8 waves per SIMD,
+    // ~3 % per SpMV): worth it unless the local problem is so large that 3 % exceeds the ~10 us per
+    // iteration the separate apply kernels cost
+    c->inline_apply = c->nnz_d < 40000000u;
     if (const char *sv = getenv("BICG_P2P_INLINE_APPLY")) c->inline_apply = atoi(sv) != 0;
     if (c->p2p && !c->single()) {
         c->halo_ring = (llword *)c->p2p->alloc(sizeof(llword) * 2 * (size_t)kHaloRing * c->halo);
