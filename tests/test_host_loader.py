@@ -182,3 +182,65 @@ def test_cache_rejects_stale_and_corrupt(tmp_path):
     with open(mtx, "a") as f:
         f.write("% touched\n")
     assert L.bicg_mtx_cache_load(cpath, mtx.encode(), 1, 2, 0, C.byref(d2), C.byref(o2), C.byref(i2)) != 0
+
+
+def test_block_builder_hook(tmp_path):
+    """bicg_mtx_set_block_builder: the loader hands a rank's triplets (file order, global indices) to the
+    installed builder (on the GPU box: bicg_coo_to_blocks_device) and uses the blocks it returns. Here the
+    builder is a Python callback that does the stable row sort with numpy and allocates with malloc."""
+    import ctypes as C
+    from mpi_bicgstab_amd import hipsolver as H
+    L = H.lib()
+    libc = C.CDLL(None)
+    libc.malloc.restype = C.c_void_p
+    libc.malloc.argtypes = [C.c_size_t]
+    up, dp = C.POINTER(C.c_uint), C.POINTER(C.c_double)
+    BUILDER = C.CFUNCTYPE(C.c_int, up, up, dp, C.c_ulong, C.c_uint, C.c_uint, C.c_uint, C.POINTER(H.CSRMatrix), C.POINTER(H.CSRMatrix))
+    seen = []
+
+    def fill(dst, rows, cols, r, c, v):
+        ptr = np.zeros(rows + 1, dtype=np.uint32)
+        np.add.at(ptr, r.astype(np.int64) + 1, 1)
+        ptr = np.cumsum(ptr).astype(np.uint32)
+        order = np.argsort(r, kind="stable")
+        c, v = np.ascontiguousarray(c[order], dtype=np.uint32), np.ascontiguousarray(v[order], dtype=np.float64)
+        for name, arr in (("ptr", ptr), ("col", c), ("val", v)):
+            mem = libc.malloc(max(arr.nbytes, 8))
+            C.memmove(mem, arr.ctypes.data, arr.nbytes)
+            setattr(dst.contents, name, C.cast(mem, up if name != "val" else dp))
+        dst.contents.rows, dst.contents.cols, dst.contents.nz = rows, cols, len(v)
+
+    def builder(row, col, val, nnz, lo, hi, ncols, diag, offd):
+        r = np.ctypeslib.as_array(row, shape=(nnz,)).copy(); c = np.ctypeslib.as_array(col, shape=(nnz,)).copy()
+        v = np.ctypeslib.as_array(val, shape=(nnz,)).copy()
+        seen.append((int(nnz), int(lo), int(hi)))
+        local = (c >= lo) & (c < hi)
+        fill(diag, hi - lo, hi - lo, r[local] - lo, c[local] - lo, v[local])
+        fill(offd, hi - lo, ncols, r[~local] - lo, c[~local], v[~local])
+        return 0
+
+    cb = BUILDER(builder)
+    A = synth.from_offsets(500, (0, 1, -1, 23, -23, 200, -200), diag_base=6.0, seed=2)
+    row, col, val = synth.colmajor_coo(A)
+    mtx = str(tmp_path / "h.mtx")
+    _write_mtx(mtx, A, row, col, val)
+    L.bicg_mtx_load_block.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(H.CSRMatrix), C.POINTER(H.CSRMatrix), C.POINTER(H.InfoMatrix)]
+    L.bicg_mtx_set_block_builder.argtypes = [C.c_void_p]
+    plain = (H.CSRMatrix(), H.CSRMatrix(), H.InfoMatrix())
+    assert L.bicg_mtx_load_block(mtx.encode(), 1, 3, *map(C.byref, plain)) == 0
+    L.bicg_mtx_set_block_builder(C.cast(cb, C.c_void_p))
+    try:
+        hooked = (H.CSRMatrix(), H.CSRMatrix(), H.InfoMatrix())
+        assert L.bicg_mtx_load_block(mtx.encode(), 1, 3, *map(C.byref, hooked)) == 0
+    finally:
+        L.bicg_mtx_set_block_builder(None)
+    assert len(seen) == 1 and seen[0][1:] == (167, 334)
+    for a, b in zip(plain[:2], hooked[:2]):
+        n = a.rows
+        assert b.rows == n and b.cols == a.cols
+        pa, pb = np.ctypeslib.as_array(a.ptr, shape=(n + 1,)), np.ctypeslib.as_array(b.ptr, shape=(n + 1,))
+        assert np.array_equal(pa, pb)
+        nz = int(pa[-1])
+        if nz:
+            assert np.array_equal(np.ctypeslib.as_array(a.col, shape=(nz,)), np.ctypeslib.as_array(b.col, shape=(nz,)))
+            assert np.array_equal(np.ctypeslib.as_array(a.val, shape=(nz,)), np.ctypeslib.as_array(b.val, shape=(nz,)))
