@@ -13,9 +13,9 @@ W+K timed iterations are genuine unconverged iterations (the real Transport need
 side b = A*1, x0 = 0 (reference src/main.c:109-117). With N GPUs the SAME matrix is row-partitioned
 exactly like the reference does (src/matrix.c:295-308): strong scaling; halo values and packed dot
 sums are stored by the producing kernels straight into the other GPUs' memory over xGMI (HIP-IPC
-mapped mailboxes, libbicgstab_hip.so's bicg_p2p.cpp) once that path's self-test has passed on every
-rank, otherwise they go through RCCL; torch.distributed (gloo) is only the bootstrap and the timing
-barrier.
+mapped mailboxes, libbicgstab_hip.so's bicg_p2p.cpp; the IPC handles are exchanged over gloo at
+set-up) once that path's self-test has passed on every rank, otherwise they go through an RCCL
+communicator; torch.distributed (gloo) is only the bootstrap and the timing barrier.
 
 Matrix and vectors are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
 """
@@ -63,9 +63,9 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host", "host-p2p"],
-                    help="auto (default): RCCL communicator, one GPU per rank, data path switched to direct "
-                         "peer-to-peer stores over xGMI when the library's self-test passes on every rank. rccl: RCCL "
-                         "collectives only. host: gloo-staged exchanges, ranks may share a GPU -- only for exercising "
+                    help="auto (default): direct peer-to-peer stores over xGMI between the kernels (IPC handles "
+                         "exchanged over gloo) when the library's self-test passes on every rank, otherwise an RCCL "
+                         "communicator, one GPU per rank. rccl: RCCL collectives only. host: gloo-staged exchanges, ranks may share a GPU -- only for exercising "
                          "the multi-rank plumbing on a one-GPU box. host-p2p: the same with the peer-to-peer data path")
     ap.add_argument("--force-comm", action="store_true",
                     help="one rank only: run the multi-rank code path anyway (1-rank RCCL communicator) -- measures what "
@@ -135,10 +135,21 @@ def main():
                 ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
             dist.broadcast(ident, src=0)
             raw = bytes(ident.numpy().tobytes())
+            from mpi_bicgstab_amd import dist_transport
+            if a.transport == "auto" and use_p2p:
+                # the peer-to-peer data path only needs a host-side exchange of IPC handles at set-up: bootstrap
+                # it over gloo, so that RCCL is not even initialised unless the self-test fails somewhere
+                dist_transport.init_host_transport(device)
+                L.bicg_comm_enable_p2p()          # collective; every rank gets the same verdict
+                if int(L.bicg_comm_p2p_active()):
+                    mode = int(L.bicg_comm_p2p_active())
+                    return mode, (f"peer-to-peer LL stores over xGMI (HIP IPC, {'uncached' if mode == 2 else 'device'} memory; "
+                                  "bootstrap gloo)")
+                L.bicg_comm_finalize()
+                use_p2p = False
             if a.transport in ("auto", "rccl"):
                 L.bicg_comm_init_rccl(rank, world, raw, device)
             else:
-                from mpi_bicgstab_amd import dist_transport
                 dist_transport.init_host_transport(device)
             if use_p2p:
                 L.bicg_comm_enable_p2p()      # collective; leaves the transport as it is when the self-test fails
