@@ -107,3 +107,30 @@ def test_c_host_ingest_options(mtx, np_, tmp_path):
     assert np.array_equal(miss, base) and np.array_equal(hit, base)
     bal, out3 = run({"BICG_PARTITION": "nnz"}, "nnz")
     assert np.abs(bal - 1.0).max() <= 1e-9
+
+
+@need
+def test_c_host_two_ranks_peer_to_peer_over_mpi(mtx, tmp_path):
+    """BICG_TRANSPORT=p2p under mpiexec -n 2: the IPC handles travel through MPI_Alltoallv (weak symbols),
+    the data path is the kernels' own LL stores. Same solve as the host-staged run up to the association of
+    the dot sums (the fused exchange lists the halo-touching row groups last, so the workgroup partials
+    are added in a different order)."""
+    def run(env_extra, tag):
+        env = dict(os.environ, BICG_CHECK_EVERY="4", **env_extra)
+        prefix = str(tmp_path / tag)
+        out = subprocess.run([MPIEXEC, "-n", "2", HOST, mtx, "bicgstab", "--dump", prefix], capture_output=True, text=True,
+                             timeout=300, env=env)
+        assert out.returncode == 0, out.stdout + out.stderr
+        xs = []
+        for p in range(2):
+            raw = open(f"{prefix}.rank{p}.bin", "rb").read()
+            nl = int(np.frombuffer(raw[4:8], dtype=np.int32)[0])
+            xs.append(np.frombuffer(raw[8:8 + 8 * nl], dtype=np.float64))
+        k = int(re.search(r"Total iter\s*:\s*(\d+)", out.stdout).group(1))
+        return k, np.concatenate(xs), out.stdout + out.stderr
+
+    k0, x0, _ = run({"BICG_TRANSPORT": "host"}, "host")
+    k1, x1, log = run({"BICG_TRANSPORT": "p2p", "BICG_P2P_TIMEOUT_MS": "5000"}, "p2p")
+    assert "not available" not in log, log
+    assert abs(k1 - k0) <= 1 and np.abs(x1 - x0).max() <= 1e-11
+    assert np.abs(x1 - 1.0).max() <= 1e-9
