@@ -161,3 +161,29 @@ def test_partition_nnz_edge_cases():
     assert (counts >= 1).all()
     uniform, _ = cut(np.full(1000, 15), 8)                 # uniform rows: the equal-rows partition
     assert np.array_equal(uniform, np.full(8, 125))
+
+
+def test_hot_kernels_stay_lean():
+    """The dot epilogue is inlined into every dot-producing kernel; when rarely used paths (seed switching,
+    peer-to-peer collect) leak into the hot instantiations they cost 26 VGPRs and three waves per SIMD
+    (DESIGN.md section 4.3). The compiler's resource report of the last build must show the single-GPU hot
+    kernels at <= 64 VGPRs, occupancy 8, no scratch."""
+    path = os.path.join(ROOT, "mpi-bicgstab_amd", "build", "kernel_resources.txt")
+    if not os.path.exists(path):
+        pytest.skip("no resource report (library not built here)")
+    kernels, cur = {}, None
+    for line in open(path):
+        m = re.search(r"Function Name: (\S+)", line)
+        if m:
+            cur = m.group(1)
+            kernels[cur] = {}
+            continue
+        m = re.search(r"remark:\s+([A-Za-z \[\]/]+):\s*(\d+)", line)
+        if m and cur:
+            kernels[cur][m.group(1).strip()] = int(m.group(2))
+    hot = [k for k in kernels if re.search(r"k_spmv_sellILi[0-3]ELb0ELb[01]ELb[01]ELb0ELb0EEEv", k)]      # no offd, no LL, light
+    hot += [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELb0EEEv", k)]
+    assert len(hot) >= 20, sorted(kernels)[:5]
+    for k in hot:
+        r = kernels[k]
+        assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
