@@ -1,0 +1,37 @@
+"""bench.py / __graft_entry__.py driver contract, the parts that can be checked without a GPU."""
+import os
+import re
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_bench_flags_and_loud_failure_without_gpu():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for flag in ("--gpus", "--steps", "--warmup"):
+        assert f'"{flag}"' in src
+    import torch
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py")], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0                       # no CPU fallback: the HIP path or nothing
+    assert "needs a GPU" in (out.stderr + out.stdout)
+    assert out.stdout.strip() == ""                  # and no fake result line on stdout
+
+
+def test_bench_json_keys_are_the_contract():
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
+        assert re.search(rf'"{key}"\s*:', src), key
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+        assert re.search(rf'"{key}"\s*:', src), key
+    for key in ("value", "unit", "cores", "kind", "sample"):
+        assert re.search(rf'\b{key}=|"{key}"', open(os.path.join(ROOT, "tools", "cpu_baseline.py")).read()), key
+
+
+def test_graft_entry_has_build_and_smoke():
+    sys.path.insert(0, ROOT)
+    import __graft_entry__ as g
+    assert callable(g.build) and callable(g.smoke)
