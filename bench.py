@@ -95,7 +95,7 @@ def main():
                   flush=True)
         os._exit(3)
 
-    watchdog_s = int(os.environ.get("BENCH_WATCHDOG_S", "1500"))
+    watchdog_s = int(os.environ.get("BENCH_WATCHDOG_S", "900"))
     stage = ["start"]
     dog = threading.Timer(watchdog_s, _give_up)
     dog.daemon = True
@@ -119,7 +119,7 @@ def main():
     dist = None
     stage[0] = "communicator bootstrap"
     os.environ.setdefault("BICG_P2P_SOFT_FAIL", "1")     # a peer-to-peer time-out becomes a fallback, not an exit
-    os.environ.setdefault("BICG_P2P_TIMEOUT_MS", "20000")  # ranks are aligned by barriers here: 20 s means a lost peer
+    os.environ.setdefault("BICG_P2P_TIMEOUT_MS", "8000")   # ranks are aligned by barriers here: 8 s means a lost peer
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")

@@ -241,6 +241,11 @@ int bicg_comm_failed(bicg_ctx *ctx);
 /* plan facts: local rows, diag nnz, offd nnz, halo length, workgroups per SpMV, halo-touching
  * workgroups, rows on the sliced-ELL path, sliced-ELL padding entries */
 int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);
+/* which code paths this context takes (tests assert on them): peer-to-peer data path in use; halo exchange
+ * folded into the sliced-ELL SpMV launch; two-stream overlap mode; 16-bit column offsets; every 256-row
+ * group on the sliced-ELL path */
+enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FLAG_COL16 = 8, BICG_FLAG_ALL_SELL = 16 };
+unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * 5. Host-only helpers (no GPU needed; unit-tested on CPU).

@@ -136,7 +136,52 @@ struct Reduce {
     int       red_off;     // sums land in Scal::red[red_off + d]
     int       phase;       // Phase applied by the finishing thread when apply_now
     int       apply_now;   // single rank: apply the phase in-kernel; multi rank: host all-reduces first
+    int       wave;        // 1: consumer-side finish -- store one partial per wavefront at row
+                           // (slot_base + workgroup) * 4 + wave and end (see Finish); nothing else is used
     P2pRed    p2p;         // peer-to-peer transport: where the finished sums are published
+};
+
+// ---- consumer-side finish of a dot group (the four solvers of reference src/solver.c) -------------
+// A kernel that PRODUCES dot sums only stores one partial per wavefront (wave shuffle, one plain
+// store, no barrier, no atomic, no ticket) and ends. The sums are completed by the kernel that
+// CONSUMES the scalars: its first kShards workgroups add up one shard of the partials each and
+// publish the shard totals as LL words (payload + sequence tag in one 8-byte store); every
+// workgroup then waits for the kShards totals, adds them in shard order, applies the scalar
+// recurrence (alpha = rTr/rTs ...) on a PRIVATE copy of the scalar block, and workgroup 0 writes
+// that copy to the other of two alternating scalar blocks (late workgroups of the same launch
+// still read the old one). The dependent chain partial -> ticket -> shard sum -> ticket -> total ->
+// apply that used to end every producer (9 us of a 56 us Transport SpMV) is gone from the
+// producers, and in the consumers it runs underneath their first vector loads.
+// Summation order is fixed by slot numbers: bit-reproducible, whoever computes a shard.
+enum FinishRole : int {
+    FIN_SHARDS  = 1,   // workgroups < kShards sum the shards and publish the shard totals
+    FIN_PUSH    = 2,   // peer-to-peer: workgroup 0 stores the local sums into every rank's mailbox
+    FIN_APPLY   = 4,   // every workgroup: global sums -> recurrence on a private copy; workgroup 0 writes Snext
+    FIN_BLOCK0  = 8,   // workgroup 0 only, IN PLACE on S: SpMV launches (phase PH_NONE: the other workgroups
+                       // read nothing but `done`) and the stand-alone finisher (any phase)
+    FIN_LOCAL   = 16,  // with FIN_BLOCK0: deposit this rank's sums only (the host enqueues an all-reduce)
+};
+struct Finish {
+    const double *partial;   // [nparts][kPartialStride] one row per producing wavefront
+    llword  *shard;          // [kShards][kRedSlots][2] LL words, tag = seq
+    unsigned nparts;
+    unsigned seq;            // 0 = nothing to finish
+    int      n, red_off;     // sums land in red[red_off .. red_off + n)
+    int      phase;          // Phase applied with FIN_APPLY
+    int      roles;
+    Scal    *Snext;          // FIN_APPLY: the scalar block later kernels read
+    int     *alarm;          // peer-to-peer: raised when a wait for a peer timed out (every later wait returns at once)
+    unsigned long long spin_ticks;   // wait this long (100 MHz) for a shard before summing it ourselves
+    P2pRed   p2p;            // p2p.seq != 0: sums are exchanged through the mailboxes
+};
+
+// what every launch wrapper needs: the scalar block to read, the group to finish (if any), the
+// stream, and which reduction epilogue the kernel is built with
+enum RedMode : int { RED_TICKET = 0, RED_TICKET_HEAVY = 1, RED_WAVE = 2 };
+struct Launch {
+    Scal *S;
+    Finish fin;
+    hipStream_t st;
 };
 
 struct CsrDev {
@@ -214,6 +259,7 @@ bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hi
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                       bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
 void launch_apply(Scal *S, int phase, hipStream_t st);
+void launch_finish(const Launch &L);   // stand-alone finisher: L.fin with FIN_BLOCK0
 void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);
 // peer-to-peer transport: wait for the P contributions of group pr.seq, sum n values, apply `phase`
 void launch_apply_p2p(Scal *S, int phase, int n, const P2pRed &pr, unsigned long long timeout_ticks, hipStream_t st);

@@ -35,11 +35,13 @@ static void launch_timed(K kernel, dim3 g, dim3 b, hipStream_t st, hipEvent_t e0
 // ------------------------------------------------------------------------------------------
 // scalar recurrences (one thread)
 // ------------------------------------------------------------------------------------------
-__device__ __forceinline__ void finish_iteration(Scal *S, double alpha_used)
+// publish = false: the caller works on a private copy of the scalar block (consumer-side finish);
+// the per-iteration trace in global memory is written by the one workgroup that publishes
+__device__ __forceinline__ void finish_iteration(Scal *S, double alpha_used, bool publish)
 {
     S->k += 1;
     const int k = S->k;
-    if (S->tr_dotr && k <= S->max_iter) {
+    if (publish && S->tr_dotr && k <= S->max_iter) {
         S->tr_alpha[k - 1] = alpha_used;
         S->tr_omega[k - 1] = S->omega;
         S->tr_beta[k - 1]  = S->beta;
@@ -56,7 +58,7 @@ __device__ __forceinline__ void finish_iteration(Scal *S, double alpha_used)
     }
 }
 
-__device__ __forceinline__ void apply_phase(Scal *S, int phase)
+__device__ __forceinline__ void apply_phase(Scal *S, int phase, bool publish = true)
 {
     const double *d = S->red;
     switch (phase) {
@@ -79,7 +81,7 @@ __device__ __forceinline__ void apply_phase(Scal *S, int phase)
         S->rTr_old = S->rTr;
         S->rTr = d[1];
         S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);
-        finish_iteration(S, S->alpha);
+        finish_iteration(S, S->alpha, publish);
         break;
     }
     case PH_RECUR_END: {
@@ -90,7 +92,7 @@ __device__ __forceinline__ void apply_phase(Scal *S, int phase)
         const double rTw = d[2], rTs = d[3], rTz = d[4];
         S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);
         S->alpha = S->rTr / (rTw + S->beta * (rTs - S->omega * rTz));
-        finish_iteration(S, alpha_used);
+        finish_iteration(S, alpha_used, publish);
         break;
     }
     default: break;
@@ -681,6 +683,203 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
     }
 }
 
+
+// ------------------------------------------------------------------------------------------
+// consumer-side finish of a dot group (struct Finish, bicg_device.h)
+// ------------------------------------------------------------------------------------------
+// producer epilogue: one partial per WAVEFRONT -- shuffle, one plain store per sum, done. No
+// barrier, no atomic: the kernel boundary in front of the consuming kernel makes it visible.
+template <int ND>
+__device__ __forceinline__ void wave_publish(double (&acc)[ND], double *partial, unsigned wg_slot)
+{
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = wave_sum(acc[d]);
+    if (lane == 0) {
+        double *row = partial + ((size_t)wg_slot * (kBlock / 64) + wave) * kPartialStride;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) row[d] = acc[d];
+    }
+}
+
+// LL words inside one GPU (agent scope): shard totals travel from the summing workgroup to every
+// workgroup of the same launch
+__device__ __forceinline__ void ll_store_agent(llword *dst, double v, unsigned seq)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const unsigned long long tag = (unsigned long long)seq << 32;
+    __hip_atomic_store(dst, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ bool ll_try_agent(const llword *src, unsigned seq, unsigned long long ticks, double *out)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spin = 0;; ++spin) {
+        const unsigned long long w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        const unsigned long long w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if ((unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq) {
+            *out = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+            return true;
+        }
+        if ((spin & 15u) == 15u) {
+            if (wall_clock64() - t0 > ticks) return false;
+            __builtin_amdgcn_s_sleep(1);
+        }
+    }
+}
+
+struct FinishLds {
+    double vals[kShards * kMaxDots];          // shard totals
+    double pv[kRedSlots * kMaxRanksP2p];      // peer-to-peer: every rank's sums
+    double sums[kRedSlots];
+    double bs[5 * kMaxDots];                  // block_sum scratch
+    unsigned missing;
+    int fail;
+};
+
+// whole workgroup: add up shard `shard` of the group's partials (slot order) and publish the total
+__device__ __forceinline__ void finish_sum_shard(const Finish &f, unsigned shard, FinishLds &L)
+{
+    const unsigned members = shard < f.nparts ? (f.nparts - shard + kShards - 1) / kShards : 0u;
+    double tot[kMaxDots];
+#pragma unroll
+    for (int d = 0; d < kMaxDots; ++d) tot[d] = 0.0;
+    for (unsigned i = threadIdx.x; i < members; i += kBlock) {
+        const double *row = f.partial + ((size_t)shard + (size_t)i * kShards) * kPartialStride;
+#pragma unroll
+        for (int d = 0; d < kMaxDots; ++d)
+            if (d < f.n) tot[d] += row[d];
+    }
+    block_sum<kMaxDots>(tot, L.bs);
+    if ((int)threadIdx.x < f.n)
+        ll_store_agent(f.shard + ((size_t)shard * kRedSlots + threadIdx.x) * 2, tot[threadIdx.x], f.seq);
+}
+
+// whole workgroup: L.sums[0..n) <- the group's sums over this GPU's partials and (peer-to-peer) over
+// all ranks. Nobody is waited for longer than spin_ticks inside the GPU: a shard total that has not
+// shown up by then is computed here (same partials, same order, same bits), so the result does
+// not depend on the order in which the hardware dispatches workgroups. False: a PEER timed out.
+__device__ __forceinline__ bool finish_totals(const Finish &f, FinishLds &L, bool block0)
+{
+    const unsigned tid = threadIdx.x;
+    const bool exchange = f.p2p.seq != 0 && !(f.roles & FIN_LOCAL);
+    if (!exchange || (f.roles & FIN_PUSH)) {
+        for (;;) {
+            if (tid == 0) L.missing = 0u;
+            __syncthreads();
+            if ((int)tid < kShards * f.n) {
+                const int sh = (int)tid / f.n, d = (int)tid % f.n;
+                double v;
+                if (ll_try_agent(f.shard + ((size_t)sh * kRedSlots + d) * 2, f.seq, f.spin_ticks, &v)) L.vals[sh * kMaxDots + d] = v;
+                else atomicOr(&L.missing, 1u << sh);
+            }
+            __syncthreads();
+            const unsigned m = L.missing;
+            if (!m) break;
+            for (unsigned sh = 0; sh < (unsigned)kShards; ++sh)
+                if ((m >> sh) & 1u) finish_sum_shard(f, sh, L);
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            __syncthreads();
+        }
+        if ((int)tid < f.n) {
+            double t = 0.0;
+            for (int sh = 0; sh < kShards; ++sh) t += L.vals[sh * kMaxDots + tid];
+            L.sums[tid] = t;
+        }
+        __syncthreads();
+    }
+    if (!exchange) return true;
+    const int P = f.p2p.nranks;
+    if ((f.roles & FIN_PUSH) && block0)
+        for (int t = tid; t < f.n * P; t += kBlock) {
+            const int p = t / f.n, d = t % f.n;
+            ll_store(f.p2p.mail[p] + mail_index(f.p2p.seq, P, f.p2p.rank, f.red_off + d), L.sums[d], f.p2p.seq);
+        }
+    if (!(f.roles & (FIN_APPLY | FIN_BLOCK0))) return true;
+    if (tid == 0) L.fail = 0;
+    __syncthreads();
+    const llword *mine = f.p2p.mail[f.p2p.rank];
+    for (int t = tid; t < f.n * P; t += kBlock) {
+        const int p = t / f.n, d = t % f.n;
+        double v;
+        if (p == f.p2p.rank && (f.roles & FIN_PUSH)) v = L.sums[d];
+        else if (!ll_wait(mine + mail_index(f.p2p.seq, P, p, f.red_off + d), f.p2p.seq, f.p2p.timeout_ticks, &v)) L.fail = 1;
+        L.pv[p * kRedSlots + d] = v;
+    }
+    __syncthreads();
+    if (L.fail) return false;
+    if ((int)tid < f.n) L.sums[tid] = rank_tree_sum(L.pv + tid, P);
+    __syncthreads();
+    return true;
+}
+
+// Prologue of a kernel that carries a Finish. bid / nblocks: this workgroup's index among the
+// workgroups that take part (SpMV launches exclude their leading halo-push workgroups).
+// Returns the scalar block the kernel has to read: S itself, or -- FIN_APPLY -- the private copy
+// *priv (LDS) on which the recurrence has been applied; workgroup 0 has then written it to
+// f.Snext as well, also when the solve is already `done` (the host switches blocks regardless).
+__device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, unsigned bid, unsigned nblocks, FinishLds &L,
+                                                    Scal *priv)
+{
+    const unsigned tid = threadIdx.x;
+    const bool all = (f.roles & FIN_APPLY) != 0, block0 = bid == 0;
+    if (all && S->done) {
+        if (block0 && tid == 0) *f.Snext = *S;
+        return S;
+    }
+    if (f.alarm && *f.alarm) {           // a peer was lost earlier: nothing will ever arrive
+        if (all) {
+            if (tid == 0) { *priv = *S; priv->done = 1; priv->comm_error = 1; if (block0) *f.Snext = *priv; }
+            __syncthreads();
+            return priv;
+        }
+        return S;
+    }
+    if (f.roles & FIN_SHARDS)
+        for (unsigned sh = bid; sh < (unsigned)kShards; sh += nblocks) finish_sum_shard(f, sh, L);
+    const bool consume = all || (block0 && (f.roles & (FIN_BLOCK0 | FIN_PUSH)));
+    if (!consume) return S;
+    const bool ok = finish_totals(f, L, block0);
+    if (!(f.roles & (FIN_APPLY | FIN_BLOCK0))) return S;
+    if (tid == 0) {
+        if (!ok && f.alarm) *f.alarm = 1;
+        if (all) {
+            Scal P = *S;
+            if (ok) {
+                for (int d = 0; d < f.n; ++d) P.red[f.red_off + d] = L.sums[d];
+                if (f.phase != PH_NONE) apply_phase(&P, f.phase, block0);
+            } else {
+                P.done = 1; P.comm_error = 1;
+            }
+            *priv = P;
+            if (block0) *f.Snext = P;
+        } else if (ok) {
+            // workgroup 0 alone, in place: the other workgroups of this launch read nothing but `done`
+            // (SpMV launches deposit sums only; the stand-alone finisher has no other reader)
+            for (int d = 0; d < f.n; ++d) S->red[f.red_off + d] = L.sums[d];
+            if (f.phase != PH_NONE) apply_phase(S, f.phase, true);
+        } else {
+            S->done = 1; S->comm_error = 1;
+        }
+    }
+    if (!all) return S;
+    __syncthreads();
+    return priv;
+}
+
+// stand-alone finisher (set-up phases, host reads, transports whose all-reduce the host enqueues)
+__global__ void __launch_bounds__(kBlock) k_finish(Scal *S, Finish f)
+{
+    __shared__ FinishLds L;
+    if (blockIdx.x == 0 && S->done) return;
+    (void)finish_group(S, f, blockIdx.x, gridDim.x, L, nullptr);
+}
+
+void launch_finish(const Launch &L)
+{
+    hipLaunchKernelGGL(k_finish, dim3(L.fin.roles & FIN_SHARDS ? kShards : 1), dim3(kBlock), 0, L.st, L.S, L.fin);
+}
+
 // ------------------------------------------------------------------------------------------
 // CSR SpMV, row-block stream
 // ------------------------------------------------------------------------------------------
@@ -927,8 +1126,11 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
                                      ((size_t)base16 / 4 + (size_t)((k0 / 4) + q) * kSliceRows + lane);
                     i16x4 dq = (i16x4)(0);
                     if (ok) dq = NT ? __builtin_nontemporal_load(p) : *p;
-                    c[4 * q + 0] = row + (int)dq.x; c[4 * q + 1] = row + (int)dq.y;
-                    c[4 * q + 2] = row + (int)dq.z; c[4 * q + 3] = row + (int)dq.w;
+                    // lanes past the last row hold padding only: their offsets are 0 and must not turn into
+                    // reads of x[row >= nrows] (the vector may end before the 64-row slice does)
+                    const uint32_t rb = live ? row : 0u;
+                    c[4 * q + 0] = rb + (int)dq.x; c[4 * q + 1] = rb + (int)dq.y;
+                    c[4 * q + 2] = rb + (int)dq.z; c[4 * q + 3] = rb + (int)dq.w;
                 }
             }
 #pragma unroll

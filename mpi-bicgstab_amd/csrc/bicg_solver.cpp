@@ -1441,6 +1441,17 @@ int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
     return 0;
 }
 
+unsigned int bicg_ctx_flags(bicg_ctx *c)
+{
+    unsigned f = 0;
+    if (c->p2p) f |= BICG_FLAG_P2P;
+    if (c->ll_fused) f |= BICG_FLAG_LL_FUSED;
+    if (c->overlap) f |= BICG_FLAG_OVERLAP;
+    if (c->s_col16) f |= BICG_FLAG_COL16;
+    if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
+    return f;
+}
+
 int bicg_solve_shifted(bicg_ctx *c, int variant, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len,
                        int seed, const bicg_options *opt, bicg_result *res)
 {

@@ -178,3 +178,66 @@ def gpu_worker(rank, world, port, kind, outdir):
     except Exception:
         open(os.path.join(outdir, f"fail{rank}"), "w").write(traceback.format_exc())
         raise
+
+
+def fullsize_worker(rank, world, port, kind, outdir):
+    """GPU box: `world` ranks (4 or 8) share cuda:0 and hold the reference's row partition
+    (src/matrix.c:295-308) of the FULL-SIZE Transport-shaped matrix -- 200 k-row slabs with their
+    +-13 807-column halos at world = 8 (BASELINE.json configs[2]). `kind` = "host" (gloo-staged
+    exchanges) or "host-p2p" (kernels store into IPC-mapped mailboxes / halo rings). Distributed SpMV
+    bit-exact against the oracle at the same P; the first iterations of all four solvers against
+    the oracle's trajectory. The oracle's outputs come from the parent (one CPU run per P)."""
+    try:
+        import numpy as np
+        dist = _init(rank, world, port)
+        from mpi_bicgstab_amd import hipsolver as H, synth
+        from mpi_bicgstab_amd import dist_transport as T
+
+        os.environ.setdefault("BICG_P2P_TIMEOUT_MS", "20000")
+        T.init_host_transport(0)
+        p2p = kind == "host-p2p"
+        if p2p:
+            assert H.lib().bicg_comm_enable_p2p() == 0, "peer-to-peer transport did not come up"
+            assert H.lib().bicg_comm_p2p_active() > 0
+        ref = np.load(os.path.join(outdir, "oracle.npz"))
+        n = int(ref["n"]); k_fix = int(ref["k_fix"])
+        counts, displs = synth.partition(n, world)
+        lo, nl = int(displs[rank]), int(counts[rank])
+        slab = synth.transport_like(n=n, rows=(lo, lo + nl), scale_decades=float(ref["scale_decades"]))
+        diag, offd = synth.split_row_slab(slab, lo)
+        ctx = H.Context(H.HostBlocks(diag, offd, n, counts, displs))
+        info, flags = ctx.plan_info(), ctx.flags()
+        assert info["halo"] > 0 and info["boundary_blocks"] > 0
+        assert info["sell_rows"] == nl and flags["all_sell"] and flags["col16"]
+        assert flags["p2p"] == p2p
+        if p2p:
+            assert flags["ll_fused"], "banded slab: the halo exchange must be folded into the SpMV launch"
+        # distributed SpMV: every row bit for bit; enough back-to-back exchanges to wrap the landing ring
+        for rep in range(11 if p2p else 2):
+            x = ref["x_in"] * (1.0 + 0.125 * rep)
+            y = ctx.spmv(x[lo:lo + nl])
+            if rep == 0:
+                assert np.array_equal(y, ref["y"][lo:lo + nl]), "distributed SpMV is not bit-exact"
+            else:
+                # scaling x by 1 + rep/8 scales products and sums: not bit-comparable with the stored y, but
+                # a stale halo value (ring slot of an earlier exchange) would show up at the 1e-1 level
+                np.testing.assert_allclose(y, ref["y"][lo:lo + nl] * (1.0 + 0.125 * rep), rtol=1e-12, atol=1e-9)
+        b = ctx.spmv(np.ones(nl))
+        assert np.array_equal(b, ref["b"][lo:lo + nl])
+        for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
+            got = ctx.solve(method, b, tol=0.0, max_iter=k_fix, krr=5, nrr=1, check_every=k_fix)
+            assert got["k"] == k_fix, (method, got["k"])
+            tr = ctx.trace(k_fix)
+            for key in ("alpha", "omega", "beta", "dotr"):
+                np.testing.assert_allclose(tr[key], ref[f"{method}_{key}"], rtol=1e-7, err_msg=f"{method} {key}")
+            xo = ref[f"{method}_x"]
+            assert np.abs(got["x"] - xo[lo:lo + nl]).max() <= 1e-8 * np.abs(xo).max(), method
+        assert not ctx.comm_failed()
+        ctx.close()
+        dist.barrier()
+        H.lib().bicg_comm_finalize()
+        dist.destroy_process_group()
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    except Exception:
+        open(os.path.join(outdir, f"fail{rank}"), "w").write(traceback.format_exc())
+        raise
