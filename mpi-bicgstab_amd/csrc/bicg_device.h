@@ -164,6 +164,8 @@ enum FinishRole : int {
 struct Finish {
     const double *partial;   // [nparts][kPartialStride] one row per producing wavefront
     llword  *shard;          // [kShards][kRedSlots][2] LL words, tag = seq
+    llword  *shard_clear;    // the previous group's LL words: zeroed by workgroup 0, so that a launch that is
+                             // replayed with the same tag (hipGraph) never meets its own earlier words
     unsigned nparts;
     unsigned seq;            // 0 = nothing to finish
     int      n, red_off;     // sums land in red[red_off .. red_off + n)
@@ -244,6 +246,7 @@ struct SpmvArgs {
     int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
     HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only
+    Finish  fin;            // a dot group of earlier kernels to finish in this launch (seq 0: none)
 };
 
 // element-wise phase kernels: pointers to the rank-local vectors
@@ -277,24 +280,26 @@ void launch_p2p_barrier(const P2pRed &pr, unsigned long long timeout_ticks, Scal
 void launch_p2p_selftest(const P2pRed &pr, unsigned seq0, int rounds, unsigned long long timeout_ticks, int *status,
                          hipStream_t st);
 
+// The kernels of the four solvers take a Launch: the scalar block to read, the dot group of earlier
+// kernels to finish first (if any) and the stream.
 // init: r = b - Ax ; rh = r ; [p = r] ; [bsave = b] ; dot (r,r)
-void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, Scal *S, Reduce red, hipStream_t st);
+void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, const Launch &L, Reduce red);
 // plain BiCGStab phases (src/solver.c:94, 105-111, 117-119)
-void launch_plain_q(const Vecs &v, Scal *S, hipStream_t st);
-void launch_plain_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
-void launch_plain_p(const Vecs &v, Scal *S, hipStream_t st);
+void launch_plain_q(const Vecs &v, const Launch &L);
+void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red);
+void launch_plain_p(const Vecs &v, const Launch &L);
 // CA-BiCGStab phases (src/solver.c:217-222, 225-228, 233-236 + 240-243)
-void launch_ca_ps(const Vecs &v, Scal *S, hipStream_t st);
-void launch_qy(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
-void launch_ca_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_ca_ps(const Vecs &v, const Launch &L);
+void launch_qy(const Vecs &v, const Launch &L, Reduce red);
+void launch_ca_xr(const Vecs &v, const Launch &L, Reduce red);
 // pipelined phases (src/solver.c:352-364, 370-380)
-void launch_pipe_f1(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
-void launch_pipe_f2(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_pipe_f1(const Vecs &v, const Launch &L, Reduce red);
+void launch_pipe_f2(const Vecs &v, const Launch &L, Reduce red);
 // residual-replacement steps (src/solver.c:494-496, 519-520, 524-525, 533-538)
-void launch_p_update(const Vecs &v, Scal *S, hipStream_t st);
-void launch_x_update(const Vecs &v, Scal *S, hipStream_t st);
-void launch_true_residual(const Vecs &v, Scal *S, hipStream_t st);
-void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_p_update(const Vecs &v, const Launch &L);
+void launch_x_update(const Vecs &v, const Launch &L);
+void launch_true_residual(const Vecs &v, const Launch &L);
+void launch_dots5(const Vecs &v, const Launch &L, Reduce red);
 // shifted BiCGStab (reference src/shifted_solver.c:182-354)
 void launch_shift_init(const Vecs &v, double *p_seed, Scal *S, Reduce red, hipStream_t st);      // r# = r, p[seed] = r, (r,r)
 void launch_shift_q(const Vecs &v, Scal *S, hipStream_t st);                                     // r_old = r ; q = r - alpha s
@@ -316,7 +321,7 @@ void launch_sw_shifts(const Vecs &v, const double *qcopy, double *p_set, double 
                       const ShiftDev *H, Scal *S, hipStream_t st);
 void launch_scale(double *x, uint32_t n, double a, hipStream_t st);                        // x <- a x (my_dscal)
 // adaptive residual replacement: red[0] = ||(b - Ax) - r||^2, red[1] = ||r||^2
-void launch_drift(const Vecs &v, Scal *S, Reduce red, hipStream_t st);
+void launch_drift(const Vecs &v, const Launch &L, Reduce red);
 // standalone dot (x,y) -> red[0]
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 

@@ -827,6 +827,8 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
         if (block0 && tid == 0) *f.Snext = *S;
         return S;
     }
+    if (block0 && f.shard_clear)
+        for (unsigned t = tid; t < (unsigned)(kShards * kRedSlots * 2); t += kBlock) f.shard_clear[t] = 0ull;
     if (f.alarm && *f.alarm) {           // a peer was lost earlier: nothing will ever arrive
         if (all) {
             if (tid == 0) { *priv = *S; priv->done = 1; priv->comm_error = 1; if (block0) *f.Snext = *priv; }
@@ -843,24 +845,19 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
     if (!(f.roles & (FIN_APPLY | FIN_BLOCK0))) return S;
     if (tid == 0) {
         if (!ok && f.alarm) *f.alarm = 1;
-        if (all) {
-            Scal P = *S;
-            if (ok) {
-                for (int d = 0; d < f.n; ++d) P.red[f.red_off + d] = L.sums[d];
-                if (f.phase != PH_NONE) apply_phase(&P, f.phase, block0);
-            } else {
-                P.done = 1; P.comm_error = 1;
-            }
-            *priv = P;
-            if (block0) *f.Snext = P;
-        } else if (ok) {
-            // workgroup 0 alone, in place: the other workgroups of this launch read nothing but `done`
-            // (SpMV launches deposit sums only; the stand-alone finisher has no other reader)
-            for (int d = 0; d < f.n; ++d) S->red[f.red_off + d] = L.sums[d];
-            if (f.phase != PH_NONE) apply_phase(S, f.phase, true);
+        // all: the recurrence runs on the private copy in LDS (other workgroups of this launch may still
+        // be reading S); otherwise workgroup 0 alone works in place: the other workgroups of an SpMV
+        // launch read nothing but `done` (sums are only deposited), the stand-alone finisher has no
+        // other reader
+        Scal *T = all ? priv : S;
+        if (all) *priv = *S;
+        if (ok) {
+            for (int d = 0; d < f.n; ++d) T->red[f.red_off + d] = L.sums[d];
+            if (f.phase != PH_NONE) apply_phase(T, f.phase, block0);
         } else {
-            S->done = 1; S->comm_error = 1;
+            T->done = 1; T->comm_error = 1;
         }
+        if (all && block0) *f.Snext = *priv;
     }
     if (!all) return S;
     __syncthreads();
@@ -899,9 +896,13 @@ template <bool NT, class T> __device__ __forceinline__ T stream_load(const T *p)
     return *p;
 }
 
-template <int NDOT, bool OFFD, bool NT, bool HEAVY>
+template <int NDOT, bool OFFD, bool NT, int MODE>
 __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 {
+    if (MODE == RED_WAVE) {
+        __shared__ FinishLds fl;
+        if (a.fin.seq) (void)finish_group(a.S, a.fin, blockIdx.x, gridDim.x, fl, nullptr);
+    }
     // The sticky convergence flag is requested here but only consumed where state would be
     // modified (y stores, dot publication): an early `if (done) return` would put one more
     // dependent global load in front of every workgroup's stream.
@@ -1006,7 +1007,10 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
         }
         __syncthreads();   // prod is rewritten by the next row block
     }
-    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1), HEAVY>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+    if (NDOT > 0 && !done) {
+        if (MODE == RED_WAVE) wave_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.red.partial, a.red.slot_base + blockIdx.x);
+        else reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+    }
 }
 
 // One workgroup per row block: the hardware dispatcher balances the ~12k workgroups of a
@@ -1018,17 +1022,28 @@ unsigned spmv_grid(uint32_t nlist)
     return nlist < (uint32_t)kSpmvMaxGrid ? nlist : (unsigned)kSpmvMaxGrid;
 }
 
+// which reduction epilogue / prologue a launch needs (RedMode)
+static inline int red_mode(const Reduce &red, const Finish &fin, bool has_dots)
+{
+    if (fin.seq || (has_dots && red.wave)) return RED_WAVE;
+    return has_dots && heavy_needed(red) ? RED_TICKET_HEAVY : RED_TICKET;
+}
+
 template <int NDOT, bool OFFD>
 static void launch_spmv_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     dim3 g(spmv_grid(a.nlist)), b(kBlock);
-    constexpr bool HV = NDOT > 0;        // without dots there is no epilogue to be heavy
-    if (HV && heavy_needed(a.red)) {
+    const int mode = red_mode(a.red, a.fin, NDOT > 0);
+    constexpr int HV = NDOT > 0 ? RED_TICKET_HEAVY : RED_TICKET;   // without dots there is no epilogue to be heavy
+    if (mode == RED_WAVE) {
+        if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true, RED_WAVE>, g, b, st, e0, e1, a);
+        else launch_timed(k_spmv<NDOT, OFFD, false, RED_WAVE>, g, b, st, e0, e1, a);
+    } else if (mode == RED_TICKET_HEAVY) {
         if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true, HV>, g, b, st, e0, e1, a);
         else launch_timed(k_spmv<NDOT, OFFD, false, HV>, g, b, st, e0, e1, a);
     } else {
-        if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true, false>, g, b, st, e0, e1, a);
-        else launch_timed(k_spmv<NDOT, OFFD, false, false>, g, b, st, e0, e1, a);
+        if (a.nt) launch_timed(k_spmv<NDOT, OFFD, true, RED_TICKET>, g, b, st, e0, e1, a);
+        else launch_timed(k_spmv<NDOT, OFFD, false, RED_TICKET>, g, b, st, e0, e1, a);
     }
 }
 
@@ -1062,7 +1077,7 @@ typedef short i16x4 __attribute__((ext_vector_type(4)));
 // C16: column indices are read as 16-bit offsets from the row (col = row + delta), four
 // consecutive entries of a lane packed in one 8-byte word: 10 instead of 12 bytes per non-zero.
 // Used when every entry of the sliced-ELL copy satisfies |col - row| < 32768 (banded matrices).
-template <int NDOT, bool OFFD, bool NT, bool C16, bool LL, bool HEAVY>
+template <int NDOT, bool OFFD, bool NT, bool C16, bool LL, int MODE>
 __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
@@ -1083,6 +1098,12 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
             return;
         }
         bid -= a.ll.npush; nblocks -= a.ll.npush;
+    }
+    if (MODE == RED_WAVE) {
+        // a dot group of EARLIER kernels rides on this launch: its first workgroups add up the shards
+        // (and hand the sums to the other ranks) while everybody else already streams the matrix
+        __shared__ FinishLds fl;
+        if (a.fin.seq) (void)finish_group(a.S, a.fin, bid, nblocks, fl, nullptr);
     }
 
     double acc[NDOT > 0 ? NDOT : 1];
@@ -1172,7 +1193,10 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
         if (NDOT == 3 && live) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
     }
     if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
-    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1), HEAVY>(acc, a.S, a.red, a.red.slot_base + bid, sm);
+    if (NDOT > 0 && !done) {
+        if (MODE == RED_WAVE) wave_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.red.partial, a.red.slot_base + bid);
+        else reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + bid, sm);
+    }
 }
 
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
@@ -1190,21 +1214,21 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 {
     if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
     dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u)), b(kBlock);
+#define SELL_MODE(ND, OF, LLV, MD)                                                                 \
+    do {                                                                                           \
+        if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV, MD>, g, b, st, e0, e1, a);          \
+        else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV, MD>, g, b, st, e0, e1, a);           \
+        else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV, MD>, g, b, st, e0, e1, a);          \
+        else launch_timed(k_spmv_sell<ND, OF, false, false, LLV, MD>, g, b, st, e0, e1, a);                  \
+    } while (0)
 #define SELL_CASE(ND, OF, LLV)                                                                     \
     do {                                                                                           \
         const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;                                  \
-        constexpr bool HV = (ND) > 0;                                                              \
-        if (HV && heavy_needed(a.red)) {                                                           \
-            if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV, HV>, g, b, st, e0, e1, a);     \
-            else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV, HV>, g, b, st, e0, e1, a);      \
-            else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV, HV>, g, b, st, e0, e1, a);     \
-            else launch_timed(k_spmv_sell<ND, OF, false, false, LLV, HV>, g, b, st, e0, e1, a);             \
-        } else {                                                                                   \
-            if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV, false>, g, b, st, e0, e1, a);  \
-            else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV, false>, g, b, st, e0, e1, a);   \
-            else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV, false>, g, b, st, e0, e1, a);  \
-            else launch_timed(k_spmv_sell<ND, OF, false, false, LLV, false>, g, b, st, e0, e1, a);          \
-        }                                                                                          \
+        const int mode = red_mode(a.red, a.fin, (ND) > 0);                                         \
+        constexpr int HV = (ND) > 0 ? RED_TICKET_HEAVY : RED_TICKET;                               \
+        if (mode == RED_WAVE) SELL_MODE(ND, OF, LLV, RED_WAVE);                                    \
+        else if (mode == RED_TICKET_HEAVY) SELL_MODE(ND, OF, LLV, HV);                             \
+        else SELL_MODE(ND, OF, LLV, RED_TICKET);                                                   \
     } while (0)
     if (fused_halo) {
         if (ndot == 0) SELL_CASE(0, true, true); else if (ndot == 1) SELL_CASE(1, true, true); else if (ndot == 2) SELL_CASE(2, true, true); else SELL_CASE(3, true, true);
@@ -1214,6 +1238,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
         if (ndot == 0) SELL_CASE(0, false, false); else if (ndot == 1) SELL_CASE(1, false, false); else if (ndot == 2) SELL_CASE(2, false, false); else SELL_CASE(3, false, false);
     }
 #undef SELL_CASE
+#undef SELL_MODE
     return true;
 }
 
@@ -1367,45 +1392,106 @@ __device__ __forceinline__ void st(double *p, uint32_t i, d2 v)
 }
 
 // F::ND dot products, F::load(S) fetches the scalars once, F::apply<T>(i, acc) handles element(s) i.
-template <class F, bool HEAVY>
-__global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce red)
+// Functors of the four solvers additionally split apply into fetch (all loads of an element pair,
+// none of which depends on a scalar) and compute: a kernel that finishes a dot group issues the
+// loads of its first pair BEFORE waiting for the sums, so the wait runs underneath them.
+// F::kModes: bit RedMode set = that instantiation is launched (keeps the others from being compiled).
+template <class F, class = void> struct vec_modes { static constexpr int value = (1 << RED_TICKET) | (1 << RED_TICKET_HEAVY); };
+template <class F> struct vec_modes<F, decltype((void)F::kModes)> { static constexpr int value = F::kModes; };
+template <class F, class = void> struct vec_split { static constexpr bool value = false; };
+template <class F> struct vec_split<F, decltype((void)F::kSplit)> { static constexpr bool value = F::kSplit; };
+constexpr int kWaveOnly = 1 << RED_WAVE, kAnyMode = (1 << RED_TICKET) | (1 << RED_TICKET_HEAVY) | (1 << RED_WAVE);
+
+template <class F, int MODE>
+__global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce red, Finish fin)
 {
-    if (S->done) return;
     constexpr int ND = F::ND > 0 ? F::ND : 1;
-    __shared__ double sm[5 * ND];
     double acc[ND];
 #pragma unroll
     for (int d = 0; d < ND; ++d) acc[d] = 0.0;
-    f.load(S);
     const uint32_t npair = n >> 1;
-    for (uint32_t i = blockIdx.x * kBlock + threadIdx.x; i < npair; i += gridDim.x * kBlock)
-        f.template apply<d2>(2 * i, acc);
-    if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
-    if (F::ND > 0) reduce_publish<ND, HEAVY>(acc, S, red, blockIdx.x, sm);
+    const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+    if constexpr (MODE == RED_WAVE) {
+        __shared__ FinishLds fl;
+        __shared__ Scal priv;
+        const Scal *sc = S;
+        if constexpr (vec_split<F>::value) {
+            typename F::template In<d2> pre{};
+            const bool have = i0 < npair;
+            // Loads return in issue order (vmcnt), so a workgroup that sums a shard must not queue its
+            // partial-sum loads behind its own vector loads: the shard totals are what every other
+            // workgroup of the launch is waiting for. Everybody else fetches first and waits underneath.
+            const bool helper = fin.seq && (fin.roles & FIN_SHARDS) && blockIdx.x < (unsigned)kShards;
+            if (have && !helper) pre = f.template fetch<d2>(2 * i0);
+            if (fin.seq) sc = finish_group(S, fin, blockIdx.x, gridDim.x, fl, &priv);
+            if (have && helper) pre = f.template fetch<d2>(2 * i0);
+            if (sc->done) return;
+            f.load(sc);
+            if (have) f.template compute<d2>(2 * i0, pre, acc);
+            for (uint32_t i = i0 + stride; i < npair; i += stride) f.template compute<d2>(2 * i, f.template fetch<d2>(2 * i), acc);
+        } else {
+            if (fin.seq) sc = finish_group(S, fin, blockIdx.x, gridDim.x, fl, &priv);
+            if (sc->done) return;
+            f.load(sc);
+            for (uint32_t i = i0; i < npair; i += stride) f.template apply<d2>(2 * i, acc);
+        }
+        if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
+        if (F::ND > 0) wave_publish<ND>(acc, red.partial, red.slot_base + blockIdx.x);
+    } else {
+        if (S->done) return;
+        __shared__ double sm[5 * ND];
+        f.load(S);
+        for (uint32_t i = i0; i < npair; i += stride) f.template apply<d2>(2 * i, acc);
+        if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
+        if (F::ND > 0) reduce_publish<ND, MODE == RED_TICKET_HEAVY>(acc, S, red, blockIdx.x, sm);
+    }
 }
 
+static bool env_on(const char *name, bool dflt);
 unsigned vec_grid(uint32_t n)
 {
+    // 256 CUs x 8 resident workgroups, grid-stride beyond (BICG_VEC_GRID: measurement knob, <= kMaxGrid)
+    static const unsigned cap = [] {
+        const char *v = getenv("BICG_VEC_GRID");
+        const int g = v ? atoi(v) : kMaxGrid;
+        return (unsigned)(g >= 1 && g <= kMaxGrid ? g : kMaxGrid);
+    }();
     unsigned g = ((n >> 1) + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
-    if (g > (unsigned)kMaxGrid) g = kMaxGrid;      // 256 CUs x 8 resident workgroups, grid-stride beyond
+    if (g > cap) g = cap;
     return g;
 }
 
 template <class F>
-static void run_vec(F f, uint32_t n, Scal *S, Reduce red, hipStream_t stream)
+static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
 {
     const unsigned g = vec_grid(n);
     red.expected = g;
     red.slot_base = 0;
-    constexpr bool HV = F::ND > 0;
-    if (HV && heavy_needed(red)) hipLaunchKernelGGL((k_vec<F, HV>), dim3(g), dim3(kBlock), 0, stream, f, n, S, red);
-    else hipLaunchKernelGGL((k_vec<F, false>), dim3(g), dim3(kBlock), 0, stream, f, n, S, red);
+    constexpr int modes = vec_modes<F>::value;
+    const int mode = modes == kWaveOnly ? RED_WAVE : red_mode(red, L.fin, F::ND > 0);
+    if (!((modes >> mode) & 1)) {
+        fprintf(stderr, "ERROR: bicgstab_hip: element-wise kernel launched in reduction mode %d it is not built for\n", mode);
+        abort();
+    }
+    if constexpr ((modes >> RED_WAVE) & 1)
+        if (mode == RED_WAVE) { hipLaunchKernelGGL((k_vec<F, RED_WAVE>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+    if constexpr (((modes >> RED_TICKET_HEAVY) & 1) && F::ND > 0)
+        if (mode == RED_TICKET_HEAVY) { hipLaunchKernelGGL((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+    if constexpr ((modes >> RED_TICKET) & 1)
+        hipLaunchKernelGGL((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin);
+}
+// shifted solvers and kernel-level entry points: scalar block updated in place, ticket reductions
+template <class F>
+static void run_vec(F f, uint32_t n, Scal *S, Reduce red, hipStream_t stream)
+{
+    run_vec(f, n, Launch{S, Finish{}, stream}, red);
 }
 
 // ---- init: r = b - Ax ; r# = r ; [p = r] ; [bsave = b] ; (r,r)     (src/solver.c:74-78, 475-479)
 struct FInit {
     static constexpr int ND = 1;
+    static constexpr int kModes = kWaveOnly;
     double *r, *rh, *p, *bs; const double *ax;
     __device__ void load(const Scal *) {}
     template <class T> __device__ void apply(uint32_t i, double *acc) const
@@ -1418,60 +1504,77 @@ struct FInit {
         acc[0] += hsum(rr * rr);
     }
 };
-void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, Scal *S, Reduce red, hipStream_t s)
+void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, const Launch &L, Reduce red)
 {
-    run_vec(FInit{v.r, v.rh, copy_p ? v.p : nullptr, save_b ? v.b : nullptr, v.ax}, v.n, S, red, s);
+    run_vec(FInit{v.r, v.rh, copy_p ? v.p : nullptr, save_b ? v.b : nullptr, v.ax}, v.n, L, red);
 }
 
 // ---- plain: q = r - alpha s (kept in r)                               (src/solver.c:94)
 struct FPlainQ {
     static constexpr int ND = 0;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *r; const double *s; double alpha;
+    template <class T> struct In { T r, s; };
     __device__ void load(const Scal *S) { alpha = S->alpha; }
-    template <class T> __device__ void apply(uint32_t i, double *) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(r, i), ld<T>(s, i)}; }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
     {
-        st(r, i, ld<T>(r, i) + (-alpha) * ld<T>(s, i));
+        st(r, i, in.r + (-alpha) * in.s);
     }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_q(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FPlainQ{v.r, v.s, 0.0}, v.n, S, Reduce{}, s); }
+void launch_plain_q(const Vecs &v, const Launch &L) { run_vec(FPlainQ{v.r, v.s, 0.0}, v.n, L, Reduce{}); }
 
 // ---- plain: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r)   (src/solver.c:105-111)
 template <bool XNT> struct FPlainXR {
     static constexpr int ND = 2;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *x, *r; const double *p, *y, *rh; double alpha, omega;
+    template <class T> struct In { T q, x, p, y, rh; };
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
-    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        T q = ld<T>(r, i);
-        T xx = (XNT ? ldnt<T>(x, i) : ld<T>(x, i)) + alpha * ld<T>(p, i);
-        xx = xx + omega * q;
+        return {ld<T>(r, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(y, i), ld<T>(rh, i)};
+    }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
+    {
+        T xx = in.x + alpha * in.p;
+        xx = xx + omega * in.q;
         if (XNT) stnt(x, i, xx); else st(x, i, xx);
-        T rr = q + (-omega) * ld<T>(y, i);
+        T rr = in.q + (-omega) * in.y;
         st(r, i, rr);
         acc[0] += hsum(rr * rr);
-        acc[1] += hsum(ld<T>(rh, i) * rr);
+        acc[1] += hsum(in.rh * rr);
     }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red)
 {
-    if (stream_x()) run_vec(FPlainXR<true>{v.x, v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, S, red, s);
-    else run_vec(FPlainXR<false>{v.x, v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, S, red, s);
+    if (stream_x()) run_vec(FPlainXR<true>{v.x, v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
+    else run_vec(FPlainXR<false>{v.x, v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- plain: p = beta p ; p += r ; p += (-beta*omega) s                (src/solver.c:117-119)
 struct FPlainP {
     static constexpr int ND = 0;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *p; const double *r, *s; double beta, c;
+    template <class T> struct In { T p, r, s; };
     __device__ void load(const Scal *S) { beta = S->beta; c = -S->beta * S->omega; }
-    template <class T> __device__ void apply(uint32_t i, double *) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(p, i), ld<T>(r, i), ld<T>(s, i)}; }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
     {
-        T pp = beta * ld<T>(p, i);
-        pp = pp + 1.0 * ld<T>(r, i);
-        pp = pp + c * ld<T>(s, i);
+        T pp = beta * in.p;
+        pp = pp + 1.0 * in.r;
+        pp = pp + c * in.s;
         st(p, i, pp);
     }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_p(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FPlainP{v.p, v.r, v.s, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+void launch_plain_p(const Vecs &v, const Launch &L) { run_vec(FPlainP{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{}); }
 
 // u <- add + beta (u - omega w): daxpy(-omega) / dscal(beta) / daxpy(1.0)   (src/solver.c:217-219 etc.)
 template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double omega, double beta)
@@ -1484,119 +1587,151 @@ template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double o
 // ---- CA: p = r + beta(p - omega s) ; s = w + beta(s - omega z)         (src/solver.c:217-222)
 struct FCaPS {
     static constexpr int ND = 0;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *p, *s; const double *r, *z, *w; double beta, omega;
+    template <class T> struct In { T p, s, r, z, w; };
     __device__ void load(const Scal *S) { beta = S->beta; omega = S->omega; }
-    template <class T> __device__ void apply(uint32_t i, double *) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        T s0 = ld<T>(s, i);
-        st(p, i, recur3<T>(ld<T>(p, i), s0, ld<T>(r, i), omega, beta));
-        st(s, i, recur3<T>(s0, ld<T>(z, i), ld<T>(w, i), omega, beta));
+        return {ld<T>(p, i), ld<T>(s, i), ld<T>(r, i), ld<T>(z, i), ld<T>(w, i)};
     }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
+    {
+        st(p, i, recur3<T>(in.p, in.s, in.r, omega, beta));
+        st(s, i, recur3<T>(in.s, in.z, in.w, omega, beta));
+    }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_ca_ps(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FCaPS{v.p, v.s, v.r, v.z, v.w, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+void launch_ca_ps(const Vecs &v, const Launch &L) { run_vec(FCaPS{v.p, v.s, v.r, v.z, v.w, 0.0, 0.0}, v.n, L, Reduce{}); }
 
 // ---- q = r - alpha s (in r) ; y = w - alpha z (in w) ; (q,y), (y,y)    (src/solver.c:225-228, 361-364)
 struct FQY {
     static constexpr int ND = 2;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *r, *w; const double *s, *z; double alpha;
+    template <class T> struct In { T r, s, w, z; };
     __device__ void load(const Scal *S) { alpha = S->alpha; }
-    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(r, i), ld<T>(s, i), ld<T>(w, i), ld<T>(z, i)}; }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
     {
-        T q = ld<T>(r, i) + (-alpha) * ld<T>(s, i);
-        T y = ld<T>(w, i) + (-alpha) * ld<T>(z, i);
+        T q = in.r + (-alpha) * in.s;
+        T y = in.w + (-alpha) * in.z;
         st(r, i, q); st(w, i, y);
         acc[0] += hsum(q * y);
         acc[1] += hsum(y * y);
     }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_qy(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FQY{v.r, v.w, v.s, v.z, 0.0}, v.n, S, red, s); }
+void launch_qy(const Vecs &v, const Launch &L, Reduce red) { run_vec(FQY{v.r, v.w, v.s, v.z, 0.0}, v.n, L, red); }
 
 // ---- CA: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r), [slot 2 left for (r#,w)], (r#,s), (r#,z)
 //      (src/solver.c:233-236, 240, 242-243; (r#,w) comes from the following SpMV's epilogue)
 template <bool XNT> struct FCaXR {
     static constexpr int ND = 5;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *x, *r; const double *p, *w, *rh, *s, *z; double alpha, omega;
+    template <class T> struct In { T q, x, p, w, rh, s, z; };
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
-    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        T q = ld<T>(r, i);
-        T xx = (XNT ? ldnt<T>(x, i) : ld<T>(x, i)) + alpha * ld<T>(p, i);
-        xx = xx + omega * q;
-        if (XNT) stnt(x, i, xx); else st(x, i, xx);
-        T rr = q + (-omega) * ld<T>(w, i);
-        st(r, i, rr);
-        T h = ld<T>(rh, i);
-        acc[0] += hsum(rr * rr);
-        acc[1] += hsum(h * rr);
-        acc[3] += hsum(h * ld<T>(s, i));
-        acc[4] += hsum(h * ld<T>(z, i));
+        return {ld<T>(r, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(w, i), ld<T>(rh, i), ld<T>(s, i), ld<T>(z, i)};
     }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
+    {
+        T xx = in.x + alpha * in.p;
+        xx = xx + omega * in.q;
+        if (XNT) stnt(x, i, xx); else st(x, i, xx);
+        T rr = in.q + (-omega) * in.w;
+        st(r, i, rr);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(in.rh * rr);
+        acc[3] += hsum(in.rh * in.s);
+        acc[4] += hsum(in.rh * in.z);
+    }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_ca_xr(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+void launch_ca_xr(const Vecs &v, const Launch &L, Reduce red)
 {
-    red.p2p.mask &= ~4u;    // slot 2 belongs to the following SpMV's epilogue
-    if (stream_x()) run_vec(FCaXR<true>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
-    else run_vec(FCaXR<false>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
+    if (stream_x()) run_vec(FCaXR<true>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
+    else run_vec(FCaXR<false>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- pipelined phase 1: p, s, z recurrences ; q, y ; (q,y), (y,y)       (src/solver.c:352-364)
 struct FPipe1 {
     static constexpr int ND = 2;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *p, *s, *z, *r, *w; const double *t, *v; double alpha, beta, omega;
+    template <class T> struct In { T r, w, s, z, p, v, t; };
     __device__ void load(const Scal *S) { alpha = S->alpha; beta = S->beta; omega = S->omega; }
-    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        T r0 = ld<T>(r, i), w0 = ld<T>(w, i), s0 = ld<T>(s, i), z0 = ld<T>(z, i);
-        st(p, i, recur3<T>(ld<T>(p, i), s0, r0, omega, beta));
-        T s1 = recur3<T>(s0, z0, w0, omega, beta);
-        T z1 = recur3<T>(z0, ld<T>(v, i), ld<T>(t, i), omega, beta);
+        return {ld<T>(r, i), ld<T>(w, i), ld<T>(s, i), ld<T>(z, i), ld<T>(p, i), ld<T>(v, i), ld<T>(t, i)};
+    }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
+    {
+        st(p, i, recur3<T>(in.p, in.s, in.r, omega, beta));
+        T s1 = recur3<T>(in.s, in.z, in.w, omega, beta);
+        T z1 = recur3<T>(in.z, in.v, in.t, omega, beta);
         st(s, i, s1); st(z, i, z1);
-        T q = r0 + (-alpha) * s1;
-        T y = w0 + (-alpha) * z1;
+        T q = in.r + (-alpha) * s1;
+        T y = in.w + (-alpha) * z1;
         st(r, i, q); st(w, i, y);
         acc[0] += hsum(q * y);
         acc[1] += hsum(y * y);
     }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_pipe_f1(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+void launch_pipe_f1(const Vecs &v, const Launch &L, Reduce red)
 {
-    run_vec(FPipe1{v.p, v.s, v.z, v.r, v.w, v.t, v.v, 0.0, 0.0, 0.0}, v.n, S, red, s);
+    run_vec(FPipe1{v.p, v.s, v.z, v.r, v.w, v.t, v.v, 0.0, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- pipelined phase 2: x ; r = q - omega y ; w = y - omega (t - alpha v) ; five dots  (src/solver.c:370-380)
 // t - alpha v is not written back: t is overwritten by the next SpMV (src/solver.c:381).
 template <bool XNT> struct FPipe2 {
     static constexpr int ND = 5;
+    static constexpr int kModes = kWaveOnly;
+    static constexpr bool kSplit = true;
     double *x, *r, *w; const double *p, *t, *v, *rh, *s, *z; double alpha, omega;
+    template <class T> struct In { T q, y, x, p, t, v, rh, s, z; };
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
-    template <class T> __device__ void apply(uint32_t i, double *acc) const
+    template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        T q = ld<T>(r, i), y = ld<T>(w, i);
-        T xx = (XNT ? ldnt<T>(x, i) : ld<T>(x, i)) + alpha * ld<T>(p, i);
-        xx = xx + omega * q;
-        if (XNT) stnt(x, i, xx); else st(x, i, xx);
-        T rr = q + (-omega) * y;
-        st(r, i, rr);
-        T tt = ld<T>(t, i) + (-alpha) * ld<T>(v, i);
-        T ww = y + (-omega) * tt;
-        st(w, i, ww);
-        T h = ld<T>(rh, i);
-        acc[0] += hsum(rr * rr);
-        acc[1] += hsum(h * rr);
-        acc[2] += hsum(h * ww);
-        acc[3] += hsum(h * ld<T>(s, i));
-        acc[4] += hsum(h * ld<T>(z, i));
+        return {ld<T>(r, i), ld<T>(w, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(t, i), ld<T>(v, i), ld<T>(rh, i),
+                ld<T>(s, i), ld<T>(z, i)};
     }
+    template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
+    {
+        T xx = in.x + alpha * in.p;
+        xx = xx + omega * in.q;
+        if (XNT) stnt(x, i, xx); else st(x, i, xx);
+        T rr = in.q + (-omega) * in.y;
+        st(r, i, rr);
+        T tt = in.t + (-alpha) * in.v;
+        T ww = in.y + (-omega) * tt;
+        st(w, i, ww);
+        acc[0] += hsum(rr * rr);
+        acc[1] += hsum(in.rh * rr);
+        acc[2] += hsum(in.rh * ww);
+        acc[3] += hsum(in.rh * in.s);
+        acc[4] += hsum(in.rh * in.z);
+    }
+    template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_pipe_f2(const Vecs &v, Scal *S, Reduce red, hipStream_t s)
+void launch_pipe_f2(const Vecs &v, const Launch &L, Reduce red)
 {
-    if (stream_x()) run_vec(FPipe2<true>{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
-    else run_vec(FPipe2<false>{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, S, red, s);
+    if (stream_x()) run_vec(FPipe2<true>{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
+    else run_vec(FPipe2<false>{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- residual replacement pieces
 struct FPUpdate {   // p = r + beta (p - omega s)                            (src/solver.c:494-496)
     static constexpr int ND = 0;
+    static constexpr int kModes = kWaveOnly;
     double *p; const double *s, *r; double beta, omega;
     __device__ void load(const Scal *S) { beta = S->beta; omega = S->omega; }
     template <class T> __device__ void apply(uint32_t i, double *) const
@@ -1604,10 +1739,11 @@ struct FPUpdate {   // p = r + beta (p - omega s)                            (sr
         st(p, i, recur3<T>(ld<T>(p, i), ld<T>(s, i), ld<T>(r, i), omega, beta));
     }
 };
-void launch_p_update(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FPUpdate{v.p, v.s, v.r, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+void launch_p_update(const Vecs &v, const Launch &L) { run_vec(FPUpdate{v.p, v.s, v.r, 0.0, 0.0}, v.n, L, Reduce{}); }
 
 struct FXUpdate {   // x += alpha p ; x += omega q                           (src/solver.c:519-520)
     static constexpr int ND = 0;
+    static constexpr int kModes = kWaveOnly;
     double *x; const double *p, *r; double alpha, omega;
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
     template <class T> __device__ void apply(uint32_t i, double *) const
@@ -1616,10 +1752,11 @@ struct FXUpdate {   // x += alpha p ; x += omega q                           (sr
         st(x, i, xx + omega * ld<T>(r, i));
     }
 };
-void launch_x_update(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FXUpdate{v.x, v.p, v.r, 0.0, 0.0}, v.n, S, Reduce{}, s); }
+void launch_x_update(const Vecs &v, const Launch &L) { run_vec(FXUpdate{v.x, v.p, v.r, 0.0, 0.0}, v.n, L, Reduce{}); }
 
 struct FTrueRes {   // r = b ; r += -1.0 * Ax                                (src/solver.c:524-525)
     static constexpr int ND = 0;
+    static constexpr int kModes = kWaveOnly;
     double *r; const double *b, *ax;
     __device__ void load(const Scal *) {}
     template <class T> __device__ void apply(uint32_t i, double *) const
@@ -1627,10 +1764,11 @@ struct FTrueRes {   // r = b ; r += -1.0 * Ax                                (sr
         st(r, i, ld<T>(b, i) + (-1.0) * ld<T>(ax, i));
     }
 };
-void launch_true_residual(const Vecs &v, Scal *S, hipStream_t s) { run_vec(FTrueRes{v.r, v.b, v.ax}, v.n, S, Reduce{}, s); }
+void launch_true_residual(const Vecs &v, const Launch &L) { run_vec(FTrueRes{v.r, v.b, v.ax}, v.n, L, Reduce{}); }
 
 struct FDots5 {     // (r,r), (r#,r), (r#,w), (r#,s), (r#,z)                 (src/solver.c:533-538)
     static constexpr int ND = 5;
+    static constexpr int kModes = kWaveOnly;
     const double *r, *rh, *w, *s, *z;
     __device__ void load(const Scal *) {}
     template <class T> __device__ void apply(uint32_t i, double *acc) const
@@ -1643,7 +1781,7 @@ struct FDots5 {     // (r,r), (r#,r), (r#,w), (r#,s), (r#,z)                 (sr
         acc[4] += hsum(h * ld<T>(z, i));
     }
 };
-void launch_dots5(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FDots5{v.r, v.rh, v.w, v.s, v.z}, v.n, S, red, s); }
+void launch_dots5(const Vecs &v, const Launch &L, Reduce red) { run_vec(FDots5{v.r, v.rh, v.w, v.s, v.z}, v.n, L, red); }
 
 // ---- shifted BiCGStab (reference src/shifted_solver.c:182-354) ---------------------------------
 struct FShiftInit {   // r# = r ; p[seed] = r ; (r,r)                                  (:238-250)
@@ -1916,6 +2054,7 @@ void launch_shift_pseed(const Vecs &v, double *p_seed, Scal *S, hipStream_t s)
 
 struct FDrift {     // how far the recursive residual has drifted from the true one (adaptive replacement)
     static constexpr int ND = 2;
+    static constexpr int kModes = kAnyMode;
     const double *b, *ax, *r;
     __device__ void load(const Scal *) {}
     template <class T> __device__ void apply(uint32_t i, double *acc) const
@@ -1926,7 +2065,7 @@ struct FDrift {     // how far the recursive residual has drifted from the true 
         acc[1] += hsum(rr * rr);
     }
 };
-void launch_drift(const Vecs &v, Scal *S, Reduce red, hipStream_t s) { run_vec(FDrift{v.b, v.ax, v.r}, v.n, S, red, s); }
+void launch_drift(const Vecs &v, const Launch &L, Reduce red) { run_vec(FDrift{v.b, v.ax, v.r}, v.n, L, red); }
 
 struct FDot {
     static constexpr int ND = 1;

@@ -104,8 +104,25 @@ struct bicg_ctx {
     // vectors and scalars
     double *slab = nullptr;
     Vecs v{};
-    Scal *S = nullptr;
+    Scal *S = nullptr;           // the scalar block kernels enqueued from now on read (= Sbuf + cur)
+    Scal *Sbuf = nullptr;        // two blocks: a kernel that finishes a dot group reads one and writes the other
+    int cur = 0;
     Scal *hS = nullptr;          // pinned mirror
+    // consumer-side finish of dot groups (struct Finish, bicg_device.h): the four solvers of src/solver.c
+    struct Group {
+        bool active = false;     // produced, not yet consumed
+        bool deferred = false;   // may ride across the next SpMV (pipelined variants, src/solver.c:363-367)
+        bool staged = false;     // an SpMV launch has already summed the shards / pushed the sums to the peers
+        unsigned seq = 0, mail_seq = 0, nparts = 0;
+        int n = 0, off = 0, phase = 0, buf = 0;
+        int ar_off = 0, ar_n = 0;   // host-enqueued all-reduce covers red[ar_off .. ar_off + ar_n)
+    } grp;
+    bool wave_mode = false;      // this call uses consumer-side finish (run_begin); false: ticket reductions
+    double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
+    llword *shard_ll = nullptr;  // 2 x [kShards][kRedSlots][2], alternating like wpart
+    int *alarm = nullptr, *h_alarm = nullptr;
+    unsigned grp_seq = 0;
+    unsigned long long spin_ticks = 2000;   // 20 us before a workgroup sums a missing shard itself (BICG_SPIN_TICKS)
     double *partial = nullptr, *shard_tot = nullptr;
     unsigned *counter = nullptr;
     unsigned nslots = 0;
@@ -119,7 +136,7 @@ struct bicg_ctx {
 
     // deferred dot group (pipelined variant: all-reduce overlaps the next SpMV)
     bool pend = false;
-    int pend_n = 0, pend_phase = 0;
+    int pend_n = 0, pend_phase = 0, pend_off = 0;
     hipEvent_t pend_ev = nullptr;
 
     // shifted solver (bicg_solve_shifted): per-shift scalar state and the two vector sets
@@ -164,7 +181,7 @@ struct bicg_ctx {
     mutable bool open_inline = false;
     Reduce red(int off, int phase, bool apply_single = true, int now_n = 0) const
     {
-        Reduce r;
+        Reduce r{};
         r.partial = partial; r.shard_tot = shard_tot; r.counter = counter; r.expected = 0; r.slot_base = 0;
         r.red_off = off; r.phase = phase;
         r.apply_now = (single() && apply_single) ? 1 : 0;
@@ -182,18 +199,106 @@ struct bicg_ctx {
 
 namespace {
 
+// ---------------------------------------------------------------- dot groups: consumer-side finish
+// (the four solvers of reference src/solver.c; struct Finish in bicg_device.h). A group is PRODUCED by
+// one or two kernels (per-wavefront partials), then CONSUMED by the kernel that needs the scalars,
+// by an SpMV that only has to deposit the sums, or by the stand-alone finisher.
+Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg = 0, int ar_off = -1, int ar_n = 0)
+{
+    if (c->grp.active) die("internal", "a dot group was produced while the previous one was still open");
+    bicg_ctx::Group &g = c->grp;
+    g = bicg_ctx::Group{};
+    g.active = true;
+    g.seq = ++c->grp_seq;
+    g.n = n; g.off = off; g.phase = phase; g.buf = (int)(g.seq & 1u);
+    g.ar_off = ar_off < 0 ? off : ar_off; g.ar_n = ar_n > 0 ? ar_n : n;
+    g.nparts = nwg * (kBlock / 64);               // SpMV producers: set by spmv()
+    if (c->p2p) g.mail_seq = c->p2p->red_seq++;
+    Reduce r{};
+    r.partial = c->wpart[g.buf];
+    r.wave = 1; r.red_off = off; r.phase = phase;
+    return r;
+}
+
+Finish grp_desc(bicg_ctx *c, int roles)
+{
+    const bicg_ctx::Group &g = c->grp;
+    Finish f{};
+    f.partial = c->wpart[g.buf]; f.nparts = g.nparts; f.seq = g.seq;
+    f.shard = c->shard_ll + (size_t)g.buf * kShards * kRedSlots * 2;
+    f.shard_clear = c->shard_ll + (size_t)(g.buf ^ 1) * kShards * kRedSlots * 2;
+    f.n = g.n; f.red_off = g.off; f.phase = g.phase; f.roles = roles;
+    f.spin_ticks = c->spin_ticks;
+    if (c->p2p) { f.p2p = c->p2p->red_desc(g.mail_seq); f.alarm = c->alarm; }
+    return f;
+}
+
+// stand-alone finisher, in place on the current scalar block. local_only: deposit this rank's sums
+// and leave the recurrence to the all-reduce + apply kernel the host enqueues next.
+void grp_close(bicg_ctx *c, bool local_only = false)
+{
+    if (!c->grp.active) return;
+    Finish f = grp_desc(c, FIN_BLOCK0 | (c->grp.staged ? 0 : FIN_SHARDS | FIN_PUSH) | (local_only ? FIN_LOCAL : 0));
+    if (local_only) f.phase = PH_NONE;
+    launch_finish(Launch{c->S, f, c->sc});
+    c->grp.active = false;
+    if (c->p2p) c->halo_unsynced = 0;
+}
+
+// transports whose collectives the host enqueues (RCCL, host callbacks)
+bool hosted(const bicg_ctx *c) { return !c->single() && !c->p2p; }
+
+// Launch descriptor for an element-wise kernel of the four solvers; the open group (if any) is
+// finished by that kernel, and everything enqueued afterwards reads the scalar block it writes.
+Launch grp_consume(bicg_ctx *c)
+{
+    Launch L{c->S, Finish{}, c->sc};
+    if (!c->grp.active) return L;
+    L.fin = grp_desc(c, FIN_APPLY | (c->grp.staged ? 0 : FIN_SHARDS | FIN_PUSH));
+    c->cur ^= 1;
+    c->S = c->Sbuf + c->cur;
+    L.fin.Snext = c->S;
+    c->grp.active = false;
+    if (c->p2p) c->halo_unsynced = 0;      // an all-reduce is a barrier among the ranks
+    return L;
+}
+
+// The open group as seen by the next SpMV launch: a deferred group is staged (shards summed, sums on
+// their way to the peers) and stays open; sums that only have to be deposited (CA-BiCGStab's
+// (r,r), (r#,r), (r#,s), (r#,z), src/solver.c:240-243) are deposited by the launch; anything else
+// is closed first.
+Finish grp_for_spmv(bicg_ctx *c)
+{
+    bicg_ctx::Group &g = c->grp;
+    if (!g.active) return Finish{};
+    if (hosted(c)) { grp_close(c, true); return Finish{}; }
+    if (g.deferred) {
+        if (g.staged) return Finish{};
+        g.staged = true;
+        return grp_desc(c, FIN_SHARDS | FIN_PUSH);
+    }
+    if (g.phase == PH_NONE) {
+        Finish f = grp_desc(c, FIN_SHARDS | FIN_PUSH | FIN_BLOCK0);
+        g.active = false;
+        if (c->p2p) c->halo_unsynced = 0;
+        return f;
+    }
+    grp_close(c);
+    return Finish{};
+}
+
 // ---------------------------------------------------------------- dot groups across ranks
 void group_enqueue(bicg_ctx *c, int n, int phase, hipEvent_t after)
 {
     if (c->comm->stream_ordered()) {
         BICG_HIP(hipStreamWaitEvent(c->sm, after, 0));
-        c->comm->allreduce_sum(c->S->red, n, c->sm);
+        c->comm->allreduce_sum(c->S->red + c->pend_off, n, c->sm);
         launch_apply(c->S, phase, c->sm);
         hipEvent_t e = c->ev_red[c->i_red++ % kEvRing];
         BICG_HIP(hipEventRecord(e, c->sm));
         c->pend_ev = e;
     } else {
-        c->comm->allreduce_sum(c->S->red, n, c->sc);   // synchronises sc
+        c->comm->allreduce_sum(c->S->red + c->pend_off, n, c->sc);   // synchronises sc
         launch_apply(c->S, phase, c->sc);
         c->pend_ev = nullptr;
     }
@@ -204,6 +309,15 @@ void group_enqueue(bicg_ctx *c, int n, int phase, hipEvent_t after)
 // through the communication stream costs two cross-stream event hand-offs, ~10 us eager)
 void group_now(bicg_ctx *c, int n, int phase)
 {
+    if (c->wave_mode) {
+        // single rank / peer-to-peer: the group stays open for the kernel that consumes it
+        if (!hosted(c)) { c->grp.deferred = false; return; }
+        const bicg_ctx::Group g = c->grp;
+        grp_close(c, true);                                   // this rank's sums -> Scal::red
+        c->comm->allreduce_sum(c->S->red + g.ar_off, g.ar_n, c->sc);
+        launch_apply(c->S, g.phase, c->sc);
+        return;
+    }
     if (c->single()) return;   // applied in-kernel by the finishing workgroup
     if (c->p2p) {              // the producers stored their sums into every rank's mailbox already
         if (c->open_inline) {  // ... and the last of them collects and applies (Reduce::p2p.n_collect)
@@ -215,6 +329,7 @@ void group_now(bicg_ctx *c, int n, int phase)
         c->halo_unsynced = 0;
         return;
     }
+    c->pend_off = 0;
     c->comm->allreduce_sum(c->S->red, n, c->sc);
     launch_apply(c->S, phase, c->sc);
 }
@@ -223,6 +338,16 @@ void group_now(bicg_ctx *c, int n, int phase)
 // joined after that SpMV: the overlap of reference src/solver.c:363-367 and 377-385
 void group_defer(bicg_ctx *c, int n, int phase)
 {
+    if (c->wave_mode) {
+        if (!hosted(c)) { c->grp.deferred = true; return; }   // staged by the next SpMV launch, applied by the consumer
+        const bicg_ctx::Group g = c->grp;
+        if (!c->overlap || !c->comm->stream_ordered()) { group_now(c, n, phase); return; }
+        grp_close(c, true);
+        hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
+        BICG_HIP(hipEventRecord(e, c->sc));
+        c->pend = true; c->pend_n = g.ar_n; c->pend_off = g.ar_off; c->pend_phase = g.phase; c->pend_ev = e;
+        return;
+    }
     if (c->single()) return;
     if (c->p2p) {   // collected after the next SpMV: the sums cross the links while it runs
         c->pend = true; c->pend_n = n; c->pend_phase = phase; c->pend_seq = c->p2p->red_seq++;
@@ -231,7 +356,7 @@ void group_defer(bicg_ctx *c, int n, int phase)
     if (!c->overlap || !c->comm->stream_ordered()) { group_now(c, n, phase); return; }
     hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
     BICG_HIP(hipEventRecord(e, c->sc));
-    c->pend = true; c->pend_n = n; c->pend_phase = phase; c->pend_ev = e;
+    c->pend = true; c->pend_n = n; c->pend_off = 0; c->pend_phase = phase; c->pend_ev = e;
 }
 
 // ---------------------------------------------------------------- distributed SpMV
@@ -239,9 +364,11 @@ void group_defer(bicg_ctx *c, int n, int phase)
 // exchange runs on the communication stream while the interior row blocks are multiplied; row
 // blocks that touch the halo run after it has landed. Every row is produced by exactly one
 // workgroup as (0 + sum_diag) + sum_offd, the reference's order.
-void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red)
+// fin: a dot group of earlier kernels that the first kernel launched here finishes (grp_for_spmv).
+void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{})
 {
     SpmvArgs a;
+    a.fin = fin;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16};
     a.glist = nullptr;
     a.nrows = c->n_loc;
@@ -262,12 +389,16 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     red.expected = merged ? g_sall + g_ci + g_cb : g_si + g_ci + g_sb + g_cb;
     red.slot_base = 0;
     a.red = red;
+    if (red.wave && ndot > 0) c->grp.nparts = red.expected * (kBlock / 64);   // one partial per wavefront
 
     // per-kernel timing: every SpMV kernel of this call gets its own start/stop event pair
     const bool timed = c->time_kernels && c->tev_used + 8 <= (int)c->tev.size();
     bool any_timed = false;
     auto ev = [&](int i) -> hipEvent_t { return timed ? c->tev[c->tev_used + i] : nullptr; };
-    auto took = [&](bool launched) { if (launched && timed) { c->tev_used += 2; any_timed = true; } };
+    auto took = [&](bool launched) {
+        if (launched) a.fin.seq = 0;          // the first kernel of this SpMV finished the open group
+        if (launched && timed) { c->tev_used += 2; any_timed = true; }
+    };
 
     auto interior = [&]() {
         a.glist = c->glist_int_identity ? nullptr : c->glist_int; a.nlist = c->ng_int; a.red.slot_base = 0;
@@ -360,12 +491,37 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             c->pend_ev = nullptr;
         }
     }
+    if (a.fin.seq) {   // no SpMV kernel was launched (a rank without work): finish the group on its own
+        Finish f = a.fin;
+        f.roles |= FIN_BLOCK0;
+        launch_finish(Launch{c->S, f, c->sc});
+    }
     if (any_timed) c->spmv_calls_timed++;
+}
+
+
+// SpMV of the four solvers (consumer-side finish): the open group is staged / deposited by this
+// launch, then the SpMV's own dots (ndot > 0) open the next group.
+void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int off = 0, int phase = PH_NONE,
+              int ar_off = -1, int ar_n = 0)
+{
+    const Finish fin = grp_for_spmv(c);
+    Reduce red{};
+    if (ndot > 0) {
+        if (c->grp.active) {     // a deferred group is still open: an SpMV with dots of its own cannot carry it
+            if (fin.seq) die("internal", "an SpMV with dots was asked to stage a deferred group");
+            grp_close(c);
+        }
+        red = grp_produce(c, off, ndot == 3 ? 2 : ndot, phase, 0, ar_off, ar_n);
+    }
+    red.apply_now = 0;
+    spmv(c, xin, yout, ndot, u, red, fin);
 }
 
 // a deferred group that no SpMV picked up (defensive)
 void group_flush(bicg_ctx *c)
 {
+    if (c->wave_mode && !hosted(c)) return;      // consumed by the next element-wise kernel or by fetch_scal
     if (!c->pend) return;
     if (c->p2p) {
         c->pend = false;
@@ -387,51 +543,63 @@ struct Driver {
     bicg_ctx *c;
     int method;
     int krr, nrr;
-    hipStream_t sc;
     Vecs &v;
-    Scal *S;
+    unsigned vg;       // workgroups of an element-wise kernel
 
-    Driver(bicg_ctx *ctx, int m, int kr, int nr) : c(ctx), method(m), krr(kr), nrr(nr), sc(ctx->sc), v(ctx->v), S(ctx->S) {}
+    Driver(bicg_ctx *ctx, int m, int kr, int nr) : c(ctx), method(m), krr(kr), nrr(nr), v(ctx->v), vg(vec_grid(ctx->v.n)) {}
+
+    // element-wise kernel without / with dots: it finishes the open group, then opens its own
+    template <class Fn> void vec(Fn launch)
+    {
+        const Launch L = grp_consume(c);
+        launch(v, L);
+    }
+    template <class Fn> void vec_dots(Fn launch, int n, int phase)
+    {
+        const Launch L = grp_consume(c);
+        const Reduce r = grp_produce(c, 0, n, phase, vg);
+        launch(v, L, r);
+    }
 
     void init()
     {
         const bool plain = method == BICG_BICGSTAB;
         const bool rr = method == BICG_PIPE_BICGSTAB_RR || (method == BICG_PIPE_BICGSTAB && c->opt.rr_drift > 0.0);
-        spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));                       // Ax = A x0
-        launch_init_residual(v, plain, rr, S, c->red(0, PH_INIT, true, 1), sc);             // r = b - Ax, r# = r, (r,r)
+        spmv_grp(c, v.x, v.ax);                                                    // Ax = A x0
+        vec_dots([&](const Vecs &vv, const Launch &L, Reduce r) { launch_init_residual(vv, plain, rr, L, r); }, 1, PH_INIT);   // r = b - Ax, r# = r, (r,r)
         group_now(c, 1, PH_INIT);
         if (plain) return;
         const bool ca = method == BICG_CA_BICGSTAB;
-        spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_INIT_ALPHA, true, ca ? 1 : 0));       // w = A r, (r,w)
+        spmv_grp(c, v.r, v.w, 1, v.r, 0, PH_INIT_ALPHA);                           // w = A r, (r,w)
         if (ca) {
             group_now(c, 1, PH_INIT_ALPHA);
         } else {
             group_defer(c, 1, PH_INIT_ALPHA);                                       // overlaps t = A w (src/solver.c:339-343)
-            spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));
+            spmv_grp(c, v.w, v.t);
             group_flush(c);
         }
     }
 
     void iter_plain()   // reference src/solver.c:88-119
     {
-        spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
+        spmv_grp(c, v.p, v.s, 1, v.rh, 0, PH_PLAIN_ALPHA);       // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
-        launch_plain_q(v, S, sc);                                // q = r - alpha s
-        spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA, true, 2));          // y = A q, (q,y), (y,y) -> omega
+        vec(launch_plain_q);                                     // q = r - alpha s
+        spmv_grp(c, v.r, v.y, 2, v.r, 0, PH_OMEGA);              // y = A q, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_plain_xr(v, S, c->red(0, PH_PLAIN_END, true, 2), sc);      // x, r, (r,r), (r#,r) -> beta, k++
+        vec_dots(launch_plain_xr, 2, PH_PLAIN_END);              // x, r, (r,r), (r#,r) -> beta, k++
         group_now(c, 2, PH_PLAIN_END);
-        launch_plain_p(v, S, sc);                                // p = r + beta (p - omega s)
+        vec(launch_plain_p);                                     // p = r + beta (p - omega s)
     }
 
     void iter_ca()      // reference src/solver.c:217-251
     {
-        launch_ca_ps(v, S, sc);                                  // p, s recurrences
-        spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
-        launch_qy(v, S, c->red(0, PH_OMEGA, true, 2), sc);       // q, y, (q,y), (y,y) -> omega
+        vec(launch_ca_ps);                                       // p, s recurrences
+        spmv_grp(c, v.s, v.z);                                   // z = A s
+        vec_dots(launch_qy, 2, PH_OMEGA);                        // q, y, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_ca_xr(v, S, c->red(0, PH_NONE, false), sc);       // x, r, (r,r), (r#,r), (r#,s), (r#,z)
-        spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END, true, 5));     // w = A r, (r#,w) -> beta, alpha, k++
+        vec_dots(launch_ca_xr, 5, PH_NONE);                      // x, r, (r,r), (r#,r), (r#,s), (r#,z): deposited by the SpMV
+        spmv_grp(c, v.r, v.w, 1, v.rh, 2, PH_RECUR_END, 0, 5);   // w = A r, (r#,w) -> beta, alpha, k++
         group_now(c, 5, PH_RECUR_END);
     }
 
@@ -440,26 +608,26 @@ struct Driver {
         const bool replace = force_replace ||
                              (method == BICG_PIPE_BICGSTAB_RR && krr > 0 && (it % krr == 0) && it > 0 && it <= krr * nrr);
         if (!replace) {
-            launch_pipe_f1(v, S, c->red(0, PH_OMEGA), sc);           // p, s, z, q, y, (q,y), (y,y)
+            vec_dots(launch_pipe_f1, 2, PH_OMEGA);                   // p, s, z, q, y, (q,y), (y,y)
             group_defer(c, 2, PH_OMEGA);
-            spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));       // v = A z   || all-reduce
-            launch_pipe_f2(v, S, c->red(0, PH_RECUR_END), sc);       // x, r, w, five dots
+            spmv_grp(c, v.z, v.v);                                   // v = A z   || all-reduce
+            vec_dots(launch_pipe_f2, 5, PH_RECUR_END);               // x, r, w, five dots
             group_defer(c, 5, PH_RECUR_END);
-            spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));       // t = A w   || all-reduce
+            spmv_grp(c, v.w, v.t);                                   // t = A w   || all-reduce
         } else {
-            launch_p_update(v, S, sc);
-            spmv(c, v.p, v.s, 0, nullptr, c->red(0, PH_NONE));       // s = A p
-            spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
-            launch_qy(v, S, c->red(0, PH_OMEGA), sc);
+            vec(launch_p_update);
+            spmv_grp(c, v.p, v.s);                                   // s = A p
+            spmv_grp(c, v.s, v.z);                                   // z = A s
+            vec_dots(launch_qy, 2, PH_OMEGA);
             group_defer(c, 2, PH_OMEGA);
-            spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));       // v = A z
-            launch_x_update(v, S, sc);
-            spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));      // Ax = A x
-            launch_true_residual(v, S, sc);                          // r = b - Ax
-            spmv(c, v.r, v.w, 0, nullptr, c->red(0, PH_NONE));       // w = A r
-            launch_dots5(v, S, c->red(0, PH_RECUR_END), sc);
+            spmv_grp(c, v.z, v.v);                                   // v = A z
+            vec(launch_x_update);
+            spmv_grp(c, v.x, v.ax);                                  // Ax = A x
+            vec(launch_true_residual);                               // r = b - Ax
+            spmv_grp(c, v.r, v.w);                                   // w = A r
+            vec_dots(launch_dots5, 5, PH_RECUR_END);
             group_defer(c, 5, PH_RECUR_END);
-            spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));       // t = A w
+            spmv_grp(c, v.w, v.t);                                   // t = A w
         }
         group_flush(c);
     }
@@ -476,8 +644,8 @@ struct Driver {
     // adaptive residual replacement (additive): true residual vs recursive one
     double drift()
     {
-        spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));
-        launch_drift(v, S, c->red(0, PH_NONE, true, 2), sc);
+        spmv_grp(c, v.x, v.ax);
+        vec_dots(launch_drift, 2, PH_NONE);
         group_now(c, 2, PH_NONE);
         fetch_scal(c);
         return c->hS->red[1] > 0.0 ? sqrt(c->hS->red[0] / c->hS->red[1]) : 0.0;
@@ -486,10 +654,13 @@ struct Driver {
 
 void fetch_scal(bicg_ctx *c)
 {
+    if (c->wave_mode) grp_close(c);      // the host wants the scalars: finish the open group now
     BICG_HIP(hipMemcpyAsync(c->hS, c->S, sizeof(Scal), hipMemcpyDeviceToHost, c->sc));
+    if (c->p2p) BICG_HIP(hipMemcpyAsync(c->h_alarm, c->alarm, sizeof(int), hipMemcpyDeviceToHost, c->sc));
     BICG_HIP(hipStreamSynchronize(c->sc));
     if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
-    if (c->hS->comm_error) {
+    if (c->hS->comm_error || (c->p2p && *c->h_alarm)) {
+        c->hS->comm_error = 1; c->hS->done = 1;
         // BICG_P2P_SOFT_FAIL=1: report through bicg_comm_failed() and stop iterating instead of
         // exiting (bench.py then falls back to the RCCL collectives)
         const char *soft = getenv("BICG_P2P_SOFT_FAIL");
@@ -513,6 +684,8 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     if (o.check_every < 1) o.check_every = 1;
     c->method = method;
     BICG_HIP(hipSetDevice(c->comm->device));
+    c->wave_mode = true;                 // dot groups are finished by the kernels that consume them
+    c->grp = bicg_ctx::Group{};
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -541,6 +714,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     h.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
     BICG_HIP(hipMemcpyAsync(c->S, &h, sizeof h, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
+    BICG_HIP(hipMemsetAsync(c->alarm, 0, sizeof(int), c->sc));
     // every work vector starts at zero: defines the reads of p, s, z, v that the reference makes
     // before writing them (src/solver.c:217-222, 352-360) and keeps halo tails finite
     const size_t st = c->stride;
@@ -576,6 +750,9 @@ bool graph_iteration(bicg_ctx *c, Driver &d)
     // GPU busy (54 us vs 60 us replayed per 17-op iteration of a 200 k-row rank); replay only pays
     // when the two-stream overlap mode is on (80 vs 105 us).
     const bool want = c->graph_mode == 1;
+    // consumer-side finish alternates between two scalar blocks: launch arguments change from one
+    // iteration to the next unless the host enqueues the collectives itself
+    if (c->wave_mode && !hosted(c)) return false;
     if (!want || c->p2p || m == BICG_PIPE_BICGSTAB_RR || c->opt.rr_drift > 0.0 || c->time_kernels || !c->comm->stream_ordered()) return false;
     if (c->graph_exec[m] && c->graph_nt[m] != c->sell_nt) {     // captured with the other streaming policy
         (void)hipGraphExecDestroy(c->graph_exec[m]);
@@ -706,6 +883,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.check_every < 1) o.check_every = 1;
     BICG_HIP(hipSetDevice(c->comm->device));
+    c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
     const size_t st = c->stride, n = c->n_loc;
 
     if (c->sh_cap < nsig) {
@@ -843,6 +1021,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.check_every < 1) o.check_every = 1;
     BICG_HIP(hipSetDevice(c->comm->device));
+    c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
     const size_t st = c->stride, n = c->n_loc;
 
     if (c->sh_cap < nsig) {
@@ -1255,8 +1434,20 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
     c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
     BICG_HIP(hipMemset(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride));
-    c->S = dev_alloc<Scal>(1);
-    BICG_HIP(hipMemset(c->S, 0, sizeof(Scal)));
+    c->Sbuf = dev_alloc<Scal>(2);
+    BICG_HIP(hipMemset(c->Sbuf, 0, 2 * sizeof(Scal)));
+    c->S = c->Sbuf;
+    for (int i = 0; i < 2; ++i) {
+        c->wpart[i] = dev_alloc<double>((size_t)c->nslots * (kBlock / 64) * kPartialStride);
+        BICG_HIP(hipMemset(c->wpart[i], 0, sizeof(double) * (size_t)c->nslots * (kBlock / 64) * kPartialStride));
+    }
+    c->shard_ll = dev_alloc<llword>((size_t)2 * kShards * kRedSlots * 2);
+    BICG_HIP(hipMemset(c->shard_ll, 0, sizeof(llword) * 2 * kShards * kRedSlots * 2));
+    c->alarm = dev_alloc<int>(1);
+    BICG_HIP(hipMemset(c->alarm, 0, sizeof(int)));
+    BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
+    *c->h_alarm = 0;
+    if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
 
@@ -1278,7 +1469,8 @@ void bicg_destroy(bicg_ctx *c)
     (void)hipSetDevice(c->comm->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
-                    c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->S, c->trace, c->sw_buf};
+                    c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
+                    c->wpart[0], c->wpart[1], c->shard_ll, c->alarm};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->p2p) {
         c->p2p->unmap(c->ring_mapped);
@@ -1287,6 +1479,7 @@ void bicg_destroy(bicg_ctx *c)
         if (c->glist_ll) (void)hipFree(c->glist_ll);
     }
     if (c->hS) (void)hipHostFree(c->hS);
+    if (c->h_alarm) (void)hipHostFree(c->h_alarm);
     for (int i = 0; i < kEvRing; ++i) {
         (void)hipEventDestroy(c->ev_pack[i]); (void)hipEventDestroy(c->ev_halo[i]); (void)hipEventDestroy(c->ev_dots[i]); (void)hipEventDestroy(c->ev_red[i]);
     }
@@ -1346,6 +1539,8 @@ int bicg_trace(bicg_ctx *c, double *alpha, double *omega, double *beta, double *
 
 static void reset_scal(bicg_ctx *c)
 {
+    c->wave_mode = false;
+    c->grp = bicg_ctx::Group{};
     BICG_HIP(hipMemsetAsync(c->S, 0, sizeof(Scal), c->sc));
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
 }
@@ -1398,7 +1593,7 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
         c->cur_shift = sigma[j]; c->cur_has_shift = true;
         spmv(c, c->v.p, c->v.ax, 0, nullptr, c->red(0, PH_NONE));
         c->cur_has_shift = false; c->cur_shift = 0.0;
-        launch_drift(w, c->S, c->red(0, PH_NONE, true, 2), c->sc);
+        launch_drift(w, Launch{c->S, Finish{}, c->sc}, c->red(0, PH_NONE, true, 2));
         group_now(c, 2, PH_NONE);
         fetch_scal(c);
         relres_out[j] = bb > 0.0 ? sqrt(c->hS->red[0] / bb) : sqrt(c->hS->red[0]);

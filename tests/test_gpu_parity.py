@@ -96,9 +96,17 @@ def test_solver_vs_golden(path, method, rr):
         assert np.abs(res["x"] - 1.0).max() <= 1e-9
         assert res["k"] == 1000 or np.sqrt(res["dot_r"] / res["dot_zero"]) <= 1e-15
     else:
-        ref_err = np.abs(g[f"{method}_P1_x"] - 1.0).max()
-        assert np.isfinite(res["x"]).all()
-        assert np.abs(res["x"] - 1.0).max() <= max(100 * ref_err, 1e-9)
+        # chaotic trajectory: where it ends depends on the summation order alone. The reference's own
+        # end states over P = 1, 2, 4, 8 (fixture) bound what is acceptable: an error within 100 x its
+        # worst finite one, or -- when the reference itself broke down to NaN at some rank count -- a
+        # breakdown that the library REPORTS (bicg_result.breakdown_iteration; the reference is silent)
+        ref_x = [g[f"{method}_P{P}_x"] for P in (1, 2, 4, 8) if f"{method}_P{P}_x" in g]
+        ref_err = max(np.abs(x - 1.0).max() for x in ref_x if np.isfinite(x).all())
+        ref_broke = any(not np.isfinite(x).all() for x in ref_x)
+        if np.isfinite(res["x"]).all():
+            assert np.abs(res["x"] - 1.0).max() <= max(100 * ref_err, 1e-9)
+        else:
+            assert ref_broke and res["result"].breakdown_iteration > 0
     ctx.close()
 
 

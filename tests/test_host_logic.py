@@ -164,10 +164,12 @@ def test_partition_nnz_edge_cases():
 
 
 def test_hot_kernels_stay_lean():
-    """The dot epilogue is inlined into every dot-producing kernel; when rarely used paths (seed switching,
-    peer-to-peer collect) leak into the hot instantiations they cost 26 VGPRs and three waves per SIMD
-    (DESIGN.md section 4.3). The compiler's resource report of the last build must show the single-GPU hot
-    kernels at <= 64 VGPRs, occupancy 8, no scratch."""
+    """The compiler's resource report of the last build: the sliced-ELL SpMV on the single-GPU hot path (no
+    offd, no in-kernel halo exchange; ticket-light and consumer-side-finish instantiations) must stay at
+    <= 64 VGPRs, occupancy 8, no scratch -- rarely used paths (seed switching, peer-to-peer collect) once
+    leaked into it and cost 26 VGPRs and three waves per SIMD. The element-wise
+    kernels of the four solvers hold the loads of their first element pair across the wait for the dot
+    sums: more registers by design, but never scratch and at least 5 waves per SIMD."""
     path = os.path.join(ROOT, "mpi-bicgstab_amd", "build", "kernel_resources.txt")
     if not os.path.exists(path):
         pytest.skip("no resource report (library not built here)")
@@ -181,9 +183,13 @@ def test_hot_kernels_stay_lean():
         m = re.search(r"remark:\s+([A-Za-z \[\]/]+):\s*(\d+)", line)
         if m and cur:
             kernels[cur][m.group(1).strip()] = int(m.group(2))
-    hot = [k for k in kernels if re.search(r"k_spmv_sellILi[0-3]ELb0ELb[01]ELb[01]ELb0ELb0EEEv", k)]      # no offd, no LL, light
-    hot += [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELb0EEEv", k)]
-    assert len(hot) >= 20, sorted(kernels)[:5]
-    for k in hot:
+    spmv = [k for k in kernels if re.search(r"k_spmv_sellILi[0-3]ELb0ELb[01]ELb[01]ELb0ELi[02]EEEv", k)]   # no offd, no LL
+    assert len(spmv) >= 32, sorted(kernels)[:5]
+    for k in spmv:
         r = kernels[k]
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
+    vec = [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELi2EEEv", k)]
+    assert len(vec) >= 11, sorted(kernels)[:5]
+    for k in vec:
+        r = kernels[k]
+        assert r["VGPRs"] <= 96 and r["Occupancy [waves/SIMD]"] >= 5 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
