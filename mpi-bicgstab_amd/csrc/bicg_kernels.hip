@@ -711,16 +711,19 @@ __device__ __forceinline__ void ll_store_agent(llword *dst, double v, unsigned s
     __hip_atomic_store(dst, tag | (bits & 0xffffffffull), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     __hip_atomic_store(dst + 1, tag | (bits >> 32), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
 }
+// one look at a word pair: true (and the value) when both carry `seq`
+__device__ __forceinline__ bool ll_peek_agent(const llword *src, unsigned seq, double *out)
+{
+    const unsigned long long w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    const unsigned long long w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    *out = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
+    return (unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq;
+}
 __device__ __forceinline__ bool ll_try_agent(const llword *src, unsigned seq, unsigned long long ticks, double *out)
 {
     const unsigned long long t0 = wall_clock64();
     for (unsigned spin = 0;; ++spin) {
-        const unsigned long long w0 = __hip_atomic_load(src, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        const unsigned long long w1 = __hip_atomic_load(src + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-        if ((unsigned)(w0 >> 32) == seq && (unsigned)(w1 >> 32) == seq) {
-            *out = __longlong_as_double((long long)((w0 & 0xffffffffull) | (w1 << 32)));
-            return true;
-        }
+        if (ll_peek_agent(src, seq, out)) return true;
         if ((spin & 15u) == 15u) {
             if (wall_clock64() - t0 > ticks) return false;
             __builtin_amdgcn_s_sleep(1);
@@ -759,18 +762,20 @@ __device__ __forceinline__ void finish_sum_shard(const Finish &f, unsigned shard
 // all ranks. Nobody is waited for longer than spin_ticks inside the GPU: a shard total that has not
 // shown up by then is computed here (same partials, same order, same bits), so the result does
 // not depend on the order in which the hardware dispatches workgroups. False: a PEER timed out.
-__device__ __forceinline__ bool finish_totals(const Finish &f, FinishLds &L, bool block0)
+// (got0, v0): outcome of a first look at this thread's shard total that the caller has already taken.
+__device__ __forceinline__ bool finish_totals(const Finish &f, FinishLds &L, bool block0, bool got0, double v0)
 {
     const unsigned tid = threadIdx.x;
     const bool exchange = f.p2p.seq != 0 && !(f.roles & FIN_LOCAL);
     if (!exchange || (f.roles & FIN_PUSH)) {
-        for (;;) {
+        for (bool first = true;; first = false) {
             if (tid == 0) L.missing = 0u;
             __syncthreads();
             if ((int)tid < kShards * f.n) {
                 const int sh = (int)tid / f.n, d = (int)tid % f.n;
-                double v;
-                if (ll_try_agent(f.shard + ((size_t)sh * kRedSlots + d) * 2, f.seq, f.spin_ticks, &v)) L.vals[sh * kMaxDots + d] = v;
+                double v = v0;
+                if ((first && got0) || ll_try_agent(f.shard + ((size_t)sh * kRedSlots + d) * 2, f.seq, f.spin_ticks, &v))
+                    L.vals[sh * kMaxDots + d] = v;
                 else atomicOr(&L.missing, 1u << sh);
             }
             __syncthreads();
@@ -823,15 +828,27 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
 {
     const unsigned tid = threadIdx.x;
     const bool all = (f.roles & FIN_APPLY) != 0, block0 = bid == 0;
-    if (all && S->done) {
-        if (block0 && tid == 0) *f.Snext = *S;
+    // everything this prologue may need from memory is requested before the first of it is looked at:
+    // `done`, the alarm, a copy of the scalar block (one wavefront) and this thread's shard total --
+    // one round trip instead of four dependent ones underneath the kernel's own loads
+    const int done = S->done;
+    const int alarm = f.alarm ? *f.alarm : 0;
+    double v0 = 0.0;
+    bool got0 = false;
+    const bool local = !(f.p2p.seq != 0 && !(f.roles & FIN_LOCAL)) || (f.roles & FIN_PUSH);
+    if (all && local && !(f.roles & FIN_SHARDS) && (int)tid < kShards * f.n)
+        got0 = ll_peek_agent(f.shard + ((size_t)((int)tid / f.n) * kRedSlots + (int)tid % f.n) * 2, f.seq, &v0);
+    if (all && tid == 64) *priv = *S;
+    if (done) {          // converged: producers wrote nothing, nothing may change any more
+        if (all && block0 && tid == 0) *f.Snext = *S;
         return S;
     }
     if (block0 && f.shard_clear)
         for (unsigned t = tid; t < (unsigned)(kShards * kRedSlots * 2); t += kBlock) f.shard_clear[t] = 0ull;
-    if (f.alarm && *f.alarm) {           // a peer was lost earlier: nothing will ever arrive
+    if (alarm) {           // a peer was lost earlier: nothing will ever arrive
         if (all) {
-            if (tid == 0) { *priv = *S; priv->done = 1; priv->comm_error = 1; if (block0) *f.Snext = *priv; }
+            __syncthreads();
+            if (tid == 0) { priv->done = 1; priv->comm_error = 1; if (block0) *f.Snext = *priv; }
             __syncthreads();
             return priv;
         }
@@ -841,16 +858,13 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
         for (unsigned sh = bid; sh < (unsigned)kShards; sh += nblocks) finish_sum_shard(f, sh, L);
     const bool consume = all || (block0 && (f.roles & (FIN_BLOCK0 | FIN_PUSH)));
     if (!consume) return S;
-    const bool ok = finish_totals(f, L, block0);
+    const bool ok = finish_totals(f, L, block0, got0, v0);
     if (!(f.roles & (FIN_APPLY | FIN_BLOCK0))) return S;
     if (tid == 0) {
         if (!ok && f.alarm) *f.alarm = 1;
         // all: the recurrence runs on the private copy in LDS (other workgroups of this launch may still
-        // be reading S); otherwise workgroup 0 alone works in place: the other workgroups of an SpMV
-        // launch read nothing but `done` (sums are only deposited), the stand-alone finisher has no
-        // other reader
+        // be reading S); otherwise (stand-alone finisher) workgroup 0 alone works in place
         Scal *T = all ? priv : S;
-        if (all) *priv = *S;
         if (ok) {
             for (int d = 0; d < f.n; ++d) T->red[f.red_off + d] = L.sums[d];
             if (f.phase != PH_NONE) apply_phase(T, f.phase, block0);
@@ -868,7 +882,6 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
 __global__ void __launch_bounds__(kBlock) k_finish(Scal *S, Finish f)
 {
     __shared__ FinishLds L;
-    if (blockIdx.x == 0 && S->done) return;
     (void)finish_group(S, f, blockIdx.x, gridDim.x, L, nullptr);
 }
 
@@ -1491,7 +1504,7 @@ static void run_vec(F f, uint32_t n, Scal *S, Reduce red, hipStream_t stream)
 // ---- init: r = b - Ax ; r# = r ; [p = r] ; [bsave = b] ; (r,r)     (src/solver.c:74-78, 475-479)
 struct FInit {
     static constexpr int ND = 1;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     double *r, *rh, *p, *bs; const double *ax;
     __device__ void load(const Scal *) {}
     template <class T> __device__ void apply(uint32_t i, double *acc) const
@@ -1512,7 +1525,7 @@ void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, const Launch 
 // ---- plain: q = r - alpha s (kept in r)                               (src/solver.c:94)
 struct FPlainQ {
     static constexpr int ND = 0;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *r; const double *s; double alpha;
     template <class T> struct In { T r, s; };
@@ -1529,7 +1542,7 @@ void launch_plain_q(const Vecs &v, const Launch &L) { run_vec(FPlainQ{v.r, v.s, 
 // ---- plain: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r)   (src/solver.c:105-111)
 template <bool XNT> struct FPlainXR {
     static constexpr int ND = 2;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *x, *r; const double *p, *y, *rh; double alpha, omega;
     template <class T> struct In { T q, x, p, y, rh; };
@@ -1559,7 +1572,7 @@ void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red)
 // ---- plain: p = beta p ; p += r ; p += (-beta*omega) s                (src/solver.c:117-119)
 struct FPlainP {
     static constexpr int ND = 0;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *p; const double *r, *s; double beta, c;
     template <class T> struct In { T p, r, s; };
@@ -1587,7 +1600,7 @@ template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double o
 // ---- CA: p = r + beta(p - omega s) ; s = w + beta(s - omega z)         (src/solver.c:217-222)
 struct FCaPS {
     static constexpr int ND = 0;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *p, *s; const double *r, *z, *w; double beta, omega;
     template <class T> struct In { T p, s, r, z, w; };
@@ -1608,7 +1621,7 @@ void launch_ca_ps(const Vecs &v, const Launch &L) { run_vec(FCaPS{v.p, v.s, v.r,
 // ---- q = r - alpha s (in r) ; y = w - alpha z (in w) ; (q,y), (y,y)    (src/solver.c:225-228, 361-364)
 struct FQY {
     static constexpr int ND = 2;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *r, *w; const double *s, *z; double alpha;
     template <class T> struct In { T r, s, w, z; };
@@ -1630,7 +1643,7 @@ void launch_qy(const Vecs &v, const Launch &L, Reduce red) { run_vec(FQY{v.r, v.
 //      (src/solver.c:233-236, 240, 242-243; (r#,w) comes from the following SpMV's epilogue)
 template <bool XNT> struct FCaXR {
     static constexpr int ND = 5;
-    static constexpr int kModes = kWaveOnly;
+    static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *x, *r; const double *p, *w, *rh, *s, *z; double alpha, omega;
     template <class T> struct In { T q, x, p, w, rh, s, z; };
@@ -1655,6 +1668,7 @@ template <bool XNT> struct FCaXR {
 };
 void launch_ca_xr(const Vecs &v, const Launch &L, Reduce red)
 {
+    red.p2p.mask &= ~4u;    // slot 2 belongs to the following SpMV's epilogue
     if (stream_x()) run_vec(FCaXR<true>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
     else run_vec(FCaXR<false>{v.x, v.r, v.p, v.w, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
 }

@@ -115,7 +115,6 @@ struct bicg_ctx {
         bool staged = false;     // an SpMV launch has already summed the shards / pushed the sums to the peers
         unsigned seq = 0, mail_seq = 0, nparts = 0;
         int n = 0, off = 0, phase = 0, buf = 0;
-        int ar_off = 0, ar_n = 0;   // host-enqueued all-reduce covers red[ar_off .. ar_off + ar_n)
     } grp;
     bool wave_mode = false;      // this call uses consumer-side finish (run_begin); false: ticket reductions
     double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
@@ -203,7 +202,7 @@ namespace {
 // (the four solvers of reference src/solver.c; struct Finish in bicg_device.h). A group is PRODUCED by
 // one or two kernels (per-wavefront partials), then CONSUMED by the kernel that needs the scalars,
 // by an SpMV that only has to deposit the sums, or by the stand-alone finisher.
-Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg = 0, int ar_off = -1, int ar_n = 0)
+Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg = 0)
 {
     if (c->grp.active) die("internal", "a dot group was produced while the previous one was still open");
     bicg_ctx::Group &g = c->grp;
@@ -211,7 +210,6 @@ Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg = 0, int
     g.active = true;
     g.seq = ++c->grp_seq;
     g.n = n; g.off = off; g.phase = phase; g.buf = (int)(g.seq & 1u);
-    g.ar_off = ar_off < 0 ? off : ar_off; g.ar_n = ar_n > 0 ? ar_n : n;
     g.nparts = nwg * (kBlock / 64);               // SpMV producers: set by spmv()
     if (c->p2p) g.mail_seq = c->p2p->red_seq++;
     Reduce r{};
@@ -264,9 +262,7 @@ Launch grp_consume(bicg_ctx *c)
 }
 
 // The open group as seen by the next SpMV launch: a deferred group is staged (shards summed, sums on
-// their way to the peers) and stays open; sums that only have to be deposited (CA-BiCGStab's
-// (r,r), (r#,r), (r#,s), (r#,z), src/solver.c:240-243) are deposited by the launch; anything else
-// is closed first.
+// their way to the peers) and stays open; anything else is closed first.
 Finish grp_for_spmv(bicg_ctx *c)
 {
     bicg_ctx::Group &g = c->grp;
@@ -276,12 +272,6 @@ Finish grp_for_spmv(bicg_ctx *c)
         if (g.staged) return Finish{};
         g.staged = true;
         return grp_desc(c, FIN_SHARDS | FIN_PUSH);
-    }
-    if (g.phase == PH_NONE) {
-        Finish f = grp_desc(c, FIN_SHARDS | FIN_PUSH | FIN_BLOCK0);
-        g.active = false;
-        if (c->p2p) c->halo_unsynced = 0;
-        return f;
     }
     grp_close(c);
     return Finish{};
@@ -314,7 +304,7 @@ void group_now(bicg_ctx *c, int n, int phase)
         if (!hosted(c)) { c->grp.deferred = false; return; }
         const bicg_ctx::Group g = c->grp;
         grp_close(c, true);                                   // this rank's sums -> Scal::red
-        c->comm->allreduce_sum(c->S->red + g.ar_off, g.ar_n, c->sc);
+        c->comm->allreduce_sum(c->S->red + g.off, g.n, c->sc);
         launch_apply(c->S, g.phase, c->sc);
         return;
     }
@@ -345,7 +335,7 @@ void group_defer(bicg_ctx *c, int n, int phase)
         grp_close(c, true);
         hipEvent_t e = c->ev_dots[c->i_dots++ % kEvRing];
         BICG_HIP(hipEventRecord(e, c->sc));
-        c->pend = true; c->pend_n = g.ar_n; c->pend_off = g.ar_off; c->pend_phase = g.phase; c->pend_ev = e;
+        c->pend = true; c->pend_n = g.n; c->pend_off = g.off; c->pend_phase = g.phase; c->pend_ev = e;
         return;
     }
     if (c->single()) return;
@@ -500,10 +490,9 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 }
 
 
-// SpMV of the four solvers (consumer-side finish): the open group is staged / deposited by this
-// launch, then the SpMV's own dots (ndot > 0) open the next group.
-void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int off = 0, int phase = PH_NONE,
-              int ar_off = -1, int ar_n = 0)
+// SpMV of the pipelined solvers (consumer-side finish): a deferred group of earlier kernels is staged
+// by this launch; the SpMV's own dots (ndot > 0) open the next group.
+void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int phase = PH_NONE)
 {
     const Finish fin = grp_for_spmv(c);
     Reduce red{};
@@ -512,9 +501,8 @@ void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double
             if (fin.seq) die("internal", "an SpMV with dots was asked to stage a deferred group");
             grp_close(c);
         }
-        red = grp_produce(c, off, ndot == 3 ? 2 : ndot, phase, 0, ar_off, ar_n);
+        red = grp_produce(c, 0, ndot, phase, 0);
     }
-    red.apply_now = 0;
     spmv(c, xin, yout, ndot, u, red, fin);
 }
 
@@ -561,45 +549,51 @@ struct Driver {
         launch(v, L, r);
     }
 
+    // plain and CA-BiCGStab: ticket reductions, scalars applied in place by the producer's last workgroup
+    Launch here() const { return Launch{c->S, Finish{}, c->sc}; }
+
     void init()
     {
         const bool plain = method == BICG_BICGSTAB;
         const bool rr = method == BICG_PIPE_BICGSTAB_RR || (method == BICG_PIPE_BICGSTAB && c->opt.rr_drift > 0.0);
-        spmv_grp(c, v.x, v.ax);                                                    // Ax = A x0
-        vec_dots([&](const Vecs &vv, const Launch &L, Reduce r) { launch_init_residual(vv, plain, rr, L, r); }, 1, PH_INIT);   // r = b - Ax, r# = r, (r,r)
-        group_now(c, 1, PH_INIT);
-        if (plain) return;
-        const bool ca = method == BICG_CA_BICGSTAB;
-        spmv_grp(c, v.r, v.w, 1, v.r, 0, PH_INIT_ALPHA);                           // w = A r, (r,w)
-        if (ca) {
+        if (!c->wave_mode) {
+            spmv(c, v.x, v.ax, 0, nullptr, c->red(0, PH_NONE));                       // Ax = A x0
+            launch_init_residual(v, plain, rr, here(), c->red(0, PH_INIT, true, 1));  // r = b - Ax, r# = r, (r,r)
+            group_now(c, 1, PH_INIT);
+            if (plain) return;
+            spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_INIT_ALPHA, true, 1));             // w = A r, (r,w)
             group_now(c, 1, PH_INIT_ALPHA);
-        } else {
-            group_defer(c, 1, PH_INIT_ALPHA);                                       // overlaps t = A w (src/solver.c:339-343)
-            spmv_grp(c, v.w, v.t);
-            group_flush(c);
+            return;
         }
+        spmv_grp(c, v.x, v.ax);                                                    // Ax = A x0
+        vec_dots([&](const Vecs &vv, const Launch &L, Reduce r) { launch_init_residual(vv, plain, rr, L, r); }, 1, PH_INIT);
+        group_now(c, 1, PH_INIT);
+        spmv_grp(c, v.r, v.w, 1, v.r, PH_INIT_ALPHA);                              // w = A r, (r,w)
+        group_defer(c, 1, PH_INIT_ALPHA);                                           // overlaps t = A w (src/solver.c:339-343)
+        spmv_grp(c, v.w, v.t);
+        group_flush(c);
     }
 
     void iter_plain()   // reference src/solver.c:88-119
     {
-        spmv_grp(c, v.p, v.s, 1, v.rh, 0, PH_PLAIN_ALPHA);       // s = A p, (r#,s) -> alpha
+        spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
-        vec(launch_plain_q);                                     // q = r - alpha s
-        spmv_grp(c, v.r, v.y, 2, v.r, 0, PH_OMEGA);              // y = A q, (q,y), (y,y) -> omega
+        launch_plain_q(v, here());                               // q = r - alpha s
+        spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA, true, 2));          // y = A q, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        vec_dots(launch_plain_xr, 2, PH_PLAIN_END);              // x, r, (r,r), (r#,r) -> beta, k++
+        launch_plain_xr(v, here(), c->red(0, PH_PLAIN_END, true, 2));     // x, r, (r,r), (r#,r) -> beta, k++
         group_now(c, 2, PH_PLAIN_END);
-        vec(launch_plain_p);                                     // p = r + beta (p - omega s)
+        launch_plain_p(v, here());                               // p = r + beta (p - omega s)
     }
 
     void iter_ca()      // reference src/solver.c:217-251
     {
-        vec(launch_ca_ps);                                       // p, s recurrences
-        spmv_grp(c, v.s, v.z);                                   // z = A s
-        vec_dots(launch_qy, 2, PH_OMEGA);                        // q, y, (q,y), (y,y) -> omega
+        launch_ca_ps(v, here());                                 // p, s recurrences
+        spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
+        launch_qy(v, here(), c->red(0, PH_OMEGA, true, 2));      // q, y, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        vec_dots(launch_ca_xr, 5, PH_NONE);                      // x, r, (r,r), (r#,r), (r#,s), (r#,z): deposited by the SpMV
-        spmv_grp(c, v.r, v.w, 1, v.rh, 2, PH_RECUR_END, 0, 5);   // w = A r, (r#,w) -> beta, alpha, k++
+        launch_ca_xr(v, here(), c->red(0, PH_NONE, false));      // x, r, (r,r), (r#,r), (r#,s), (r#,z)
+        spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END, true, 5));     // w = A r, (r#,w) -> beta, alpha, k++
         group_now(c, 5, PH_RECUR_END);
     }
 
@@ -684,7 +678,11 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     if (o.check_every < 1) o.check_every = 1;
     c->method = method;
     BICG_HIP(hipSetDevice(c->comm->device));
-    c->wave_mode = true;                 // dot groups are finished by the kernels that consume them
+    // Plain and CA-BiCGStab need every scalar right after the kernel that produces its sums: the ticket
+    // chain at the end of the producer (memory system draining) is then the shortest path. The
+    // pipelined solvers defer their groups across an SpMV (src/solver.c:363-367, 377-385): there the sums
+    // are staged by that SpMV and finished by the kernel that consumes them, off the critical path.
+    c->wave_mode = method >= BICG_PIPE_BICGSTAB;
     c->grp = bicg_ctx::Group{};
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good

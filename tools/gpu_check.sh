@@ -4,7 +4,7 @@
 tag=${1:-chk}; out=gpurun_out/$tag; mkdir -p $out
 export BENCH_WATCHDOG_S=300
 if [ "$2" != "nobuildtests" ]; then
-timeout 900 python -m pytest tests -q -m gpu --deselect tests/test_multirank_fullsize.py --deselect tests/test_bench_torchrun.py > $out/pytest.log 2>&1
+timeout 900 python -m pytest tests -q --capture=sys -m gpu --deselect tests/test_multirank_fullsize.py --deselect tests/test_bench_torchrun.py > $out/pytest.log 2>&1
 echo "pytest rc=$?" | tee -a $out/pytest.log; tail -15 $out/pytest.log
 BICG_SPIN_TICKS=0 timeout 600 python -m pytest tests/test_gpu_parity.py tests/test_full_size.py -x -q -m gpu > $out/pytest_spin0.log 2>&1
 echo "spin0 rc=$?" | tee -a $out/pytest_spin0.log; tail -5 $out/pytest_spin0.log
