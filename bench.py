@@ -15,18 +15,27 @@ exactly like the reference does (src/matrix.c:295-308): strong scaling; halo val
 sums are stored by the producing kernels straight into the other GPUs' memory over xGMI (HIP-IPC
 mapped mailboxes, libbicgstab_hip.so's bicg_p2p.cpp; the IPC handles are exchanged over gloo at
 set-up) once that path's self-test has passed on every rank, otherwise they go through an RCCL
-communicator; torch.distributed (gloo) is only the bootstrap and the timing barrier.
+communicator, and if that cannot be created either, through gloo-staged exchanges;
+torch.distributed (gloo) is otherwise only the bootstrap and the timing barrier.
 
-Matrix and vectors are resident in HBM before the timed region. Rank 0 prints ONE JSON line.
+Matrix and vectors are resident in HBM before the timed region. Rank 0 prints ONE JSON line; besides
+the headline it carries the other workloads north_star names (`extras`: synthetic banded CSR at
+half-bandwidth 8 / 64 / 512 at every GPU count; on one GPU also an irregular FEM-like matrix and the
+256^3 Laplacian = one GPU's share of configs[3] under CA-BiCGStab) and the roofline fraction of every
+solver variant on the headline matrix (`variant_rooflines`).
 """
 from __future__ import annotations
 
 import argparse
+import csv
 import ctypes as C
+import glob
 import json
 import os
+import shutil
 import subprocess
 import sys
+import tempfile
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -35,6 +44,7 @@ sys.path.insert(0, ROOT)
 import numpy as np  # noqa: E402
 
 HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured copy)
+H_UNIQUE = 128
 
 
 def spmv_bytes(nnz, rows, halo=0):
@@ -42,7 +52,67 @@ def spmv_bytes(nnz, rows, halo=0):
     return 12 * nnz + 4 * (rows + 1) + 8 * rows + 8 * rows + 16 * halo
 
 
+# fused-minimum vector bytes per row and iteration (SURVEY.md section 8d "Algorithmic bytes, iteration")
 ITER_VECTOR_BYTES_PER_ROW = {"bicgstab": 120, "ca_bicgstab": 184, "pipe_bicgstab": 192, "pipe_bicgstab_rr": 192}
+
+
+def iteration_bytes(method, nnz, rows):
+    return 2 * spmv_bytes(nnz, rows) + ITER_VECTOR_BYTES_PER_ROW[method] * rows
+
+
+def shifted_iteration_bytes(nshift, nnz, rows, pipelined):
+    """config 5: 2 SpMV + the batched multi-shift update (32 n per non-seed shift,
+    p_j and x_j read and written once) + the seed's own vectors (plain 120 n, pipelined 192 n)"""
+    return 2 * spmv_bytes(nnz, rows) + (nshift - 1) * 32 * rows + (192 if pipelined else 120) * rows
+
+
+def measure_traffic(argv_inner, note):
+    """HBM bytes per SpMV launch of THIS run's kernel, from rocprofv3 PMC counters collected now: two
+    separate passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; the TCC block cannot hold both) over a short
+    inner run of this script. Units and the gfx950 correction follow MI355X_MICROARCH.md (HBM section):
+    both counters are KiB, FETCH_SIZE tallies 128-byte requests as 64 -> x2. The x2 is re-checked in
+    the same pass on k_vec<FPlainQ>, whose read bytes are known exactly (2 vectors of n doubles);
+    the SpMV issues 8-byte loads, for which the guide does not state the factor -- the figure is the
+    measured counters under the factor that reproduces the element-wise kernel."""
+    rocprof = shutil.which("rocprofv3") or "/opt/rocm/bin/rocprofv3"
+    if not os.path.exists(rocprof):
+        return None
+    out = {}
+    tmp = tempfile.mkdtemp(prefix="bicg_pmc_", dir="/tmp")
+    try:
+        for ctr in ("FETCH_SIZE", "WRITE_SIZE"):
+            d = os.path.join(tmp, ctr)
+            cmd = [rocprof, "--kernel-trace", "--pmc", ctr, "-d", d, "-o", "p", "--output-format", "csv", "--",
+                   sys.executable, os.path.join(ROOT, "bench.py")] + argv_inner
+            env = dict(os.environ, TMPDIR="/tmp")
+            r = subprocess.run(cmd, cwd="/tmp", env=env, capture_output=True, text=True, timeout=240)
+            files = glob.glob(os.path.join(d, "**", "*counter_collection.csv"), recursive=True)
+            if not files:
+                note(f"traffic: no counter file from the {ctr} pass (rc {r.returncode})")
+                return None
+            acc = {}
+            for row in csv.DictReader(open(files[0])):
+                if row.get("Counter_Name") != ctr:
+                    continue
+                acc.setdefault(row["Kernel_Name"], []).append(float(row["Counter_Value"]))
+            out[ctr] = acc
+    except Exception as e:  # reported, never required
+        note(f"traffic: {e!r}")
+        return None
+    finally:
+        shutil.rmtree(tmp, ignore_errors=True)
+
+    def per_launch(ctr, key):
+        vals = [v for name, lst in out[ctr].items() if key(name) for v in lst]
+        return (1024.0 * sum(vals) / len(vals), len(vals)) if vals else (None, 0)
+
+    dots = lambda nm: "k_spmv_sell<1" in nm or "k_spmv_sell<2" in nm          # the in-solver SpMV with its dot epilogue
+    fetch, nf = per_launch("FETCH_SIZE", dots)
+    write, nw = per_launch("WRITE_SIZE", dots)
+    qf, _ = per_launch("FETCH_SIZE", lambda nm: "FPlainQ" in nm)
+    if fetch is None or write is None:
+        return None
+    return dict(fetch_counter_bytes=fetch, write_counter_bytes=write, launches=min(nf, nw), fplainq_fetch_counter_bytes=qf)
 
 
 def main():
@@ -51,16 +121,21 @@ def main():
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
     ap.add_argument("--method", default="bicgstab", choices=list(ITER_VECTOR_BYTES_PER_ROW))
-    ap.add_argument("--rows", dest="n", type=int, default=0, help="rows (default: 1602111)")
+    ap.add_argument("--rows", dest="n", type=int, default=0, help="rows (default: 1602111; banded: ~24 M non-zeros)")
     ap.add_argument("--scale-decades", type=float, default=2.0)
-    ap.add_argument("--workload", default="transport", choices=["transport", "laplace7"],
-                    help="transport: BASELINE configs[1] (default). laplace7: 7-point Laplacian on an m^3 grid "
-                         "(configs[3] is m = 512 over 8 GPUs = 64 planes of 512^2 per GPU)")
+    ap.add_argument("--workload", default="transport", choices=["transport", "laplace7", "banded", "fem_like"],
+                    help="transport: BASELINE configs[1] (default, the headline). banded: dense band, --half-bandwidth b "
+                         "(SURVEY 8d synthetic input ii). fem_like: irregular rows (3..27 per row) on the Transport node "
+                         "numbering. laplace7: 7-point Laplacian on an m^3 grid (configs[3] is m = 512 over 8 GPUs = 64 "
+                         "planes of 512^2 per GPU)")
+    ap.add_argument("--half-bandwidth", type=int, default=64)
     ap.add_argument("--grid", dest="m", type=int, default=256, help="grid edge for --workload laplace7")
     ap.add_argument("--matrix", default=None, help="Matrix-Market file (coordinate real general) instead of the "
                     "synthetic; data/Transport.mtx is picked up automatically when it exists")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-variants", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip the banded / FEM-like / Laplacian legs")
+    ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host", "host-p2p"],
                     help="auto (default): direct peer-to-peer stores over xGMI between the kernels (IPC handles "
@@ -70,6 +145,7 @@ def main():
     ap.add_argument("--force-comm", action="store_true",
                     help="one rank only: run the multi-rank code path anyway (1-rank RCCL communicator) -- measures what "
                          "the transport adds to an iteration")
+    ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps for roofline.traffic
     a = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -118,24 +194,27 @@ def main():
 
     dist = None
     stage[0] = "communicator bootstrap"
-    os.environ.setdefault("BICG_P2P_SOFT_FAIL", "1")     # a peer-to-peer time-out becomes a fallback, not an exit
-    os.environ.setdefault("BICG_P2P_TIMEOUT_MS", "8000")   # ranks are aligned by barriers here: 8 s means a lost peer
+    os.environ.setdefault("BICG_P2P_SOFT_FAIL", "1")      # a peer-to-peer time-out becomes a fallback, not an exit
+    os.environ.setdefault("BICG_COMM_SOFT_FAIL", "1")     # so does an RCCL communicator that cannot be created
+    os.environ.setdefault("BICG_P2P_TIMEOUT_MS", "8000")  # ranks are aligned by barriers here: 8 s means a lost peer
     if world > 1:
         import torch.distributed as dist
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="gloo", rank=rank, world_size=world)
 
-    def comm_setup(use_p2p):
+    def everyone(ok):
+        """True when `ok` holds on every rank (collective over gloo)"""
+        if dist is None:
+            return bool(ok)
+        t = torch.tensor([0 if ok else 1], dtype=torch.int32)
+        dist.all_reduce(t)
+        return int(t[0]) == 0
+
+    def comm_setup(use_p2p, allow_rccl=True):
         """(Re)create the library's communicator; returns a description of the data path in use."""
+        from mpi_bicgstab_amd import dist_transport
         if world > 1:
             ident = torch.zeros(H_UNIQUE, dtype=torch.uint8)
-            if rank == 0:
-                buf = (C.c_char * H_UNIQUE)()
-                L.bicg_comm_unique_id(buf)
-                ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
-            dist.broadcast(ident, src=0)
-            raw = bytes(ident.numpy().tobytes())
-            from mpi_bicgstab_amd import dist_transport
             if a.transport == "auto" and use_p2p:
                 # the peer-to-peer data path only needs a host-side exchange of IPC handles at set-up: bootstrap
                 # it over gloo, so that RCCL is not even initialised unless the self-test fails somewhere
@@ -147,8 +226,21 @@ def main():
                                   "bootstrap gloo)")
                 L.bicg_comm_finalize()
                 use_p2p = False
-            if a.transport in ("auto", "rccl"):
-                L.bicg_comm_init_rccl(rank, world, raw, device)
+            base = "gloo-staged"
+            if a.transport in ("auto", "rccl") and allow_rccl:
+                if rank == 0:
+                    buf = (C.c_char * H_UNIQUE)()
+                    L.bicg_comm_unique_id(buf)
+                    ident = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+                dist.broadcast(ident, src=0)
+                rc = L.bicg_comm_init_rccl(rank, world, bytes(ident.numpy().tobytes()), device)
+                if everyone(rc == 0):
+                    base = "rccl"
+                else:           # some rank could not join: every rank drops RCCL, exchanges are staged through gloo
+                    note("RCCL communicator could not be created on every rank: falling back to gloo-staged exchanges")
+                    L.bicg_comm_finalize()
+                    dist_transport.init_host_transport(device)
+                    base = "gloo-staged (fallback: RCCL communicator could not be created)"
             else:
                 dist_transport.init_host_transport(device)
             if use_p2p:
@@ -158,14 +250,13 @@ def main():
             buf = (C.c_char * H_UNIQUE)()
             L.bicg_comm_unique_id(buf)
             L.bicg_comm_init_rccl(0, 1, buf.raw, device)
+            base = "rccl"
             if use_p2p:
                 L.bicg_comm_enable_p2p()
         else:
             L.bicg_comm_init_single(device)
-        mode = int(L.bicg_comm_p2p_active())
-        base = "rccl" if a.transport in ("auto", "rccl") else "gloo-staged"
-        if world == 1 and not a.force_comm:
             return 0, "none"
+        mode = int(L.bicg_comm_p2p_active())
         if mode:
             return mode, (f"peer-to-peer LL stores over xGMI (HIP IPC, {'uncached' if mode == 2 else 'device'} memory; "
                           f"bootstrap {base})")
@@ -177,119 +268,152 @@ def main():
         if dist is not None:
             dist.barrier()
 
-    note(f"communicator ready: {world} rank(s)")
-    stage[0] = "matrix generation / upload"
-    # ---- workload: this rank's row slab of the global matrix
-    mtx = a.matrix or (os.path.join(ROOT, "data", "Transport.mtx") if a.workload == "transport" and not a.n and
-                       os.path.exists(os.path.join(ROOT, "data", "Transport.mtx")) else None)
-    if mtx:
-        blocks = H.load_mtx_blocks(mtx, rank, world)
-        n, nnz_global = int(blocks.info.rows), blocks.nnz_global
-        counts, displs = synth.partition(n, world)
-        lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
-    elif a.workload == "laplace7":
-        n = a.m ** 3
-        nnz_global = synth.stencil7_nnz(a.m)
-    else:
-        n = a.n or synth.TRANSPORT_N
-        nnz_global = synth.transport_nnz(n)
-    if not mtx:
-        counts, displs = synth.partition(n, world)
-        lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
-        if a.workload == "laplace7":
-            slab = synth.stencil7(a.m, synth.LAPLACE_WEIGHTS, rows=(lo, hi))
-        else:
-            slab = synth.transport_like(n=n, rows=(lo, hi), scale_decades=a.scale_decades)
-        diag, offd = synth.split_row_slab(slab, lo)
-        blocks = H.HostBlocks(diag, offd if world > 1 else None, n, counts, displs)
-    ones = np.ones(hi - lo)
-    x0 = np.zeros(hi - lo)
-    ctx = H.Context(blocks)
-    plan = ctx.plan_info()
-    b = ctx.spmv(ones)                       # b = A*1 (reference src/main.c:109-113), collective
-
+    note(f"communicator ready: {world} rank(s), data path: {transport_name}")
     K, W = a.steps, a.warmup
+
+    # ------------------------------------------------------------------ workloads: this rank's row slab
+    def build(workload, n=0, half_bw=64, m=256, matrix=None):
+        """-> dict(name, rows, nnz, blocks, lo, hi, note): this rank's blocks of the global matrix"""
+        mtx = matrix or (os.path.join(ROOT, "data", "Transport.mtx") if workload == "transport" and not n and
+                         os.path.exists(os.path.join(ROOT, "data", "Transport.mtx")) else None)
+        if mtx:
+            blocks = H.load_mtx_blocks(mtx, rank, world)
+            rows, nnz = int(blocks.info.rows), blocks.nnz_global
+            counts, displs = synth.partition(rows, world)
+            lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+            return dict(name="file:" + os.path.basename(mtx), rows=rows, nnz=nnz, blocks=blocks, lo=lo, hi=hi, data="file:" + os.path.basename(mtx),
+                        desc=f"{os.path.basename(mtx)} through the library's block loader, b = A*1, x0 = 0")
+        if workload == "laplace7":
+            rows, nnz = m ** 3, synth.stencil7_nnz(m)
+            desc = f"BASELINE.json configs[3] family: 7-point 3-D Laplacian {m}^3 generated in memory, b = A*1, x0 = 0"
+            gen = lambda lo, hi: synth.stencil7(m, synth.LAPLACE_WEIGHTS, rows=(lo, hi))
+        elif workload == "banded":
+            rows = n or synth.banded_rows_for(24_000_000, half_bw)
+            nnz = synth.banded_nnz(rows, half_bw)
+            desc = (f"synthetic banded CSR (SURVEY.md 8d input ii): half-bandwidth {half_bw}, {rows} rows, value law of the "
+                    f"Transport-shaped synthetic scaled over {a.scale_decades} decades, b = A*1, x0 = 0")
+            gen = lambda lo, hi: synth.banded(rows, half_bw, rows=(lo, hi), scale_decades=a.scale_decades)
+        elif workload == "fem_like":
+            rows = n or synth.TRANSPORT_N
+            nnz = None
+            desc = ("irregular FEM-like CSR: 27-point stencil on the Transport node numbering, every off-diagonal kept with "
+                    "probability 0.55 (row lengths 3..27), b = A*1, x0 = 0")
+            gen = lambda lo, hi: synth.fem_like(rows, rows=(lo, hi))
+        else:
+            rows = n or synth.TRANSPORT_N
+            nnz = synth.transport_nnz(rows)
+            desc = ("BASELINE.json configs[1]: plain BiCGStab, Transport-shaped synthetic (Transport.mtx unavailable offline), "
+                    "b = A*1, x0 = 0")
+            gen = lambda lo, hi: synth.transport_like(n=rows, rows=(lo, hi), scale_decades=a.scale_decades)
+        counts, displs = synth.partition(rows, world)
+        lo, hi = int(displs[rank]), int(displs[rank] + counts[rank])
+        slab = gen(lo, hi)
+        if nnz is None:
+            t = torch.tensor([slab.nnz], dtype=torch.int64)
+            if dist is not None:
+                dist.all_reduce(t)
+            nnz = int(t[0])
+        diag, offd = synth.split_row_slab(slab, lo)
+        blocks = H.HostBlocks(diag, offd if world > 1 else None, rows, counts, displs)
+        return dict(name=workload, rows=rows, nnz=nnz, blocks=blocks, lo=lo, hi=hi, data="synthetic", desc=desc)
+
+    class Leg:
+        """one resident matrix: context, right-hand side, timed solves"""
+
+        def __init__(self, wl):
+            self.wl = wl
+            self.ctx = H.Context(wl["blocks"])
+            self.plan = self.ctx.plan_info()
+            self.ones = np.ones(wl["hi"] - wl["lo"])
+            self.x0 = np.zeros(wl["hi"] - wl["lo"])
+            self.b = self.ctx.spmv(self.ones)         # b = A*1 (reference src/main.c:109-113), collective
+
+        def close(self):
+            self.ctx.close()
+
+        def timed(self, method, kernel_events=False, steps=None, warm=None):
+            k, w = steps or K, W if warm is None else warm
+            ctx = self.ctx
+            ctx.load(self.x0, self.b)
+            ctx.run_begin(method, tol=0.0, max_iter=w + k, check_every=max(w, k, 1), krr=50, nrr=2,
+                          time_kernels=1 if kernel_events else 0)
+            if w:
+                ctx.run_iterate(w)
+            barrier(); ctx.sync(); torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            ctx.run_iterate(k)
+            ctx.sync(); torch.cuda.synchronize(); barrier()
+            dt = time.perf_counter() - t0
+            res = ctx.run_end()
+            if dist is not None:
+                t = torch.tensor([dt], dtype=torch.float64)
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                dt = float(t[0])
+            return dt, res
+
+        def check(self):
+            """Did the exchanges deliver? The TRUE residual b - A x, recomputed with one more distributed
+            SpMV, must agree with the recursive residual the iterations carried (plain BiCGStab keeps them
+            within a small factor over a few hundred iterations). All ranks get the same answer."""
+            x, r = self.ctx.fetch()
+            tr = self.b - self.ctx.spmv(x)
+            sums = torch.tensor([float(tr @ tr), float(r @ r), float(self.b @ self.b), 1.0 if self.ctx.comm_failed() else 0.0],
+                                dtype=torch.float64)
+            if dist is not None:
+                dist.all_reduce(sums)
+            s = [float(v) for v in sums]
+            true_rel = float(np.sqrt(s[0] / s[2])) if s[2] > 0 else float("nan")
+            rec_rel = float(np.sqrt(s[1] / s[2])) if s[2] > 0 else float("nan")
+            ok = s[3] == 0 and np.isfinite(true_rel) and np.isfinite(rec_rel) and true_rel <= 100.0 * rec_rel + 1e-12
+            return bool(ok), true_rel
+
+    # ------------------------------------------------------------------ headline workload
+    stage[0] = "matrix generation / upload"
+    wl = build(a.workload, a.n, a.half_bandwidth, a.m, a.matrix)
+    leg = Leg(wl)
+    n, nnz_global, plan = wl["rows"], wl["nnz"], leg.plan
     note(f"matrix resident: {plan}")
+    leg.ctx.spmv_bench(50)       # clocks and caches in steady state before the first timed iteration
     stage[0] = "timed iterations"
 
-    def timed_run(method, kernel_events):
-        ctx.load(x0, b)
-        ctx.run_begin(method, tol=0.0, max_iter=W + K, check_every=max(W, K, 1), krr=50, nrr=2,
-                      time_kernels=1 if kernel_events else 0)
-        if W:
-            ctx.run_iterate(W)
-        barrier(); ctx.sync(); torch.cuda.synchronize()
-        t0 = time.perf_counter()
-        ctx.run_iterate(K)
-        ctx.sync(); torch.cuda.synchronize(); barrier()
-        dt = time.perf_counter() - t0
-        res = ctx.run_end()
-        if dist is not None:
-            t = torch.tensor([dt], dtype=torch.float64)
-            dist.all_reduce(t, op=dist.ReduceOp.MAX)
-            dt = float(t[0])
-        return dt, res
-
-    def transport_check(res):
-        """Did the exchanges deliver? The TRUE residual b - A x, recomputed with one more distributed
-        SpMV, must agree with the recursive residual the iterations carried (plain BiCGStab keeps them
-        within a small factor over a few hundred iterations). All ranks get the same answer."""
-        x, r = ctx.fetch()
-        tr = b - ctx.spmv(x)
-        sums = torch.tensor([float(tr @ tr), float(r @ r), float(b @ b), 1.0 if ctx.comm_failed() else 0.0], dtype=torch.float64)
-        if dist is not None:
-            dist.all_reduce(sums)
-        true_rel = float(np.sqrt(sums[0] / sums[2])) if sums[2] > 0 else float("nan")
-        rec_rel = float(np.sqrt(sums[1] / sums[2])) if sums[2] > 0 else float("nan")
-        ok = sums[3] == 0 and np.isfinite(true_rel) and np.isfinite(rec_rel) and true_rel <= 100.0 * rec_rel + 1e-12
-        return bool(ok), true_rel
-
-    # main timed region: exactly K iterations, no per-kernel instrumentation
-    dt, res = timed_run(a.method, kernel_events=False)
-    ok, true_relres = transport_check(res)
+    # main timed region: exactly K iterations after W warm-up iterations, no per-kernel instrumentation
+    dt, res = leg.timed(a.method)
+    ok, true_relres = leg.check()
     if not ok and p2p_mode:
-        # the peer-to-peer data path passed its self-test but not this check: measure with RCCL instead
+        # the peer-to-peer data path passed its self-test but not this check: measure with the collectives instead
         note(f"peer-to-peer data path failed the residual check (true relres {true_relres:.3e}); falling back")
         stage[0] = "fallback to the transport's collectives"
         failed_name = transport_name
-        ctx.close()
+        leg.close()
         barrier()
         L.bicg_comm_finalize()
         p2p_mode, transport_name = comm_setup(False)
         transport_name += f" (fallback: '{failed_name}' failed the residual check)"
-        ctx = H.Context(blocks)
-        plan = ctx.plan_info()
-        b = ctx.spmv(ones)
-        dt, res = timed_run(a.method, kernel_events=False)
-        ok, true_relres = transport_check(res)
+        leg = Leg(wl)
+        plan = leg.plan
+        dt, res = leg.timed(a.method)
+        ok, true_relres = leg.check()
     ms_step = 1e3 * dt / K
     relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
     genuine = res.iterations == W + K and np.isfinite(relres) and ok
-
     note(f"{a.method}: {ms_step:.4f} ms/iteration")
-    stage[0] = "roofline / variant legs"
-    # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
-    # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps
-    dt_ev, res_ev = timed_run(a.method, kernel_events=True)
-    spmv_ms = res_ev.spmv_ms_total / max(res_ev.spmv_launches, 1)
-    b_spmv = spmv_bytes(plan["nnz_diag"] + plan["nnz_offd"], plan["rows"], plan["halo"])
-    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
-    traffic = None
-    pmc = os.path.join(ROOT, "profiles", "pmc_spmv.json")
-    if os.path.exists(pmc) and a.workload == "transport" and not a.n and world == 1 and not mtx:
-        try:
-            traffic = json.load(open(pmc)).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
+    if a.inner:       # the run rocprofv3 wraps: kernels only, no result line needed
+        leg.close()
+        dog.cancel()
+        return
 
-    variants = {}
+    stage[0] = "variant legs"
+    variants, variant_roof = {}, {}
     if not a.no_variants:
         for m in ITER_VECTOR_BYTES_PER_ROW:
             if m == a.method:
                 variants[m] = ms_step
-                continue
-            dtv, resv = timed_run(m, kernel_events=False)
-            variants[m] = 1e3 * dtv / K
+            else:
+                dtv, _ = leg.timed(m)
+                variants[m] = 1e3 * dtv / K
+            ib = iteration_bytes(m, nnz_global, n)
+            variant_roof[m] = dict(ms_per_iteration=variants[m], algorithmic_bytes=ib, gbps=ib / (variants[m] * 1e-3) / 1e9,
+                                   frac=ib / (variants[m] * 1e-3) / 1e9 / HBM_PEAK_GBS)
     if not a.no_variants and a.workload == "transport":
         # BASELINE.json configs[4] family: 16 shifts, seed 7, sigma_j = (j+1) 0.01/16 (reference
         # src/main_shifted.c:99 pattern); 2 SpMV + one batched update over all shifts per iteration
@@ -297,17 +421,80 @@ def main():
         sigma = (np.arange(nsh) + 1.0) * 0.01 / nsh
         ks = min(K, 100)
         for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab"):
-            rs = ctx.solve_shifted(b + sigma[seed] * ones, sigma, seed, tol=0.0, max_iter=ks, check_every=ks, which=which)
-            variants[f"{which}_{nsh}shifts"] = 1e3 * rs["result"].seconds / max(rs["k"], 1)
-    spmv_alone_ms = ctx.spmv_bench(200)
+            rs = leg.ctx.solve_shifted(leg.b + sigma[seed] * leg.ones, sigma, seed, tol=0.0, max_iter=ks, check_every=ks, which=which)
+            key = f"{which}_{nsh}shifts"
+            variants[key] = 1e3 * rs["result"].seconds / max(rs["k"], 1)
+            ib = shifted_iteration_bytes(nsh, nnz_global, n, "pipe" in which)
+            variant_roof[key] = dict(ms_per_iteration=variants[key], algorithmic_bytes=ib, gbps=ib / (variants[key] * 1e-3) / 1e9,
+                                     frac=ib / (variants[key] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+    spmv_alone_ms = leg.ctx.spmv_bench(200)
+    # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
+    # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps. It comes after
+    # the other timed legs of this matrix: event-timed launches put the queue into a profiling mode whose switch
+    # back costs the next ordinary launches ~10 ms.
+    stage[0] = "roofline leg"
+    dt_ev, res_ev = leg.timed(a.method, kernel_events=True)
+    spmv_ms = res_ev.spmv_ms_total / max(res_ev.spmv_launches, 1)
+    b_spmv = spmv_bytes(plan["nnz_diag"] + plan["nnz_offd"], plan["rows"], plan["halo"])
+    achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    leg.timed(a.method, steps=4, warm=0)       # back to ordinary launches before the next matrix is timed
+    leg.close()
+
+    # ------------------------------------------------------------------ the other workloads north_star names
+    extras = {}
+    if not a.no_extras and a.workload == "transport" and not a.n and not a.matrix:
+        def extra(name, wl2, methods, steps):
+            stage[0] = f"extra workload {name}"
+            lg = Leg(wl2)
+            out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan)
+            for m in methods:
+                dtv, rv = lg.timed(m, steps=steps, warm=min(W, 10))
+                ms = 1e3 * dtv / steps
+                ib = iteration_bytes(m, wl2["nnz"], wl2["rows"])
+                out[m] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9,
+                              frac=ib / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, iterations=int(rv.iterations))
+            sp = lg.ctx.spmv_bench(100)
+            bs = spmv_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"], lg.plan["halo"])
+            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, frac=bs / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                            algorithmic_bytes_rank0=bs)
+            lg.close()
+            note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods))
+            return out
+        ke = min(K, 100)
+        for hb in (8, 64, 512):
+            extras[f"banded_b{hb}"] = extra(f"banded b={hb}", build("banded", 0, hb), ("bicgstab", "pipe_bicgstab"), ke)
+        if world == 1:
+            extras["fem_like"] = extra("fem_like", build("fem_like"), ("bicgstab", "pipe_bicgstab"), ke)
+            extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
+            extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "
+                                                 "= 16.8 M rows per GPU), CA-BiCGStab")
+
+    # ------------------------------------------------------------------ HBM traffic of this run's SpMV (rocprofv3 PMC)
+    traffic, traffic_detail = None, None
+    if rank == 0 and world == 1 and not a.no_traffic and a.workload == "transport" and not a.matrix:
+        stage[0] = "rocprofv3 counter passes"
+        inner = ["--inner", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-variants", "--no-extras", "--no-traffic",
+                 "--method", a.method, "--scale-decades", str(a.scale_decades)] + (["--rows", str(a.n)] if a.n else [])
+        m = measure_traffic(inner, note)
+        if m:
+            q_known = 2 * 8 * n
+            factor = q_known / m["fplainq_fetch_counter_bytes"] if m.get("fplainq_fetch_counter_bytes") else 2.0
+            traffic = 2.0 * m["fetch_counter_bytes"] + m["write_counter_bytes"]
+            traffic_detail = dict(method="rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE in separate passes over a 30-iteration "
+                                         "inner run of this command; KiB x 1024; FETCH_SIZE x 2 (gfx950: 128-byte requests tallied at 64)",
+                                  fetch_bytes_x2=2.0 * m["fetch_counter_bytes"], write_bytes=m["write_counter_bytes"], launches=m["launches"],
+                                  fetch_factor_reproducing_k_vec_FPlainQ=factor,
+                                  caveat="the x2 is stated by the guide for wide coalesced reads and re-checked here on the element-wise "
+                                         "kernel; the SpMV issues 8- and 16-byte loads")
 
     cpu = None
     cpu_all = None
-    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "transport" and not mtx:
+    if rank == 0 and world == 1 and not a.no_cpu_baseline and a.workload == "transport" and not a.matrix:
+        stage[0] = "cpu baseline"
         try:
             out = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "cpu_baseline.py"), "--n", str(n),
                                   "--scale-decades", str(a.scale_decades), "--iters", str(a.cpu_iters),
-                                  "--method", a.method], capture_output=True, text=True, timeout=900)
+                                  "--method", a.method], capture_output=True, text=True, timeout=600)
             cpu = json.loads(out.stdout.strip().splitlines()[-1])
         except Exception as e:  # the baseline is reported, never required
             cpu = {"error": repr(e)}
@@ -326,16 +513,15 @@ def main():
             cpu_all = {"error": repr(e)}
 
     if rank == 0:
-        iter_bytes = 2 * spmv_bytes(nnz_global, n) + ITER_VECTOR_BYTES_PER_ROW[a.method] * n
+        iter_bytes = iteration_bytes(a.method, nnz_global, n)
+        shape = {"transport": "Transport-shaped CSR", "laplace7": f"7-point Laplacian {a.m}^3", "banded": f"banded CSR b={a.half_bandwidth}",
+                 "fem_like": "FEM-like irregular CSR"}[a.workload]
         line = {
-            "metric": f"ms/iteration, {a.method}, " + ("Transport-shaped CSR" if a.workload == "transport" else f"7-point Laplacian {a.m}^3")
-                      + f" ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
+            "metric": f"ms/iteration, {a.method}, {shape} ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
             "value": ms_step, "unit": "ms/iteration", "n_gpus": world, "steps": K, "warmup": W,
             "ms_per_step": ms_step, "higher_is_better": False, "scaling": "strong", "vs_baseline": None,
-            "dtype": "f64", "data": ("synthetic" if not mtx else "file:" + os.path.basename(mtx)),
-            "config": {"workload": ("BASELINE.json configs[1]: plain BiCGStab, Transport-shaped synthetic "
-                                    "(Transport.mtx unavailable offline), b = A*1, x0 = 0") if a.workload == "transport" else
-                                   f"BASELINE.json configs[3] family: 7-point 3-D Laplacian {a.m}^3 generated in memory, b = A*1, x0 = 0",
+            "dtype": "f64", "data": wl["data"],
+            "config": {"workload": wl["desc"],
                        "rows": n, "nnz": nnz_global, "scale_decades": a.scale_decades, "method": a.method,
                        "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
                        "transport": transport_name,
@@ -345,7 +531,7 @@ def main():
             "iteration_algorithmic_bytes": iter_bytes,
             "roofline": {"kernel": "k_spmv_sell (sliced-ELL SpMV with fused dot epilogue), rank 0 share", "bound": "hbm",
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "algorithmic_bytes_per_launch": b_spmv,
+                         "traffic": traffic, "traffic_detail": traffic_detail, "algorithmic_bytes_per_launch": b_spmv,
                          "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,
                          "ms_per_step_with_events": 1e3 * dt_ev / K,
                          "back_to_back_spmv_ms": spmv_alone_ms,
@@ -353,18 +539,17 @@ def main():
             "cpu_baseline": cpu,
             "cpu_baseline_multicore": cpu_all,
             "variants_ms_per_iteration": variants,
+            "variant_rooflines": variant_roof,
+            "extras": extras,
         }
         print(json.dumps(line), file=result_out, flush=True)
 
     dog.cancel()
-    ctx.close()
     if dist is not None:
         dist.barrier()
         L.bicg_comm_finalize()
         dist.destroy_process_group()
 
-
-H_UNIQUE = 128
 
 if __name__ == "__main__":
     main()

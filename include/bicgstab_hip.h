@@ -118,7 +118,9 @@ int shifted_lopbicg_switching_noovlp(CSR_Matrix *A_loc_diag, CSR_Matrix *A_loc_o
 
 /* rank 0: create an RCCL unique id to broadcast to the other ranks by any means */
 int bicg_comm_unique_id(void *id_out /* BICG_UNIQUE_ID_BYTES */);
-/* all ranks: join. device = HIP device ordinal for this process (-1: rank % device count) */
+/* all ranks: join. device = HIP device ordinal for this process (-1: rank % device count). Returns 0; with
+ * BICG_COMM_SOFT_FAIL=1 in the environment a failing ncclCommInitRank returns 1 instead of exiting (no
+ * communicator is installed then -- the caller picks another transport on all ranks). */
 int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device);
 
 /* Host-staged transport. Callbacks operate on HOST buffers and are collective.

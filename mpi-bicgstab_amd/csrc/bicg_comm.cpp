@@ -225,7 +225,17 @@ Comm *make_rccl(int rank, int nranks, const void *id, int device)
     c->device = pick_device(rank, device);
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
-    BICG_NCCL(rccl().CommInitRank(&c->comm, nranks, uid, rank));
+    const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, uid, rank);
+    if (r != ncclSuccess) {
+        // BICG_COMM_SOFT_FAIL=1 (bench.py): report instead of exiting, so that the caller can fall back to
+        // another transport collectively
+        const char *soft = getenv("BICG_COMM_SOFT_FAIL");
+        if (!soft || atoi(soft) == 0) die("ncclCommInitRank", rccl().GetErrorString(r));
+        fprintf(stderr, "bicgstab_hip: rank %d: ncclCommInitRank failed: %s\n", rank, rccl().GetErrorString(r));
+        c->comm = nullptr;
+        delete c;
+        return nullptr;
+    }
     return c;
 }
 
@@ -262,7 +272,9 @@ int bicg_comm_unique_id(void *id_out) { return rccl_unique_id(id_out); }
 int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device)
 {
     const char *force = getenv("BICG_FORCE_COMM");     // tests: a real 1-rank RCCL communicator
-    comm_set(nranks > 1 || (force && atoi(force)) ? make_rccl(rank, nranks, id, device) : make_single(device));
+    Comm *c = nranks > 1 || (force && atoi(force)) ? make_rccl(rank, nranks, id, device) : make_single(device);
+    if (!c) return 1;                                  // BICG_COMM_SOFT_FAIL: no communicator was installed
+    comm_set(c);
     return 0;
 }
 
@@ -300,8 +312,11 @@ int bicg_comm_init_mpi(const char *transport, int device)
         char id[BICG_UNIQUE_ID_BYTES];
         if (rank == 0) rccl_unique_id(id);
         bicg_mpi_bcast_bytes(id, BICG_UNIQUE_ID_BYTES, 0);
-        comm_set(make_rccl(rank, size, id, device));
-    } else {
+        Comm *rc = make_rccl(rank, size, id, device);
+        if (rc) comm_set(rc);
+        else use_rccl = false;          // BICG_COMM_SOFT_FAIL: staged through MPI instead
+    }
+    if (!use_rccl) {
         comm_set(make_host(rank, size, bicg_mpi_allreduce_sum, bicg_mpi_alltoallv_bytes, nullptr, device));
     }
     const bool automatic = !transport || strcmp(transport, "auto") == 0;

@@ -45,7 +45,6 @@ struct P2p {
     Comm *comm = nullptr;
     int rank = 0, nranks = 1;
     bool uncached = false;                 // mailboxes live in uncached (fine-grained) device memory
-    bool plain_memory = false;             // uncached allocations could not be exported: use hipMalloc
     llword *mail = nullptr;                // this rank's all-reduce mailbox
     llword **mail_dev = nullptr;           // device array [nranks]: all mailboxes as mapped here
     std::vector<void *> mapped;            // IPC mappings of the mailboxes
@@ -60,7 +59,7 @@ struct P2p {
         r.n_collect = 0; r.timeout_ticks = timeout_ticks;
         return r;
     }
-    void *alloc(size_t bytes);             // zero-filled device memory other ranks may map
+    void *alloc(size_t bytes);             // zero-filled UNCACHED device memory other ranks may map; nullptr if unavailable
     void release(void *p);
     // Collective. Maps `local` of every rank into this process: peers[p] (peers[rank] = local);
     // the mappings of the other ranks are appended to `opened`. 0 when it worked on EVERY rank.

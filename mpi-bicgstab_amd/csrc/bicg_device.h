@@ -279,6 +279,11 @@ void launch_p2p_barrier(const P2pRed &pr, unsigned long long timeout_ticks, Scal
 // counts mismatches, status[1] time-outs
 void launch_p2p_selftest(const P2pRed &pr, unsigned seq0, int rounds, unsigned long long timeout_ticks, int *status,
                          hipStream_t st);
+// ... and of the halo pattern: `rounds` exchanges of `entries` values per rank pair through test rings laid out
+// [kHaloRing][source rank][entries][2], slots reused, ranks out of step, token barrier (sequence bar_seq0...) every
+// kHaloRing - 2 rounds; status[0] counts wrong / stale values, status[1] time-outs
+void launch_p2p_ringtest(const P2pRed &pr, llword *const *rings, int entries, unsigned seq0, int rounds, unsigned bar_seq0,
+                         unsigned long long timeout_ticks, int *status, hipStream_t st);
 
 // The kernels of the four solvers take a Launch: the scalar block to read, the dot group of earlier
 // kernels to finish first (if any) and the stream.

@@ -1344,6 +1344,61 @@ void launch_p2p_barrier(const P2pRed &pr, unsigned long long timeout_ticks, Scal
     hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, st, pr, timeout_ticks, S);
 }
 
+// Second part of the transport self-test: the HALO pattern -- every rank stores `entries` values per
+// round into the landing ring of every other rank and reads what the others stored into its own,
+// for more rounds than the ring has slots (a reused slot must never be read with its old contents),
+// with the ranks deliberately out of step and the solver's flow control (a token barrier every
+// kHaloRing - 2 exchanges). Ring layout: [kHaloRing][source rank][entries][2 words].
+__device__ __forceinline__ double ringtest_value(int rank, unsigned seq, int i)
+{
+    return (double)(rank * 1009 + i * 17 + 1) * 1.0000001 + (double)seq * 0.25;
+}
+__global__ void __launch_bounds__(kBlock) k_p2p_ringtest(P2pRed pr, llword *const *rings, int entries, unsigned seq0, int rounds,
+                                                         unsigned bar_seq0, unsigned long long timeout_ticks, int *status)
+{
+    __shared__ int s_bad, s_timeout;
+    const int P = pr.nranks, me = pr.rank;
+    if (threadIdx.x == 0) { s_bad = 0; s_timeout = 0; }
+    __syncthreads();
+    for (int r = 0; r < rounds; ++r) {
+        const unsigned seq = seq0 + (unsigned)r;
+        const size_t slot = seq % kHaloRing;
+        if (r % (kHaloRing - 2) == 0) {          // flow control, as in spmv(): nobody runs more than a ring ahead
+            const unsigned bs = bar_seq0 + (unsigned)(r / (kHaloRing - 2));
+            for (int p = threadIdx.x; p < P; p += kBlock)
+                ll_store(pr.mail[p] + mail_index(bs, P, me, kRedSlots - 1), 0.0, bs);
+            for (int p = threadIdx.x; p < P; p += kBlock) {
+                double v;
+                if (!ll_wait(pr.mail[me] + mail_index(bs, P, p, kRedSlots - 1), bs, timeout_ticks, &v)) s_timeout = 1;
+            }
+            __syncthreads();
+        }
+        if ((r + me) & 1) __builtin_amdgcn_s_sleep(127);     // keep the ranks out of step
+        for (int t = threadIdx.x; t < P * entries; t += kBlock) {
+            const int p = t / entries, i = t % entries;
+            ll_store(rings[p] + ((slot * P + me) * entries + i) * 2, ringtest_value(me, seq, i), seq);
+        }
+        for (int t = threadIdx.x; t < P * entries; t += kBlock) {
+            const int p = t / entries, i = t % entries;
+            double v;
+            if (!ll_wait(rings[me] + ((slot * P + p) * entries + i) * 2, seq, timeout_ticks, &v)) s_timeout = 1;
+            else if (!(v == ringtest_value(p, seq, i))) s_bad = 1;
+        }
+        __syncthreads();
+        if (s_timeout) break;
+    }
+    if (threadIdx.x == 0) {
+        if (s_bad) atomicAdd(&status[0], 1);
+        if (s_timeout) atomicAdd(&status[1], 1);
+    }
+}
+
+void launch_p2p_ringtest(const P2pRed &pr, llword *const *rings, int entries, unsigned seq0, int rounds, unsigned bar_seq0,
+                         unsigned long long timeout_ticks, int *status, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_p2p_ringtest, dim3(1), dim3(kBlock), 0, st, pr, rings, entries, seq0, rounds, bar_seq0, timeout_ticks, status);
+}
+
 void launch_p2p_selftest(const P2pRed &pr, unsigned seq0, int rounds, unsigned long long timeout_ticks, int *status,
                          hipStream_t st)
 {

@@ -66,13 +66,22 @@ void *P2p::alloc(size_t bytes)
 {
     void *p = nullptr;
     if (bytes == 0) bytes = 16;
-    const char *mode = getenv("BICG_P2P_ALLOC");   // uncached (default) | default
+    // Mailboxes and landing rings are written by other GPUs and polled here: they must live in UNCACHED
+    // (fine-grained) device memory. With ordinary hipMalloc memory a line polled earlier may stay in this
+    // GPU's L2, which a peer's store over xGMI does not invalidate -- a reused ring slot could be read
+    // stale until the time-out. No silent fallback: if the runtime cannot provide (or export) uncached
+    // memory the peer-to-peer path stays off and the transport's own collectives are used.
+    // BICG_P2P_ALLOC=default asks for ordinary memory explicitly (single-GPU experiments only).
+    const char *mode = getenv("BICG_P2P_ALLOC");
     uncached = false;
-    if (!plain_memory && (!mode || strcmp(mode, "default") != 0)) {
-        if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess && p) uncached = true;
-        else { (void)hipGetLastError(); p = nullptr; }
+    if (mode && strcmp(mode, "default") == 0) {
+        BICG_HIP(hipMalloc(&p, bytes));
+    } else if (hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached) == hipSuccess && p) {
+        uncached = true;
+    } else {
+        (void)hipGetLastError();
+        return nullptr;
     }
-    if (!p) BICG_HIP(hipMalloc(&p, bytes));
     BICG_HIP(hipMemset(p, 0, bytes));
     BICG_HIP(hipDeviceSynchronize());
     return p;
@@ -93,7 +102,7 @@ int P2p::share(void *local, std::vector<void *> &peers, std::vector<void *> &ope
     mine.device = comm->device;
     mine.host = host_hash();
     mine.pid = (long long)getpid();
-    mine.ok = hipIpcGetMemHandle(&mine.handle, local) == hipSuccess ? 1 : 0;
+    mine.ok = local && hipIpcGetMemHandle(&mine.handle, local) == hipSuccess ? 1 : 0;
     if (!mine.ok) (void)hipGetLastError();
 
     std::vector<ShareMsg> out(P, mine), in(P);
@@ -155,15 +164,6 @@ int p2p_enable(Comm *c)
     t->mail = (llword *)t->alloc(words * sizeof(llword));
     std::vector<void *> peers;
     int rc = t->share(t->mail, peers, t->mapped);
-    if (rc != 0 && t->uncached) {
-        // some runtimes refuse to export uncached allocations: retry with ordinary device memory
-        // (the words are only ever accessed with system-scope atomics, which bypass the caches)
-        t->unmap(t->mapped);
-        t->release(t->mail);
-        t->plain_memory = true;
-        t->mail = (llword *)t->alloc(words * sizeof(llword));
-        rc = t->share(t->mail, peers, t->mapped);
-    }
     if (rc == 0) {
         BICG_HIP(hipMalloc((void **)&t->mail_dev, sizeof(llword *) * c->nranks));
         BICG_HIP(hipMemcpy(t->mail_dev, peers.data(), sizeof(llword *) * c->nranks, hipMemcpyHostToDevice));
@@ -182,10 +182,44 @@ int p2p_enable(Comm *c)
         BICG_HIP(hipMemcpy(h, status, sizeof h, hipMemcpyDeviceToHost));
         BICG_HIP(hipStreamDestroy(st));
         BICG_HIP(hipFree(status));
-        const int bad = (h[0] != 0 || h[1] != 0) ? 1 : 0;
+        int bad = (h[0] != 0 || h[1] != 0) ? 1 : 0;
         if (bad && !getenv("BICG_QUIET"))
             fprintf(stderr, "bicgstab_hip: rank %d: peer-to-peer self-test failed (%d wrong sums, %d time-outs)\n", c->rank, h[0], h[1]);
         rc = all_zero(c, bad) ? 0 : 2;
+        if (rc == 0) {
+            // halo pattern: landing rings of the solver's kind, more rounds than slots, ranks out of step
+            const int entries = 64, rounds = 3 * kHaloRing + 2;
+            llword *ring = (llword *)t->alloc(sizeof(llword) * 2 * (size_t)kHaloRing * c->nranks * entries);
+            std::vector<void *> rpeers, ropened;
+            int rrc = t->share(ring, rpeers, ropened);
+            if (rrc == 0) {
+                llword **rings_dev = nullptr;
+                BICG_HIP(hipMalloc((void **)&rings_dev, sizeof(llword *) * c->nranks));
+                BICG_HIP(hipMemcpy(rings_dev, rpeers.data(), sizeof(llword *) * c->nranks, hipMemcpyHostToDevice));
+                int *st2 = nullptr, h2[2] = {0, 0};
+                BICG_HIP(hipMalloc((void **)&st2, sizeof h2));
+                BICG_HIP(hipMemset(st2, 0, sizeof h2));
+                hipStream_t s2;
+                BICG_HIP(hipStreamCreateWithFlags(&s2, hipStreamNonBlocking));
+                BICG_HIP(hipDeviceSynchronize());
+                launch_p2p_ringtest(t->red_desc(0), rings_dev, entries, 1u, rounds, t->bar_seq, t->timeout_ticks, st2, s2);
+                t->bar_seq += (unsigned)(rounds / (kHaloRing - 2) + 1);
+                BICG_HIP(hipStreamSynchronize(s2));
+                BICG_HIP(hipMemcpy(h2, st2, sizeof h2, hipMemcpyDeviceToHost));
+                BICG_HIP(hipStreamDestroy(s2));
+                BICG_HIP(hipFree(st2));
+                BICG_HIP(hipFree(rings_dev));
+                bad = (h2[0] != 0 || h2[1] != 0) ? 1 : 0;
+                if (bad && !getenv("BICG_QUIET"))
+                    fprintf(stderr, "bicgstab_hip: rank %d: peer-to-peer halo-ring self-test failed (%d stale or wrong values, %d time-outs)\n",
+                            c->rank, h2[0], h2[1]);
+            } else {
+                bad = 1;
+            }
+            rc = all_zero(c, bad) ? 0 : 3;     // every rank has finished with the test rings before any is unmapped
+            t->unmap(ropened);
+            t->release(ring);
+        }
     }
     if (rc != 0) {
         delete t;

@@ -1189,28 +1189,37 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     Comm *comm = comm_get();
     BICG_HIP(hipSetDevice(comm->device));
     if (info->rows != info->cols) { fprintf(stderr, "ERROR: bicg_create: matrix is not square\n"); return nullptr; }
-    if (diag->rows == 0) { fprintf(stderr, "ERROR: bicg_create: a rank without rows is not supported\n"); return nullptr; }
 
     bicg_ctx *c = new bicg_ctx;
     c->comm = comm; c->nranks = comm->nranks; c->rank = comm->rank;
     c->n_loc = diag->rows; c->n_glob = info->rows;
-    c->nnz_d = diag->ptr[diag->rows];
+    c->nnz_d = diag->rows ? diag->ptr[diag->rows] : 0u;
     const int P = c->nranks;
 
     const bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
-    {   // the enqueue mode changes the ORDER of RCCL calls, so every rank must take the same decision:
-        // it is based on the average number of local non-zeros over all ranks
+    {   // Every rank learns every rank's (non-zeros, rows). The enqueue mode changes the ORDER of RCCL calls,
+        // so all ranks must take the same decision: it is based on the average number of local non-zeros.
+        // A rank WITHOUT rows (more ranks than rows, or an empty block of a non-zero balanced partition) is not
+        // supported -- the reference's loops simply run over zero rows there (src/matrix.c:295-298); here such
+        // a rank would still have to take part in every exchange. All ranks see it and give up together.
         uint64_t total = c->nnz_d;
+        bool empty = c->n_loc == 0;
         if (P > 1) {
-            std::vector<int> one(P, (int)sizeof(uint32_t)), off(P);
-            std::vector<uint32_t> mine(P, c->nnz_d), all(P, 0u);
-            for (int p = 0; p < P; ++p) off[p] = p * (int)sizeof(uint32_t);
-            comm->alltoallv_host(mine.data(), one.data(), off.data(), all.data(), one.data(), off.data());
+            std::vector<int> cnt(P, 2 * (int)sizeof(uint32_t)), off(P);
+            std::vector<uint32_t> mine(2 * (size_t)P), all(2 * (size_t)P, 0u);
+            for (int p = 0; p < P; ++p) { off[p] = 2 * p * (int)sizeof(uint32_t); mine[2 * p] = c->nnz_d; mine[2 * p + 1] = c->n_loc; }
+            comm->alltoallv_host(mine.data(), cnt.data(), off.data(), all.data(), cnt.data(), off.data());
+            all[2 * c->rank] = c->nnz_d; all[2 * c->rank + 1] = c->n_loc;
             total = 0;
-            for (int p = 0; p < P; ++p) total += all[p];
+            for (int p = 0; p < P; ++p) { total += all[2 * p]; empty = empty || all[2 * p + 1] == 0; }
+        }
+        if (empty) {
+            if (c->rank == 0) fprintf(stderr, "ERROR: bicg_create: a rank without rows is not supported (%u rows over %d ranks)\n", info->rows, P);
+            delete c;
+            return nullptr;
         }
         c->overlap = total / (uint64_t)P >= 6000000u;
     }
@@ -1283,6 +1292,11 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         for (uint32_t g = 0; g < ngroups; ++g)
             if (group_fits(g, &dummy)) rows_fit += std::min(nrows, (g + 1) * (uint32_t)kGroupRows) - g * kGroupRows;
         sell_worthwhile = 2 * rows_fit >= nrows;
+        // Lane = row needs rows to parallelise over: a few thousand very long rows (banded, half-bandwidth 512:
+        // 23 k rows x 1025 entries = 92 workgroups for 256 CUs, 125 us per SpMV) belong on the row-block kernel,
+        // whose parallelism is the number of non-zeros
+        if (ngroups < 512 && (uint64_t)c->nnz_d > 64ull * nrows && !(getenv("BICG_FORCE_SELL") && atoi(getenv("BICG_FORCE_SELL"))))
+            sell_worthwhile = false;
     }
     uint64_t sell_entries = 0;
     for (uint32_t g = 0; g < ngroups; ++g) {

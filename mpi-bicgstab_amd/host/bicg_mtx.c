@@ -3,6 +3,7 @@
 
 #include <ctype.h>
 #include <stdint.h>
+#include <limits.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -17,6 +18,7 @@ typedef struct { unsigned r, c; double v; } triplet;
 typedef struct {
     unsigned long m, n, nz;
     int pattern, integer, symmetric;
+    unsigned long long emitted;      /* entries handed to emit() by parse_entries (mirrored ones included) */
     size_t data_off;      /* byte offset of the first entry line */
 } mtx_header;
 
@@ -119,7 +121,11 @@ static int parse_header(const char *buf, mtx_header *h)
     h->pattern = strstr(banner, "pattern") != NULL;
     h->integer = strstr(banner, "integer") != NULL;
     h->symmetric = strstr(banner, "symmetric") != NULL && strstr(banner, "skew") == NULL;
-    if (!strstr(banner, "coordinate") || strstr(banner, "complex")) {
+    h->emitted = 0;
+    /* skew-symmetric / hermitian storage would need sign / conjugate handling on the mirrored half: refuse
+     * rather than silently treat the file as general (the reference's block loader ignores the banner
+     * altogether, src/matrix.c:268-396) */
+    if (!strstr(banner, "coordinate") || strstr(banner, "complex") || strstr(banner, "skew") || strstr(banner, "hermitian")) {
         fprintf(stderr, "Sorry, this application does not support Market Market type: [%s]\n", banner);
         return 3;
     }
@@ -143,11 +149,12 @@ static void tpush(tvec *v, unsigned r, unsigned c, double val)
 }
 
 /* tokenise entry lines in [p, end): calls emit(row, col, val) with 0-based GLOBAL indices (src/matrix.c:333-334) */
-static int parse_entries(const char *p, const char *end, const mtx_header *h, unsigned long max_entries,
+static int parse_entries(const char *p, const char *end, mtx_header *h, unsigned long max_entries,
                          void (*emit)(void *, unsigned long, unsigned long, double), void *ctx)
 {
     char *q;
     unsigned long seen = 0;
+    h->emitted = 0;
     while (p < end && seen < max_entries) {
         while (p < end && isspace((unsigned char)*p)) ++p;
         if (p >= end) break;
@@ -160,7 +167,8 @@ static int parse_entries(const char *p, const char *end, const mtx_header *h, un
         if (!h->pattern) { v = strtod(p, &q); p = q; }
         --i; --j;
         emit(ctx, i, j, v);
-        if (h->symmetric && i != j) emit(ctx, j, i, v);
+        h->emitted++;
+        if (h->symmetric && i != j) { emit(ctx, j, i, v); h->emitted++; }
         ++seen;
     }
     return 0;
@@ -252,6 +260,12 @@ int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, C
     rc = parse_entries(buf + h.data_off, buf + len, &h, h.nz, emit_serial, &s);
     free(buf);
     if (rc) return rc;
+    /* nz = entries of the matrix that is actually solved: for 'symmetric' storage the banner counts one
+     * triangle only (the reference's loader does not mirror: it would solve that triangle) */
+    info->nz = (unsigned)h.emitted;
+    if (h.symmetric && rank == 0)
+        fprintf(stderr, "bicg_mtx: 'symmetric' storage: mirrored to %llu entries (the reference's block loader keeps the stored triangle only)\n",
+                h.emitted);
     build_blocks(s.mine.t, s.mine.n, s.lo, s.hi, (unsigned)h.n, diag, offd);
     free(s.mine.t);
     return 0;
@@ -439,22 +453,46 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     if (!rc && p < q) rc = parse_entries(p, q, &h, (unsigned long)-1, emit_par, &pc);
     free(buf);
     if (rc) return rc;
+    {   /* see the serial loader: nz = entries actually emitted, over all byte ranges */
+        unsigned long long tot = p < q ? h.emitted : 0ull;
+        MPI_Allreduce(MPI_IN_PLACE, &tot, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+        info->nz = (unsigned)tot;
+        if (h.symmetric && me == 0)
+            fprintf(stderr, "bicg_mtx: 'symmetric' storage: mirrored to %llu entries (the reference's block loader keeps the stored triangle only)\n", tot);
+    }
 
-    /* exchange: counts, then triplets (as bytes); source-rank order = file order */
+    /* exchange: counts, then triplets; source-rank order = file order. Counts and displacements are in
+     * TRIPLETS (a 16-byte MPI datatype), so a pair of ranks may exchange up to INT_MAX of them; beyond that
+     * (> 2^31 entries to or from one rank) the int-based MPI interface cannot express the exchange at all */
     int *scnt = (int *)malloc(sizeof(int) * np), *sdsp = (int *)malloc(sizeof(int) * np);
     int *rcnt = (int *)malloc(sizeof(int) * np), *rdsp = (int *)malloc(sizeof(int) * np);
     size_t stot = 0;
-    for (int r = 0; r < np; ++r) { scnt[r] = (int)(pc.bins[r].n * sizeof(triplet)); sdsp[r] = (int)stot; stot += (size_t)scnt[r]; }
+    int too_big = 0;
+    for (int r = 0; r < np; ++r) {
+        if (pc.bins[r].n > (size_t)INT_MAX || stot > (size_t)INT_MAX) too_big = 1;
+        scnt[r] = (int)pc.bins[r].n; sdsp[r] = (int)stot; stot += pc.bins[r].n;
+    }
     MPI_Alltoall(scnt, 1, MPI_INT, rcnt, 1, MPI_INT, MPI_COMM_WORLD);
     size_t rtot = 0;
-    for (int r = 0; r < np; ++r) { rdsp[r] = (int)rtot; rtot += (size_t)rcnt[r]; }
-    char *sbuf = (char *)malloc(stot ? stot : 1), *rbuf = (char *)malloc(rtot ? rtot : 1);
-    for (int r = 0; r < np; ++r) { if (scnt[r]) memcpy(sbuf + sdsp[r], pc.bins[r].t, (size_t)scnt[r]); free(pc.bins[r].t); }
+    for (int r = 0; r < np; ++r) { if (rtot > (size_t)INT_MAX) too_big = 1; rdsp[r] = (int)rtot; rtot += (size_t)rcnt[r]; }
+    MPI_Allreduce(MPI_IN_PLACE, &too_big, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+    if (too_big) {
+        if (me == 0) fprintf(stderr, "ERROR: bicg_mtx: more than 2^31 entries to or from one rank: use more ranks or the serial loader\n");
+        for (int r = 0; r < np; ++r) free(pc.bins[r].t);
+        free(pc.bins); free(scnt); free(sdsp); free(rcnt); free(rdsp);
+        return 7;
+    }
+    MPI_Datatype trip;
+    MPI_Type_contiguous((int)sizeof(triplet), MPI_BYTE, &trip);
+    MPI_Type_commit(&trip);
+    triplet *sbuf = (triplet *)malloc(sizeof(triplet) * (stot ? stot : 1)), *rbuf = (triplet *)malloc(sizeof(triplet) * (rtot ? rtot : 1));
+    for (int r = 0; r < np; ++r) { if (scnt[r]) memcpy(sbuf + sdsp[r], pc.bins[r].t, sizeof(triplet) * (size_t)scnt[r]); free(pc.bins[r].t); }
     free(pc.bins);
-    MPI_Alltoallv(sbuf, scnt, sdsp, MPI_BYTE, rbuf, rcnt, rdsp, MPI_BYTE, MPI_COMM_WORLD);
+    MPI_Alltoallv(sbuf, scnt, sdsp, trip, rbuf, rcnt, rdsp, trip, MPI_COMM_WORLD);
+    MPI_Type_free(&trip);
     free(sbuf);
     const unsigned lo = (unsigned)info->displs[me], hi = lo + (unsigned)info->recvcounts[me];
-    build_blocks((const triplet *)rbuf, rtot / sizeof(triplet), lo, hi, (unsigned)h.n, diag, offd);
+    build_blocks(rbuf, rtot, lo, hi, (unsigned)h.n, diag, offd);
     free(rbuf); free(scnt); free(sdsp); free(rcnt); free(rdsp);
     return 0;
 }

@@ -103,22 +103,28 @@ def transport_like(n: int = TRANSPORT_N, diag_base: float = 16.0, seed: int = 12
     return from_offsets(n, TRANSPORT_OFFSETS, diag_base, seed, rows, scale_decades)
 
 
-def fem_like(n: int = TRANSPORT_N, seed: int = 4242, keep: float = 0.55) -> CSR:
+def fem_like(n: int = TRANSPORT_N, seed: int = 4242, keep: float = 0.55, rows=None) -> CSR:
     """Irregular rows like an unstructured FEM matrix: a 27-offset 3-D stencil (117 x 117 x ~117
     node numbering) from which every off-diagonal entry is kept with probability `keep`, so row
     lengths vary between ~6 and 27 (mean ~15.3 at keep = 0.55; Transport.mtx: 14.66). Used to
-    exercise the sliced-ELL / CSR hybrid on ragged rows; values follow from_offsets' law."""
+    exercise the sliced-ELL / CSR hybrid on ragged rows; values follow from_offsets' law.
+    rows=(lo, hi): only that row range of the same global matrix (GLOBAL columns)."""
     nx = 117
-    offs = sorted({dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)})
-    A = from_offsets(n, offs, diag_base=32.0, seed=seed)
+    offs = np.array(sorted({dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)}),
+                    dtype=np.int64)
+    A = from_offsets(n, offs.tolist(), diag_base=32.0, seed=seed, rows=rows)
+    lo = 0 if rows is None else rows[0]
     ptr = A.ptr.astype(np.int64)
-    rowid = np.repeat(np.arange(n, dtype=np.int64), np.diff(ptr))
-    is_diag = A.col.astype(np.int64) == rowid
-    keep_mask = is_diag | (_uniform(np.arange(A.nnz, dtype=np.int64), seed + 1) < keep)
-    cnt = np.bincount(rowid[keep_mask], minlength=n)
-    p2 = np.zeros(n + 1, dtype=np.int64)
+    rowid = np.repeat(np.arange(lo, lo + A.rows, dtype=np.int64), np.diff(ptr))
+    col = A.col.astype(np.int64)
+    is_diag = col == rowid
+    # the decision depends on (row, offset) only, so every slab sees the same global matrix
+    eid = rowid * len(offs) + np.searchsorted(offs, col - rowid)
+    keep_mask = is_diag | (_uniform(eid, seed + 1) < keep)
+    cnt = np.bincount(rowid[keep_mask] - lo, minlength=A.rows)
+    p2 = np.zeros(A.rows + 1, dtype=np.int64)
     np.cumsum(cnt, out=p2[1:])
-    return CSR(n, n, p2.astype(np.uint32), A.col[keep_mask], A.val[keep_mask])
+    return CSR(A.rows, n, p2.astype(np.uint32), A.col[keep_mask], A.val[keep_mask])
 
 
 def transport_nnz(n: int = TRANSPORT_N) -> int:
@@ -143,10 +149,20 @@ def split_row_slab(slab: CSR, lo: int):
     return build(local, slab.rows, lo), build(~local, slab.cols, 0)
 
 
-def banded(n: int, half_bw: int, diag_base: float | None = None, seed: int = 777) -> CSR:
+def banded(n: int, half_bw: int, diag_base: float | None = None, seed: int = 777, rows=None, scale_decades: float = 0.0) -> CSR:
+    """dense band of half-bandwidth b (SURVEY.md section 8d synthetic input (ii)); rows=(lo, hi): a row slab"""
     if diag_base is None:
         diag_base = 2.0 * half_bw + 1.0
-    return from_offsets(n, range(-half_bw, half_bw + 1), diag_base, seed)
+    return from_offsets(n, range(-half_bw, half_bw + 1), diag_base, seed, rows, scale_decades)
+
+
+def banded_nnz(n: int, half_bw: int) -> int:
+    return sum(max(n - abs(o), 0) for o in range(-half_bw, half_bw + 1))
+
+
+def banded_rows_for(nnz_target: int, half_bw: int) -> int:
+    """rows of the band matrix with about nnz_target non-zeros"""
+    return max(2 * half_bw + 2, int(round(nnz_target / (2 * half_bw + 1))))
 
 
 LAPLACE_WEIGHTS = (6.0, -1.0, -1.0, -1.0, -1.0, -1.0, -1.0)

@@ -12,6 +12,8 @@ for p in (ROOT, os.path.join(ROOT, "tests")):
 
 
 def _init(rank, world, port):
+    import torch
+    torch.set_num_threads(1)      # 8 ranks x (cores) OpenMP threads spinning would starve the gloo exchanges
     import torch.distributed as dist
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)

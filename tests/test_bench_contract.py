@@ -25,8 +25,14 @@ def test_bench_json_keys_are_the_contract():
     for key in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
                 "vs_baseline", "dtype", "data", "config", "roofline", "cpu_baseline"):
         assert re.search(rf'"{key}"\s*:', src), key
-    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic"):
+    for key in ("bound", "achieved", "peak", "unit", "frac", "traffic", "traffic_detail"):
         assert re.search(rf'"{key}"\s*:', src), key
+    # round-2 additions: the other workloads north_star names and per-variant roofline fractions ride on the same line
+    for key in ("variant_rooflines", "extras", "variants_ms_per_iteration", "cpu_baseline_multicore"):
+        assert re.search(rf'"{key}"\s*:', src), key
+    for wl in ("banded", "fem_like", "laplace7"):
+        assert f'"{wl}"' in src
+    assert "--half-bandwidth" in src and "--no-extras" in src and "--no-traffic" in src
     for key in ("value", "unit", "cores", "kind", "sample"):
         assert re.search(rf'\b{key}=|"{key}"', open(os.path.join(ROOT, "tools", "cpu_baseline.py")).read()), key
 

@@ -26,9 +26,9 @@ def run_bench(n, extra=()):
     return json.loads(lines[0])
 
 
-@pytest.mark.parametrize("n,transport", [(2, "host-p2p"), (4, "host-p2p"), (2, "host")])
-def test_bench_under_torchrun(n, transport):
-    d = run_bench(n, ("--transport", transport))
+@pytest.mark.parametrize("n,transport,extras", [(2, "host-p2p", True), (4, "host-p2p", False), (2, "host", False)])
+def test_bench_under_torchrun(n, transport, extras):
+    d = run_bench(n, ("--transport", transport) + (() if extras else ("--no-extras",)))
     assert d["n_gpus"] == n and d["steps"] == 20 and d["warmup"] == 5
     assert d["unit"] == "ms/iteration" and d["higher_is_better"] is False and d["scaling"] == "strong"
     assert isinstance(d["value"], float) and math.isfinite(d["value"]) and d["value"] > 0
@@ -37,3 +37,30 @@ def test_bench_under_torchrun(n, transport):
     assert ("peer-to-peer" in cfg["transport"]) == (transport == "host-p2p"), cfg["transport"]
     assert math.isfinite(cfg["true_relres_after_timed_region"])
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    if extras:      # north_star: "Transport.mtx and synthetic banded CSR reported at 1, 2, 4 and 8 GPUs"
+        for hb in (8, 64, 512):
+            e = d["extras"][f"banded_b{hb}"]
+            assert e["nnz"] > 20_000_000
+            for m in ("bicgstab", "pipe_bicgstab"):
+                assert math.isfinite(e[m]["ms_per_iteration"]) and 0 < e[m]["frac"] < 1.0
+
+
+def test_bench_single_gpu_line_has_every_leg():
+    """the N = 1 line the driver records: headline unchanged, plus roofline fractions of every variant, the banded /
+    FEM-like / 256^3-Laplacian legs and the HBM traffic measured in this run (rocprofv3 PMC passes)"""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
+    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_WATCHDOG_S="800"))
+    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
+    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
+    d = json.loads(lines[0])
+    assert d["n_gpus"] == 1 and d["config"]["iterations_genuine"] is True and "configs[1]" in d["config"]["workload"]
+    for m in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr", "shifted_lopbicgstab_16shifts", "shifted_pipe_lopbicgstab_16shifts"):
+        r = d["variant_rooflines"][m]
+        assert 0.3 < r["frac"] < 1.0 and r["algorithmic_bytes"] > 8e8, (m, r)
+    for key in ("banded_b8", "banded_b64", "banded_b512", "fem_like", "laplace7_256_ca"):
+        assert key in d["extras"], key
+    assert d["extras"]["laplace7_256_ca"]["rows"] == 256 ** 3 and d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"] > 0
+    rf = d["roofline"]
+    assert rf["traffic"] is not None, "rocprofv3 counter passes did not deliver"
+    assert 0.7 * rf["algorithmic_bytes_per_launch"] < rf["traffic"] < 1.5 * rf["algorithmic_bytes_per_launch"]
+    assert 1.7 < rf["traffic_detail"]["fetch_factor_reproducing_k_vec_FPlainQ"] < 2.3

@@ -98,6 +98,27 @@ def test_loader_symmetric_and_pattern(tmp_path):
     assert np.array_equal(dense, want)
 
 
+def test_symmetric_nz_counts_mirrored_entries_and_skew_is_refused(tmp_path):
+    """INFO_Matrix.nz is the number of entries of the matrix that is solved (8 here: 5 stored, 3 mirrored), not the
+    banner's triangle count, in the serial and in the MPI loader; skew-symmetric / hermitian files are refused
+    instead of being read as general"""
+    import ctypes as C
+    from mpi_bicgstab_amd import hipsolver as H
+    mtx = str(tmp_path / "s.mtx")
+    open(mtx, "w").write("%%MatrixMarket matrix coordinate real symmetric\n4 4 5\n1 1 2.0\n2 1 -1.0\n3 2 -1.0\n4 4 2.0\n4 1 0.5\n")
+    blk = H.load_mtx_blocks(mtx, 0, 1)
+    assert blk.nnz_global == 8 and int(blk.diag.nz) == 8
+    out = subprocess.run([MPIEXEC, "-n", "2", DUMP, mtx, str(tmp_path / "o"), "mpi"], capture_output=True, text=True, timeout=60)
+    assert out.returncode == 0 and "mirrored to 8 entries" in out.stderr
+    for kind in ("skew-symmetric", "hermitian"):
+        bad = str(tmp_path / f"{kind}.mtx")
+        open(bad, "w").write(f"%%MatrixMarket matrix coordinate real {kind}\n2 2 1\n2 1 1.0\n")
+        d, o, info = H.CSRMatrix(), H.CSRMatrix(), H.InfoMatrix()
+        L = H.lib()
+        L.bicg_mtx_load_block.argtypes = [C.c_char_p, C.c_int, C.c_int, C.POINTER(H.CSRMatrix), C.POINTER(H.CSRMatrix), C.POINTER(H.InfoMatrix)]
+        assert L.bicg_mtx_load_block(bad.encode(), 0, 1, C.byref(d), C.byref(o), C.byref(info)) != 0
+
+
 def _write_mtx(path, A, row, col, val):
     with open(path, "w") as f:
         f.write("%%MatrixMarket matrix coordinate real general\n")
