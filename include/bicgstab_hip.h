@@ -195,6 +195,21 @@ void bicg_default_options(bicg_options *o);
 bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info);
 void bicg_destroy(bicg_ctx *ctx);
 
+/* Matrix residency of the drop-in entry points (section 1 and the shifted ones): the context of the last drop-in call
+ * stays resident and is reused when the caller passes the same blocks again -- same arrays, sizes, partition,
+ * communicator AND contents (a 64-bit hash over every value / column / row pointer: the matrix may have been edited in
+ * place, e.g. by the reference's csr_shift_diagonal, src/matrix.c:518-531). The reference's drivers call a solver 10-28 x
+ * on one matrix (src/main_repeat.c:109-132): only the first call pays for plan + upload. All ranks agree on hit / miss.
+ * BICG_DROPIN_CACHE=0 in the environment restores create / destroy per call.
+ *   bicg_dropin_context  the resident context for these blocks (created or reused; collective); owned by the library --
+ *                        do NOT bicg_destroy it. Lets a host form b = A*1 with bicg_spmv and then call bicgstab() with
+ *                        one upload (host/bicg_main.c)
+ *   bicg_dropin_release  drop the resident context now (also happens in bicg_comm_finalize)
+ *   bicg_dropin_stats    hits / misses so far */
+bicg_ctx *bicg_dropin_context(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info);
+void bicg_dropin_release(void);
+void bicg_dropin_stats(unsigned int *hits, unsigned int *misses);
+
 /* Whole solve with host vectors, semantics of section 1 (x_loc/r_loc in-out). */
 int bicg_solve(bicg_ctx *ctx, int method, double *x_loc, double *r_loc, const bicg_options *opt,
                bicg_result *res);
@@ -248,6 +263,8 @@ int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);
  * group on the sliced-ELL path */
 enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FLAG_COL16 = 8, BICG_FLAG_ALL_SELL = 16 };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
+/* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
+unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * 5. Host-only helpers (no GPU needed; unit-tested on CPU).

@@ -244,7 +244,10 @@ static Comm *g_comm = nullptr;
 
 void comm_set(Comm *c)
 {
-    if (g_comm) delete g_comm;
+    if (g_comm) {
+        bicg_dropin_release();       // the resident drop-in context was built on this communicator
+        delete g_comm;
+    }
     g_comm = c;
 }
 

@@ -94,10 +94,10 @@ int main(int argc, char **argv)
     const unsigned nl = diag.rows;
     double *x = (double *)malloc(sizeof(double) * nl), *r = (double *)malloc(sizeof(double) * nl);
     for (unsigned i = 0; i < nl; ++i) x[i] = 1.0;          /* exact solution: all ones */
-    bicg_ctx *ctx = bicg_create(&diag, &offd, &info);
+    /* the context the solver call below will reuse: plan + upload happen once */
+    bicg_ctx *ctx = bicg_dropin_context(&diag, &offd, &info);
     if (!ctx) exit(EXIT_FAILURE);
     bicg_spmv(ctx, x, r);                                  /* b = A * 1 */
-    bicg_destroy(ctx);
     for (unsigned i = 0; i < nl; ++i) x[i] = 0.0;          /* x0 = 0 */
 
     int k;

@@ -58,7 +58,7 @@ EXPORTS = [
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_version",
 ]
 
@@ -92,7 +92,12 @@ def lib():
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
         L.bicg_comm_failed.argtypes = [C.c_void_p]
+        L.bicg_dropin_context.restype = C.c_void_p
+        L.bicg_dropin_context.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix)]
+        L.bicg_dropin_stats.argtypes = [_up, _up]
         L.bicg_ctx_flags.argtypes = [C.c_void_p]
+        L.bicg_device_matrix_bytes.argtypes = [C.c_void_p]
+        L.bicg_device_matrix_bytes.restype = C.c_ulonglong
         L.bicg_ctx_flags.restype = C.c_uint
         L.bicg_shifted_residuals.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, _dp]
         L.bicg_default_options.argtypes = [C.POINTER(Options)]
@@ -302,6 +307,9 @@ class Context:
     def flags(self):
         f = int(lib().bicg_ctx_flags(self.h))
         return {k: bool(f & v) for k, v in self.FLAGS.items()}
+
+    def device_matrix_bytes(self) -> int:
+        return int(lib().bicg_device_matrix_bytes(self.h))
 
     def plan_info(self):
         out = (C.c_uint * 8)()

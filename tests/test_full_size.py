@@ -26,6 +26,10 @@ def test_plan_is_sliced_ell(big):
     info = ctx.plan_info()
     assert info["sell_rows"] == A.rows                   # banded: every group on the sliced-ELL path
     assert info["sell_padding"] <= 0.01 * A.nnz
+    # device footprint: sliced-ELL values + 16-bit columns + row pointers only (the CSR copy and the 32-bit
+    # sliced-ELL columns no kernel reads are not uploaded): below the 12 B per non-zero of the reference's CSR
+    assert ctx.device_matrix_bytes() <= 1.3 * (12 * A.nnz + 4 * (A.rows + 1))
+    assert ctx.device_matrix_bytes() <= 11.5 * A.nnz
 
 
 def test_spmv_bitexact_and_linear(big):
