@@ -239,6 +239,12 @@ int bicg_solve_shifted(bicg_ctx *ctx, int variant, double *x_loc_set, double *r_
  * || (A + sigma_j I) x_j - b || / || b || for every shift (x_loc_set shift-major as above). Collective. */
 int bicg_shifted_residuals(bicg_ctx *ctx, const double *x_loc_set, const double *b_loc, const double *sigma, int sigma_len,
                            double *relres_out);
+/* "Batched SpMV" (BASELINE.json configs[4]): Y_j = (A + sigma_j I) X_j for nvec vectors with every matrix entry read once
+ * per 16 vectors (sliced-ELL SpMM) -- what the loop above does internally. x_loc_set / y_loc_set are shift-major like
+ * x_loc_set of the shifted solvers; sigma may be NULL (Y_j = A X_j). Every column is bit-identical to bicg_spmv of that
+ * vector. Returns 1 without computing when the matrix is not entirely on the sliced-ELL path (ragged rows). ms_device
+ * (optional) receives the device time of the passes (halo exchanges, layout change and SpMM kernel). Collective. */
+int bicg_spmm(bicg_ctx *ctx, const double *x_loc_set, const double *sigma, int nvec, double *y_loc_set, double *ms_device);
 /* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */
 int bicg_trace(bicg_ctx *ctx, double *alpha, double *omega, double *beta, double *dot_r);
 

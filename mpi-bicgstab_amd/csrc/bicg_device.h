@@ -249,6 +249,21 @@ struct SpmvArgs {
     Finish  fin;            // a dot group of earlier kernels to finish in this launch (seq 0: none)
 };
 
+// Sliced-ELL SpMM over kSpmmCols vectors held row-major (bicg_kernels.hip, k_spmm_sell)
+constexpr int kSpmmCols = 16;
+struct SpmmArgs {
+    SellDev sell;
+    const uint32_t *dptr;   // diag row pointers (row lengths)
+    CsrDev offd;            // columns renumbered to rows + halo position
+    uint32_t nrows, ngroups;
+    const double *xt;       // [rows + halo][kSpmmCols]
+    double *yt;             // [rows][kSpmmCols] or null
+    const double *b;        // with b: partial[wg][col] = sum over the workgroup's rows of (b_i - y_ij)^2
+    const double *sigma;    // [kSpmmCols] or null: y_j += sigma_j x_j
+    double *partial;
+    int xcd_map;            // XCD-contiguous assignment of row groups
+};
+
 // element-wise phase kernels: pointers to the rank-local vectors
 struct Vecs {
     double *x, *r, *rh, *p, *s, *y, *z, *w, *v, *t, *ax, *b;   // shifted solver: ax doubles as r_old
@@ -261,6 +276,11 @@ struct Vecs {
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);        // CSR row-block stream
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                       bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
+void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
+unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
+void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st);          // out[col] = sum_wg partial[wg][col]
+void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st);
+void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y, hipStream_t st);
 void launch_apply(Scal *S, int phase, hipStream_t st);
 void launch_finish(const Launch &L);   // stand-alone finisher: L.fin with FIN_BLOCK0
 void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);

@@ -1255,6 +1255,197 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     return true;
 }
 
+// ------------------------------------------------------------------------------------------
+// Sliced-ELL SpMM: Y_j = (A + sigma_j I) X_j for kSpmmCols vectors at once -- the verification loop of
+// the reference's shifted driver (src/test_shifted.c:129-154: one SpMV per shift, A read nsig
+// times) with A read ONCE. X is held row-major, kSpmmCols values per row = one 128-byte line, so a
+// lane fetches everything it needs for one matrix entry with eight 16-byte loads of one line; every
+// column of every row is accumulated in stored order like mult() (reference src/matrix.c:506-515), so
+// each Y_j is bit-identical to the SpMV of that column. With b given, || b - Y_j ||^2 is fused (the
+// partial sums of a workgroup go to partial[wg][col], k_colsum adds them in a fixed order) and Y is
+// never written. Bound: the vector L1 -- 128 B of X per lane and entry = 3 GB per pass on Transport.
+// ------------------------------------------------------------------------------------------
+template <bool C16, bool OFFD>
+__global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
+{
+    constexpr int NB = kSpmmCols;
+    __shared__ double sm[(kBlock / 64) * NB];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // XCD-contiguous mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
+    // giving XCD x the x-th eighth of the row groups makes one L2 fetch (almost) every line of X once
+    // instead of all eight fetching all of it (16 vectors: 8 x 205 MB on Transport)
+    unsigned g = blockIdx.x;
+    if (a.xcd_map) {
+        const unsigned per = (a.ngroups + 7u) / 8u;
+        g = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
+    double acc[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) acc[j] = 0.0;
+    if (g < a.ngroups) {
+        const uint32_t row = g * kGroupRows + tid;
+        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
+        const bool live = row < a.nrows;
+        uint32_t base = 0u, len = 0u, base16 = 0u;
+        if (slice * kSliceRows < a.nrows) {
+            base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
+            if (C16) base16 = a.sell.slice_base16[slice];
+        }
+        const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
+        const uint32_t rb = live ? row : 0u;
+        double sum[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) sum[j] = 0.0;
+        auto add_entry = [&](double v, uint32_t c, bool on) {
+            const f64x2 *xr = reinterpret_cast<const f64x2 *>(a.xt + (size_t)c * NB);
+            f64x2 x[NB / 2];
+#pragma unroll
+            for (int q = 0; q < NB / 2; ++q) x[q] = xr[q];
+            if (on) {
+#pragma unroll
+                for (int q = 0; q < NB / 2; ++q) { sum[2 * q] += v * x[q].x; sum[2 * q + 1] += v * x[q].y; }
+            }
+        };
+        if (C16) {
+            for (uint32_t k0 = 0; k0 < len; k0 += 4) {
+                const i16x4 dq = *(reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)(k0 / 4) * kSliceRows + lane));
+                const int dl[4] = {dq.x, dq.y, dq.z, dq.w};
+                double v[4];
+#pragma unroll
+                for (int e = 0; e < 4; ++e) v[e] = k0 + e < len ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) add_entry(v[e], rb + dl[e], k0 + e < mylen);
+            }
+        } else {
+            for (uint32_t k = 0; k < len; ++k) {
+                const uint32_t j = base + k * kSliceRows + lane;
+                add_entry(a.sell.val[j], a.sell.col[j], k < mylen);
+            }
+        }
+        double y[NB];
+#pragma unroll
+        for (int j = 0; j < NB; ++j) y[j] = 0.0 + sum[j];                     // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+        if (OFFD && live) {
+            double so[NB];
+#pragma unroll
+            for (int j = 0; j < NB; ++j) so[j] = 0.0;
+            for (uint32_t k = a.offd.ptr[row]; k < a.offd.ptr[row + 1]; ++k) {
+                const double v = a.offd.val[k];
+                const f64x2 *xr = reinterpret_cast<const f64x2 *>(a.xt + (size_t)a.offd.col[k] * NB);
+#pragma unroll
+                for (int q = 0; q < NB / 2; ++q) { const f64x2 x = xr[q]; so[2 * q] += v * x.x; so[2 * q + 1] += v * x.y; }
+            }
+#pragma unroll
+            for (int j = 0; j < NB; ++j) y[j] += so[j];                        // second mult() call, src/matrix.c:440
+        }
+        if (live) {
+            if (a.sigma) {
+                const f64x2 *xr = reinterpret_cast<const f64x2 *>(a.xt + (size_t)row * NB);
+#pragma unroll
+                for (int q = 0; q < NB / 2; ++q) {
+                    const f64x2 x = xr[q];
+                    y[2 * q] += a.sigma[2 * q] * x.x; y[2 * q + 1] += a.sigma[2 * q + 1] * x.y;   // += sigma_j x_j (src/test_shifted.c:133)
+                }
+            }
+            if (a.yt) {
+                f64x2 *yr = reinterpret_cast<f64x2 *>(a.yt + (size_t)row * NB);
+#pragma unroll
+                for (int q = 0; q < NB / 2; ++q) { f64x2 t; t.x = y[2 * q]; t.y = y[2 * q + 1]; yr[q] = t; }
+            }
+            if (a.b) {
+                const double bi = a.b[row];
+#pragma unroll
+                for (int j = 0; j < NB; ++j) { const double d = (bi + (-1.0) * y[j]) - 0.0; acc[j] += d * d; }
+            }
+        }
+    }
+    if (a.b) {
+#pragma unroll
+        for (int j = 0; j < NB; ++j) acc[j] = wave_sum(acc[j]);
+        if (lane == 0) {
+#pragma unroll
+            for (int j = 0; j < NB; ++j) sm[wave * NB + j] = acc[j];
+        }
+        __syncthreads();
+        if (tid < NB) {
+            double t = sm[tid];
+            for (int w = 1; w < kBlock / 64; ++w) t += sm[w * NB + tid];
+            a.partial[(size_t)blockIdx.x * NB + tid] = t;
+        }
+    }
+}
+
+// out[col] = sum over workgroups of partial[wg][col], fixed order
+__global__ void __launch_bounds__(kBlock) k_colsum(const double *partial, unsigned nwg, double *out)
+{
+    constexpr int NB = kSpmmCols;
+    __shared__ double sm[kBlock];
+    const unsigned col = threadIdx.x % NB, part = threadIdx.x / NB, nparts = kBlock / NB;
+    double t = 0.0;
+    for (unsigned w = part; w < nwg; w += nparts) t += partial[(size_t)w * NB + col];
+    sm[threadIdx.x] = t;
+    __syncthreads();
+    if (threadIdx.x < NB) {
+        double tot = 0.0;
+        for (unsigned p2 = 0; p2 < nparts; ++p2) tot += sm[p2 * NB + threadIdx.x];
+        out[threadIdx.x] = tot;
+    }
+}
+
+// shift-major vectors x[j * stride + i] -> row-major xt[i * kSpmmCols + j] (columns >= nvec are zero)
+__global__ void __launch_bounds__(kBlock) k_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt)
+{
+    constexpr int NB = kSpmmCols;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    double v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = j < nvec ? x[(size_t)j * stride + i] : 0.0;
+    f64x2 *dst = reinterpret_cast<f64x2 *>(xt + (size_t)i * NB);
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) { f64x2 t; t.x = v[2 * q]; t.y = v[2 * q + 1]; dst[q] = t; }
+}
+__global__ void __launch_bounds__(kBlock) k_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y)
+{
+    constexpr int NB = kSpmmCols;
+    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
+    if (i >= n) return;
+    const f64x2 *src = reinterpret_cast<const f64x2 *>(yt + (size_t)i * NB);
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) {
+        const f64x2 t = src[q];
+        if (2 * q < nvec) y[(size_t)(2 * q) * stride + i] = t.x;
+        if (2 * q + 1 < nvec) y[(size_t)(2 * q + 1) * stride + i] = t.y;
+    }
+}
+
+void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
+{
+    if (a.ngroups == 0) return;
+    const unsigned grid = a.xcd_map ? ((a.ngroups + 7u) / 8u) * 8u : a.ngroups;
+    const bool c16 = a.sell.col16 != nullptr;
+    if (with_offd) {
+        if (c16) hipLaunchKernelGGL((k_spmm_sell<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((k_spmm_sell<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+    } else {
+        if (c16) hipLaunchKernelGGL((k_spmm_sell<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        else hipLaunchKernelGGL((k_spmm_sell<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+    }
+}
+unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
+void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(kBlock), 0, st, partial, nwg, out);
+}
+void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_rows_from_vectors, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, stride, nvec, n, xt);
+}
+void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y, hipStream_t st)
+{
+    if (n) hipLaunchKernelGGL(k_vectors_from_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, yt, stride, nvec, n, y);
+}
+
 void launch_apply(Scal *S, int phase, hipStream_t st)
 {
     hipLaunchKernelGGL(k_apply, dim3(1), dim3(phase >= PH_SH_INIT ? kBlock : 1), 0, st, S, phase);

@@ -148,6 +148,11 @@ struct bicg_ctx {
     double cur_shift = 0.0;
     bool cur_has_shift = false;
 
+    // SpMM (bicg_spmm, bicg_shifted_residuals): kSpmmCols shift-major vectors with halo tails, their row-major
+    // image [rows + halo][kSpmmCols], the row-major result and the per-workgroup column sums
+    double *mm_in = nullptr, *mm_xt = nullptr, *mm_yt = nullptr, *mm_part = nullptr, *mm_out = nullptr, *mm_sigma = nullptr;
+    bool mm_xcd = true;          // XCD-contiguous row groups in the SpMM (BICG_SPMM_XCD=0: round robin like the SpMV)
+
     // state of the solve in progress (run_begin / run_iterate / run_end)
     bicg_options opt{};
     int method = 0, it = 0, printed = 0, adaptive_rr = 0;
@@ -505,6 +510,65 @@ void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double
         red = grp_produce(c, 0, ndot, phase, 0);
     }
     spmv(c, xin, yout, ndot, u, red, fin);
+}
+
+// The halo exchange of spmv() on its own: afterwards xin[rows .. rows + halo) holds the other ranks' values.
+void halo_only(bicg_ctx *c, double *xin)
+{
+    if (c->single() || (c->halo == 0 && c->nsend == 0)) return;
+    if (c->p2p) {
+        if (c->halo_unsynced >= kHaloRing - 2) {
+            launch_p2p_barrier(c->p2p->red_desc(c->p2p->bar_seq++), c->p2p->timeout_ticks, c->S, c->sc);
+            c->halo_unsynced = 0;
+        }
+        const unsigned seq = ++c->halo_seq;
+        c->halo_unsynced++;
+        launch_halo_push(xin, c->send_idx, c->nsend, c->push_dst0, c->push_stride, seq, c->S, c->sc);
+        launch_halo_unpack(c->halo_ring, c->halo, seq, xin + c->n_loc, c->S, c->p2p->timeout_ticks, c->sc);
+        return;
+    }
+    launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
+    c->comm->exchange(c->sendbuf, c->scnt.data(), c->sdsp.data(), xin + c->n_loc, c->rcnt.data(), c->rdsp.data(), c->sc);
+}
+
+// Y_j = (A + sigma_j I) X_j for nvec <= kSpmmCols vectors that sit shift-major in c->mm_in: one pass over A.
+// with_b: c->v.b holds b, c->mm_out receives || b - Y_j ||^2 (this rank's rows); otherwise c->mm_yt receives Y.
+void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
+{
+    const size_t st = c->stride;
+    for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
+    launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
+    SpmmArgs a{};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16};
+    a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
+    a.nrows = c->n_loc; a.ngroups = c->ng_int + c->ng_bnd;
+    a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
+    a.xcd_map = c->mm_xcd ? 1 : 0;
+    if (sigma_host) {
+        double sg[kSpmmCols] = {0};
+        for (int j = 0; j < nvec; ++j) sg[j] = sigma_host[j];
+        BICG_HIP(hipMemcpyAsync(c->mm_sigma, sg, sizeof sg, hipMemcpyHostToDevice, c->sc));
+        BICG_HIP(hipStreamSynchronize(c->sc));     // sg lives on this stack frame
+        a.sigma = c->mm_sigma;
+    }
+    launch_spmm_sell(a, !c->single(), c->sc);
+    if (with_b) launch_colsum(c->mm_part, spmm_grid(a.ngroups, a.xcd_map != 0), c->mm_out, c->sc);
+}
+
+bool spmm_possible(const bicg_ctx *c) { return c->glist_all && c->nblk == 0 && c->sell_entries > 0; }
+
+void spmm_buffers(bicg_ctx *c)
+{
+    if (c->mm_in) return;
+    const size_t st = c->stride, ngroups = c->ng_int + c->ng_bnd;
+    c->mm_in = dev_alloc<double>((size_t)kSpmmCols * st);
+    c->mm_xt = dev_alloc<double>((size_t)kSpmmCols * st);
+    c->mm_yt = dev_alloc<double>((size_t)kSpmmCols * st);
+    c->mm_part = dev_alloc<double>((ngroups + 8) * kSpmmCols);
+    c->mm_out = dev_alloc<double>(kSpmmCols);
+    c->mm_sigma = dev_alloc<double>(kSpmmCols);
+    BICG_HIP(hipMemset(c->mm_in, 0, sizeof(double) * kSpmmCols * st));
+    c->mm_xcd = !(getenv("BICG_SPMM_XCD") && atoi(getenv("BICG_SPMM_XCD")) == 0);
 }
 
 // a deferred group that no SpMV picked up (defensive)
@@ -1587,7 +1651,7 @@ void bicg_destroy(bicg_ctx *c)
     (void)hipDeviceSynchronize();
     void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
-                    c->wpart[0], c->wpart[1], c->shard_ll, c->alarm};
+                    c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     if (c->p2p) {
         c->p2p->unmap(c->ring_mapped);
@@ -1703,6 +1767,31 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
     group_now(c, 1, PH_NONE);
     fetch_scal(c);
     const double bb = c->hS->red[0];
+    if (spmm_possible(c) && !(getenv("BICG_NO_SPMM") && atoi(getenv("BICG_NO_SPMM")))) {
+        // every matrix entry is read once for kSpmmCols shifts (the only place where
+        // the reference multiplies A with many vectors is this verification loop, one SpMV per shift)
+        spmm_buffers(c);
+        std::vector<double> sq(kSpmmCols);
+        for (int j0 = 0; j0 < nsig; j0 += kSpmmCols) {
+            const int nv = std::min(kSpmmCols, nsig - j0);
+            for (int j = 0; j < nv; ++j)
+                BICG_HIP(hipMemcpyAsync(c->mm_in + (size_t)j * c->stride, x_loc_set + (size_t)(j0 + j) * n, sizeof(double) * n,
+                                        hipMemcpyHostToDevice, c->sc));
+            spmm_pass(c, nv, sigma + j0, true);
+            BICG_HIP(hipMemcpyAsync(sq.data(), c->mm_out, sizeof(double) * kSpmmCols, hipMemcpyDeviceToHost, c->sc));
+            fetch_scal(c);                                   // synchronises; reports a lost peer
+            if (!c->single()) {                              // sum over ranks (host-side: kSpmmCols doubles)
+                std::vector<int> cnt(c->nranks, (int)(sizeof(double) * kSpmmCols)), dsp(c->nranks);
+                std::vector<double> all((size_t)c->nranks * kSpmmCols), mine((size_t)c->nranks * kSpmmCols);
+                for (int p = 0; p < c->nranks; ++p) { dsp[p] = p * (int)(sizeof(double) * kSpmmCols); std::copy(sq.begin(), sq.end(), mine.begin() + (size_t)p * kSpmmCols); }
+                c->comm->alltoallv_host(mine.data(), cnt.data(), dsp.data(), all.data(), cnt.data(), dsp.data());
+                std::copy(sq.begin(), sq.end(), all.begin() + (size_t)c->rank * kSpmmCols);
+                for (int j = 0; j < kSpmmCols; ++j) { double t = 0.0; for (int p = 0; p < c->nranks; ++p) t += all[(size_t)p * kSpmmCols + j]; sq[j] = t; }
+            }
+            for (int j = 0; j < nv; ++j) relres_out[j0 + j] = bb > 0.0 ? sqrt(sq[j] / bb) : sqrt(sq[j]);
+        }
+        return 0;
+    }
     Vecs w = c->v;
     w.r = c->v.t;                               // zero vector: FDrift then yields || b - A x ||^2
     for (int j = 0; j < nsig; ++j) {
@@ -1715,6 +1804,41 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
         fetch_scal(c);
         relres_out[j] = bb > 0.0 ? sqrt(c->hS->red[0] / bb) : sqrt(c->hS->red[0]);
     }
+    return 0;
+}
+
+// Y_j = (A + sigma_j I) X_j, j < nvec, with A read once per kSpmmCols vectors ("batched SpMV", BASELINE.json configs[4]);
+// x_loc_set / y_loc_set shift-major like the shifted solvers' x_loc_set; sigma may be NULL. Returns 1 (nothing done)
+// when the matrix is not entirely on the sliced-ELL path. ms_out (optional): device time of the passes.
+int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nvec, double *y_loc_set, double *ms_out)
+{
+    BICG_HIP(hipSetDevice(c->comm->device));
+    if (!spmm_possible(c)) return 1;
+    reset_scal(c);
+    spmm_buffers(c);
+    const size_t n = c->n_loc;
+    hipEvent_t e0, e1;
+    BICG_HIP(hipEventCreate(&e0)); BICG_HIP(hipEventCreate(&e1));
+    float total = 0.f;
+    for (int j0 = 0; j0 < nvec; j0 += kSpmmCols) {
+        const int nv = std::min(kSpmmCols, nvec - j0);
+        for (int j = 0; j < nv; ++j)
+            BICG_HIP(hipMemcpyAsync(c->mm_in + (size_t)j * c->stride, x_loc_set + (size_t)(j0 + j) * n, sizeof(double) * n,
+                                    hipMemcpyHostToDevice, c->sc));
+        BICG_HIP(hipEventRecord(e0, c->sc));
+        spmm_pass(c, nv, sigma ? sigma + j0 : nullptr, false);
+        BICG_HIP(hipEventRecord(e1, c->sc));
+        launch_vectors_from_rows(c->mm_yt, c->stride, nv, c->n_loc, c->mm_in, c->sc);     // result back to shift-major (reuses mm_in)
+        for (int j = 0; j < nv; ++j)
+            BICG_HIP(hipMemcpyAsync(y_loc_set + (size_t)(j0 + j) * n, c->mm_in + (size_t)j * c->stride, sizeof(double) * n,
+                                    hipMemcpyDeviceToHost, c->sc));
+        fetch_scal(c);
+        float ms = 0.f;
+        BICG_HIP(hipEventElapsedTime(&ms, e0, e1));
+        total += ms;
+    }
+    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
+    if (ms_out) *ms_out = (double)total;
     return 0;
 }
 

@@ -58,7 +58,7 @@ EXPORTS = [
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_version",
 ]
 
@@ -95,6 +95,7 @@ def lib():
         L.bicg_dropin_context.restype = C.c_void_p
         L.bicg_dropin_context.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix)]
         L.bicg_dropin_stats.argtypes = [_up, _up]
+        L.bicg_spmm.argtypes = [C.c_void_p, _dp, _dp, C.c_int, _dp, _dp]
         L.bicg_ctx_flags.argtypes = [C.c_void_p]
         L.bicg_device_matrix_bytes.argtypes = [C.c_void_p]
         L.bicg_device_matrix_bytes.restype = C.c_ulonglong
@@ -244,6 +245,17 @@ class Context:
         out = np.zeros(len(sigma))
         lib().bicg_shifted_residuals(self.h, _d(x), _d(b), _d(sigma), len(sigma), _d(out))
         return out
+
+    def spmm(self, x_set, sigma=None):
+        """Y_j = (A + sigma_j I) X_j for all rows of x_set [nvec][n], A read once per 16 vectors -> (Y, device ms)"""
+        x = np.ascontiguousarray(x_set, dtype=np.float64).reshape(-1, self.n)
+        y = np.zeros_like(x)
+        sg = None if sigma is None else np.ascontiguousarray(sigma, dtype=np.float64)
+        ms = C.c_double(0.0)
+        rc = lib().bicg_spmm(self.h, _d(x), None if sg is None else _d(sg), x.shape[0], _d(y), C.byref(ms))
+        if rc != 0:
+            raise RuntimeError("bicg_spmm: the matrix is not entirely on the sliced-ELL path")
+        return y, ms.value
 
     def load(self, x0, b):
         x0 = np.ascontiguousarray(x0, dtype=np.float64)

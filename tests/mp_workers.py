@@ -27,6 +27,8 @@ def test_matrix(kind):
         return synth.from_offsets(4001, (0, 1, -1, 7, -7, 300, -300, 1999, -1999), diag_base=12.0, seed=3)
     if kind == "stencil":
         return synth.stencil7(14)
+    if kind == "laplace":      # BASELINE.json configs[3] family, z-slabs over the ranks
+        return synth.stencil7(40, synth.LAPLACE_WEIGHTS)
     if kind == "ragged":
         return synth.random_rows(900, 9, seed=21, empty_frac=0.05, long_rows={40: 700})
     raise ValueError(kind)
@@ -137,6 +139,13 @@ def gpu_worker(rank, world, port, kind, outdir):
         y_orc = O.spmv(A.rows, row, col, val, x, nranks=world)[lo:lo + nl]
         lens = np.diff(A.ptr.astype(np.int64))[lo:lo + nl]
         assert np.array_equal(y[lens <= 2048], y_orc[lens <= 2048]), "distributed SpMV is not bit-exact"
+        if ctx.plan_info()["sell_rows"] == nl and ctx.plan_info()["row_blocks"] == (nl + 255) // 256:
+            # distributed SpMM (halo of every vector, offd part per column): columns = the distributed SpMV of each vector
+            X = np.random.default_rng(17).standard_normal((5, A.rows))
+            Y, _ = ctx.spmm(X[:, lo:lo + nl], 0.25 * np.arange(5))
+            for j in range(5):
+                yj = O.spmv(A.rows, row, col, val, X[j], nranks=world)[lo:lo + nl] + 0.25 * j * X[j, lo:lo + nl]
+                assert np.array_equal(Y[j], yj), f"SpMM column {j}"
         d = ctx.dot(x[lo:lo + nl], y_orc)
         d_ref = float(np.dot(x, O.spmv(A.rows, row, col, val, x, nranks=world)))
         assert abs(d - d_ref) <= 1e-11 * abs(d_ref) + 1e-9

@@ -46,6 +46,23 @@ def test_spmv_bitexact_and_linear(big):
     assert abs(d - float(np.dot(x, y))) <= 1e-11 * float(np.abs(x * y).sum())
 
 
+def test_spmm_16_vectors_reads_the_matrix_once(big):
+    """BASELINE.json configs[4] "batched SpMV": 16 vectors through one pass over A. Bit-identical columns, and far
+    cheaper than 16 SpMVs (the reference's verification loop, src/test_shifted.c:129-154)."""
+    A, (row, col, val), ctx = big
+    rng = np.random.default_rng(4)
+    X = rng.standard_normal((16, A.rows))
+    sigma = (np.arange(16) + 1.0) * 0.01 / 16
+    Y, ms = ctx.spmm(X, sigma)
+    for j in (0, 7, 15):
+        assert np.array_equal(Y[j], O.spmv(A.rows, row, col, val, X[j]) + sigma[j] * X[j])
+    ctx.spmm(X, sigma)
+    ms = min(ctx.spmm(X, sigma)[1] for _ in range(3))          # device time: layout change + SpMM kernel
+    one = ctx.spmv_bench(100)
+    print(f"SpMM 16 vectors {1e3 * ms:.1f} us, one SpMV {1e3 * one:.1f} us")
+    assert ms <= 0.45 * 16 * one
+
+
 @pytest.mark.parametrize("method", ["bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"])
 def test_first_iterations_and_residual_identity(big, method):
     A, (row, col, val), ctx = big
@@ -89,4 +106,32 @@ def test_hybrid_plan_with_ragged_rows():
     short = np.diff(p2) <= 2044
     assert np.array_equal(y[short], y_orc[short])
     assert np.abs(y - y_orc).max() <= 1e-12 * np.abs(y_orc).max()
+    ctx.close()
+
+
+def test_laplace7_slab_generator_and_ca_bicgstab_against_oracle():
+    """BASELINE.json configs[3] family: the in-memory 7-point Laplacian (synth.stencil7 with LAPLACE_WEIGHTS, built
+    slab by slab as bench.py does for one GPU's z-planes) at 96^3 = 885 k rows: the slabs tile the global matrix, the
+    SpMV is bit-exact against the oracle and CA-BiCGStab follows the oracle's trajectory (src/solver.c:160-278)."""
+    H.lib().bicg_comm_init_single(0)
+    m = 96
+    n = m ** 3
+    cuts = [0, 17 * m * m, 48 * m * m, n]                         # three z-slabs of unequal thickness
+    slabs = [synth.stencil7(m, synth.LAPLACE_WEIGHTS, rows=(cuts[i], cuts[i + 1])) for i in range(3)]
+    A = synth.stencil7(m, synth.LAPLACE_WEIGHTS)
+    assert A.nnz == synth.stencil7_nnz(m) == sum(s.nnz for s in slabs)
+    assert np.array_equal(np.concatenate([s.col for s in slabs]), A.col) and np.array_equal(np.concatenate([s.val for s in slabs]), A.val)
+    row, col, val = A.to_coo()
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert ctx.plan_info()["sell_rows"] == n
+    x = np.random.default_rng(6).standard_normal(n)
+    assert np.array_equal(ctx.spmv(x), O.spmv(n, row, col, val, x))
+    b = O.spmv(n, row, col, val, np.ones(n))
+    for method in ("ca_bicgstab", "bicgstab"):
+        orc = O.solve(method, n, row, col, val, b, tol=0.0, max_iter=15)
+        got = ctx.solve(method, b, tol=0.0, max_iter=15, check_every=15)
+        tr = ctx.trace(15)
+        for key in ("alpha", "omega", "beta", "dotr"):
+            np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=f"{method} {key}")
+        assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
     ctx.close()

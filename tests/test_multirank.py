@@ -45,7 +45,7 @@ def test_multirank_solver_on_one_gpu(kind, world):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("kind,world", [("offsets+p2p", 2), ("stencil+p2p", 2), ("ragged+p2p", 3), ("ragged+nnz+p2p", 2)])
+@pytest.mark.parametrize("kind,world", [("offsets+p2p", 2), ("stencil+p2p", 2), ("ragged+p2p", 3), ("ragged+nnz+p2p", 2), ("laplace+p2p", 4)])
 def test_multirank_solver_peer_to_peer(kind, world):
     """Same checks with the peer-to-peer data path: the ranks map each other's mailboxes and halo
     rings through HIP IPC (here inside one GPU) and the kernels exchange LL words directly."""

@@ -108,3 +108,36 @@ def test_hip_shifted_single_shift_equals_plain():
     assert abs(sh["k"] - pl["k"]) <= 1
     assert np.abs(sh["x"][0] - 1.0).max() <= 1e-9
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_spmm_columns_are_the_spmv_of_each_vector():
+    """bicg_spmm / the SpMM inside bicg_shifted_residuals (A read once for 16 shifts; the reference's verification loop
+    src/test_shifted.c:129-154 does one SpMV per shift): every column bit-identical to the single-vector SpMV with the
+    shift added the reference's way, residual norms equal to the per-shift loop's."""
+    import os
+    H.lib().bicg_comm_init_single(0)
+    A = synth.from_offsets(30011, (0, 1, -1, 37, -37, 2999, -2999), diag_base=9.0, seed=5)
+    ctx = H.Context(H.single_rank_blocks(A))
+    rng = np.random.default_rng(8)
+    for nvec in (1, 5, 16, 21):                       # less than, exactly and more than one pass of 16
+        X = rng.standard_normal((nvec, A.rows))
+        sigma = 0.01 * (np.arange(nvec) + 1.0)
+        Y, ms = ctx.spmm(X, sigma)
+        for j in range(nvec):
+            yj = ctx.spmv(X[j])
+            yj = yj + sigma[j] * X[j]                  # my_daxpy(sigma_j, x_j, y_j): one rounding per element, like the kernel
+            assert np.array_equal(Y[j], yj), (nvec, j)
+        Y0, _ = ctx.spmm(X)                            # no shift: plain A X
+        assert np.array_equal(Y0[0], ctx.spmv(X[0]))
+        b = rng.standard_normal(A.rows)
+        r1 = ctx.shifted_residuals(X, b, sigma)
+        os.environ["BICG_NO_SPMM"] = "1"
+        try:
+            r2 = ctx.shifted_residuals(X, b, sigma)    # one SpMV + one fused norm kernel per shift
+        finally:
+            del os.environ["BICG_NO_SPMM"]
+        np.testing.assert_allclose(r1, r2, rtol=1e-13)
+        want = [np.linalg.norm(b - (ctx.spmv(X[j]) + sigma[j] * X[j])) / np.linalg.norm(b) for j in range(nvec)]
+        np.testing.assert_allclose(r1, want, rtol=1e-12)
+    ctx.close()
