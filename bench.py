@@ -331,6 +331,13 @@ def main():
         def close(self):
             self.ctx.close()
 
+        def best(self, method, steps=None, warm=None, tries=2):
+            """the variant / extra legs: the faster of two timed regions. (The runtime occasionally stalls a queue for
+            10-80 ms -- seen in one leg per few runs, never twice in a row, not reproducible outside this script; the
+            headline `value` is a single region of exactly K iterations.)"""
+            runs = [self.timed(method, steps=steps, warm=warm) for _ in range(tries)]
+            return min(runs, key=lambda r: r[0])
+
         def timed(self, method, kernel_events=False, steps=None, warm=None):
             k, w = steps or K, W if warm is None else warm
             ctx = self.ctx
@@ -409,7 +416,7 @@ def main():
             if m == a.method:
                 variants[m] = ms_step
             else:
-                dtv, _ = leg.timed(m)
+                dtv, _ = leg.best(m)
                 variants[m] = 1e3 * dtv / K
             ib = iteration_bytes(m, nnz_global, n)
             variant_roof[m] = dict(ms_per_iteration=variants[m], algorithmic_bytes=ib, gbps=ib / (variants[m] * 1e-3) / 1e9,
@@ -448,7 +455,7 @@ def main():
             lg = Leg(wl2)
             out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan)
             for m in methods:
-                dtv, rv = lg.timed(m, steps=steps, warm=min(W, 10))
+                dtv, rv = lg.best(m, steps=steps, warm=min(W, 10))
                 ms = 1e3 * dtv / steps
                 ib = iteration_bytes(m, wl2["nnz"], wl2["rows"])
                 out[m] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9,

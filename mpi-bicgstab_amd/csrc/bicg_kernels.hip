@@ -1258,19 +1258,24 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 // ------------------------------------------------------------------------------------------
 // Sliced-ELL SpMM: Y_j = (A + sigma_j I) X_j for kSpmmCols vectors at once -- the verification loop of
 // the reference's shifted driver (src/test_shifted.c:129-154: one SpMV per shift, A read nsig
-// times) with A read ONCE. X is held row-major, kSpmmCols values per row = one 128-byte line, so a
-// lane fetches everything it needs for one matrix entry with eight 16-byte loads of one line; every
-// column of every row is accumulated in stored order like mult() (reference src/matrix.c:506-515), so
-// each Y_j is bit-identical to the SpMV of that column. With b given, || b - Y_j ||^2 is fused (the
-// partial sums of a workgroup go to partial[wg][col], k_colsum adds them in a fixed order) and Y is
-// never written. Bound: the vector L1 -- 128 B of X per lane and entry = 3 GB per pass on Transport.
+// times) with A read ONCE. X is held row-major, kSpmmCols values per row = one 128-byte line.
+// A wavefront works on 8 rows at a time, 8 lanes per row, each lane owning TWO columns: the load of
+// the X values of one matrix entry is then one instruction over 8 fully used lines (a first version
+// with lane = row touched 64 lines per instruction, 16 bytes of each: 0.56 ms on Transport, bound by
+// the vector L1's tag rate). The 8 lanes of a row read the same (val, col) word -- one broadcast
+// access. Every column of every row is accumulated in stored order like mult() (reference
+// src/matrix.c:506-515), so each Y_j is bit-identical to the SpMV of that column. With b given,
+// || b - Y_j ||^2 is fused (workgroup sums go to partial[wg][col], k_colsum adds them in a fixed
+// order) and Y is never written.
 // ------------------------------------------------------------------------------------------
 template <bool C16, bool OFFD>
 __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
 {
     constexpr int NB = kSpmmCols;
+    static_assert(NB == 16, "8 lanes per row x 2 columns per lane");
     __shared__ double sm[(kBlock / 64) * NB];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned sub = lane >> 3, cp = lane & 7u;          // row within the 8-row batch, column pair
     // XCD-contiguous mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
     // giving XCD x the x-th eighth of the row groups makes one L2 fetch (almost) every line of X once
     // instead of all eight fetching all of it (16 vectors: 8 x 205 MB on Transport)
@@ -1279,93 +1284,73 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
         const unsigned per = (a.ngroups + 7u) / 8u;
         g = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
-    double acc[NB];
-#pragma unroll
-    for (int j = 0; j < NB; ++j) acc[j] = 0.0;
+    double acc0 = 0.0, acc1 = 0.0;
     if (g < a.ngroups) {
-        const uint32_t row = g * kGroupRows + tid;
-        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
-        const bool live = row < a.nrows;
+        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;      // this wavefront's 64 rows
         uint32_t base = 0u, len = 0u, base16 = 0u;
         if (slice * kSliceRows < a.nrows) {
             base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
             if (C16) base16 = a.sell.slice_base16[slice];
         }
-        const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
-        const uint32_t rb = live ? row : 0u;
-        double sum[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) sum[j] = 0.0;
-        auto add_entry = [&](double v, uint32_t c, bool on) {
-            const f64x2 *xr = reinterpret_cast<const f64x2 *>(a.xt + (size_t)c * NB);
-            f64x2 x[NB / 2];
-#pragma unroll
-            for (int q = 0; q < NB / 2; ++q) x[q] = xr[q];
-            if (on) {
-#pragma unroll
-                for (int q = 0; q < NB / 2; ++q) { sum[2 * q] += v * x[q].x; sum[2 * q + 1] += v * x[q].y; }
-            }
-        };
-        if (C16) {
-            for (uint32_t k0 = 0; k0 < len; k0 += 4) {
-                const i16x4 dq = *(reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)(k0 / 4) * kSliceRows + lane));
-                const int dl[4] = {dq.x, dq.y, dq.z, dq.w};
-                double v[4];
-#pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = k0 + e < len ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) add_entry(v[e], rb + dl[e], k0 + e < mylen);
-            }
-        } else {
-            for (uint32_t k = 0; k < len; ++k) {
-                const uint32_t j = base + k * kSliceRows + lane;
-                add_entry(a.sell.val[j], a.sell.col[j], k < mylen);
-            }
-        }
-        double y[NB];
-#pragma unroll
-        for (int j = 0; j < NB; ++j) y[j] = 0.0 + sum[j];                     // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
-        if (OFFD && live) {
-            double so[NB];
-#pragma unroll
-            for (int j = 0; j < NB; ++j) so[j] = 0.0;
-            for (uint32_t k = a.offd.ptr[row]; k < a.offd.ptr[row + 1]; ++k) {
-                const double v = a.offd.val[k];
-                const f64x2 *xr = reinterpret_cast<const f64x2 *>(a.xt + (size_t)a.offd.col[k] * NB);
-#pragma unroll
-                for (int q = 0; q < NB / 2; ++q) { const f64x2 x = xr[q]; so[2 * q] += v * x.x; so[2 * q + 1] += v * x.y; }
-            }
-#pragma unroll
-            for (int j = 0; j < NB; ++j) y[j] += so[j];                        // second mult() call, src/matrix.c:440
-        }
-        if (live) {
-            if (a.sigma) {
-                const f64x2 *xr = reinterpret_cast<const f64x2 *>(a.xt + (size_t)row * NB);
-#pragma unroll
-                for (int q = 0; q < NB / 2; ++q) {
-                    const f64x2 x = xr[q];
-                    y[2 * q] += a.sigma[2 * q] * x.x; y[2 * q + 1] += a.sigma[2 * q + 1] * x.y;   // += sigma_j x_j (src/test_shifted.c:133)
+        const double sg0 = a.sigma ? a.sigma[2 * cp] : 0.0, sg1 = a.sigma ? a.sigma[2 * cp + 1] : 0.0;
+        for (unsigned batch = 0; batch < kSliceRows / 8; ++batch) {
+            const unsigned rl = batch * 8 + sub;                          // row within the slice
+            const uint32_t row = slice * kSliceRows + rl;
+            const bool live = row < a.nrows;
+            const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
+            const uint32_t rb = live ? row : 0u;
+            double s0 = 0.0, s1 = 0.0;
+            constexpr int U = 4;                                          // entries in flight (one packed column quad)
+            for (uint32_t k0 = 0; k0 < len; k0 += U) {
+                uint32_t c[U];
+                double v[U];
+                if (C16) {
+                    const i16x4 dq = *(reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)(k0 / 4) * kSliceRows + rl));
+                    c[0] = rb + (int)dq.x; c[1] = rb + (int)dq.y; c[2] = rb + (int)dq.z; c[3] = rb + (int)dq.w;
                 }
-            }
-            if (a.yt) {
-                f64x2 *yr = reinterpret_cast<f64x2 *>(a.yt + (size_t)row * NB);
 #pragma unroll
-                for (int q = 0; q < NB / 2; ++q) { f64x2 t; t.x = y[2 * q]; t.y = y[2 * q + 1]; yr[q] = t; }
-            }
-            if (a.b) {
-                const double bi = a.b[row];
+                for (int e = 0; e < U; ++e) {
+                    const bool ok = k0 + e < len;
+                    const uint32_t j = base + (k0 + e) * kSliceRows + rl;
+                    if (!C16) c[e] = ok ? a.sell.col[j] : 0u;
+                    v[e] = ok ? a.sell.val[j] : 0.0;
+                }
+                f64x2 x[U];
 #pragma unroll
-                for (int j = 0; j < NB; ++j) { const double d = (bi + (-1.0) * y[j]) - 0.0; acc[j] += d * d; }
+                for (int e = 0; e < U; ++e) x[e] = *reinterpret_cast<const f64x2 *>(a.xt + (size_t)c[e] * NB + 2 * cp);
+#pragma unroll
+                for (int e = 0; e < U; ++e)
+                    if (k0 + e < mylen) { s0 += v[e] * x[e].x; s1 += v[e] * x[e].y; }        // stored order; padding never added
+            }
+            double y0 = 0.0 + s0, y1 = 0.0 + s1;                          // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+            if (OFFD && live) {
+                double o0 = 0.0, o1 = 0.0;
+                for (uint32_t k = a.offd.ptr[row]; k < a.offd.ptr[row + 1]; ++k) {
+                    const double v = a.offd.val[k];
+                    const f64x2 x = *reinterpret_cast<const f64x2 *>(a.xt + (size_t)a.offd.col[k] * NB + 2 * cp);
+                    o0 += v * x.x; o1 += v * x.y;
+                }
+                y0 += o0; y1 += o1;                                       // second mult() call, src/matrix.c:440
+            }
+            if (live) {
+                if (a.sigma) {
+                    const f64x2 x = *reinterpret_cast<const f64x2 *>(a.xt + (size_t)row * NB + 2 * cp);
+                    y0 += sg0 * x.x; y1 += sg1 * x.y;                     // += sigma_j x_j (src/test_shifted.c:133)
+                }
+                if (a.yt) { f64x2 t; t.x = y0; t.y = y1; *reinterpret_cast<f64x2 *>(a.yt + (size_t)row * NB + 2 * cp) = t; }
+                if (a.b) {
+                    const double bi = a.b[row];
+                    const double d0 = (bi + (-1.0) * y0) - 0.0, d1 = (bi + (-1.0) * y1) - 0.0;
+                    acc0 += d0 * d0; acc1 += d1 * d1;
+                }
             }
         }
     }
     if (a.b) {
+        // lanes with the same column pair sit 8 apart: fold the 8 row positions, then the 4 wavefronts
 #pragma unroll
-        for (int j = 0; j < NB; ++j) acc[j] = wave_sum(acc[j]);
-        if (lane == 0) {
-#pragma unroll
-            for (int j = 0; j < NB; ++j) sm[wave * NB + j] = acc[j];
-        }
+        for (int off = 32; off >= 8; off >>= 1) { acc0 += __shfl_down(acc0, off, 64); acc1 += __shfl_down(acc1, off, 64); }
+        if (lane < 8) { sm[wave * NB + 2 * lane] = acc0; sm[wave * NB + 2 * lane + 1] = acc1; }
         __syncthreads();
         if (tid < NB) {
             double t = sm[tid];

@@ -568,6 +568,7 @@ void spmm_buffers(bicg_ctx *c)
     c->mm_out = dev_alloc<double>(kSpmmCols);
     c->mm_sigma = dev_alloc<double>(kSpmmCols);
     BICG_HIP(hipMemset(c->mm_in, 0, sizeof(double) * kSpmmCols * st));
+    BICG_HIP(hipDeviceSynchronize());      // the memset ran on the null stream: c->sc does not wait for it
     c->mm_xcd = !(getenv("BICG_SPMM_XCD") && atoi(getenv("BICG_SPMM_XCD")) == 0);
 }
 
@@ -1455,11 +1456,6 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         for (uint32_t g = 0; g < ngroups; ++g)
             if (group_fits(g, &dummy)) rows_fit += std::min(nrows, (g + 1) * (uint32_t)kGroupRows) - g * kGroupRows;
         sell_worthwhile = 2 * rows_fit >= nrows;
-        // Lane = row needs rows to parallelise over: a few thousand very long rows (banded, half-bandwidth 512:
-        // 23 k rows x 1025 entries = 92 workgroups for 256 CUs, 125 us per SpMV) belong on the row-block kernel,
-        // whose parallelism is the number of non-zeros
-        if (ngroups < 512 && (uint64_t)c->nnz_d > 64ull * nrows && !(getenv("BICG_FORCE_SELL") && atoi(getenv("BICG_FORCE_SELL"))))
-            sell_worthwhile = false;
     }
     uint64_t sell_entries = 0;
     for (uint32_t g = 0; g < ngroups; ++g) {

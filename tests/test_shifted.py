@@ -115,7 +115,7 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
     """bicg_spmm / the SpMM inside bicg_shifted_residuals (A read once for 16 shifts; the reference's verification loop
     src/test_shifted.c:129-154 does one SpMV per shift): every column bit-identical to the single-vector SpMV with the
     shift added the reference's way, residual norms equal to the per-shift loop's."""
-    import os
+    from mpi_bicgstab_amd import hipsolver as H
     H.lib().bicg_comm_init_single(0)
     A = synth.from_offsets(30011, (0, 1, -1, 37, -37, 2999, -2999), diag_base=9.0, seed=5)
     ctx = H.Context(H.single_rank_blocks(A))
