@@ -227,6 +227,12 @@ struct HaloLL {
     unsigned long long timeout_ticks;
 };
 
+// element-wise phase kernels: pointers to the rank-local vectors
+struct Vecs {
+    double *x, *r, *rh, *p, *s, *y, *z, *w, *v, *t, *ax, *b;   // shifted solver: ax doubles as r_old
+    uint32_t n;
+};
+
 struct SpmvArgs {
     SellDev sell;
     const uint32_t *glist;  // SELL launch: 256-row groups to process (null = groups 0..nlist-1)
@@ -247,6 +253,7 @@ struct SpmvArgs {
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
     HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only
     Finish  fin;            // a dot group of earlier kernels to finish in this launch (seq 0: none)
+    Vecs    epi;            // launch_spmv_sell_epi: the vectors of the element-wise phase in the epilogue
 };
 
 // Sliced-ELL SpMM over kSpmmCols vectors held row-major (bicg_kernels.hip, k_spmm_sell)
@@ -264,11 +271,6 @@ struct SpmmArgs {
     int xcd_map;            // XCD-contiguous assignment of row groups
 };
 
-// element-wise phase kernels: pointers to the rank-local vectors
-struct Vecs {
-    double *x, *r, *rh, *p, *s, *y, *z, *w, *v, *t, *ax, *b;   // shifted solver: ax doubles as r_old
-    uint32_t n;
-};
 
 // ---- launch wrappers (bicg_kernels.hip) ----
 // Both return false when there was nothing to launch. e0/e1 (optional): start/stop events bound to
@@ -281,6 +283,10 @@ unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st);          // out[col] = sum_wg partial[wg][col]
 void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st);
 void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y, hipStream_t st);
+// SpMV + pipelined phase in the epilogue (epi 1: phase 2 after v = A z; epi 2: phase 1 after t = A w); a.fin is
+// applied at the epilogue, a.red receives the phase's dot partials
+bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
+                          bool fused_halo = false);
 void launch_apply(Scal *S, int phase, hipStream_t st);
 void launch_finish(const Launch &L);   // stand-alone finisher: L.fin with FIN_BLOCK0
 void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend, double *sendbuf, Scal *S, hipStream_t st);

@@ -556,11 +556,28 @@ __global__ void __launch_bounds__(kBlock) k_p2p_selftest(P2pRed pr, unsigned seq
 // ------------------------------------------------------------------------------------------
 // reductions
 // ------------------------------------------------------------------------------------------
+// Sum over the 64 lanes of a wavefront with DPP lane permutations (quad swaps, row mirrors, row
+// broadcasts): plain VALU moves, where __shfl_down goes through the LDS crossbar (ds_bpermute, two per
+// double and step: ~0.4 us per sum at the end of every dot-producing workgroup). Fixed association;
+// every lane receives the total.
+template <int CTRL, int ROW_MASK>
+__device__ __forceinline__ double dpp_add(double v)
+{
+    int lo = __double2loint(v), hi = __double2hiint(v);
+    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);     // rows outside ROW_MASK receive 0: v + 0.0
+    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    return v + __hiloint2double(hi, lo);
+}
 __device__ __forceinline__ double wave_sum(double v)
 {
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
-    return v;   // lane 0 holds the sum of the 64 lanes
+    v = dpp_add<0xB1, 0xF>(v);      // quad_perm [1,0,3,2]: pairs
+    v = dpp_add<0x4E, 0xF>(v);      // quad_perm [2,3,0,1]: quads
+    v = dpp_add<0x141, 0xF>(v);     // row_half_mirror: 8 lanes
+    v = dpp_add<0x140, 0xF>(v);     // row_mirror: rows of 16
+    v = dpp_add<0x142, 0xA>(v);     // row_bcast:15 into rows 1 and 3
+    v = dpp_add<0x143, 0xC>(v);     // row_bcast:31 into rows 2 and 3: lane 63 holds the wavefront's sum
+    const int lo = __builtin_amdgcn_readlane(__double2loint(v), 63), hi = __builtin_amdgcn_readlane(__double2hiint(v), 63);
+    return __hiloint2double(hi, lo);
 }
 
 // Sum ND values over the workgroup; every thread receives the totals in v[].
@@ -763,11 +780,11 @@ __device__ __forceinline__ void finish_sum_shard(const Finish &f, unsigned shard
 // shown up by then is computed here (same partials, same order, same bits), so the result does
 // not depend on the order in which the hardware dispatches workgroups. False: a PEER timed out.
 // (got0, v0): outcome of a first look at this thread's shard total that the caller has already taken.
-__device__ __forceinline__ bool finish_totals(const Finish &f, FinishLds &L, bool block0, bool got0, double v0)
+__device__ __forceinline__ bool finish_totals(const Finish &f, int roles, FinishLds &L, bool block0, bool got0, double v0)
 {
     const unsigned tid = threadIdx.x;
-    const bool exchange = f.p2p.seq != 0 && !(f.roles & FIN_LOCAL);
-    if (!exchange || (f.roles & FIN_PUSH)) {
+    const bool exchange = f.p2p.seq != 0 && !(roles & FIN_LOCAL);
+    if (!exchange || (roles & FIN_PUSH)) {
         for (bool first = true;; first = false) {
             if (tid == 0) L.missing = 0u;
             __syncthreads();
@@ -795,19 +812,19 @@ __device__ __forceinline__ bool finish_totals(const Finish &f, FinishLds &L, boo
     }
     if (!exchange) return true;
     const int P = f.p2p.nranks;
-    if ((f.roles & FIN_PUSH) && block0)
+    if ((roles & FIN_PUSH) && block0)
         for (int t = tid; t < f.n * P; t += kBlock) {
             const int p = t / f.n, d = t % f.n;
             ll_store(f.p2p.mail[p] + mail_index(f.p2p.seq, P, f.p2p.rank, f.red_off + d), L.sums[d], f.p2p.seq);
         }
-    if (!(f.roles & (FIN_APPLY | FIN_BLOCK0))) return true;
+    if (!(roles & (FIN_APPLY | FIN_BLOCK0))) return true;
     if (tid == 0) L.fail = 0;
     __syncthreads();
     const llword *mine = f.p2p.mail[f.p2p.rank];
     for (int t = tid; t < f.n * P; t += kBlock) {
         const int p = t / f.n, d = t % f.n;
         double v;
-        if (p == f.p2p.rank && (f.roles & FIN_PUSH)) v = L.sums[d];
+        if (p == f.p2p.rank && (roles & FIN_PUSH)) v = L.sums[d];
         else if (!ll_wait(mine + mail_index(f.p2p.seq, P, p, f.red_off + d), f.p2p.seq, f.p2p.timeout_ticks, &v)) L.fail = 1;
         L.pv[p * kRedSlots + d] = v;
     }
@@ -823,11 +840,12 @@ __device__ __forceinline__ bool finish_totals(const Finish &f, FinishLds &L, boo
 // Returns the scalar block the kernel has to read: S itself, or -- FIN_APPLY -- the private copy
 // *priv (LDS) on which the recurrence has been applied; workgroup 0 has then written it to
 // f.Snext as well, also when the solve is already `done` (the host switches blocks regardless).
-__device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, unsigned bid, unsigned nblocks, FinishLds &L,
+// roles: what THIS call does of roles (a launch may sum the shards at its start and apply at its epilogue).
+__device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, int roles, unsigned bid, unsigned nblocks, FinishLds &L,
                                                     Scal *priv)
 {
     const unsigned tid = threadIdx.x;
-    const bool all = (f.roles & FIN_APPLY) != 0, block0 = bid == 0;
+    const bool all = (roles & FIN_APPLY) != 0, block0 = bid == 0;
     // everything this prologue may need from memory is requested before the first of it is looked at:
     // `done`, the alarm, a copy of the scalar block (one wavefront) and this thread's shard total --
     // one round trip instead of four dependent ones underneath the kernel's own loads
@@ -835,8 +853,8 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
     const int alarm = f.alarm ? *f.alarm : 0;
     double v0 = 0.0;
     bool got0 = false;
-    const bool local = !(f.p2p.seq != 0 && !(f.roles & FIN_LOCAL)) || (f.roles & FIN_PUSH);
-    if (all && local && !(f.roles & FIN_SHARDS) && (int)tid < kShards * f.n)
+    const bool local = !(f.p2p.seq != 0 && !(roles & FIN_LOCAL)) || (roles & FIN_PUSH);
+    if (all && local && !(roles & FIN_SHARDS) && (int)tid < kShards * f.n)
         got0 = ll_peek_agent(f.shard + ((size_t)((int)tid / f.n) * kRedSlots + (int)tid % f.n) * 2, f.seq, &v0);
     if (all && tid == 64) *priv = *S;
     if (done) {          // converged: producers wrote nothing, nothing may change any more
@@ -854,12 +872,12 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
         }
         return S;
     }
-    if (f.roles & FIN_SHARDS)
+    if (roles & FIN_SHARDS)
         for (unsigned sh = bid; sh < (unsigned)kShards; sh += nblocks) finish_sum_shard(f, sh, L);
-    const bool consume = all || (block0 && (f.roles & (FIN_BLOCK0 | FIN_PUSH)));
+    const bool consume = all || (block0 && (roles & (FIN_BLOCK0 | FIN_PUSH)));
     if (!consume) return S;
-    const bool ok = finish_totals(f, L, block0, got0, v0);
-    if (!(f.roles & (FIN_APPLY | FIN_BLOCK0))) return S;
+    const bool ok = finish_totals(f, roles, L, block0, got0, v0);
+    if (!(roles & (FIN_APPLY | FIN_BLOCK0))) return S;
     if (tid == 0) {
         if (!ok && f.alarm) *f.alarm = 1;
         // all: the recurrence runs on the private copy in LDS (other workgroups of this launch may still
@@ -882,7 +900,7 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, un
 __global__ void __launch_bounds__(kBlock) k_finish(Scal *S, Finish f)
 {
     __shared__ FinishLds L;
-    (void)finish_group(S, f, blockIdx.x, gridDim.x, L, nullptr);
+    (void)finish_group(S, f, f.roles, blockIdx.x, gridDim.x, L, nullptr);
 }
 
 void launch_finish(const Launch &L)
@@ -914,7 +932,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 {
     if (MODE == RED_WAVE) {
         __shared__ FinishLds fl;
-        if (a.fin.seq) (void)finish_group(a.S, a.fin, blockIdx.x, gridDim.x, fl, nullptr);
+        if (a.fin.seq) (void)finish_group(a.S, a.fin, a.fin.roles, blockIdx.x, gridDim.x, fl, nullptr);
     }
     // The sticky convergence flag is requested here but only consumed where state would be
     // modified (y stores, dot publication): an early `if (done) return` would put one more
@@ -1090,33 +1108,120 @@ typedef short i16x4 __attribute__((ext_vector_type(4)));
 // C16: column indices are read as 16-bit offsets from the row (col = row + delta), four
 // consecutive entries of a lane packed in one 8-byte word: 10 instead of 12 bytes per non-zero.
 // Used when every entry of the sliced-ELL copy satisfies |col - row| < 32768 (banded matrices).
+// u <- add + beta (u - omega w): daxpy(-omega) / dscal(beta) / daxpy(1.0)   (src/solver.c:217-219 etc.)
+template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double omega, double beta)
+{
+    T t = u + (-omega) * w;
+    t = beta * t;
+    return t + 1.0 * add;
+}
+
+// y_i of this lane's row of list entry gi (diag part in stored order, then the offd part, then the shift):
+// the body shared by the SpMV kernel and the SpMV-with-epilogue kernel below
+template <bool OFFD, bool NT, bool C16, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
+__device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed)
+{
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const double *__restrict__ x = a.x;
+    const unsigned g = a.glist ? a.glist[gi] : gi;
+    row = g * kGroupRows + tid;                                // = slice * 64 + lane
+    const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
+    live = row < a.nrows;
+
+    uint32_t base = 0u, len = 0u, base16 = 0u;
+    if (slice * kSliceRows < a.nrows) {
+        base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
+        if (C16) base16 = a.sell.slice_base16[slice];
+    }
+    uint32_t mylen = 0u, oa = 0u, ob = 0u;
+    if (live) {
+        mylen = a.diag.ptr[row + 1] - a.diag.ptr[row];
+        if (OFFD && (!LL || gi >= a.ll.first_bnd)) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
+    }
+
+    double sum = 0.0;
+    for (uint32_t k0 = 0; k0 < len; k0 += U) {
+        uint32_t c[U];
+        double   v[U];
+        if (C16) {
+            static_assert(U % 4 == 0, "packed 16-bit columns come four at a time");
+#pragma unroll
+            for (int q = 0; q < U / 4; ++q) {
+                const bool ok = k0 + 4 * q < len;             // wave-uniform; the quad is padded
+                const i16x4 *p = reinterpret_cast<const i16x4 *>(a.sell.col16) +
+                                 ((size_t)base16 / 4 + (size_t)((k0 / 4) + q) * kSliceRows + lane);
+                i16x4 dq = (i16x4)(0);
+                if (ok) dq = NT ? __builtin_nontemporal_load(p) : *p;
+                // lanes past the last row hold padding only: their offsets are 0 and must not turn into
+                // reads of x[row >= nrows] (the vector may end before the 64-row slice does)
+                const uint32_t rb = live ? row : 0u;
+                c[4 * q + 0] = rb + (int)dq.x; c[4 * q + 1] = rb + (int)dq.y;
+                c[4 * q + 2] = rb + (int)dq.z; c[4 * q + 3] = rb + (int)dq.w;
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const bool ok = k0 + e < len;                     // wave-uniform
+            const uint32_t j = base + (k0 + e) * kSliceRows + lane;
+            if (!C16) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
+            v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
+        }
+        double xv[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) xv[e] = x[c[e]];
+#pragma unroll
+        for (int e = 0; e < U; ++e)
+            if (k0 + e < mylen) sum += v[e] * xv[e];          // stored order; padding never added
+    }
+    double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+    if (OFFD) {
+        double so = 0.0;
+        for (uint32_t k = oa; k < ob; ++k) {
+            double xh;
+            if (LL) {
+                // the value comes straight from the landing ring; the diag part above ran while it travelled
+                xh = 0.0;
+                if (!done && !ll_wait(a.ll.ring + ((size_t)(a.ll.seq % kHaloRing) * a.ll.halo + (a.offd.col[k] - a.nrows)) * 2,
+                                      a.ll.seq, a.ll.timeout_ticks, &xh))
+                    ll_failed = true;
+            } else {
+                xh = x[a.offd.col[k]];
+            }
+            so += a.offd.val[k] * xh;
+        }
+        yi += so;                                             // second mult() call, src/matrix.c:440
+    }
+    if (a.has_shift && live) yi += a.shift * x[row];          // (A + sigma I) x, src/shifted_solver.c:260
+    return yi;
+}
+
+// the leading workgroups of a launch with in-kernel halo exchange: store the send list into the peers' landing rings
+__device__ __forceinline__ void sell_halo_push(const SpmvArgs &a, unsigned bid, int done)
+{
+    if (done) return;
+    for (uint32_t i = bid * kBlock + threadIdx.x; i < a.ll.nsend; i += a.ll.npush * kBlock)
+        ll_store(reinterpret_cast<llword *>(a.ll.dst0[i] + (unsigned long long)(a.ll.seq % kHaloRing) * a.ll.dstride[i]),
+                 a.x[a.ll.send_idx[i]], a.ll.seq);
+}
+
 template <int NDOT, bool OFFD, bool NT, bool C16, bool LL, int MODE>
 __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
     __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
-    constexpr int U = 8;              // entries per lane in flight (4, 8, 16 measured identical)
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const double *__restrict__ x = a.x;
     unsigned bid = blockIdx.x, nblocks = gridDim.x;
     bool ll_failed = false;
     if (LL) {
         // peer-to-peer exchange inside the launch: the leading workgroups are scheduled first and
         // send; x is complete (it was written by earlier kernels), so nothing has to be waited for
-        if (bid < a.ll.npush) {
-            if (!done)
-                for (uint32_t i = bid * kBlock + tid; i < a.ll.nsend; i += a.ll.npush * kBlock)
-                    ll_store(reinterpret_cast<llword *>(a.ll.dst0[i] + (unsigned long long)(a.ll.seq % kHaloRing) * a.ll.dstride[i]),
-                             x[a.ll.send_idx[i]], a.ll.seq);
-            return;
-        }
+        if (bid < a.ll.npush) { sell_halo_push(a, bid, done); return; }
         bid -= a.ll.npush; nblocks -= a.ll.npush;
     }
     if (MODE == RED_WAVE) {
         // a dot group of EARLIER kernels rides on this launch: its first workgroups add up the shards
         // (and hand the sums to the other ranks) while everybody else already streams the matrix
         __shared__ FinishLds fl;
-        if (a.fin.seq) (void)finish_group(a.S, a.fin, bid, nblocks, fl, nullptr);
+        if (a.fin.seq) (void)finish_group(a.S, a.fin, a.fin.roles, bid, nblocks, fl, nullptr);
     }
 
     double acc[NDOT > 0 ? NDOT : 1];
@@ -1129,87 +1234,123 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
     // over the XCDs is kept: an XCD-contiguous mapping cuts the fabric reads from 386 to 309 MB
     // (x is then fetched by one L2 instead of eight) but is 3-5 % SLOWER in wall time.
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
-        const unsigned g = a.glist ? a.glist[gi] : gi;
-        const uint32_t row = g * kGroupRows + tid;                 // = slice * 64 + lane
-        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
-        const bool live = row < a.nrows;
-
-        uint32_t base = 0u, len = 0u, base16 = 0u;
-        if (slice * kSliceRows < a.nrows) {
-            base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
-            if (C16) base16 = a.sell.slice_base16[slice];
-        }
-        uint32_t mylen = 0u, oa = 0u, ob = 0u;
-        double ume = 0.0;
-        if (live) {
-            mylen = a.diag.ptr[row + 1] - a.diag.ptr[row];
-            if (OFFD && (!LL || gi >= a.ll.first_bnd)) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
-            if (NDOT >= 1) ume = a.u[row];
-        }
-
-        double sum = 0.0;
-        for (uint32_t k0 = 0; k0 < len; k0 += U) {
-            uint32_t c[U];
-            double   v[U];
-            if (C16) {
-                static_assert(U % 4 == 0, "packed 16-bit columns come four at a time");
-#pragma unroll
-                for (int q = 0; q < U / 4; ++q) {
-                    const bool ok = k0 + 4 * q < len;             // wave-uniform; the quad is padded
-                    const i16x4 *p = reinterpret_cast<const i16x4 *>(a.sell.col16) +
-                                     ((size_t)base16 / 4 + (size_t)((k0 / 4) + q) * kSliceRows + lane);
-                    i16x4 dq = (i16x4)(0);
-                    if (ok) dq = NT ? __builtin_nontemporal_load(p) : *p;
-                    // lanes past the last row hold padding only: their offsets are 0 and must not turn into
-                    // reads of x[row >= nrows] (the vector may end before the 64-row slice does)
-                    const uint32_t rb = live ? row : 0u;
-                    c[4 * q + 0] = rb + (int)dq.x; c[4 * q + 1] = rb + (int)dq.y;
-                    c[4 * q + 2] = rb + (int)dq.z; c[4 * q + 3] = rb + (int)dq.w;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < U; ++e) {
-                const bool ok = k0 + e < len;                     // wave-uniform
-                const uint32_t j = base + (k0 + e) * kSliceRows + lane;
-                if (!C16) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
-                v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
-            }
-            double xv[U];
-#pragma unroll
-            for (int e = 0; e < U; ++e) xv[e] = x[c[e]];
-#pragma unroll
-            for (int e = 0; e < U; ++e)
-                if (k0 + e < mylen) sum += v[e] * xv[e];          // stored order; padding never added
-        }
-        double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
-        if (OFFD) {
-            double so = 0.0;
-            for (uint32_t k = oa; k < ob; ++k) {
-                double xh;
-                if (LL) {
-                    // the value comes straight from the landing ring; the diag part above ran while it travelled
-                    xh = 0.0;
-                    if (!done && !ll_wait(a.ll.ring + ((size_t)(a.ll.seq % kHaloRing) * a.ll.halo + (a.offd.col[k] - a.nrows)) * 2,
-                                          a.ll.seq, a.ll.timeout_ticks, &xh))
-                        ll_failed = true;
-                } else {
-                    xh = x[a.offd.col[k]];
-                }
-                so += a.offd.val[k] * xh;
-            }
-            yi += so;                                             // second mult() call, src/matrix.c:440
-        }
-        if (a.has_shift && live) yi += a.shift * x[row];          // (A + sigma I) x, src/shifted_solver.c:260
+        uint32_t row;
+        bool live;
+        const double yi = sell_row<OFFD, NT, C16, LL>(a, gi, done, row, live, ll_failed);
         if (live && !done) a.y[row] = yi;
-        if (NDOT >= 1 && live) acc[0] += ume * yi;
-        if (NDOT == 2 && live) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
-        if (NDOT == 3 && live) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
+        if (NDOT >= 1 && live) {
+            const double ume = a.u[row];
+            acc[0] += ume * yi;
+            if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+            if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ume * ume;
+        }
     }
     if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
     if (NDOT > 0 && !done) {
         if (MODE == RED_WAVE) wave_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.red.partial, a.red.slot_base + bid);
         else reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + bid, sm);
     }
+}
+
+// ------------------------------------------------------------------------------------------
+// SpMV + element-wise phase in ONE launch: the pipelined iteration as two kernels
+//   EPI = 1:  v = A z ; then phase 2 on the workgroup's own rows (x, r, w, five dots; src/solver.c:366-380)
+//   EPI = 2:  t = A w ; then phase 1 of the NEXT iteration (p, s, z, q, y, two dots; src/solver.c:352-364)
+// The phase needs, per row, only values of that row -- among them the y_i this lane has just
+// computed -- so it rides in the SpMV's epilogue: two launches per iteration instead of four, and the
+// dot group the phase's scalars come from (produced by the previous launch) is summed by this
+// launch's first workgroups while everybody streams the matrix; by the time a workgroup reaches its
+// epilogue the totals are there. On a 200 k-row rank (1/8 of Transport) every launch boundary and
+// every exposed reduction costs as much as the arithmetic, which is what this removes.
+// The phase's expressions are those of FPipe1 / FPipe2, operation for operation; y lives in its own
+// vector (a.epi.y) because w is this SpMV's input while the epilogue of EPI = 2 produces y.
+// ------------------------------------------------------------------------------------------
+template <int EPI, bool OFFD, bool NT, bool C16, bool LL>
+__global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
+{
+    constexpr int ND = EPI == 1 ? 5 : 2;
+    const int done = a.S->done;
+    __shared__ FinishLds fl;
+    __shared__ Scal priv;
+    unsigned bid = blockIdx.x, nblocks = gridDim.x;
+    bool ll_failed = false;
+    if (LL) {
+        if (bid < a.ll.npush) { sell_halo_push(a, bid, done); return; }
+        bid -= a.ll.npush; nblocks -= a.ll.npush;
+    }
+    // The open dot group. kShards DEDICATED workgroups in front of the row workgroups sum the shards (and,
+    // peer-to-peer, the first of them hands the local sums to the other ranks) and leave; the first one also applies
+    // the recurrence and writes the next scalar block. A workgroup with rows of its own would start them that much
+    // later, and the launch ends with its slowest workgroup. Row workgroups apply privately at their epilogue.
+    const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;
+    if (bid < nhelp) {
+        (void)finish_group(a.S, a.fin, a.fin.roles & (FIN_SHARDS | FIN_PUSH), bid, nhelp, fl, nullptr);
+        if (bid == 0) (void)finish_group(a.S, a.fin, FIN_APPLY, 0u, nhelp, fl, &priv);
+        return;
+    }
+    bid -= nhelp; nblocks -= nhelp;
+    // staged by an earlier launch (or nothing to sum): row workgroup 0 publishes the scalar block
+    const unsigned fin_bid = nhelp ? bid + 1u : bid;
+    double acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = 0.0;
+    const Vecs &e = a.epi;
+    bool have = false;
+    int sdone = done;
+    double alpha = 0.0, beta = 0.0, omega = 0.0;
+#define EPI_SCALARS()                                                                                     \
+    do {                                                                                                  \
+        const Scal *sc_ = a.S;                                                                            \
+        if (a.fin.seq) sc_ = finish_group(a.S, a.fin, FIN_APPLY, fin_bid, nblocks, fl, &priv);            \
+        sdone = sc_->done; alpha = sc_->alpha; beta = sc_->beta; omega = sc_->omega;                      \
+        have = true;                                                                                      \
+    } while (0)
+    for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
+        // The phase's inputs (values of this lane's own row) are requested BEFORE the row product: on a small rank
+        // a launch is as long as its longest chain of dependent memory round trips, and these loads depend on nothing.
+        // For the same reason the row product keeps 16 entries in flight: a Transport row (15 entries) is one batch.
+        const uint32_t row0 = (a.glist ? a.glist[gi] : gi) * kGroupRows + threadIdx.x;
+        const uint32_t rr_ = row0 < a.nrows ? row0 : 0u;
+        double in0, in1, in2, in3, in4, in5, in6 = 0.0, in7 = 0.0;
+        if (EPI == 1) { in0 = e.r[rr_]; in1 = e.y[rr_]; in2 = e.x[rr_]; in3 = e.p[rr_]; in4 = e.t[rr_]; in5 = e.rh[rr_]; in6 = e.s[rr_]; in7 = e.z[rr_]; }
+        else { in0 = e.r[rr_]; in1 = e.w[rr_]; in2 = e.s[rr_]; in3 = e.z[rr_]; in4 = e.p[rr_]; in5 = e.v[rr_]; }
+        uint32_t row;
+        bool live;
+        const double yi = sell_row<OFFD, NT, C16, LL, 8>(a, gi, done, row, live, ll_failed);
+        if (live && !done) a.y[row] = yi;
+        if (!have) EPI_SCALARS();
+        if (EPI == 1) {
+            const double q = in0, y = in1, x0 = in2, p0 = in3, t0 = in4, h = in5, s0 = in6, z0 = in7;
+            if (live && !sdone) {
+                double xx = x0 + alpha * p0;
+                xx = xx + omega * q;
+                e.x[row] = xx;
+                const double rr = q + (-omega) * y;
+                e.r[row] = rr;
+                const double tt = t0 + (-alpha) * yi;
+                const double ww = y + (-omega) * tt;
+                e.w[row] = ww;
+                acc[0] += rr * rr; acc[1] += h * rr; acc[2] += h * ww; acc[3] += h * s0; acc[4] += h * z0;
+            }
+        } else {
+            const double r0 = in0, w0 = in1, s0 = in2, z0 = in3, p0 = in4, v0 = in5;
+            if (live && !sdone) {
+                e.p[row] = recur3<double>(p0, s0, r0, omega, beta);
+                const double s1 = recur3<double>(s0, z0, w0, omega, beta);
+                const double z1 = recur3<double>(z0, v0, yi, omega, beta);
+                e.s[row] = s1; e.z[row] = z1;
+                const double q = r0 + (-alpha) * s1;
+                const double y = w0 + (-alpha) * z1;
+                e.r[row] = q; e.y[row] = y;
+                acc[0] += q * y; acc[1] += y * y;
+            }
+        }
+    }
+    if (!have && fin_bid == 0) EPI_SCALARS();  // the publishing workgroup writes the scalar block even without rows
+#undef EPI_SCALARS
+    if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
+    if (have && !sdone) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + bid);
+    else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + bid);
 }
 
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
@@ -1429,6 +1570,28 @@ void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t
 void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y, hipStream_t st)
 {
     if (n) hipLaunchKernelGGL(k_vectors_from_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, yt, stride, nvec, n, y);
+}
+
+bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
+{
+    if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
+    const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;      // dedicated shard summers
+    dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u) + nhelp), b(kBlock);
+    const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;
+#define EPI_CASE(EP, OF, LLV)                                                                                   \
+    do {                                                                                                        \
+        if (nt && c16) launch_timed(k_spmv_sell_epi<EP, OF, true, true, LLV>, g, b, st, e0, e1, a);             \
+        else if (nt) launch_timed(k_spmv_sell_epi<EP, OF, true, false, LLV>, g, b, st, e0, e1, a);              \
+        else if (c16) launch_timed(k_spmv_sell_epi<EP, OF, false, true, LLV>, g, b, st, e0, e1, a);             \
+        else launch_timed(k_spmv_sell_epi<EP, OF, false, false, LLV>, g, b, st, e0, e1, a);                     \
+    } while (0)
+    if (epi == 1) {
+        if (fused_halo) EPI_CASE(1, true, true); else if (with_offd) EPI_CASE(1, true, false); else EPI_CASE(1, false, false);
+    } else {
+        if (fused_halo) EPI_CASE(2, true, true); else if (with_offd) EPI_CASE(2, true, false); else EPI_CASE(2, false, false);
+    }
+#undef EPI_CASE
+    return true;
 }
 
 void launch_apply(Scal *S, int phase, hipStream_t st)
@@ -1667,14 +1830,14 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
             // workgroup of the launch is waiting for. Everybody else fetches first and waits underneath.
             const bool helper = fin.seq && (fin.roles & FIN_SHARDS) && blockIdx.x < (unsigned)kShards;
             if (have && !helper) pre = f.template fetch<d2>(2 * i0);
-            if (fin.seq) sc = finish_group(S, fin, blockIdx.x, gridDim.x, fl, &priv);
+            if (fin.seq) sc = finish_group(S, fin, fin.roles, blockIdx.x, gridDim.x, fl, &priv);
             if (have && helper) pre = f.template fetch<d2>(2 * i0);
             if (sc->done) return;
             f.load(sc);
             if (have) f.template compute<d2>(2 * i0, pre, acc);
             for (uint32_t i = i0 + stride; i < npair; i += stride) f.template compute<d2>(2 * i, f.template fetch<d2>(2 * i), acc);
         } else {
-            if (fin.seq) sc = finish_group(S, fin, blockIdx.x, gridDim.x, fl, &priv);
+            if (fin.seq) sc = finish_group(S, fin, fin.roles, blockIdx.x, gridDim.x, fl, &priv);
             if (sc->done) return;
             f.load(sc);
             for (uint32_t i = i0; i < npair; i += stride) f.template apply<d2>(2 * i, acc);
@@ -1820,14 +1983,6 @@ struct FPlainP {
 };
 void launch_plain_p(const Vecs &v, const Launch &L) { run_vec(FPlainP{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{}); }
 
-// u <- add + beta (u - omega w): daxpy(-omega) / dscal(beta) / daxpy(1.0)   (src/solver.c:217-219 etc.)
-template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double omega, double beta)
-{
-    T t = u + (-omega) * w;
-    t = beta * t;
-    return t + 1.0 * add;
-}
-
 // ---- CA: p = r + beta(p - omega s) ; s = w + beta(s - omega z)         (src/solver.c:217-222)
 struct FCaPS {
     static constexpr int ND = 0;
@@ -1905,11 +2060,13 @@ void launch_ca_xr(const Vecs &v, const Launch &L, Reduce red)
 }
 
 // ---- pipelined phase 1: p, s, z recurrences ; q, y ; (q,y), (y,y)       (src/solver.c:352-364)
+// y = w - alpha z goes to its own vector yb (the reference keeps it in w, :363-364): w is the input of the
+// SpMV t = A w in whose epilogue this phase may run (k_spmv_sell_epi), so it cannot be overwritten there
 struct FPipe1 {
     static constexpr int ND = 2;
     static constexpr int kModes = kWaveOnly;
     static constexpr bool kSplit = true;
-    double *p, *s, *z, *r, *w; const double *t, *v; double alpha, beta, omega;
+    double *p, *s, *z, *r, *yb; const double *w, *t, *v; double alpha, beta, omega;
     template <class T> struct In { T r, w, s, z, p, v, t; };
     __device__ void load(const Scal *S) { alpha = S->alpha; beta = S->beta; omega = S->omega; }
     template <class T> __device__ In<T> fetch(uint32_t i) const
@@ -1924,7 +2081,7 @@ struct FPipe1 {
         st(s, i, s1); st(z, i, z1);
         T q = in.r + (-alpha) * s1;
         T y = in.w + (-alpha) * z1;
-        st(r, i, q); st(w, i, y);
+        st(r, i, q); st(yb, i, y);
         acc[0] += hsum(q * y);
         acc[1] += hsum(y * y);
     }
@@ -1932,7 +2089,7 @@ struct FPipe1 {
 };
 void launch_pipe_f1(const Vecs &v, const Launch &L, Reduce red)
 {
-    run_vec(FPipe1{v.p, v.s, v.z, v.r, v.w, v.t, v.v, 0.0, 0.0, 0.0}, v.n, L, red);
+    run_vec(FPipe1{v.p, v.s, v.z, v.r, v.y, v.w, v.t, v.v, 0.0, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- pipelined phase 2: x ; r = q - omega y ; w = y - omega (t - alpha v) ; five dots  (src/solver.c:370-380)
@@ -1941,12 +2098,12 @@ template <bool XNT> struct FPipe2 {
     static constexpr int ND = 5;
     static constexpr int kModes = kWaveOnly;
     static constexpr bool kSplit = true;
-    double *x, *r, *w; const double *p, *t, *v, *rh, *s, *z; double alpha, omega;
+    double *x, *r, *w; const double *yb, *p, *t, *v, *rh, *s, *z; double alpha, omega;
     template <class T> struct In { T q, y, x, p, t, v, rh, s, z; };
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
     template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        return {ld<T>(r, i), ld<T>(w, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(t, i), ld<T>(v, i), ld<T>(rh, i),
+        return {ld<T>(r, i), ld<T>(yb, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(t, i), ld<T>(v, i), ld<T>(rh, i),
                 ld<T>(s, i), ld<T>(z, i)};
     }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
@@ -1969,8 +2126,8 @@ template <bool XNT> struct FPipe2 {
 };
 void launch_pipe_f2(const Vecs &v, const Launch &L, Reduce red)
 {
-    if (stream_x()) run_vec(FPipe2<true>{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
-    else run_vec(FPipe2<false>{v.x, v.r, v.w, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
+    if (stream_x()) run_vec(FPipe2<true>{v.x, v.r, v.w, v.y, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
+    else run_vec(FPipe2<false>{v.x, v.r, v.w, v.y, v.p, v.t, v.v, v.rh, v.s, v.z, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- residual replacement pieces

@@ -118,6 +118,9 @@ struct bicg_ctx {
         int n = 0, off = 0, phase = 0, buf = 0;
     } grp;
     bool wave_mode = false;      // this call uses consumer-side finish (run_begin); false: ticket reductions
+    bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues -- chosen for ranks whose
+                                 // launches are latency-bound (< 6 M local non-zeros; BICG_FUSE_PIPE=0/1 overrides)
+    bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
     double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
     llword *shard_ll = nullptr;  // 2 x [kShards][kRedSlots][2], alternating like wpart
     int *alarm = nullptr, *h_alarm = nullptr;
@@ -361,17 +364,20 @@ void group_defer(bicg_ctx *c, int n, int phase)
 // blocks that touch the halo run after it has landed. Every row is produced by exactly one
 // workgroup as (0 + sum_diag) + sum_offd, the reference's order.
 // fin: a dot group of earlier kernels that the first kernel launched here finishes (grp_for_spmv).
-void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{})
+void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{}, int epi = 0,
+          Scal *S = nullptr)
 {
     SpmvArgs a;
     a.fin = fin;
+    a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16};
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
     a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.desc = nullptr; a.nlist = 0;
-    a.x = xin; a.y = yout; a.u = u; a.S = c->S;
+    a.x = xin; a.y = yout; a.u = u; a.S = S ? S : c->S;
+    Scal *const Sh = a.S;        // every kernel of this call reads the same scalar block
     a.nt = c->sell_nt ? 1 : 0;
     a.shift = c->cur_shift; a.has_shift = c->cur_has_shift ? 1 : 0;
     // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
@@ -385,7 +391,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     red.expected = merged ? g_sall + g_ci + g_cb : g_si + g_ci + g_sb + g_cb;
     red.slot_base = 0;
     a.red = red;
-    if (red.wave && ndot > 0) c->grp.nparts = red.expected * (kBlock / 64);   // one partial per wavefront
+    if (red.wave && (ndot > 0 || epi)) c->grp.nparts = red.expected * (kBlock / 64);   // one partial per wavefront
 
     // per-kernel timing: every SpMV kernel of this call gets its own start/stop event pair
     const bool timed = c->time_kernels && c->tev_used + 8 <= (int)c->tev.size();
@@ -409,14 +415,20 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         took(launch_spmv(a, ndot, true, c->sc, ev(0), ev(1)));
     };
 
+    if (epi && !(c->glist_all && c->nblk == 0 && (c->single() || fused))) die("internal", "SpMV epilogue on a multi-launch SpMV");
     if (c->single()) {
-        interior();
+        if (epi) {
+            a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
+            took(launch_spmv_sell_epi(a, epi, false, c->sc, ev(0), ev(1)));
+        } else {
+            interior();
+        }
     } else if (c->p2p) {
         // peer-to-peer: the send list is stored straight into the landing rings of the ranks that
         // need it, the interior rows run while the values cross the links, one kernel decodes the
         // ring slot into the halo tail of x, then the rows that touch the halo run
         if (c->halo_unsynced >= kHaloRing - 2) {   // nothing has throttled the senders for a while
-            launch_p2p_barrier(c->p2p->red_desc(c->p2p->bar_seq++), c->p2p->timeout_ticks, c->S, c->sc);
+            launch_p2p_barrier(c->p2p->red_desc(c->p2p->bar_seq++), c->p2p->timeout_ticks, Sh, c->sc);
             c->halo_unsynced = 0;
         }
         const unsigned seq = ++c->halo_seq;
@@ -432,14 +444,15 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             a.ll.send_idx = c->send_idx; a.ll.dst0 = c->push_dst0; a.ll.dstride = c->push_stride;
             a.ll.timeout_ticks = c->p2p->timeout_ticks;
             a.glist = c->glist_ll; a.nlist = c->ng_int + c->ng_bnd; a.red.slot_base = 0;
-            took(launch_spmv_sell(a, ndot, true, c->sc, ev(0), ev(1), true));
+            if (epi) took(launch_spmv_sell_epi(a, epi, true, c->sc, ev(0), ev(1), true));
+            else took(launch_spmv_sell(a, ndot, true, c->sc, ev(0), ev(1), true));
             a.glist = nullptr;
             a.desc = c->desc_int; a.nlist = c->n_int; a.red.slot_base = g_sall;
             took(launch_spmv(a, ndot, false, c->sc, ev(0), ev(1)));
         } else {
-            if (!lose) launch_halo_push(xin, c->send_idx, c->nsend, c->push_dst0, c->push_stride, seq, c->S, c->sc);
+            if (!lose) launch_halo_push(xin, c->send_idx, c->nsend, c->push_dst0, c->push_stride, seq, Sh, c->sc);
             interior();
-            launch_halo_unpack(c->halo_ring, c->halo, seq, xin + c->n_loc, c->S, c->p2p->timeout_ticks, c->sc);
+            launch_halo_unpack(c->halo_ring, c->halo, seq, xin + c->n_loc, Sh, c->p2p->timeout_ticks, c->sc);
             boundary();
         }
         if (c->pend) {
@@ -448,7 +461,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             c->halo_unsynced = 0;
         }
     } else {
-        launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, c->S, c->sc);
+        launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, Sh, c->sc);
         const bool two_streams = c->comm->stream_ordered() && c->overlap;
         hipEvent_t eh = nullptr;
         if (two_streams) {
@@ -572,6 +585,15 @@ void spmm_buffers(bicg_ctx *c)
     c->mm_xcd = !(getenv("BICG_SPMM_XCD") && atoi(getenv("BICG_SPMM_XCD")) == 0);
 }
 
+// SpMV whose epilogue runs a pipelined phase on the workgroup's own rows (k_spmv_sell_epi): the open dot group is
+// summed by the launch's first workgroups and applied at the epilogue; the phase's own nd dots open the next group.
+void spmv_epi(bicg_ctx *c, double *xin, double *yout, int epi, int nd, int phase)
+{
+    const Launch L = grp_consume(c);
+    Reduce red = grp_produce(c, 0, nd, phase, 0);
+    spmv(c, xin, yout, 0, nullptr, red, L.fin, epi, L.S);
+}
+
 // a deferred group that no SpMV picked up (defensive)
 void group_flush(bicg_ctx *c)
 {
@@ -663,18 +685,43 @@ struct Driver {
         group_now(c, 5, PH_RECUR_END);
     }
 
-    void iter_pipe(int it, bool force_replace)   // reference src/solver.c:352-390 and 494-548
+    bool replaces(int it) const { return method == BICG_PIPE_BICGSTAB_RR && krr > 0 && (it % krr == 0) && it > 0 && it <= krr * nrr; }
+    // two launches per iteration (phases in the SpMV epilogues): every row on the sliced-ELL path and a single
+    // SpMV launch per product (one rank, or the peer-to-peer exchange folded into the launch)
+    bool fused() const
     {
-        const bool replace = force_replace ||
-                             (method == BICG_PIPE_BICGSTAB_RR && krr > 0 && (it % krr == 0) && it > 0 && it <= krr * nrr);
+        return c->fuse_pipe && c->wave_mode && !hosted(c) && c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused));
+    }
+
+    // last: the caller looks at x / r after this iteration (end of a run_iterate call, adaptive replacement check):
+    // phase 1 of the next iteration, which overwrites r with q, must not have run yet
+    void iter_pipe(int it, bool force_replace, bool last)   // reference src/solver.c:352-390 and 494-548
+    {
+        const bool replace = force_replace || replaces(it);
         if (!replace) {
-            vec_dots(launch_pipe_f1, 2, PH_OMEGA);                   // p, s, z, q, y, (q,y), (y,y)
-            group_defer(c, 2, PH_OMEGA);
-            spmv_grp(c, v.z, v.v);                                   // v = A z   || all-reduce
-            vec_dots(launch_pipe_f2, 5, PH_RECUR_END);               // x, r, w, five dots
-            group_defer(c, 5, PH_RECUR_END);
-            spmv_grp(c, v.w, v.t);                                   // t = A w   || all-reduce
+            if (!c->f1_done) {
+                vec_dots(launch_pipe_f1, 2, PH_OMEGA);                   // p, s, z, q, y, (q,y), (y,y)
+                group_defer(c, 2, PH_OMEGA);
+            }
+            c->f1_done = false;
+            if (fused()) {
+                spmv_epi(c, v.z, v.v, 1, 5, PH_RECUR_END);               // v = A z ; x, r, w, five dots   || all-reduce of (q,y), (y,y)
+                group_defer(c, 5, PH_RECUR_END);
+                if (!last && !replaces(it + 1)) {
+                    spmv_epi(c, v.w, v.t, 2, 2, PH_OMEGA);               // t = A w ; phase 1 of iteration it + 1   || all-reduce of the five
+                    group_defer(c, 2, PH_OMEGA);
+                    c->f1_done = true;
+                } else {
+                    spmv_grp(c, v.w, v.t);                               // t = A w   || all-reduce
+                }
+            } else {
+                spmv_grp(c, v.z, v.v);                                   // v = A z   || all-reduce
+                vec_dots(launch_pipe_f2, 5, PH_RECUR_END);               // x, r, w, five dots
+                group_defer(c, 5, PH_RECUR_END);
+                spmv_grp(c, v.w, v.t);                                   // t = A w   || all-reduce
+            }
         } else {
+            if (c->f1_done) die("internal", "replacement step after phase 1 of the same iteration has run");
             vec(launch_p_update);
             spmv_grp(c, v.p, v.s);                                   // s = A p
             spmv_grp(c, v.s, v.z);                                   // z = A s
@@ -692,12 +739,12 @@ struct Driver {
         group_flush(c);
     }
 
-    void iterate(int it, bool force_replace = false)
+    void iterate(int it, bool force_replace = false, bool last = true)
     {
         switch (method) {
         case BICG_BICGSTAB: iter_plain(); break;
         case BICG_CA_BICGSTAB: iter_ca(); break;
-        default: iter_pipe(it, force_replace); break;
+        default: iter_pipe(it, force_replace, last); break;
         }
     }
 
@@ -750,6 +797,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     // are staged by that SpMV and finished by the kernel that consumes them, off the critical path.
     c->wave_mode = method >= BICG_PIPE_BICGSTAB;
     c->grp = bicg_ctx::Group{};
+    c->f1_done = false;
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -776,7 +824,8 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     h.tr_omega = c->trace + c->trace_cap;
     h.tr_beta = c->trace + 2 * (size_t)c->trace_cap;
     h.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
-    BICG_HIP(hipMemcpyAsync(c->S, &h, sizeof h, hipMemcpyHostToDevice, c->sc));
+    for (int i = 0; i < 2; ++i)       // both scalar blocks: the idle one must not carry `done` of an earlier solve
+        BICG_HIP(hipMemcpyAsync(c->Sbuf + i, &h, sizeof h, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->alarm, 0, sizeof(int), c->sc));
     // every work vector starts at zero: defines the reads of p, s, z, v that the reference makes
@@ -826,7 +875,7 @@ bool graph_iteration(bicg_ctx *c, Driver &d)
         if (c->graph_warm[m] < 2) { c->graph_warm[m]++; return false; }
         hipGraph_t g = nullptr;
         if (hipStreamBeginCapture(c->sc, hipStreamCaptureModeThreadLocal) != hipSuccess) { c->graph_mode = 0; return false; }
-        d.iterate(c->it);
+        d.iterate(c->it, false, true);
         const hipError_t e = hipStreamEndCapture(c->sc, &g);
         if (e != hipSuccess || !g) {
             fprintf(stderr, "bicgstab_hip: graph capture failed (%s); continuing with eager launches\n", hipGetErrorString(e));
@@ -859,8 +908,10 @@ int run_iterate(bicg_ctx *c, int nsteps)
             c->adaptive_rr++;
         }
         for (int j = 0; j < chunk; ++j) {
-            if (j == 0 && force) { d.iterate(c->it, true); continue; }
-            if (!graph_iteration(c, d)) d.iterate(c->it + j);
+            // the last iteration before the caller (or the drift check) reads x / r leaves them as the reference would
+            const bool last = j == chunk - 1 && (c->it + chunk >= stop || o.rr_drift > 0.0);
+            if (j == 0 && force) { d.iterate(c->it, true, last); continue; }
+            if (!graph_iteration(c, d)) d.iterate(c->it + j, false, last);
         }
         c->it += chunk;
         fetch_scal(c);
@@ -1625,6 +1676,9 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
     *c->h_alarm = 0;
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
+    // two launches per pipelined iteration pay on a 200 k-row rank (30.8 vs 34.7 us), not on 1.6 M rows (171 vs 164 us)
+    c->fuse_pipe = c->nnz_d < 6000000u;
+    if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
 

@@ -49,7 +49,10 @@ def problem():
     ctx = H.Context(H.single_rank_blocks(A))
     b = ctx.spmv(np.ones(A.rows))
     ctx.close()
-    return A, b, _solve_all(A, b, BICG_GRAPH=0)
+    # BICG_FUSE_PIPE=0: a small single rank runs the pipelined phases in the SpMV epilogues (two launches per iteration),
+    # the host-enqueued transports keep them as separate kernels; same arithmetic per element, but the dot sums are then
+    # associated differently -- bit equality across transports is a statement about identical kernels
+    return A, b, _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=0)
 
 
 def _same(got, ref):
@@ -60,7 +63,7 @@ def _same(got, ref):
 
 def test_graph_replay_single_rank(problem):
     A, b, ref = problem
-    _same(_solve_all(A, b, BICG_GRAPH=1), ref)
+    _same(_solve_all(A, b, BICG_GRAPH=1, BICG_FUSE_PIPE=0), ref)
 
 
 @pytest.mark.parametrize("overlap", [0, 1])
@@ -97,7 +100,19 @@ def test_forced_comm_peer_to_peer_one_rank(problem, monkeypatch):
     try:
         assert H.lib().bicg_comm_enable_p2p() == 0
         assert H.lib().bicg_comm_p2p_active() > 0
-        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=0), ref)
+        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=0, BICG_FUSE_PIPE=0), ref)
     finally:
         monkeypatch.delenv("BICG_FORCE_COMM")
         H.lib().bicg_comm_init_single(0)
+
+
+def test_fused_pipelined_iteration_matches_separate_kernels(problem):
+    """k_spmv_sell_epi (phases in the SpMV epilogues) against the four-kernel iteration: same iteration count, same
+    solution to rounding (only the association of the dot sums differs)"""
+    A, b, ref = problem
+    got = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1)
+    for m in ("pipe_bicgstab", "pipe_bicgstab_rr"):
+        assert abs(got[m][0] - ref[m][0]) <= 1, m
+        assert np.abs(got[m][1] - ref[m][1]).max() <= 1e-9 * np.abs(ref[m][1]).max(), m
+    for m in ("bicgstab", "ca_bicgstab"):          # untouched by the switch
+        assert got[m][0] == ref[m][0] and np.array_equal(got[m][1], ref[m][1])
