@@ -16,6 +16,7 @@ constexpr int kPadEntries = 4;                  // val/col device arrays are pad
 constexpr int kMaxDots = 5;                 // widest dot group (pipelined phase 2)
 constexpr int kRedSlots = 8;                // packed all-reduce buffer, doubles
 constexpr int kPartialStride = 8;           // doubles per block in the partial-sum table (64 B)
+constexpr int kShardLL = 33;                // rows of the LL shard-total table: kShards totals + one row of applied scalars
 constexpr int kShards = 32;                 // arrival counters per dot group (one word saturates at ~88 atomics/us)
 constexpr int kCounterStride = 32;          // unsigneds between shard counters (128 B apart)
 constexpr int kMaxGrid = 2048;              // element-wise kernels: 256 CUs x 8 resident workgroups, grid-stride beyond

@@ -862,7 +862,7 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, in
         return S;
     }
     if (block0 && f.shard_clear)
-        for (unsigned t = tid; t < (unsigned)(kShards * kRedSlots * 2); t += kBlock) f.shard_clear[t] = 0ull;
+        for (unsigned t = tid; t < (unsigned)(kShardLL * kRedSlots * 2); t += kBlock) f.shard_clear[t] = 0ull;
     if (alarm) {           // a peer was lost earlier: nothing will ever arrive
         if (all) {
             __syncthreads();
@@ -1285,7 +1285,16 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
     const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;
     if (bid < nhelp) {
         (void)finish_group(a.S, a.fin, a.fin.roles & (FIN_SHARDS | FIN_PUSH), bid, nhelp, fl, nullptr);
-        if (bid == 0) (void)finish_group(a.S, a.fin, FIN_APPLY, 0u, nhelp, fl, &priv);
+        if (bid == 0) {
+            // ... applies the recurrence, writes the next scalar block, and hands the few scalars the phase needs to the
+            // row workgroups as LL words (row kShards of the shard-total table): one small poll at their epilogue
+            // instead of kShards x n totals, a reduction and the recurrence in every workgroup
+            const Scal *sc = finish_group(a.S, a.fin, FIN_APPLY, 0u, nhelp, fl, &priv);
+            if (threadIdx.x < 4) {
+                const double v = threadIdx.x == 0 ? sc->alpha : threadIdx.x == 1 ? sc->beta : threadIdx.x == 2 ? sc->omega : (double)sc->done;
+                ll_store_agent(a.fin.shard + ((size_t)kShards * kRedSlots + threadIdx.x) * 2, v, a.fin.seq);
+            }
+        }
         return;
     }
     bid -= nhelp; nblocks -= nhelp;
@@ -1301,8 +1310,25 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
 #define EPI_SCALARS()                                                                                     \
     do {                                                                                                  \
         const Scal *sc_ = a.S;                                                                            \
-        if (a.fin.seq) sc_ = finish_group(a.S, a.fin, FIN_APPLY, fin_bid, nblocks, fl, &priv);            \
-        sdone = sc_->done; alpha = sc_->alpha; beta = sc_->beta; omega = sc_->omega;                      \
+        bool got_ = false;                                                                                \
+        if (a.fin.seq && nhelp) {          /* the scalars as published by helper workgroup 0 */           \
+            if (threadIdx.x == 0) fl.missing = 0u;                                                        \
+            __syncthreads();                                                                              \
+            if (threadIdx.x < 4) {                                                                        \
+                double v_;                                                                                \
+                if (ll_try_agent(a.fin.shard + ((size_t)kShards * kRedSlots + threadIdx.x) * 2, a.fin.seq, a.fin.spin_ticks, &v_)) \
+                    fl.sums[threadIdx.x] = v_;                                                            \
+                else atomicOr(&fl.missing, 1u);                                                           \
+            }                                                                                             \
+            __syncthreads();                                                                              \
+            got_ = fl.missing == 0u;                                                                      \
+            if (got_) { alpha = fl.sums[0]; beta = fl.sums[1]; omega = fl.sums[2]; sdone = fl.sums[3] != 0.0 ? 1 : 0; } \
+            __syncthreads();                                                                              \
+        }                                                                                                 \
+        if (!got_) {                       /* staged earlier, nothing open, or helper 0 is late: apply here */ \
+            if (a.fin.seq) sc_ = finish_group(a.S, a.fin, FIN_APPLY, fin_bid, nblocks, fl, &priv);        \
+            sdone = sc_->done; alpha = sc_->alpha; beta = sc_->beta; omega = sc_->omega;                  \
+        }                                                                                                 \
         have = true;                                                                                      \
     } while (0)
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {

@@ -232,8 +232,8 @@ Finish grp_desc(bicg_ctx *c, int roles)
     const bicg_ctx::Group &g = c->grp;
     Finish f{};
     f.partial = c->wpart[g.buf]; f.nparts = g.nparts; f.seq = g.seq;
-    f.shard = c->shard_ll + (size_t)g.buf * kShards * kRedSlots * 2;
-    f.shard_clear = c->shard_ll + (size_t)(g.buf ^ 1) * kShards * kRedSlots * 2;
+    f.shard = c->shard_ll + (size_t)g.buf * kShardLL * kRedSlots * 2;
+    f.shard_clear = c->shard_ll + (size_t)(g.buf ^ 1) * kShardLL * kRedSlots * 2;
     f.n = g.n; f.red_off = g.off; f.phase = g.phase; f.roles = roles;
     f.spin_ticks = c->spin_ticks;
     if (c->p2p) { f.p2p = c->p2p->red_desc(g.mail_seq); f.alarm = c->alarm; }
@@ -1669,8 +1669,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->wpart[i] = dev_alloc<double>((size_t)c->nslots * (kBlock / 64) * kPartialStride);
         BICG_HIP(hipMemset(c->wpart[i], 0, sizeof(double) * (size_t)c->nslots * (kBlock / 64) * kPartialStride));
     }
-    c->shard_ll = dev_alloc<llword>((size_t)2 * kShards * kRedSlots * 2);
-    BICG_HIP(hipMemset(c->shard_ll, 0, sizeof(llword) * 2 * kShards * kRedSlots * 2));
+    c->shard_ll = dev_alloc<llword>((size_t)2 * kShardLL * kRedSlots * 2);
+    BICG_HIP(hipMemset(c->shard_ll, 0, sizeof(llword) * 2 * kShardLL * kRedSlots * 2));
     c->alarm = dev_alloc<int>(1);
     BICG_HIP(hipMemset(c->alarm, 0, sizeof(int)));
     BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
