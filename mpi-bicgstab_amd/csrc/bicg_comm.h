@@ -24,6 +24,11 @@ struct Comm {
     // p2p_enable() has succeeded on every rank: halo values and dot sums are then stored straight
     // into the other GPUs' memory by the producing kernels; the transport below only bootstraps.
     P2p *p2p = nullptr;
+    // ranks of this communicator that drive the SAME GPU as this one (1 in production; > 1 when a one-GPU box
+    // stands in for a node in tests). Kernels that wait for another rank's data hold their workgroup slots while
+    // they wait; with several ranks on one device the launches of all of them must fit on it together, or the
+    // waiting workgroups of one rank keep out the workgroups of the rank they are waiting for (p2p_enable sets it).
+    int ranks_on_device = 1;
     virtual ~Comm();
     virtual const char *name() const = 0;
     // true: collectives are enqueued on `st` and complete in stream order (RCCL);

@@ -359,6 +359,7 @@ void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce re
 
 unsigned sell_grid(uint32_t ngroups, int per_wg); // workgroups launched for ngroups 256-row groups
 unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
+void set_vec_grid_cap(unsigned cap);  // ranks sharing one GPU (tests): fewer workgroups per launch (0 = default)
 unsigned spmv_grid(uint32_t nlist);   // workgroups used by the CSR SpMV for nlist row blocks
 
 }  // namespace bicg

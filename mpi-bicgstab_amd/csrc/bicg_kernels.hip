@@ -748,6 +748,18 @@ __device__ __forceinline__ bool ll_try_agent(const llword *src, unsigned seq, un
     }
 }
 
+// long wait with back-off (a value that another GPU's sums have to arrive for first): polls get rarer the longer it takes
+__device__ __forceinline__ bool ll_wait_agent(const llword *src, unsigned seq, unsigned long long ticks, double *out)
+{
+    const unsigned long long t0 = wall_clock64();
+    for (unsigned spin = 0;; ++spin) {
+        if (ll_peek_agent(src, seq, out)) return true;
+        if (spin < 32u) { __builtin_amdgcn_s_sleep(1); continue; }
+        if (wall_clock64() - t0 > ticks) return false;
+        if (spin < 256u) __builtin_amdgcn_s_sleep(8); else __builtin_amdgcn_s_sleep(64);
+    }
+}
+
 struct FinishLds {
     double vals[kShards * kMaxDots];          // shard totals
     double pv[kRedSlots * kMaxRanksP2p];      // peer-to-peer: every rank's sums
@@ -876,6 +888,26 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, in
         for (unsigned sh = bid; sh < (unsigned)kShards; sh += nblocks) finish_sum_shard(f, sh, L);
     const bool consume = all || (block0 && (roles & (FIN_BLOCK0 | FIN_PUSH)));
     if (!consume) return S;
+    llword *const row = f.shard + (size_t)kShards * kRedSlots * 2;      // the applied scalars as workgroup 0 publishes them
+    if (all && !block0 && f.p2p.seq != 0) {
+        // Sums that cross GPUs are collected by ONE workgroup (the first of the launch: it waits for peers, never for
+        // this launch); everybody else takes the applied scalars from it. Hundreds of workgroups polling the mailbox
+        // in uncached memory would crowd out the very stores they are waiting for.
+        if (tid == 0) L.fail = 0;
+        __syncthreads();
+        if (tid < 4) {
+            double v;
+            if (ll_wait_agent(row + 2 * tid, f.seq, f.p2p.timeout_ticks, &v)) L.sums[tid] = v;
+            else L.fail = 1;
+        }
+        __syncthreads();
+        if (tid == 0) {
+            if (L.fail) { if (f.alarm) *f.alarm = 1; priv->done = 1; priv->comm_error = 1; }
+            else { priv->alpha = L.sums[0]; priv->beta = L.sums[1]; priv->omega = L.sums[2]; priv->done = L.sums[3] != 0.0 ? 1 : 0; }
+        }
+        __syncthreads();
+        return priv;
+    }
     const bool ok = finish_totals(f, roles, L, block0, got0, v0);
     if (!(roles & (FIN_APPLY | FIN_BLOCK0))) return S;
     if (tid == 0) {
@@ -893,6 +925,10 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, in
     }
     if (!all) return S;
     __syncthreads();
+    if (block0 && tid < 4) {
+        const double v = tid == 0 ? priv->alpha : tid == 1 ? priv->beta : tid == 2 ? priv->omega : (double)priv->done;
+        ll_store_agent(row + 2 * tid, v, f.seq);
+    }
     return priv;
 }
 
@@ -1289,11 +1325,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
             // ... applies the recurrence, writes the next scalar block, and hands the few scalars the phase needs to the
             // row workgroups as LL words (row kShards of the shard-total table): one small poll at their epilogue
             // instead of kShards x n totals, a reduction and the recurrence in every workgroup
-            const Scal *sc = finish_group(a.S, a.fin, FIN_APPLY, 0u, nhelp, fl, &priv);
-            if (threadIdx.x < 4) {
-                const double v = threadIdx.x == 0 ? sc->alpha : threadIdx.x == 1 ? sc->beta : threadIdx.x == 2 ? sc->omega : (double)sc->done;
-                ll_store_agent(a.fin.shard + ((size_t)kShards * kRedSlots + threadIdx.x) * 2, v, a.fin.seq);
-            }
+            (void)finish_group(a.S, a.fin, FIN_APPLY, 0u, nhelp, fl, &priv);
         }
         return;
     }
@@ -1311,12 +1343,16 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
     do {                                                                                                  \
         const Scal *sc_ = a.S;                                                                            \
         bool got_ = false;                                                                                \
-        if (a.fin.seq && nhelp) {          /* the scalars as published by helper workgroup 0 */           \
+        if (done) {                        /* converged before this launch: nothing is published, nothing changes */ \
+            got_ = true; sdone = 1;                                                                       \
+        } else if (a.fin.seq && nhelp) {   /* the scalars as published by helper workgroup 0 */           \
             if (threadIdx.x == 0) fl.missing = 0u;                                                        \
             __syncthreads();                                                                              \
             if (threadIdx.x < 4) {                                                                        \
                 double v_;                                                                                \
-                if (ll_try_agent(a.fin.shard + ((size_t)kShards * kRedSlots + threadIdx.x) * 2, a.fin.seq, a.fin.spin_ticks, &v_)) \
+                const llword *w_ = a.fin.shard + ((size_t)kShards * kRedSlots + threadIdx.x) * 2;         \
+                if (a.fin.p2p.seq ? ll_wait_agent(w_, a.fin.seq, a.fin.p2p.timeout_ticks, &v_)            \
+                                  : ll_try_agent(w_, a.fin.seq, a.fin.spin_ticks, &v_))                   \
                     fl.sums[threadIdx.x] = v_;                                                            \
                 else atomicOr(&fl.missing, 1u);                                                           \
             }                                                                                             \
@@ -1881,14 +1917,17 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
 }
 
 static bool env_on(const char *name, bool dflt);
+static unsigned g_vec_grid_cap = 0;
+void set_vec_grid_cap(unsigned cap) { g_vec_grid_cap = cap; }
 unsigned vec_grid(uint32_t n)
 {
     // 256 CUs x 8 resident workgroups, grid-stride beyond (BICG_VEC_GRID: measurement knob, <= kMaxGrid)
-    static const unsigned cap = [] {
+    static const unsigned env_cap = [] {
         const char *v = getenv("BICG_VEC_GRID");
         const int g = v ? atoi(v) : kMaxGrid;
         return (unsigned)(g >= 1 && g <= kMaxGrid ? g : kMaxGrid);
     }();
+    const unsigned cap = g_vec_grid_cap && g_vec_grid_cap < env_cap ? g_vec_grid_cap : env_cap;
     unsigned g = ((n >> 1) + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
     if (g > cap) g = cap;

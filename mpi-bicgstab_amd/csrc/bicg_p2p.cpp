@@ -152,6 +152,18 @@ int p2p_enable(Comm *c)
     if (strcmp(c->name(), "single") == 0) return 0;     // nothing to exchange
     BICG_HIP(hipSetDevice(c->device));
 
+    {   // who shares my GPU? (host name hash, device ordinal) of every rank
+        const int P = c->nranks;
+        struct Where { unsigned long long host; int device; int pad; } mine = {host_hash(), c->device, 0};
+        std::vector<Where> out(P, mine), in(P);
+        std::vector<int> cnt(P, (int)sizeof(Where)), dsp(P);
+        for (int p = 0; p < P; ++p) dsp[p] = p * (int)sizeof(Where);
+        c->alltoallv_host(out.data(), cnt.data(), dsp.data(), in.data(), cnt.data(), dsp.data());
+        in[c->rank] = mine;
+        int same = 0;
+        for (int p = 0; p < P; ++p) same += in[p].host == mine.host && in[p].device == mine.device;
+        c->ranks_on_device = same > 0 ? same : 1;
+    }
     P2p *t = new P2p;
     t->comm = c; t->rank = c->rank; t->nranks = c->nranks;
     // a rank may legitimately arrive late at a collective solver call (I/O, printing): wait long

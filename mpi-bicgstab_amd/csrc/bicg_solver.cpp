@@ -121,6 +121,7 @@ struct bicg_ctx {
     bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues -- chosen for ranks whose
                                  // launches are latency-bound (< 6 M local non-zeros; BICG_FUSE_PIPE=0/1 overrides)
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
+    unsigned wg_cap = 0;         // ranks sharing this GPU (tests): workgroups per launch that may wait for another rank
     double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
     llword *shard_ll = nullptr;  // 2 x [kShards][kRedSlots][2], alternating like wpart
     int *alarm = nullptr, *h_alarm = nullptr;
@@ -416,6 +417,13 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     };
 
     if (epi && !(c->glist_all && c->nblk == 0 && (c->single() || fused))) die("internal", "SpMV epilogue on a multi-launch SpMV");
+    if (epi && c->wg_cap) {      // every row workgroup of this launch waits for the scalars: all ranks' launches must fit on the GPU
+        const unsigned ng = c->ng_int + c->ng_bnd;
+        a.groups_per_wg = std::max<int>(a.groups_per_wg, (int)((ng + c->wg_cap - 1) / c->wg_cap));
+        red.expected = sell_grid(ng, a.groups_per_wg) + g_ci;
+        a.red.expected = red.expected;
+        c->grp.nparts = red.expected * (kBlock / 64);
+    }
     if (c->single()) {
         if (epi) {
             a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
@@ -1437,6 +1445,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             return nullptr;
         }
         c->overlap = total / (uint64_t)P >= 6000000u;
+        // two launches per pipelined iteration pay on a 200 k-row rank (27.7 vs 33.9 us; 400 k rows: 47.4 vs 49.8), not
+        // on 800 k rows (86.8 vs 81.4) or 1.6 M (175 vs 163 us). Like the enqueue mode this changes the sequence of
+        // exchanges, so it is decided from the average over all ranks, never from the local block alone.
+        c->fuse_pipe = total / (uint64_t)P < 6000000u;
     }
     if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
@@ -1675,9 +1687,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     BICG_HIP(hipMemset(c->alarm, 0, sizeof(int)));
     BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
     *c->h_alarm = 0;
+    if (comm->ranks_on_device > 1) {
+        // one-GPU box standing in for a node: 1024 = 256 CUs x 4 resident workgroups of the largest kernels
+        c->wg_cap = 1024u / (unsigned)(comm->ranks_on_device + 1);
+        set_vec_grid_cap(c->wg_cap);
+    }
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
-    // two launches per pipelined iteration pay on a 200 k-row rank (30.8 vs 34.7 us), not on 1.6 M rows (171 vs 164 us)
-    c->fuse_pipe = c->nnz_d < 6000000u;
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
