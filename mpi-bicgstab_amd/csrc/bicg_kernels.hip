@@ -1465,8 +1465,10 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 // A wavefront works on 8 rows at a time, 8 lanes per row, each lane owning TWO columns: the load of
 // the X values of one matrix entry is then one instruction over 8 fully used lines (a first version
 // with lane = row touched 64 lines per instruction, 16 bytes of each: 0.56 ms on Transport, bound by
-// the vector L1's tag rate). The 8 lanes of a row read the same (val, col) word -- one broadcast
-// access. Every column of every row is accumulated in stored order like mult() (reference
+// the vector L1's tag rate). val / col are read from memory once per wavefront, lane = row, fully
+// coalesced, into LDS; the 8 lanes of a row then take them from there with broadcast reads (a
+// version in which they loaded the same word from memory issued 8 x the load instructions of the
+// SpMV: 469 us). Every column of every row is accumulated in stored order like mult() (reference
 // src/matrix.c:506-515), so each Y_j is bit-identical to the SpMV of that column. With b given,
 // || b - Y_j ||^2 is fused (workgroup sums go to partial[wg][col], k_colsum adds them in a fixed
 // order) and Y is never written.
@@ -1475,10 +1477,14 @@ template <bool C16, bool OFFD>
 __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
 {
     constexpr int NB = kSpmmCols;
+    constexpr int KC = 16;                                   // matrix entries per row staged in LDS at a time
     static_assert(NB == 16, "8 lanes per row x 2 columns per lane");
+    struct Ent { double v; uint32_t off, pad; };            // value and byte offset of the row of X it multiplies
+    __shared__ Ent se[kBlock / 64][KC][kSliceRows];          // this wavefront's slice, entry-major: read from memory ONCE,
+                                                             // lane = row, fully coalesced
     __shared__ double sm[(kBlock / 64) * NB];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const unsigned sub = lane >> 3, cp = lane & 7u;          // row within the 8-row batch, column pair
+    const unsigned sub = lane >> 3, cp = lane & 7u;          // row within an 8-row batch, column pair
     // XCD-contiguous mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
     // giving XCD x the x-th eighth of the row groups makes one L2 fetch (almost) every line of X once
     // instead of all eight fetching all of it (16 vectors: 8 x 205 MB on Transport)
@@ -1496,36 +1502,70 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
             if (C16) base16 = a.sell.slice_base16[slice];
         }
         const double sg0 = a.sigma ? a.sigma[2 * cp] : 0.0, sg1 = a.sigma ? a.sigma[2 * cp + 1] : 0.0;
-        for (unsigned batch = 0; batch < kSliceRows / 8; ++batch) {
-            const unsigned rl = batch * 8 + sub;                          // row within the slice
-            const uint32_t row = slice * kSliceRows + rl;
-            const bool live = row < a.nrows;
-            const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
-            const uint32_t rb = live ? row : 0u;
-            double s0 = 0.0, s1 = 0.0;
-            constexpr int U = 4;                                          // entries in flight (one packed column quad)
-            for (uint32_t k0 = 0; k0 < len; k0 += U) {
-                uint32_t c[U];
-                double v[U];
-                if (C16) {
-                    const i16x4 dq = *(reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)(k0 / 4) * kSliceRows + rl));
-                    c[0] = rb + (int)dq.x; c[1] = rb + (int)dq.y; c[2] = rb + (int)dq.z; c[3] = rb + (int)dq.w;
+        const char *const xb = reinterpret_cast<const char *>(a.xt) + 16u * cp;     // this lane's two columns
+        // stage role: lane = row of the slice
+        const uint32_t srow = slice * kSliceRows + lane;
+        const uint32_t srb = srow < a.nrows ? srow : 0u;
+        // shortest row of the slice: entries below it need no per-row test (the usual case is all of them)
+        uint32_t minlen = srow < a.nrows ? a.dptr[srow + 1] - a.dptr[srow] : 0u;
+#pragma unroll
+        for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(minlen, off, 64); minlen = o < minlen ? o : minlen; }
+        // compute role: 8 batches of 8 rows; this lane's row in batch bt is bt * 8 + sub
+        double s0[kSliceRows / 8], s1[kSliceRows / 8];
+        uint32_t mylen[kSliceRows / 8];
+#pragma unroll
+        for (int bt = 0; bt < kSliceRows / 8; ++bt) {
+            const uint32_t row = slice * kSliceRows + bt * 8 + sub;
+            s0[bt] = 0.0; s1[bt] = 0.0;
+            mylen[bt] = row < a.nrows ? a.dptr[row + 1] - a.dptr[row] : 0u;
+        }
+        for (uint32_t k0 = 0; k0 < len; k0 += KC) {
+            const uint32_t kn = len - k0 < (uint32_t)KC ? len - k0 : (uint32_t)KC;
+            // ---- stage: coalesced loads, 512 bytes of val per instruction
+            if (C16) {
+                for (uint32_t q = 0; 4 * q < kn; ++q) {
+                    const i16x4 dq = *(reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)(k0 / 4 + q) * kSliceRows + lane));
+                    se[wave][4 * q + 0][lane].off = (srb + (int)dq.x) * (NB * 8u); se[wave][4 * q + 1][lane].off = (srb + (int)dq.y) * (NB * 8u);
+                    se[wave][4 * q + 2][lane].off = (srb + (int)dq.z) * (NB * 8u); se[wave][4 * q + 3][lane].off = (srb + (int)dq.w) * (NB * 8u);
                 }
-#pragma unroll
-                for (int e = 0; e < U; ++e) {
-                    const bool ok = k0 + e < len;
-                    const uint32_t j = base + (k0 + e) * kSliceRows + rl;
-                    if (!C16) c[e] = ok ? a.sell.col[j] : 0u;
-                    v[e] = ok ? a.sell.val[j] : 0.0;
-                }
-                f64x2 x[U];
-#pragma unroll
-                for (int e = 0; e < U; ++e) x[e] = *reinterpret_cast<const f64x2 *>(a.xt + (size_t)c[e] * NB + 2 * cp);
-#pragma unroll
-                for (int e = 0; e < U; ++e)
-                    if (k0 + e < mylen) { s0 += v[e] * x[e].x; s1 += v[e] * x[e].y; }        // stored order; padding never added
             }
-            double y0 = 0.0 + s0, y1 = 0.0 + s1;                          // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+            for (uint32_t e = 0; e < kn; ++e) {
+                const uint32_t j = base + (k0 + e) * kSliceRows + lane;
+                if (!C16) se[wave][e][lane].off = a.sell.col[j] * (NB * 8u);
+                se[wave][e][lane].v = a.sell.val[j];
+            }
+            __builtin_amdgcn_wave_barrier();      // same wavefront writes and reads: program order of its LDS operations is enough
+            // ---- multiply: per batch and entry one broadcast LDS read of {val, offset} and ONE load of 8 full lines
+            // of X; the 8 batches are independent, their loads are in flight together. Entries below the slice's
+            // shortest row take the path without per-row tests (the kernel is bound by instruction issue).
+            const uint32_t nfast = k0 >= minlen ? 0u : (minlen - k0 < kn ? minlen - k0 : kn);
+            for (uint32_t e = 0; e < nfast; ++e) {
+                f64x2 x[kSliceRows / 8];
+                double v[kSliceRows / 8];
+#pragma unroll
+                for (int bt = 0; bt < kSliceRows / 8; ++bt) {
+                    const Ent en = se[wave][e][bt * 8 + sub];
+                    v[bt] = en.v;
+                    x[bt] = *reinterpret_cast<const f64x2 *>(xb + en.off);
+                }
+#pragma unroll
+                for (int bt = 0; bt < kSliceRows / 8; ++bt) { s0[bt] += v[bt] * x[bt].x; s1[bt] += v[bt] * x[bt].y; }     // stored order
+            }
+            for (uint32_t e = nfast; e < kn; ++e) {
+#pragma unroll
+                for (int bt = 0; bt < kSliceRows / 8; ++bt) {
+                    const Ent en = se[wave][e][bt * 8 + sub];
+                    const f64x2 x = *reinterpret_cast<const f64x2 *>(xb + en.off);
+                    if (k0 + e < mylen[bt]) { s0[bt] += en.v * x.x; s1[bt] += en.v * x.y; }                                 // padding never added
+                }
+            }
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int bt = 0; bt < kSliceRows / 8; ++bt) {
+            const uint32_t row = slice * kSliceRows + bt * 8 + sub;
+            const bool live = row < a.nrows;
+            double y0 = 0.0 + s0[bt], y1 = 0.0 + s1[bt];                  // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
             if (OFFD && live) {
                 double o0 = 0.0, o1 = 0.0;
                 for (uint32_t k = a.offd.ptr[row]; k < a.offd.ptr[row + 1]; ++k) {
@@ -1563,47 +1603,54 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
     }
 }
 
-// out[col] = sum over workgroups of partial[wg][col], fixed order
+// out[col] = sum over workgroups of partial[wg][col], fixed order; one workgroup per column
 __global__ void __launch_bounds__(kBlock) k_colsum(const double *partial, unsigned nwg, double *out)
 {
     constexpr int NB = kSpmmCols;
-    __shared__ double sm[kBlock];
-    const unsigned col = threadIdx.x % NB, part = threadIdx.x / NB, nparts = kBlock / NB;
-    double t = 0.0;
-    for (unsigned w = part; w < nwg; w += nparts) t += partial[(size_t)w * NB + col];
-    sm[threadIdx.x] = t;
-    __syncthreads();
-    if (threadIdx.x < NB) {
-        double tot = 0.0;
-        for (unsigned p2 = 0; p2 < nparts; ++p2) tot += sm[p2 * NB + threadIdx.x];
-        out[threadIdx.x] = tot;
-    }
+    __shared__ double sm[5];
+    const unsigned col = blockIdx.x;
+    double t[1] = {0.0};
+    for (unsigned w = threadIdx.x; w < nwg; w += kBlock) t[0] += partial[(size_t)w * NB + col];
+    block_sum<1>(t, sm);
+    if (threadIdx.x == 0) out[col] = t[0];
 }
 
-// shift-major vectors x[j * stride + i] -> row-major xt[i * kSpmmCols + j] (columns >= nvec are zero)
+// shift-major vectors x[j * stride + i] <-> row-major xt[i * kSpmmCols + j] (columns >= nvec are zero), a tile of
+// 256 rows through LDS so that both the reads and the writes are coalesced
 __global__ void __launch_bounds__(kBlock) k_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt)
 {
     constexpr int NB = kSpmmCols;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    double v[NB];
+    __shared__ double tile[kBlock][NB + 1];
+    const uint32_t r0 = blockIdx.x * kBlock, i = r0 + threadIdx.x;
 #pragma unroll
-    for (int j = 0; j < NB; ++j) v[j] = j < nvec ? x[(size_t)j * stride + i] : 0.0;
-    f64x2 *dst = reinterpret_cast<f64x2 *>(xt + (size_t)i * NB);
-#pragma unroll
-    for (int q = 0; q < NB / 2; ++q) { f64x2 t; t.x = v[2 * q]; t.y = v[2 * q + 1]; dst[q] = t; }
+    for (int j = 0; j < NB; ++j) tile[threadIdx.x][j] = (j < nvec && i < n) ? x[(size_t)j * stride + i] : 0.0;
+    __syncthreads();
+    // piece q of the tile = 16 bytes: row q / 8, columns 2 (q % 8), +1; consecutive threads write consecutive pieces
+    for (unsigned q = threadIdx.x; q < kBlock * (NB / 2); q += kBlock) {
+        const unsigned row = q / (NB / 2), c2 = (q % (NB / 2)) * 2;
+        if (r0 + row < n) {
+            f64x2 t; t.x = tile[row][c2]; t.y = tile[row][c2 + 1];
+            *reinterpret_cast<f64x2 *>(xt + (size_t)(r0 + row) * NB + c2) = t;
+        }
+    }
 }
 __global__ void __launch_bounds__(kBlock) k_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y)
 {
     constexpr int NB = kSpmmCols;
-    const uint32_t i = blockIdx.x * kBlock + threadIdx.x;
-    if (i >= n) return;
-    const f64x2 *src = reinterpret_cast<const f64x2 *>(yt + (size_t)i * NB);
+    __shared__ double tile[kBlock][NB + 1];
+    const uint32_t r0 = blockIdx.x * kBlock, i = r0 + threadIdx.x;
+    for (unsigned q = threadIdx.x; q < kBlock * (NB / 2); q += kBlock) {
+        const unsigned row = q / (NB / 2), c2 = (q % (NB / 2)) * 2;
+        if (r0 + row < n) {
+            const f64x2 t = *reinterpret_cast<const f64x2 *>(yt + (size_t)(r0 + row) * NB + c2);
+            tile[row][c2] = t.x; tile[row][c2 + 1] = t.y;
+        }
+    }
+    __syncthreads();
+    if (i < n) {
 #pragma unroll
-    for (int q = 0; q < NB / 2; ++q) {
-        const f64x2 t = src[q];
-        if (2 * q < nvec) y[(size_t)(2 * q) * stride + i] = t.x;
-        if (2 * q + 1 < nvec) y[(size_t)(2 * q + 1) * stride + i] = t.y;
+        for (int j = 0; j < NB; ++j)
+            if (j < nvec) y[(size_t)j * stride + i] = tile[threadIdx.x][j];
     }
 }
 
@@ -1623,7 +1670,7 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_colsum, dim3(1), dim3(kBlock), 0, st, partial, nwg, out);
+    hipLaunchKernelGGL(k_colsum, dim3(kSpmmCols), dim3(kBlock), 0, st, partial, nwg, out);
 }
 void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st)
 {

@@ -576,7 +576,8 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     if (with_b) launch_colsum(c->mm_part, spmm_grid(a.ngroups, a.xcd_map != 0), c->mm_out, c->sc);
 }
 
-bool spmm_possible(const bicg_ctx *c) { return c->glist_all && c->nblk == 0 && c->sell_entries > 0; }
+// every row on the sliced-ELL path, and 32-bit byte offsets into the row-major X (128 B per row) suffice
+bool spmm_possible(const bicg_ctx *c) { return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && (uint64_t)c->stride < (1ull << 25); }
 
 void spmm_buffers(bicg_ctx *c)
 {
