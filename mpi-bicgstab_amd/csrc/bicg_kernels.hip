@@ -1302,7 +1302,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 // vector (a.epi.y) because w is this SpMV's input while the epilogue of EPI = 2 produces y.
 // ------------------------------------------------------------------------------------------
 template <int EPI, bool OFFD, bool NT, bool C16, bool LL>
-__global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_spmv_sell_epi(SpmvArgs a)
 {
     constexpr int ND = EPI == 1 ? 5 : 2;
     const int done = a.S->done;
@@ -1368,18 +1368,17 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_epi(SpmvArgs a)
         have = true;                                                                                      \
     } while (0)
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
-        // The phase's inputs (values of this lane's own row) are requested BEFORE the row product: on a small rank
-        // a launch is as long as its longest chain of dependent memory round trips, and these loads depend on nothing.
-        // For the same reason the row product keeps 16 entries in flight: a Transport row (15 entries) is one batch.
-        const uint32_t row0 = (a.glist ? a.glist[gi] : gi) * kGroupRows + threadIdx.x;
-        const uint32_t rr_ = row0 < a.nrows ? row0 : 0u;
-        double in0, in1, in2, in3, in4, in5, in6 = 0.0, in7 = 0.0;
-        if (EPI == 1) { in0 = e.r[rr_]; in1 = e.y[rr_]; in2 = e.x[rr_]; in3 = e.p[rr_]; in4 = e.t[rr_]; in5 = e.rh[rr_]; in6 = e.s[rr_]; in7 = e.z[rr_]; }
-        else { in0 = e.r[rr_]; in1 = e.w[rr_]; in2 = e.s[rr_]; in3 = e.z[rr_]; in4 = e.p[rr_]; in5 = e.v[rr_]; }
         uint32_t row;
         bool live;
         const double yi = sell_row<OFFD, NT, C16, LL, 8>(a, gi, done, row, live, ll_failed);
         if (live && !done) a.y[row] = yi;
+        // The phase's inputs (values of this lane's own row) are requested right after the row product and BEFORE the
+        // scalars are waited for: their round trip and the scalar poll's are one. (Requested before the row product
+        // they sit in front of its loads -- loads return in issue order -- and delay every batch: BICG_EPI_EARLY.)
+        const uint32_t rr_ = live ? row : 0u;
+        double in0, in1, in2, in3, in4, in5, in6 = 0.0, in7 = 0.0;
+        if (EPI == 1) { in0 = e.r[rr_]; in1 = e.y[rr_]; in2 = e.x[rr_]; in3 = e.p[rr_]; in4 = e.t[rr_]; in5 = e.rh[rr_]; in6 = e.s[rr_]; in7 = e.z[rr_]; }
+        else { in0 = e.r[rr_]; in1 = e.w[rr_]; in2 = e.s[rr_]; in3 = e.z[rr_]; in4 = e.p[rr_]; in5 = e.v[rr_]; }
         if (!have) EPI_SCALARS();
         if (EPI == 1) {
             const double q = in0, y = in1, x0 = in2, p0 = in3, t0 = in4, h = in5, s0 = in6, z0 = in7;

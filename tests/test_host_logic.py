@@ -193,3 +193,9 @@ def test_hot_kernels_stay_lean():
     for k in vec:
         r = kernels[k]
         assert r["VGPRs"] <= 96 and r["Occupancy [waves/SIMD]"] >= 5 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
+    # the fused pipelined iteration: a 200k-row rank is 783 workgroups x 4 wavefronts = 3.06 per SIMD, so a
+    # fifth VGPR over 128 (occupancy 3) buys a second round of workgroups: +5 us per iteration, measured
+    epi = [k for k in kernels if "k_spmv_sell_epi" in k]
+    assert len(epi) >= 16
+    for k in epi:
+        assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
