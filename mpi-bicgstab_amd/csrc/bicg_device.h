@@ -209,7 +209,11 @@ struct SellDev {
     // slice_base16; null when some |col - row| >= 32768
     const short    *col16;
     const uint32_t *slice_base16;
+    // jagged slices (ragged rows): step k of a slice stores the entries of the rows longer than k only, in lane
+    // order; slice_base counts entries, col16 is indexed like val (no quads), slice_base16 is unused
+    int jag;
 };
+enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3 };
 
 // Peer-to-peer halo exchange folded into the sliced-ELL SpMV launch: the first `npush` workgroups
 // store this rank's send list into the landing rings of the ranks that need it, the others

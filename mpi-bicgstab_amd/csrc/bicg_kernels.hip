@@ -1154,9 +1154,10 @@ template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double o
 
 // y_i of this lane's row of list entry gi (diag part in stored order, then the offd part, then the shift):
 // the body shared by the SpMV kernel and the SpMV-with-epilogue kernel below
-template <bool OFFD, bool NT, bool C16, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
+template <bool OFFD, bool NT, int LAY, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
 __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed)
 {
+    constexpr bool C16 = (LAY & 1) != 0, JAG = LAY >= LAY_JAG32;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const double *__restrict__ x = a.x;
     const unsigned g = a.glist ? a.glist[gi] : gi;
@@ -1167,7 +1168,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
     uint32_t base = 0u, len = 0u, base16 = 0u;
     if (slice * kSliceRows < a.nrows) {
         base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
-        if (C16) base16 = a.sell.slice_base16[slice];
+        if (C16 && !JAG) base16 = a.sell.slice_base16[slice];
     }
     uint32_t mylen = 0u, oa = 0u, ob = 0u;
     if (live) {
@@ -1176,7 +1177,43 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
     }
 
     double sum = 0.0;
-    for (uint32_t k0 = 0; k0 < len; k0 += U) {
+    if (JAG) {
+        // Jagged slice: step k of the slice holds the entries of the lanes whose row has more than k entries, and
+        // only those, in lane order -- no padding is stored or read. A lane's entry is at (entries of the earlier
+        // steps) + (live lanes below it): a ballot, a population count and mbcnt, all from the row lengths, so
+        // every load of a batch is still issued back to back. With equal row lengths this IS the padded layout.
+        const uint32_t rb = live ? row : 0u;
+        uint32_t pos = base;                                  // wave-uniform: first entry of step k
+        for (uint32_t k0 = 0; k0 < len; k0 += U) {
+            uint32_t c[U];
+            double   v[U];
+            bool     mine[U];
+            // The val / col loads are predicated per lane, and NOTHING that depends on a loaded value sits inside
+            // the predicated block (the compiler waits for a load before the block ends otherwise: one round trip per
+            // entry instead of one per batch). The gathers are unpredicated for the same reason: a lane whose row
+            // has ended reads x of its own row.
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                mine[e] = k0 + e < mylen;
+                const unsigned long long m = __ballot(mine[e]);
+                const uint32_t j = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                pos += (uint32_t)__builtin_popcountll(m);
+                c[e] = 0u; v[e] = 0.0;
+                if (mine[e]) {
+                    if (C16) c[e] = (uint32_t)(int)(NT ? __builtin_nontemporal_load(a.sell.col16 + j) : a.sell.col16[j]);
+                    else c[e] = NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j];
+                    v[e] = NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j];
+                }
+            }
+            double xv[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) xv[e] = x[mine[e] ? (C16 ? rb + c[e] : c[e]) : rb];
+#pragma unroll
+            for (int e = 0; e < U; ++e)
+                if (mine[e]) sum += v[e] * xv[e];             // stored order
+        }
+    }
+    for (uint32_t k0 = 0; !JAG && k0 < len; k0 += U) {
         uint32_t c[U];
         double   v[U];
         if (C16) {
@@ -1240,7 +1277,7 @@ __device__ __forceinline__ void sell_halo_push(const SpmvArgs &a, unsigned bid, 
                  a.x[a.ll.send_idx[i]], a.ll.seq);
 }
 
-template <int NDOT, bool OFFD, bool NT, bool C16, bool LL, int MODE>
+template <int NDOT, bool OFFD, bool NT, int LAY, bool LL, int MODE>
 __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
@@ -1272,7 +1309,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
         uint32_t row;
         bool live;
-        const double yi = sell_row<OFFD, NT, C16, LL>(a, gi, done, row, live, ll_failed);
+        const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed);
         if (live && !done) a.y[row] = yi;
         if (NDOT >= 1 && live) {
             const double ume = a.u[row];
@@ -1301,7 +1338,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
 // The phase's expressions are those of FPipe1 / FPipe2, operation for operation; y lives in its own
 // vector (a.epi.y) because w is this SpMV's input while the epilogue of EPI = 2 produces y.
 // ------------------------------------------------------------------------------------------
-template <int EPI, bool OFFD, bool NT, bool C16, bool LL>
+template <int EPI, bool OFFD, bool NT, int LAY, bool LL>
 __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_spmv_sell_epi(SpmvArgs a)
 {
     constexpr int ND = EPI == 1 ? 5 : 2;
@@ -1370,7 +1407,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
         uint32_t row;
         bool live;
-        const double yi = sell_row<OFFD, NT, C16, LL, 8>(a, gi, done, row, live, ll_failed);
+        const double yi = sell_row<OFFD, NT, LAY, LL, 8>(a, gi, done, row, live, ll_failed);
         if (live && !done) a.y[row] = yi;
         // The phase's inputs (values of this lane's own row) are requested right after the row product and BEFORE the
         // scalars are waited for: their round trip and the scalar poll's are one. (Requested before the row product
@@ -1414,6 +1451,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + bid);
 }
 
+static inline int sell_layout(const SellDev &d) { return (d.jag ? LAY_JAG32 : LAY_PAD32) + (d.col16 ? 1 : 0); }
+
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
 unsigned sell_grid(uint32_t ngroups, int per_wg)
 {
@@ -1429,16 +1468,21 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 {
     if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
     dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u)), b(kBlock);
+#define SELL_LAY(ND, OF, NTV, LLV, MD)                                                             \
+    do {                                                                                           \
+        if (lay == LAY_PAD16) launch_timed(k_spmv_sell<ND, OF, NTV, LAY_PAD16, LLV, MD>, g, b, st, e0, e1, a);      \
+        else if (lay == LAY_JAG32) launch_timed(k_spmv_sell<ND, OF, NTV, LAY_JAG32, LLV, MD>, g, b, st, e0, e1, a); \
+        else if (lay == LAY_JAG16) launch_timed(k_spmv_sell<ND, OF, NTV, LAY_JAG16, LLV, MD>, g, b, st, e0, e1, a); \
+        else launch_timed(k_spmv_sell<ND, OF, NTV, LAY_PAD32, LLV, MD>, g, b, st, e0, e1, a);                       \
+    } while (0)
 #define SELL_MODE(ND, OF, LLV, MD)                                                                 \
     do {                                                                                           \
-        if (nt && c16) launch_timed(k_spmv_sell<ND, OF, true, true, LLV, MD>, g, b, st, e0, e1, a);          \
-        else if (nt) launch_timed(k_spmv_sell<ND, OF, true, false, LLV, MD>, g, b, st, e0, e1, a);           \
-        else if (c16) launch_timed(k_spmv_sell<ND, OF, false, true, LLV, MD>, g, b, st, e0, e1, a);          \
-        else launch_timed(k_spmv_sell<ND, OF, false, false, LLV, MD>, g, b, st, e0, e1, a);                  \
+        if (nt) SELL_LAY(ND, OF, true, LLV, MD); else SELL_LAY(ND, OF, false, LLV, MD);            \
     } while (0)
 #define SELL_CASE(ND, OF, LLV)                                                                     \
     do {                                                                                           \
-        const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;                                  \
+        const bool nt = a.nt != 0;                                                                 \
+        const int lay = sell_layout(a.sell);                                                       \
         const int mode = red_mode(a.red, a.fin, (ND) > 0);                                         \
         constexpr int HV = (ND) > 0 ? RED_TICKET_HEAVY : RED_TICKET;                               \
         if (mode == RED_WAVE) SELL_MODE(ND, OF, LLV, RED_WAVE);                                    \
@@ -1454,6 +1498,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     }
 #undef SELL_CASE
 #undef SELL_MODE
+#undef SELL_LAY
     return true;
 }
 
@@ -1685,13 +1730,18 @@ bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_
     if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
     const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;      // dedicated shard summers
     dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u) + nhelp), b(kBlock);
-    const bool nt = a.nt != 0, c16 = a.sell.col16 != nullptr;
+    const bool nt = a.nt != 0;
+    const int lay = sell_layout(a.sell);
+#define EPI_LAY(EP, OF, NTV, LLV)                                                                               \
+    do {                                                                                                        \
+        if (lay == LAY_PAD16) launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_PAD16, LLV>, g, b, st, e0, e1, a);       \
+        else if (lay == LAY_JAG32) launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_JAG32, LLV>, g, b, st, e0, e1, a);  \
+        else if (lay == LAY_JAG16) launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_JAG16, LLV>, g, b, st, e0, e1, a);  \
+        else launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_PAD32, LLV>, g, b, st, e0, e1, a);                        \
+    } while (0)
 #define EPI_CASE(EP, OF, LLV)                                                                                   \
     do {                                                                                                        \
-        if (nt && c16) launch_timed(k_spmv_sell_epi<EP, OF, true, true, LLV>, g, b, st, e0, e1, a);             \
-        else if (nt) launch_timed(k_spmv_sell_epi<EP, OF, true, false, LLV>, g, b, st, e0, e1, a);              \
-        else if (c16) launch_timed(k_spmv_sell_epi<EP, OF, false, true, LLV>, g, b, st, e0, e1, a);             \
-        else launch_timed(k_spmv_sell_epi<EP, OF, false, false, LLV>, g, b, st, e0, e1, a);                     \
+        if (nt) EPI_LAY(EP, OF, true, LLV); else EPI_LAY(EP, OF, false, LLV);                                   \
     } while (0)
     if (epi == 1) {
         if (fused_halo) EPI_CASE(1, true, true); else if (with_offd) EPI_CASE(1, true, false); else EPI_CASE(1, false, false);
@@ -1699,6 +1749,7 @@ bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_
         if (fused_halo) EPI_CASE(2, true, true); else if (with_offd) EPI_CASE(2, true, false); else EPI_CASE(2, false, false);
     }
 #undef EPI_CASE
+#undef EPI_LAY
     return true;
 }
 

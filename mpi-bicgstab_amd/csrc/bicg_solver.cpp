@@ -74,6 +74,7 @@ struct bicg_ctx {
     double *s_val = nullptr;
     uint32_t *s_col = nullptr, *s_base = nullptr, *s_len = nullptr, *s_base16 = nullptr;
     short *s_col16 = nullptr;
+    bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
     uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
     uint64_t sell_entries = 0, sell_nnz = 0;
@@ -118,6 +119,9 @@ struct bicg_ctx {
         int n = 0, off = 0, phase = 0, buf = 0;
     } grp;
     bool wave_mode = false;      // this call uses consumer-side finish (run_begin); false: ticket reductions
+    bool spmm_ok = false;        // spmm_possible() on every rank (the SpMM exchanges the halos of all its vectors at once)
+    bool fuse_plan_ok = false;   // every row on the sliced-ELL path and one launch per SpMV -- ON EVERY RANK (the fused and the
+                                 // separate flow exchange their dot groups differently: the choice is collective)
     bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues -- chosen for ranks whose
                                  // launches are latency-bound (< 6 M local non-zeros; BICG_FUSE_PIPE=0/1 overrides)
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
@@ -371,7 +375,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     SpmvArgs a;
     a.fin = fin;
     a.epi = c->v;
-    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0};
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -560,7 +564,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
     launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
-    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0};
     a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.nrows = c->n_loc; a.ngroups = c->ng_int + c->ng_bnd;
     a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
@@ -577,7 +581,10 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
 }
 
 // every row on the sliced-ELL path, and 32-bit byte offsets into the row-major X (128 B per row) suffice
-bool spmm_possible(const bicg_ctx *c) { return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && (uint64_t)c->stride < (1ull << 25); }
+bool spmm_possible(const bicg_ctx *c)
+{
+    return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && !c->sell_jag && (uint64_t)c->stride < (1ull << 25);
+}
 
 void spmm_buffers(bicg_ctx *c)
 {
@@ -699,7 +706,7 @@ struct Driver {
     // SpMV launch per product (one rank, or the peer-to-peer exchange folded into the launch)
     bool fused() const
     {
-        return c->fuse_pipe && c->wave_mode && !hosted(c) && c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused));
+        return c->fuse_pipe && c->wave_mode && !hosted(c) && c->fuse_plan_ok;
     }
 
     // last: the caller looks at x / r after this iteration (end of a run_iterate call, adaptive replacement check):
@@ -1482,11 +1489,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         for (int p = 1; p < P; ++p) c->sdsp[p] = c->sdsp[p - 1] + c->scnt[p - 1];
     }
 
-    // ---- SpMV plan. Rows are cut into groups of 256 (4 slices of 64 = one workgroup). A group goes
-    // to the sliced-ELL kernel when padding its slices to their longest row costs < 25 % extra
-    // entries; the other groups (ragged or very long rows) are covered by CSR row blocks of whole
-    // rows with <= kRowBlockNnz non-zeros. Either kind is "boundary" when one of its rows has offd
-    // entries (it then runs after the halo has landed).
+    // ---- SpMV plan. Rows are cut into groups of 256 (4 slices of 64 rows = one workgroup, lane = row).
+    // Two layouts of a slice: PADDED to its longest row (banded matrices: nothing to pad, 8-byte loads of four
+    // 16-bit column offsets) or JAGGED (ragged rows: step k stores the rows longer than k only; exactly the CSR's
+    // bytes, lane = row kept). Jagged is chosen for the whole block when padding would add > 2 % entries. Groups
+    // with a very long row go to the CSR row-block kernel (strided workgroup reduction of one row). Either kind
+    // is "boundary" when one of its rows has offd entries (it then runs after the halo has landed).
     const uint32_t nrows = c->n_loc;
     const uint32_t nslices = (nrows + kSliceRows - 1) / kSliceRows, ngroups = (nrows + kGroupRows - 1) / kGroupRows;
     std::vector<uint32_t> slice_len(nslices, 0u), slice_base(nslices, 0u);
@@ -1495,9 +1503,26 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     std::vector<uint32_t> gl_int, gl_bnd;
     std::vector<uint4> bint, bbnd;
     std::vector<char> group_is_sell(ngroups, 0);
-    auto group_fits = [&](uint32_t g, uint64_t *padded_out) {
+    const uint32_t jag_max_row = std::max<uint64_t>(64, nrows ? 4 * (uint64_t)c->nnz_d / nrows : 0);   // 4 x the average row
+    bool jag = false;
+    {
+        uint64_t padded_rows = 0;
+        for (uint32_t sl = 0; sl < nslices; ++sl)
+            padded_rows += (uint64_t)slice_len[sl] * std::min<uint32_t>(kSliceRows, nrows - sl * kSliceRows);
+        jag = padded_rows > (uint64_t)c->nnz_d + c->nnz_d / 50;
+        if (const char *sv = getenv("BICG_SELL_LAYOUT")) jag = !strcmp(sv, "jag") ? true : !strcmp(sv, "pad") ? false : jag;
+    }
+    auto group_fits = [&](uint32_t g, uint64_t *stored_out) {
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
         const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
+        if (jag) {
+            // a lane walks its row alone: an outlier row would keep its wavefront busy long after the launch's other
+            // rows are done, so it goes to the CSR kernel, which spreads one row over a workgroup
+            *stored_out = nnz_g;
+            for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl)
+                if (slice_len[sl] > jag_max_row) return false;
+            return true;
+        }
         // storage always covers 64 lanes per slice; the criterion only counts lanes that hold a row, so
         // that the last, partly filled group of a block does not fall to the CSR kernel (an extra
         // launch per SpMV for a few dozen rows)
@@ -1506,14 +1531,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             padded += (uint64_t)slice_len[sl] * kSliceRows;
             padded_rows += (uint64_t)slice_len[sl] * std::min<uint32_t>(kSliceRows, r1 - sl * kSliceRows);
         }
-        *padded_out = padded;
+        *stored_out = padded;
         return padded_rows <= nnz_g + nnz_g / 4 + 2 * kSliceRows;
     };
-    // Ragged matrices (unstructured FEM: row lengths 3..26) leave only a few groups under the
-    // padding limit; two kernels per SpMV are then slower than the CSR kernel alone (measured on
-    // synth.fem_like: 70 vs 63 us), and sorting rows by length inside the groups (SELL-C-sigma)
-    // removes the padding but also the coalesced x gather (66.9 us). So: sliced ELL only when at
-    // least half of the rows qualify.
+    // (Round 1, before the jagged layout: a ragged matrix left only a few groups under the padding limit; two
+    // kernels per SpMV were then slower than the CSR kernel alone -- synth.fem_like 70 vs 63 us -- and sorting rows
+    // by length inside the groups, SELL-C-sigma, removes the padding but also the coalesced x gather: 66.9 us.)
     bool sell_worthwhile = use_sell;
     if (use_sell) {
         uint64_t rows_fit = 0, dummy;
@@ -1525,46 +1548,66 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     for (uint32_t g = 0; g < ngroups; ++g) {
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
         const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
-        uint64_t padded = 0;
-        const bool sell = sell_worthwhile && group_fits(g, &padded) && sell_entries + padded < 0xFFFFFF00ull;
+        uint64_t stored = 0;
+        const bool sell = sell_worthwhile && group_fits(g, &stored) && sell_entries + stored < 0xFFFFFF00ull;
         group_is_sell[g] = sell;
         if (!sell) continue;
         for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) {
             slice_base[sl] = (uint32_t)sell_entries;
-            sell_entries += (uint64_t)slice_len[sl] * kSliceRows;
+            if (jag) sell_entries += diag->ptr[std::min(nrows, (sl + 1) * (uint32_t)kSliceRows)] - diag->ptr[sl * kSliceRows];
+            else sell_entries += (uint64_t)slice_len[sl] * kSliceRows;
         }
         c->sell_nnz += nnz_g; c->sell_rows += r1 - r0;
         const bool touches_halo = P > 1 && optr[r1] > optr[r0];
         (touches_halo ? gl_bnd : gl_int).push_back(g);
     }
     c->sell_entries = sell_entries;
+    c->sell_jag = jag && sell_entries > 0;
     std::vector<double> sval(sell_entries ? sell_entries : 1, 0.0);
     std::vector<uint32_t> scol(sell_entries ? sell_entries : 1, 0u);
-    for (uint32_t r = 0; r < nrows; ++r) {
-        if (!group_is_sell[r / kGroupRows]) continue;
-        const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
-        for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
-            const size_t e = (size_t)slice_base[sl] + (size_t)k * kSliceRows + lane;
-            sval[e] = diag->val[j]; scol[e] = diag->col[j];
-        }
-    }
     // 16-bit column offsets when every sliced-ELL entry is within +-32767 of its row
     bool c16 = sell_entries > 0 && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
     std::vector<uint32_t> slice_base16(nslices, 0u);
     uint64_t n16 = 0;
-    for (uint32_t sl = 0; sl < nslices; ++sl) {
-        slice_base16[sl] = (uint32_t)n16;
-        if (group_is_sell[sl / (kGroupRows / kSliceRows)]) n16 += (uint64_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows;
-    }
+    if (jag) n16 = sell_entries;
+    else
+        for (uint32_t sl = 0; sl < nslices; ++sl) {
+            slice_base16[sl] = (uint32_t)n16;
+            if (group_is_sell[sl / (kGroupRows / kSliceRows)]) n16 += (uint64_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows;
+        }
     if (n16 >= 0xFFFFFF00ull) c16 = false;
-    std::vector<short> scol16(c16 ? n16 : 1, 0);
     for (uint32_t r = 0; c16 && r < nrows; ++r) {
         if (!group_is_sell[r / kGroupRows]) continue;
-        const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
-        for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
+        for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
             const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
             if (dlt < -32767 || dlt > 32767) { c16 = false; break; }
-            scol16[(size_t)slice_base16[sl] + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] = (short)dlt;
+        }
+    }
+    std::vector<short> scol16(c16 ? n16 : 1, 0);
+    if (jag) {
+        for (uint32_t sl = 0; sl < nslices; ++sl) {
+            if (!group_is_sell[sl / (kGroupRows / kSliceRows)]) continue;
+            const uint32_t r0 = sl * kSliceRows, r1 = std::min(nrows, r0 + (uint32_t)kSliceRows);
+            size_t e = slice_base[sl];
+            for (uint32_t k = 0; k < slice_len[sl]; ++k)
+                for (uint32_t r = r0; r < r1; ++r) {
+                    if (diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
+                    const uint32_t j = diag->ptr[r] + k;
+                    sval[e] = diag->val[j]; scol[e] = diag->col[j];
+                    if (c16) scol16[e] = (short)((int64_t)diag->col[j] - (int64_t)r);
+                    ++e;
+                }
+        }
+    } else {
+        for (uint32_t r = 0; r < nrows; ++r) {
+            if (!group_is_sell[r / kGroupRows]) continue;
+            const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
+            for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
+                const size_t e = (size_t)slice_base[sl] + (size_t)k * kSliceRows + lane;
+                sval[e] = diag->val[j]; scol[e] = diag->col[j];
+                if (c16) scol16[(size_t)slice_base16[sl] + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] =
+                             (short)((int64_t)diag->col[j] - (int64_t)r);
+            }
         }
     }
 
@@ -1603,14 +1646,15 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->o_ptr = dev_upload(optr.data(), (size_t)c->n_loc + 1);
     c->desc_int = dev_upload(bint.data(), bint.size());
     c->desc_bnd = dev_upload(bbnd.data(), bbnd.size());
-    c->s_val = dev_upload(sval.data(), (size_t)sell_entries);
-    c->s_col = dev_upload(scol.data(), c16 ? 0 : (size_t)sell_entries);
+    // (jagged slices: lanes whose row has ended read up to one entry past the last -- kPadEntries of slack)
+    c->s_val = dev_upload_padded(sval.data(), (size_t)sell_entries, kPadEntries);
+    c->s_col = dev_upload_padded(scol.data(), c16 ? 0 : (size_t)sell_entries, kPadEntries);
     c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) + 8ull * nslices + 4ull * (nrows + 1) +
                       (uint64_t)(c->nnz_d - c->sell_nnz) * 12 + (uint64_t)c->nnz_o * 12;
     c->device_matrix_bytes = (need_csr ? 12ull * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
-        c->s_col16 = dev_upload(scol16.data(), scol16.size());
+        c->s_col16 = dev_upload_padded(scol16.data(), scol16.size(), kPadEntries);
         c->s_base16 = dev_upload(slice_base16.data(), slice_base16.size());
     }
     c->s_base = dev_upload(slice_base.data(), slice_base.size());
@@ -1695,6 +1739,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     }
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
+    c->spmm_ok = all_ranks(comm, spmm_possible(c));
+    c->fuse_plan_ok = all_ranks(comm, c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused)));
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
 
@@ -1833,7 +1879,7 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
     group_now(c, 1, PH_NONE);
     fetch_scal(c);
     const double bb = c->hS->red[0];
-    if (spmm_possible(c) && !(getenv("BICG_NO_SPMM") && atoi(getenv("BICG_NO_SPMM")))) {
+    if (c->spmm_ok && !(getenv("BICG_NO_SPMM") && atoi(getenv("BICG_NO_SPMM")))) {
         // every matrix entry is read once for kSpmmCols shifts (the only place where
         // the reference multiplies A with many vectors is this verification loop, one SpMV per shift)
         spmm_buffers(c);
@@ -1879,7 +1925,7 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
 int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nvec, double *y_loc_set, double *ms_out)
 {
     BICG_HIP(hipSetDevice(c->comm->device));
-    if (!spmm_possible(c)) return 1;
+    if (!c->spmm_ok) return 1;
     reset_scal(c);
     spmm_buffers(c);
     const size_t n = c->n_loc;
@@ -1966,6 +2012,8 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->ll_fused) f |= BICG_FLAG_LL_FUSED;
     if (c->overlap) f |= BICG_FLAG_OVERLAP;
     if (c->s_col16) f |= BICG_FLAG_COL16;
+    if (c->sell_jag) f |= BICG_FLAG_JAGGED;
+    if (c->spmm_ok) f |= BICG_FLAG_SPMM;
     if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
     return f;
 }

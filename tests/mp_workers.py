@@ -139,7 +139,7 @@ def gpu_worker(rank, world, port, kind, outdir):
         y_orc = O.spmv(A.rows, row, col, val, x, nranks=world)[lo:lo + nl]
         lens = np.diff(A.ptr.astype(np.int64))[lo:lo + nl]
         assert np.array_equal(y[lens <= 2048], y_orc[lens <= 2048]), "distributed SpMV is not bit-exact"
-        if ctx.plan_info()["sell_rows"] == nl and ctx.plan_info()["row_blocks"] == (nl + 255) // 256:
+        if ctx.flags()["spmm"]:      # the same on every rank: the SpMM exchanges halos
             # distributed SpMM (halo of every vector, offd part per column): columns = the distributed SpMV of each vector
             X = np.random.default_rng(17).standard_normal((5, A.rows))
             Y, _ = ctx.spmm(X[:, lo:lo + nl], 0.25 * np.arange(5))

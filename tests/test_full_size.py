@@ -136,6 +136,41 @@ def test_hybrid_plan_with_ragged_rows():
     ctx.close()
 
 
+def test_jagged_slices_on_fem_like_rows(monkeypatch):
+    """ragged rows (synth.fem_like: 27-point stencil with 45 % of the off-diagonals dropped) take the jagged
+    sliced-ELL layout -- no padding stored, every row still summed in stored order: SpMV bit-identical to the
+    oracle, and identical to what the padded layout / the CSR kernel give; the four solvers follow the oracle."""
+    H.lib().bicg_comm_init_single(0)
+    A = synth.fem_like(n=117 * 117 * 6)
+    row, col, val = A.to_coo()
+    rng = np.random.default_rng(5)
+    x = rng.standard_normal(A.rows)
+    y_orc = O.spmv(A.rows, row, col, val, x)
+    ctx = H.Context(H.single_rank_blocks(A))
+    fl, info = ctx.flags(), ctx.plan_info()
+    assert fl["jagged"] and fl["all_sell"] and fl["col16"] and info["sell_padding"] == 0
+    assert ctx.device_matrix_bytes() <= 10.6 * A.nnz + 8 * A.rows + 4096
+    assert np.array_equal(ctx.spmv(x), y_orc)
+    b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+    for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
+        orc = O.solve(method, A.rows, row, col, val, b, krr=10, nrr=2)
+        got = ctx.solve(method, b, krr=10, nrr=2) if method.endswith("_rr") else ctx.solve(method, b)
+        assert abs(got["k"] - orc["k"]) <= 2, (method, got["k"], orc["k"])
+        assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max(), method
+    ctx.close()
+    monkeypatch.setenv("BICG_NO_COL16", "1")          # 32-bit columns in jagged slices
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert ctx.flags()["jagged"] and not ctx.flags()["col16"]
+    assert np.array_equal(ctx.spmv(x), y_orc)
+    ctx.close()
+    monkeypatch.delenv("BICG_NO_COL16")
+    monkeypatch.setenv("BICG_SELL_LAYOUT", "pad")     # padded slices: most groups fall to the CSR kernel
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert not ctx.flags()["jagged"]
+    assert np.array_equal(ctx.spmv(x), y_orc)
+    ctx.close()
+
+
 def test_laplace7_slab_generator_and_ca_bicgstab_against_oracle():
     """BASELINE.json configs[3] family: the in-memory 7-point Laplacian (synth.stencil7 with LAPLACE_WEIGHTS, built
     slab by slab as bench.py does for one GPU's z-planes) at 96^3 = 885 k rows: the slabs tile the global matrix, the
