@@ -22,6 +22,15 @@
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events bound to ONE kernel (roofline timing)
 #include <cstdlib>
 
+// This file is compiled several times (Makefile: BICG_PART = 0..3, in parallel): the sliced-ELL launchers instantiate
+// several hundred kernels and would otherwise serialise the build. Part 0 holds everything that is not a template
+// (kernels and launch wrappers), parts 1-3 one group of sliced-ELL instantiations each; without BICG_PART the
+// file is one translation unit.
+#ifndef BICG_PART
+#define BICG_PART -1
+#endif
+#define PART_IS(p) (BICG_PART == -1 || BICG_PART == (p))
+
 namespace bicg {
 
 // launch with optional per-kernel timing events (kernel-accurate, unlike events recorded around a launch)
@@ -431,11 +440,13 @@ static inline bool heavy_needed(const Reduce &red)
     return red.apply_now && (red.p2p.seq != 0 || red.phase >= PH_SW_INIT);
 }
 
+#if PART_IS(0)
 __global__ void __launch_bounds__(kBlock) k_apply(Scal *S, int phase)
 {
     if (S->done) return;
     apply_phase_block<true>(S, phase);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // peer-to-peer transport: LL words (see bicg_device.h)
@@ -500,6 +511,7 @@ __device__ __forceinline__ bool p2p_collect(Scal *S, int n, const P2pRed &pr, un
     return true;
 }
 
+#if PART_IS(0)
 __global__ void __launch_bounds__(kBlock) k_apply_p2p(Scal *S, int phase, int n, P2pRed pr, unsigned long long timeout_ticks)
 {
     if (S->done) return;
@@ -508,6 +520,7 @@ __global__ void __launch_bounds__(kBlock) k_apply_p2p(Scal *S, int phase, int n,
     if (!p2p_collect(S, n, pr, timeout_ticks, vals, &s_fail)) return;
     if (phase != PH_NONE) apply_phase_block<true>(S, phase);
 }
+#endif
 
 // Self-test of the transport: `rounds` all-reduces of five values that depend on (rank, round,
 // slot), each checked against the sum recomputed locally. One workgroup; status[0] counts wrong
@@ -517,6 +530,7 @@ __device__ __forceinline__ double selftest_value(int rank, unsigned seq, int d)
     return (double)(rank * 131 + d * 17 + 1) * 1.000000119 + (double)seq * 0.333333333333;
 }
 
+#if PART_IS(0)
 __global__ void __launch_bounds__(kBlock) k_p2p_selftest(P2pRed pr, unsigned seq0, int rounds, unsigned long long timeout_ticks,
                                                          int *status)
 {
@@ -552,6 +566,7 @@ __global__ void __launch_bounds__(kBlock) k_p2p_selftest(P2pRed pr, unsigned seq
         __syncthreads();
     }
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // reductions
@@ -933,6 +948,7 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, in
 }
 
 // stand-alone finisher (set-up phases, host reads, transports whose all-reduce the host enqueues)
+#if PART_IS(0)
 __global__ void __launch_bounds__(kBlock) k_finish(Scal *S, Finish f)
 {
     __shared__ FinishLds L;
@@ -943,6 +959,7 @@ void launch_finish(const Launch &L)
 {
     hipLaunchKernelGGL(k_finish, dim3(L.fin.roles & FIN_SHARDS ? kShards : 1), dim3(kBlock), 0, L.st, L.S, L.fin);
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // CSR SpMV, row-block stream
@@ -1083,11 +1100,13 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 // One workgroup per row block: the hardware dispatcher balances the ~12k workgroups of a
 // Transport-sized matrix better than a persistent grid; beyond kSpmvMaxGrid row blocks the kernel's
 // loop strides.
+#if PART_IS(0)
 unsigned spmv_grid(uint32_t nlist)
 {
     if (nlist == 0) return 0;
     return nlist < (uint32_t)kSpmvMaxGrid ? nlist : (unsigned)kSpmvMaxGrid;
 }
+#endif
 
 // which reduction epilogue / prologue a launch needs (RedMode)
 static inline int red_mode(const Reduce &red, const Finish &fin, bool has_dots)
@@ -1096,6 +1115,7 @@ static inline int red_mode(const Reduce &red, const Finish &fin, bool has_dots)
     return has_dots && heavy_needed(red) ? RED_TICKET_HEAVY : RED_TICKET;
 }
 
+#if PART_IS(0)
 template <int NDOT, bool OFFD>
 static void launch_spmv_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
@@ -1126,6 +1146,7 @@ bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hi
     }
     return true;
 }
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Sliced-ELL SpMV (the default path for rows whose slice pads by < 25 %)
@@ -1454,6 +1475,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
 static inline int sell_layout(const SellDev &d) { return (d.jag ? LAY_JAG32 : LAY_PAD32) + (d.col16 ? 1 : 0); }
 
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
+#if PART_IS(0)
 unsigned sell_grid(uint32_t ngroups, int per_wg)
 {
     if (ngroups == 0) return 0;
@@ -1463,26 +1485,22 @@ unsigned sell_grid(uint32_t ngroups, int per_wg)
     const unsigned each = (ngroups + grid0 - 1) / grid0;
     return (ngroups + each - 1) / each;
 }
+#endif
 
-bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
+// One sliced-ELL layout's instantiations (96 SpMV kernels + 12 with an epilogue): a translation unit each.
+template <int LAY>
+static bool sell_launch_layout(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
 {
     if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
     dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u)), b(kBlock);
-#define SELL_LAY(ND, OF, NTV, LLV, MD)                                                             \
-    do {                                                                                           \
-        if (lay == LAY_PAD16) launch_timed(k_spmv_sell<ND, OF, NTV, LAY_PAD16, LLV, MD>, g, b, st, e0, e1, a);      \
-        else if (lay == LAY_JAG32) launch_timed(k_spmv_sell<ND, OF, NTV, LAY_JAG32, LLV, MD>, g, b, st, e0, e1, a); \
-        else if (lay == LAY_JAG16) launch_timed(k_spmv_sell<ND, OF, NTV, LAY_JAG16, LLV, MD>, g, b, st, e0, e1, a); \
-        else launch_timed(k_spmv_sell<ND, OF, NTV, LAY_PAD32, LLV, MD>, g, b, st, e0, e1, a);                       \
-    } while (0)
 #define SELL_MODE(ND, OF, LLV, MD)                                                                 \
     do {                                                                                           \
-        if (nt) SELL_LAY(ND, OF, true, LLV, MD); else SELL_LAY(ND, OF, false, LLV, MD);            \
+        if (nt) launch_timed(k_spmv_sell<ND, OF, true, LAY, LLV, MD>, g, b, st, e0, e1, a);        \
+        else launch_timed(k_spmv_sell<ND, OF, false, LAY, LLV, MD>, g, b, st, e0, e1, a);          \
     } while (0)
 #define SELL_CASE(ND, OF, LLV)                                                                     \
     do {                                                                                           \
         const bool nt = a.nt != 0;                                                                 \
-        const int lay = sell_layout(a.sell);                                                       \
         const int mode = red_mode(a.red, a.fin, (ND) > 0);                                         \
         constexpr int HV = (ND) > 0 ? RED_TICKET_HEAVY : RED_TICKET;                               \
         if (mode == RED_WAVE) SELL_MODE(ND, OF, LLV, RED_WAVE);                                    \
@@ -1498,9 +1516,78 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     }
 #undef SELL_CASE
 #undef SELL_MODE
-#undef SELL_LAY
     return true;
 }
+
+template <int LAY>
+static bool sell_epi_launch_layout(const SpmvArgs &a, int epi, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
+{
+    if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
+    const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;      // dedicated shard summers
+    dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u) + nhelp), b(kBlock);
+    const bool nt = a.nt != 0;
+#define EPI_CASE(EP, OF, LLV)                                                                      \
+    do {                                                                                           \
+        if (nt) launch_timed(k_spmv_sell_epi<EP, OF, true, LAY, LLV>, g, b, st, e0, e1, a);        \
+        else launch_timed(k_spmv_sell_epi<EP, OF, false, LAY, LLV>, g, b, st, e0, e1, a);          \
+    } while (0)
+    if (epi == 1) {
+        if (fused_halo) EPI_CASE(1, true, true); else if (with_offd) EPI_CASE(1, true, false); else EPI_CASE(1, false, false);
+    } else {
+        if (fused_halo) EPI_CASE(2, true, true); else if (with_offd) EPI_CASE(2, true, false); else EPI_CASE(2, false, false);
+    }
+#undef EPI_CASE
+    return true;
+}
+
+#define SELL_PART_ARGS const SpmvArgs &a, int n, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo
+bool launch_spmv_sell_pad32(SELL_PART_ARGS);
+bool launch_spmv_sell_pad16(SELL_PART_ARGS);
+bool launch_spmv_sell_jag32(SELL_PART_ARGS);
+bool launch_spmv_sell_jag16(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_pad32(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_pad16(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_jag32(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_jag16(SELL_PART_ARGS);
+#if PART_IS(1)
+bool launch_spmv_sell_pad32(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_pad32(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
+#if PART_IS(2)
+bool launch_spmv_sell_pad16(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD16>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_pad16(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD16>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
+#if PART_IS(3)
+bool launch_spmv_sell_jag32(SELL_PART_ARGS) { return sell_launch_layout<LAY_JAG32>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_jag32(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_JAG32>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
+#if PART_IS(4)
+bool launch_spmv_sell_jag16(SELL_PART_ARGS) { return sell_launch_layout<LAY_JAG16>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_jag16(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_JAG16>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
+#undef SELL_PART_ARGS
+
+#if PART_IS(0)
+bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
+{
+    switch (sell_layout(a.sell)) {
+    case LAY_PAD16: return launch_spmv_sell_pad16(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAG32: return launch_spmv_sell_jag32(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAG16: return launch_spmv_sell_jag16(a, ndot, with_offd, st, e0, e1, fused_halo);
+    default:        return launch_spmv_sell_pad32(a, ndot, with_offd, st, e0, e1, fused_halo);
+    }
+}
+
+bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
+{
+    switch (sell_layout(a.sell)) {
+    case LAY_PAD16: return launch_spmv_sell_epi_pad16(a, epi, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAG32: return launch_spmv_sell_epi_jag32(a, epi, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAG16: return launch_spmv_sell_epi_jag16(a, epi, with_offd, st, e0, e1, fused_halo);
+    default:        return launch_spmv_sell_epi_pad32(a, epi, with_offd, st, e0, e1, fused_halo);
+    }
+}
+#endif
 
 // ------------------------------------------------------------------------------------------
 // Sliced-ELL SpMM: Y_j = (A + sigma_j I) X_j for kSpmmCols vectors at once -- the verification loop of
@@ -1517,6 +1604,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 // || b - Y_j ||^2 is fused (workgroup sums go to partial[wg][col], k_colsum adds them in a fixed
 // order) and Y is never written.
 // ------------------------------------------------------------------------------------------
+#if PART_IS(0)
 template <bool C16, bool OFFD>
 __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
 {
@@ -1724,35 +1812,9 @@ void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_
 {
     if (n) hipLaunchKernelGGL(k_vectors_from_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, yt, stride, nvec, n, y);
 }
+#endif
 
-bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
-{
-    if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
-    const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;      // dedicated shard summers
-    dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u) + nhelp), b(kBlock);
-    const bool nt = a.nt != 0;
-    const int lay = sell_layout(a.sell);
-#define EPI_LAY(EP, OF, NTV, LLV)                                                                               \
-    do {                                                                                                        \
-        if (lay == LAY_PAD16) launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_PAD16, LLV>, g, b, st, e0, e1, a);       \
-        else if (lay == LAY_JAG32) launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_JAG32, LLV>, g, b, st, e0, e1, a);  \
-        else if (lay == LAY_JAG16) launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_JAG16, LLV>, g, b, st, e0, e1, a);  \
-        else launch_timed(k_spmv_sell_epi<EP, OF, NTV, LAY_PAD32, LLV>, g, b, st, e0, e1, a);                        \
-    } while (0)
-#define EPI_CASE(EP, OF, LLV)                                                                                   \
-    do {                                                                                                        \
-        if (nt) EPI_LAY(EP, OF, true, LLV); else EPI_LAY(EP, OF, false, LLV);                                   \
-    } while (0)
-    if (epi == 1) {
-        if (fused_halo) EPI_CASE(1, true, true); else if (with_offd) EPI_CASE(1, true, false); else EPI_CASE(1, false, false);
-    } else {
-        if (fused_halo) EPI_CASE(2, true, true); else if (with_offd) EPI_CASE(2, true, false); else EPI_CASE(2, false, false);
-    }
-#undef EPI_CASE
-#undef EPI_LAY
-    return true;
-}
-
+#if PART_IS(0)
 void launch_apply(Scal *S, int phase, hipStream_t st)
 {
     hipLaunchKernelGGL(k_apply, dim3(1), dim3(phase >= PH_SH_INIT ? kBlock : 1), 0, st, S, phase);
@@ -2642,4 +2704,5 @@ void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce re
     run_vec(FDot{x, y}, n, S, red, s);
 }
 
+#endif
 }  // namespace bicg

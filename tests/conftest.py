@@ -17,6 +17,6 @@ def pytest_sessionstart(session):
     lib = os.path.join(ROOT, "mpi-bicgstab_amd", "libbicgstab_hip.so")
     dump = os.path.join(ROOT, "mpi-bicgstab_amd", "host", "bicg_mtx_dump")
     if not (os.path.exists(lib) and os.path.exists(dump)):
-        subprocess.call(["make", "-C", os.path.join(ROOT, "mpi-bicgstab_amd"), "all"])
+        subprocess.call(["make", "-j", "8", "-C", os.path.join(ROOT, "mpi-bicgstab_amd"), "all"])
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
