@@ -267,9 +267,9 @@ int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);
 /* which code paths this context takes (tests assert on them): peer-to-peer data path in use; halo exchange
  * folded into the sliced-ELL SpMV launch; two-stream overlap mode; 16-bit column offsets; every 256-row
  * group on the sliced-ELL path; jagged slices (ragged rows, no padding stored); bicg_spmm available (the same
- * on every rank) */
+ * on every rank); x windows in LDS with 16-bit slots instead of column indices */
 enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FLAG_COL16 = 8, BICG_FLAG_ALL_SELL = 16, BICG_FLAG_JAGGED = 32,
-       BICG_FLAG_SPMM = 64 };
+       BICG_FLAG_SPMM = 64, BICG_FLAG_WINDOW = 128 };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 /* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);

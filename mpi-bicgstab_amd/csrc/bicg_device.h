@@ -212,8 +212,16 @@ struct SellDev {
     // jagged slices (ragged rows): step k of a slice stores the entries of the rows longer than k only, in lane
     // order; slice_base counts entries, col16 is indexed like val (no quads), slice_base16 is unused
     int jag;
+    // x window (jagged slices only): the columns a 256-row group touches, merged into runs of consecutive columns,
+    // are copied into LDS once per group with coalesced loads; col16 then holds 16-bit LDS SLOTS instead of offsets
+    // (10 bytes per non-zero whatever the bandwidth of the matrix) and the x gather is an LDS read.
+    // win_ptr[g] .. win_ptr[g+1]: the group's runs in win_runs, each {first column, (first slot << 16) | length}
+    const uint32_t *win_ptr;
+    const uint2    *win_runs;
+    uint32_t        win_slots;   // LDS doubles the largest group needs (0: no window)
 };
-enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3 };
+enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4 };
+constexpr uint32_t kWinMaxSlots = 4096;      // 32 KB of LDS per workgroup: 4 workgroups per CU
 
 // Peer-to-peer halo exchange folded into the sliced-ELL SpMV launch: the first `npush` workgroups
 // store this rank's send list into the landing rings of the ranks that need it, the others

@@ -22,9 +22,9 @@
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events bound to ONE kernel (roofline timing)
 #include <cstdlib>
 
-// This file is compiled several times (Makefile: BICG_PART = 0..3, in parallel): the sliced-ELL launchers instantiate
+// This file is compiled several times (Makefile: BICG_PART = 0..5, in parallel): the sliced-ELL launchers instantiate
 // several hundred kernels and would otherwise serialise the build. Part 0 holds everything that is not a template
-// (kernels and launch wrappers), parts 1-3 one group of sliced-ELL instantiations each; without BICG_PART the
+// (kernels and launch wrappers), parts 1-5 one group of sliced-ELL instantiations each; without BICG_PART the
 // file is one translation unit.
 #ifndef BICG_PART
 #define BICG_PART -1
@@ -35,10 +35,15 @@ namespace bicg {
 
 // launch with optional per-kernel timing events (kernel-accurate, unlike events recorded around a launch)
 template <class K, class... Args>
+static void launch_timed_lds(K kernel, dim3 g, dim3 b, unsigned lds_bytes, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args)
+{
+    if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, lds_bytes, st, e0, e1, 0, args...);
+    else hipLaunchKernelGGL(kernel, g, b, lds_bytes, st, args...);
+}
+template <class K, class... Args>
 static void launch_timed(K kernel, dim3 g, dim3 b, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args)
 {
-    if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, 0, st, e0, e1, 0, args...);
-    else hipLaunchKernelGGL(kernel, g, b, 0, st, args...);
+    launch_timed_lds(kernel, g, b, 0u, st, e0, e1, args...);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -1175,10 +1180,26 @@ template <class T> __device__ __forceinline__ T recur3(T u, T w, T add, double o
 
 // y_i of this lane's row of list entry gi (diag part in stored order, then the offd part, then the shift):
 // the body shared by the SpMV kernel and the SpMV-with-epilogue kernel below
-template <bool OFFD, bool NT, int LAY, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
-__device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed)
+extern __shared__ double dyn_lds[];      // the x window of LAY_JAGW launches (SellDev::win_slots doubles)
+
+// LAY_JAGW: copy the x values the group's rows touch into LDS (all 256 threads; the caller's loop is workgroup-uniform)
+__device__ __forceinline__ void sell_stage_window(const SpmvArgs &a, unsigned g, double *win)
 {
-    constexpr bool C16 = (LAY & 1) != 0, JAG = LAY >= LAY_JAG32;
+    __syncthreads();                                          // the previous group's reads of the window are done
+    const uint32_t r0 = a.sell.win_ptr[g], r1 = a.sell.win_ptr[g + 1];
+    for (uint32_t r = r0; r < r1; ++r) {
+        const uint2 run = a.sell.win_runs[r];                 // wave-uniform
+        const uint32_t len = run.y & 0xFFFFu, slot0 = run.y >> 16;
+        for (uint32_t i = threadIdx.x; i < len; i += kBlock) win[slot0 + i] = a.x[run.x + i];
+    }
+    __syncthreads();
+}
+
+template <bool OFFD, bool NT, int LAY, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
+__device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed,
+                                           const double *win = nullptr)
+{
+    constexpr bool WIN = LAY == LAY_JAGW, C16 = (LAY & 1) != 0 || WIN, JAG = LAY >= LAY_JAG32;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const double *__restrict__ x = a.x;
     const unsigned g = a.glist ? a.glist[gi] : gi;
@@ -1221,14 +1242,23 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
                 pos += (uint32_t)__builtin_popcountll(m);
                 c[e] = 0u; v[e] = 0.0;
                 if (mine[e]) {
-                    if (C16) c[e] = (uint32_t)(int)(NT ? __builtin_nontemporal_load(a.sell.col16 + j) : a.sell.col16[j]);
-                    else c[e] = NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j];
+                    if (WIN) {
+                        const unsigned short *sl = reinterpret_cast<const unsigned short *>(a.sell.col16);
+                        c[e] = NT ? __builtin_nontemporal_load(sl + j) : sl[j];
+                    } else if (C16) {
+                        c[e] = (uint32_t)(int)(NT ? __builtin_nontemporal_load(a.sell.col16 + j) : a.sell.col16[j]);
+                    } else {
+                        c[e] = NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j];
+                    }
                     v[e] = NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j];
                 }
             }
             double xv[U];
 #pragma unroll
-            for (int e = 0; e < U; ++e) xv[e] = x[mine[e] ? (C16 ? rb + c[e] : c[e]) : rb];
+            for (int e = 0; e < U; ++e) {
+                if (WIN) xv[e] = win[c[e]];                   // slot 0 for a lane whose row has ended
+                else xv[e] = x[mine[e] ? (C16 ? rb + c[e] : c[e]) : rb];
+            }
 #pragma unroll
             for (int e = 0; e < U; ++e)
                 if (mine[e]) sum += v[e] * xv[e];             // stored order
@@ -1330,7 +1360,8 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
         uint32_t row;
         bool live;
-        const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed);
+        if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
+        const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed, dyn_lds);
         if (live && !done) a.y[row] = yi;
         if (NDOT >= 1 && live) {
             const double ume = a.u[row];
@@ -1428,7 +1459,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
         uint32_t row;
         bool live;
-        const double yi = sell_row<OFFD, NT, LAY, LL, 8>(a, gi, done, row, live, ll_failed);
+        if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
+        const double yi = sell_row<OFFD, NT, LAY, LL, 8>(a, gi, done, row, live, ll_failed, dyn_lds);
         if (live && !done) a.y[row] = yi;
         // The phase's inputs (values of this lane's own row) are requested right after the row product and BEFORE the
         // scalars are waited for: their round trip and the scalar poll's are one. (Requested before the row product
@@ -1472,7 +1504,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + bid);
 }
 
-static inline int sell_layout(const SellDev &d) { return (d.jag ? LAY_JAG32 : LAY_PAD32) + (d.col16 ? 1 : 0); }
+static inline int sell_layout(const SellDev &d)
+{
+    if (d.win_slots) return LAY_JAGW;
+    return (d.jag ? LAY_JAG32 : LAY_PAD32) + (d.col16 ? 1 : 0);
+}
 
 // workgroups launched for ngroups 256-row groups: every workgroup gets the same number (+-1)
 #if PART_IS(0)
@@ -1493,10 +1529,11 @@ static bool sell_launch_layout(const SpmvArgs &a, int ndot, bool with_offd, hipS
 {
     if (a.nlist == 0 && !(fused_halo && a.ll.npush > 0)) return false;
     dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u)), b(kBlock);
+    const unsigned lds = LAY == LAY_JAGW ? a.sell.win_slots * (unsigned)sizeof(double) : 0u;
 #define SELL_MODE(ND, OF, LLV, MD)                                                                 \
     do {                                                                                           \
-        if (nt) launch_timed(k_spmv_sell<ND, OF, true, LAY, LLV, MD>, g, b, st, e0, e1, a);        \
-        else launch_timed(k_spmv_sell<ND, OF, false, LAY, LLV, MD>, g, b, st, e0, e1, a);          \
+        if (nt) launch_timed_lds(k_spmv_sell<ND, OF, true, LAY, LLV, MD>, g, b, lds, st, e0, e1, a);   \
+        else launch_timed_lds(k_spmv_sell<ND, OF, false, LAY, LLV, MD>, g, b, lds, st, e0, e1, a);     \
     } while (0)
 #define SELL_CASE(ND, OF, LLV)                                                                     \
     do {                                                                                           \
@@ -1526,10 +1563,11 @@ static bool sell_epi_launch_layout(const SpmvArgs &a, int epi, bool with_offd, h
     const unsigned nhelp = a.fin.seq && (a.fin.roles & FIN_SHARDS) ? (unsigned)kShards : 0u;      // dedicated shard summers
     dim3 g(sell_grid(a.nlist, a.groups_per_wg) + (fused_halo ? a.ll.npush : 0u) + nhelp), b(kBlock);
     const bool nt = a.nt != 0;
+    const unsigned lds = LAY == LAY_JAGW ? a.sell.win_slots * (unsigned)sizeof(double) : 0u;
 #define EPI_CASE(EP, OF, LLV)                                                                      \
     do {                                                                                           \
-        if (nt) launch_timed(k_spmv_sell_epi<EP, OF, true, LAY, LLV>, g, b, st, e0, e1, a);        \
-        else launch_timed(k_spmv_sell_epi<EP, OF, false, LAY, LLV>, g, b, st, e0, e1, a);          \
+        if (nt) launch_timed_lds(k_spmv_sell_epi<EP, OF, true, LAY, LLV>, g, b, lds, st, e0, e1, a);   \
+        else launch_timed_lds(k_spmv_sell_epi<EP, OF, false, LAY, LLV>, g, b, lds, st, e0, e1, a);     \
     } while (0)
     if (epi == 1) {
         if (fused_halo) EPI_CASE(1, true, true); else if (with_offd) EPI_CASE(1, true, false); else EPI_CASE(1, false, false);
@@ -1549,6 +1587,8 @@ bool launch_spmv_sell_epi_pad32(SELL_PART_ARGS);
 bool launch_spmv_sell_epi_pad16(SELL_PART_ARGS);
 bool launch_spmv_sell_epi_jag32(SELL_PART_ARGS);
 bool launch_spmv_sell_epi_jag16(SELL_PART_ARGS);
+bool launch_spmv_sell_jagw(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_jagw(SELL_PART_ARGS);
 #if PART_IS(1)
 bool launch_spmv_sell_pad32(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
 bool launch_spmv_sell_epi_pad32(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
@@ -1565,6 +1605,10 @@ bool launch_spmv_sell_epi_jag32(SELL_PART_ARGS) { return sell_epi_launch_layout<
 bool launch_spmv_sell_jag16(SELL_PART_ARGS) { return sell_launch_layout<LAY_JAG16>(a, n, with_offd, st, e0, e1, fused_halo); }
 bool launch_spmv_sell_epi_jag16(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_JAG16>(a, n, with_offd, st, e0, e1, fused_halo); }
 #endif
+#if PART_IS(5)
+bool launch_spmv_sell_jagw(SELL_PART_ARGS) { return sell_launch_layout<LAY_JAGW>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_jagw(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_JAGW>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
 #undef SELL_PART_ARGS
 
 #if PART_IS(0)
@@ -1574,6 +1618,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     case LAY_PAD16: return launch_spmv_sell_pad16(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG32: return launch_spmv_sell_jag32(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG16: return launch_spmv_sell_jag16(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAGW:  return launch_spmv_sell_jagw(a, ndot, with_offd, st, e0, e1, fused_halo);
     default:        return launch_spmv_sell_pad32(a, ndot, with_offd, st, e0, e1, fused_halo);
     }
 }
@@ -1584,6 +1629,7 @@ bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_
     case LAY_PAD16: return launch_spmv_sell_epi_pad16(a, epi, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG32: return launch_spmv_sell_epi_jag32(a, epi, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG16: return launch_spmv_sell_epi_jag16(a, epi, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAGW:  return launch_spmv_sell_epi_jagw(a, epi, with_offd, st, e0, e1, fused_halo);
     default:        return launch_spmv_sell_epi_pad32(a, epi, with_offd, st, e0, e1, fused_halo);
     }
 }

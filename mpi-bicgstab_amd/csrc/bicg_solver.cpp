@@ -75,6 +75,8 @@ struct bicg_ctx {
     uint32_t *s_col = nullptr, *s_base = nullptr, *s_len = nullptr, *s_base16 = nullptr;
     short *s_col16 = nullptr;
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
+    uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
+    uint2 *win_runs = nullptr;
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
     uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
     uint64_t sell_entries = 0, sell_nnz = 0;
@@ -375,7 +377,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     SpmvArgs a;
     a.fin = fin;
     a.epi = c->v;
-    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots};
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -564,7 +566,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
     launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
-    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots};
     a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.nrows = c->n_loc; a.ngroups = c->ng_int + c->ng_bnd;
     a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
@@ -1512,6 +1514,16 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         jag = padded_rows > (uint64_t)c->nnz_d + c->nnz_d / 50;
         if (const char *sv = getenv("BICG_SELL_LAYOUT")) jag = !strcmp(sv, "jag") ? true : !strcmp(sv, "pad") ? false : jag;
     }
+    // x windows in LDS (SellDev::win_*): wanted for ragged rows, where the x gather of one step touches many cache
+    // lines (FEM-like: 63 -> 58 us per SpMV). With equal rows the gathers are perfectly coalesced and the window
+    // only adds staging loads and two barriers per group (Transport-shaped +2 %, 256^3 Laplacian +9 % although its
+    // columns shrink from 32 to 16 bits), so there it is taken on request only: BICG_SELL_WINDOW = 1 asks for it
+    // whenever it fits, 0 never. It needs the jagged layout.
+    const bool jag_auto = jag;
+    int win_env = -1;
+    if (const char *sv = getenv("BICG_SELL_WINDOW")) win_env = atoi(sv);
+    bool want_win = use_sell && win_env != 0 && (win_env == 1 || jag_auto);
+    if (want_win) jag = true;
     auto group_fits = [&](uint32_t g, uint64_t *stored_out) {
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
         const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
@@ -1538,13 +1550,19 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // kernels per SpMV were then slower than the CSR kernel alone -- synth.fem_like 70 vs 63 us -- and sorting rows
     // by length inside the groups, SELL-C-sigma, removes the padding but also the coalesced x gather: 66.9 us.)
     bool sell_worthwhile = use_sell;
+    uint64_t sell_entries = 0;
+    std::vector<uint32_t> win_ptr;
+    std::vector<uint2> win_runs;
+    uint32_t win_slots = 0;
+  select_groups:
+    sell_entries = 0; c->sell_nnz = 0; c->sell_rows = 0;
+    gl_int.clear(); gl_bnd.clear();
     if (use_sell) {
         uint64_t rows_fit = 0, dummy;
         for (uint32_t g = 0; g < ngroups; ++g)
             if (group_fits(g, &dummy)) rows_fit += std::min(nrows, (g + 1) * (uint32_t)kGroupRows) - g * kGroupRows;
         sell_worthwhile = 2 * rows_fit >= nrows;
     }
-    uint64_t sell_entries = 0;
     for (uint32_t g = 0; g < ngroups; ++g) {
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
         const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
@@ -1561,12 +1579,64 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         const bool touches_halo = P > 1 && optr[r1] > optr[r0];
         (touches_halo ? gl_bnd : gl_int).push_back(g);
     }
+    if (want_win) {
+        // per group: the columns its rows touch (a bitmap over the group's column span), merged into runs of
+        // consecutive columns (gaps of up to kWinGap unused values are copied along: cheaper than another run)
+        constexpr uint32_t kWinGap = 8;
+        win_ptr.assign(ngroups + 1, 0u); win_runs.clear(); win_slots = 0;
+        std::vector<uint64_t> bm;
+        std::vector<uint32_t> cols;
+        bool ok = sell_entries > 0;
+        for (uint32_t g = 0; g < ngroups && ok; ++g) {
+            win_ptr[g + 1] = win_ptr[g];
+            if (!group_is_sell[g]) continue;
+            const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
+            const uint32_t j0 = diag->ptr[r0], j1 = diag->ptr[r1];
+            if (j0 == j1) continue;
+            uint32_t lo = UINT32_MAX, hi = 0;
+            for (uint32_t j = j0; j < j1; ++j) { lo = std::min(lo, diag->col[j]); hi = std::max(hi, diag->col[j]); }
+            cols.clear();
+            if ((uint64_t)hi - lo < (1ull << 24)) {
+                bm.assign(((size_t)hi - lo) / 64 + 1, 0ull);
+                for (uint32_t j = j0; j < j1; ++j) { const uint32_t d = diag->col[j] - lo; bm[d >> 6] |= 1ull << (d & 63); }
+                for (size_t w = 0; w < bm.size(); ++w)
+                    for (uint64_t bits = bm[w]; bits; bits &= bits - 1) cols.push_back(lo + (uint32_t)(w * 64) + (uint32_t)__builtin_ctzll(bits));
+            } else {
+                cols.assign(diag->col + j0, diag->col + j1);
+                std::sort(cols.begin(), cols.end());
+                cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            }
+            uint32_t slots = 0;
+            for (size_t i = 0; i < cols.size();) {
+                size_t k = i;
+                while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= kWinGap + 1 && cols[k + 1] - cols[i] < 65535u) ++k;
+                const uint32_t len = cols[k] - cols[i] + 1;
+                if (slots + len > kWinMaxSlots) { ok = false; break; }
+                win_runs.push_back(make_uint2(cols[i], (slots << 16) | len));
+                slots += len;
+                i = k + 1;
+            }
+            win_ptr[g + 1] = (uint32_t)win_runs.size();
+            win_slots = std::max(win_slots, slots);
+        }
+        if (!ok) {                          // some group's window does not fit: no windows for this block
+            want_win = false; win_slots = 0; win_runs.clear(); win_ptr.clear();
+            if (!jag_auto) { jag = false; std::fill(group_is_sell.begin(), group_is_sell.end(), 0); goto select_groups; }
+        }
+    }
+    const bool win = want_win && win_slots > 0;
+    // the slot of a column inside its group's window
+    auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
+        uint32_t a = win_ptr[g], b = win_ptr[g + 1];                 // last run whose first column is <= col
+        while (b - a > 1) { const uint32_t m = (a + b) / 2; if (win_runs[m].x <= col) a = m; else b = m; }
+        return (win_runs[a].y >> 16) + (col - win_runs[a].x);
+    };
     c->sell_entries = sell_entries;
     c->sell_jag = jag && sell_entries > 0;
     std::vector<double> sval(sell_entries ? sell_entries : 1, 0.0);
     std::vector<uint32_t> scol(sell_entries ? sell_entries : 1, 0u);
     // 16-bit column offsets when every sliced-ELL entry is within +-32767 of its row
-    bool c16 = sell_entries > 0 && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
+    bool c16 = sell_entries > 0 && (win || !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16"))));
     std::vector<uint32_t> slice_base16(nslices, 0u);
     uint64_t n16 = 0;
     if (jag) n16 = sell_entries;
@@ -1576,7 +1646,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             if (group_is_sell[sl / (kGroupRows / kSliceRows)]) n16 += (uint64_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows;
         }
     if (n16 >= 0xFFFFFF00ull) c16 = false;
-    for (uint32_t r = 0; c16 && r < nrows; ++r) {
+    for (uint32_t r = 0; c16 && !win && r < nrows; ++r) {
         if (!group_is_sell[r / kGroupRows]) continue;
         for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
             const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
@@ -1594,7 +1664,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
                     if (diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
                     const uint32_t j = diag->ptr[r] + k;
                     sval[e] = diag->val[j]; scol[e] = diag->col[j];
-                    if (c16) scol16[e] = (short)((int64_t)diag->col[j] - (int64_t)r);
+                    if (win) scol16[e] = (short)(unsigned short)slot_of(sl / (kGroupRows / kSliceRows), diag->col[j]);
+                    else if (c16) scol16[e] = (short)((int64_t)diag->col[j] - (int64_t)r);
                     ++e;
                 }
         }
@@ -1656,6 +1727,13 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (c16) {
         c->s_col16 = dev_upload_padded(scol16.data(), scol16.size(), kPadEntries);
         c->s_base16 = dev_upload(slice_base16.data(), slice_base16.size());
+    }
+    if (win) {
+        c->win_ptr = dev_upload(win_ptr.data(), win_ptr.size());
+        c->win_runs = dev_upload(win_runs.data(), win_runs.size());
+        c->win_slots = win_slots;
+        c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
+        c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
     }
     c->s_base = dev_upload(slice_base.data(), slice_base.size());
     c->s_len = dev_upload(slice_len.data(), slice_len.size());
@@ -1761,7 +1839,7 @@ void bicg_destroy(bicg_ctx *c)
     if (!c) return;
     (void)hipSetDevice(c->comm->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->win_ptr, c->win_runs, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -2013,6 +2091,7 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->overlap) f |= BICG_FLAG_OVERLAP;
     if (c->s_col16) f |= BICG_FLAG_COL16;
     if (c->sell_jag) f |= BICG_FLAG_JAGGED;
+    if (c->win_slots) f |= BICG_FLAG_WINDOW;
     if (c->spmm_ok) f |= BICG_FLAG_SPMM;
     if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
     return f;

@@ -148,7 +148,7 @@ def test_jagged_slices_on_fem_like_rows(monkeypatch):
     y_orc = O.spmv(A.rows, row, col, val, x)
     ctx = H.Context(H.single_rank_blocks(A))
     fl, info = ctx.flags(), ctx.plan_info()
-    assert fl["jagged"] and fl["all_sell"] and fl["col16"] and info["sell_padding"] == 0
+    assert fl["jagged"] and fl["window"] and fl["all_sell"] and fl["col16"] and info["sell_padding"] == 0
     assert ctx.device_matrix_bytes() <= 10.6 * A.nnz + 8 * A.rows + 4096
     assert np.array_equal(ctx.spmv(x), y_orc)
     b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
@@ -158,16 +158,66 @@ def test_jagged_slices_on_fem_like_rows(monkeypatch):
         assert abs(got["k"] - orc["k"]) <= 2, (method, got["k"], orc["k"])
         assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max(), method
     ctx.close()
+    monkeypatch.setenv("BICG_SELL_WINDOW", "0")       # jagged slices, x gathered from memory (16-bit offsets)
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert ctx.flags()["jagged"] and ctx.flags()["col16"] and not ctx.flags()["window"]
+    assert np.array_equal(ctx.spmv(x), y_orc)
+    got = ctx.solve("pipe_bicgstab", b)
+    orc = O.solve("pipe_bicgstab", A.rows, row, col, val, b)
+    assert abs(got["k"] - orc["k"]) <= 2
+    ctx.close()
     monkeypatch.setenv("BICG_NO_COL16", "1")          # 32-bit columns in jagged slices
     ctx = H.Context(H.single_rank_blocks(A))
     assert ctx.flags()["jagged"] and not ctx.flags()["col16"]
     assert np.array_equal(ctx.spmv(x), y_orc)
     ctx.close()
     monkeypatch.delenv("BICG_NO_COL16")
+    monkeypatch.delenv("BICG_SELL_WINDOW")
     monkeypatch.setenv("BICG_SELL_LAYOUT", "pad")     # padded slices: most groups fall to the CSR kernel
     ctx = H.Context(H.single_rank_blocks(A))
     assert not ctx.flags()["jagged"]
     assert np.array_equal(ctx.spmv(x), y_orc)
+    ctx.close()
+
+
+def test_x_window_for_columns_far_from_the_row(monkeypatch):
+    """columns further than 32767 from the row (a 3-D stencil's z neighbours at full size): 16-bit offsets do not
+    apply, the x window in LDS would -- 16-bit slots, 10 bytes per non-zero, SpMV bit-identical -- but with equal
+    rows it is only taken on request (BICG_SELL_WINDOW=1; measured slower on the 256^3 Laplacian: as many staging
+    loads as gathers); a group whose window would not fit LDS switches the whole block back to memory gathers."""
+    H.lib().bicg_comm_init_single(0)
+    A = synth.from_offsets(150000, (0, 1, -1, 300, -300, 40000, -40000), diag_base=9.0, seed=3)
+    row, col, val = A.to_coo()
+    x = np.random.default_rng(6).standard_normal(A.rows)
+    y_orc = O.spmv(A.rows, row, col, val, x)
+    ctx = H.Context(H.single_rank_blocks(A))      # equal rows, perfectly coalesced gathers: padded slices, 32-bit columns
+    assert not ctx.flags()["window"] and not ctx.flags()["col16"] and not ctx.flags()["jagged"]
+    ctx.close()
+    monkeypatch.setenv("BICG_SELL_WINDOW", "1")   # on request
+    ctx = H.Context(H.single_rank_blocks(A))
+    fl = ctx.flags()
+    assert fl["window"] and fl["jagged"] and fl["col16"] and fl["all_sell"]
+    assert ctx.device_matrix_bytes() <= 10.6 * A.nnz + 8 * A.rows + 4096
+    assert np.array_equal(ctx.spmv(x), y_orc)
+    b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+    for method in ("bicgstab", "ca_bicgstab"):
+        orc = O.solve(method, A.rows, row, col, val, b)
+        got = ctx.solve(method, b)
+        assert abs(got["k"] - orc["k"]) <= 2 and np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max(), method
+    ctx.close()
+    monkeypatch.setenv("BICG_SELL_WINDOW", "0")
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert not ctx.flags()["window"] and not ctx.flags()["col16"]
+    assert np.array_equal(ctx.spmv(x), y_orc)
+    ctx.close()
+    monkeypatch.delenv("BICG_SELL_WINDOW")
+    # 40 scattered columns per row: a 256-row group touches > 4096 distinct x values
+    B = synth.random_rows(20000, 40, seed=11)
+    ctx = H.Context(H.single_rank_blocks(B))
+    assert not ctx.flags()["window"]
+    rb, cb, vb = B.to_coo()
+    xb = np.random.default_rng(7).standard_normal(B.rows)
+    assert np.array_equal(ctx.spmv(xb), O.spmv(B.rows, rb, cb, vb, xb))
     ctx.close()
 
 
