@@ -246,6 +246,7 @@ void comm_set(Comm *c)
 {
     if (g_comm) {
         bicg_dropin_release();       // the resident drop-in context was built on this communicator
+        contexts_orphan();           // contexts the caller still holds: they give back what lives in the transport
         delete g_comm;
     }
     g_comm = c;

@@ -70,6 +70,13 @@ extern "C" int bicg_coo_to_blocks_device(const unsigned int *row, const unsigned
     using namespace bicg;
     Comm *comm = comm_get();
     BICG_HIP(hipSetDevice(comm->device));
+    // rocPRIM reports hipGetLastError() after its launches: an error some EARLIER call of this thread left behind
+    // (a probe the caller tolerated, another library's) would be blamed on the sort. Start from a clean slate.
+    {
+        const hipError_t stale = hipGetLastError();
+        if (stale != hipSuccess && getenv("BICG_DEBUG"))
+            fprintf(stderr, "bicgstab_hip: note: clearing an earlier HIP error before the ingest: %s\n", hipGetErrorString(stale));
+    }
     const unsigned rows = hi - lo;
     if (nnz >= 0xFFFFFFFFul || rows >= 0x7FFFFFFFu) die("bicg_coo_to_blocks_device", "block too large for 32-bit indices");
     for (unsigned long e = 0; e < nnz; ++e)

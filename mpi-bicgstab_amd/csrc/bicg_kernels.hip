@@ -20,6 +20,7 @@
 #include "bicg_device.h"
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events bound to ONE kernel (roofline timing)
+#include <cstdio>
 #include <cstdlib>
 
 // This file is compiled several times (Makefile: BICG_PART = 0..5, in parallel): the sliced-ELL launchers instantiate
@@ -34,11 +35,27 @@
 namespace bicg {
 
 // launch with optional per-kernel timing events (kernel-accurate, unlike events recorded around a launch)
+// BICG_DEBUG=1: report a launch the runtime refused (or an error an earlier call left behind) where it happens
+static inline void launch_debug(const char *what)
+{
+    static const bool debug = getenv("BICG_DEBUG") != nullptr;
+    if (!debug) return;
+    const hipError_t err = hipGetLastError();
+    if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: HIP error \"%s\" noticed at: %s\n", hipGetErrorString(err), what);
+}
+#define BICG_LAUNCH(kernel, ...)                 \
+    do {                                         \
+        hipLaunchKernelGGL(kernel, __VA_ARGS__); \
+        launch_debug(#kernel);                   \
+    } while (0)
+
 template <class K, class... Args>
 static void launch_timed_lds(K kernel, dim3 g, dim3 b, unsigned lds_bytes, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args)
 {
+    launch_debug("(left behind by an earlier call)");
     if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, lds_bytes, st, e0, e1, 0, args...);
     else hipLaunchKernelGGL(kernel, g, b, lds_bytes, st, args...);
+    launch_debug(__PRETTY_FUNCTION__);
 }
 template <class K, class... Args>
 static void launch_timed(K kernel, dim3 g, dim3 b, hipStream_t st, hipEvent_t e0, hipEvent_t e1, Args... args)
@@ -962,7 +979,7 @@ __global__ void __launch_bounds__(kBlock) k_finish(Scal *S, Finish f)
 
 void launch_finish(const Launch &L)
 {
-    hipLaunchKernelGGL(k_finish, dim3(L.fin.roles & FIN_SHARDS ? kShards : 1), dim3(kBlock), 0, L.st, L.S, L.fin);
+    BICG_LAUNCH(k_finish, dim3(L.fin.roles & FIN_SHARDS ? kShards : 1), dim3(kBlock), 0, L.st, L.S, L.fin);
 }
 #endif
 
@@ -1838,32 +1855,32 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
     const unsigned grid = a.xcd_map ? ((a.ngroups + 7u) / 8u) * 8u : a.ngroups;
     const bool c16 = a.sell.col16 != nullptr;
     if (with_offd) {
-        if (c16) hipLaunchKernelGGL((k_spmm_sell<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((k_spmm_sell<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        if (c16) BICG_LAUNCH((k_spmm_sell<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
+        else BICG_LAUNCH((k_spmm_sell<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
     } else {
-        if (c16) hipLaunchKernelGGL((k_spmm_sell<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-        else hipLaunchKernelGGL((k_spmm_sell<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        if (c16) BICG_LAUNCH((k_spmm_sell<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
+        else BICG_LAUNCH((k_spmm_sell<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
     }
 }
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_colsum, dim3(kSpmmCols), dim3(kBlock), 0, st, partial, nwg, out);
+    BICG_LAUNCH(k_colsum, dim3(kSpmmCols), dim3(kBlock), 0, st, partial, nwg, out);
 }
 void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st)
 {
-    if (n) hipLaunchKernelGGL(k_rows_from_vectors, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, stride, nvec, n, xt);
+    if (n) BICG_LAUNCH(k_rows_from_vectors, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, stride, nvec, n, xt);
 }
 void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y, hipStream_t st)
 {
-    if (n) hipLaunchKernelGGL(k_vectors_from_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, yt, stride, nvec, n, y);
+    if (n) BICG_LAUNCH(k_vectors_from_rows, dim3((n + kBlock - 1) / kBlock), dim3(kBlock), 0, st, yt, stride, nvec, n, y);
 }
 #endif
 
 #if PART_IS(0)
 void launch_apply(Scal *S, int phase, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_apply, dim3(1), dim3(phase >= PH_SH_INIT ? kBlock : 1), 0, st, S, phase);
+    BICG_LAUNCH(k_apply, dim3(1), dim3(phase >= PH_SH_INIT ? kBlock : 1), 0, st, S, phase);
 }
 
 // gather the entries of x other ranks need into the contiguous send buffer
@@ -1878,12 +1895,12 @@ void launch_halo_pack(const double *x, const uint32_t *send_idx, uint32_t nsend,
     if (nsend == 0) return;
     unsigned g = (nsend + kBlock - 1) / kBlock;
     if (g > 1024) g = 1024;
-    hipLaunchKernelGGL(k_halo_pack, dim3(g), dim3(kBlock), 0, st, x, send_idx, nsend, sendbuf, S);
+    BICG_LAUNCH(k_halo_pack, dim3(g), dim3(kBlock), 0, st, x, send_idx, nsend, sendbuf, S);
 }
 
 void launch_apply_p2p(Scal *S, int phase, int n, const P2pRed &pr, unsigned long long timeout_ticks, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_apply_p2p, dim3(1), dim3(kBlock), 0, st, S, phase, n, pr, timeout_ticks);
+    BICG_LAUNCH(k_apply_p2p, dim3(1), dim3(kBlock), 0, st, S, phase, n, pr, timeout_ticks);
 }
 
 __global__ void __launch_bounds__(kBlock) k_halo_push(const double *x, const uint32_t *idx, uint32_t n,
@@ -1901,7 +1918,7 @@ void launch_halo_push(const double *x, const uint32_t *send_idx, uint32_t nsend,
                       const unsigned long long *dst_stride, unsigned seq, Scal *S, hipStream_t st)
 {
     if (nsend == 0) return;
-    hipLaunchKernelGGL(k_halo_push, dim3((nsend + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, send_idx, nsend, dst0,
+    BICG_LAUNCH(k_halo_push, dim3((nsend + kBlock - 1) / kBlock), dim3(kBlock), 0, st, x, send_idx, nsend, dst0,
                        dst_stride, seq, (const Scal *)S);
 }
 
@@ -1924,7 +1941,7 @@ void launch_halo_unpack(const llword *ring, uint32_t halo, unsigned seq, double 
                         unsigned long long timeout_ticks, hipStream_t st)
 {
     if (halo == 0) return;
-    hipLaunchKernelGGL(k_halo_unpack, dim3((halo + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ring, halo, seq, tail, S,
+    BICG_LAUNCH(k_halo_unpack, dim3((halo + kBlock - 1) / kBlock), dim3(kBlock), 0, st, ring, halo, seq, tail, S,
                        timeout_ticks);
 }
 
@@ -1947,7 +1964,7 @@ __global__ void __launch_bounds__(64) k_p2p_barrier(P2pRed pr, unsigned long lon
 
 void launch_p2p_barrier(const P2pRed &pr, unsigned long long timeout_ticks, Scal *S, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p2p_barrier, dim3(1), dim3(64), 0, st, pr, timeout_ticks, S);
+    BICG_LAUNCH(k_p2p_barrier, dim3(1), dim3(64), 0, st, pr, timeout_ticks, S);
 }
 
 // Second part of the transport self-test: the HALO pattern -- every rank stores `entries` values per
@@ -2002,13 +2019,13 @@ __global__ void __launch_bounds__(kBlock) k_p2p_ringtest(P2pRed pr, llword *cons
 void launch_p2p_ringtest(const P2pRed &pr, llword *const *rings, int entries, unsigned seq0, int rounds, unsigned bar_seq0,
                          unsigned long long timeout_ticks, int *status, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p2p_ringtest, dim3(1), dim3(kBlock), 0, st, pr, rings, entries, seq0, rounds, bar_seq0, timeout_ticks, status);
+    BICG_LAUNCH(k_p2p_ringtest, dim3(1), dim3(kBlock), 0, st, pr, rings, entries, seq0, rounds, bar_seq0, timeout_ticks, status);
 }
 
 void launch_p2p_selftest(const P2pRed &pr, unsigned seq0, int rounds, unsigned long long timeout_ticks, int *status,
                          hipStream_t st)
 {
-    hipLaunchKernelGGL(k_p2p_selftest, dim3(1), dim3(kBlock), 0, st, pr, seq0, rounds, timeout_ticks, status);
+    BICG_LAUNCH(k_p2p_selftest, dim3(1), dim3(kBlock), 0, st, pr, seq0, rounds, timeout_ticks, status);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2152,11 +2169,11 @@ static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
         abort();
     }
     if constexpr ((modes >> RED_WAVE) & 1)
-        if (mode == RED_WAVE) { hipLaunchKernelGGL((k_vec<F, RED_WAVE>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+        if (mode == RED_WAVE) { BICG_LAUNCH((k_vec<F, RED_WAVE>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
     if constexpr (((modes >> RED_TICKET_HEAVY) & 1) && F::ND > 0)
-        if (mode == RED_TICKET_HEAVY) { hipLaunchKernelGGL((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+        if (mode == RED_TICKET_HEAVY) { BICG_LAUNCH((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
     if constexpr ((modes >> RED_TICKET) & 1)
-        hipLaunchKernelGGL((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin);
+        BICG_LAUNCH((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin);
 }
 // shifted solvers and kernel-level entry points: scalar block updated in place, ticket reductions
 template <class F>
@@ -2626,7 +2643,7 @@ void launch_scale(double *x, uint32_t n, double a, hipStream_t s)
     if (n == 0) return;
     unsigned g = (n + kBlock - 1) / kBlock;
     if (g > (unsigned)kMaxGrid) g = kMaxGrid;
-    hipLaunchKernelGGL(k_scale, dim3(g), dim3(kBlock), 0, s, x, n, a);
+    BICG_LAUNCH(k_scale, dim3(g), dim3(kBlock), 0, s, x, n, a);
 }
 
 // ---- pipelined shifted variant (reference src/shifted_solver.c:794-843)

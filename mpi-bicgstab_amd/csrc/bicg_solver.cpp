@@ -56,7 +56,8 @@ template <class T> T *dev_upload_padded(const T *src, size_t n, size_t pad)
 }  // namespace
 
 struct bicg_ctx {
-    Comm *comm = nullptr;
+    Comm *comm = nullptr;                  // null once the communicator has been replaced (contexts_orphan)
+    int device = 0;
     int nranks = 1, rank = 0;
     uint32_t n_loc = 0, n_glob = 0, halo = 0, stride = 0, nnz_d = 0, nnz_o = 0;
 
@@ -211,6 +212,20 @@ struct bicg_ctx {
         return r;
     }
 };
+
+namespace {
+// contexts alive in this process: a context holds pointers into its communicator (transport, peer-to-peer state),
+// so replacing the communicator (bicg_comm_init_*, bicg_comm_finalize) orphans them -- they can still be
+// destroyed, nothing else
+std::vector<bicg_ctx *> g_live;
+
+void use_device(const bicg_ctx *c)
+{
+    if (!c->comm)
+        die("bicg_ctx", "the communicator this context was built on has been replaced or finalized; only bicg_destroy is valid now");
+    BICG_HIP(hipSetDevice(c->device));
+}
+}  // namespace
 
 namespace {
 
@@ -808,7 +823,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.check_every < 1) o.check_every = 1;
     c->method = method;
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     // Plain and CA-BiCGStab need every scalar right after the kernel that produces its sums: the ticket
     // chain at the end of the producer (memory system draining) is then the shortest path. The
     // pipelined solvers defer their groups across an SpMV (src/solver.c:363-367, 377-385): there the sums
@@ -913,7 +928,7 @@ bool graph_iteration(bicg_ctx *c, Driver &d)
 int run_iterate(bicg_ctx *c, int nsteps)
 {
     const bicg_options &o = c->opt;
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     Driver d(c, c->method, o.krr, o.nrr);
     const bool talk = c->rank == 0 && !o.quiet;
     const double t0 = now_sec();
@@ -1015,7 +1030,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.check_every < 1) o.check_every = 1;
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
     const size_t st = c->stride, n = c->n_loc;
 
@@ -1153,7 +1168,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
     if (o.max_iter < 0) o.max_iter = 0;
     if (o.check_every < 1) o.check_every = 1;
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
     const size_t st = c->stride, n = c->n_loc;
 
@@ -1424,7 +1439,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (info->rows != info->cols) { fprintf(stderr, "ERROR: bicg_create: matrix is not square\n"); return nullptr; }
 
     bicg_ctx *c = new bicg_ctx;
-    c->comm = comm; c->nranks = comm->nranks; c->rank = comm->rank;
+    c->comm = comm; c->device = comm->device; c->nranks = comm->nranks; c->rank = comm->rank;
+    g_live.push_back(c);
     c->n_loc = diag->rows; c->n_glob = info->rows;
     c->nnz_d = diag->rows ? diag->ptr[diag->rows] : 0u;
     const int P = c->nranks;
@@ -1834,21 +1850,41 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     return c;
 }
 
+namespace {
+// the halo landing ring lives in the transport's shared memory: give it back while the transport exists
+void release_p2p(bicg_ctx *c)
+{
+    if (!c->p2p) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    c->p2p->unmap(c->ring_mapped);
+    c->p2p->release(c->halo_ring);
+    c->ring_mapped.clear(); c->halo_ring = nullptr; c->p2p = nullptr;
+}
+}  // namespace
+
+// called by comm_set() before the communicator goes away (bicg_comm.cpp)
+extern "C++" {
+void bicg::contexts_orphan()
+{
+    for (bicg_ctx *c : g_live) { release_p2p(c); c->comm = nullptr; }
+}
+}
+
 void bicg_destroy(bicg_ctx *c)
 {
     if (!c) return;
-    (void)hipSetDevice(c->comm->device);
+    g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
+    (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
     void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->win_ptr, c->win_runs, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
-    if (c->p2p) {
-        c->p2p->unmap(c->ring_mapped);
-        c->p2p->release(c->halo_ring);
-        (void)hipFree(c->push_dst0); (void)hipFree(c->push_stride);
-        if (c->glist_ll) (void)hipFree(c->glist_ll);
-    }
+    release_p2p(c);
+    if (c->push_dst0) (void)hipFree(c->push_dst0);
+    if (c->push_stride) (void)hipFree(c->push_stride);
+    if (c->glist_ll) (void)hipFree(c->glist_ll);
     if (c->hS) (void)hipHostFree(c->hS);
     if (c->h_alarm) (void)hipHostFree(c->h_alarm);
     for (int i = 0; i < kEvRing; ++i) {
@@ -1863,7 +1899,7 @@ void bicg_destroy(bicg_ctx *c)
 
 int bicg_load(bicg_ctx *c, const double *x0, const double *b)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     BICG_HIP(hipMemcpy(c->v.x, x0, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
     BICG_HIP(hipMemcpy(c->v.r, b, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
     return 0;
@@ -1871,7 +1907,7 @@ int bicg_load(bicg_ctx *c, const double *x0, const double *b)
 
 int bicg_fetch(bicg_ctx *c, double *x, double *r)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     BICG_HIP(hipStreamSynchronize(c->sc));
     if (x) BICG_HIP(hipMemcpy(x, c->v.x, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
     if (r) BICG_HIP(hipMemcpy(r, c->v.r, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
@@ -1884,7 +1920,7 @@ int bicg_run_iterate(bicg_ctx *c, int nsteps) { return run_iterate(c, nsteps); }
 int bicg_run_end(bicg_ctx *c, bicg_result *res) { return run_end(c, res); }
 int bicg_sync(bicg_ctx *c)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     BICG_HIP(hipStreamSynchronize(c->sc));
     if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
     return 0;
@@ -1918,7 +1954,7 @@ static void reset_scal(bicg_ctx *c)
 
 int bicg_spmv(bicg_ctx *c, const double *x, double *y)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     reset_scal(c);
     BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
     c->time_kernels = false;
@@ -1931,7 +1967,7 @@ int bicg_spmv(bicg_ctx *c, const double *x, double *y)
 
 double bicg_dot(bicg_ctx *c, const double *x, const double *y)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     reset_scal(c);
     BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemcpyAsync(c->v.s, y, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
@@ -1947,7 +1983,7 @@ double bicg_dot(bicg_ctx *c, const double *x, const double *y)
 int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b_loc, const double *sigma, int nsig,
                            double *relres_out)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     reset_scal(c);
     const size_t n = c->n_loc;
     BICG_HIP(hipMemcpyAsync(c->v.b, b_loc, sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
@@ -2002,7 +2038,7 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
 // when the matrix is not entirely on the sliced-ELL path. ms_out (optional): device time of the passes.
 int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nvec, double *y_loc_set, double *ms_out)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     if (!c->spmm_ok) return 1;
     reset_scal(c);
     spmm_buffers(c);
@@ -2034,7 +2070,7 @@ int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nve
 
 int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
 {
-    BICG_HIP(hipSetDevice(c->comm->device));
+    use_device(c);
     reset_scal(c);
     std::vector<double> ones(c->n_loc, 1.0);
     BICG_HIP(hipMemcpyAsync(c->v.p, ones.data(), sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));

@@ -23,6 +23,7 @@ from mpi_bicgstab_amd import hipsolver as H
 from mpi_bicgstab_amd import synth
 
 pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 GOLDEN = sorted(p for p in glob.glob(os.path.join(os.path.dirname(__file__), "golden", "*.npz"))
                 if not os.path.basename(p).startswith(("shifted_", "switching_", "ranks_")))
@@ -243,6 +244,30 @@ def test_adaptive_residual_replacement():
     assert np.sqrt(res["dot_r"] / res["dot_zero"]) <= 1e-15
     assert np.abs(res["x"] - 1.0).max() <= 1e-9
     ctx.close()
+
+
+def test_context_outliving_its_communicator():
+    """bicg_comm_init_* replaces the process communicator: a context built on the old one gives back what lives
+    in the transport at that moment and can still be destroyed (it used to read the freed communicator in
+    bicg_destroy -- a stale "invalid device ordinal" that rocPRIM then reported from the next ingest);
+    using it for anything else is refused loudly."""
+    import subprocess
+    import sys
+    A = synth.stencil7(6)
+    ctx = H.Context(H.single_rank_blocks(A))
+    y = ctx.spmv(np.ones(A.rows))
+    H.lib().bicg_comm_init_single(0)
+    ctx.close()
+    ctx2 = H.Context(H.single_rank_blocks(A))
+    assert np.array_equal(ctx2.spmv(np.ones(A.rows)), y)
+    ctx2.close()
+    code = ("import sys; sys.path.insert(0, %r)\nimport numpy as np\n"
+            "from mpi_bicgstab_amd import hipsolver as H, synth\n"
+            "A = synth.stencil7(6); H.lib().bicg_comm_init_single(0)\n"
+            "ctx = H.Context(H.single_rank_blocks(A)); H.lib().bicg_comm_init_single(0)\n"
+            "print('computed', ctx.spmv(np.ones(A.rows)).sum())\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300)
+    assert out.returncode != 0 and "computed" not in out.stdout and "communicator" in out.stderr
 
 
 def test_device_ingest_matches_host():
