@@ -125,8 +125,8 @@ struct bicg_ctx {
     bool spmm_ok = false;        // spmm_possible() on every rank (the SpMM exchanges the halos of all its vectors at once)
     bool fuse_plan_ok = false;   // every row on the sliced-ELL path and one launch per SpMV -- ON EVERY RANK (the fused and the
                                  // separate flow exchange their dot groups differently: the choice is collective)
-    bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues -- chosen for ranks whose
-                                 // launches are latency-bound (< 6 M local non-zeros; BICG_FUSE_PIPE=0/1 overrides)
+    bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues (BICG_FUSE_PIPE=0/1 overrides)
+    bool fuse_small = true;      // ... the average block has < 6 M non-zeros: fused whatever the layout
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
     unsigned wg_cap = 0;         // ranks sharing this GPU (tests): workgroups per launch that may wait for another rank
     double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
@@ -438,9 +438,14 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     };
 
     if (epi && !(c->glist_all && c->nblk == 0 && (c->single() || fused))) die("internal", "SpMV epilogue on a multi-launch SpMV");
-    if (epi && c->wg_cap) {      // every row workgroup of this launch waits for the scalars: all ranks' launches must fit on the GPU
+    // Epilogue launches publish one partial row per WAVEFRONT for 32 helper workgroups to add: beyond a few thousand
+    // workgroups that sum, not the matrix, sets the pace (16.8 M rows = 65 k workgroups: 4.6 instead of 1.25 ms per
+    // iteration), so a workgroup takes several 256-row groups. Ranks sharing a GPU (tests): every row workgroup of
+    // the launch waits for the scalars, all ranks' launches must fit on the GPU together.
+    const unsigned epi_cap = c->wg_cap ? c->wg_cap : 8192u;
+    if (epi && c->ng_int + c->ng_bnd > epi_cap) {
         const unsigned ng = c->ng_int + c->ng_bnd;
-        a.groups_per_wg = std::max<int>(a.groups_per_wg, (int)((ng + c->wg_cap - 1) / c->wg_cap));
+        a.groups_per_wg = std::max<int>(a.groups_per_wg, (int)((ng + epi_cap - 1) / epi_cap));
         red.expected = sell_grid(ng, a.groups_per_wg) + g_ci;
         a.red.expected = red.expected;
         c->grp.nparts = red.expected * (kBlock / 64);
@@ -1471,10 +1476,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             return nullptr;
         }
         c->overlap = total / (uint64_t)P >= 6000000u;
-        // two launches per pipelined iteration pay on a 200 k-row rank (27.7 vs 33.9 us; 400 k rows: 47.4 vs 49.8), not
-        // on 800 k rows (86.8 vs 81.4) or 1.6 M (175 vs 163 us). Like the enqueue mode this changes the sequence of
-        // exchanges, so it is decided from the average over all ranks, never from the local block alone.
-        c->fuse_pipe = total / (uint64_t)P < 6000000u;
+        // two launches per pipelined iteration (phases in the SpMV epilogues): latency on small ranks (200 k rows 26.2
+        // vs 34.1 us), the traffic of v and t on large ones (1.6 M rows 159 vs 163 us, banded b = 8 158 vs 169, the
+        // 16.8 M-row Laplacian share 1.14 vs 1.25 ms) -- except with x windows, whose epilogue kernels at 4 waves per
+        // SIMD lose on large blocks (FEM-like 189 vs 175 us). Like the enqueue mode this changes the sequence of
+        // exchanges, so it is decided from facts all ranks share (see fuse_plan_ok), never from the local block alone.
+        c->fuse_small = total / (uint64_t)P < 6000000u;
     }
     if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
@@ -1832,6 +1839,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         set_vec_grid_cap(c->wg_cap);
     }
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
+    c->fuse_pipe = c->fuse_small || all_ranks(comm, c->win_slots == 0);
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
     c->spmm_ok = all_ranks(comm, spmm_possible(c));
     c->fuse_plan_ok = all_ranks(comm, c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused)));
