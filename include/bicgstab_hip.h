@@ -301,6 +301,16 @@ int bicg_halo_send_lists(int rank, int nranks, const INFO_Matrix *info, unsigned
  * rowblk[nblk+1] (caller provides rows+1 entries) */
 unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int rows, unsigned int chunk,
                              unsigned int max_rows, unsigned int *rowblk);
+/* x windows of the sliced-ELL plan for ragged rows: for every group of group_rows rows
+ * (group_mask[g] != 0, or all when NULL) the columns its rows touch, merged into runs of consecutive columns
+ * (gaps of <= gap unused columns are bridged). runs[2i] = first column, runs[2i+1] = (first slot << 16) | length;
+ * win_ptr[g] .. win_ptr[g+1] index a group's runs; *slots_used = slots of the largest window. Returns the
+ * number of runs, -1 when a group needs more than max_slots slots. runs / win_ptr / slots_used may be NULL
+ * (count only). bicg_window_slot: the slot of column c in the window runs[2*first .. 2*end). */
+long bicg_window_plan(const unsigned int *ptr, const unsigned int *col, unsigned int rows, unsigned int group_rows,
+                      const char *group_mask, unsigned int max_slots, unsigned int gap, unsigned int *win_ptr,
+                      unsigned int *runs, unsigned int *slots_used);
+unsigned int bicg_window_slot(const unsigned int *runs, unsigned int first, unsigned int end, unsigned int c);
 
 /* Matrix-Market block loader (host only): what MPI_csr_load_matrix_block produces for `rank` of
  * `nranks` (reference src/matrix.c:402-419) -- diag block with local columns, offd block with global

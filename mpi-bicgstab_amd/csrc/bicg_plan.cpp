@@ -97,3 +97,64 @@ extern "C" unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int ro
     }
     return nblk;
 }
+
+
+// ---- x windows (SellDev::win_*, bicg_device.h): for every marked group of `group_rows` rows, the columns its rows
+// touch, merged into runs of consecutive columns; gaps of up to `gap` unused values are copied along (cheaper than
+// another run). A run is {first column, (first slot << 16) | length}. Returns the number of runs, or -1 when some
+// group needs more than max_slots (<= 65535) slots. runs == NULL: count only. Host-only, O(nnz + column span / 64).
+extern "C" long bicg_window_plan(const unsigned int *ptr, const unsigned int *col, unsigned int rows, unsigned int group_rows,
+                                 const char *group_mask, unsigned int max_slots, unsigned int gap, unsigned int *win_ptr,
+                                 unsigned int *runs, unsigned int *slots_used)
+{
+    const unsigned ngroups = (rows + group_rows - 1) / group_rows;
+    std::vector<unsigned long long> bm;
+    std::vector<unsigned> cols;
+    long nruns = 0;
+    unsigned most = 0;
+    if (win_ptr) win_ptr[0] = 0;
+    for (unsigned g = 0; g < ngroups; ++g) {
+        if (win_ptr) win_ptr[g + 1] = (unsigned)nruns;
+        if (group_mask && !group_mask[g]) continue;
+        const unsigned r0 = g * group_rows, r1 = std::min(rows, r0 + group_rows);
+        const unsigned j0 = ptr[r0], j1 = ptr[r1];
+        if (j0 == j1) continue;
+        unsigned lo = 0xFFFFFFFFu, hi = 0;
+        for (unsigned j = j0; j < j1; ++j) { lo = std::min(lo, col[j]); hi = std::max(hi, col[j]); }
+        cols.clear();
+        if ((unsigned long long)hi - lo < (1ull << 24)) {       // a bitmap over the group's column span
+            bm.assign(((size_t)hi - lo) / 64 + 1, 0ull);
+            for (unsigned j = j0; j < j1; ++j) { const unsigned d = col[j] - lo; bm[d >> 6] |= 1ull << (d & 63); }
+            for (size_t w = 0; w < bm.size(); ++w)
+                for (unsigned long long bits = bm[w]; bits; bits &= bits - 1)
+                    cols.push_back(lo + (unsigned)(w * 64) + (unsigned)__builtin_ctzll(bits));
+        } else {
+            cols.assign(col + j0, col + j1);
+            std::sort(cols.begin(), cols.end());
+            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+        }
+        unsigned slots = 0;
+        for (size_t i = 0; i < cols.size();) {
+            size_t k = i;
+            while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= gap + 1 && cols[k + 1] - cols[i] < 65535u) ++k;
+            const unsigned len = cols[k] - cols[i] + 1;
+            if (slots + len > max_slots || slots + len > 65535u) return -1;
+            if (runs) { runs[2 * nruns] = cols[i]; runs[2 * nruns + 1] = (slots << 16) | len; }
+            ++nruns;
+            slots += len;
+            i = k + 1;
+        }
+        if (win_ptr) win_ptr[g + 1] = (unsigned)nruns;
+        most = std::max(most, slots);
+    }
+    if (slots_used) *slots_used = most;
+    return nruns;
+}
+
+// the slot of column `c` in the window whose runs are runs[2*first .. 2*end): last run whose first column is <= c
+extern "C" unsigned int bicg_window_slot(const unsigned int *runs, unsigned int first, unsigned int end, unsigned int c)
+{
+    unsigned a = first, b = end;
+    while (b - a > 1) { const unsigned m = (a + b) / 2; if (runs[2 * m] <= c) a = m; else b = m; }
+    return (runs[2 * a + 1] >> 16) + (c - runs[2 * a]);
+}

@@ -1603,44 +1603,19 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         (touches_halo ? gl_bnd : gl_int).push_back(g);
     }
     if (want_win) {
-        // per group: the columns its rows touch (a bitmap over the group's column span), merged into runs of
-        // consecutive columns (gaps of up to kWinGap unused values are copied along: cheaper than another run)
+        // per group: the columns its rows touch, merged into runs of consecutive columns (bicg_plan.cpp)
         constexpr uint32_t kWinGap = 8;
-        win_ptr.assign(ngroups + 1, 0u); win_runs.clear(); win_slots = 0;
-        std::vector<uint64_t> bm;
-        std::vector<uint32_t> cols;
         bool ok = sell_entries > 0;
-        for (uint32_t g = 0; g < ngroups && ok; ++g) {
-            win_ptr[g + 1] = win_ptr[g];
-            if (!group_is_sell[g]) continue;
-            const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
-            const uint32_t j0 = diag->ptr[r0], j1 = diag->ptr[r1];
-            if (j0 == j1) continue;
-            uint32_t lo = UINT32_MAX, hi = 0;
-            for (uint32_t j = j0; j < j1; ++j) { lo = std::min(lo, diag->col[j]); hi = std::max(hi, diag->col[j]); }
-            cols.clear();
-            if ((uint64_t)hi - lo < (1ull << 24)) {
-                bm.assign(((size_t)hi - lo) / 64 + 1, 0ull);
-                for (uint32_t j = j0; j < j1; ++j) { const uint32_t d = diag->col[j] - lo; bm[d >> 6] |= 1ull << (d & 63); }
-                for (size_t w = 0; w < bm.size(); ++w)
-                    for (uint64_t bits = bm[w]; bits; bits &= bits - 1) cols.push_back(lo + (uint32_t)(w * 64) + (uint32_t)__builtin_ctzll(bits));
-            } else {
-                cols.assign(diag->col + j0, diag->col + j1);
-                std::sort(cols.begin(), cols.end());
-                cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
-            }
-            uint32_t slots = 0;
-            for (size_t i = 0; i < cols.size();) {
-                size_t k = i;
-                while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= kWinGap + 1 && cols[k + 1] - cols[i] < 65535u) ++k;
-                const uint32_t len = cols[k] - cols[i] + 1;
-                if (slots + len > kWinMaxSlots) { ok = false; break; }
-                win_runs.push_back(make_uint2(cols[i], (slots << 16) | len));
-                slots += len;
-                i = k + 1;
-            }
-            win_ptr[g + 1] = (uint32_t)win_runs.size();
-            win_slots = std::max(win_slots, slots);
+        long nruns = ok ? bicg_window_plan(diag->ptr, diag->col, nrows, kGroupRows, group_is_sell.data(), kWinMaxSlots, kWinGap,
+                                           nullptr, nullptr, nullptr) : -1;
+        if (nruns >= 0) {
+            win_ptr.assign(ngroups + 1, 0u);
+            win_runs.assign((size_t)nruns + 1, make_uint2(0u, 0u));
+            static_assert(sizeof(uint2) == 2 * sizeof(unsigned int), "run = two 32-bit words");
+            bicg_window_plan(diag->ptr, diag->col, nrows, kGroupRows, group_is_sell.data(), kWinMaxSlots, kWinGap, win_ptr.data(),
+                             reinterpret_cast<unsigned int *>(win_runs.data()), &win_slots);
+        } else {
+            ok = false;
         }
         if (!ok) {                          // some group's window does not fit: no windows for this block
             want_win = false; win_slots = 0; win_runs.clear(); win_ptr.clear();
@@ -1648,11 +1623,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         }
     }
     const bool win = want_win && win_slots > 0;
-    // the slot of a column inside its group's window
     auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
-        uint32_t a = win_ptr[g], b = win_ptr[g + 1];                 // last run whose first column is <= col
-        while (b - a > 1) { const uint32_t m = (a + b) / 2; if (win_runs[m].x <= col) a = m; else b = m; }
-        return (win_runs[a].y >> 16) + (col - win_runs[a].x);
+        return bicg_window_slot(reinterpret_cast<const unsigned int *>(win_runs.data()), win_ptr[g], win_ptr[g + 1], col);
     };
     c->sell_entries = sell_entries;
     c->sell_jag = jag && sell_entries > 0;

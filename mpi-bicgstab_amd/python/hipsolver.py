@@ -59,7 +59,7 @@ EXPORTS = [
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
-    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_version",
+    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version",
 ]
 
 _lib = None
@@ -114,6 +114,10 @@ def lib():
                                            C.c_void_p, _up]
         L.bicg_row_blocks.argtypes = [_up, C.c_uint, C.c_uint, C.c_uint, _up]
         L.bicg_row_blocks.restype = C.c_uint
+        L.bicg_window_plan.argtypes = [_up, _up, C.c_uint, C.c_uint, C.c_char_p, C.c_uint, C.c_uint, _up, _up, _up]
+        L.bicg_window_plan.restype = C.c_long
+        L.bicg_window_slot.argtypes = [_up, C.c_uint, C.c_uint, C.c_uint]
+        L.bicg_window_slot.restype = C.c_uint
         L.bicg_version.restype = C.c_char_p
         for name in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
             getattr(L, name).argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp]
@@ -125,6 +129,23 @@ def lib():
 
 def _d(a):
     return a.ctypes.data_as(_dp)
+
+
+def window_plan(A: CSR, group_rows: int = 256, max_slots: int = 4096, gap: int = 8):
+    """x windows of a block (bicg_window_plan): (win_ptr, runs[n][2], slots of the largest window) or None when a
+    group does not fit max_slots"""
+    ptr = np.ascontiguousarray(A.ptr, dtype=np.uint32)
+    col = np.ascontiguousarray(A.col, dtype=np.uint32)
+    up = lambda a: a.ctypes.data_as(_up)
+    n = lib().bicg_window_plan(up(ptr), up(col), A.rows, group_rows, None, max_slots, gap, None, None, None)
+    if n < 0:
+        return None
+    ngroups = (A.rows + group_rows - 1) // group_rows
+    win_ptr = np.zeros(ngroups + 1, dtype=np.uint32)
+    runs = np.zeros((max(n, 1), 2), dtype=np.uint32)
+    used = C.c_uint(0)
+    lib().bicg_window_plan(up(ptr), up(col), A.rows, group_rows, None, max_slots, gap, up(win_ptr), up(runs), C.byref(used))
+    return win_ptr, runs[:n], int(used.value)
 
 
 class HostBlocks:

@@ -199,3 +199,44 @@ def test_hot_kernels_stay_lean():
     assert len(epi) >= 16
     for k in epi:
         assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
+
+
+def test_window_plan_covers_every_column_once():
+    """bicg_window_plan (x windows of the ragged-rows SpMV): per 256-row group the runs
+    are sorted, disjoint, cover every column the group touches, their slots are consecutive, gaps of <= 8 unused
+    columns are bridged and nothing larger; bicg_window_slot inverts them; a group that touches too many
+    scattered columns makes the whole plan fail."""
+    A = synth.fem_like(n=117 * 117 * 3)
+    plan = H.window_plan(A)
+    assert plan is not None
+    win_ptr, runs, used = plan
+    ptr = A.ptr.astype(np.int64)
+    ngroups = (A.rows + 255) // 256
+    assert len(win_ptr) == ngroups + 1 and win_ptr[-1] == len(runs) and 0 < used <= 4096
+    up = C.POINTER(C.c_uint)
+    flat = np.ascontiguousarray(runs.reshape(-1))
+    most = 0
+    for g in (0, 1, 7, ngroups // 2, ngroups - 1):
+        r0, r1 = g * 256, min(A.rows, g * 256 + 256)
+        cols = np.unique(A.col[ptr[r0]:ptr[r1]]).astype(np.int64)
+        rg = runs[win_ptr[g]:win_ptr[g + 1]].astype(np.int64)
+        start, slot0, length = rg[:, 0], rg[:, 1] >> 16, rg[:, 1] & 0xFFFF
+        assert np.all(np.diff(start) > 0) and np.all(start[1:] > start[:-1] + length[:-1] - 1 + 8)   # gaps > 8 between runs
+        assert np.array_equal(slot0, np.concatenate(([0], np.cumsum(length)[:-1])))               # slots are consecutive
+        covered = np.concatenate([np.arange(s, s + l) for s, l in zip(start, length)])
+        assert np.all(np.isin(cols, covered))
+        assert np.isin(start, cols).all() and np.isin(start + length - 1, cols).all()             # runs begin and end on a used column
+        inside = np.isin(covered, cols)
+        # a bridged gap is at most 8 unused columns long
+        gaps = np.diff(np.flatnonzero(np.concatenate(([True], inside, [True])))) - 1
+        assert gaps.max() <= 8
+        for c in cols[:: max(1, len(cols) // 50)]:
+            s = H.lib().bicg_window_slot(flat.ctypes.data_as(up), int(win_ptr[g]), int(win_ptr[g + 1]), int(c))
+            i = np.searchsorted(start, c, side="right") - 1
+            assert s == slot0[i] + (c - start[i]) and s < used
+        most = max(most, int(length.sum()))
+    assert most <= used
+    assert used == 3 * (2 * 117 + 258)                    # the 27-point stencil: per z-plane the three y-neighbour clusters overlap
+    B = synth.random_rows(20000, 40, seed=11)             # ~5000 scattered columns per group
+    assert H.window_plan(B) is None
+    assert H.window_plan(B, max_slots=65535) is not None
