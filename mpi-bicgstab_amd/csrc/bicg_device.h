@@ -219,6 +219,10 @@ struct SellDev {
     const uint32_t *win_ptr;
     const uint2    *win_runs;
     uint32_t        win_slots;   // LDS doubles the largest group needs (0: no window)
+    // with windows the x gather is an LDS read, so lanes need not hold CONSECUTIVE rows any more: the rows of a
+    // 256-row group are dealt to the lanes by decreasing length (perm[g * 256 + lane] = row within the group),
+    // which makes the four slices of a group as long as their own longest row instead of the group's (null: lane = row)
+    const unsigned char *perm;
 };
 enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4 };
 constexpr uint32_t kWinMaxSlots = 4096;      // 32 KB of LDS per workgroup: 4 workgroups per CU

@@ -1221,6 +1221,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
     const double *__restrict__ x = a.x;
     const unsigned g = a.glist ? a.glist[gi] : gi;
     row = g * kGroupRows + tid;                                // = slice * 64 + lane
+    if (LAY == LAY_JAGW && a.sell.perm) row = g * kGroupRows + a.sell.perm[(size_t)g * kGroupRows + tid];
     const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
     live = row < a.nrows;
 

@@ -78,6 +78,7 @@ struct bicg_ctx {
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
     uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
     uint2 *win_runs = nullptr;
+    unsigned char *sell_perm = nullptr;    // SellDev::perm
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
     uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
     uint64_t sell_entries = 0, sell_nnz = 0;
@@ -392,7 +393,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     SpmvArgs a;
     a.fin = fin;
     a.epi = c->v;
-    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -586,7 +587,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
     launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
-    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots};
+    a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.nrows = c->n_loc; a.ngroups = c->ng_int + c->ng_bnd;
     a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
@@ -1626,6 +1627,35 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
         return bicg_window_slot(reinterpret_cast<const unsigned int *>(win_runs.data()), win_ptr[g], win_ptr[g + 1], col);
     };
+    // With windows: deal the rows of every group to the lanes by decreasing length (SellDev::perm). The group's
+    // entries stay where they are as a whole; the slices inside it change length.
+    std::vector<unsigned char> perm;
+    if (win && !(getenv("BICG_SELL_SORT") && atoi(getenv("BICG_SELL_SORT")) == 0)) {
+        perm.assign((size_t)ngroups * kGroupRows, 0);
+        uint64_t at = 0;
+        for (uint32_t g = 0; g < ngroups; ++g) {
+            unsigned char *pg = perm.data() + (size_t)g * kGroupRows;
+            for (uint32_t t = 0; t < kGroupRows; ++t) pg[t] = (unsigned char)t;
+            if (!group_is_sell[g]) continue;
+            const uint32_t r0 = g * kGroupRows;
+            auto len_of = [&](unsigned t) -> uint32_t { return r0 + t < nrows ? diag->ptr[r0 + t + 1] - diag->ptr[r0 + t] : 0u; };
+            std::stable_sort(pg, pg + kGroupRows, [&](unsigned char x, unsigned char y) { return len_of(x) > len_of(y); });
+            for (uint32_t w = 0; w < kGroupRows / kSliceRows; ++w) {
+                const uint32_t sl = g * (kGroupRows / kSliceRows) + w;
+                if (sl >= nslices) break;
+                uint32_t longest = 0; uint64_t sum = 0;
+                for (uint32_t l = 0; l < kSliceRows; ++l) { const uint32_t n = len_of(pg[w * kSliceRows + l]); longest = std::max(longest, n); sum += n; }
+                slice_len[sl] = longest; slice_base[sl] = (uint32_t)at;
+                at += sum;
+            }
+        }
+        if (at != sell_entries) die("bicg_create", "internal: sorted slices do not add up");
+    }
+    auto row_of = [&](uint32_t sl, uint32_t lane) -> uint32_t {      // the row lane `lane` of slice `sl` works on
+        if (perm.empty()) return sl * kSliceRows + lane;
+        const uint32_t g = sl / (kGroupRows / kSliceRows), w = sl % (kGroupRows / kSliceRows);
+        return g * kGroupRows + perm[(size_t)g * kGroupRows + w * kSliceRows + lane];
+    };
     c->sell_entries = sell_entries;
     c->sell_jag = jag && sell_entries > 0;
     std::vector<double> sval(sell_entries ? sell_entries : 1, 0.0);
@@ -1652,11 +1682,11 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (jag) {
         for (uint32_t sl = 0; sl < nslices; ++sl) {
             if (!group_is_sell[sl / (kGroupRows / kSliceRows)]) continue;
-            const uint32_t r0 = sl * kSliceRows, r1 = std::min(nrows, r0 + (uint32_t)kSliceRows);
             size_t e = slice_base[sl];
             for (uint32_t k = 0; k < slice_len[sl]; ++k)
-                for (uint32_t r = r0; r < r1; ++r) {
-                    if (diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
+                for (uint32_t lane = 0; lane < kSliceRows; ++lane) {
+                    const uint32_t r = row_of(sl, lane);
+                    if (r >= nrows || diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
                     const uint32_t j = diag->ptr[r] + k;
                     sval[e] = diag->val[j]; scol[e] = diag->col[j];
                     if (win) scol16[e] = (short)(unsigned short)slot_of(sl / (kGroupRows / kSliceRows), diag->col[j]);
@@ -1727,6 +1757,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->win_ptr = dev_upload(win_ptr.data(), win_ptr.size());
         c->win_runs = dev_upload(win_runs.data(), win_runs.size());
         c->win_slots = win_slots;
+        if (!perm.empty()) c->sell_perm = dev_upload(perm.data(), perm.size());
         c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
         c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
     }
@@ -1857,7 +1888,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->win_ptr, c->win_runs, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
