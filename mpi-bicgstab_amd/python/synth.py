@@ -103,16 +103,17 @@ def transport_like(n: int = TRANSPORT_N, diag_base: float = 16.0, seed: int = 12
     return from_offsets(n, TRANSPORT_OFFSETS, diag_base, seed, rows, scale_decades)
 
 
-def fem_like(n: int = TRANSPORT_N, seed: int = 4242, keep: float = 0.55, rows=None) -> CSR:
+def fem_like(n: int = TRANSPORT_N, seed: int = 4242, keep: float = 0.55, rows=None, scale_decades: float = 0.0) -> CSR:
     """Irregular rows like an unstructured FEM matrix: a 27-offset 3-D stencil (117 x 117 x ~117
     node numbering) from which every off-diagonal entry is kept with probability `keep`, so row
     lengths vary between ~6 and 27 (mean ~15.3 at keep = 0.55; Transport.mtx: 14.66). Used to
     exercise the sliced-ELL / CSR hybrid on ragged rows; values follow from_offsets' law.
-    rows=(lo, hi): only that row range of the same global matrix (GLOBAL columns)."""
+    rows=(lo, hi): only that row range of the same global matrix (GLOBAL columns); scale_decades as in
+    from_offsets (a harder system: bench.py needs a few hundred unconverged iterations)."""
     nx = 117
     offs = np.array(sorted({dz * nx * nx + dy * nx + dx for dz in (-1, 0, 1) for dy in (-1, 0, 1) for dx in (-1, 0, 1)}),
                     dtype=np.int64)
-    A = from_offsets(n, offs.tolist(), diag_base=32.0, seed=seed, rows=rows)
+    A = from_offsets(n, offs.tolist(), diag_base=32.0, seed=seed, rows=rows, scale_decades=scale_decades)
     lo = 0 if rows is None else rows[0]
     ptr = A.ptr.astype(np.int64)
     rowid = np.repeat(np.arange(lo, lo + A.rows, dtype=np.int64), np.diff(ptr))

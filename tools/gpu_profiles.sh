@@ -11,8 +11,12 @@ run() {   # name, env assignment (or ''), bench args...
   f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
   if [ -n "$f" ]; then cp $f $out/kernel_stats_$name.csv; echo "== $name"; head -6 $out/kernel_stats_$name.csv | cut -c1-170; else echo "== $name: no stats"; tail -5 $out/prof_$name.log; fi
 }
-run plain "BICG_X=1"
-run pipe_nt "BICG_X=1" --method pipe_bicgstab
-run ca_nt "BICG_X=1" --method ca_bicgstab
-run fem_like_window "BICG_X=1" --workload fem_like
-run fem_like_csr "BICG_NO_SELL=1" --workload fem_like
+want() { [ -z "$ONLY" ] || echo " $ONLY " | grep -q " $1 "; }
+want plain && run plain "BICG_X=1"
+want pipe_nt && run pipe_nt "BICG_X=1" --method pipe_bicgstab
+want pipe_separate && run pipe_separate "BICG_FUSE_PIPE=0" --method pipe_bicgstab
+want ca_nt && run ca_nt "BICG_X=1" --method ca_bicgstab
+want fem_like_window && run fem_like_window "BICG_X=1" --workload fem_like
+want fem_like_pipe && run fem_like_pipe "BICG_X=1" --workload fem_like --method pipe_bicgstab
+want fem_like_csr && run fem_like_csr "BICG_NO_SELL=1" --workload fem_like
+true
