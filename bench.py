@@ -38,6 +38,11 @@ import sys
 import tempfile
 import time
 
+# the host driver of this pool only supports dmabuf IPC: without this the HIP-IPC mapping of the peer-to-peer
+# mailboxes (and RCCL's own IPC) fails with "hipIpcGetMemHandle: invalid argument". Must be set before the HIP
+# runtime initialises; normally exported already.
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 

@@ -11,6 +11,8 @@ import os
 
 import numpy as np
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")   # dmabuf IPC only on this pool's host driver (peer-to-peer mailboxes, RCCL)
+
 from .synth import CSR
 
 PKG_DIR = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
