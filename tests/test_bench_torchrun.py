@@ -59,6 +59,8 @@ def test_bench_single_gpu_line_has_every_leg():
         assert 0.3 < r["frac"] < 1.0 and r["algorithmic_bytes"] > 8e8, (m, r)
     for key in ("banded_b8", "banded_b64", "banded_b512", "fem_like", "laplace7_256_ca"):
         assert key in d["extras"], key
+        legs = [v for v in d["extras"][key].values() if isinstance(v, dict) and "ms_per_iteration" in v]
+        assert legs and all(v["iterations_genuine"] is True for v in legs), (key, legs)   # no leg timed a converged solve
     assert d["extras"]["laplace7_256_ca"]["rows"] == 256 ** 3 and d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"] > 0
     rf = d["roofline"]
     assert rf["traffic"] is not None, "rocprofv3 counter passes did not deliver"
