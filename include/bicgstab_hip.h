@@ -258,6 +258,11 @@ double bicg_dot(bicg_ctx *ctx, const double *x_loc, const double *y_loc);
 /* reps back-to-back SpMVs on device-resident vectors; returns average ms per SpMV (HIP events on
  * the library's compute stream) */
 int bicg_spmv_bench(bicg_ctx *ctx, int reps, double *ms_per_spmv);
+/* STREAM-style bandwidth of THIS GPU, the denominator north_star prices the SpMV against ("measure
+ * its own STREAM-triad/copy on the box"): kind 0 copy a = b, 1 triad a = b + s c (both 16-byte accesses), 2 read-only with
+ * 8-byte loads, 3 read-only with 16-byte loads. bytes_per_array should exceed the 256 MiB Infinity Cache several times
+ * (bench.py: 1 GiB). gbps = bytes read + written per second; ms = one pass. Returns 0. Needs a GPU. */
+int bicg_stream_bench(int kind, unsigned long long bytes_per_array, int reps, double *gbps, double *ms);
 /* 1 after a peer-to-peer wait of this context timed out (only reachable with BICG_P2P_SOFT_FAIL=1; the
  * default is to print the error and exit like any other HIP/RCCL failure). The solve in progress stops. */
 int bicg_comm_failed(bicg_ctx *ctx);
@@ -267,9 +272,11 @@ int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);
 /* which code paths this context takes (tests assert on them): peer-to-peer data path in use; halo exchange
  * folded into the sliced-ELL SpMV launch; two-stream overlap mode; 16-bit column offsets; every 256-row
  * group on the sliced-ELL path; jagged slices (ragged rows, no padding stored); bicg_spmm available (the same
- * on every rank); x windows in LDS with 16-bit slots instead of column indices */
+ * on every rank); x windows in LDS with 16-bit slots instead of column indices; rows spread over lanes */
 enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FLAG_COL16 = 8, BICG_FLAG_ALL_SELL = 16, BICG_FLAG_JAGGED = 32,
-       BICG_FLAG_SPMM = 64, BICG_FLAG_WINDOW = 128 };
+       BICG_FLAG_SPMM = 64, BICG_FLAG_WINDOW = 128,
+       BICG_FLAG_ROWSPLIT = 256   /* long rows: a row is spread over 8..64 lanes (k_spmv_rows); row sums then agree with the
+                                     reference's to 1e-13 x sum |a_ij x_j| instead of bit for bit */ };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 /* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);

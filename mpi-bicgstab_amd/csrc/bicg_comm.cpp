@@ -317,8 +317,19 @@ int bicg_comm_init_mpi(const char *transport, int device)
         if (rank == 0) rccl_unique_id(id);
         bicg_mpi_bcast_bytes(id, BICG_UNIQUE_ID_BYTES, 0);
         Comm *rc = make_rccl(rank, size, id, device);
-        if (rc) comm_set(rc);
-        else use_rccl = false;          // BICG_COMM_SOFT_FAIL: staged through MPI instead
+        // BICG_COMM_SOFT_FAIL: a rank whose ncclCommInitRank failed gets nullptr. The transport must be the same
+        // everywhere (ranks on different transports hang in their first collective), so the verdicts are summed over
+        // MPI and ONE failure sends every rank to the MPI-staged transport.
+        double failed = rc ? 0.0 : 1.0;
+        bicg_mpi_allreduce_sum(&failed, 1, nullptr);
+        if (failed == 0.0) {
+            comm_set(rc);
+        } else {
+            if (rc && rank == 0)
+                fprintf(stderr, "bicgstab_hip: %d rank(s) could not join the RCCL communicator; all ranks use the MPI-staged transport\n", (int)failed);
+            delete rc;
+            use_rccl = false;
+        }
     }
     if (!use_rccl) {
         comm_set(make_host(rank, size, bicg_mpi_allreduce_sum, bicg_mpi_alltoallv_bytes, nullptr, device));
@@ -340,6 +351,7 @@ int bicg_comm_selftest_rccl(int device)
     char id[BICG_UNIQUE_ID_BYTES];
     rccl_unique_id(id);
     Comm *c = make_rccl(0, 1, id, device);
+    if (!c) return 100;                // BICG_COMM_SOFT_FAIL and the communicator could not be created
     hipStream_t st;
     BICG_HIP(hipStreamCreateWithFlags(&st, hipStreamNonBlocking));
     double h[5] = {1.5, -2.0, 3.25, 0.0, 1e300}, back[5] = {0, 0, 0, 0, 0};

@@ -255,6 +255,8 @@ struct SpmvArgs {
     const uint32_t *glist;  // SELL launch: 256-row groups to process (null = groups 0..nlist-1)
     uint32_t nrows;         // local rows
     CsrDev diag;            // local columns
+    const short *diag_col16;  // CSR-order 16-bit column offsets (col - row) for the rows-over-lanes kernel, or null
+    int     rowsplit;       // the CSR row blocks of this context go to k_spmv_rows (a row is spread over T lanes)
     CsrDev offd;            // columns renumbered to rows + halo position; ptr over ALL local rows
     const uint4 *desc;      // row blocks of this launch: {first row, end row, first nnz, end nnz}
     uint32_t nlist;         // number of row blocks to process

@@ -917,6 +917,10 @@ __device__ __forceinline__ const Scal *finish_group(Scal *S, const Finish &f, in
             __syncthreads();
             if (tid == 0) { priv->done = 1; priv->comm_error = 1; if (block0) *f.Snext = *priv; }
             __syncthreads();
+            // the workgroups that take the applied scalars from this one must not sit through their own peer time-out
+            // (one per occupancy wave of row workgroups): the row is published all the same, with done = 1
+            if (block0 && tid < 4)
+                ll_store_agent(f.shard + (size_t)kShards * kRedSlots * 2 + 2 * tid, tid == 3 ? 1.0 : 0.0, f.seq);
             return priv;
         }
         return S;
@@ -1156,9 +1160,152 @@ static void launch_spmv_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hi
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Rows over lanes (long rows). Lane = row (sliced ELL) needs >= 256 rows per workgroup: a block of a few ten
+// thousand rows with ~1000 entries each (synthetic banded CSR, half-bandwidth 512: 23 415 rows = 92 workgroups
+// for 256 CUs, every lane walking 128 dependent batches) ran at 0.27 of the HBM roofline. Here a row is spread
+// over T = 8..64 lanes (T from the block's mean row length, wave-uniform): lane l adds entries l, l + T, l + 2T, ...
+// of its row in stored order, 8 loads of val and col in flight per lane, the T partial sums are combined by a
+// fixed butterfly (DPP inside rows of 16 lanes, two bpermute steps above) -- so val / col are read fully
+// coalesced straight from the CSR arrays (16-bit column offsets when they fit: 10 B per non-zero), a workgroup
+// holds a few rows only (row blocks of <= 8192 non-zeros) and a 24 M-non-zero matrix makes ~3000 workgroups
+// whatever its row length. The association of a row's sum differs from mult() (reference src/matrix.c:506-515):
+// the result agrees to ~1e-16 x sum |a_ij x_j|, tested at 1e-13 (north_star: a stated tolerance); it is fixed, so
+// runs are bit-reproducible. Taken when the block's rows average >= 128 entries and lane = row would leave the
+// GPU short of workgroups (bicg_create; BICG_ROWSPLIT=0/1 overrides).
+// ------------------------------------------------------------------------------------------
+template <int T>
+__device__ __forceinline__ double lanes_sum(double v)     // every lane of each aligned group of T lanes gets the group's sum
+{
+    v = dpp_add<0xB1, 0xF>(v);                   // quad_perm [1,0,3,2]
+    v = dpp_add<0x4E, 0xF>(v);                   // quad_perm [2,3,0,1]
+    if (T >= 8) v = dpp_add<0x141, 0xF>(v);      // row_half_mirror
+    if (T >= 16) v = dpp_add<0x140, 0xF>(v);     // row_mirror
+    if (T >= 32) v += __shfl_xor(v, 16);
+    if (T >= 64) v += __shfl_xor(v, 32);
+    return v;
+}
+
+template <int NDOT, bool OFFD, bool NT, bool C16, int T, int MODE>
+__device__ __forceinline__ void rows_block(const SpmvArgs &a, uint32_t r0, uint32_t r1, int done, double (&acc)[NDOT > 0 ? NDOT : 1])
+{
+    constexpr int U = 8;
+    constexpr uint32_t NSUB = kBlock / T;
+    const unsigned tid = threadIdx.x, sub = tid / T, l = tid % T;
+    const double *__restrict__ x = a.x;
+    for (uint32_t rb = r0; rb < r1; rb += NSUB) {               // workgroup-uniform trip count
+        const uint32_t r = rb + sub;
+        const bool have = r < r1;
+        const uint32_t pa = have ? a.diag.ptr[r] : 0u, pb = have ? a.diag.ptr[r + 1] : 0u;
+        const uint32_t rs = have ? r : r0;                      // a safe x index for lanes without an entry
+        double ur = 0.0;
+        if (NDOT >= 1 && have && l == 0) ur = a.u[r];
+        double s = 0.0;
+        for (uint32_t j0 = pa + l; j0 < pb; j0 += U * T) {
+            uint32_t c[U];
+            double   v[U];
+            // raw loads only inside the predicated part (a use of a loaded value there costs one round trip per
+            // entry, see sell_row); out-of-range entries multiply 0.0 with x[row]
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const uint32_t j = j0 + e * T;
+                const bool ok = j < pb;
+                v[e] = 0.0;
+                if (C16) {
+                    int d = 0;
+                    if (ok) { d = NT ? __builtin_nontemporal_load(a.diag_col16 + j) : a.diag_col16[j]; v[e] = stream_load<NT>(a.diag.val + j); }
+                    c[e] = rs + (uint32_t)d;
+                } else {
+                    c[e] = rs;
+                    if (ok) { c[e] = stream_load<NT>(a.diag.col + j); v[e] = stream_load<NT>(a.diag.val + j); }
+                }
+            }
+            double xv[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) xv[e] = x[c[e]];
+#pragma unroll
+            for (int e = 0; e < U; ++e) s += v[e] * xv[e];
+        }
+        s = lanes_sum<T>(s);
+        if (have && l == 0) {
+            double yi = 0.0 + s;                                 // y = 0 ; y += tempy  (src/matrix.c:434-437)
+            if (OFFD) {
+                double so = 0.0;
+                for (uint32_t k = a.offd.ptr[r]; k < a.offd.ptr[r + 1]; ++k) so += a.offd.val[k] * x[a.offd.col[k]];
+                yi += so;                                        // second mult() call, src/matrix.c:440
+            }
+            if (a.has_shift) yi += a.shift * x[r];
+            if (!done) a.y[r] = yi;
+            if (NDOT >= 1) acc[0] += ur * yi;
+            if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+            if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ur * ur;
+        }
+    }
+}
+
+template <int NDOT, bool OFFD, bool NT, bool C16, int MODE>
+__global__ void __launch_bounds__(kBlock) k_spmv_rows(SpmvArgs a)
+{
+    if (MODE == RED_WAVE) {
+        __shared__ FinishLds fl;
+        if (a.fin.seq) (void)finish_group(a.S, a.fin, a.fin.roles, blockIdx.x, gridDim.x, fl, nullptr);
+    }
+    const int done = a.S->done;
+    __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
+    double acc[NDOT > 0 ? NDOT : 1];
+#pragma unroll
+    for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
+    for (unsigned bi = blockIdx.x; bi < a.nlist; bi += gridDim.x) {
+        const uint4 d = a.desc[bi];
+        const uint32_t nr = d.y - d.x, mean = nr ? (d.w - d.z) / nr : 0u;
+        // lanes per row from the block's mean row length (workgroup-uniform): ~8 entries per lane and batch
+        if (mean >= 320u) rows_block<NDOT, OFFD, NT, C16, 64, MODE>(a, d.x, d.y, done, acc);
+        else if (mean >= 160u) rows_block<NDOT, OFFD, NT, C16, 32, MODE>(a, d.x, d.y, done, acc);
+        else if (mean >= 80u) rows_block<NDOT, OFFD, NT, C16, 16, MODE>(a, d.x, d.y, done, acc);
+        else rows_block<NDOT, OFFD, NT, C16, 8, MODE>(a, d.x, d.y, done, acc);
+    }
+    if (NDOT > 0 && !done) {
+        if (MODE == RED_WAVE) wave_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.red.partial, a.red.slot_base + blockIdx.x);
+        else reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
+    }
+}
+
+template <int NDOT, bool OFFD>
+static void launch_spmv_rows_var(const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
+{
+    dim3 g(spmv_grid(a.nlist)), b(kBlock);
+    const int mode = red_mode(a.red, a.fin, NDOT > 0);
+    constexpr int HV = NDOT > 0 ? RED_TICKET_HEAVY : RED_TICKET;
+    const bool c16 = a.diag_col16 != nullptr, nt = a.nt != 0;
+#define ROWS_GO(MD)                                                                                        \
+    do {                                                                                                   \
+        if (c16) { if (nt) launch_timed(k_spmv_rows<NDOT, OFFD, true, true, MD>, g, b, st, e0, e1, a);       \
+                   else launch_timed(k_spmv_rows<NDOT, OFFD, false, true, MD>, g, b, st, e0, e1, a); }      \
+        else { if (nt) launch_timed(k_spmv_rows<NDOT, OFFD, true, false, MD>, g, b, st, e0, e1, a);          \
+               else launch_timed(k_spmv_rows<NDOT, OFFD, false, false, MD>, g, b, st, e0, e1, a); }         \
+    } while (0)
+    if (mode == RED_WAVE) ROWS_GO(RED_WAVE);
+    else if (mode == RED_TICKET_HEAVY) ROWS_GO(HV);
+    else ROWS_GO(RED_TICKET);
+#undef ROWS_GO
+}
+
+static bool launch_spmv_rows(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
+{
+    if (with_offd) {
+        if (ndot == 0) launch_spmv_rows_var<0, true>(a, st, e0, e1); else if (ndot == 1) launch_spmv_rows_var<1, true>(a, st, e0, e1);
+        else if (ndot == 2) launch_spmv_rows_var<2, true>(a, st, e0, e1); else launch_spmv_rows_var<3, true>(a, st, e0, e1);
+    } else {
+        if (ndot == 0) launch_spmv_rows_var<0, false>(a, st, e0, e1); else if (ndot == 1) launch_spmv_rows_var<1, false>(a, st, e0, e1);
+        else if (ndot == 2) launch_spmv_rows_var<2, false>(a, st, e0, e1); else launch_spmv_rows_var<3, false>(a, st, e0, e1);
+    }
+    return true;
+}
+
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.nlist == 0) return false;
+    if (a.rowsplit) return launch_spmv_rows(a, ndot, with_offd, st, e0, e1);
     if (with_offd) {
         if (ndot == 0) launch_spmv_var<0, true>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, true>(a, st, e0, e1);
         else if (ndot == 2) launch_spmv_var<2, true>(a, st, e0, e1); else launch_spmv_var<3, true>(a, st, e0, e1);

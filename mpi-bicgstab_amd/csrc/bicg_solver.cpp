@@ -65,6 +65,8 @@ struct bicg_ctx {
     double *d_val = nullptr, *o_val = nullptr;
     uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
     uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // CSR row-block descriptors: interior / halo-touching
+    bool rowsplit = false;                 // long rows: the row blocks go to k_spmv_rows (a row spread over T lanes)
+    short *d_col16 = nullptr;              // ... with CSR-order 16-bit column offsets when they fit
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
@@ -143,7 +145,7 @@ struct bicg_ctx {
     int last_iters = 0;
 
     hipStream_t sc = nullptr, sm = nullptr;   // compute, communication
-    hipEvent_t ev_pack[kEvRing], ev_halo[kEvRing], ev_dots[kEvRing], ev_red[kEvRing];
+    hipEvent_t ev_pack[kEvRing] = {}, ev_halo[kEvRing] = {}, ev_dots[kEvRing] = {}, ev_red[kEvRing] = {};
     unsigned i_pack = 0, i_halo = 0, i_dots = 0, i_red = 0;
 
     // deferred dot group (pipelined variant: all-reduce overlaps the next SpMV)
@@ -397,6 +399,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
+    a.diag_col16 = c->d_col16; a.rowsplit = c->rowsplit ? 1 : 0;
     a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.desc = nullptr; a.nlist = 0;
     a.x = xin; a.y = yout; a.u = u; a.S = S ? S : c->S;
@@ -1388,12 +1391,26 @@ bool all_ranks(Comm *comm, bool mine)
     return true;
 }
 
+bool dropin_cache_enabled()
+{
+    static const bool enabled = !(getenv("BICG_DROPIN_CACHE") && atoi(getenv("BICG_DROPIN_CACHE")) == 0);
+    return enabled;
+}
+
 // the resident context for these blocks: reused when nothing changed, rebuilt otherwise (collective)
 bicg_ctx *dropin_context(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
 {
     Comm *comm = comm_get();
-    static const bool enabled = !(getenv("BICG_DROPIN_CACHE") && atoi(getenv("BICG_DROPIN_CACHE")) == 0);
-    if (!enabled) return bicg_create(diag, offd, info);
+    if (!dropin_cache_enabled()) {
+        // create / destroy per call, but the library keeps ownership all the same (a caller that asked for the context
+        // through bicg_dropin_context must not be left with one to free, and must not meet a SECOND copy of the matrix
+        // on the GPU when it calls a solver next): the previous context goes before the new one is built
+        if (g_dropin.ctx) { bicg_destroy(g_dropin.ctx); g_dropin.ctx = nullptr; }
+        g_dropin.misses++;
+        g_dropin.ctx = bicg_create(diag, offd, info);
+        g_dropin.key = DropinKey{};
+        return g_dropin.ctx;
+    }
     const DropinKey key = dropin_key(diag, offd, info, comm);
     const bool hit = all_ranks(comm, g_dropin.ctx != nullptr && g_dropin.key == key);
     if (hit) { g_dropin.hits++; return g_dropin.ctx; }
@@ -1405,7 +1422,8 @@ bicg_ctx *dropin_context(const CSR_Matrix *diag, const CSR_Matrix *offd, const I
 }
 void dropin_release(bicg_ctx *c)
 {
-    if (c && c != g_dropin.ctx) bicg_destroy(c);     // caching disabled: per-call context
+    // caching disabled: the context does not outlive the solver call
+    if (c && !dropin_cache_enabled() && c == g_dropin.ctx) { bicg_destroy(c); g_dropin.ctx = nullptr; }
 }
 
 int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, double *x, double *r, int krr, int nrr)
@@ -1451,10 +1469,11 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->nnz_d = diag->rows ? diag->ptr[diag->rows] : 0u;
     const int P = c->nranks;
 
-    const bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
+    bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
+    uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
     {   // Every rank learns every rank's (non-zeros, rows). The enqueue mode changes the ORDER of RCCL calls,
         // so all ranks must take the same decision: it is based on the average number of local non-zeros.
         // A rank WITHOUT rows (more ranks than rows, or an empty block of a non-zero balanced partition) is not
@@ -1473,9 +1492,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         }
         if (empty) {
             if (c->rank == 0) fprintf(stderr, "ERROR: bicg_create: a rank without rows is not supported (%u rows over %d ranks)\n", info->rows, P);
-            delete c;
+            bicg_destroy(c);          // nothing is allocated yet; takes the context out of the registry of live ones
             return nullptr;
         }
+        nnz_diag_all = total;
         c->overlap = total / (uint64_t)P >= 6000000u;
         // two launches per pipelined iteration (phases in the SpMV epilogues): latency on small ranks (200 k rows 26.2
         // vs 34.1 us), the traffic of v and t on large ones (1.6 M rows 159 vs 163 us, banded b = 8 158 vs 169, the
@@ -1523,6 +1543,18 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // is "boundary" when one of its rows has offd entries (it then runs after the halo has landed).
     const uint32_t nrows = c->n_loc;
     const uint32_t nslices = (nrows + kSliceRows - 1) / kSliceRows, ngroups = (nrows + kGroupRows - 1) / kGroupRows;
+    // Long rows: lane = row needs 256 rows per workgroup, so a block of few, long rows (banded, half-bandwidth 512:
+    // 23 k rows of 1025 entries = 92 workgroups for 256 CUs) starves the GPU. Such a block goes to the rows-over-lanes
+    // kernel (k_spmv_rows) as a whole: row blocks of <= 8192 non-zeros, a row spread over 8..64 lanes. The row sums
+    // are then associated differently from mult() (tolerance 1e-13 x sum |a_ij x_j| instead of bit-exact).
+    // Decided from the GLOBAL shape (mean row length, rows per rank) so that all ranks agree.
+    {
+        const uint64_t mean_len = info->rows ? nnz_diag_all / info->rows : 0;     // (INFO_Matrix.nz is not always filled in)
+        const uint64_t groups_per_rank = ((uint64_t)info->rows / (uint64_t)P + kGroupRows - 1) / kGroupRows;
+        c->rowsplit = use_sell && mean_len >= 128 && groups_per_rank < 1024;
+        if (const char *sv = getenv("BICG_ROWSPLIT")) c->rowsplit = atoi(sv) != 0;
+        if (c->rowsplit) use_sell = false;
+    }
     std::vector<uint32_t> slice_len(nslices, 0u), slice_base(nslices, 0u);
     for (uint32_t r = 0; r < nrows; ++r)
         slice_len[r / kSliceRows] = std::max(slice_len[r / kSliceRows], diag->ptr[r + 1] - diag->ptr[r]);
@@ -1715,7 +1747,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         while (g1 < ngroups && !group_is_sell[g1]) ++g1;
         const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, g1 * kGroupRows);
         // bicg_row_blocks works on a ptr array that starts at the run's first row
-        const uint32_t nb = bicg_row_blocks(diag->ptr + r0, r1 - r0, kRowBlockNnz, 1024, rb.data());
+        const uint32_t nb = c->rowsplit ? bicg_row_blocks(diag->ptr + r0, r1 - r0, 8192, 256, rb.data())
+                                        : bicg_row_blocks(diag->ptr + r0, r1 - r0, kRowBlockNnz, 1024, rb.data());
         for (uint32_t b = 0; b < nb; ++b) {
             const uint32_t a0 = r0 + rb[b], a1 = r0 + rb[b + 1];
             const bool touches_halo = P > 1 && optr[a1] > optr[a0];
@@ -1734,8 +1767,20 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // CSR kernel (none for banded matrices: everything is on the sliced-ELL path), the 32-bit sliced-ELL
     // columns when the 16-bit offsets do not apply. (Round 1 kept all of them: 2.3 x the matrix.)
     const bool need_csr = c->nblk > 0;
+    bool csr16 = c->rowsplit && need_csr && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
+    std::vector<short> dcol16;
+    if (csr16) {                  // rows-over-lanes kernel: 16-bit column offsets in CSR order when every entry fits
+        dcol16.resize((size_t)c->nnz_d + kPadEntries, 0);
+        for (uint32_t r = 0; csr16 && r < nrows; ++r)
+            for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
+                const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
+                if (dlt < -32767 || dlt > 32767) { csr16 = false; break; }
+                dcol16[j] = (short)dlt;
+            }
+    }
     c->d_val = dev_upload_padded(diag->val, need_csr ? c->nnz_d : 0, kPadEntries);
-    c->d_col = dev_upload_padded(diag->col, need_csr ? c->nnz_d : 0, kPadEntries);
+    c->d_col = dev_upload_padded(diag->col, need_csr && !csr16 ? c->nnz_d : 0, kPadEntries);
+    if (csr16) c->d_col16 = dev_upload(dcol16.data(), dcol16.size());
     c->d_ptr = dev_upload(diag->ptr, (size_t)c->n_loc + 1);
     c->o_val = dev_upload(oval.data(), c->nnz_o);
     c->o_col = dev_upload(ocol.data(), c->nnz_o);
@@ -1746,8 +1791,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->s_val = dev_upload_padded(sval.data(), (size_t)sell_entries, kPadEntries);
     c->s_col = dev_upload_padded(scol.data(), c16 ? 0 : (size_t)sell_entries, kPadEntries);
     c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) + 8ull * nslices + 4ull * (nrows + 1) +
-                      (uint64_t)(c->nnz_d - c->sell_nnz) * 12 + (uint64_t)c->nnz_o * 12;
-    c->device_matrix_bytes = (need_csr ? 12ull * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
+                      (uint64_t)(c->nnz_d - c->sell_nnz) * (csr16 ? 10 : 12) + (uint64_t)c->nnz_o * 12;
+    c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
         c->s_col16 = dev_upload_padded(scol16.data(), scol16.size(), kPadEntries);
@@ -1888,7 +1933,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -1899,7 +1944,8 @@ void bicg_destroy(bicg_ctx *c)
     if (c->hS) (void)hipHostFree(c->hS);
     if (c->h_alarm) (void)hipHostFree(c->h_alarm);
     for (int i = 0; i < kEvRing; ++i) {
-        (void)hipEventDestroy(c->ev_pack[i]); (void)hipEventDestroy(c->ev_halo[i]); (void)hipEventDestroy(c->ev_dots[i]); (void)hipEventDestroy(c->ev_red[i]);
+        for (hipEvent_t e : {c->ev_pack[i], c->ev_halo[i], c->ev_dots[i], c->ev_red[i]})
+            if (e) (void)hipEventDestroy(e);      // a context that failed early in bicg_create has none
     }
     for (auto &e : c->tev) (void)hipEventDestroy(e);
     for (auto &ge : c->graph_exec) if (ge) (void)hipGraphExecDestroy(ge);
@@ -2141,6 +2187,7 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->win_slots) f |= BICG_FLAG_WINDOW;
     if (c->spmm_ok) f |= BICG_FLAG_SPMM;
     if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
+    if (c->rowsplit) f |= BICG_FLAG_ROWSPLIT;
     return f;
 }
 

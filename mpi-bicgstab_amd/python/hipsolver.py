@@ -61,7 +61,7 @@ EXPORTS = [
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
-    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version",
+    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench",
 ]
 
 _lib = None
@@ -121,6 +121,7 @@ def lib():
         L.bicg_window_slot.argtypes = [_up, C.c_uint, C.c_uint, C.c_uint]
         L.bicg_window_slot.restype = C.c_uint
         L.bicg_version.restype = C.c_char_p
+        L.bicg_stream_bench.argtypes = [C.c_int, C.c_ulonglong, C.c_int, _dp, _dp]
         for name in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
             getattr(L, name).argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp]
         L.pipe_bicgstab_rr.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp,
@@ -337,7 +338,7 @@ class Context:
     def comm_failed(self) -> bool:
         return bool(lib().bicg_comm_failed(self.h))
 
-    FLAGS = {"p2p": 1, "ll_fused": 2, "overlap": 4, "col16": 8, "all_sell": 16, "jagged": 32, "spmm": 64, "window": 128}
+    FLAGS = {"p2p": 1, "ll_fused": 2, "overlap": 4, "col16": 8, "all_sell": 16, "jagged": 32, "spmm": 64, "window": 128, "rowsplit": 256}
 
     def flags(self):
         f = int(lib().bicg_ctx_flags(self.h))
@@ -351,6 +352,17 @@ class Context:
         lib().bicg_plan_info(self.h, out)
         return dict(zip(("rows", "nnz_diag", "nnz_offd", "halo", "row_blocks", "boundary_blocks", "sell_rows",
                          "sell_padding"), list(out)))
+
+
+STREAM_KINDS = {"copy": 0, "triad": 1, "read8": 2, "read16": 3}
+
+
+def stream_bench(kind: str, bytes_per_array: int = 1 << 30, reps: int = 20) -> float:
+    """GB/s of a STREAM-style pass on the current GPU (bicg_stream_bench): copy / triad / read8 / read16"""
+    g, ms = C.c_double(0.0), C.c_double(0.0)
+    if lib().bicg_stream_bench(STREAM_KINDS[kind], bytes_per_array, reps, C.byref(g), C.byref(ms)) != 0:
+        raise RuntimeError("bicg_stream_bench failed")
+    return g.value
 
 
 # ---- host-only helpers (no GPU) ----------------------------------------------------------------
