@@ -1551,7 +1551,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     {
         const uint64_t mean_len = info->rows ? nnz_diag_all / info->rows : 0;     // (INFO_Matrix.nz is not always filled in)
         const uint64_t groups_per_rank = ((uint64_t)info->rows / (uint64_t)P + kGroupRows - 1) / kGroupRows;
-        c->rowsplit = use_sell && mean_len >= 128 && groups_per_rank < 1024;
+        c->rowsplit = use_sell && (mean_len >= 256 || (mean_len >= 128 && groups_per_rank < 512));
         if (const char *sv = getenv("BICG_ROWSPLIT")) c->rowsplit = atoi(sv) != 0;
         if (c->rowsplit) use_sell = false;
     }

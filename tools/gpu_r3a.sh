@@ -3,7 +3,7 @@
 cd "$GRAFT_REPO_ROOT"
 mkdir -p gpurun_out
 export TMPDIR=/tmp
-python - > gpurun_out/stream.txt 2>&1 <<'PY'
+BICG_STREAM_VERBOSE=1 python - > gpurun_out/stream.txt 2>&1 <<'PY'
 import sys; sys.path.insert(0, '.')
 from mpi_bicgstab_amd import hipsolver as H
 H.lib().bicg_comm_init_single(0)
@@ -16,5 +16,9 @@ cat gpurun_out/stream.txt
 B="python bench.py --workload banded --half-bandwidth 512 --steps 100 --warmup 10 --no-cpu-baseline --no-variants --no-extras --no-traffic"
 for rs in 1 0; do
   BICG_ROWSPLIT=$rs timeout 200 $B 2>gpurun_out/b512_rs$rs.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rowsplit=$rs b512 plain', '%.1f us' % (1e3*d['value']), 'spmv in-solver %.1f us' % (1e3*d['roofline']['avg_launch_ms']), 'b2b %.1f us' % (1e3*d['roofline']['back_to_back_spmv_ms']), 'frac', round(d['roofline']['frac'],3))" | tee -a gpurun_out/b512.txt
+done
+B64="python bench.py --workload banded --half-bandwidth 64 --steps 100 --warmup 10 --no-cpu-baseline --no-variants --no-extras --no-traffic"
+for rs in 1 0; do
+  BICG_ROWSPLIT=$rs timeout 200 $B64 2>gpurun_out/b64_rs$rs.err | python -c "import sys,json; d=json.loads(sys.stdin.read().strip().splitlines()[-1]); print('rowsplit=$rs b64 plain', '%.1f us' % (1e3*d['value']), 'spmv in-solver %.1f us' % (1e3*d['roofline']['avg_launch_ms']), 'b2b %.1f us' % (1e3*d['roofline']['back_to_back_spmv_ms']), 'frac', round(d['roofline']['frac'],3))" | tee -a gpurun_out/b512.txt
 done
 timeout 900 python -m pytest tests/test_bench_workloads.py -x -q -m gpu --durations=10 2>&1 | tail -25 | tee gpurun_out/test_bench_workloads.log
