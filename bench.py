@@ -48,7 +48,7 @@ sys.path.insert(0, ROOT)
 
 import numpy as np  # noqa: E402
 
-HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md (6290 measured copy)
+HBM_PEAK_GBS = 8000.0   # MI355X HBM3E spec, /opt/skills/guides/MI355X_MICROARCH.md; the box's own STREAM rates are measured (stream leg)
 H_UNIQUE = 128
 
 
@@ -141,6 +141,8 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the banded / FEM-like / Laplacian legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--no-stream", action="store_true", help="skip the STREAM probes (roofline.stream_measured_gbps = null)")
+    ap.add_argument("--no-rccl-leg", action="store_true", help="N > 1: do not time the headline a second time over RCCL collectives")
     ap.add_argument("--cpu-iters", type=int, default=100)
     ap.add_argument("--transport", default="auto", choices=["auto", "rccl", "host", "host-p2p"],
                     help="auto (default): direct peer-to-peer stores over xGMI between the kernels (IPC handles "
@@ -215,16 +217,20 @@ def main():
         dist.all_reduce(t)
         return int(t[0]) == 0
 
-    def comm_setup(use_p2p, allow_rccl=True):
+    comm_info = {"world": world, "p2p_selftest": None, "rccl_nranks": None, "transport_used": None, "fallback_reason": None}
+
+    def comm_setup(use_p2p, allow_rccl=True, want="auto"):
         """(Re)create the library's communicator; returns a description of the data path in use."""
         from mpi_bicgstab_amd import dist_transport
+        transport = a.transport if want == "auto" else want
         if world > 1:
             ident = torch.zeros(H_UNIQUE, dtype=torch.uint8)
-            if a.transport == "auto" and use_p2p:
+            if transport == "auto" and use_p2p:
                 # the peer-to-peer data path only needs a host-side exchange of IPC handles at set-up: bootstrap
                 # it over gloo, so that RCCL is not even initialised unless the self-test fails somewhere
                 dist_transport.init_host_transport(device)
-                L.bicg_comm_enable_p2p()          # collective; every rank gets the same verdict
+                rc_p2p = int(L.bicg_comm_enable_p2p())          # collective; every rank gets the same verdict
+                comm_info["p2p_selftest"] = "passed" if rc_p2p == 0 and int(L.bicg_comm_p2p_active()) else f"failed (code {rc_p2p})"
                 if int(L.bicg_comm_p2p_active()):
                     mode = int(L.bicg_comm_p2p_active())
                     return mode, (f"peer-to-peer LL stores over xGMI (HIP IPC, {'uncached' if mode == 2 else 'device'} memory; "
@@ -232,7 +238,7 @@ def main():
                 L.bicg_comm_finalize()
                 use_p2p = False
             base = "gloo-staged"
-            if a.transport in ("auto", "rccl") and allow_rccl:
+            if transport in ("auto", "rccl") and allow_rccl:
                 if rank == 0:
                     buf = (C.c_char * H_UNIQUE)()
                     L.bicg_comm_unique_id(buf)
@@ -241,15 +247,18 @@ def main():
                 rc = L.bicg_comm_init_rccl(rank, world, bytes(ident.numpy().tobytes()), device)
                 if everyone(rc == 0):
                     base = "rccl"
+                    comm_info["rccl_nranks"] = int(L.bicg_comm_size())
                 else:           # some rank could not join: every rank drops RCCL, exchanges are staged through gloo
                     note("RCCL communicator could not be created on every rank: falling back to gloo-staged exchanges")
                     L.bicg_comm_finalize()
                     dist_transport.init_host_transport(device)
                     base = "gloo-staged (fallback: RCCL communicator could not be created)"
+                    comm_info["rccl_nranks"] = 0
             else:
                 dist_transport.init_host_transport(device)
             if use_p2p:
-                L.bicg_comm_enable_p2p()      # collective; leaves the transport as it is when the self-test fails
+                rc_p2p = int(L.bicg_comm_enable_p2p())      # collective; leaves the transport as it is when the self-test fails
+                comm_info["p2p_selftest"] = "passed" if rc_p2p == 0 and int(L.bicg_comm_p2p_active()) else f"failed (code {rc_p2p})"
         elif a.force_comm:
             os.environ["BICG_FORCE_COMM"] = "1"
             buf = (C.c_char * H_UNIQUE)()
@@ -269,9 +278,32 @@ def main():
 
     p2p_mode, transport_name = comm_setup(a.transport in ("auto", "host-p2p"))
 
+    # ------------------------------------------------------------------ this GPU's own STREAM rates
+    stream = None
+    if not a.no_stream and not a.inner:
+        stage[0] = "STREAM probes"
+        shared = world > torch.cuda.device_count()      # ranks sharing a GPU (tests): rank 0 measures, the others wait
+        try:
+            if dist is not None:
+                dist.barrier()
+            if not shared or rank == 0:
+                stream = {k: max(H.stream_bench(k, 1 << 30, 10) for _ in range(2)) for k in ("copy", "triad", "read8", "read16")}
+            if dist is not None:
+                dist.barrier()
+            if stream is None:
+                raise RuntimeError("measured by rank 0 only (ranks share the device)")
+            stream["note"] = ("GB/s of bytes read + written, 1 GiB per array (4 x the Infinity Cache), fastest of {grid-stride, one "
+                              "workgroup per 16 KiB tile} x {ordinary, non-temporal} accesses; libbicgstab_hip.so bicg_stream_bench")
+            note("STREAM on this GPU: " + ", ".join(f"{k} {v:.0f} GB/s" for k, v in stream.items() if k != "note"))
+        except Exception as e:  # reported, never required
+            stream = {"error": repr(e)}
+
     def barrier():
         if dist is not None:
             dist.barrier()
+
+    def base_is_rccl(name):
+        return name == "rccl" or "bootstrap rccl" in name
 
     note(f"communicator ready: {world} rank(s), data path: {transport_name}")
     K, W = a.steps, a.warmup
@@ -401,6 +433,7 @@ def main():
         L.bicg_comm_finalize()
         p2p_mode, transport_name = comm_setup(False)
         transport_name += f" (fallback: '{failed_name}' failed the residual check)"
+        comm_info["fallback_reason"] = f"'{failed_name}' failed the residual check after the timed region (true relres {true_relres:.3e})"
         leg = Leg(wl)
         plan = leg.plan
         dt, res = leg.timed(a.method)
@@ -451,6 +484,39 @@ def main():
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     leg.timed(a.method, steps=4, warm=0)       # back to ordinary launches before the next matrix is timed
     leg.close()
+    comm_info["transport_used"] = transport_name
+
+    # ------------------------------------------------------------------ N > 1: the same matrix over RCCL collectives
+    # north_star names "halo exchange and dot-product all-reduce on RCCL over xGMI": whichever path produced `value`,
+    # the headline method is timed once more with the library's RCCL transport (grouped ncclSend/ncclRecv halo exchange,
+    # packed ncclAllReduce per dot group, second stream above 6 M non-zeros per rank), so that a multi-GPU record says
+    # what BOTH paths cost -- or why RCCL could not run.
+    rccl_leg = None
+    if world > 1 and not a.no_rccl_leg and not a.inner:
+        stage[0] = "RCCL leg"
+        if base_is_rccl(transport_name) and not p2p_mode:
+            rccl_leg = {"ms_per_iteration": ms_step, "note": "the headline itself ran on the RCCL collectives"}
+        elif world > torch.cuda.device_count() or a.transport in ("host", "host-p2p"):
+            rccl_leg = {"unavailable": f"ranks share a device ({world} ranks, {torch.cuda.device_count()} GPU(s)): RCCL needs one GPU per rank"}
+        else:
+            barrier()
+            L.bicg_comm_finalize()
+            _, rname = comm_setup(False, want="rccl")
+            if comm_info["rccl_nranks"]:
+                lg = Leg(wl)
+                dtr, resr = lg.best(a.method)
+                okr, true_r = lg.check()
+                rccl_leg = {"ms_per_iteration": 1e3 * dtr / K, "transport": rname, "rccl_nranks": comm_info["rccl_nranks"],
+                            "iterations_genuine": bool(resr.iterations == W + K and okr), "true_relres_after_timed_region": true_r}
+                lg.close()
+            else:
+                rccl_leg = {"unavailable": "the RCCL communicator could not be created on every rank (see stderr)"}
+            # the extras below run on the transport that produced the headline
+            barrier()
+            L.bicg_comm_finalize()
+            p2p_mode, _ = comm_setup(a.transport in ("auto", "host-p2p") and comm_info["fallback_reason"] is None)
+        if rank == 0:
+            note(f"RCCL leg: {rccl_leg}")
 
     # ------------------------------------------------------------------ the other workloads north_star names
     extras = {}
@@ -550,7 +616,12 @@ def main():
                          "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,
                          "ms_per_step_with_events": 1e3 * dt_ev / K,
                          "back_to_back_spmv_ms": spmv_alone_ms,
-                         "frac_of_measured_copy_6290": achieved / 6290.0},
+                         # the denominators north_star asks for, measured on THIS GPU in this run (stream leg above)
+                         "stream_measured_gbps": stream,
+                         "frac_of_measured_stream": (achieved / stream["triad"]) if stream and "triad" in stream else None,
+                         "frac_of_measured_copy": (achieved / stream["copy"]) if stream and "copy" in stream else None,
+                         "frac_of_measured_read": (achieved / stream["read8"]) if stream and "read8" in stream else None},
+            "comm": dict(comm_info, rccl_leg=rccl_leg),
             "cpu_baseline": cpu,
             "cpu_baseline_multicore": cpu_all,
             "variants_ms_per_iteration": variants,

@@ -337,6 +337,9 @@ int bicg_comm_init_mpi(const char *transport, int device)
     const bool automatic = !transport || strcmp(transport, "auto") == 0;
     if (want_p2p || (automatic && use_rccl)) {
         const int rc = p2p_enable(g_comm);
+        // a bet on the self-test: the drop-in path can take it back (BICG_P2P_FALLBACK=1: also when asked for explicitly)
+        const char *fb = getenv("BICG_P2P_FALLBACK");
+        if (rc == 0 && (!want_p2p || (fb && atoi(fb)))) g_comm->p2p_auto = true;
         if (rc != 0 && want_p2p && rank == 0)
             fprintf(stderr, "bicgstab_hip: peer-to-peer transport not available (code %d), using %s\n", rc, g_comm->name());
     }

@@ -24,6 +24,9 @@ struct Comm {
     // p2p_enable() has succeeded on every rank: halo values and dot sums are then stored straight
     // into the other GPUs' memory by the producing kernels; the transport below only bootstraps.
     P2p *p2p = nullptr;
+    // the peer-to-peer path was switched on by "auto" selection (bicg_comm_init_mpi), not asked for: a time-out in a
+    // drop-in solve then falls back to this transport's own collectives instead of ending the program
+    bool p2p_auto = false;
     // ranks of this communicator that drive the SAME GPU as this one (1 in production; > 1 when a one-GPU box
     // stands in for a node in tests). Kernels that wait for another rank's data hold their workgroup slots while
     // they wait; with several ranks on one device the launches of all of them must fit on it together, or the
@@ -75,6 +78,8 @@ struct P2p {
 // Collective: set up and self-test the peer-to-peer path on communicator c. 0 = enabled on every
 // rank; otherwise nothing changed and the transport keeps working as before.
 int p2p_enable(Comm *c);
+// Collective: give the peer-to-peer path up again (no context may still be using it).
+void p2p_disable(Comm *c);
 
 Comm *comm_get();                 // process-global communicator (auto-initialised on first use)
 void comm_set(Comm *c);           // takes ownership

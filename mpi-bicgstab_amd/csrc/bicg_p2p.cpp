@@ -166,9 +166,9 @@ int p2p_enable(Comm *c)
     }
     P2p *t = new P2p;
     t->comm = c; t->rank = c->rank; t->nranks = c->nranks;
-    // a rank may legitimately arrive late at a collective solver call (I/O, printing): wait long (30 s; bench.py: 8 s)
+    // a rank may legitimately arrive late at a collective solver call (I/O, printing): wait long (10 s; bench.py: 8 s)
     // before declaring a peer lost -- the spinning kernels occupy one wavefront each
-    double timeout_ms = 30000.0;
+    double timeout_ms = 10000.0;
     if (const char *e = getenv("BICG_P2P_TIMEOUT_MS")) timeout_ms = atof(e);
     t->timeout_ticks = (unsigned long long)(timeout_ms * 1.0e5);     // 100 MHz wall clock
 
@@ -239,6 +239,16 @@ int p2p_enable(Comm *c)
     }
     c->p2p = t;
     return 0;
+}
+
+void p2p_disable(Comm *c)
+{
+    if (!c->p2p) return;
+    (void)hipSetDevice(c->device);
+    (void)hipDeviceSynchronize();
+    delete c->p2p;
+    c->p2p = nullptr;
+    c->p2p_auto = false;
 }
 
 }  // namespace bicg

@@ -102,6 +102,7 @@ struct bicg_ctx {
     int halo_unsynced = 0;          // exchanges since the last all-reduce or barrier (flow control)
     unsigned pend_seq = 0;
     bool comm_failed = false;       // a peer-to-peer wait timed out (BICG_P2P_SOFT_FAIL)
+    bool soft_fail = false;         // ... report it through comm_failed instead of ending the program (drop-in fallback)
     // Exchange folded into the SpMV launch (HaloLL): possible when every halo-touching row is on the
     // sliced-ELL path. One launch covers push + interior + halo-touching groups (listed in that order).
     bool ll_fused = false;
@@ -813,7 +814,7 @@ void fetch_scal(bicg_ctx *c)
         // BICG_P2P_SOFT_FAIL=1: report through bicg_comm_failed() and stop iterating instead of
         // exiting (bench.py then falls back to the RCCL collectives)
         const char *soft = getenv("BICG_P2P_SOFT_FAIL");
-        if (!soft || atoi(soft) == 0)
+        if (!c->soft_fail && (!soft || atoi(soft) == 0))
             die("peer-to-peer transport", "timed out waiting for another rank (BICG_P2P_TIMEOUT_MS)");
         if (!c->comm_failed)
             fprintf(stderr, "bicgstab_hip: rank %d: peer-to-peer transport timed out waiting for another rank\n", c->rank);
@@ -976,7 +977,8 @@ int run_iterate(bicg_ctx *c, int nsteps)
 int run_end(bicg_ctx *c, bicg_result *res)
 {
     const bicg_options &o = c->opt;
-    const bool talk = c->rank == 0 && !o.quiet;
+    // (a drop-in solve that lost its peer-to-peer path is about to be repeated: no summary of the aborted attempt)
+    const bool talk = c->rank == 0 && !o.quiet && !(c->comm_failed && c->soft_fail);
     const int k = c->hS->k;
     c->last_iters = k;
     double spmv_ms = 0.0;
@@ -1426,6 +1428,30 @@ void dropin_release(bicg_ctx *c)
     if (c && !dropin_cache_enabled() && c == g_dropin.ctx) { bicg_destroy(c); g_dropin.ctx = nullptr; }
 }
 
+// drop-in fallback from an automatically chosen peer-to-peer path. p2p_guard: arm it for this call (keeps copies of the
+// caller's vectors); p2p_fell_back: collective -- true when some rank timed out; the resident context and the
+// peer-to-peer state are gone then, and the next dropin_context() builds on the transport's collectives.
+bool p2p_guard(bicg_ctx *c, const double *x, const double *r, std::vector<double> &x0, std::vector<double> &b)
+{
+    if (!c->p2p || !c->comm->p2p_auto) return false;
+    c->soft_fail = true;
+    x0.assign(x, x + c->n_loc); b.assign(r, r + c->n_loc);
+    return true;
+}
+bool p2p_fell_back(bicg_ctx *c)
+{
+    Comm *comm = c->comm;
+    const bool failed = !all_ranks(comm, !c->comm_failed);
+    if (!failed) return false;
+    if (comm->rank == 0)
+        fprintf(stderr, "bicgstab_hip: the peer-to-peer data path timed out in a solve although its self-test had passed; "
+                        "repeating the solve with the %s collectives\n", comm->name());
+    bicg_dropin_release();
+    if (!g_live.empty()) die("peer-to-peer transport", "timed out, and other contexts still use it: cannot fall back");
+    p2p_disable(comm);
+    return true;
+}
+
 int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, double *x, double *r, int krr, int nrr)
 {
     check_square(info);
@@ -1435,7 +1461,19 @@ int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, do
     bicg_ctx *c = dropin_context(diag, offd, info);
     if (!c) die("bicg_create", "failed");
     bicg_result res;
-    const int k = bicg_solve(c, method, x, r, &o, &res);
+    // The peer-to-peer data path is chosen automatically when its self-test passes (bicg_comm_init_mpi "auto"). Should it
+    // fail in a real solve all the same -- a wait for a peer times out -- the solve is repeated on the transport's own
+    // collectives (RCCL / MPI-staged) from the caller's x0 and b instead of ending the program.
+    std::vector<double> x0, b;
+    const bool guarded = p2p_guard(c, x, r, x0, b);
+    int k = bicg_solve(c, method, x, r, &o, &res);
+    if (guarded && p2p_fell_back(c)) {
+        memcpy(x, x0.data(), sizeof(double) * x0.size());
+        memcpy(r, b.data(), sizeof(double) * b.size());
+        c = dropin_context(diag, offd, info);
+        if (!c) die("bicg_create", "failed");
+        k = bicg_solve(c, method, x, r, &o, &res);
+    }
     dropin_release(c);
     return k;
 }
@@ -2206,7 +2244,17 @@ static int dropin_shifted(int mode, CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i
     bicg_ctx *c = dropin_context(d, o, i);
     if (!c) die("bicg_create", "failed");
     bicg_result res;
-    const int k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
+    std::vector<double> x0, b, xs0;
+    const bool guarded = p2p_guard(c, x_set, r, x0, b);
+    if (guarded) xs0.assign(x_set, x_set + (size_t)nsig * c->n_loc);
+    int k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
+    if (guarded && p2p_fell_back(c)) {
+        memcpy(x_set, xs0.data(), sizeof(double) * xs0.size());
+        memcpy(r, b.data(), sizeof(double) * b.size());
+        c = dropin_context(d, o, i);
+        if (!c) die("bicg_create", "failed");
+        k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
+    }
     dropin_release(c);
     return k;
 }

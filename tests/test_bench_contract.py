@@ -30,6 +30,13 @@ def test_bench_json_keys_are_the_contract():
     # round-2 additions: the other workloads north_star names and per-variant roofline fractions ride on the same line
     for key in ("variant_rooflines", "extras", "variants_ms_per_iteration", "cpu_baseline_multicore"):
         assert re.search(rf'"{key}"\s*:', src), key
+    # round-3 additions: the box's own STREAM rates as roofline denominators (no hard-coded 6290 any more), and at N > 1
+    # the communicator report + the second leg over RCCL collectives
+    for key in ("stream_measured_gbps", "frac_of_measured_stream", "frac_of_measured_copy", "frac_of_measured_read", "comm"):
+        assert re.search(rf'"{key}"\s*:', src), key
+    for key in ("world", "p2p_selftest", "rccl_nranks", "transport_used", "fallback_reason"):
+        assert f'"{key}"' in src, key
+    assert "6290.0" not in src and "rccl_leg" in src
     for wl in ("banded", "fem_like", "laplace7"):
         assert f'"{wl}"' in src
     assert "--half-bandwidth" in src and "--no-extras" in src and "--no-traffic" in src

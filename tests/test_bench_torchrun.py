@@ -37,6 +37,16 @@ def test_bench_under_torchrun(n, transport, extras):
     assert ("peer-to-peer" in cfg["transport"]) == (transport == "host-p2p"), cfg["transport"]
     assert math.isfinite(cfg["true_relres_after_timed_region"])
     assert d["roofline"]["bound"] == "hbm" and d["roofline"]["achieved"] > 0
+    # the communicator report: which data path produced `value`, what the self-test said, whether RCCL saw N ranks, and the
+    # second leg over the RCCL collectives -- on this one-GPU box it cannot run (ranks share the device) but MUST say so
+    cm = d["comm"]
+    assert cm["world"] == n and cm["transport_used"] == cfg["transport"] and cm["fallback_reason"] is None
+    assert (cm["p2p_selftest"] == "passed") == (transport == "host-p2p"), cm
+    assert cm["rccl_leg"] is not None and ("unavailable" in cm["rccl_leg"] or cm["rccl_leg"]["ms_per_iteration"] > 0), cm
+    if "unavailable" in cm["rccl_leg"]:
+        assert "share a device" in cm["rccl_leg"]["unavailable"]
+    st = d["roofline"]["stream_measured_gbps"]
+    assert st and 3000 < st["copy"] < 8000 and 3000 < st["triad"] < 8000 and 3000 < st["read8"] < 8000, st
     if extras:      # north_star: "Transport.mtx and synthetic banded CSR reported at 1, 2, 4 and 8 GPUs"
         for hb in (8, 64, 512):
             e = d["extras"][f"banded_b{hb}"]
@@ -63,6 +73,10 @@ def test_bench_single_gpu_line_has_every_leg():
         assert legs and all(v["iterations_genuine"] is True for v in legs), (key, legs)   # no leg timed a converged solve
     assert d["extras"]["laplace7_256_ca"]["rows"] == 256 ** 3 and d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"] > 0
     rf = d["roofline"]
+    st = rf["stream_measured_gbps"]
+    assert st and 4000 < st["copy"] < 8000 and 4000 < st["triad"] < 8000 and 4000 < st["read8"] < 8000, st
+    assert 0.5 < rf["frac_of_measured_stream"] < 1.2 and 0.5 < rf["frac_of_measured_read"] < 1.0, rf
+    assert d["comm"]["world"] == 1 and d["comm"]["rccl_leg"] is None
     assert rf["traffic"] is not None, "rocprofv3 counter passes did not deliver"
     assert 0.7 * rf["algorithmic_bytes_per_launch"] < rf["traffic"] < 1.5 * rf["algorithmic_bytes_per_launch"]
     assert 1.7 < rf["traffic_detail"]["fetch_factor_reproducing_k_vec_FPlainQ"] < 2.3

@@ -134,3 +134,25 @@ def test_c_host_two_ranks_peer_to_peer_over_mpi(mtx, tmp_path):
     assert "not available" not in log, log
     assert abs(k1 - k0) <= 1 and np.abs(x1 - x0).max() <= 1e-11
     assert np.abs(x1 - 1.0).max() <= 1e-9
+
+
+@need
+def test_c_host_falls_back_when_the_peer_to_peer_path_fails_in_a_solve(mtx, tmp_path):
+    """the automatically chosen peer-to-peer path is a bet on its self-test: when a wait for a peer times out in a
+    real solve (here: rank 1 stops sending halo values from its 7th exchange on, BICG_P2P_FAULT_AFTER) the drop-in
+    entry point repeats the solve on the transport's own collectives instead of ending the program with a time-out"""
+    env = dict(os.environ, BICG_CHECK_EVERY="4", BICG_TRANSPORT="p2p", BICG_P2P_FALLBACK="1", BICG_P2P_TIMEOUT_MS="1500",
+               BICG_P2P_FAULT_AFTER="7")
+    prefix = str(tmp_path / "fb")
+    out = subprocess.run([MPIEXEC, "-n", "2", HOST, mtx, "bicgstab", "--dump", prefix], capture_output=True, text=True,
+                         timeout=300, env=env)
+    log = out.stdout + out.stderr
+    assert out.returncode == 0, log
+    assert "repeating the solve" in log, log
+    xs = []
+    for p in range(2):
+        raw = open(f"{prefix}.rank{p}.bin", "rb").read()
+        nl = int(np.frombuffer(raw[4:8], dtype=np.int32)[0])
+        xs.append(np.frombuffer(raw[8:8 + 8 * nl], dtype=np.float64))
+    assert np.abs(np.concatenate(xs) - 1.0).max() <= 1e-9
+    assert float(re.search(r"Final r\s*:\s*(\S+)", out.stdout).group(1)) <= 1e-15
