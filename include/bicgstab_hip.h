@@ -276,7 +276,9 @@ int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);
 enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FLAG_COL16 = 8, BICG_FLAG_ALL_SELL = 16, BICG_FLAG_JAGGED = 32,
        BICG_FLAG_SPMM = 64, BICG_FLAG_WINDOW = 128,
        BICG_FLAG_ROWSPLIT = 256   /* long rows: a row is spread over 8..64 lanes (k_spmv_rows); row sums then agree with the
-                                     reference's to 1e-13 x sum |a_ij x_j| instead of bit for bit */ };
+                                     reference's to 1e-13 x sum |a_ij x_j| instead of bit for bit */,
+       BICG_FLAG_PERSIST = 512    /* pipe_bicgstab runs as ONE persistent launch per chunk of iterations (latency-bound ranks:
+                                     matrix slices and x window in LDS, vectors in registers; bicg_persist.hip) */ };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 /* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);

@@ -275,6 +275,53 @@ struct SpmvArgs {
     Vecs    epi;            // launch_spmv_sell_epi: the vectors of the element-wise phase in the epilogue
 };
 
+// ---- persistent pipelined iteration for latency-bound ranks (bicg_persist.hip) ---------------------------------
+// ONE launch runs `niter` iterations of pipe_bicgstab (reference src/solver.c:351-398). A workgroup of 64 * spw
+// threads owns spw consecutive 64-row slices for the whole launch (lane = row): its rows' vectors live in registers,
+// its part of the matrix and the x values its rows touch live in LDS. Nothing crosses a kernel boundary, so whatever
+// one workgroup needs from another travels as LL words (8 bytes = 32 payload bits + 32-bit sequence tag, one store, a
+// stale word is recognisable -- no flags, no fences): the two SpMV input vectors z and w (every row publishes its
+// value, the consumers' window loads spin on the tags), the dot partials (one row of a table per workgroup) and the
+// applied scalars (one row, written by a helper workgroup that owns no rows: it adds the table in a fixed order,
+// exchanges the sums with the other ranks through the peer-to-peer mailboxes, applies the recurrence and publishes
+// alpha / beta / omega / done). Halo values of other ranks arrive in the landing ring as LL words exactly as in the
+// multi-launch path and are read by the same window loads.
+struct PersistArgs {
+    uint32_t nrows, nslices, nwg, spw;   // nwg row workgroups (+ 1 helper) of 64 * spw threads
+    // matrix, padded slices with diag entries first, then offd entries (x_ext numbering): entry k of lane l of slice s
+    // at pbase[s] + k * 64 + l; pslot = slot of the entry's column in the workgroup's window
+    const double         *pval;
+    const unsigned short *pslot;
+    const uint32_t       *pbase;         // [nslices + 1]
+    const unsigned short *rlen, *rdiag;  // [nrows] entries of the row / of its diag part
+    const uint32_t *win_ptr;             // [nwg + 1] runs of workgroup g
+    const uint2    *win_runs;            // {first column (>= nrows: halo position + nrows), (first slot << 16) | length}
+    uint32_t win_slots, max_runs;        // LDS doubles of the largest window; most runs of one workgroup
+    uint32_t mat_entries;                // > 0: the workgroup's matrix entries are copied into LDS (at most this many)
+    llword *llv[2];                      // [nrows][2] local LL images of z and w
+    llword *dtab[2];                     // [nwg][kRedSlots][2] dot partials of the two groups
+    llword *arow[2];                     // [4][2] applied scalars after each group: alpha, beta, omega, done
+    unsigned seq0;                       // tags of this launch: seq0 + 2 it + 1 (z group), + 2 (w group)
+    int niter;
+    // halo (multi rank, peer-to-peer transport)
+    int multi;
+    const llword *ring; uint32_t halo; unsigned halo_seq0;        // exchange numbers halo_seq0 + 2 it + 1 / + 2
+    const uint32_t *snd_ptr;             // [nwg + 1] send-list entries of workgroup g
+    const unsigned short *snd_row;       // row within the workgroup
+    const unsigned long long *snd_dst0, *snd_stride;
+    P2pRed p2p;                          // mailboxes; group numbers p2p.seq + 2 it / + 1
+    Vecs v;
+    Scal *S;
+    int *alarm;
+    unsigned long long timeout_ticks;
+    unsigned first_sleep;                // row wavefronts: s_sleep(8) periods (~0.22 us each) before the first look at the window
+    int xcd_map;                         // XCD-contiguous assignment of row ranges to workgroups
+    unsigned long long *dbg;             // BICG_PERSIST_TRACE: 100 MHz time stamps of one row workgroup and the helper, [it][16]
+};
+void launch_pipe_persist(const PersistArgs &a, hipStream_t st);
+unsigned persist_lds_bytes(const PersistArgs &a);
+constexpr unsigned kPersistMaxLds = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for (static part: < 1 KiB)
+
 // Sliced-ELL SpMM over kSpmmCols vectors held row-major (bicg_kernels.hip, k_spmm_sell)
 constexpr int kSpmmCols = 16;
 struct SpmmArgs {

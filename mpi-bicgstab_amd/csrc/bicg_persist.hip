@@ -1,0 +1,523 @@
+// bicg_persist.hip -- the pipelined BiCGStab iteration (reference src/solver.c:351-398) as ONE persistent launch for
+// latency-bound ranks: a 200 k-row rank (1/8 of Transport) holds 30 MB of matrix -- 117 KB per CU, which fits the
+// 160 KB of LDS of a CDNA4 CU -- and 10 work vectors of one value per thread. So a workgroup of up to 1024 threads owns
+// the same <= 1024 rows for a whole chunk of iterations: matrix slices and the x window in LDS, the vectors in
+// registers, and the only traffic per iteration is what other workgroups (or other GPUs) must see, sent as LL words.
+// See struct PersistArgs (bicg_device.h) for the protocol. The multi-launch form of the same iteration
+// (k_spmv_sell_epi, two launches of ~13 us on such a rank) pays a kernel boundary per SpMV; here an SpMV costs one
+// neighbour hand-off (~1-2 us) plus LDS arithmetic.
+//
+// Arithmetic: every expression is the one of FPipe1 / FPipe2 / sell_row (bicg_kernels.hip), operation for operation,
+// with -ffp-contract=off: rows and element-wise phases are bit-identical to the multi-launch path and to the
+// reference; the dot sums are associated differently (wavefront -> workgroup -> table in workgroup order), fixed, so
+// runs are bit-reproducible.
+#include "bicg_device.h"
+#include "bicg_devfn.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace bicg {
+
+namespace {
+
+constexpr int kMaxWaves = 16;             // 15 row wavefronts + the communication wavefront
+
+struct PersistLds {
+    Scal   priv;                          // helper: the scalar block the recurrence runs on
+    double wsum[kMaxWaves * kMaxDots];    // per-wavefront partial sums
+    double sums[kRedSlots];
+    double sc[4];                         // alpha, beta, omega, done as received
+    double pv[kRedSlots * kMaxRanksP2p];  // helper, multi rank: every rank's sums
+    int    fail;
+};
+
+// Workgroup barrier that orders LDS traffic only. __syncthreads() also waits for the wavefront's outstanding GLOBAL
+// accesses, and nothing inside a workgroup is ever handed over through global memory here.
+__device__ __forceinline__ void lds_barrier()
+{
+    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+}
+
+__device__ __forceinline__ bool alarm_raised(const int *alarm)
+{
+    return __hip_atomic_load(alarm, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) != 0;
+}
+__device__ __forceinline__ void raise_alarm(int *alarm)
+{
+    __hip_atomic_store(alarm, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+// An LL pair (one double) as ONE 16-byte access: {payload lo, tag, payload hi, tag}. Each 8-byte half carries its own
+// tag, so a torn access is recognisable. (The s_nop after the store: a VALU write to the data registers of a store wider
+// than 64 bits needs wait states the compiler inserts for its own stores but cannot know about here.) Write-through / L1-bypassing (sc0 sc1: system scope, also right for the
+// uncached landing rings other GPUs store into). Scalar 8-byte write-through stores cost ~3 x the fabric time per byte.
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ void ll_store16(llword *dst, double v, unsigned tag)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const u32x4 w = {(unsigned)bits, tag, (unsigned)(bits >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc0 sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+}
+__device__ __forceinline__ bool ll_decode(const u32x4 &w, unsigned tag, double *out)
+{
+    *out = __longlong_as_double((long long)(((unsigned long long)w.z << 32) | (unsigned long long)w.x));
+    return w.y == tag && w.w == tag;
+}
+// loads of 1 / 2 / 4 / 5 pairs, all requested before the first result is waited for (the waitcnt is part of the asm
+// statement: the compiler never sees a register that is still in flight). SYS: system scope (sc0 sc1) for words another
+// GPU stores into; agent scope (sc1) inside this GPU.
+#define LL_LD(SYSV) (SYSV ? "sc0 sc1" : "sc1")
+template <bool SYS> __device__ __forceinline__ void ll_load16_x1(const llword *p0, u32x4 &r0)
+{
+    if (SYS) asm volatile("global_load_dwordx4 %0, %1, off sc0 sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(p0) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %1, off sc1\n\ts_waitcnt vmcnt(0)" : "=&v"(r0) : "v"(p0) : "memory");
+}
+template <bool SYS> __device__ __forceinline__ void ll_load16_x2(const llword *p0, const llword *p1, u32x4 &r0, u32x4 &r1)
+{
+    if (SYS) asm volatile("global_load_dwordx4 %0, %2, off sc0 sc1\n\tglobal_load_dwordx4 %1, %3, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                          : "=&v"(r0), "=&v"(r1) : "v"(p0), "v"(p1) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %2, off sc1\n\tglobal_load_dwordx4 %1, %3, off sc1\n\ts_waitcnt vmcnt(0)"
+                      : "=&v"(r0), "=&v"(r1) : "v"(p0), "v"(p1) : "memory");
+}
+template <bool SYS> __device__ __forceinline__ void ll_load16_x4(const llword *const (&p)[4], u32x4 (&r)[4])
+{
+    if (SYS) asm volatile("global_load_dwordx4 %0, %4, off sc0 sc1\n\tglobal_load_dwordx4 %1, %5, off sc0 sc1\n\t"
+                          "global_load_dwordx4 %2, %6, off sc0 sc1\n\tglobal_load_dwordx4 %3, %7, off sc0 sc1\n\ts_waitcnt vmcnt(0)"
+                          : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+    else asm volatile("global_load_dwordx4 %0, %4, off sc1\n\tglobal_load_dwordx4 %1, %5, off sc1\n\t"
+                      "global_load_dwordx4 %2, %6, off sc1\n\tglobal_load_dwordx4 %3, %7, off sc1\n\ts_waitcnt vmcnt(0)"
+                      : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]) : "v"(p[0]), "v"(p[1]), "v"(p[2]), "v"(p[3]) : "memory");
+}
+__device__ __forceinline__ void ll_load16_x5(const llword *p, u32x4 (&r)[5])       // five consecutive pairs, inside this GPU
+{
+    asm volatile("global_load_dwordx4 %0, %5, off sc1\n\tglobal_load_dwordx4 %1, %5, off offset:16 sc1\n\t"
+                 "global_load_dwordx4 %2, %5, off offset:32 sc1\n\tglobal_load_dwordx4 %3, %5, off offset:48 sc1\n\t"
+                 "global_load_dwordx4 %4, %5, off offset:64 sc1\n\ts_waitcnt vmcnt(0)"
+                 : "=&v"(r[0]), "=&v"(r[1]), "=&v"(r[2]), "=&v"(r[3]), "=&v"(r[4]) : "v"(p) : "memory");
+}
+// stores inside this GPU: agent scope
+__device__ __forceinline__ void ll_store16_agent(llword *dst, double v, unsigned tag)
+{
+    const unsigned long long bits = (unsigned long long)__double_as_longlong(v);
+    const u32x4 w = {(unsigned)bits, tag, (unsigned)(bits >> 32), tag};
+    asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(w) : "memory");
+}
+
+// The x window (row wavefronts): the columns this workgroup's rows touch, as LL pairs of sequence `seq` (local rows) or
+// `hseq` (halo positions, landing ring slot hseq % kHaloRing). Every thread requests its values first and then re-reads
+// only those whose tags have not arrived. Row wavefronts never store to global memory inside the iteration loop: on
+// gfx9 loads and stores share one in-order counter, so a load issued behind a write-through store would not be seen
+// before that store has been acknowledged (~2 us) -- all stores are the communication wavefront's.
+template <bool MULTI>
+__device__ __forceinline__ void stage_window(const PersistArgs &a, const uint2 *runs, unsigned nruns, unsigned nslots, const llword *src,
+                                             unsigned seq, unsigned hseq, double *win, unsigned nrt, PersistLds &L, const double *zs,
+                                             uint32_t row0, uint32_t nmine)
+{
+    constexpr int W = 4;                  // values per thread and round
+    const unsigned tid = threadIdx.x;
+    const llword *ring = a.ring + (size_t)(hseq % kHaloRing) * a.halo * 2;
+    bool ok = true;
+    for (unsigned base = 0; base < nslots && ok; base += W * nrt) {
+        const llword *p[W];
+        unsigned want[W];
+        unsigned pend = 0u;
+#pragma unroll
+        for (int j = 0; j < W; ++j) {
+            const unsigned s = base + tid + j * nrt;
+            p[j] = src; want[j] = seq;
+            if (s < nslots) {
+                unsigned r = 0;
+                while (r + 1 < nruns && (runs[r + 1].y >> 16) <= s) ++r;       // runs are few and ordered by slot
+                const uint32_t col = runs[r].x + (s - (runs[r].y >> 16));
+                if (col - row0 < nmine) { win[s] = zs[col - row0]; continue; }      // this workgroup's own rows: straight from LDS
+                if (col < a.nrows) { p[j] = src + 2 * (size_t)col; }
+                else { p[j] = ring + 2 * (size_t)(col - a.nrows); want[j] = hseq; }
+                pend |= 1u << j;
+            }
+        }
+        const unsigned long long t0 = wall_clock64();
+        // Nothing can have arrived before the neighbours' stores have crossed the fabric (~1 us): polling from the first
+        // cycle only fills the fabric with 200 k threads' failed reads and delays the very stores they wait for.
+        if (base == 0) for (unsigned i = 0; i < a.first_sleep; ++i) __builtin_amdgcn_s_sleep(8);
+        for (unsigned spin = 0; pend; ++spin) {
+            if (spin) __builtin_amdgcn_s_sleep(6);
+            u32x4 w[W];
+            ll_load16_x4<MULTI>(p, w);
+#pragma unroll
+            for (int j = 0; j < W; ++j) {
+                double val;
+                if (((pend >> j) & 1u) && ll_decode(w[j], want[j], &val)) {
+                    win[base + tid + j * nrt] = val;
+                    pend &= ~(1u << j);
+                }
+            }
+            if (pend && (spin & 15u) == 15u) {
+                if (wall_clock64() - t0 > a.timeout_ticks || alarm_raised(a.alarm)) { ok = false; break; }
+            }
+        }
+    }
+    if (!ok) { L.fail = 1; raise_alarm(a.alarm); }
+}
+
+// y_i of this lane's row: diag entries in stored order, then the offd entries (reference src/matrix.c:434-440, 506-515)
+template <bool MULTI>
+__device__ __forceinline__ double persist_row(const double *mval, const unsigned short *mslot, uint32_t slen, uint32_t mylen, uint32_t mydiag,
+                                              const double *win)
+{
+    constexpr int U = 8;
+    const unsigned lane = threadIdx.x & 63u;
+    double sd = 0.0, so = 0.0;
+    for (uint32_t k0 = 0; k0 < slen; k0 += U) {
+        double v[U];
+        unsigned sl[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            const bool in = k0 + e < slen;            // wave-uniform
+            const uint32_t j = (k0 + e) * kSliceRows + lane;
+            v[e] = in ? mval[j] : 0.0;
+            sl[e] = in ? (unsigned)mslot[j] : 0u;
+        }
+        double xv[U];
+#pragma unroll
+        for (int e = 0; e < U; ++e) xv[e] = win[sl[e]];
+#pragma unroll
+        for (int e = 0; e < U; ++e) {
+            if (k0 + e < mydiag) sd += v[e] * xv[e];
+            else if (MULTI && k0 + e < mylen) so += v[e] * xv[e];
+        }
+    }
+    double yi = 0.0 + sd;
+    if (MULTI) yi += so;
+    return yi;
+}
+
+// row wavefronts: this row's value of the vector to publish and the wavefront's dot partials go to LDS
+template <int N>
+__device__ __forceinline__ void hand_over(double val, double (&acc)[N], double *zs, PersistLds &L, llword *img_row, unsigned seq)
+{
+    const unsigned lane = threadIdx.x & 63u, wave = threadIdx.x >> 6;
+    // One 16-byte write-through store per row, all wavefronts at once (a single wavefront storing the whole image took
+    // 1.6 us). The wavefront's next global loads -- the window -- cannot return before this store is acknowledged
+    // (one in-order counter on gfx9), but nothing it waits for can be there earlier either.
+    if (img_row) ll_store16_agent(img_row, val, seq);
+    zs[threadIdx.x] = val;
+#pragma unroll
+    for (int d = 0; d < N; ++d) acc[d] = wave_sum(acc[d]);
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) L.wsum[wave * kMaxDots + d] = acc[d];
+    }
+}
+
+// communication wavefront: everything the rest of the GPU (and the other GPUs) gets from this workgroup in one phase --
+// the LL image of its rows' values, the halo values other ranks need, its row of the dot table -- then the wait for the
+// applied scalars of that group (needed by the row wavefronts only after their product)
+template <int N, bool MULTI>
+__device__ __forceinline__ void comm_phase(const PersistArgs &a, unsigned lane, uint32_t row0, uint32_t nmine, unsigned nrw, const double *zs,
+                                           llword *img, unsigned seq, unsigned hseq, unsigned ns0, unsigned ns1, llword *tab_row,
+                                           PersistLds &L)
+{
+    // the dot partials first: the helper's chain (table -> sums -> recurrence -> scalars back) is the longest of the phase
+    if ((int)lane < N) {
+        double t[kMaxWaves];
+#pragma unroll
+        for (int w = 0; w < kMaxWaves - 1; ++w) t[w] = (unsigned)w < nrw ? L.wsum[w * kMaxDots + lane] : 0.0;
+        double s = t[0];
+#pragma unroll
+        for (int w = 1; w < kMaxWaves - 1; ++w) s += t[w];                          // wavefront order (+ 0.0 beyond the last)
+        ll_store16_agent(tab_row + 2 * lane, s, seq);
+    }
+    if (MULTI)
+        for (unsigned i = ns0 + lane; i < ns1; i += 64u)
+            ll_store16(reinterpret_cast<llword *>(a.snd_dst0[i] + (unsigned long long)(hseq % kHaloRing) * a.snd_stride[i]),
+                       zs[a.snd_row[i]], hseq);
+}
+
+// ... and, once the row wavefronts are busy with their product, the wait for the applied scalars of that group
+__device__ __forceinline__ void comm_scalars(const PersistArgs &a, unsigned lane, const llword *arow, unsigned seq, PersistLds &L)
+{
+    if (lane < 4) {
+        double v = 0.0;
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spin = 0;; ++spin) {
+            u32x4 w;
+            ll_load16_x1<false>(arow + 2 * lane, w);
+            if (ll_decode(w, seq, &v)) break;
+            __builtin_amdgcn_s_sleep(4);
+            if ((spin & 15u) == 15u && (wall_clock64() - t0 > a.timeout_ticks || alarm_raised(a.alarm))) {
+                L.fail = 1; raise_alarm(a.alarm); v = 0.0;
+                break;
+            }
+        }
+        L.sc[lane] = v;
+    }
+}
+
+// helper workgroup: sums of group `seq` over the table (workgroup order, fixed tree), exchanged with the other ranks,
+// recurrence applied on L.priv, scalars published.
+template <int N>
+__device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword *tab, llword *row, unsigned seq, unsigned mseq, int phase,
+                                             PersistLds &L, unsigned long long *stamp)
+{
+#define HSTAMP(i) do { if (stamp && threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
+    const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = nt >> 6;
+    double acc[N];
+#pragma unroll
+    for (int d = 0; d < N; ++d) acc[d] = 0.0;
+    bool ok = true;
+    for (unsigned g = tid; g < a.nwg && ok; g += nt) {
+        const llword *src = tab + (size_t)g * kRedSlots * 2;
+        double v[N];
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spin = 0;; ++spin) {
+            bool all = true;
+            if (N == 2) {
+                u32x4 w0, w1;
+                ll_load16_x2<false>(src, src + 2, w0, w1);
+                all = ll_decode(w0, seq, &v[0]) & ll_decode(w1, seq, &v[1]);
+            } else {
+                u32x4 w[5];
+                ll_load16_x5(src, w);
+#pragma unroll
+                for (int d = 0; d < N; ++d) all = ll_decode(w[d], seq, &v[d]) && all;
+            }
+            if (all) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((spin & 15u) == 15u && (wall_clock64() - t0 > a.timeout_ticks || alarm_raised(a.alarm))) { ok = false; break; }
+        }
+        if (!ok) break;
+#pragma unroll
+        for (int d = 0; d < N; ++d) acc[d] += v[d];
+    }
+    if (!ok) { L.fail = 1; raise_alarm(a.alarm); }
+    HSTAMP(0);
+#pragma unroll
+    for (int d = 0; d < N; ++d) acc[d] = wave_sum(acc[d]);
+    if (lane == 0) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) L.wsum[wave * kMaxDots + d] = acc[d];
+    }
+    lds_barrier();
+    HSTAMP(1);
+    if (L.fail) return false;
+    if ((int)tid < N) {
+        double s = L.wsum[tid];
+        for (unsigned w = 1; w < nw; ++w) s += L.wsum[w * kMaxDots + tid];
+        L.sums[tid] = s;
+    }
+    lds_barrier();
+    if (a.multi) {
+        // all-reduce over the ranks through the mailboxes (reference: one MPI_Iallreduce per dot, e.g. src/solver.c:363-367):
+        // store this rank's sums into every rank's mailbox, wait for the P contributions, add them like a
+        // recursive-doubling all-reduce would -- every rank gets the same bits. The stores are the LAST wavefront's, the
+        // waits the first wavefronts': a wavefront's loads are not seen before its own earlier stores are acknowledged.
+        const int P = a.p2p.nranks;
+        if (wave == nw - 1)
+            for (int t = lane; t < N * P; t += 64) {
+                const int p = t / N, d = t % N;
+                ll_store(a.p2p.mail[p] + mail_index(mseq, P, a.p2p.rank, d), L.sums[d], mseq);
+            }
+        const llword *mine = a.p2p.mail[a.p2p.rank];
+        const unsigned npoll = nw > 1 ? (nw - 1) * 64u : 64u;
+        if (tid < npoll)
+            for (int t = tid; t < N * P; t += npoll) {
+                const int p = t / N, d = t % N;
+                double v;
+                if (!ll_wait(mine + mail_index(mseq, P, p, d), mseq, a.timeout_ticks, &v)) L.fail = 1;
+                L.pv[p * kRedSlots + d] = v;
+            }
+        lds_barrier();
+        if (L.fail) { if (tid == 0) raise_alarm(a.alarm); return false; }
+        if ((int)tid < N) L.sums[tid] = rank_tree_sum(L.pv + tid, P);
+        lds_barrier();
+    }
+    if (tid == 0) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) L.priv.red[d] = L.sums[d];
+        apply_phase(&L.priv, phase, true);
+    }
+    lds_barrier();
+    HSTAMP(2);
+    if (tid < 4) {
+        const double v = tid == 0 ? L.priv.alpha : tid == 1 ? L.priv.beta : tid == 2 ? L.priv.omega : (double)L.priv.done;
+        ll_store16_agent(row + 2 * tid, v, seq);
+    }
+#undef HSTAMP
+    return true;
+}
+
+template <bool LDSMAT, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_pipe_persist(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    // Workgroup b runs on XCD b % 8 (observed placement, for speed only): give every XCD a contiguous range of rows, so that
+    // most of what a workgroup needs was published by a workgroup of its own XCD
+    unsigned wg = blockIdx.x;
+    if (a.xcd_map && wg < (a.nwg / 8u) * 8u) wg = (wg % 8u) * (a.nwg / 8u) + wg / 8u;
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        // ---------------- helper: no rows. Turns dot partials into applied scalars, twice per iteration.
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            const unsigned sz = a.seq0 + 2u * (unsigned)it + 1u, sw = sz + 1u;
+            unsigned long long *st = a.dbg && it < 32 ? a.dbg + it * 32 + 16 : nullptr;
+            if (!helper_group<2>(a, a.dtab[0], a.arow[0], sz, a.p2p.seq + 2u * (unsigned)it, PH_OMEGA, L, st ? st + 12 : nullptr)) break;
+            if (a.dbg && tid == 0 && it < 32) a.dbg[it * 32 + 10] = wall_clock64();
+            if (!helper_group<5>(a, a.dtab[1], a.arow[1], sw, a.p2p.seq + 2u * (unsigned)it + 1u, PH_RECUR_END, L, nullptr)) break;
+            if (a.dbg && tid == 0 && it < 32) a.dbg[it * 32 + 11] = wall_clock64();
+        }
+        lds_barrier();
+        if (tid == 0) {
+            if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
+            *a.S = L.priv;
+        }
+        return;
+    }
+
+    // ---------------- row workgroup: spw row wavefronts (slices wg * spw ..., lane = row) + one communication wavefront
+    double *win = dyn;
+    double *mval = dyn + a.win_slots;
+    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
+    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
+    double *zs = reinterpret_cast<double *>(runs + a.max_runs);         // [64 * spw] this workgroup's values of the vector being published
+
+    const unsigned nrw = a.spw, nrt = 64u * a.spw;                      // row wavefronts / row threads
+    const bool comm = wave == nrw;
+    const uint32_t s0 = wg * a.spw, s1 = min(a.nslices, s0 + a.spw);
+    const uint32_t row0 = s0 * kSliceRows, nmine = min(a.nrows, s1 * kSliceRows) - row0;
+    const uint32_t slice = s0 + wave;
+    const bool have_slice = !comm && slice < a.nslices;
+    const uint32_t row = slice * kSliceRows + lane;
+    const bool live = have_slice && row < a.nrows;
+    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1];
+    uint32_t sbase = 0, slen = 0;
+    if (have_slice) { sbase = a.pbase[slice]; slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
+    const uint32_t mylen = live ? a.rlen[row] : 0u, mydiag = live ? a.rdiag[row] : 0u;
+    const unsigned r0w = a.win_ptr[wg], nruns = a.win_ptr[wg + 1] - r0w;
+    for (unsigned i = tid; i < nruns; i += nt) runs[i] = a.win_runs[r0w + i];
+    unsigned nslots = 0;
+    if (nruns) { const uint2 last = a.win_runs[r0w + nruns - 1]; nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
+    const double *gval = a.pval + sbase;
+    const unsigned short *gslot = a.pslot + sbase;
+    if (LDSMAT) {
+        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
+        gval = mval + (sbase - e0); gslot = mslot + (sbase - e0);
+    }
+    const Vecs &e = a.v;
+    const uint32_t rr_ = live ? row : 0u;
+    double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], z = e.z[rr_], w = e.w[rr_], v = e.v[rr_], t = e.t[rr_];
+    const double h = e.rh[rr_];
+    double y = 0.0;
+    const unsigned ns0 = MULTI ? a.snd_ptr[wg] : 0u, ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    const bool trace = a.dbg && wg == a.nwg / 2 && (tid == 0 || tid == nrt);
+    const int tr0 = tid == 0 ? 0 : 32;
+#define STAMP(i) do { if (trace && it < 32) a.dbg[(it * 2 + (tr0 ? 1 : 0)) * 16 + (i)] = wall_clock64(); } while (0)
+    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    for (int it = 0; it < a.niter && !done; ++it) {
+        const unsigned sz = a.seq0 + 2u * (unsigned)it + 1u, sw = sz + 1u;
+        const unsigned hz = a.halo_seq0 + 2u * (unsigned)it + 1u, hw = hz + 1u;
+        STAMP(0);
+        // ---- phase 1: p, s, z recurrences, q (kept in r), y, (q,y), (y,y)            (src/solver.c:352-364, FPipe1)
+        if (!comm) {
+            p = recur3<double>(p, s, r, omega, beta);
+            const double s1n = recur3<double>(s, z, w, omega, beta);
+            const double z1n = recur3<double>(z, v, t, omega, beta);
+            s = s1n; z = z1n;
+            r = r + (-alpha) * s;             // q
+            y = w + (-alpha) * z;
+            double acc[2] = {live ? r * y : 0.0, live ? y * y : 0.0};
+            hand_over<2>(z, acc, zs, L, live ? a.llv[0] + 2 * (size_t)row : nullptr, sz);
+        }
+        lds_barrier();                        // B1: values and partials are in LDS
+        STAMP(1);
+        // ---- v = A z (row wavefronts)  ||  publish z, halo, partials; wait for omega (communication wavefront)
+        if (comm) comm_phase<2, MULTI>(a, lane, row0, nmine, nrw, zs, a.llv[0], sz, hz, ns0, ns1, tab0, L);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[0], sz, hz, win, nrt, L, zs, row0, nmine);
+        STAMP(2);
+        lds_barrier();                        // B2: window staged (the row wavefronts' concern)
+        if (comm) comm_scalars(a, lane, a.arow[0], sz, L);
+        else v = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+        STAMP(3);
+        lds_barrier();                        // B3: omega from (q,y), (y,y) is in L.sc          (src/solver.c:363-369)
+        if (L.fail) break;
+        omega = L.sc[2];
+        STAMP(4);
+        // ---- phase 2: x, r, w, five dots                                             (src/solver.c:370-380, FPipe2)
+        if (!comm) {
+            const double q = r;
+            double xx = x + alpha * p;
+            xx = xx + omega * q;
+            x = xx;
+            r = q + (-omega) * y;
+            const double tt = t + (-alpha) * v;
+            w = y + (-omega) * tt;
+            double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (live) { acc[0] = r * r; acc[1] = h * r; acc[2] = h * w; acc[3] = h * s; acc[4] = h * z; }
+            hand_over<5>(w, acc, zs, L, live ? a.llv[1] + 2 * (size_t)row : nullptr, sw);
+        }
+        lds_barrier();                        // B4
+        STAMP(5);
+        // ---- t = A w  ||  publish w, halo, partials; wait for beta, alpha, done       (src/solver.c:377-390)
+        if (comm) comm_phase<5, MULTI>(a, lane, row0, nmine, nrw, zs, a.llv[1], sw, hw, ns0, ns1, tab1, L);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[1], sw, hw, win, nrt, L, zs, row0, nmine);
+        STAMP(6);
+        lds_barrier();                        // B5
+        if (comm) comm_scalars(a, lane, a.arow[1], sw, L);
+        else t = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+        STAMP(7);
+        lds_barrier();                        // B6
+        if (L.fail) break;
+        alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] != 0.0 ? 1 : 0;
+        STAMP(8);
+    }
+#undef STAMP
+    if (live) {
+        e.x[row] = x; e.r[row] = r; e.p[row] = p; e.s[row] = s; e.z[row] = z; e.w[row] = w; e.v[row] = v; e.t[row] = t; e.y[row] = y;
+    }
+}
+
+}  // namespace
+
+unsigned persist_lds_bytes(const PersistArgs &a)
+{
+    const size_t threads = 64u * a.spw;       // row threads
+    return (unsigned)(8u * (size_t)a.win_slots + 8u * (size_t)a.mat_entries + 2u * (((size_t)a.mat_entries + 3u) & ~(size_t)3u) +
+                      8u * (size_t)a.max_runs + 8u * threads);
+}
+
+void launch_pipe_persist(const PersistArgs &a, hipStream_t st)
+{
+    const unsigned lds = persist_lds_bytes(a);
+    const dim3 g(a.nwg + 1u), b(64u * (a.spw + 1u));        // + the communication wavefront
+    auto go = [&](auto kernel) {
+        static bool raised[4] = {false, false, false, false};
+        const int idx = (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0);
+        if (!raised[idx]) {
+            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
+            if (e != hipSuccess) {
+                (void)hipGetLastError();
+                if (getenv("BICG_DEBUG")) fprintf(stderr, "bicgstab_hip: hipFuncSetAttribute(max dynamic LDS) said: %s\n", hipGetErrorString(e));
+            }
+            raised[idx] = true;
+        }
+        hipLaunchKernelGGL(kernel, g, b, lds, st, a);
+    };
+    if (a.mat_entries) { if (a.multi) go(k_pipe_persist<true, true>); else go(k_pipe_persist<true, false>); }
+    else { if (a.multi) go(k_pipe_persist<false, true>); else go(k_pipe_persist<false, false>); }
+    if (getenv("BICG_DEBUG")) {
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: HIP error \"%s\" noticed at: k_pipe_persist\n", hipGetErrorString(err));
+    }
+}
+
+}  // namespace bicg

@@ -132,6 +132,11 @@ struct bicg_ctx {
     bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues (BICG_FUSE_PIPE=0/1 overrides)
     bool fuse_small = true;      // ... the average block has < 6 M non-zeros: fused whatever the layout
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
+    // persistent pipelined iteration (bicg_persist.hip, struct PersistArgs): plan + LL buffers; persist.nwg == 0: not available
+    PersistArgs persist{};
+    bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0/1 overrides
+    unsigned persist_seq = 0;    // LL tags used so far
+    std::vector<void *> persist_mem;
     unsigned wg_cap = 0;         // ranks sharing this GPU (tests): workgroups per launch that may wait for another rank
     double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
     llword *shard_ll = nullptr;  // 2 x [kShards][kRedSlots][2], alternating like wpart
@@ -656,6 +661,9 @@ void group_flush(bicg_ctx *c)
 }
 
 void fetch_scal(bicg_ctx *c);
+}  // namespace
+void persist_chunk(bicg_ctx *c, int niter);
+namespace {
 
 // ---------------------------------------------------------------- the four iterations
 struct Driver {
@@ -806,10 +814,10 @@ void fetch_scal(bicg_ctx *c)
 {
     if (c->wave_mode) grp_close(c);      // the host wants the scalars: finish the open group now
     BICG_HIP(hipMemcpyAsync(c->hS, c->S, sizeof(Scal), hipMemcpyDeviceToHost, c->sc));
-    if (c->p2p) BICG_HIP(hipMemcpyAsync(c->h_alarm, c->alarm, sizeof(int), hipMemcpyDeviceToHost, c->sc));
+    if (c->p2p || c->persist_on) BICG_HIP(hipMemcpyAsync(c->h_alarm, c->alarm, sizeof(int), hipMemcpyDeviceToHost, c->sc));
     BICG_HIP(hipStreamSynchronize(c->sc));
     if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
-    if (c->hS->comm_error || (c->p2p && *c->h_alarm)) {
+    if (c->hS->comm_error || ((c->p2p || c->persist_on) && *c->h_alarm)) {
         c->hS->comm_error = 1; c->hS->done = 1;
         // BICG_P2P_SOFT_FAIL=1: report through bicg_comm_failed() and stop iterating instead of
         // exiting (bench.py then falls back to the RCCL collectives)
@@ -950,7 +958,9 @@ int run_iterate(bicg_ctx *c, int nsteps)
             force = true;
             c->adaptive_rr++;
         }
-        for (int j = 0; j < chunk; ++j) {
+        const bool persist = c->persist_on && c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0 && !c->time_kernels;
+        if (persist) persist_chunk(c, chunk);         // one launch for the whole chunk (bicg_persist.hip)
+        for (int j = 0; j < chunk && !persist; ++j) {
             // the last iteration before the caller (or the drift check) reads x / r leaves them as the reference would
             const bool last = j == chunk - 1 && (c->it + chunk >= stop || o.rr_drift > 0.0);
             if (j == 0 && force) { d.iterate(c->it, true, last); continue; }
@@ -1480,6 +1490,202 @@ int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, do
 
 }  // namespace
 
+// ---------------------------------------------------------------- persistent pipelined iteration: plan
+// Which rows a workgroup owns, its part of the matrix in padded slices (diag entries first, then offd entries in the
+// x_ext numbering [local rows | halo positions]) with window slots instead of columns, the window runs, and -- multi
+// rank -- the send-list entries of every workgroup. Returns false when the block does not qualify.
+bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32_t> &optr, const std::vector<uint32_t> &ocol,
+                   const std::vector<double> &oval, const std::vector<uint32_t> &send_idx, const std::vector<unsigned long long> &dst0,
+                   const std::vector<unsigned long long> &dstride)
+{
+    const uint32_t nrows = c->n_loc;
+    const bool multi = !c->single();
+    if (nrows == 0 || c->fault_after > 0) return false;
+    if (!(c->glist_all && c->nblk == 0 && !c->rowsplit && (c->single() || (c->p2p && c->ll_fused)))) return false;
+    hipDeviceProp_t prop;
+    BICG_HIP(hipGetDeviceProperties(&prop, c->device));
+    const int cus = prop.multiProcessorCount;
+    // one workgroup per CU (its LDS): ranks sharing a GPU (tests) share the CUs; one CU is the helper's
+    const int gmax = cus / std::max(1, c->comm->ranks_on_device) - 1;
+    if (gmax < 1) return false;
+    const uint32_t nslices = (nrows + kSliceRows - 1) / kSliceRows;
+    const uint32_t spw = (nslices + (uint32_t)gmax - 1) / (uint32_t)gmax;
+    if (spw > 15) return false;                                    // 15 row wavefronts + the communication wavefront per workgroup
+    const uint32_t nwg = (nslices + spw - 1) / spw, grows = spw * kSliceRows;
+
+    // merged rows in x_ext numbering
+    std::vector<uint32_t> mptr(nrows + 1, 0u);
+    for (uint32_t r = 0; r < nrows; ++r) mptr[r + 1] = mptr[r] + (diag->ptr[r + 1] - diag->ptr[r]) + (multi ? optr[r + 1] - optr[r] : 0u);
+    std::vector<uint32_t> mcol(mptr[nrows] ? mptr[nrows] : 1);
+    std::vector<double> mval(mptr[nrows] ? mptr[nrows] : 1);
+    std::vector<unsigned short> rlen(nrows), rdiag(nrows);
+    for (uint32_t r = 0; r < nrows; ++r) {
+        uint32_t at = mptr[r];
+        const uint32_t dl = diag->ptr[r + 1] - diag->ptr[r], ol = multi ? optr[r + 1] - optr[r] : 0u;
+        if (dl + ol > 65535u) return false;
+        for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j, ++at) { mcol[at] = diag->col[j]; mval[at] = diag->val[j]; }
+        if (multi) for (uint32_t j = optr[r]; j < optr[r + 1]; ++j, ++at) { mcol[at] = ocol[j]; mval[at] = oval[j]; }
+        rlen[r] = (unsigned short)(dl + ol); rdiag[r] = (unsigned short)dl;
+    }
+    // windows: runs of consecutive columns per workgroup; a run never straddles the local / halo boundary
+    const uint32_t max_slots = 16384;
+    std::vector<uint32_t> wptr0(nwg + 1, 0u);
+    long nruns = bicg_window_plan(mptr.data(), mcol.data(), nrows, grows, nullptr, max_slots, 8, nullptr, nullptr, nullptr);
+    if (nruns < 0) return false;
+    std::vector<uint32_t> runs0(2 * (size_t)nruns + 2);
+    uint32_t slots_used = 0;
+    bicg_window_plan(mptr.data(), mcol.data(), nrows, grows, nullptr, max_slots, 8, wptr0.data(), runs0.data(), &slots_used);
+    std::vector<uint32_t> wptr(nwg + 1, 0u);
+    std::vector<uint2> runs;
+    uint32_t max_runs = 0;
+    for (uint32_t g = 0; g < nwg; ++g) {
+        wptr[g] = (uint32_t)runs.size();
+        for (uint32_t i = wptr0[g]; i < wptr0[g + 1]; ++i) {
+            const uint32_t c0 = runs0[2 * i], slot0 = runs0[2 * i + 1] >> 16, len = runs0[2 * i + 1] & 0xFFFFu;
+            if (c0 < nrows && c0 + len > nrows) {
+                const uint32_t l1 = nrows - c0;
+                runs.push_back(make_uint2(c0, (slot0 << 16) | l1));
+                runs.push_back(make_uint2(nrows, ((slot0 + l1) << 16) | (len - l1)));
+            } else {
+                runs.push_back(make_uint2(c0, (slot0 << 16) | len));
+            }
+        }
+        max_runs = std::max<uint32_t>(max_runs, (uint32_t)runs.size() - wptr[g]);
+    }
+    wptr[nwg] = (uint32_t)runs.size();
+    if (max_runs > 1024) return false;
+    auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
+        uint32_t a = wptr[g], b = wptr[g + 1];
+        while (b - a > 1) { const uint32_t m = (a + b) / 2; if (runs[m].x <= col) a = m; else b = m; }
+        return (runs[a].y >> 16) + (col - runs[a].x);
+    };
+    // padded slices
+    std::vector<uint32_t> pbase(nslices + 1, 0u);
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        uint32_t longest = 0;
+        for (uint32_t r = sl * kSliceRows; r < std::min(nrows, (sl + 1) * (uint32_t)kSliceRows); ++r) longest = std::max<uint32_t>(longest, rlen[r]);
+        const uint64_t next = (uint64_t)pbase[sl] + (uint64_t)longest * kSliceRows;
+        if (next >= 0xFFFFFF00ull) return false;
+        pbase[sl + 1] = (uint32_t)next;
+    }
+    const size_t entries = pbase[nslices];
+    std::vector<double> pval(entries ? entries : 1, 0.0);
+    std::vector<unsigned short> pslot(entries ? entries : 1, 0);
+    uint32_t max_entries = 0;
+    for (uint32_t g = 0; g < nwg; ++g) {
+        const uint32_t s0 = g * spw, s1 = std::min(nslices, s0 + spw);
+        max_entries = std::max(max_entries, pbase[s1] - pbase[s0]);
+        for (uint32_t r = s0 * kSliceRows; r < std::min(nrows, s1 * (uint32_t)kSliceRows); ++r) {
+            const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
+            for (uint32_t j = mptr[r], k = 0; j < mptr[r + 1]; ++j, ++k) {
+                const size_t e = (size_t)pbase[sl] + (size_t)k * kSliceRows + lane;
+                pval[e] = mval[j];
+                pslot[e] = (unsigned short)slot_of(g, mcol[j]);
+            }
+        }
+    }
+    PersistArgs &a = c->persist;
+    a = PersistArgs{};
+    a.nrows = nrows; a.nslices = nslices; a.nwg = nwg; a.spw = spw;
+    a.win_slots = slots_used; a.max_runs = max_runs;
+    // the matrix goes to LDS when everything fits next to the window
+    a.mat_entries = max_entries;
+    if (getenv("BICG_PERSIST_LDSMAT") && atoi(getenv("BICG_PERSIST_LDSMAT")) == 0) a.mat_entries = 0;
+    if (persist_lds_bytes(a) > kPersistMaxLds) a.mat_entries = 0;
+    if (persist_lds_bytes(a) > kPersistMaxLds) { a = PersistArgs{}; return false; }
+    auto keep = [&](void *p) { c->persist_mem.push_back(p); return p; };
+    a.pval = (const double *)keep(dev_upload(pval.data(), pval.size()));
+    a.pslot = (const unsigned short *)keep(dev_upload(pslot.data(), pslot.size()));
+    a.pbase = (const uint32_t *)keep(dev_upload(pbase.data(), pbase.size()));
+    a.rlen = (const unsigned short *)keep(dev_upload(rlen.data(), rlen.size()));
+    a.rdiag = (const unsigned short *)keep(dev_upload(rdiag.data(), rdiag.size()));
+    a.win_ptr = (const uint32_t *)keep(dev_upload(wptr.data(), wptr.size()));
+    a.win_runs = (const uint2 *)keep(dev_upload(runs.data(), runs.size()));
+    for (int i = 0; i < 2; ++i) {
+        a.llv[i] = (llword *)keep(dev_alloc<llword>(2 * (size_t)nrows));
+        BICG_HIP(hipMemset(a.llv[i], 0, sizeof(llword) * 2 * (size_t)nrows));
+        a.dtab[i] = (llword *)keep(dev_alloc<llword>((size_t)nwg * kRedSlots * 2));
+        BICG_HIP(hipMemset(a.dtab[i], 0, sizeof(llword) * (size_t)nwg * kRedSlots * 2));
+        a.arow[i] = (llword *)keep(dev_alloc<llword>(8));
+        BICG_HIP(hipMemset(a.arow[i], 0, sizeof(llword) * 8));
+    }
+    a.multi = multi ? 1 : 0;
+    if (multi) {
+        // send-list entries by owning workgroup (the list is grouped by destination, a row may go to several ranks)
+        std::vector<uint32_t> sptr(nwg + 1, 0u);
+        for (uint32_t i = 0; i < c->nsend; ++i) sptr[send_idx[i] / grows + 1]++;
+        for (uint32_t g = 0; g < nwg; ++g) sptr[g + 1] += sptr[g];
+        std::vector<uint32_t> fill(sptr.begin(), sptr.end() - 1);
+        std::vector<unsigned short> srow(c->nsend ? c->nsend : 1);
+        std::vector<unsigned long long> sd0(c->nsend ? c->nsend : 1), sst(c->nsend ? c->nsend : 1);
+        for (uint32_t i = 0; i < c->nsend; ++i) {
+            const uint32_t g = send_idx[i] / grows, at = fill[g]++;
+            srow[at] = (unsigned short)(send_idx[i] - g * grows); sd0[at] = dst0[i]; sst[at] = dstride[i];
+        }
+        a.snd_ptr = (const uint32_t *)keep(dev_upload(sptr.data(), sptr.size()));
+        a.snd_row = (const unsigned short *)keep(dev_upload(srow.data(), srow.size()));
+        a.snd_dst0 = (const unsigned long long *)keep(dev_upload(sd0.data(), sd0.size()));
+        a.snd_stride = (const unsigned long long *)keep(dev_upload(sst.data(), sst.size()));
+        a.ring = c->halo_ring; a.halo = c->halo;
+    }
+    a.v = c->v;
+    a.alarm = c->alarm;
+    if (getenv("BICG_DEBUG"))
+        fprintf(stderr, "bicgstab_hip: rank %d: persistent plan: %u workgroups x (%u + 64) threads (+1 helper), window %u slots (%u runs at most), "
+                        "matrix %s (%u entries per workgroup), %u bytes of LDS\n", c->rank, nwg, 64 * spw, slots_used, max_runs,
+                a.mat_entries ? "in LDS" : "in memory", max_entries, persist_lds_bytes(a));
+    return true;
+}
+
+// niter iterations of pipe_bicgstab in one launch (the open dot group has been closed: fetch_scal precedes every chunk)
+void persist_chunk(bicg_ctx *c, int niter)
+{
+    if (c->grp.active) die("internal", "persistent chunk with an open dot group");
+    if (c->f1_done) die("internal", "persistent chunk after phase 1 of the next iteration has run");
+    PersistArgs a = c->persist;
+    a.v = c->v; a.S = c->S; a.alarm = c->alarm; a.niter = niter;
+    a.seq0 = c->persist_seq;
+    c->persist_seq += 2u * (unsigned)niter;
+    a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;          // 2 s inside one GPU
+    static const int xcd_map = getenv("BICG_PERSIST_XCD") ? atoi(getenv("BICG_PERSIST_XCD")) : 1;
+    a.xcd_map = xcd_map;
+    static const int first_sleep = getenv("BICG_PERSIST_SLEEP") ? atoi(getenv("BICG_PERSIST_SLEEP")) : 1;
+    a.first_sleep = (unsigned)first_sleep;
+    if (a.multi) {
+        // every rank advances its exchange and group numbers by the whole chunk, converged early or not
+        a.halo_seq0 = c->halo_seq; c->halo_seq += 2u * (unsigned)niter;
+        a.p2p = c->p2p->red_desc(c->p2p->red_seq); c->p2p->red_seq += 2u * (unsigned)niter;
+        a.ring = c->halo_ring;
+        c->halo_unsynced = 0;
+    }
+    static const bool want_trace = getenv("BICG_PERSIST_TRACE") != nullptr;
+    unsigned long long *dbg = nullptr;
+    if (want_trace) {
+        dbg = dev_alloc<unsigned long long>(64 * 16);
+        BICG_HIP(hipMemset(dbg, 0, 64 * 16 * sizeof(unsigned long long)));
+        a.dbg = dbg;
+    }
+    launch_pipe_persist(a, c->sc);
+    if (want_trace) {
+        // 10 ns ticks of one row workgroup (0 start, 1 z and partials published, 2 window staged, 3 product done, 4 omega here,
+        // 5 w and partials published, 6 window, 7 product, 8 scalars here) and of the helper (10 / 11: group 1 / 2 published)
+        std::vector<unsigned long long> h(64 * 16);
+        BICG_HIP(hipStreamSynchronize(c->sc));
+        BICG_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+        BICG_HIP(hipFree(dbg));
+        for (int it = std::max(0, std::min(niter, 32) - 5); it < std::min(niter, 32); ++it)
+            for (int who = 0; who < 2; ++who) {
+                const unsigned long long *q = h.data() + (size_t)(it * 2 + who) * 16, *q0 = h.data() + (size_t)(it * 2) * 16;
+                fprintf(stderr, "persist trace it %2d %s:", it, who ? "comm" : "row ");
+                for (int i = 0; i <= 8; ++i) fprintf(stderr, " %d:%+.2f", i, 0.01 * (double)(long long)(q[i] - q0[0]));
+                if (!who) fprintf(stderr, "  helper g1 %+.2f g2 %+.2f", 0.01 * (double)(long long)(q[10] - q0[0]), 0.01 * (double)(long long)(q[11] - q0[0]));
+                else fprintf(stderr, "  helper g1: arrived %+.2f summed %+.2f applied %+.2f", 0.01 * (double)(long long)(q[12] - q0[0]),
+                             0.01 * (double)(long long)(q[13] - q0[0]), 0.01 * (double)(long long)(q[14] - q0[0]));
+                fprintf(stderr, "\n");
+            }
+    }
+}
+
 // =====================================================================================  C ABI
 extern "C" {
 
@@ -1854,6 +2060,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // ---- peer-to-peer transport: publish this rank's halo landing ring, learn where every entry
     // of the send list lands in the ring of the rank that needs it (collective)
     c->p2p = comm->p2p;
+    std::vector<unsigned long long> dst0, dstride;
     if (const char *sv = getenv("BICG_P2P_FAULT_AFTER")) c->fault_after = atoi(sv);
     // in-kernel collect needs the HEAVY kernel instantiations (occupancy 5 instead of 8 waves per SIMD,
     // ~3 % per SpMV): worth it unless the local problem is so large that 3 % exceeds the ~10 us per
@@ -1872,7 +2079,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             dsp[p] = 2 * p * (int)sizeof(int);
         }
         comm->alltoallv_host(mine.data(), cnt.data(), dsp.data(), theirs.data(), cnt.data(), dsp.data());
-        std::vector<unsigned long long> dst0(c->nsend ? c->nsend : 1, 0ull), dstride(c->nsend ? c->nsend : 1, 0ull);
+        dst0.assign(c->nsend ? c->nsend : 1, 0ull); dstride.assign(c->nsend ? c->nsend : 1, 0ull);
         for (int p = 0; p < P; ++p)
             for (int j = 0; j < c->scnt[p]; ++j) {
                 const size_t i = (size_t)c->sdsp[p] + j;
@@ -1931,6 +2138,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->fuse_plan_ok = all_ranks(comm, c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused)));
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
+    {   // persistent pipelined iteration for latency-bound ranks: available when the plan fits on EVERY rank
+        const char *pe = getenv("BICG_PERSIST");
+        bool mine = !(pe && atoi(pe) == 0) && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
+        c->persist_on = all_ranks(comm, mine);
+        if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
+    }
 
     BICG_HIP(hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking));
     if (P > 1 || c->force_comm) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
@@ -1975,6 +2188,7 @@ void bicg_destroy(bicg_ctx *c)
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
+    for (void *p : c->persist_mem) if (p) (void)hipFree(p);
     release_p2p(c);
     if (c->push_dst0) (void)hipFree(c->push_dst0);
     if (c->push_stride) (void)hipFree(c->push_stride);
@@ -2226,6 +2440,7 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->spmm_ok) f |= BICG_FLAG_SPMM;
     if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
     if (c->rowsplit) f |= BICG_FLAG_ROWSPLIT;
+    if (c->persist_on) f |= BICG_FLAG_PERSIST;
     return f;
 }
 

@@ -338,7 +338,7 @@ class Context:
     def comm_failed(self) -> bool:
         return bool(lib().bicg_comm_failed(self.h))
 
-    FLAGS = {"p2p": 1, "ll_fused": 2, "overlap": 4, "col16": 8, "all_sell": 16, "jagged": 32, "spmm": 64, "window": 128, "rowsplit": 256}
+    FLAGS = {"p2p": 1, "ll_fused": 2, "overlap": 4, "col16": 8, "all_sell": 16, "jagged": 32, "spmm": 64, "window": 128, "rowsplit": 256, "persist": 512}
 
     def flags(self):
         f = int(lib().bicg_ctx_flags(self.h))

@@ -20,6 +20,9 @@ SHIFTED = ["shifted_lopbicgstab", "shifted_pipe_lopbicgstab", "shifted_bicgstab"
 
 def _solve_all(A, b, **env):
     import os
+    # bit equality across transports is a statement about identical kernels: the persistent one-launch form of
+    # pipe_bicgstab (bicg_persist.hip) associates the dot sums differently and is compared on its own below
+    env.setdefault("BICG_PERSIST", 0)
     saved = {k: os.environ.get(k) for k in env}
     os.environ.update({k: str(v) for k, v in env.items()})
     try:
@@ -116,3 +119,61 @@ def test_fused_pipelined_iteration_matches_separate_kernels(problem):
         assert np.abs(got[m][1] - ref[m][1]).max() <= 1e-9 * np.abs(ref[m][1]).max(), m
     for m in ("bicgstab", "ca_bicgstab"):          # untouched by the switch
         assert got[m][0] == ref[m][0] and np.array_equal(got[m][1], ref[m][1])
+
+
+def test_persistent_pipelined_iteration(problem, monkeypatch):
+    """pipe_bicgstab as ONE persistent launch per chunk of iterations (bicg_persist.hip: matrix slices and x window in
+    LDS, vectors in registers, everything that crosses workgroups as LL words) against the multi-launch forms: same
+    iteration count +-1, same solution to rounding (the dot sums are associated per wavefront -> workgroup -> table);
+    bit-reproducible from run to run; independent of how often the host looks (chunk length); and the same through the
+    peer-to-peer transport driven by one rank (helper workgroup exchanging the sums through the mailboxes)."""
+    A, b, ref = problem
+    H.lib().bicg_comm_init_single(0)
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert not ctx.flags()["persist"] or True
+    ctx.close()
+    runs = []
+    for check_every in (5, 5, 1, 64):
+        monkeypatch.setenv("BICG_PERSIST", "1")
+        ctx = H.Context(H.single_rank_blocks(A))
+        assert ctx.flags()["persist"], ctx.flags()
+        r = ctx.solve("pipe_bicgstab", b, tol=1e-9, check_every=check_every)
+        tr = ctx.trace(r["k"])
+        runs.append((r["k"], r["x"].copy(), r["r"].copy(), tr["alpha"].copy(), tr["dotr"].copy()))
+        # the other solvers are untouched by the switch
+        r2 = ctx.solve("bicgstab", b, tol=1e-15, check_every=5)
+        assert r2["k"] == ref["bicgstab"][0] and np.array_equal(r2["x"], ref["bicgstab"][1])
+        ctx.close()
+    k0, x0, r0, a0, d0 = runs[0]
+    assert abs(k0 - ref["pipe_bicgstab"][0]) <= 1
+    assert np.abs(x0 - ref["pipe_bicgstab"][1]).max() <= 1e-9 * np.abs(ref["pipe_bicgstab"][1]).max()
+    for k, x, r, a, d in runs[1:]:
+        assert k == k0 and np.array_equal(x, x0) and np.array_equal(r, r0) and np.array_equal(a, a0) and np.array_equal(d, d0)
+    # through the peer-to-peer transport, one rank: dot groups via the mailboxes, (empty) halo pushes
+    monkeypatch.setenv("BICG_FORCE_COMM", "1")
+    buf = (C.c_char * 128)()
+    H.lib().bicg_comm_unique_id(buf)
+    H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
+    try:
+        assert H.lib().bicg_comm_enable_p2p() == 0
+        ctx = H.Context(H.single_rank_blocks(A))
+        assert ctx.flags()["persist"] and ctx.flags()["p2p"], ctx.flags()
+        r = ctx.solve("pipe_bicgstab", b, tol=1e-9, check_every=5)
+        assert r["k"] == k0 and np.array_equal(r["x"], x0) and np.array_equal(r["r"], r0)
+        ctx.close()
+    finally:
+        monkeypatch.delenv("BICG_FORCE_COMM")
+        H.lib().bicg_comm_init_single(0)
+
+
+def test_fused_pipelined_iteration_is_bit_reproducible(problem, monkeypatch):
+    """the two-launch form (k_spmv_sell_epi) twice, and once more with BICG_SPIN_TICKS=0 -- every workgroup then sums
+    the shards it is waiting for itself (same partials, same order): same bits whoever computes a shard"""
+    A, b, ref = problem
+    H.lib().bicg_comm_init_single(0)
+    a1 = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1)
+    a2 = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1)
+    a3 = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1, BICG_SPIN_TICKS=0)
+    for m in ("pipe_bicgstab", "pipe_bicgstab_rr"):
+        for other in (a2, a3):
+            assert other[m][0] == a1[m][0] and np.array_equal(other[m][1], a1[m][1]) and np.array_equal(other[m][2], a1[m][2]), m
