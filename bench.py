@@ -524,7 +524,7 @@ def main():
         def extra(name, wl2, methods, steps):
             stage[0] = f"extra workload {name}"
             lg = Leg(wl2)
-            out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan)
+            out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v])
             for m in methods:
                 dtv, rv = lg.best(m, steps=steps, warm=min(W, 10))
                 ms = 1e3 * dtv / steps
@@ -545,6 +545,13 @@ def main():
         for hb in (8, 64, 512):
             extras[f"banded_b{hb}"] = extra(f"banded b={hb}", build("banded", 0, hb), ("bicgstab", "pipe_bicgstab"), ke)
         if world == 1:
+            # what ONE of 8 GPUs does in BASELINE.json configs[2]: a 200 k-row rank (1/8 of the Transport-shaped matrix, the
+            # reference's partition) -- latency-bound, the pipelined solver runs it as one persistent launch per chunk of
+            # iterations (bicg_persist.hip). Single rank here: no halo, no cross-rank sums; tools/small_rank_times.sh drives
+            # the same rank through the complete multi-rank path.
+            n8 = (synth.TRANSPORT_N + 7) // 8
+            wl8 = dict(build("transport", n=n8), desc=f"1/8 of the Transport-shaped matrix as one rank holds it at 8 GPUs ({n8} rows)")
+            extras["transport_rank_of_8"] = extra("1/8 Transport rank", wl8, ("pipe_bicgstab", "bicgstab"), max(ke, 200))
             extras["fem_like"] = extra("fem_like", build("fem_like"), ("bicgstab", "pipe_bicgstab"), ke)
             extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
             extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "

@@ -1638,9 +1638,15 @@ bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_
 // order) and Y is never written.
 // ------------------------------------------------------------------------------------------
 #if PART_IS(0)
-template <bool C16, bool OFFD>
+template <int LAY, bool OFFD>
 __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
 {
+    // LAY: the block's sliced-ELL layout (SellLayout). Padded slices: entry k of lane l at base + k * 64 + l. Jagged slices
+    // (ragged rows): step k holds the entries of the rows longer than k only -- the staging pass finds a lane's entry with
+    // a ballot like sell_row does. With x windows the stored 16-bit value is an LDS slot of the SpMV's window: the column
+    // comes back through the group's runs. Rows dealt to the lanes by decreasing length (SellDev::perm): the lane -> row
+    // map of the slice goes through LDS.
+    constexpr bool WIN = LAY == LAY_JAGW, C16 = (LAY & 1) != 0 || WIN, JAG = LAY >= LAY_JAG32;
     constexpr int NB = kSpmmCols;
     constexpr int KC = 16;                                   // matrix entries per row staged in LDS at a time
     static_assert(NB == 16, "8 lanes per row x 2 columns per lane");
@@ -1648,6 +1654,8 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
     __shared__ Ent se[kBlock / 64][KC][kSliceRows];          // this wavefront's slice, entry-major: read from memory ONCE,
                                                              // lane = row, fully coalesced
     __shared__ double sm[(kBlock / 64) * NB];
+    __shared__ uint32_t rowmap[kBlock];                      // row of slice lane l (identity without SellDev::perm)
+    __shared__ uint2 wruns[WIN ? 64 : 1];                    // the group's window runs (WIN)
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned sub = lane >> 3, cp = lane & 7u;          // row within an 8-row batch, column pair
     // XCD-contiguous mapping: workgroup b runs on XCD b % 8 (observed placement, used for speed only), so
@@ -1659,20 +1667,32 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
         g = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
     }
     double acc0 = 0.0, acc1 = 0.0;
+    unsigned nwr = 0;
+    if (g < a.ngroups) {
+        rowmap[tid] = g * kGroupRows + ((WIN && a.sell.perm) ? (uint32_t)a.sell.perm[(size_t)g * kGroupRows + tid] : tid);
+        if (WIN) {
+            const uint32_t r0 = a.sell.win_ptr[g];
+            nwr = a.sell.win_ptr[g + 1] - r0;
+            if (tid < nwr && tid < 64u) wruns[tid] = a.sell.win_runs[r0 + tid];
+        }
+    }
+    __syncthreads();
     if (g < a.ngroups) {
         const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;      // this wavefront's 64 rows
         uint32_t base = 0u, len = 0u, base16 = 0u;
         if (slice * kSliceRows < a.nrows) {
             base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
-            if (C16) base16 = a.sell.slice_base16[slice];
+            if (C16 && !JAG) base16 = a.sell.slice_base16[slice];
         }
         const double sg0 = a.sigma ? a.sigma[2 * cp] : 0.0, sg1 = a.sigma ? a.sigma[2 * cp + 1] : 0.0;
         const char *const xb = reinterpret_cast<const char *>(a.xt) + 16u * cp;     // this lane's two columns
         // stage role: lane = row of the slice
-        const uint32_t srow = slice * kSliceRows + lane;
+        const uint32_t srow = rowmap[wave * kSliceRows + lane];
         const uint32_t srb = srow < a.nrows ? srow : 0u;
+        const uint32_t slen_me = srow < a.nrows ? a.dptr[srow + 1] - a.dptr[srow] : 0u;
+        uint32_t jpos = base;                                // jagged: first entry of the current step (wave-uniform)
         // shortest row of the slice: entries below it need no per-row test (the usual case is all of them)
-        uint32_t minlen = srow < a.nrows ? a.dptr[srow + 1] - a.dptr[srow] : 0u;
+        uint32_t minlen = slen_me;
 #pragma unroll
         for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(minlen, off, 64); minlen = o < minlen ? o : minlen; }
         // compute role: 8 batches of 8 rows; this lane's row in batch bt is bt * 8 + sub
@@ -1680,21 +1700,45 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
         uint32_t mylen[kSliceRows / 8];
 #pragma unroll
         for (int bt = 0; bt < kSliceRows / 8; ++bt) {
-            const uint32_t row = slice * kSliceRows + bt * 8 + sub;
+            const uint32_t row = rowmap[wave * kSliceRows + bt * 8 + sub];
             s0[bt] = 0.0; s1[bt] = 0.0;
             mylen[bt] = row < a.nrows ? a.dptr[row + 1] - a.dptr[row] : 0u;
         }
         for (uint32_t k0 = 0; k0 < len; k0 += KC) {
             const uint32_t kn = len - k0 < (uint32_t)KC ? len - k0 : (uint32_t)KC;
             // ---- stage: coalesced loads, 512 bytes of val per instruction
-            if (C16) {
+            if (JAG) {
+                for (uint32_t e = 0; e < kn; ++e) {
+                    const bool mine = k0 + e < slen_me;
+                    const unsigned long long m = __ballot(mine);
+                    const uint32_t j = jpos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    jpos += (uint32_t)__builtin_popcountll(m);
+                    uint32_t colv = srb;
+                    double vv = 0.0;
+                    if (mine) {
+                        vv = a.sell.val[j];
+                        if (WIN) {
+                            const uint32_t slot = reinterpret_cast<const unsigned short *>(a.sell.col16)[j];
+                            unsigned r = 0;
+                            while (r + 1 < nwr && (wruns[r + 1].y >> 16) <= slot) ++r;
+                            colv = wruns[r].x + (slot - (wruns[r].y >> 16));
+                        } else if (C16) {
+                            colv = srb + (uint32_t)(int)a.sell.col16[j];
+                        } else {
+                            colv = a.sell.col[j];
+                        }
+                    }
+                    se[wave][e][lane].off = colv * (NB * 8u);
+                    se[wave][e][lane].v = vv;
+                }
+            } else if (C16) {
                 for (uint32_t q = 0; 4 * q < kn; ++q) {
                     const i16x4 dq = *(reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)(k0 / 4 + q) * kSliceRows + lane));
                     se[wave][4 * q + 0][lane].off = (srb + (int)dq.x) * (NB * 8u); se[wave][4 * q + 1][lane].off = (srb + (int)dq.y) * (NB * 8u);
                     se[wave][4 * q + 2][lane].off = (srb + (int)dq.z) * (NB * 8u); se[wave][4 * q + 3][lane].off = (srb + (int)dq.w) * (NB * 8u);
                 }
             }
-            for (uint32_t e = 0; e < kn; ++e) {
+            for (uint32_t e = 0; !JAG && e < kn; ++e) {
                 const uint32_t j = base + (k0 + e) * kSliceRows + lane;
                 if (!C16) se[wave][e][lane].off = a.sell.col[j] * (NB * 8u);
                 se[wave][e][lane].v = a.sell.val[j];
@@ -1728,7 +1772,7 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
         }
 #pragma unroll
         for (int bt = 0; bt < kSliceRows / 8; ++bt) {
-            const uint32_t row = slice * kSliceRows + bt * 8 + sub;
+            const uint32_t row = rowmap[wave * kSliceRows + bt * 8 + sub];
             const bool live = row < a.nrows;
             double y0 = 0.0 + s0[bt], y1 = 0.0 + s1[bt];                  // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
             if (OFFD && live) {
@@ -1823,14 +1867,19 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
 {
     if (a.ngroups == 0) return;
     const unsigned grid = a.xcd_map ? ((a.ngroups + 7u) / 8u) * 8u : a.ngroups;
-    const bool c16 = a.sell.col16 != nullptr;
-    if (with_offd) {
-        if (c16) BICG_LAUNCH((k_spmm_sell<true, true>), dim3(grid), dim3(kBlock), 0, st, a);
-        else BICG_LAUNCH((k_spmm_sell<false, true>), dim3(grid), dim3(kBlock), 0, st, a);
-    } else {
-        if (c16) BICG_LAUNCH((k_spmm_sell<true, false>), dim3(grid), dim3(kBlock), 0, st, a);
-        else BICG_LAUNCH((k_spmm_sell<false, false>), dim3(grid), dim3(kBlock), 0, st, a);
+#define SPMM_GO(LAYV)                                                                                      \
+    do {                                                                                                   \
+        if (with_offd) BICG_LAUNCH((k_spmm_sell<LAYV, true>), dim3(grid), dim3(kBlock), 0, st, a);         \
+        else BICG_LAUNCH((k_spmm_sell<LAYV, false>), dim3(grid), dim3(kBlock), 0, st, a);                  \
+    } while (0)
+    switch (sell_layout(a.sell)) {
+    case LAY_PAD16: SPMM_GO(LAY_PAD16); break;
+    case LAY_JAG32: SPMM_GO(LAY_JAG32); break;
+    case LAY_JAG16: SPMM_GO(LAY_JAG16); break;
+    case LAY_JAGW:  SPMM_GO(LAY_JAGW); break;
+    default:        SPMM_GO(LAY_PAD32); break;
     }
+#undef SPMM_GO
 }
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)

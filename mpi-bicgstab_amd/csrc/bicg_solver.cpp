@@ -79,6 +79,7 @@ struct bicg_ctx {
     short *s_col16 = nullptr;
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
     uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
+    uint32_t win_max_runs = 0;             // most runs of one group's window
     uint2 *win_runs = nullptr;
     unsigned char *sell_perm = nullptr;    // SellDev::perm
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
@@ -615,7 +616,8 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
 // every row on the sliced-ELL path, and 32-bit byte offsets into the row-major X (128 B per row) suffice
 bool spmm_possible(const bicg_ctx *c)
 {
-    return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && !c->sell_jag && (uint64_t)c->stride < (1ull << 25);
+    // (x windows: the kernel keeps a group's runs in 64 LDS entries)
+    return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && c->win_max_runs <= 64 && (uint64_t)c->stride < (1ull << 25);
 }
 
 void spmm_buffers(bicg_ctx *c)
@@ -2046,6 +2048,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->win_ptr = dev_upload(win_ptr.data(), win_ptr.size());
         c->win_runs = dev_upload(win_runs.data(), win_runs.size());
         c->win_slots = win_slots;
+        for (uint32_t g = 0; g < ngroups; ++g) c->win_max_runs = std::max(c->win_max_runs, win_ptr[g + 1] - win_ptr[g]);
         if (!perm.empty()) c->sell_perm = dev_upload(perm.data(), perm.size());
         c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
         c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();

@@ -8,5 +8,8 @@ for m in bicgstab pipe_bicgstab ca_bicgstab; do
   timeout 100 $B --method $m --force-comm --transport auto 2>/dev/null | show "p2p fused     $m"
   timeout 100 $B --method $m --force-comm --transport rccl 2>/dev/null | show "rccl (1 rank) $m"
 done
-BICG_FUSE_PIPE=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, phases as separate kernels  pipe_bicgstab"
-BICG_FUSE_PIPE=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, phases as separate kernels     pipe_bicgstab"
+# the multi-launch forms of the pipelined iteration (the default above is ONE persistent launch per chunk, bicg_persist.hip)
+BICG_PERSIST=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, two launches per iteration   pipe_bicgstab"
+BICG_PERSIST=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, two launches per iteration      pipe_bicgstab"
+BICG_PERSIST=0 BICG_FUSE_PIPE=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, phases as separate kernels  pipe_bicgstab"
+BICG_PERSIST=0 BICG_FUSE_PIPE=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, phases as separate kernels     pipe_bicgstab"
