@@ -141,6 +141,7 @@ def main():
     ap.add_argument("--no-variants", action="store_true")
     ap.add_argument("--no-extras", action="store_true", help="skip the banded / FEM-like / Laplacian legs")
     ap.add_argument("--no-traffic", action="store_true", help="skip the rocprofv3 PMC passes (roofline.traffic = null)")
+    ap.add_argument("--no-laplace512", action="store_true", help="skip the 512^3 Laplacian leg (needs ~45 GB of HBM and ~15 s)")
     ap.add_argument("--no-stream", action="store_true", help="skip the STREAM probes (roofline.stream_measured_gbps = null)")
     ap.add_argument("--no-rccl-leg", action="store_true", help="N > 1: do not time the headline a second time over RCCL collectives")
     ap.add_argument("--cpu-iters", type=int, default=100)
@@ -541,6 +542,40 @@ def main():
             lg.close()
             note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods))
             return out
+        def laplace512():
+            """BASELINE.json configs[3] at its stated size on ONE GPU (the N = 1 anchor of the 8-GPU configuration): 134 M rows,
+            938 M non-zeros. The matrix is generated and planned on the device (bicg_stencil7_device, bicg_create_device_csr):
+            no host copy exists; vectors (1 GB each) cross PCIe once."""
+            stage[0] = "extra workload laplace7 512^3"
+            m = 512
+            rows, nnz = m ** 3, synth.stencil7_nnz(m)
+            t0 = time.perf_counter()
+            ctx, nnz_dev, plan_s, gen_s = H.Context.stencil7_on_device(m, synth.LAPLACE_WEIGHTS)
+            assert nnz_dev == nnz
+            out = dict(rows=rows, nnz=nnz, workload="BASELINE.json configs[3]: 7-point Laplacian 512^3 (134 M rows), generated and planned "
+                       "on the GPU, b = A*1, x0 = 0, one MI355X", plan=ctx.plan_info(), flags=[k for k, v in ctx.flags().items() if v],
+                       generate_seconds=gen_s, plan_seconds=plan_s, device_matrix_bytes=ctx.device_matrix_bytes())
+            lg = Leg.__new__(Leg)
+            lg.wl = dict(lo=0, hi=rows); lg.ctx = ctx; lg.plan = out["plan"]
+            lg.ones = np.ones(rows); lg.x0 = np.zeros(rows)
+            lg.b = ctx.spmv(lg.ones)
+            steps = min(K, 20)
+            for mth in ("ca_bicgstab", "bicgstab"):
+                dtv, rv = lg.best(mth, steps=steps, warm=3, tries=1)
+                ms = 1e3 * dtv / steps
+                ib = iteration_bytes(mth, nnz, rows)
+                out[mth] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9, frac=ib / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                iterations=int(rv.iterations),
+                                iterations_genuine=bool(int(rv.iterations) == steps + 3 and rv.breakdown_iteration == 0
+                                                        and np.isfinite(rv.dot_r) and rv.dot_r > 0.0))
+            sp = ctx.spmv_bench(20)
+            bs = spmv_bytes(nnz, rows)
+            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, frac=bs / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_rank0=bs)
+            out["set_up_seconds_total"] = time.perf_counter() - t0
+            ctx.close()
+            note(f"laplace7 512^3: generated {gen_s:.2f} s, planned {plan_s:.2f} s, ca_bicgstab {out['ca_bicgstab']['ms_per_iteration']:.3f} ms, "
+                 f"bicgstab {out['bicgstab']['ms_per_iteration']:.3f} ms per iteration")
+            return out
         ke = min(K, 100)
         for hb in (8, 64, 512):
             extras[f"banded_b{hb}"] = extra(f"banded b={hb}", build("banded", 0, hb), ("bicgstab", "pipe_bicgstab"), ke)
@@ -556,6 +591,8 @@ def main():
             extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
             extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "
                                                  "= 16.8 M rows per GPU), CA-BiCGStab")
+            if not a.no_laplace512:
+                extras["laplace7_512_ca"] = laplace512()
 
     # ------------------------------------------------------------------ HBM traffic of this run's SpMV (rocprofv3 PMC)
     traffic, traffic_detail = None, None

@@ -194,6 +194,19 @@ void bicg_default_options(bicg_options *o);
  * Returns NULL after printing to stderr on failure. The host arrays are not referenced afterwards. */
 bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info);
 void bicg_destroy(bicg_ctx *ctx);
+/* Single rank, matrix ALREADY in device memory as CSR (device pointers, 32-bit indices, ptr_d[rows] = nnz): the sliced-ELL plan
+ * is built by kernels, no host copy of the matrix is made -- what lets BASELINE.json configs[3] at its stated size (512^3
+ * Laplacian: 134 M rows, 938 M non-zeros) be generated, planned and solved on ONE MI355X inside a bench run. The arrays are
+ * not referenced after the call. plan_seconds (optional): wall time of the call. Returns NULL (after a line on stderr) for
+ * blocks that need the host plan: ragged rows (jagged slices / x windows), long rows (rows over lanes), more than one rank.
+ *   bicg_stencil7_device  CSR of the 7-point stencil on an m^3 grid in device memory (weights = centre, x-, x+, y-, y+, z-, z+;
+ *                         entries in ascending column order: the matrix of the reference-style generator used by bench.py and
+ *                         the tests, python/synth.py stencil7); arrays are released with bicg_device_free */
+bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d, const unsigned int *ptr_d, unsigned int rows,
+                                 double *plan_seconds);
+int bicg_stencil7_device(unsigned int m, const double *weights, double **val_d, unsigned int **col_d, unsigned int **ptr_d,
+                         unsigned long long *nnz);
+void bicg_device_free(void *p);
 
 /* Matrix residency of the drop-in entry points (section 1 and the shifted ones): the context of the last drop-in call
  * stays resident and is reused when the caller passes the same blocks again -- same arrays, sizes, partition,
@@ -242,7 +255,8 @@ int bicg_shifted_residuals(bicg_ctx *ctx, const double *x_loc_set, const double 
 /* "Batched SpMV" (BASELINE.json configs[4]): Y_j = (A + sigma_j I) X_j for nvec vectors with every matrix entry read once
  * per 16 vectors (sliced-ELL SpMM) -- what the loop above does internally. x_loc_set / y_loc_set are shift-major like
  * x_loc_set of the shifted solvers; sigma may be NULL (Y_j = A X_j). Every column is bit-identical to bicg_spmv of that
- * vector. Returns 1 without computing when the matrix is not entirely on the sliced-ELL path (ragged rows). ms_device
+ * vector. Padded and jagged slices, x-window slots and lane-permuted groups are all read (BICG_FLAG_SPMM); returns 1 without
+ * computing only when some rows are on the CSR / rows-over-lanes kernels (a row several times longer than the average). ms_device
  * (optional) receives the device time of the passes (halo exchanges, layout change and SpMM kernel). Collective. */
 int bicg_spmm(bicg_ctx *ctx, const double *x_loc_set, const double *sigma, int nvec, double *y_loc_set, double *ms_device);
 /* per-iteration trace of the last run (record_trace): arrays of length >= iterations, may be NULL */

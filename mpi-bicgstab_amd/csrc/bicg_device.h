@@ -422,6 +422,12 @@ void launch_drift(const Vecs &v, const Launch &L, Reduce red);
 // standalone dot (x,y) -> red[0]
 void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce red, hipStream_t st);
 
+// device-side sliced-ELL plan (bicg_plan_device.hip): slice lengths + "some column is further than 32767 from its row",
+// then the column-major padded copy (32-bit columns or packed 16-bit offsets)
+void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far, hipStream_t st);
+void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
+                      const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st);
+
 unsigned sell_grid(uint32_t ngroups, int per_wg); // workgroups launched for ngroups 256-row groups
 unsigned vec_grid(uint32_t n);        // workgroups used by the element-wise kernels for length n
 void set_vec_grid_cap(unsigned cap);  // ranks sharing one GPU (tests): fewer workgroups per launch (0 = default)

@@ -1,0 +1,145 @@
+// bicg_plan_device.hip -- the sliced-ELL plan built ON the GPU from a device-resident CSR (bicg_create_device_csr,
+// bicg_solver.cpp), and a device-side generator of the 7-point stencil of BASELINE.json configs[3] (bicg_stencil7_device).
+//
+// The host plan of bicg_create is one thread walking the matrix three times: ~1 s for Transport, ~5 s for a 256^3 share,
+// ~40 s for the 512^3 Laplacian after 15 GB of host arrays have been generated and shipped. Here the matrix never exists
+// on the host: rows are counted, scanned (rocPRIM, set-up path only) and filled in by kernels, the plan is two more
+// kernels (slice lengths; the column-major padded copy) around an 8 MB prefix sum.
+#include <cstdio>
+#include <cstdlib>
+
+#include <hip/hip_runtime.h>
+#include <rocprim/device/device_scan.hpp>
+
+#include "../../include/bicgstab_hip.h"
+#include "bicg_comm.h"
+#include "bicg_device.h"
+
+namespace bicg {
+
+namespace {
+
+constexpr int kThreads = 256;
+
+// slice_len[s] = longest row of slice s; *far != 0 when some |col - row| > 32767
+__global__ void __launch_bounds__(kThreads) k_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    uint32_t len = 0;
+    bool is_far = false;
+    if (r < rows) {
+        const uint32_t a = ptr[r], b = ptr[r + 1];
+        len = b - a;
+        for (uint32_t j = a; j < b; ++j) {
+            const long long d = (long long)col[j] - (long long)r;
+            is_far = is_far || d < -32767 || d > 32767;
+        }
+    }
+    // the 64 rows of a slice are the 64 lanes of one wavefront
+    for (int off = 32; off > 0; off >>= 1) { const uint32_t o = __shfl_xor(len, off, 64); len = o > len ? o : len; }
+    if ((threadIdx.x & 63u) == 0 && r < rows) slice_len[r / kSliceRows] = len;
+    if (__any(is_far) && (threadIdx.x & 63u) == 0) atomicOr(far, 1);
+}
+
+// entry k of row r -> slice_base[r / 64] + k * 64 + r % 64 (padding stays zero); 16-bit offsets four to a word
+__global__ void __launch_bounds__(kThreads) k_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
+                                                        const uint32_t *slice_base, const uint32_t *slice_base16, double *sval,
+                                                        uint32_t *scol, short *scol16)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
+    const size_t base = slice_base[sl];
+    const size_t base16 = scol16 ? slice_base16[sl] : 0;
+    const uint32_t a = ptr[r], b = ptr[r + 1];
+    for (uint32_t j = a, k = 0; j < b; ++j, ++k) {
+        const size_t e = base + (size_t)k * kSliceRows + lane;      // consecutive lanes write consecutive entries
+        sval[e] = val[j];
+        if (scol16) scol16[base16 + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] = (short)((long long)col[j] - (long long)r);
+        else scol[e] = col[j];
+    }
+}
+
+// 7-point stencil on an m^3 grid, rows [lo, hi): weights = (centre, x-, x+, y-, y+, z-, z+), entries in ascending column
+// order -- the matrix of mpi-bicgstab_amd/python/synth.py stencil7 (the generator bench.py and the tests use on the host)
+__device__ __forceinline__ unsigned stencil_count(unsigned long long r, unsigned m)
+{
+    const unsigned ix = (unsigned)(r % m), iy = (unsigned)((r / m) % m), iz = (unsigned)(r / ((unsigned long long)m * m));
+    return 1u + (ix > 0) + (ix < m - 1) + (iy > 0) + (iy < m - 1) + (iz > 0) + (iz < m - 1);
+}
+__global__ void __launch_bounds__(kThreads) k_stencil_counts(unsigned m, uint32_t rows, uint32_t *cnt)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    if (r <= rows) cnt[r] = r < rows ? stencil_count(r, m) : 0u;
+}
+struct Weights { double w[7]; };
+__global__ void __launch_bounds__(kThreads) k_stencil_fill(unsigned m, uint32_t rows, const uint32_t *ptr, Weights W, uint32_t *col, double *val)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    if (r >= rows) return;
+    const unsigned ix = r % m, iy = (r / m) % m, iz = r / (m * m);
+    uint32_t at = ptr[r];
+    const uint32_t mm = m * m;
+    if (iz > 0)     { col[at] = r - mm; val[at++] = W.w[5]; }
+    if (iy > 0)     { col[at] = r - m;  val[at++] = W.w[3]; }
+    if (ix > 0)     { col[at] = r - 1;  val[at++] = W.w[1]; }
+    col[at] = r; val[at++] = W.w[0];
+    if (ix < m - 1) { col[at] = r + 1;  val[at++] = W.w[2]; }
+    if (iy < m - 1) { col[at] = r + m;  val[at++] = W.w[4]; }
+    if (iz < m - 1) { col[at] = r + mm; val[at++] = W.w[6]; }
+}
+
+}  // namespace
+
+void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_plan_rowstats, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, rows, slice_len, far);
+}
+void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
+                      const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_plan_fill, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, val, rows, slice_base,
+                       slice_base16, sval, scol, scol16);
+}
+
+}  // namespace bicg
+
+using namespace bicg;
+
+// CSR of the 7-point stencil in DEVICE memory (the whole matrix: single rank). Arrays are hipMalloc'ed here; release them
+// with bicg_device_free once the context has been created (bicg_create_device_csr copies what it keeps).
+extern "C" int bicg_stencil7_device(unsigned int m, const double *weights, double **val_d, unsigned int **col_d, unsigned int **ptr_d,
+                                    unsigned long long *nnz_out)
+{
+    BICG_HIP(hipSetDevice(comm_get()->device));
+    const unsigned long long n64 = (unsigned long long)m * m * m, nnz64 = 7ull * n64 - 6ull * m * m;
+    if (m < 2 || n64 >= 0x7FFFFFFFull || nnz64 >= 0xFFFFFF00ull) { fprintf(stderr, "ERROR: bicg_stencil7_device: grid too large for 32-bit indices\n"); return 1; }
+    const uint32_t rows = (uint32_t)n64;
+    uint32_t *cnt = nullptr, *ptr = nullptr, *col = nullptr;
+    double *val = nullptr;
+    BICG_HIP(hipMalloc((void **)&cnt, sizeof(uint32_t) * ((size_t)rows + 1)));
+    BICG_HIP(hipMalloc((void **)&ptr, sizeof(uint32_t) * ((size_t)rows + 1)));
+    hipLaunchKernelGGL(k_stencil_counts, dim3(rows / kThreads + 1), dim3(kThreads), 0, 0, m, rows, cnt);
+    (void)hipGetLastError();
+    size_t tmp_bytes = 0;
+    void *tmp = nullptr;
+    BICG_HIP(rocprim::exclusive_scan(nullptr, tmp_bytes, cnt, ptr, 0u, (size_t)rows + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+    BICG_HIP(hipMalloc(&tmp, tmp_bytes ? tmp_bytes : 1));
+    BICG_HIP(rocprim::exclusive_scan(tmp, tmp_bytes, cnt, ptr, 0u, (size_t)rows + 1, rocprim::plus<uint32_t>(), (hipStream_t)0));
+    BICG_HIP(hipMalloc((void **)&col, sizeof(uint32_t) * (size_t)nnz64));
+    BICG_HIP(hipMalloc((void **)&val, sizeof(double) * (size_t)nnz64));
+    Weights W;
+    for (int i = 0; i < 7; ++i) W.w[i] = weights[i];
+    hipLaunchKernelGGL(k_stencil_fill, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, 0, m, rows, ptr, W, col, val);
+    BICG_HIP(hipDeviceSynchronize());
+    BICG_HIP(hipFree(cnt));
+    BICG_HIP(hipFree(tmp));
+    *val_d = val; *col_d = col; *ptr_d = ptr;
+    if (nnz_out) *nnz_out = nnz64;
+    return 0;
+}
+
+extern "C" void bicg_device_free(void *p)
+{
+    if (p) (void)hipFree(p);
+}

@@ -1688,6 +1688,56 @@ void persist_chunk(bicg_ctx *c, int niter)
     }
 }
 
+// vectors, reduction scratch and scalar blocks of a context whose plan (n_loc, halo, nblk) is known
+static void ctx_state(bicg_ctx *c, Comm *comm, uint32_t ngroups)
+{
+    // ---- vectors: 12 x (rows + halo), each 256-byte aligned; order x r | rh p s y z w v t ax b
+    c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
+    c->slab = dev_alloc<double>(12 * (size_t)c->stride);
+    BICG_HIP(hipMemset(c->slab, 0, sizeof(double) * 12 * (size_t)c->stride));
+    double *base = c->slab;
+    double **slots[12] = {&c->v.x, &c->v.r, &c->v.rh, &c->v.p, &c->v.s, &c->v.y, &c->v.z, &c->v.w, &c->v.v, &c->v.t, &c->v.ax, &c->v.b};
+    for (int i = 0; i < 12; ++i) *slots[i] = base + (size_t)i * c->stride;
+    c->v.n = c->n_loc;
+
+    c->nslots = std::max<unsigned>(ngroups + c->nblk, kMaxGrid) + 64;
+    c->partial = dev_alloc<double>((size_t)c->nslots * kPartialStride);
+    c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
+    c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
+    BICG_HIP(hipMemset(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride));
+    c->Sbuf = dev_alloc<Scal>(2);
+    BICG_HIP(hipMemset(c->Sbuf, 0, 2 * sizeof(Scal)));
+    c->S = c->Sbuf;
+    for (int i = 0; i < 2; ++i) {
+        c->wpart[i] = dev_alloc<double>((size_t)c->nslots * (kBlock / 64) * kPartialStride);
+        BICG_HIP(hipMemset(c->wpart[i], 0, sizeof(double) * (size_t)c->nslots * (kBlock / 64) * kPartialStride));
+    }
+    c->shard_ll = dev_alloc<llword>((size_t)2 * kShardLL * kRedSlots * 2);
+    BICG_HIP(hipMemset(c->shard_ll, 0, sizeof(llword) * 2 * kShardLL * kRedSlots * 2));
+    c->alarm = dev_alloc<int>(1);
+    BICG_HIP(hipMemset(c->alarm, 0, sizeof(int)));
+    BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
+    *c->h_alarm = 0;
+    if (comm->ranks_on_device > 1) {
+        // one-GPU box standing in for a node: 1024 = 256 CUs x 4 resident workgroups of the largest kernels
+        c->wg_cap = 1024u / (unsigned)(comm->ranks_on_device + 1);
+        set_vec_grid_cap(c->wg_cap);
+    }
+}
+
+static void ctx_streams(bicg_ctx *c, int P)
+{
+    BICG_HIP(hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking));
+    if (P > 1 || c->force_comm) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
+    for (int i = 0; i < kEvRing; ++i) {
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_pack[i], hipEventDisableTiming));
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_halo[i], hipEventDisableTiming));
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_dots[i], hipEventDisableTiming));
+        BICG_HIP(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming));
+    }
+    BICG_HIP(hipDeviceSynchronize());       // uploads and memsets above used the null stream
+}
+
 // =====================================================================================  C ABI
 extern "C" {
 
@@ -2102,38 +2152,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->p2p = nullptr;
     }
 
-    // ---- vectors: 12 x (rows + halo), each 256-byte aligned; order x r | rh p s y z w v t ax b
-    c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
-    c->slab = dev_alloc<double>(12 * (size_t)c->stride);
-    BICG_HIP(hipMemset(c->slab, 0, sizeof(double) * 12 * (size_t)c->stride));
-    double *base = c->slab;
-    double **slots[12] = {&c->v.x, &c->v.r, &c->v.rh, &c->v.p, &c->v.s, &c->v.y, &c->v.z, &c->v.w, &c->v.v, &c->v.t, &c->v.ax, &c->v.b};
-    for (int i = 0; i < 12; ++i) *slots[i] = base + (size_t)i * c->stride;
-    c->v.n = c->n_loc;
-
-    c->nslots = std::max<unsigned>(ngroups + c->nblk, kMaxGrid) + 64;
-    c->partial = dev_alloc<double>((size_t)c->nslots * kPartialStride);
-    c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
-    c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
-    BICG_HIP(hipMemset(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride));
-    c->Sbuf = dev_alloc<Scal>(2);
-    BICG_HIP(hipMemset(c->Sbuf, 0, 2 * sizeof(Scal)));
-    c->S = c->Sbuf;
-    for (int i = 0; i < 2; ++i) {
-        c->wpart[i] = dev_alloc<double>((size_t)c->nslots * (kBlock / 64) * kPartialStride);
-        BICG_HIP(hipMemset(c->wpart[i], 0, sizeof(double) * (size_t)c->nslots * (kBlock / 64) * kPartialStride));
-    }
-    c->shard_ll = dev_alloc<llword>((size_t)2 * kShardLL * kRedSlots * 2);
-    BICG_HIP(hipMemset(c->shard_ll, 0, sizeof(llword) * 2 * kShardLL * kRedSlots * 2));
-    c->alarm = dev_alloc<int>(1);
-    BICG_HIP(hipMemset(c->alarm, 0, sizeof(int)));
-    BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
-    *c->h_alarm = 0;
-    if (comm->ranks_on_device > 1) {
-        // one-GPU box standing in for a node: 1024 = 256 CUs x 4 resident workgroups of the largest kernels
-        c->wg_cap = 1024u / (unsigned)(comm->ranks_on_device + 1);
-        set_vec_grid_cap(c->wg_cap);
-    }
+    ctx_state(c, comm, ngroups);
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
     c->fuse_pipe = c->fuse_small || all_ranks(comm, c->win_slots == 0);
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
@@ -2148,15 +2167,105 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
     }
 
-    BICG_HIP(hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking));
-    if (P > 1 || c->force_comm) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
-    for (int i = 0; i < kEvRing; ++i) {
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_pack[i], hipEventDisableTiming));
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_halo[i], hipEventDisableTiming));
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_dots[i], hipEventDisableTiming));
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming));
+    ctx_streams(c, P);
+    return c;
+}
+
+// Single rank, the matrix ALREADY in device memory as CSR: the sliced-ELL plan (slice lengths, bases, the column-major
+// padded copy, 16-bit column offsets when they fit) is built by kernels (bicg_plan_device.hip) -- no host copy of the
+// matrix ever exists. This is what makes BASELINE.json configs[3] at its stated size fit a bench run: the 512^3 Laplacian
+// (134 M rows, 938 M non-zeros, 11 GB of CSR) is generated on the GPU (bicg_stencil7_device) and planned in a fraction of
+// a second, where the one-thread host plan of bicg_create would take the better part of a minute after a 15 GB transfer.
+// Blocks whose rows are too ragged for padded slices (or long enough for the rows-over-lanes kernel) are refused: the
+// caller downloads the CSR and takes bicg_create.
+bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d, const unsigned int *ptr_d, unsigned int rows,
+                                 double *plan_seconds)
+{
+    Comm *comm = comm_get();
+    BICG_HIP(hipSetDevice(comm->device));
+    if (comm->nranks != 1) { fprintf(stderr, "ERROR: bicg_create_device_csr: single rank only\n"); return nullptr; }
+    if (rows == 0) { fprintf(stderr, "ERROR: bicg_create_device_csr: empty matrix\n"); return nullptr; }
+    const double t0 = now_sec();
+    unsigned nnz = 0;
+    BICG_HIP(hipMemcpy(&nnz, ptr_d + rows, sizeof(unsigned), hipMemcpyDeviceToHost));
+    const uint32_t nslices = (rows + kSliceRows - 1) / kSliceRows, ngroups = (rows + kGroupRows - 1) / kGroupRows;
+    uint32_t *slen_d = dev_alloc<uint32_t>(nslices);
+    int *far_d = dev_alloc<int>(1);
+    BICG_HIP(hipMemset(slen_d, 0, sizeof(uint32_t) * nslices));
+    BICG_HIP(hipMemset(far_d, 0, sizeof(int)));
+    launch_plan_rowstats(ptr_d, col_d, rows, slen_d, far_d, nullptr);
+    std::vector<uint32_t> slen(nslices), sbase(nslices), sbase16(nslices);
+    int far = 0;
+    BICG_HIP(hipMemcpy(slen.data(), slen_d, sizeof(uint32_t) * nslices, hipMemcpyDeviceToHost));
+    BICG_HIP(hipMemcpy(&far, far_d, sizeof(int), hipMemcpyDeviceToHost));
+    uint64_t entries = 0, n16 = 0, padded_rows = 0;
+    uint32_t longest = 0;
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        sbase[sl] = (uint32_t)entries; sbase16[sl] = (uint32_t)n16;
+        entries += (uint64_t)slen[sl] * kSliceRows;
+        n16 += (uint64_t)((slen[sl] + 3) / 4) * 4 * kSliceRows;
+        padded_rows += (uint64_t)slen[sl] * std::min<uint32_t>(kSliceRows, rows - sl * kSliceRows);
+        longest = std::max(longest, slen[sl]);
     }
-    BICG_HIP(hipDeviceSynchronize());       // uploads and memsets above used the null stream
+    const bool c16 = !far && n16 < 0xFFFFFF00ull && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
+    const char *why = nullptr;
+    if (entries >= 0xFFFFFF00ull) why = "more than 2^32 sliced-ELL entries";
+    else if (padded_rows > (uint64_t)nnz + nnz / 50) why = "ragged rows (jagged slices are planned on the host)";
+    else if ((uint64_t)nnz / rows >= 128 && ngroups < 512) why = "long rows (the rows-over-lanes plan is built on the host)";
+    else if (longest > std::max<uint64_t>(64, 4 * (uint64_t)nnz / rows)) why = "a row much longer than the average";
+    if (why) {
+        fprintf(stderr, "bicgstab_hip: bicg_create_device_csr: %s -- use bicg_create\n", why);
+        BICG_HIP(hipFree(slen_d)); BICG_HIP(hipFree(far_d));
+        return nullptr;
+    }
+    bicg_ctx *c = new bicg_ctx;
+    c->comm = comm; c->device = comm->device; c->nranks = 1; c->rank = 0;
+    g_live.push_back(c);
+    c->n_loc = rows; c->n_glob = rows; c->nnz_d = nnz;
+    if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
+    if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
+    c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;
+    c->scnt.assign(1, 0); c->sdsp.assign(1, 0); c->rcnt.assign(1, 0); c->rdsp.assign(1, 0);
+    c->sell_entries = entries; c->sell_nnz = nnz; c->sell_rows = rows; c->sell_jag = false;
+    c->s_val = dev_alloc<double>((size_t)entries + kPadEntries);
+    BICG_HIP(hipMemset(c->s_val, 0, sizeof(double) * ((size_t)entries + kPadEntries)));
+    if (c16) {
+        c->s_col16 = dev_alloc<short>((size_t)n16 + kPadEntries);
+        BICG_HIP(hipMemset(c->s_col16, 0, sizeof(short) * ((size_t)n16 + kPadEntries)));
+        c->s_base16 = dev_upload(sbase16.data(), sbase16.size());
+        c->s_col = dev_alloc<uint32_t>(kPadEntries);
+    } else {
+        c->s_col = dev_alloc<uint32_t>((size_t)entries + kPadEntries);
+        BICG_HIP(hipMemset(c->s_col, 0, sizeof(uint32_t) * ((size_t)entries + kPadEntries)));
+    }
+    c->s_base = dev_upload(sbase.data(), sbase.size());
+    c->s_len = slen_d;
+    launch_plan_fill(ptr_d, col_d, val_d, rows, c->s_base, c->s_base16, c->s_val, c16 ? nullptr : c->s_col, c16 ? c->s_col16 : nullptr, nullptr);
+    c->d_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
+    BICG_HIP(hipMemcpy(c->d_ptr, ptr_d, sizeof(uint32_t) * ((size_t)rows + 1), hipMemcpyDeviceToDevice));
+    c->d_val = dev_alloc<double>(kPadEntries); c->d_col = dev_alloc<uint32_t>(kPadEntries);
+    c->o_val = dev_alloc<double>(1); c->o_col = dev_alloc<uint32_t>(1);
+    c->o_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
+    BICG_HIP(hipMemset(c->o_ptr, 0, sizeof(uint32_t) * ((size_t)rows + 1)));
+    c->desc_int = dev_alloc<uint4>(1); c->desc_bnd = dev_alloc<uint4>(1);
+    c->glist_int = dev_alloc<uint32_t>(1); c->glist_bnd = dev_alloc<uint32_t>(1);
+    c->send_idx = dev_alloc<uint32_t>(1); c->sendbuf = dev_alloc<double>(1);
+    c->ng_int = ngroups; c->ng_bnd = 0; c->n_int = c->n_bnd = c->nblk = 0;
+    c->glist_int_identity = true; c->glist_all = true;
+    c->matrix_bytes = entries * (c16 ? 10 : 12) + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
+    c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
+    BICG_HIP(hipFree(far_d));
+    ctx_state(c, comm, ngroups);
+    if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
+    c->fuse_pipe = true;
+    if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
+    c->spmm_ok = spmm_possible(c);
+    c->fuse_plan_ok = true;
+    BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
+    memset(c->hS, 0, sizeof(Scal));
+    ctx_streams(c, 1);
+    if (plan_seconds) *plan_seconds = now_sec() - t0;
     return c;
 }
 

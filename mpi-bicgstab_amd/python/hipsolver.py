@@ -61,7 +61,7 @@ EXPORTS = [
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
-    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench",
+    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free",
 ]
 
 _lib = None
@@ -122,6 +122,11 @@ def lib():
         L.bicg_window_slot.restype = C.c_uint
         L.bicg_version.restype = C.c_char_p
         L.bicg_stream_bench.argtypes = [C.c_int, C.c_ulonglong, C.c_int, _dp, _dp]
+        L.bicg_create_device_csr.restype = C.c_void_p
+        L.bicg_create_device_csr.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint, _dp]
+        L.bicg_stencil7_device.argtypes = [C.c_uint, _dp, C.POINTER(C.c_void_p), C.POINTER(C.c_void_p), C.POINTER(C.c_void_p),
+                                           C.POINTER(C.c_ulonglong)]
+        L.bicg_device_free.argtypes = [C.c_void_p]
         for name in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
             getattr(L, name).argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp]
         L.pipe_bicgstab_rr.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix), _dp, _dp,
@@ -215,6 +220,30 @@ class Context:
         self.h = lib().bicg_create(C.byref(blocks.diag), C.byref(blocks.offd), C.byref(blocks.info))
         if not self.h:
             raise RuntimeError("bicg_create failed")
+
+    @classmethod
+    def stencil7_on_device(cls, m: int, weights):
+        """Single rank: the 7-point stencil on an m^3 grid generated, planned and kept on the GPU (bicg_stencil7_device +
+        bicg_create_device_csr) -- no host copy of the matrix. Returns (context, nnz, plan seconds, generation seconds)."""
+        import time
+        L = lib()
+        w = np.ascontiguousarray(weights, dtype=np.float64)
+        val, col, ptr = C.c_void_p(), C.c_void_p(), C.c_void_p()
+        nnz = C.c_ulonglong(0)
+        t0 = time.perf_counter()
+        if L.bicg_stencil7_device(m, _d(w), C.byref(val), C.byref(col), C.byref(ptr), C.byref(nnz)) != 0:
+            raise RuntimeError("bicg_stencil7_device failed")
+        t_gen = time.perf_counter() - t0
+        secs = C.c_double(0.0)
+        self = cls.__new__(cls)
+        self.blocks = None
+        self.n = m ** 3
+        self.h = L.bicg_create_device_csr(val, col, ptr, m ** 3, C.byref(secs))
+        for p in (val, col, ptr):
+            L.bicg_device_free(p)
+        if not self.h:
+            raise RuntimeError("bicg_create_device_csr refused the matrix")
+        return self, int(nnz.value), float(secs.value), t_gen
 
     def close(self):
         if self.h:

@@ -67,11 +67,20 @@ def test_bench_single_gpu_line_has_every_leg():
     for m in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr", "shifted_lopbicgstab_16shifts", "shifted_pipe_lopbicgstab_16shifts"):
         r = d["variant_rooflines"][m]
         assert 0.3 < r["frac"] < 1.0 and r["algorithmic_bytes"] > 8e8, (m, r)
-    for key in ("banded_b8", "banded_b64", "banded_b512", "fem_like", "laplace7_256_ca"):
+    for key in ("banded_b8", "banded_b64", "banded_b512", "fem_like", "laplace7_256_ca", "laplace7_512_ca", "transport_rank_of_8"):
         assert key in d["extras"], key
         legs = [v for v in d["extras"][key].values() if isinstance(v, dict) and "ms_per_iteration" in v]
         assert legs and all(v["iterations_genuine"] is True for v in legs), (key, legs)   # no leg timed a converged solve
     assert d["extras"]["laplace7_256_ca"]["rows"] == 256 ** 3 and d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"] > 0
+    # BASELINE.json configs[3] at its stated size on one GPU: generated and planned on the device in well under 3 s
+    big = d["extras"]["laplace7_512_ca"]
+    assert big["rows"] == 512 ** 3 and big["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2
+    assert big["plan_seconds"] < 3.0 and big["generate_seconds"] < 3.0, big
+    assert 0.5 < big["ca_bicgstab"]["frac"] < 1.0 and big["ca_bicgstab"]["ms_per_iteration"] < 10 * d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"]
+    # the rank one of 8 GPUs holds (configs[2]): the pipelined solver takes it as one persistent launch per chunk
+    r8 = d["extras"]["transport_rank_of_8"]
+    assert "persist" in r8["flags"] and r8["pipe_bicgstab"]["ms_per_iteration"] < 0.020, r8
+    assert "rowsplit" in d["extras"]["banded_b512"]["flags"] and d["extras"]["banded_b512"]["spmv_back_to_back"]["frac"] > 0.6
     rf = d["roofline"]
     st = rf["stream_measured_gbps"]
     assert st and 4000 < st["copy"] < 8000 and 4000 < st["triad"] < 8000 and 4000 < st["read8"] < 8000, st

@@ -247,3 +247,34 @@ def test_laplace7_slab_generator_and_ca_bicgstab_against_oracle():
             np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=f"{method} {key}")
         assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
     ctx.close()
+
+
+def test_device_side_plan_matches_host_plan():
+    """bicg_stencil7_device + bicg_create_device_csr (matrix generated and planned on the GPU, no host copy: what
+    bench.py's 512^3 leg uses) against the host path on the same stencil at 96^3: the same plan facts, SpMV bit-identical
+    to the oracle (hence to the host-planned context), CA-BiCGStab on the oracle's trajectory; the non-symmetric test
+    weights too (every one of the seven positions carries its own value)."""
+    H.lib().bicg_comm_init_single(0)
+    for m, weights in ((96, synth.LAPLACE_WEIGHTS), (33, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0))):
+        A = synth.stencil7(m, weights)
+        row, col, val = A.to_coo()
+        ctx, nnz, plan_s, gen_s = H.Context.stencil7_on_device(m, weights)
+        ref = H.Context(H.single_rank_blocks(A))
+        assert nnz == A.nnz == synth.stencil7_nnz(m)
+        pi, pr = ctx.plan_info(), ref.plan_info()
+        for key in ("rows", "nnz_diag", "sell_rows", "sell_padding", "row_blocks"):
+            assert pi[key] == pr[key], (key, pi, pr)
+        assert ctx.flags() == ref.flags() or {k: v for k, v in ctx.flags().items() if k != "persist"} == {k: v for k, v in ref.flags().items() if k != "persist"}
+        assert ctx.device_matrix_bytes() <= ref.device_matrix_bytes() + 8 * A.rows + 64
+        x = np.random.default_rng(m).standard_normal(A.rows)
+        y = ctx.spmv(x)
+        assert np.array_equal(y, O.spmv(A.rows, row, col, val, x)) and np.array_equal(y, ref.spmv(x))
+        b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+        orc = O.solve("ca_bicgstab", A.rows, row, col, val, b, tol=0.0, max_iter=10)
+        got = ctx.solve("ca_bicgstab", b, tol=0.0, max_iter=10, check_every=10)
+        tr = ctx.trace(10)
+        for key in ("alpha", "omega", "beta", "dotr"):
+            np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=key)
+        assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
+        print(f"stencil {m}^3: generated on the device in {gen_s:.3f} s, planned in {plan_s:.3f} s")
+        ctx.close(); ref.close()
