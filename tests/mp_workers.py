@@ -281,12 +281,11 @@ def fullsize_worker(rank, world, port, kind, outdir):
         for method in ([str(m) for m in ref["converge_methods"]] if "converge_methods" in ref else []):
             tol = float(ref["converge_tol"])
             got = ctx.solve(method, b, tol=tol, max_iter=4000, check_every=16)
-            k_orc = int(ref[f"{method}_conv_k"])
-            assert abs(got["k"] - k_orc) <= max(3, k_orc // 12), (method, got["k"], k_orc)
+            kmin, kmax = int(ref[f"{method}_conv_kmin"]), int(ref[f"{method}_conv_kmax"])
+            assert 0.95 * kmin <= got["k"] <= 1.05 * kmax, (method, got["k"], kmin, kmax)      # inside the reference's own spread over P
             relres = np.sqrt(got["result"].dot_r / got["result"].dot_zero)
             assert relres <= tol, (method, relres)
-            err_orc = float(ref[f"{method}_conv_err"])
-            assert np.abs(got["x"] - 1.0).max() <= max(20 * err_orc, 1e-6), (method, np.abs(got["x"] - 1.0).max(), err_orc)
+            assert np.abs(got["x"] - 1.0).max() <= 3.0 * float(ref[f"{method}_conv_err"]), (method, np.abs(got["x"] - 1.0).max())
         assert not ctx.comm_failed()
         ctx.close()
         dist.barrier()

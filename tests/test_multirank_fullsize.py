@@ -48,13 +48,19 @@ def oracle_outputs(matrix, world):
         for key in ("alpha", "omega", "beta", "dotr", "x"):
             out[f"{method}_{key}"] = orc[key]
     if world == 8:
-        # plain and CA-BiCGStab all the way to 1e-9 (the pipelined recurrences stagnate above that on this matrix)
+        # plain and CA-BiCGStab all the way to 1e-9 (the pipelined recurrences stagnate above that on this matrix, SURVEY
+        # section 4). The yardstick is the reference's OWN spread over rank counts (tests/golden/transport_convergence.json,
+        # written by make_transport_convergence.py through the pinned oracle: plain 526 / 621 / 669 / 567 iterations at
+        # P = 1 / 2 / 4 / 8, CA 596 / 617 / 563 / 540 -- the association of the dot sums alone moves the count by +-13 %)
+        import json
+        gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "transport_convergence.json")))
+        assert gold["rows"] == A.rows and gold["nnz"] == A.nnz
         out["converge_methods"] = np.array(["bicgstab", "ca_bicgstab"])
-        out["converge_tol"] = 1e-9
+        out["converge_tol"] = gold["tol"]
         for method in ("bicgstab", "ca_bicgstab"):
-            orc = O.solve(method, A.rows, row, col, val, out["b"], nranks=world, tol=1e-9, max_iter=4000)
-            out[f"{method}_conv_k"] = orc["k"]
-            out[f"{method}_conv_err"] = float(np.abs(orc["x"] - 1.0).max())
+            ks = [gold["runs"][f"{method}_P{P}"]["k"] for P in (1, 2, 4, 8)]
+            out[f"{method}_conv_kmin"], out[f"{method}_conv_kmax"] = min(ks), max(ks)
+            out[f"{method}_conv_err"] = max(gold["runs"][f"{method}_P{P}"]["max_err_vs_ones"] for P in (1, 2, 4, 8))
     _oracle_cache[world] = out
     return out
 
