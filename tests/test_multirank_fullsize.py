@@ -69,7 +69,10 @@ def oracle_outputs(matrix, world):
 @pytest.mark.parametrize("kind", ["host", "host-p2p"])
 def test_fullsize_partition_against_oracle(matrix, world, kind):
     with tempfile.TemporaryDirectory() as td:
-        np.savez(os.path.join(td, "oracle.npz"), **oracle_outputs(matrix, world))
+        out = dict(oracle_outputs(matrix, world))
+        if kind != "host-p2p":        # the runs to convergence (8 ranks time-slicing one GPU: ~1 minute) once, on the production data path
+            out = {k: v for k, v in out.items() if "conv" not in k}
+        np.savez(os.path.join(td, "oracle.npz"), **out)
         mp.start_processes(W.fullsize_worker, args=(world, _free_port(), kind, td), nprocs=world, join=True,
                            start_method="spawn")
         fails = glob.glob(os.path.join(td, "fail*"))
