@@ -319,6 +319,8 @@ struct PersistArgs {
     unsigned long long *dbg;             // BICG_PERSIST_TRACE: 100 MHz time stamps of one row workgroup and the helper, [it][16]
 };
 void launch_pipe_persist(const PersistArgs &a, hipStream_t st);
+void launch_plain_persist(const PersistArgs &a, hipStream_t st);    // plain BiCGStab: three groups per iteration
+void launch_ca_persist(const PersistArgs &a, hipStream_t st);       // CA-BiCGStab: two groups per iteration
 unsigned persist_lds_bytes(const PersistArgs &a);
 constexpr unsigned kPersistMaxLds = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for (static part: < 1 KiB)
 

@@ -201,7 +201,7 @@ __device__ __forceinline__ void hand_over(double val, double (&acc)[N], double *
     // 1.6 us). The wavefront's next global loads -- the window -- cannot return before this store is acknowledged
     // (one in-order counter on gfx9), but nothing it waits for can be there earlier either.
     if (img_row) ll_store16_agent(img_row, val, seq);
-    zs[threadIdx.x] = val;
+    if (zs) zs[threadIdx.x] = val;
 #pragma unroll
     for (int d = 0; d < N; ++d) acc[d] = wave_sum(acc[d]);
     if (lane == 0) {
@@ -213,12 +213,9 @@ __device__ __forceinline__ void hand_over(double val, double (&acc)[N], double *
 // communication wavefront: everything the rest of the GPU (and the other GPUs) gets from this workgroup in one phase --
 // the LL image of its rows' values, the halo values other ranks need, its row of the dot table -- then the wait for the
 // applied scalars of that group (needed by the row wavefronts only after their product)
-template <int N, bool MULTI>
-__device__ __forceinline__ void comm_phase(const PersistArgs &a, unsigned lane, uint32_t row0, uint32_t nmine, unsigned nrw, const double *zs,
-                                           llword *img, unsigned seq, unsigned hseq, unsigned ns0, unsigned ns1, llword *tab_row,
-                                           PersistLds &L)
+template <int N>
+__device__ __forceinline__ void comm_partials(unsigned lane, unsigned nrw, llword *tab_row, unsigned seq, PersistLds &L)
 {
-    // the dot partials first: the helper's chain (table -> sums -> recurrence -> scalars back) is the longest of the phase
     if ((int)lane < N) {
         double t[kMaxWaves];
 #pragma unroll
@@ -228,10 +225,23 @@ __device__ __forceinline__ void comm_phase(const PersistArgs &a, unsigned lane, 
         for (int w = 1; w < kMaxWaves - 1; ++w) s += t[w];                          // wavefront order (+ 0.0 beyond the last)
         ll_store16_agent(tab_row + 2 * lane, s, seq);
     }
+}
+template <bool MULTI>
+__device__ __forceinline__ void comm_halo(const PersistArgs &a, unsigned lane, const double *zs, unsigned hseq, unsigned ns0, unsigned ns1)
+{
     if (MULTI)
         for (unsigned i = ns0 + lane; i < ns1; i += 64u)
             ll_store16(reinterpret_cast<llword *>(a.snd_dst0[i] + (unsigned long long)(hseq % kHaloRing) * a.snd_stride[i]),
                        zs[a.snd_row[i]], hseq);
+}
+template <int N, bool MULTI>
+__device__ __forceinline__ void comm_phase(const PersistArgs &a, unsigned lane, uint32_t row0, uint32_t nmine, unsigned nrw, const double *zs,
+                                           llword *img, unsigned seq, unsigned hseq, unsigned ns0, unsigned ns1, llword *tab_row,
+                                           PersistLds &L)
+{
+    // the dot partials first: the helper's chain (table -> sums -> recurrence -> scalars back) is the longest of the phase
+    comm_partials<N>(lane, nrw, tab_row, seq, L);
+    comm_halo<MULTI>(a, lane, zs, hseq, ns0, ns1);
 }
 
 // ... and, once the row wavefronts are busy with their product, the wait for the applied scalars of that group
@@ -272,10 +282,14 @@ __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword 
         const unsigned long long t0 = wall_clock64();
         for (unsigned spin = 0;; ++spin) {
             bool all = true;
-            if (N == 2) {
+            if (N == 1) {
+                u32x4 w0;
+                ll_load16_x1<false>(src, w0);
+                all = ll_decode(w0, seq, &v[0]);
+            } else if (N == 2) {
                 u32x4 w0, w1;
                 ll_load16_x2<false>(src, src + 2, w0, w1);
-                all = ll_decode(w0, seq, &v[0]) & ll_decode(w1, seq, &v[1]);
+                all = ll_decode(w0, seq, &v[0]) & ll_decode(w1, seq, &v[N > 1 ? 1 : 0]);
             } else {
                 u32x4 w[5];
                 ll_load16_x5(src, w);
@@ -486,6 +500,271 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Plain BiCGStab (reference src/solver.c:86-120) in the same persistent form. Its three scalars are each needed by the
+// very next element-wise step (alpha before q, omega before x / r, beta before p), so the three reductions of an
+// iteration are exposed -- partial -> helper -> scalars back, ~3 us each -- where the pipelined recurrence hides its two
+// behind the products; what goes away against the five-launch form are the five kernel boundaries and every vector
+// access: 39 -> ~20 us per iteration on a 200 k-row rank. Expressions: FPlainQ / FPlainXR / FPlainP, operation for operation.
+// Groups per iteration (tags seq0 + 3 it + 1 / 2 / 3): (r#,s) -> alpha ; (q,y),(y,y) -> omega ; (r,r),(r#,r) -> beta, k++.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool LDSMAT, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_plain_persist(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned wg = blockIdx.x;
+    if (a.xcd_map && wg < (a.nwg / 8u) * 8u) wg = (wg % 8u) * (a.nwg / 8u) + wg / 8u;
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            const unsigned s1 = a.seq0 + 3u * (unsigned)it + 1u, m1 = a.p2p.seq + 3u * (unsigned)it;
+            if (!helper_group<1>(a, a.dtab[0], a.arow[0], s1, m1, PH_PLAIN_ALPHA, L, nullptr)) break;
+            if (!helper_group<2>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_OMEGA, L, nullptr)) break;
+            if (!helper_group<2>(a, a.dtab[0], a.arow[0], s1 + 2u, m1 + 2u, PH_PLAIN_END, L, nullptr)) break;
+        }
+        lds_barrier();
+        if (tid == 0) {
+            if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
+            *a.S = L.priv;
+        }
+        return;
+    }
+
+    double *win = dyn;
+    double *mval = dyn + a.win_slots;
+    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
+    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
+    double *zs = reinterpret_cast<double *>(runs + a.max_runs);
+    const unsigned nrw = a.spw, nrt = 64u * a.spw;
+    const bool comm = wave == nrw;
+    const uint32_t s0 = wg * a.spw, s1w = min(a.nslices, s0 + a.spw);
+    const uint32_t row0 = s0 * kSliceRows, nmine = min(a.nrows, s1w * kSliceRows) - row0;
+    const uint32_t slice = s0 + wave;
+    const bool have_slice = !comm && slice < a.nslices;
+    const uint32_t row = slice * kSliceRows + lane;
+    const bool live = have_slice && row < a.nrows;
+    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1w];
+    uint32_t sbase = 0, slen = 0;
+    if (have_slice) { sbase = a.pbase[slice]; slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
+    const uint32_t mylen = live ? a.rlen[row] : 0u, mydiag = live ? a.rdiag[row] : 0u;
+    const unsigned r0w = a.win_ptr[wg], nruns = a.win_ptr[wg + 1] - r0w;
+    for (unsigned i = tid; i < nruns; i += nt) runs[i] = a.win_runs[r0w + i];
+    unsigned nslots = 0;
+    if (nruns) { const uint2 last = a.win_runs[r0w + nruns - 1]; nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
+    const double *gval = a.pval + sbase;
+    const unsigned short *gslot = a.pslot + sbase;
+    if (LDSMAT) {
+        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
+        gval = mval + (sbase - e0); gslot = mslot + (sbase - e0);
+    }
+    const Vecs &e = a.v;
+    const uint32_t rr_ = live ? row : 0u;
+    double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], y = 0.0, q = 0.0;
+    const double h = e.rh[rr_];
+    const unsigned ns0 = MULTI ? a.snd_ptr[wg] : 0u, ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    llword *const img0 = live ? a.llv[0] + 2 * (size_t)row : nullptr, *const img1 = live ? a.llv[1] + 2 * (size_t)row : nullptr;
+    for (int it = 0; it < a.niter && !done; ++it) {
+        const unsigned g1 = a.seq0 + 3u * (unsigned)it + 1u, g2 = g1 + 1u, g3 = g1 + 2u;
+        const unsigned hp = a.halo_seq0 + 2u * (unsigned)it + 1u, hq = hp + 1u;
+        // ---- s = A p ; (r#,s) -> alpha                                               (src/solver.c:88-93)
+        if (!comm) { double none[1] = {0.0}; hand_over<1>(p, none, zs, L, img0, g1); }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, zs, hp, ns0, ns1);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[0], g1, hp, win, nrt, L, zs, row0, nmine);
+        lds_barrier();
+        if (!comm) {
+            s = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+            double acc[1] = {live ? h * s : 0.0};
+            hand_over<1>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<1>(lane, nrw, tab0, g1, L); comm_scalars(a, lane, a.arow[0], g1, L); }
+        lds_barrier();
+        if (L.fail) break;
+        alpha = L.sc[0];
+        // ---- q = r - alpha s ; y = A q ; (q,y), (y,y) -> omega                       (src/solver.c:94-104)
+        if (!comm) { q = r + (-alpha) * s; double none[1] = {0.0}; hand_over<1>(q, none, zs, L, img1, g2); }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, zs, hq, ns0, ns1);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[1], g2, hq, win, nrt, L, zs, row0, nmine);
+        lds_barrier();
+        if (!comm) {
+            y = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+            double acc[2] = {live ? q * y : 0.0, live ? y * y : 0.0};
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, nrw, tab1, g2, L); comm_scalars(a, lane, a.arow[1], g2, L); }
+        lds_barrier();
+        if (L.fail) break;
+        omega = L.sc[2];
+        // ---- x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r) -> beta, k++   (src/solver.c:105-116)
+        if (!comm) {
+            double xx = x + alpha * p;
+            xx = xx + omega * q;
+            x = xx;
+            r = q + (-omega) * y;
+            double acc[2] = {live ? r * r : 0.0, live ? h * r : 0.0};
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, nrw, tab0, g3, L); comm_scalars(a, lane, a.arow[0], g3, L); }
+        lds_barrier();
+        if (L.fail) break;
+        beta = L.sc[1]; done = L.sc[3] != 0.0 ? 1 : 0;
+        // ---- p = beta p ; p += r ; p += (-beta omega) s                              (src/solver.c:117-119)
+        if (!comm && !done) {
+            double pp = beta * p;
+            pp = pp + 1.0 * r;
+            pp = pp + (-beta * omega) * s;
+            p = pp;
+        }
+        lds_barrier();                        // L.sc is rewritten by the next group
+    }
+    if (live) { e.x[row] = x; e.r[row] = r; e.p[row] = p; e.s[row] = s; e.y[row] = y; }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// CA-BiCGStab (reference src/solver.c:216-251) in the persistent form: z = A s and w = A r per iteration, two groups --
+// (q,y),(y,y) -> omega, needed at once by the x / r update, and (r,r),(r#,r),(r#,w),(r#,s),(r#,z) -> beta, alpha, k++ after
+// the second product -- both exposed. Expressions: FCaPS / FQY / FCaXR, operation for operation. The helper's schedule is
+// the pipelined solver's (PH_OMEGA, PH_RECUR_END).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool LDSMAT, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ca_persist(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned wg = blockIdx.x;
+    if (a.xcd_map && wg < (a.nwg / 8u) * 8u) wg = (wg % 8u) * (a.nwg / 8u) + wg / 8u;
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            const unsigned s1 = a.seq0 + 2u * (unsigned)it + 1u, m1 = a.p2p.seq + 2u * (unsigned)it;
+            if (!helper_group<2>(a, a.dtab[0], a.arow[0], s1, m1, PH_OMEGA, L, nullptr)) break;
+            if (!helper_group<5>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_RECUR_END, L, nullptr)) break;
+        }
+        lds_barrier();
+        if (tid == 0) {
+            if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
+            *a.S = L.priv;
+        }
+        return;
+    }
+
+    double *win = dyn;
+    double *mval = dyn + a.win_slots;
+    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
+    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
+    double *zs = reinterpret_cast<double *>(runs + a.max_runs);
+    const unsigned nrw = a.spw, nrt = 64u * a.spw;
+    const bool comm = wave == nrw;
+    const uint32_t s0 = wg * a.spw, s1w = min(a.nslices, s0 + a.spw);
+    const uint32_t row0 = s0 * kSliceRows, nmine = min(a.nrows, s1w * kSliceRows) - row0;
+    const uint32_t slice = s0 + wave;
+    const bool have_slice = !comm && slice < a.nslices;
+    const uint32_t row = slice * kSliceRows + lane;
+    const bool live = have_slice && row < a.nrows;
+    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1w];
+    uint32_t sbase = 0, slen = 0;
+    if (have_slice) { sbase = a.pbase[slice]; slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
+    const uint32_t mylen = live ? a.rlen[row] : 0u, mydiag = live ? a.rdiag[row] : 0u;
+    const unsigned r0w = a.win_ptr[wg], nruns = a.win_ptr[wg + 1] - r0w;
+    for (unsigned i = tid; i < nruns; i += nt) runs[i] = a.win_runs[r0w + i];
+    unsigned nslots = 0;
+    if (nruns) { const uint2 last = a.win_runs[r0w + nruns - 1]; nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
+    const double *gval = a.pval + sbase;
+    const unsigned short *gslot = a.pslot + sbase;
+    if (LDSMAT) {
+        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
+        gval = mval + (sbase - e0); gslot = mslot + (sbase - e0);
+    }
+    const Vecs &e = a.v;
+    const uint32_t rr_ = live ? row : 0u;
+    double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], z = e.z[rr_], w = e.w[rr_];
+    const double h = e.rh[rr_];
+    const unsigned ns0 = MULTI ? a.snd_ptr[wg] : 0u, ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    llword *const img0 = live ? a.llv[0] + 2 * (size_t)row : nullptr, *const img1 = live ? a.llv[1] + 2 * (size_t)row : nullptr;
+    for (int it = 0; it < a.niter && !done; ++it) {
+        const unsigned g1 = a.seq0 + 2u * (unsigned)it + 1u, g2 = g1 + 1u;
+        const unsigned hs = a.halo_seq0 + 2u * (unsigned)it + 1u, hr = hs + 1u;
+        // ---- p = r + beta (p - omega s) ; s = w + beta (s - omega z) ; z = A s      (src/solver.c:217-224)
+        if (!comm) {
+            p = recur3<double>(p, s, r, omega, beta);
+            s = recur3<double>(s, z, w, omega, beta);
+            double none[1] = {0.0};
+            hand_over<1>(s, none, zs, L, img0, g1);
+        }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, zs, hs, ns0, ns1);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[0], g1, hs, win, nrt, L, zs, row0, nmine);
+        lds_barrier();
+        // ---- q = r - alpha s (in r) ; y = w - alpha z (in w) ; (q,y), (y,y) -> omega   (src/solver.c:225-232)
+        if (!comm) {
+            z = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+            r = r + (-alpha) * s;
+            w = w + (-alpha) * z;
+            double acc[2] = {live ? r * w : 0.0, live ? w * w : 0.0};
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, nrw, tab0, g1, L); comm_scalars(a, lane, a.arow[0], g1, L); }
+        lds_barrier();
+        if (L.fail) break;
+        omega = L.sc[2];
+        // ---- x += alpha p + omega q ; r = q - omega y ; w = A r                       (src/solver.c:233-239)
+        if (!comm) {
+            double xx = x + alpha * p;
+            xx = xx + omega * r;
+            x = xx;
+            r = r + (-omega) * w;
+            double none[1] = {0.0};
+            hand_over<1>(r, none, zs, L, img1, g2);
+        }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, zs, hr, ns0, ns1);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[1], g2, hr, win, nrt, L, zs, row0, nmine);
+        lds_barrier();
+        // ---- (r,r), (r#,r), (r#,w), (r#,s), (r#,z) -> beta, alpha, k++                 (src/solver.c:240-251)
+        if (!comm) {
+            w = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+            double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (live) { acc[0] = r * r; acc[1] = h * r; acc[2] = h * w; acc[3] = h * s; acc[4] = h * z; }
+            hand_over<5>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<5>(lane, nrw, tab1, g2, L); comm_scalars(a, lane, a.arow[1], g2, L); }
+        lds_barrier();
+        if (L.fail) break;
+        alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] != 0.0 ? 1 : 0;
+        lds_barrier();                        // L.sc is rewritten by the next group
+    }
+    if (live) { e.x[row] = x; e.r[row] = r; e.p[row] = p; e.s[row] = s; e.z[row] = z; e.w[row] = w; }
+}
+
 }  // namespace
 
 unsigned persist_lds_bytes(const PersistArgs &a)
@@ -495,29 +774,37 @@ unsigned persist_lds_bytes(const PersistArgs &a)
                       8u * (size_t)a.max_runs + 8u * threads);
 }
 
-void launch_pipe_persist(const PersistArgs &a, hipStream_t st)
+static void launch_persist(const PersistArgs &a, hipStream_t st, int method)
 {
     const unsigned lds = persist_lds_bytes(a);
     const dim3 g(a.nwg + 1u), b(64u * (a.spw + 1u));        // + the communication wavefront
-    auto go = [&](auto kernel) {
-        static bool raised[4] = {false, false, false, false};
-        const int idx = (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0);
-        if (!raised[idx]) {
-            const hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
-            if (e != hipSuccess) {
-                (void)hipGetLastError();
-                if (getenv("BICG_DEBUG")) fprintf(stderr, "bicgstab_hip: hipFuncSetAttribute(max dynamic LDS) said: %s\n", hipGetErrorString(e));
-            }
+    auto go = [&](auto kernel, int slot) {
+        static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+        const int idx = slot * 4 + (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0);
+        if (!raised[idx]) {       // (the runtime answers "invalid argument" and launches with > 64 KiB of LDS all the same)
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
+            (void)hipGetLastError();
             raised[idx] = true;
         }
         hipLaunchKernelGGL(kernel, g, b, lds, st, a);
     };
-    if (a.mat_entries) { if (a.multi) go(k_pipe_persist<true, true>); else go(k_pipe_persist<true, false>); }
-    else { if (a.multi) go(k_pipe_persist<false, true>); else go(k_pipe_persist<false, false>); }
+    if (method == 0) {
+        if (a.mat_entries) { if (a.multi) go(k_pipe_persist<true, true>, 0); else go(k_pipe_persist<true, false>, 0); }
+        else { if (a.multi) go(k_pipe_persist<false, true>, 0); else go(k_pipe_persist<false, false>, 0); }
+    } else if (method == 1) {
+        if (a.mat_entries) { if (a.multi) go(k_plain_persist<true, true>, 1); else go(k_plain_persist<true, false>, 1); }
+        else { if (a.multi) go(k_plain_persist<false, true>, 1); else go(k_plain_persist<false, false>, 1); }
+    } else {
+        if (a.mat_entries) { if (a.multi) go(k_ca_persist<true, true>, 2); else go(k_ca_persist<true, false>, 2); }
+        else { if (a.multi) go(k_ca_persist<false, true>, 2); else go(k_ca_persist<false, false>, 2); }
+    }
     if (getenv("BICG_DEBUG")) {
         const hipError_t err = hipGetLastError();
-        if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: HIP error \"%s\" noticed at: k_pipe_persist\n", hipGetErrorString(err));
+        if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: HIP error \"%s\" noticed at: persistent kernel\n", hipGetErrorString(err));
     }
 }
+void launch_pipe_persist(const PersistArgs &a, hipStream_t st) { launch_persist(a, st, 0); }
+void launch_plain_persist(const PersistArgs &a, hipStream_t st) { launch_persist(a, st, 1); }
+void launch_ca_persist(const PersistArgs &a, hipStream_t st) { launch_persist(a, st, 2); }
 
 }  // namespace bicg

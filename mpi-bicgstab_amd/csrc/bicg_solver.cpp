@@ -136,6 +136,7 @@ struct bicg_ctx {
     // persistent pipelined iteration (bicg_persist.hip, struct PersistArgs): plan + LL buffers; persist.nwg == 0: not available
     PersistArgs persist{};
     bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0/1 overrides
+    bool persist_plain = true;   // ... and for plain BiCGStab (BICG_PERSIST_PLAIN=0: the five-launch iteration)
     unsigned persist_seq = 0;    // LL tags used so far
     std::vector<void *> persist_mem;
     unsigned wg_cap = 0;         // ranks sharing this GPU (tests): workgroups per launch that may wait for another rank
@@ -960,7 +961,9 @@ int run_iterate(bicg_ctx *c, int nsteps)
             force = true;
             c->adaptive_rr++;
         }
-        const bool persist = c->persist_on && c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0 && !c->time_kernels;
+        const bool persist = c->persist_on && !c->time_kernels &&
+                             ((c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0) ||
+                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain));
         if (persist) persist_chunk(c, chunk);         // one launch for the whole chunk (bicg_persist.hip)
         for (int j = 0; j < chunk && !persist; ++j) {
             // the last iteration before the caller (or the drift check) reads x / r leaves them as the reference would
@@ -1644,10 +1647,12 @@ void persist_chunk(bicg_ctx *c, int niter)
 {
     if (c->grp.active) die("internal", "persistent chunk with an open dot group");
     if (c->f1_done) die("internal", "persistent chunk after phase 1 of the next iteration has run");
+    const bool plain = c->method == BICG_BICGSTAB;
+    const unsigned groups = plain ? 3u : 2u;                  // dot groups (tags, mailbox numbers) per iteration
     PersistArgs a = c->persist;
     a.v = c->v; a.S = c->S; a.alarm = c->alarm; a.niter = niter;
     a.seq0 = c->persist_seq;
-    c->persist_seq += 2u * (unsigned)niter;
+    c->persist_seq += groups * (unsigned)niter;
     a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;          // 2 s inside one GPU
     static const int xcd_map = getenv("BICG_PERSIST_XCD") ? atoi(getenv("BICG_PERSIST_XCD")) : 1;
     a.xcd_map = xcd_map;
@@ -1656,7 +1661,7 @@ void persist_chunk(bicg_ctx *c, int niter)
     if (a.multi) {
         // every rank advances its exchange and group numbers by the whole chunk, converged early or not
         a.halo_seq0 = c->halo_seq; c->halo_seq += 2u * (unsigned)niter;
-        a.p2p = c->p2p->red_desc(c->p2p->red_seq); c->p2p->red_seq += 2u * (unsigned)niter;
+        a.p2p = c->p2p->red_desc(c->p2p->red_seq); c->p2p->red_seq += groups * (unsigned)niter;
         a.ring = c->halo_ring;
         c->halo_unsynced = 0;
     }
@@ -1667,8 +1672,10 @@ void persist_chunk(bicg_ctx *c, int niter)
         BICG_HIP(hipMemset(dbg, 0, 64 * 16 * sizeof(unsigned long long)));
         a.dbg = dbg;
     }
-    launch_pipe_persist(a, c->sc);
-    if (want_trace) {
+    if (plain) launch_plain_persist(a, c->sc);
+    else if (c->method == BICG_CA_BICGSTAB) launch_ca_persist(a, c->sc);
+    else launch_pipe_persist(a, c->sc);
+    if (want_trace && c->method == BICG_PIPE_BICGSTAB) {
         // 10 ns ticks of one row workgroup (0 start, 1 z and partials published, 2 window staged, 3 product done, 4 omega here,
         // 5 w and partials published, 6 window, 7 product, 8 scalars here) and of the helper (10 / 11: group 1 / 2 published)
         std::vector<unsigned long long> h(64 * 16);
@@ -2164,6 +2171,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         const char *pe = getenv("BICG_PERSIST");
         bool mine = !(pe && atoi(pe) == 0) && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
         c->persist_on = all_ranks(comm, mine);
+        if (const char *pp = getenv("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
         if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
     }
 

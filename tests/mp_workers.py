@@ -169,21 +169,21 @@ def gpu_worker(rank, world, port, kind, outdir):
             # the pipelined solver's three forms across ranks: persistent one-launch chunks (the default when the plan fits on
             # every rank), two launches per iteration, separate kernels -- same answer up to the association of the dot sums
             fl = ctx.flags()
-            orc = O.solve("pipe_bicgstab", A.rows, row, col, val, b_full, nranks=world, tol=1e-9)
-            forms = {}
+            orcs = {m: O.solve(m, A.rows, row, col, val, b_full, nranks=world, tol=1e-9) for m in ("pipe_bicgstab", "bicgstab", "ca_bicgstab")}
             for name, env in (("persistent", {"BICG_PERSIST": "1"}), ("two-launch", {"BICG_PERSIST": "0", "BICG_FUSE_PIPE": "1"}),
                               ("separate", {"BICG_PERSIST": "0", "BICG_FUSE_PIPE": "0"})):
                 os.environ.update(env)
                 c2 = H.Context(H.HostBlocks(diag, offd, A.rows, counts, displs))
                 if name == "persistent" and kind in ("offsets", "stencil", "laplace"):      # (a block with a 700-entry row does not qualify)
                     assert c2.flags()["persist"], c2.flags()
-                g2 = c2.solve("pipe_bicgstab", b, tol=1e-9, check_every=4)
-                forms[name] = g2
-                slack = max(2, orc["k"] // 15) if kind == "laplace" else 2
-                assert abs(g2["k"] - orc["k"]) <= slack, (name, g2["k"], orc["k"])
-                assert np.abs(g2["x"] - 1.0).max() <= max(100 * np.abs(orc["x"] - 1.0).max(), 1e-6), name
-                g3 = c2.solve("pipe_bicgstab", b, tol=1e-9, check_every=4)          # run to run: same bits
-                assert g3["k"] == g2["k"] and np.array_equal(g3["x"], g2["x"]), name
+                for m in (("pipe_bicgstab", "bicgstab", "ca_bicgstab") if name == "persistent" else ("pipe_bicgstab",)):
+                    orc = orcs[m]
+                    g2 = c2.solve(m, b, tol=1e-9, check_every=4)
+                    slack = max(2, orc["k"] // 15) if kind == "laplace" else 2
+                    assert abs(g2["k"] - orc["k"]) <= slack, (name, m, g2["k"], orc["k"])
+                    assert np.abs(g2["x"] - 1.0).max() <= max(100 * np.abs(orc["x"] - 1.0).max(), 1e-6), (name, m)
+                    g3 = c2.solve(m, b, tol=1e-9, check_every=4)          # run to run: same bits
+                    assert g3["k"] == g2["k"] and np.array_equal(g3["x"], g2["x"]), (name, m)
                 c2.close()
             for k_ in ("BICG_PERSIST", "BICG_FUSE_PIPE"):
                 os.environ.pop(k_, None)

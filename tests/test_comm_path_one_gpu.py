@@ -121,34 +121,39 @@ def test_fused_pipelined_iteration_matches_separate_kernels(problem):
         assert got[m][0] == ref[m][0] and np.array_equal(got[m][1], ref[m][1])
 
 
-def test_persistent_pipelined_iteration(problem, monkeypatch):
-    """pipe_bicgstab as ONE persistent launch per chunk of iterations (bicg_persist.hip: matrix slices and x window in
-    LDS, vectors in registers, everything that crosses workgroups as LL words) against the multi-launch forms: same
-    iteration count +-1, same solution to rounding (the dot sums are associated per wavefront -> workgroup -> table);
-    bit-reproducible from run to run; independent of how often the host looks (chunk length); and the same through the
-    peer-to-peer transport driven by one rank (helper workgroup exchanging the sums through the mailboxes)."""
+def test_persistent_iterations(problem, monkeypatch):
+    """pipe_bicgstab, bicgstab and ca_bicgstab as ONE persistent launch per chunk of iterations (bicg_persist.hip: matrix
+    slices and x window in LDS, vectors in registers, everything that crosses workgroups as LL words) against the
+    multi-launch forms: same iteration count +-1, same solution to rounding (the dot sums are associated per wavefront ->
+    workgroup -> table); bit-reproducible from run to run; independent of how often the host looks (chunk length); and the
+    same bits through the peer-to-peer transport driven by one rank (helper workgroup exchanging the sums through the
+    mailboxes). pipe_bicgstab_rr (replacement steps) keeps the multi-launch form."""
     A, b, ref = problem
     H.lib().bicg_comm_init_single(0)
-    ctx = H.Context(H.single_rank_blocks(A))
-    assert not ctx.flags()["persist"] or True
-    ctx.close()
+    tols = dict(METHODS)
+    methods = ("pipe_bicgstab", "bicgstab", "ca_bicgstab")
     runs = []
     for check_every in (5, 5, 1, 64):
         monkeypatch.setenv("BICG_PERSIST", "1")
         ctx = H.Context(H.single_rank_blocks(A))
         assert ctx.flags()["persist"], ctx.flags()
-        r = ctx.solve("pipe_bicgstab", b, tol=1e-9, check_every=check_every)
-        tr = ctx.trace(r["k"])
-        runs.append((r["k"], r["x"].copy(), r["r"].copy(), tr["alpha"].copy(), tr["dotr"].copy()))
-        # the other solvers are untouched by the switch
-        r2 = ctx.solve("bicgstab", b, tol=1e-15, check_every=5)
-        assert r2["k"] == ref["bicgstab"][0] and np.array_equal(r2["x"], ref["bicgstab"][1])
+        out = {}
+        for m in methods:
+            r = ctx.solve(m, b, tol=tols[m], check_every=check_every)
+            tr = ctx.trace(r["k"])
+            out[m] = (r["k"], r["x"].copy(), r["r"].copy(), tr["alpha"].copy(), tr["dotr"].copy())
+        r = ctx.solve("pipe_bicgstab_rr", b, tol=1e-15, krr=10, nrr=3, check_every=5)
+        # (the replacement variant keeps its multi-launch forms; the default two-launch one against the separate kernels of ref)
+        assert abs(r["k"] - ref["pipe_bicgstab_rr"][0]) <= 1 and np.abs(r["x"] - ref["pipe_bicgstab_rr"][1]).max() <= 1e-9
+        runs.append(out)
         ctx.close()
-    k0, x0, r0, a0, d0 = runs[0]
-    assert abs(k0 - ref["pipe_bicgstab"][0]) <= 1
-    assert np.abs(x0 - ref["pipe_bicgstab"][1]).max() <= 1e-9 * np.abs(ref["pipe_bicgstab"][1]).max()
-    for k, x, r, a, d in runs[1:]:
-        assert k == k0 and np.array_equal(x, x0) and np.array_equal(r, r0) and np.array_equal(a, a0) and np.array_equal(d, d0)
+    for m in methods:
+        k0, x0, r0, a0, d0 = runs[0][m]
+        assert abs(k0 - ref[m][0]) <= 1, m
+        assert np.abs(x0 - ref[m][1]).max() <= 1e-9 * np.abs(ref[m][1]).max(), m
+        for other in runs[1:]:
+            k, x, r, a, d = other[m]
+            assert k == k0 and np.array_equal(x, x0) and np.array_equal(r, r0) and np.array_equal(a, a0) and np.array_equal(d, d0), m
     # through the peer-to-peer transport, one rank: dot groups via the mailboxes, (empty) halo pushes
     monkeypatch.setenv("BICG_FORCE_COMM", "1")
     buf = (C.c_char * 128)()
@@ -158,8 +163,10 @@ def test_persistent_pipelined_iteration(problem, monkeypatch):
         assert H.lib().bicg_comm_enable_p2p() == 0
         ctx = H.Context(H.single_rank_blocks(A))
         assert ctx.flags()["persist"] and ctx.flags()["p2p"], ctx.flags()
-        r = ctx.solve("pipe_bicgstab", b, tol=1e-9, check_every=5)
-        assert r["k"] == k0 and np.array_equal(r["x"], x0) and np.array_equal(r["r"], r0)
+        for m in methods:
+            r = ctx.solve(m, b, tol=tols[m], check_every=5)
+            k0, x0, r0, _, _ = runs[0][m]
+            assert r["k"] == k0 and np.array_equal(r["x"], x0) and np.array_equal(r["r"], r0), m
         ctx.close()
     finally:
         monkeypatch.delenv("BICG_FORCE_COMM")

@@ -8,6 +8,10 @@ for m in bicgstab pipe_bicgstab ca_bicgstab; do
   timeout 100 $B --method $m --force-comm --transport auto 2>/dev/null | show "p2p fused     $m"
   timeout 100 $B --method $m --force-comm --transport rccl 2>/dev/null | show "rccl (1 rank) $m"
 done
+for m in bicgstab ca_bicgstab; do
+  BICG_PERSIST=0 timeout 100 $B --method $m 2>/dev/null | show "single, multi-launch form            $m"
+  BICG_PERSIST=0 timeout 100 $B --method $m --force-comm --transport auto 2>/dev/null | show "p2p, multi-launch form               $m"
+done
 # the multi-launch forms of the pipelined iteration (the default above is ONE persistent launch per chunk, bicg_persist.hip)
 BICG_PERSIST=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, two launches per iteration   pipe_bicgstab"
 BICG_PERSIST=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, two launches per iteration      pipe_bicgstab"
