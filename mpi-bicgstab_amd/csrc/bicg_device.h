@@ -250,7 +250,26 @@ struct Vecs {
     uint32_t n;
 };
 
+// Window-fused SpMV of plain BiCGStab on padded slices with 16-bit column offsets (k_spmv_sell_fw): the input vector is
+// not read from memory but FORMED while the columns a 256-row group touches are staged in LDS --
+//   wf 1:  q  = r - alpha s            (the my_daxpy of reference src/solver.c:94, then y = A q)
+//   wf 2:  p' = beta p + r - beta omega s   (src/solver.c:117-119, then s = A p')
+// which removes the two element-wise launches of the iteration, their vector traffic, and (wf 1) the read of the dot
+// operand. The columns of a group are g0 + row-in-group + d with d from a small set of offsets that falls into a few
+// clusters (Transport: {-13807..-13689}, {-118..118}, {13689..13807}); cluster k of every group is the window run
+// [g0 + lo_k, g0 + 255 + hi_k], so the LDS slot of an entry is  thread + d + bias_k  -- no per-group plan.
+constexpr int kFwMaxClusters = 4;
+struct FusedWindow {
+    int wf;                          // 0: not fused
+    int ncl;                         // clusters of column offsets, ascending
+    int lo[kFwMaxClusters], hi[kFwMaxClusters], bias[kFwMaxClusters];   // bias_k = slot0_k - lo_k
+    unsigned slots;                  // LDS doubles of a window
+    const double *v0, *v1, *v2;      // wf 1: r, s ; wf 2: p, r, s
+    double *wout;                    // the formed vector (own rows): q / p'
+};
+
 struct SpmvArgs {
+    FusedWindow fw;
     SellDev sell;
     const uint32_t *glist;  // SELL launch: 256-row groups to process (null = groups 0..nlist-1)
     uint32_t nrows;         // local rows
@@ -346,6 +365,7 @@ struct SpmmArgs {
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);        // CSR row-block stream
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                       bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
+bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // a.fw.wf = 1 / 2
 void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st);          // out[col] = sum_wg partial[wg][col]
@@ -385,7 +405,7 @@ void launch_p2p_ringtest(const P2pRed &pr, llword *const *rings, int entries, un
 void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, const Launch &L, Reduce red);
 // plain BiCGStab phases (src/solver.c:94, 105-111, 117-119)
 void launch_plain_q(const Vecs &v, const Launch &L);
-void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red);
+void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red, const double *q = nullptr);   // q: where q lives (default: in r)
 void launch_plain_p(const Vecs &v, const Launch &L);
 // CA-BiCGStab phases (src/solver.c:217-222, 225-228, 233-236 + 240-243)
 void launch_ca_ps(const Vecs &v, const Launch &L);

@@ -65,6 +65,12 @@ struct bicg_ctx {
     double *d_val = nullptr, *o_val = nullptr;
     uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
     uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // CSR row-block descriptors: interior / halo-touching
+    FusedWindow fw{};                      // plain BiCGStab with the q / p updates formed in the SpMV's window (fw.ncl > 0: available)
+    bool fuse_plain = false;               // ... use it: BICG_FUSE_PLAIN=1. Off by default -- measured (profiles/NOTES.md, round 3): bit-identical
+                                           // to the five-launch iteration but not faster: forming q / p for the ~5.8 x 256 columns a Transport
+                                           // group touches costs the two products more (+12 us each) than the two launches it removes (8 + 7 us);
+                                           // on a narrow band (redundancy 1.06) it is a tie (146.2 vs 145.9 us)
+    int pl_flip = 0;                       // which of the ping-pong pairs (p | w), (s | z) holds the current p and s
     bool rowsplit = false;                 // long rows: the row blocks go to k_spmv_rows (a row spread over T lanes)
     short *d_col16 = nullptr;              // ... with CSR-order 16-bit column offsets when they fit
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
@@ -398,9 +404,10 @@ void group_defer(bicg_ctx *c, int n, int phase)
 // workgroup as (0 + sum_diag) + sum_offd, the reference's order.
 // fin: a dot group of earlier kernels that the first kernel launched here finishes (grp_for_spmv).
 void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{}, int epi = 0,
-          Scal *S = nullptr)
+          Scal *S = nullptr, const FusedWindow *fw = nullptr)
 {
     SpmvArgs a;
+    a.fw = fw ? *fw : FusedWindow{};
     a.fin = fin;
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
@@ -466,6 +473,9 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         if (epi) {
             a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
             took(launch_spmv_sell_epi(a, epi, false, c->sc, ev(0), ev(1)));
+        } else if (fw) {
+            a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
+            took(launch_spmv_sell_fw(a, ndot, c->sc, ev(0), ev(1)));
         } else {
             interior();
         }
@@ -716,8 +726,34 @@ struct Driver {
         group_flush(c);
     }
 
+    // plain BiCGStab with q = r - alpha s and p = r + beta (p - omega s) formed in the windows of the two products (struct
+    // FusedWindow): three launches per iteration. p and s alternate between two buffers each (a workgroup forms the values
+    // of rows other workgroups own, so nothing it reads may be overwritten by the launch), q has its own.
+    bool fused_plain() const
+    {
+        return c->fuse_plain && c->fw.ncl > 0 && c->single() && c->glist_all && c->nblk == 0 && c->glist_int_identity && c->sell_gpw_dots == 1;
+    }
+    void iter_plain_fused()
+    {
+        double *pa = c->pl_flip ? v.w : v.p, *pb = c->pl_flip ? v.p : v.w;
+        double *sa = c->pl_flip ? v.z : v.s, *sb = c->pl_flip ? v.s : v.z;
+        FusedWindow f = c->fw;
+        f.wf = 2; f.v0 = pa; f.v1 = v.r; f.v2 = sa; f.wout = pb;
+        spmv(c, pb, sb, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1), Finish{}, 0, nullptr, &f);   // p', s = A p', (r#,s) -> alpha
+        group_now(c, 1, PH_PLAIN_ALPHA);
+        f.wf = 1; f.v0 = v.r; f.v1 = sb; f.v2 = nullptr; f.wout = v.t;
+        spmv(c, v.t, v.y, 2, v.t, c->red(0, PH_OMEGA, true, 2), Finish{}, 0, nullptr, &f);         // q, y = A q, (q,y), (y,y) -> omega
+        group_now(c, 2, PH_OMEGA);
+        Vecs vv = v;
+        vv.p = pb;
+        launch_plain_xr(vv, here(), c->red(0, PH_PLAIN_END, true, 2), v.t);                        // x, r, (r,r), (r#,r) -> beta, k++
+        group_now(c, 2, PH_PLAIN_END);
+        c->pl_flip ^= 1;
+    }
+
     void iter_plain()   // reference src/solver.c:88-119
     {
+        if (fused_plain()) { iter_plain_fused(); return; }
         spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
         launch_plain_q(v, here());                               // q = r - alpha s
@@ -852,6 +888,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     c->wave_mode = method >= BICG_PIPE_BICGSTAB;
     c->grp = bicg_ctx::Group{};
     c->f1_done = false;
+    c->pl_flip = 0;
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -2006,12 +2043,43 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             if (group_is_sell[sl / (kGroupRows / kSliceRows)]) n16 += (uint64_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows;
         }
     if (n16 >= 0xFFFFFF00ull) c16 = false;
-    for (uint32_t r = 0; c16 && !win && r < nrows; ++r) {
-        if (!group_is_sell[r / kGroupRows]) continue;
-        for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
-            const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
-            if (dlt < -32767 || dlt > 32767) { c16 = false; break; }
+    std::vector<int> offsets_seen;          // distinct column offsets (col - row), while they stay few: the fused-window clusters
+    bool offsets_few = true;
+    {
+        std::vector<unsigned char> mark(65536, 0);
+        for (uint32_t r = 0; c16 && !win && r < nrows; ++r) {
+            if (!group_is_sell[r / kGroupRows]) continue;
+            for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
+                const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
+                if (dlt < -32767 || dlt > 32767) { c16 = false; break; }
+                if (offsets_few && !mark[dlt + 32768]) {
+                    mark[dlt + 32768] = 1;
+                    offsets_seen.push_back((int)dlt);
+                    if (offsets_seen.size() > 4096) offsets_few = false;
+                }
+            }
         }
+    }
+    // Fused-window clusters (struct FusedWindow): the offsets fall into <= 4 clusters (gaps of more than 512 columns separate
+    // them) and a group's window -- 256 + span columns per cluster -- fits 2048 LDS slots. Padded slices with 16-bit offsets,
+    // every row on the sliced-ELL path, one rank.
+    if (c16 && !jag && !win && offsets_few && P == 1 && sell_entries > 0) {
+        offsets_seen.push_back(0);
+        std::sort(offsets_seen.begin(), offsets_seen.end());
+        FusedWindow f{};
+        int ncl = 0, slots = 0;
+        bool ok = true;
+        for (size_t i = 0; i < offsets_seen.size() && ok;) {
+            size_t k = i;
+            while (k + 1 < offsets_seen.size() && offsets_seen[k + 1] - offsets_seen[k] <= 512) ++k;
+            if (ncl == kFwMaxClusters) { ok = false; break; }
+            f.lo[ncl] = offsets_seen[i]; f.hi[ncl] = offsets_seen[k];
+            f.bias[ncl] = slots - f.lo[ncl];
+            slots += kGroupRows + f.hi[ncl] - f.lo[ncl];
+            ++ncl;
+            i = k + 1;
+        }
+        if (ok && slots <= 2048) { f.ncl = ncl; f.slots = (unsigned)slots; c->fw = f; }
     }
     std::vector<short> scol16(c16 ? n16 : 1, 0);
     if (jag) {
@@ -2172,6 +2240,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         bool mine = !(pe && atoi(pe) == 0) && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
         c->persist_on = all_ranks(comm, mine);
         if (const char *pp = getenv("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
+        if (const char *pp = getenv("BICG_FUSE_PLAIN")) c->fuse_plain = atoi(pp) != 0;
         if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
     }
 

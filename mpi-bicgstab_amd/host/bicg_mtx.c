@@ -1,5 +1,10 @@
 /* bicg_mtx.c -- see bicg_mtx.h */
+#define _GNU_SOURCE
 #include "bicg_mtx.h"
+
+#include <pthread.h>
+#include <sched.h>
+#include <unistd.h>
 
 #include <ctype.h>
 #include <stdint.h>
@@ -233,6 +238,64 @@ static void emit_serial(void *c, unsigned long i, unsigned long j, double v)
     if (i >= s->lo && i < s->hi) tpush(&s->mine, (unsigned)i, (unsigned)j, v);
 }
 
+/* The entry lines tokenised by several threads: the text is cut into byte ranges at line boundaries, every thread keeps
+ * the triplets of [lo, hi) it finds in its own list, and the lists are joined in range order -- file order, like the
+ * one-thread pass (the reference has every rank fscanf() the whole file twice, src/matrix.c:315-341, 357-393; a
+ * Transport-sized file -- 840 MB, 23.9 M lines -- took the single tokeniser 2.1 s of a 2.9 s run). BICG_MTX_THREADS
+ * overrides the count (default: the cores the process may use, at most 16; 1 = the serial pass). */
+typedef struct { const char *p, *end; mtx_header h; serial_ctx s; int rc; } parse_job;
+static void *parse_job_run(void *arg)
+{
+    parse_job *j = (parse_job *)arg;
+    j->rc = parse_entries(j->p, j->end, &j->h, (unsigned long)-1, emit_serial, &j->s);
+    return NULL;
+}
+static int parse_threaded(const char *p, const char *end, mtx_header *h, serial_ctx *out)
+{
+    long nt = sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) nt = CPU_COUNT(&set);
+    if (nt > 16) nt = 16;
+    if ((size_t)(end - p) < ((size_t)1 << 22)) nt = 1;           /* small files: not worth the threads */
+    const char *env = getenv("BICG_MTX_THREADS");
+    if (env) nt = atol(env);
+    if (nt <= 1) return parse_entries(p, end, h, h->nz, emit_serial, out);
+    parse_job *jobs = (parse_job *)calloc((size_t)nt, sizeof(parse_job));
+    pthread_t *tid = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+    const size_t len = (size_t)(end - p);
+    const char *cut = p;
+    for (long t = 0; t < nt; ++t) {
+        const char *stop = t == nt - 1 ? end : p + len * (size_t)(t + 1) / (size_t)nt;
+        while (stop < end && stop > cut && stop[-1] != '\n') ++stop;      /* a range ends after a newline */
+        jobs[t].p = cut; jobs[t].end = stop; jobs[t].h = *h; jobs[t].s = *out; jobs[t].s.mine.t = NULL; jobs[t].s.mine.n = jobs[t].s.mine.cap = 0;
+        cut = stop;
+    }
+    for (long t = 0; t < nt; ++t)
+        if (pthread_create(&tid[t], NULL, parse_job_run, &jobs[t]) != 0) { parse_job_run(&jobs[t]); tid[t] = 0; }
+    int rc = 0;
+    size_t total = 0;
+    h->emitted = 0;
+    for (long t = 0; t < nt; ++t) {
+        if (tid[t]) pthread_join(tid[t], NULL);
+        if (jobs[t].rc) rc = jobs[t].rc;
+        total += jobs[t].s.mine.n;
+        h->emitted += jobs[t].h.emitted;
+    }
+    if (!rc) {
+        out->mine.t = (triplet *)realloc(out->mine.t, sizeof(triplet) * (total ? total : 1));
+        out->mine.cap = total ? total : 1;
+        size_t at = out->mine.n;
+        for (long t = 0; t < nt; ++t) {
+            if (jobs[t].s.mine.n) memcpy(out->mine.t + at, jobs[t].s.mine.t, sizeof(triplet) * jobs[t].s.mine.n);
+            at += jobs[t].s.mine.n;
+        }
+        out->mine.n = at;
+    }
+    for (long t = 0; t < nt; ++t) free(jobs[t].s.mine.t);
+    free(jobs); free(tid);
+    return rc;
+}
+
 static void emit_count(void *c, unsigned long i, unsigned long j, double v)
 {
     (void)j; (void)v;
@@ -257,7 +320,7 @@ int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, C
         free(cnt);
     }
     serial_ctx s = {{0, 0, 0}, (unsigned)info->displs[rank], (unsigned)(info->displs[rank] + info->recvcounts[rank])};
-    rc = parse_entries(buf + h.data_off, buf + len, &h, h.nz, emit_serial, &s);
+    rc = parse_threaded(buf + h.data_off, buf + len, &h, &s);
     free(buf);
     if (rc) return rc;
     /* nz = entries of the matrix that is actually solved: for 'symmetric' storage the banner counts one

@@ -67,13 +67,17 @@ def test_loader_blocks(tmp_path, world, mode, order):
         for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
             f.write(f"{i + 1} {j + 1} {v!r}\n")
     prefix = str(tmp_path / "out")
-    subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode], check=True, timeout=120)
-    for rank in range(world):
-        rows, ncols, d, o = _read(prefix, rank)
-        ed, eo, counts, _ = _expected(A.rows, row, col, val, world, rank)
-        assert rows == counts[rank] and ncols == A.cols
-        assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[1], ed.col) and np.array_equal(d[2], ed.val)
-        assert np.array_equal(o[0], eo.ptr) and np.array_equal(o[1], eo.col) and np.array_equal(o[2], eo.val)
+    # serial mode: the entry lines tokenised by one thread, and by several (byte ranges cut at line boundaries, lists joined
+    # in range order: the file order inside every row must survive)
+    for threads in (("1", "5") if mode == "serial" else ("1",)):
+        subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode], check=True, timeout=120,
+                       env=dict(os.environ, BICG_MTX_THREADS=threads))
+        for rank in range(world):
+            rows, ncols, d, o = _read(prefix, rank)
+            ed, eo, counts, _ = _expected(A.rows, row, col, val, world, rank)
+            assert rows == counts[rank] and ncols == A.cols
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[1], ed.col) and np.array_equal(d[2], ed.val), threads
+            assert np.array_equal(o[0], eo.ptr) and np.array_equal(o[1], eo.col) and np.array_equal(o[2], eo.val), threads
 
 
 def test_loader_symmetric_and_pattern(tmp_path):
