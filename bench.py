@@ -418,7 +418,8 @@ def main():
     leg = Leg(wl)
     n, nnz_global, plan = wl["rows"], wl["nnz"], leg.plan
     note(f"matrix resident: {plan}")
-    leg.ctx.spmv_bench(50)       # clocks and caches in steady state before the first timed iteration
+    leg.ctx.spmv_bench(600)      # clocks and caches in steady state before the first timed iteration (the GPU idled while the
+                                 # matrix was generated on the host: a 20-iteration region right after 2.5 ms of warm-up read 3 % high)
     stage[0] = "timed iterations"
 
     # main timed region: exactly K iterations after W warm-up iterations, no per-kernel instrumentation

@@ -210,6 +210,13 @@ __device__ __forceinline__ void hand_over(double val, double (&acc)[N], double *
     }
 }
 
+// ... a value without dot partials
+__device__ __forceinline__ void publish_only(double val, double *zs, llword *img_row, unsigned seq)
+{
+    if (img_row) ll_store16_agent(img_row, val, seq);
+    zs[threadIdx.x] = val;
+}
+
 // communication wavefront: everything the rest of the GPU (and the other GPUs) gets from this workgroup in one phase --
 // the LL image of its rows' values, the halo values other ranks need, its row of the dot table -- then the wait for the
 // applied scalars of that group (needed by the row wavefronts only after their product)
@@ -579,7 +586,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
         const unsigned g1 = a.seq0 + 3u * (unsigned)it + 1u, g2 = g1 + 1u, g3 = g1 + 2u;
         const unsigned hp = a.halo_seq0 + 2u * (unsigned)it + 1u, hq = hp + 1u;
         // ---- s = A p ; (r#,s) -> alpha                                               (src/solver.c:88-93)
-        if (!comm) { double none[1] = {0.0}; hand_over<1>(p, none, zs, L, img0, g1); }
+        if (!comm) { publish_only(p, zs, img0, g1); }
         lds_barrier();
         if (comm) comm_halo<MULTI>(a, lane, zs, hp, ns0, ns1);
         else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[0], g1, hp, win, nrt, L, zs, row0, nmine);
@@ -595,7 +602,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (L.fail) break;
         alpha = L.sc[0];
         // ---- q = r - alpha s ; y = A q ; (q,y), (y,y) -> omega                       (src/solver.c:94-104)
-        if (!comm) { q = r + (-alpha) * s; double none[1] = {0.0}; hand_over<1>(q, none, zs, L, img1, g2); }
+        if (!comm) { q = r + (-alpha) * s; publish_only(q, zs, img1, g2); }
         lds_barrier();
         if (comm) comm_halo<MULTI>(a, lane, zs, hq, ns0, ns1);
         else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[1], g2, hq, win, nrt, L, zs, row0, nmine);
@@ -715,8 +722,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
         if (!comm) {
             p = recur3<double>(p, s, r, omega, beta);
             s = recur3<double>(s, z, w, omega, beta);
-            double none[1] = {0.0};
-            hand_over<1>(s, none, zs, L, img0, g1);
+            publish_only(s, zs, img0, g1);
         }
         lds_barrier();
         if (comm) comm_halo<MULTI>(a, lane, zs, hs, ns0, ns1);
@@ -741,8 +747,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
             xx = xx + omega * r;
             x = xx;
             r = r + (-omega) * w;
-            double none[1] = {0.0};
-            hand_over<1>(r, none, zs, L, img1, g2);
+            publish_only(r, zs, img1, g2);
         }
         lds_barrier();
         if (comm) comm_halo<MULTI>(a, lane, zs, hr, ns0, ns1);
