@@ -199,6 +199,18 @@ def test_hot_kernels_stay_lean():
     assert len(epi) >= 16
     for k in epi:
         assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
+    # round 3. The persistent kernels: up to 16 wavefronts of one workgroup per CU = 4 per SIMD = 128 VGPRs each; the
+    # rows-over-lanes SpMV and the window-fused SpMV at full occupancy
+    persist = [k for k in kernels if re.search(r"k_(pipe|plain|ca)_persist", k)]
+    assert len(persist) == 12, persist
+    for k in persist:
+        assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
+    rows = [k for k in kernels if re.search(r"k_spmv_rowsILi[0-3]ELb0ELb[01]ELb[01]ELi[02]EEEv", k)]      # no offd, light epilogues
+    assert len(rows) >= 24, len(rows)
+    for k in rows:
+        assert kernels[k]["VGPRs"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] == 8 and kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
+    for k in [k for k in kernels if "k_spmv_sell_fw" in k]:
+        assert kernels[k]["VGPRs"] <= 80 and kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
 
 
 def test_window_plan_covers_every_column_once():
