@@ -140,7 +140,15 @@ struct Reduce {
     int       wave;        // 1: consumer-side finish -- store one partial per wavefront at row
                            // (slot_base + workgroup) * 4 + wave and end (see Finish); nothing else is used
     P2pRed    p2p;         // peer-to-peer transport: where the finished sums are published
+    // Tail finish (single GPU, round 3): every workgroup stores its partials as LL words (tag tail_seq) and ENDS -- no
+    // acknowledged store, no returning atomic (2-3 us of every workgroup's life on a Transport-sized product); the LAST
+    // min(expected, kShards) workgroups of the group stay, add one shard of the table each (slot order) and publish the shard
+    // totals as LL words, the very last one adds those and applies the recurrence. 0: arrival tickets as before.
+    llword   *tail_tab;    // [slots][kTailStride] LL words
+    llword   *tail_shard;  // [kShards][kRedSlots][2]
+    unsigned  tail_seq;
 };
+constexpr int kTailStride = 16;             // LL words per slot of the tail table (8 doubles)
 
 // ---- consumer-side finish of a dot group (the four solvers of reference src/solver.c) -------------
 // A kernel that PRODUCES dot sums only stores one partial per wavefront (wave shuffle, one plain
@@ -289,6 +297,7 @@ struct SpmvArgs {
     Reduce  red;
     int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
+    int     xcd_map;        // sliced-ELL: XCD-contiguous order of the groups (workgroup b runs on XCD b % 8; measurement knob)
     HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only
     Finish  fin;            // a dot group of earlier kernels to finish in this launch (seq 0: none)
     Vecs    epi;            // launch_spmv_sell_epi: the vectors of the element-wise phase in the epilogue

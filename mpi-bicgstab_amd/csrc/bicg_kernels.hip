@@ -531,6 +531,67 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
     __shared__ unsigned s_last;
     const unsigned shard = slot % kShards;
     block_sum<ND>(acc, sm);
+    if (!HEAVY && red.tail_seq) {
+        // ---- tail finish: LL-tagged partials, producers leave at once (struct Reduce)
+        const unsigned seq = red.tail_seq, nsh = red.expected < (unsigned)kShards ? red.expected : (unsigned)kShards;
+        if (threadIdx.x < ND) ll_store_agent(red.tail_tab + (size_t)slot * kTailStride + 2 * threadIdx.x, acc[threadIdx.x], seq);
+        if (slot + nsh < red.expected) return;
+        const unsigned sh = red.expected - 1u - slot;                        // this workgroup's shard: 0 = the very last workgroup
+        const unsigned long long patience = 400000000ull;                   // 4 s: a lost workgroup must not hang the GPU
+        double tot[ND];
+#pragma unroll
+        for (int d = 0; d < ND; ++d) tot[d] = 0.0;
+        bool lost = false;
+        for (unsigned i = sh + threadIdx.x * nsh; i < red.expected && !lost; i += kBlock * nsh) {     // slots sh, sh + nsh, ... in order
+            const llword *row = red.tail_tab + (size_t)i * kTailStride;
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spin = 0;; ++spin) {
+                double v[ND];
+                bool all = true;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) all = ll_peek_agent(row + 2 * d, seq, &v[d]) && all;
+                if (all) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) tot[d] += v[d];
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(8);
+                if ((spin & 63u) == 63u && wall_clock64() - t0 > patience) { lost = true; break; }
+            }
+        }
+        block_sum<ND>(tot, sm);
+        if (threadIdx.x < ND) ll_store_agent(red.tail_shard + ((size_t)sh * kRedSlots + threadIdx.x) * 2, tot[threadIdx.x], seq);
+        if (sh != 0) return;
+#pragma unroll
+        for (int d = 0; d < ND; ++d) tot[d] = 0.0;
+        if (threadIdx.x < nsh) {
+            const unsigned long long t0 = wall_clock64();
+            for (unsigned spin = 0;; ++spin) {
+                double v[ND];
+                bool all = true;
+#pragma unroll
+                for (int d = 0; d < ND; ++d) all = ll_peek_agent(red.tail_shard + ((size_t)threadIdx.x * kRedSlots + d) * 2, seq, &v[d]) && all;
+                if (all) {
+#pragma unroll
+                    for (int d = 0; d < ND; ++d) tot[d] = v[d];
+                    break;
+                }
+                __builtin_amdgcn_s_sleep(2);
+                if ((spin & 63u) == 63u && wall_clock64() - t0 > patience) { lost = true; break; }
+            }
+        }
+        block_sum<ND>(tot, sm);
+        if (threadIdx.x == 0) {
+#pragma unroll
+            for (int d = 0; d < ND; ++d) S->red[red.red_off + d] = tot[d];
+            if (lost) { S->comm_error = 1; S->done = 1; }
+        }
+        if (red.apply_now) {
+            __syncthreads();
+            apply_phase_block<HEAVY>(S, red.phase);
+        }
+        return;
+    }
     if (threadIdx.x < ND)
         __hip_atomic_store(&red.partial[(size_t)slot * kPartialStride + threadIdx.x], acc[threadIdx.x],
                            __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -1074,7 +1135,7 @@ __device__ __forceinline__ void rows_block(const SpmvArgs &a, uint32_t r0, uint3
 }
 
 template <int NDOT, bool OFFD, bool NT, bool C16, int MODE>
-__global__ void __launch_bounds__(kBlock) k_spmv_rows(SpmvArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == RED_TICKET ? 8 : 4, 8))) k_spmv_rows(SpmvArgs a)
 {
     if (MODE == RED_WAVE) {
         __shared__ FinishLds fl;
@@ -1316,7 +1377,7 @@ __device__ __forceinline__ void sell_halo_push(const SpmvArgs &a, unsigned bid, 
 }
 
 template <int NDOT, bool OFFD, bool NT, int LAY, bool LL, int MODE>
-__global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == RED_TICKET ? 8 : 4, 8))) k_spmv_sell(SpmvArgs a)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
     __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
@@ -1344,14 +1405,21 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell(SpmvArgs a)
     // 10 us per SpMV on Transport; a few groups per workgroup amortise it. Round-robin placement
     // over the XCDs is kept: an XCD-contiguous mapping cuts the fabric reads from 386 to 309 MB
     // (x is then fetched by one L2 instead of eight) but is 3-5 % SLOWER in wall time.
-    for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
+    for (unsigned gi0 = bid; gi0 < a.nlist; gi0 += nblocks) {
+        unsigned gi = gi0;
+        if (a.xcd_map && !LL && nblocks == a.nlist && gi0 < (a.nlist / 8u) * 8u) gi = (gi0 % 8u) * (a.nlist / 8u) + gi0 / 8u;
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
+        // the dot operand of this lane's row is requested BEFORE the row product (one load in front of the product's
+        // batches; after it, it was a dependent round trip at the very end of every workgroup)
+        double upre = 0.0;
+        const uint32_t rguess = (a.glist ? a.glist[gi] : gi) * kGroupRows + threadIdx.x;
+        if (NDOT >= 1 && rguess < a.nrows) upre = a.u[rguess];
         const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed, dyn_lds);
         if (live && !done) a.y[row] = yi;
         if (NDOT >= 1 && live) {
-            const double ume = a.u[row];
+            const double ume = row == rguess ? upre : a.u[row];
             acc[0] += ume * yi;
             if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
             if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += ume * ume;

@@ -153,6 +153,10 @@ struct bicg_ctx {
     unsigned long long spin_ticks = 2000;   // 20 us before a workgroup sums a missing shard itself (BICG_SPIN_TICKS)
     double *partial = nullptr, *shard_tot = nullptr;
     unsigned *counter = nullptr;
+    // tail finish of ticket-mode dot groups (struct Reduce): LL table + shard totals; BICG_TAIL_FINISH=0: arrival tickets
+    llword *tail_tab = nullptr, *tail_shard = nullptr;
+    mutable unsigned tail_seq = 0;
+    bool tail_finish = true;
     unsigned nslots = 0;
     double *trace = nullptr;     // 4 * trace_cap
     int trace_cap = 0;
@@ -219,6 +223,9 @@ struct bicg_ctx {
         r.red_off = off; r.phase = phase;
         r.apply_now = (single() && apply_single) ? 1 : 0;
         r.p2p = P2pRed{};
+        r.tail_tab = tail_tab; r.tail_shard = tail_shard;
+        // (not under hipGraph replay: a captured launch would meet its own earlier words under the same tag)
+        r.tail_seq = (tail_finish && !p2p && tail_tab && graph_mode != 1) ? ++tail_seq : 0u;
         if (p2p) {
             r.p2p = p2p->red_desc(p2p->red_seq);   // the group being produced; closed by group_now/defer
             if (apply_single && now_n > 0 && inline_apply) {
@@ -424,6 +431,8 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
     // order): {sliced-ELL groups, CSR row blocks} x {interior, halo-touching}.
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
+    static const int xcd_map_env = getenv("BICG_SELL_XCD") ? atoi(getenv("BICG_SELL_XCD")) : 0;
+    a.xcd_map = xcd_map_env;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
     const bool fused = c->p2p && c->ll_fused;
@@ -1749,6 +1758,11 @@ static void ctx_state(bicg_ctx *c, Comm *comm, uint32_t ngroups)
     c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
     c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
     BICG_HIP(hipMemset(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride));
+    c->tail_tab = dev_alloc<llword>((size_t)c->nslots * kTailStride);
+    BICG_HIP(hipMemset(c->tail_tab, 0, sizeof(llword) * (size_t)c->nslots * kTailStride));
+    c->tail_shard = dev_alloc<llword>((size_t)kShards * kRedSlots * 2);
+    BICG_HIP(hipMemset(c->tail_shard, 0, sizeof(llword) * kShards * kRedSlots * 2));
+    if (const char *sv = getenv("BICG_TAIL_FINISH")) c->tail_finish = atoi(sv) != 0;
     c->Sbuf = dev_alloc<Scal>(2);
     BICG_HIP(hipMemset(c->Sbuf, 0, 2 * sizeof(Scal)));
     c->S = c->Sbuf;
@@ -2375,7 +2389,7 @@ void bicg_destroy(bicg_ctx *c)
     (void)hipDeviceSynchronize();
     void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
-                    c->wpart[0], c->wpart[1], c->shard_ll, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
+                    c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
     for (void *p : c->persist_mem) if (p) (void)hipFree(p);
     release_p2p(c);

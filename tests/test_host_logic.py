@@ -205,8 +205,8 @@ def test_hot_kernels_stay_lean():
     assert len(persist) == 12, persist
     for k in persist:
         assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
-    rows = [k for k in kernels if re.search(r"k_spmv_rowsILi[0-3]ELb0ELb[01]ELb[01]ELi[02]EEEv", k)]      # no offd, light epilogues
-    assert len(rows) >= 24, len(rows)
+    rows = [k for k in kernels if re.search(r"k_spmv_rowsILi[0-3]ELb0ELb[01]ELb[01]ELi0EEEv", k)]      # no offd, ticket / tail epilogue
+    assert len(rows) >= 12, len(rows)
     for k in rows:
         assert kernels[k]["VGPRs"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] == 8 and kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
     for k in [k for k in kernels if "k_spmv_sell_fw" in k]:
