@@ -335,6 +335,17 @@ long bicg_window_plan(const unsigned int *ptr, const unsigned int *col, unsigned
                       unsigned int *runs, unsigned int *slots_used);
 unsigned int bicg_window_slot(const unsigned int *runs, unsigned int first, unsigned int end, unsigned int c);
 
+/* Plan of the persistent iteration (host only, what bicg_create builds for latency-bound ranks): the
+ * workgroups' slices as padded entries {value, 16-bit slot of the column in the workgroup's window}, diag entries first, then
+ * the offd entries (offd_renumbered: columns = local rows + halo position as bicg_halo_plan renumbers them; NULL for one rank),
+ * and the window runs {first column, (first slot << 16) | length} per workgroup. gmax = workgroups available (CUs - 1).
+ * summary = {slices per workgroup, workgroups, window slots, most runs of a workgroup, most entries of a workgroup, entries,
+ * runs, 0}; arrays may be NULL (sizes: a first call). Returns 0 when the block qualifies (<= 15 slices per workgroup, windows
+ * within 16 384 slots). */
+int bicg_persist_plan(const CSR_Matrix *diag, const CSR_Matrix *offd_renumbered, unsigned int gmax, unsigned int summary[8],
+                      unsigned int *pbase, unsigned short *pslot, double *pval, unsigned short *rlen, unsigned short *rdiag,
+                      unsigned int *win_ptr, unsigned int *win_runs);
+
 /* Matrix-Market block loader (host only): what MPI_csr_load_matrix_block produces for `rank` of
  * `nranks` (reference src/matrix.c:402-419) -- diag block with local columns, offd block with global
  * columns, file order inside a row, equal-rows partition -- reading the file once. Arrays are

@@ -5,6 +5,7 @@
 //                    MPI_Iallgatherv of reference src/matrix.c:432 by a halo)
 //   bicg_row_blocks  greedy row blocks for the row-block-stream SpMV
 #include "../../include/bicgstab_hip.h"
+#include "bicg_plan.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -157,4 +158,119 @@ extern "C" unsigned int bicg_window_slot(const unsigned int *runs, unsigned int 
     unsigned a = first, b = end;
     while (b - a > 1) { const unsigned m = (a + b) / 2; if (runs[2 * m] <= c) a = m; else b = m; }
     return (runs[2 * a + 1] >> 16) + (c - runs[2 * a]);
+}
+
+
+// ---- plan of the persistent iteration (bicg_persist.hip, struct PersistArgs): which slices a workgroup owns, its part of
+// the matrix as padded slices (diag entries first, then offd entries in the x_ext numbering [local rows | halo positions])
+// with window slots instead of columns, and the window runs. Host-only; false when the block does not qualify.
+namespace bicg {
+bool persist_plan_host(const CSR_Matrix *diag, const unsigned *optr, const unsigned *ocol, const double *oval, unsigned gmax,
+                       PersistPlan &P)
+{
+    constexpr uint32_t kSlice = 64;
+    const uint32_t nrows = diag->rows;
+    const bool multi = optr != nullptr;
+    if (nrows == 0 || gmax < 1) return false;
+    P = PersistPlan{};
+    P.nrows = nrows;
+    P.nslices = (nrows + kSlice - 1) / kSlice;
+    P.spw = (P.nslices + gmax - 1) / gmax;
+    if (P.spw > 15) return false;                                  // 15 row wavefronts + the communication wavefront per workgroup
+    P.nwg = (P.nslices + P.spw - 1) / P.spw;
+    const uint32_t grows = P.spw * kSlice, nslices = P.nslices, nwg = P.nwg, spw = P.spw;
+
+    // merged rows in x_ext numbering
+    std::vector<uint32_t> mptr(nrows + 1, 0u);
+    for (uint32_t r = 0; r < nrows; ++r) mptr[r + 1] = mptr[r] + (diag->ptr[r + 1] - diag->ptr[r]) + (multi ? optr[r + 1] - optr[r] : 0u);
+    std::vector<uint32_t> mcol(mptr[nrows] ? mptr[nrows] : 1);
+    std::vector<double> mval(mptr[nrows] ? mptr[nrows] : 1);
+    P.rlen.assign(nrows, 0); P.rdiag.assign(nrows, 0);
+    for (uint32_t r = 0; r < nrows; ++r) {
+        uint32_t at = mptr[r];
+        const uint32_t dl = diag->ptr[r + 1] - diag->ptr[r], ol = multi ? optr[r + 1] - optr[r] : 0u;
+        if (dl + ol > 65535u) return false;
+        for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j, ++at) { mcol[at] = diag->col[j]; mval[at] = diag->val[j]; }
+        if (multi) for (uint32_t j = optr[r]; j < optr[r + 1]; ++j, ++at) { mcol[at] = ocol[j]; mval[at] = oval[j]; }
+        P.rlen[r] = (unsigned short)(dl + ol); P.rdiag[r] = (unsigned short)dl;
+    }
+    // windows: runs of consecutive columns per workgroup; a run never straddles the local / halo boundary
+    const uint32_t max_slots = 16384;
+    std::vector<uint32_t> wptr0(nwg + 1, 0u);
+    const long nruns = bicg_window_plan(mptr.data(), mcol.data(), nrows, grows, nullptr, max_slots, 8, nullptr, nullptr, nullptr);
+    if (nruns < 0) return false;
+    std::vector<uint32_t> runs0(2 * (size_t)nruns + 2);
+    bicg_window_plan(mptr.data(), mcol.data(), nrows, grows, nullptr, max_slots, 8, wptr0.data(), runs0.data(), &P.win_slots);
+    P.wptr.assign(nwg + 1, 0u);
+    for (uint32_t g = 0; g < nwg; ++g) {
+        P.wptr[g] = (uint32_t)(P.runs.size() / 2);
+        for (uint32_t i = wptr0[g]; i < wptr0[g + 1]; ++i) {
+            const uint32_t c0 = runs0[2 * i], slot0 = runs0[2 * i + 1] >> 16, len = runs0[2 * i + 1] & 0xFFFFu;
+            if (c0 < nrows && c0 + len > nrows) {
+                const uint32_t l1 = nrows - c0;
+                P.runs.push_back(c0); P.runs.push_back((slot0 << 16) | l1);
+                P.runs.push_back(nrows); P.runs.push_back(((slot0 + l1) << 16) | (len - l1));
+            } else {
+                P.runs.push_back(c0); P.runs.push_back((slot0 << 16) | len);
+            }
+        }
+        P.max_runs = std::max<uint32_t>(P.max_runs, (uint32_t)(P.runs.size() / 2) - P.wptr[g]);
+    }
+    P.wptr[nwg] = (uint32_t)(P.runs.size() / 2);
+    if (P.max_runs > 1024) return false;
+    auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
+        uint32_t a = P.wptr[g], b = P.wptr[g + 1];
+        while (b - a > 1) { const uint32_t m = (a + b) / 2; if (P.runs[2 * m] <= col) a = m; else b = m; }
+        return (P.runs[2 * a + 1] >> 16) + (col - P.runs[2 * a]);
+    };
+    // padded slices
+    P.pbase.assign(nslices + 1, 0u);
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        uint32_t longest = 0;
+        for (uint32_t r = sl * kSlice; r < std::min(nrows, (sl + 1) * kSlice); ++r) longest = std::max<uint32_t>(longest, P.rlen[r]);
+        const uint64_t next = (uint64_t)P.pbase[sl] + (uint64_t)longest * kSlice;
+        if (next >= 0xFFFFFF00ull) return false;
+        P.pbase[sl + 1] = (uint32_t)next;
+    }
+    const size_t entries = P.pbase[nslices];
+    P.pval.assign(entries ? entries : 1, 0.0);
+    P.pslot.assign(entries ? entries : 1, 0);
+    for (uint32_t g = 0; g < nwg; ++g) {
+        const uint32_t s0 = g * spw, s1 = std::min(nslices, s0 + spw);
+        P.max_entries = std::max(P.max_entries, P.pbase[s1] - P.pbase[s0]);
+        for (uint32_t r = s0 * kSlice; r < std::min(nrows, s1 * kSlice); ++r) {
+            const uint32_t sl = r / kSlice, lane = r % kSlice;
+            for (uint32_t j = mptr[r], k = 0; j < mptr[r + 1]; ++j, ++k) {
+                const size_t e = (size_t)P.pbase[sl] + (size_t)k * kSlice + lane;
+                P.pval[e] = mval[j];
+                P.pslot[e] = (unsigned short)slot_of(g, mcol[j]);
+            }
+        }
+    }
+    return true;
+}
+}  // namespace bicg
+
+// C view for tests: summary = {spw, nwg, window slots, most runs of a workgroup, most matrix entries of a workgroup, entries,
+// runs, 0}; the arrays (sizes known from a first call with NULL arrays) are filled when given. offd_renumbered: columns =
+// rows + halo position (bicg_halo_plan), or NULL for one rank. Returns 0 when the block qualifies.
+extern "C" int bicg_persist_plan(const CSR_Matrix *diag, const CSR_Matrix *offd_renumbered, unsigned int gmax, unsigned int summary[8],
+                                 unsigned int *pbase, unsigned short *pslot, double *pval, unsigned short *rlen, unsigned short *rdiag,
+                                 unsigned int *win_ptr, unsigned int *win_runs)
+{
+    bicg::PersistPlan P;
+    const bool multi = offd_renumbered != nullptr;
+    if (!bicg::persist_plan_host(diag, multi ? offd_renumbered->ptr : nullptr, multi ? offd_renumbered->col : nullptr,
+                                 multi ? offd_renumbered->val : nullptr, gmax, P))
+        return 1;
+    const unsigned s[8] = {P.spw, P.nwg, P.win_slots, P.max_runs, P.max_entries, P.pbase[P.nslices], (unsigned)(P.runs.size() / 2), 0u};
+    for (int i = 0; i < 8; ++i) summary[i] = s[i];
+    if (pbase) std::copy(P.pbase.begin(), P.pbase.end(), pbase);
+    if (pslot) std::copy(P.pslot.begin(), P.pslot.begin() + P.pbase[P.nslices], pslot);
+    if (pval) std::copy(P.pval.begin(), P.pval.begin() + P.pbase[P.nslices], pval);
+    if (rlen) std::copy(P.rlen.begin(), P.rlen.end(), rlen);
+    if (rdiag) std::copy(P.rdiag.begin(), P.rdiag.end(), rdiag);
+    if (win_ptr) std::copy(P.wptr.begin(), P.wptr.end(), win_ptr);
+    if (win_runs) std::copy(P.runs.begin(), P.runs.end(), win_runs);
+    return 0;
 }

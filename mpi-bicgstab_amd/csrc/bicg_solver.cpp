@@ -16,6 +16,7 @@
 #include <vector>
 
 #include "bicg_comm.h"
+#include "bicg_plan.h"
 #include "bicg_device.h"
 
 using namespace bicg;
@@ -1559,82 +1560,17 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
     // one workgroup per CU (its LDS): ranks sharing a GPU (tests) share the CUs; one CU is the helper's
     const int gmax = cus / std::max(1, c->comm->ranks_on_device) - 1;
     if (gmax < 1) return false;
-    const uint32_t nslices = (nrows + kSliceRows - 1) / kSliceRows;
-    const uint32_t spw = (nslices + (uint32_t)gmax - 1) / (uint32_t)gmax;
-    if (spw > 15) return false;                                    // 15 row wavefronts + the communication wavefront per workgroup
-    const uint32_t nwg = (nslices + spw - 1) / spw, grows = spw * kSliceRows;
-
-    // merged rows in x_ext numbering
-    std::vector<uint32_t> mptr(nrows + 1, 0u);
-    for (uint32_t r = 0; r < nrows; ++r) mptr[r + 1] = mptr[r] + (diag->ptr[r + 1] - diag->ptr[r]) + (multi ? optr[r + 1] - optr[r] : 0u);
-    std::vector<uint32_t> mcol(mptr[nrows] ? mptr[nrows] : 1);
-    std::vector<double> mval(mptr[nrows] ? mptr[nrows] : 1);
-    std::vector<unsigned short> rlen(nrows), rdiag(nrows);
-    for (uint32_t r = 0; r < nrows; ++r) {
-        uint32_t at = mptr[r];
-        const uint32_t dl = diag->ptr[r + 1] - diag->ptr[r], ol = multi ? optr[r + 1] - optr[r] : 0u;
-        if (dl + ol > 65535u) return false;
-        for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j, ++at) { mcol[at] = diag->col[j]; mval[at] = diag->val[j]; }
-        if (multi) for (uint32_t j = optr[r]; j < optr[r + 1]; ++j, ++at) { mcol[at] = ocol[j]; mval[at] = oval[j]; }
-        rlen[r] = (unsigned short)(dl + ol); rdiag[r] = (unsigned short)dl;
-    }
-    // windows: runs of consecutive columns per workgroup; a run never straddles the local / halo boundary
-    const uint32_t max_slots = 16384;
-    std::vector<uint32_t> wptr0(nwg + 1, 0u);
-    long nruns = bicg_window_plan(mptr.data(), mcol.data(), nrows, grows, nullptr, max_slots, 8, nullptr, nullptr, nullptr);
-    if (nruns < 0) return false;
-    std::vector<uint32_t> runs0(2 * (size_t)nruns + 2);
-    uint32_t slots_used = 0;
-    bicg_window_plan(mptr.data(), mcol.data(), nrows, grows, nullptr, max_slots, 8, wptr0.data(), runs0.data(), &slots_used);
-    std::vector<uint32_t> wptr(nwg + 1, 0u);
-    std::vector<uint2> runs;
-    uint32_t max_runs = 0;
-    for (uint32_t g = 0; g < nwg; ++g) {
-        wptr[g] = (uint32_t)runs.size();
-        for (uint32_t i = wptr0[g]; i < wptr0[g + 1]; ++i) {
-            const uint32_t c0 = runs0[2 * i], slot0 = runs0[2 * i + 1] >> 16, len = runs0[2 * i + 1] & 0xFFFFu;
-            if (c0 < nrows && c0 + len > nrows) {
-                const uint32_t l1 = nrows - c0;
-                runs.push_back(make_uint2(c0, (slot0 << 16) | l1));
-                runs.push_back(make_uint2(nrows, ((slot0 + l1) << 16) | (len - l1)));
-            } else {
-                runs.push_back(make_uint2(c0, (slot0 << 16) | len));
-            }
-        }
-        max_runs = std::max<uint32_t>(max_runs, (uint32_t)runs.size() - wptr[g]);
-    }
-    wptr[nwg] = (uint32_t)runs.size();
-    if (max_runs > 1024) return false;
-    auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
-        uint32_t a = wptr[g], b = wptr[g + 1];
-        while (b - a > 1) { const uint32_t m = (a + b) / 2; if (runs[m].x <= col) a = m; else b = m; }
-        return (runs[a].y >> 16) + (col - runs[a].x);
-    };
-    // padded slices
-    std::vector<uint32_t> pbase(nslices + 1, 0u);
-    for (uint32_t sl = 0; sl < nslices; ++sl) {
-        uint32_t longest = 0;
-        for (uint32_t r = sl * kSliceRows; r < std::min(nrows, (sl + 1) * (uint32_t)kSliceRows); ++r) longest = std::max<uint32_t>(longest, rlen[r]);
-        const uint64_t next = (uint64_t)pbase[sl] + (uint64_t)longest * kSliceRows;
-        if (next >= 0xFFFFFF00ull) return false;
-        pbase[sl + 1] = (uint32_t)next;
-    }
-    const size_t entries = pbase[nslices];
-    std::vector<double> pval(entries ? entries : 1, 0.0);
-    std::vector<unsigned short> pslot(entries ? entries : 1, 0);
-    uint32_t max_entries = 0;
-    for (uint32_t g = 0; g < nwg; ++g) {
-        const uint32_t s0 = g * spw, s1 = std::min(nslices, s0 + spw);
-        max_entries = std::max(max_entries, pbase[s1] - pbase[s0]);
-        for (uint32_t r = s0 * kSliceRows; r < std::min(nrows, s1 * (uint32_t)kSliceRows); ++r) {
-            const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
-            for (uint32_t j = mptr[r], k = 0; j < mptr[r + 1]; ++j, ++k) {
-                const size_t e = (size_t)pbase[sl] + (size_t)k * kSliceRows + lane;
-                pval[e] = mval[j];
-                pslot[e] = (unsigned short)slot_of(g, mcol[j]);
-            }
-        }
-    }
+    PersistPlan P;
+    if (!persist_plan_host(diag, multi ? optr.data() : nullptr, multi ? ocol.data() : nullptr, multi ? oval.data() : nullptr, (unsigned)gmax, P))
+        return false;
+    const uint32_t nslices = P.nslices, spw = P.spw, nwg = P.nwg, grows = spw * kSliceRows;
+    const uint32_t slots_used = P.win_slots, max_runs = P.max_runs, max_entries = P.max_entries;
+    const std::vector<uint32_t> &pbase = P.pbase, &wptr = P.wptr;
+    const std::vector<double> &pval = P.pval;
+    const std::vector<unsigned short> &pslot = P.pslot, &rlen = P.rlen, &rdiag = P.rdiag;
+    static_assert(sizeof(uint2) == 2 * sizeof(uint32_t), "run = two 32-bit words");
+    std::vector<uint2> runs(P.runs.size() / 2 + 1);
+    for (size_t i = 0; i < P.runs.size() / 2; ++i) runs[i] = make_uint2(P.runs[2 * i], P.runs[2 * i + 1]);
     PersistArgs &a = c->persist;
     a = PersistArgs{};
     a.nrows = nrows; a.nslices = nslices; a.nwg = nwg; a.spw = spw;

@@ -61,7 +61,7 @@ EXPORTS = [
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
-    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free",
+    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan",
 ]
 
 _lib = None
@@ -395,6 +395,41 @@ def stream_bench(kind: str, bytes_per_array: int = 1 << 30, reps: int = 20) -> f
 
 
 # ---- host-only helpers (no GPU) ----------------------------------------------------------------
+def persist_plan(blocks: HostBlocks, nranks: int, gmax: int):
+    """Plan of the persistent iteration (bicg_persist_plan) for one rank's blocks -> dict, or None when the block does not
+    qualify. With nranks > 1 the offd block is renumbered to [rows + halo position] through bicg_halo_plan first."""
+    L = lib()
+    _usp = C.POINTER(C.c_ushort)
+    L.bicg_persist_plan.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.c_uint, _up, _up, _usp, _dp, _usp, _usp, _up, _up]
+    offd_p, keep = None, None
+    halo = 0
+    if nranks > 1:
+        halo, halo_cols, rc, ren = halo_plan(blocks, nranks)
+        nz = int(blocks.offd.ptr[blocks.offd.rows])
+        ren = np.ascontiguousarray(ren[:max(nz, 1)], dtype=np.uint32)
+        keep = (ren,)
+        o = CSRMatrix(blocks.offd.val, ren.ctypes.data_as(_up), blocks.offd.ptr, nz, blocks.offd.rows, blocks.n_loc + halo)
+        offd_p = C.byref(o)
+    summ = (C.c_uint * 8)()
+    if L.bicg_persist_plan(C.byref(blocks.diag), offd_p, gmax, summ, None, None, None, None, None, None, None) != 0:
+        return None
+    spw, nwg, win_slots, max_runs, max_entries, entries, nruns, _ = list(summ)
+    n = blocks.n_loc
+    nslices = (n + 63) // 64
+    pbase = np.zeros(nslices + 1, dtype=np.uint32)
+    pslot = np.zeros(max(entries, 1), dtype=np.uint16)
+    pval = np.zeros(max(entries, 1))
+    rlen = np.zeros(n, dtype=np.uint16)
+    rdiag = np.zeros(n, dtype=np.uint16)
+    wptr = np.zeros(nwg + 1, dtype=np.uint32)
+    runs = np.zeros(2 * max(nruns, 1), dtype=np.uint32)
+    rc2 = L.bicg_persist_plan(C.byref(blocks.diag), offd_p, gmax, summ, pbase.ctypes.data_as(_up), pslot.ctypes.data_as(_usp), _d(pval),
+                              rlen.ctypes.data_as(_usp), rdiag.ctypes.data_as(_usp), wptr.ctypes.data_as(_up), runs.ctypes.data_as(_up))
+    assert rc2 == 0
+    return dict(spw=spw, nwg=nwg, win_slots=win_slots, max_runs=max_runs, max_entries=max_entries, entries=entries, halo=halo,
+                pbase=pbase, pslot=pslot[:entries], pval=pval[:entries], rlen=rlen, rdiag=rdiag, wptr=wptr, runs=runs[:2 * nruns].reshape(-1, 2))
+
+
 def partition(n: int, nranks: int):
     cnt = np.zeros(nranks, dtype=np.int32)
     dsp = np.zeros(nranks, dtype=np.int32)

@@ -252,3 +252,61 @@ def test_window_plan_covers_every_column_once():
     B = synth.random_rows(20000, 40, seed=11)             # ~5000 scattered columns per group
     assert H.window_plan(B) is None
     assert H.window_plan(B, max_slots=65535) is not None
+
+
+@pytest.mark.parametrize("world", [1, 3])
+@pytest.mark.parametrize("kind", ["transport", "fem", "stencil"])
+def test_persist_plan_decodes_back_to_the_matrix(kind, world):
+    """bicg_persist_plan (the plan of the persistent iteration, host only): every workgroup owns spw
+    consecutive 64-row slices; entry k of row r sits at pbase[slice] + 64 k + lane, diag entries first, then the offd entries
+    in the [local rows | halo positions] numbering; its 16-bit slot, looked up in the workgroup's runs, is its column again;
+    runs are ordered, their slots consecutive, none straddles the local / halo boundary; padding holds zeros; the largest
+    window and matrix share are what the summary says."""
+    if kind == "transport":
+        A = synth.from_offsets(40013, (0, 1, -1, 117, -117, 118, -118, 3689, -3689, 3807, -3807), diag_base=14.0, seed=9)
+    elif kind == "fem":
+        A = synth.fem_like(n=117 * 117 * 2)
+    else:
+        A = synth.stencil7(23)
+    for rank in range(world):
+        diag, offd, counts, displs = synth.split_blocks(A, world, rank)
+        blk = H.HostBlocks(diag, offd if world > 1 else None, A.rows, counts, displs)
+        gmax = 60
+        P = H.persist_plan(blk, world, gmax)
+        assert P is not None
+        n = diag.rows
+        nslices = (n + 63) // 64
+        assert P["spw"] == -(-nslices // gmax) and P["nwg"] == -(-nslices // P["spw"]) <= gmax
+        halo = P["halo"]
+        if world > 1:
+            _, halo_cols, _, ren = H.halo_plan(blk, world)
+        runs, wptr = P["runs"].astype(np.int64), P["wptr"]
+        dptr, optr = diag.ptr.astype(np.int64), offd.ptr.astype(np.int64)
+        most_slots = most_entries = 0
+        for g in range(P["nwg"]):
+            rg = runs[wptr[g]:wptr[g + 1]]
+            first, slot0, length = rg[:, 0], rg[:, 1] >> 16, rg[:, 1] & 0xFFFF
+            assert np.all(np.diff(first) > 0) and np.array_equal(slot0, np.concatenate(([0], np.cumsum(length)[:-1])))
+            assert np.all((first + length <= n) | (first >= n)), "a run straddles the local / halo boundary"
+            assert np.all(first + length <= n + halo)
+            most_slots = max(most_slots, int(length.sum()))
+            s0, s1 = g * P["spw"], min(nslices, (g + 1) * P["spw"])
+            most_entries = max(most_entries, int(P["pbase"][s1] - P["pbase"][s0]))
+            col_of_slot = np.concatenate([np.arange(f, f + l) for f, l in zip(first, length)]) if len(rg) else np.zeros(0, dtype=np.int64)
+            for r in range(s0 * 64, min(n, s1 * 64)):
+                want_cols = diag.col[dptr[r]:dptr[r + 1]].astype(np.int64)
+                want_vals = diag.val[dptr[r]:dptr[r + 1]]
+                if world > 1:
+                    want_cols = np.concatenate((want_cols, ren[optr[r]:optr[r + 1]].astype(np.int64)))
+                    want_vals = np.concatenate((want_vals, offd.val[optr[r]:optr[r + 1]]))
+                assert P["rdiag"][r] == dptr[r + 1] - dptr[r] and P["rlen"][r] == len(want_cols)
+                e = int(P["pbase"][r // 64]) + 64 * np.arange(len(want_cols)) + r % 64
+                assert np.array_equal(col_of_slot[P["pslot"][e]], want_cols), (g, r)
+                assert np.array_equal(P["pval"][e], want_vals)
+        assert most_slots == P["win_slots"] and most_entries == P["max_entries"]
+        # padding: everything that is not an entry of some row is zero
+        total = sum(int(P["rlen"][r]) for r in range(n))
+        assert np.count_nonzero(P["pval"]) <= total and P["entries"] >= total
+    # a block too large for the workgroups on offer (more than 15 slices each) does not qualify
+    big = H.single_rank_blocks(synth.from_offsets(64 * 16 * 3 + 1, (0, 1, -1), diag_base=4.0, seed=1))
+    assert H.persist_plan(big, 1, 3) is None
