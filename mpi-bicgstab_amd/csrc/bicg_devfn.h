@@ -123,8 +123,13 @@ template <int CTRL, int ROW_MASK>
 __device__ __forceinline__ double dpp_add(double v)
 {
     int lo = __double2loint(v), hi = __double2hiint(v);
-    lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);     // rows outside ROW_MASK receive 0: v + 0.0
-    hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    if (ROW_MASK == 0xF) {       // every lane has a source: no previous value to keep, no register to clear first
+        lo = __builtin_amdgcn_mov_dpp(lo, CTRL, 0xF, 0xF, true);
+        hi = __builtin_amdgcn_mov_dpp(hi, CTRL, 0xF, 0xF, true);
+    } else {
+        lo = __builtin_amdgcn_update_dpp(0, lo, CTRL, ROW_MASK, 0xF, false);     // rows outside ROW_MASK receive 0: v + 0.0
+        hi = __builtin_amdgcn_update_dpp(0, hi, CTRL, ROW_MASK, 0xF, false);
+    }
     return v + __hiloint2double(hi, lo);
 }
 __device__ __forceinline__ double wave_sum(double v)

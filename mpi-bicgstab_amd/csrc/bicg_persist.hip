@@ -368,16 +368,84 @@ __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword 
     return true;
 }
 
+// ---- what the three persistent kernels share ------------------------------------------------------------------
+// Workgroup b runs on XCD b % 8 (observed placement, for speed only): give every XCD a contiguous range of rows, so that
+// most of what a workgroup needs was published by a workgroup of its own XCD
+__device__ __forceinline__ unsigned persist_wg(const PersistArgs &a)
+{
+    const unsigned b = blockIdx.x;
+    return (a.xcd_map && b < (a.nwg / 8u) * 8u) ? (b % 8u) * (a.nwg / 8u) + b / 8u : b;
+}
+
+// the helper workgroup's last act: the scalar block goes back to memory (the host reads k, (r,r), done from it)
+__device__ __forceinline__ void helper_finish(const PersistArgs &a, PersistLds &L)
+{
+    lds_barrier();
+    if (threadIdx.x == 0) {
+        if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
+        *a.S = L.priv;
+    }
+}
+
+// A row workgroup: spw row wavefronts (slices wg * spw ..., lane = row) + one communication wavefront. LDS: the window,
+// the workgroup's matrix entries (LDSMAT), its window runs, the values it publishes in the current phase.
+struct RowWg {
+    double *win, *zs;
+    const uint2 *runs;
+    unsigned nrw, nrt, nruns, nslots, ns0, ns1;
+    bool comm, live;
+    uint32_t row0, nmine, row, slen, mylen, mydiag;
+    const double *gval;
+    const unsigned short *gslot;
+    llword *tab0, *tab1, *img0, *img1;
+};
+template <bool LDSMAT, bool MULTI>
+__device__ __forceinline__ RowWg row_setup(const PersistArgs &a, unsigned wg, double *dyn)
+{
+    const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    RowWg R;
+    R.win = dyn;
+    double *mval = dyn + a.win_slots;
+    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
+    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
+    R.runs = runs;
+    R.zs = reinterpret_cast<double *>(runs + a.max_runs);          // [64 * spw] this workgroup's values of the vector being published
+    R.nrw = a.spw; R.nrt = 64u * a.spw;
+    R.comm = wave == R.nrw;
+    const uint32_t s0 = wg * a.spw, s1 = min(a.nslices, s0 + a.spw);
+    R.row0 = s0 * kSliceRows; R.nmine = min(a.nrows, s1 * kSliceRows) - R.row0;
+    const uint32_t slice = s0 + wave;
+    const bool have_slice = !R.comm && slice < a.nslices;
+    R.row = slice * kSliceRows + lane;
+    R.live = have_slice && R.row < a.nrows;
+    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1];
+    uint32_t sbase = 0;
+    R.slen = 0;
+    if (have_slice) { sbase = a.pbase[slice]; R.slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
+    R.mylen = R.live ? a.rlen[R.row] : 0u; R.mydiag = R.live ? a.rdiag[R.row] : 0u;
+    const unsigned r0w = a.win_ptr[wg];
+    R.nruns = a.win_ptr[wg + 1] - r0w;
+    for (unsigned i = tid; i < R.nruns; i += nt) runs[i] = a.win_runs[r0w + i];
+    R.nslots = 0;
+    if (R.nruns) { const uint2 last = a.win_runs[r0w + R.nruns - 1]; R.nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
+    R.gval = a.pval + sbase; R.gslot = a.pslot + sbase;
+    if (LDSMAT) {
+        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
+        R.gval = mval + (sbase - e0); R.gslot = mslot + (sbase - e0);
+    }
+    R.ns0 = MULTI ? a.snd_ptr[wg] : 0u; R.ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
+    R.tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2; R.tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    R.img0 = R.live ? a.llv[0] + 2 * (size_t)R.row : nullptr; R.img1 = R.live ? a.llv[1] + 2 * (size_t)R.row : nullptr;
+    return R;
+}
+
 template <bool LDSMAT, bool MULTI>
 __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_pipe_persist(PersistArgs a)
 {
     extern __shared__ double dyn[];
     __shared__ PersistLds L;
     const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
-    // Workgroup b runs on XCD b % 8 (observed placement, for speed only): give every XCD a contiguous range of rows, so that
-    // most of what a workgroup needs was published by a workgroup of its own XCD
-    unsigned wg = blockIdx.x;
-    if (a.xcd_map && wg < (a.nwg / 8u) * 8u) wg = (wg % 8u) * (a.nwg / 8u) + wg / 8u;
+    const unsigned wg = persist_wg(a);
     if (tid == 0) { L.priv = *a.S; L.fail = 0; }
     lds_barrier();
 
@@ -392,49 +460,24 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (!helper_group<5>(a, a.dtab[1], a.arow[1], sw, a.p2p.seq + 2u * (unsigned)it + 1u, PH_RECUR_END, L, nullptr)) break;
             if (a.dbg && tid == 0 && it < 32) a.dbg[it * 32 + 11] = wall_clock64();
         }
-        lds_barrier();
-        if (tid == 0) {
-            if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
-            *a.S = L.priv;
-        }
+        helper_finish(a, L);
         return;
     }
 
     // ---------------- row workgroup: spw row wavefronts (slices wg * spw ..., lane = row) + one communication wavefront
-    double *win = dyn;
-    double *mval = dyn + a.win_slots;
-    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
-    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
-    double *zs = reinterpret_cast<double *>(runs + a.max_runs);         // [64 * spw] this workgroup's values of the vector being published
-
-    const unsigned nrw = a.spw, nrt = 64u * a.spw;                      // row wavefronts / row threads
-    const bool comm = wave == nrw;
-    const uint32_t s0 = wg * a.spw, s1 = min(a.nslices, s0 + a.spw);
-    const uint32_t row0 = s0 * kSliceRows, nmine = min(a.nrows, s1 * kSliceRows) - row0;
-    const uint32_t slice = s0 + wave;
-    const bool have_slice = !comm && slice < a.nslices;
-    const uint32_t row = slice * kSliceRows + lane;
-    const bool live = have_slice && row < a.nrows;
-    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1];
-    uint32_t sbase = 0, slen = 0;
-    if (have_slice) { sbase = a.pbase[slice]; slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
-    const uint32_t mylen = live ? a.rlen[row] : 0u, mydiag = live ? a.rdiag[row] : 0u;
-    const unsigned r0w = a.win_ptr[wg], nruns = a.win_ptr[wg + 1] - r0w;
-    for (unsigned i = tid; i < nruns; i += nt) runs[i] = a.win_runs[r0w + i];
-    unsigned nslots = 0;
-    if (nruns) { const uint2 last = a.win_runs[r0w + nruns - 1]; nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
-    const double *gval = a.pval + sbase;
-    const unsigned short *gslot = a.pslot + sbase;
-    if (LDSMAT) {
-        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
-        gval = mval + (sbase - e0); gslot = mslot + (sbase - e0);
-    }
+    const RowWg R = row_setup<LDSMAT, MULTI>(a, wg, dyn);
+    double *const win = R.win, *const zs = R.zs;
+    const uint2 *const runs = R.runs;
+    const unsigned nrw = R.nrw, nrt = R.nrt, nruns = R.nruns, nslots = R.nslots, ns0 = R.ns0, ns1 = R.ns1;
+    const bool comm = R.comm, live = R.live;
+    const uint32_t row0 = R.row0, nmine = R.nmine, row = R.row, slen = R.slen, mylen = R.mylen, mydiag = R.mydiag;
+    const double *const gval = R.gval;
+    const unsigned short *const gslot = R.gslot;
     const Vecs &e = a.v;
     const uint32_t rr_ = live ? row : 0u;
     double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], z = e.z[rr_], w = e.w[rr_], v = e.v[rr_], t = e.t[rr_];
     const double h = e.rh[rr_];
     double y = 0.0;
-    const unsigned ns0 = MULTI ? a.snd_ptr[wg] : 0u, ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
     double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
     int done = L.priv.done;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -443,7 +486,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     const bool trace = a.dbg && wg == a.nwg / 2 && (tid == 0 || tid == nrt);
     const int tr0 = tid == 0 ? 0 : 32;
 #define STAMP(i) do { if (trace && it < 32) a.dbg[(it * 2 + (tr0 ? 1 : 0)) * 16 + (i)] = wall_clock64(); } while (0)
-    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    llword *const tab0 = R.tab0, *const tab1 = R.tab1;
     for (int it = 0; it < a.niter && !done; ++it) {
         const unsigned sz = a.seq0 + 2u * (unsigned)it + 1u, sw = sz + 1u;
         const unsigned hz = a.halo_seq0 + 2u * (unsigned)it + 1u, hw = hz + 1u;
@@ -522,8 +565,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     extern __shared__ double dyn[];
     __shared__ PersistLds L;
     const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
-    unsigned wg = blockIdx.x;
-    if (a.xcd_map && wg < (a.nwg / 8u) * 8u) wg = (wg % 8u) * (a.nwg / 8u) + wg / 8u;
+    const unsigned wg = persist_wg(a);
     if (tid == 0) { L.priv = *a.S; L.fail = 0; }
     lds_barrier();
 
@@ -535,53 +577,29 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (!helper_group<2>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_OMEGA, L, nullptr)) break;
             if (!helper_group<2>(a, a.dtab[0], a.arow[0], s1 + 2u, m1 + 2u, PH_PLAIN_END, L, nullptr)) break;
         }
-        lds_barrier();
-        if (tid == 0) {
-            if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
-            *a.S = L.priv;
-        }
+        helper_finish(a, L);
         return;
     }
 
-    double *win = dyn;
-    double *mval = dyn + a.win_slots;
-    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
-    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
-    double *zs = reinterpret_cast<double *>(runs + a.max_runs);
-    const unsigned nrw = a.spw, nrt = 64u * a.spw;
-    const bool comm = wave == nrw;
-    const uint32_t s0 = wg * a.spw, s1w = min(a.nslices, s0 + a.spw);
-    const uint32_t row0 = s0 * kSliceRows, nmine = min(a.nrows, s1w * kSliceRows) - row0;
-    const uint32_t slice = s0 + wave;
-    const bool have_slice = !comm && slice < a.nslices;
-    const uint32_t row = slice * kSliceRows + lane;
-    const bool live = have_slice && row < a.nrows;
-    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1w];
-    uint32_t sbase = 0, slen = 0;
-    if (have_slice) { sbase = a.pbase[slice]; slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
-    const uint32_t mylen = live ? a.rlen[row] : 0u, mydiag = live ? a.rdiag[row] : 0u;
-    const unsigned r0w = a.win_ptr[wg], nruns = a.win_ptr[wg + 1] - r0w;
-    for (unsigned i = tid; i < nruns; i += nt) runs[i] = a.win_runs[r0w + i];
-    unsigned nslots = 0;
-    if (nruns) { const uint2 last = a.win_runs[r0w + nruns - 1]; nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
-    const double *gval = a.pval + sbase;
-    const unsigned short *gslot = a.pslot + sbase;
-    if (LDSMAT) {
-        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
-        gval = mval + (sbase - e0); gslot = mslot + (sbase - e0);
-    }
+    const RowWg R = row_setup<LDSMAT, MULTI>(a, wg, dyn);
+    double *const win = R.win, *const zs = R.zs;
+    const uint2 *const runs = R.runs;
+    const unsigned nrw = R.nrw, nrt = R.nrt, nruns = R.nruns, nslots = R.nslots, ns0 = R.ns0, ns1 = R.ns1;
+    const bool comm = R.comm, live = R.live;
+    const uint32_t row0 = R.row0, nmine = R.nmine, row = R.row, slen = R.slen, mylen = R.mylen, mydiag = R.mydiag;
+    const double *const gval = R.gval;
+    const unsigned short *const gslot = R.gslot;
     const Vecs &e = a.v;
     const uint32_t rr_ = live ? row : 0u;
     double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], y = 0.0, q = 0.0;
     const double h = e.rh[rr_];
-    const unsigned ns0 = MULTI ? a.snd_ptr[wg] : 0u, ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
     double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
     int done = L.priv.done;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
-    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
-    llword *const img0 = live ? a.llv[0] + 2 * (size_t)row : nullptr, *const img1 = live ? a.llv[1] + 2 * (size_t)row : nullptr;
+    llword *const tab0 = R.tab0, *const tab1 = R.tab1;
+    llword *const img0 = R.img0, *const img1 = R.img1;
     for (int it = 0; it < a.niter && !done; ++it) {
         const unsigned g1 = a.seq0 + 3u * (unsigned)it + 1u, g2 = g1 + 1u, g3 = g1 + 2u;
         const unsigned hp = a.halo_seq0 + 2u * (unsigned)it + 1u, hq = hp + 1u;
@@ -656,8 +674,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     extern __shared__ double dyn[];
     __shared__ PersistLds L;
     const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
-    unsigned wg = blockIdx.x;
-    if (a.xcd_map && wg < (a.nwg / 8u) * 8u) wg = (wg % 8u) * (a.nwg / 8u) + wg / 8u;
+    const unsigned wg = persist_wg(a);
     if (tid == 0) { L.priv = *a.S; L.fail = 0; }
     lds_barrier();
 
@@ -668,53 +685,29 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
             if (!helper_group<2>(a, a.dtab[0], a.arow[0], s1, m1, PH_OMEGA, L, nullptr)) break;
             if (!helper_group<5>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_RECUR_END, L, nullptr)) break;
         }
-        lds_barrier();
-        if (tid == 0) {
-            if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
-            *a.S = L.priv;
-        }
+        helper_finish(a, L);
         return;
     }
 
-    double *win = dyn;
-    double *mval = dyn + a.win_slots;
-    unsigned short *mslot = reinterpret_cast<unsigned short *>(mval + a.mat_entries);
-    uint2 *runs = reinterpret_cast<uint2 *>(mslot + ((a.mat_entries + 3u) & ~3u));
-    double *zs = reinterpret_cast<double *>(runs + a.max_runs);
-    const unsigned nrw = a.spw, nrt = 64u * a.spw;
-    const bool comm = wave == nrw;
-    const uint32_t s0 = wg * a.spw, s1w = min(a.nslices, s0 + a.spw);
-    const uint32_t row0 = s0 * kSliceRows, nmine = min(a.nrows, s1w * kSliceRows) - row0;
-    const uint32_t slice = s0 + wave;
-    const bool have_slice = !comm && slice < a.nslices;
-    const uint32_t row = slice * kSliceRows + lane;
-    const bool live = have_slice && row < a.nrows;
-    const uint32_t e0 = a.pbase[s0], e1 = a.pbase[s1w];
-    uint32_t sbase = 0, slen = 0;
-    if (have_slice) { sbase = a.pbase[slice]; slen = (a.pbase[slice + 1] - sbase) / kSliceRows; }
-    const uint32_t mylen = live ? a.rlen[row] : 0u, mydiag = live ? a.rdiag[row] : 0u;
-    const unsigned r0w = a.win_ptr[wg], nruns = a.win_ptr[wg + 1] - r0w;
-    for (unsigned i = tid; i < nruns; i += nt) runs[i] = a.win_runs[r0w + i];
-    unsigned nslots = 0;
-    if (nruns) { const uint2 last = a.win_runs[r0w + nruns - 1]; nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
-    const double *gval = a.pval + sbase;
-    const unsigned short *gslot = a.pslot + sbase;
-    if (LDSMAT) {
-        for (uint32_t j = e0 + tid; j < e1; j += nt) { mval[j - e0] = a.pval[j]; mslot[j - e0] = a.pslot[j]; }
-        gval = mval + (sbase - e0); gslot = mslot + (sbase - e0);
-    }
+    const RowWg R = row_setup<LDSMAT, MULTI>(a, wg, dyn);
+    double *const win = R.win, *const zs = R.zs;
+    const uint2 *const runs = R.runs;
+    const unsigned nrw = R.nrw, nrt = R.nrt, nruns = R.nruns, nslots = R.nslots, ns0 = R.ns0, ns1 = R.ns1;
+    const bool comm = R.comm, live = R.live;
+    const uint32_t row0 = R.row0, nmine = R.nmine, row = R.row, slen = R.slen, mylen = R.mylen, mydiag = R.mydiag;
+    const double *const gval = R.gval;
+    const unsigned short *const gslot = R.gslot;
     const Vecs &e = a.v;
     const uint32_t rr_ = live ? row : 0u;
     double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], z = e.z[rr_], w = e.w[rr_];
     const double h = e.rh[rr_];
-    const unsigned ns0 = MULTI ? a.snd_ptr[wg] : 0u, ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
     double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
     int done = L.priv.done;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
-    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
-    llword *const img0 = live ? a.llv[0] + 2 * (size_t)row : nullptr, *const img1 = live ? a.llv[1] + 2 * (size_t)row : nullptr;
+    llword *const tab0 = R.tab0, *const tab1 = R.tab1;
+    llword *const img0 = R.img0, *const img1 = R.img1;
     for (int it = 0; it < a.niter && !done; ++it) {
         const unsigned g1 = a.seq0 + 2u * (unsigned)it + 1u, g2 = g1 + 1u;
         const unsigned hs = a.halo_seq0 + 2u * (unsigned)it + 1u, hr = hs + 1u;
