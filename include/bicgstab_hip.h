@@ -148,6 +148,8 @@ int bicg_comm_enable_p2p(void);
 /* 0: not active; 1: active, mailboxes in ordinary device memory; 2: active, uncached device memory */
 int bicg_comm_p2p_active(void);
 void bicg_comm_finalize(void);
+/* 1 when librccl and every entry point the RCCL transport uses resolve (dies with a message otherwise); no device call */
+int bicg_comm_rccl_loadable(void);
 /* one-rank RCCL round trip (library load, communicator, all-reduce); 0 = ok. Needs a GPU. */
 int bicg_comm_selftest_rccl(int device);
 int bicg_comm_rank(void);

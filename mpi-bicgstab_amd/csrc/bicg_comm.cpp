@@ -125,10 +125,13 @@ static RcclApi &rccl()
 {
     static RcclApi api;
     if (api.handle) return api;
-    // librccl.so.1 resolves to an already loaded RCCL (e.g. the one PyTorch ships) by SONAME
+    // librccl.so.1 resolves to an already loaded RCCL (e.g. the one PyTorch ships) by SONAME.
+    // RTLD_LOCAL: RCCL pulls in /opt/rocm's librocm_smi64; made global, a PyTorch imported LATER binds the statics of
+    // its own bundled librocm_smi64 to that copy and both destroy them at exit ("double free or corruption", exit 134
+    // after every test had passed)
     const char *names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
     for (const char *nm : names) {
-        api.handle = dlopen(nm, RTLD_NOW | RTLD_GLOBAL);
+        api.handle = dlopen(nm, RTLD_NOW | RTLD_LOCAL);
         if (api.handle) break;
     }
     if (!api.handle) die("dlopen(librccl)", dlerror());
@@ -155,6 +158,8 @@ static RcclApi &rccl()
         ncclResult_t r_ = (call);                                            \
         if (r_ != ncclSuccess) die(#call, rccl().GetErrorString(r_));        \
     } while (0)
+
+int rccl_loadable() { return rccl().handle != nullptr; }
 
 int rccl_unique_id(void *out)
 {
@@ -272,6 +277,7 @@ using namespace bicg;
 extern "C" {
 
 int bicg_comm_unique_id(void *id_out) { return rccl_unique_id(id_out); }
+int bicg_comm_rccl_loadable(void) { return rccl_loadable(); }
 
 int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device)
 {

@@ -88,6 +88,7 @@ Comm *make_single(int device);
 Comm *make_host(int rank, int nranks, bicg_allreduce_fn ar, bicg_alltoallv_fn a2a, void *user, int device);
 Comm *make_rccl(int rank, int nranks, const void *id, int device);
 int   rccl_unique_id(void *out);
+int   rccl_loadable();
 int   pick_device(int rank, int requested);
 
 [[noreturn]] void die(const char *what, const char *detail);

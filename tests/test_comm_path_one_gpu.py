@@ -184,3 +184,20 @@ def test_fused_pipelined_iteration_is_bit_reproducible(problem, monkeypatch):
     for m in ("pipe_bicgstab", "pipe_bicgstab_rr"):
         for other in (a2, a3):
             assert other[m][0] == a1[m][0] and np.array_equal(other[m][1], a1[m][1]) and np.array_equal(other[m][2], a1[m][2]), m
+
+
+def test_process_with_rccl_and_torch_exits_cleanly():
+    """A real one-rank RCCL round trip through the library, THEN `import torch`, then a normal exit: the process
+    status must be 0 (see tests/test_host_logic.py::test_rccl_loaded_by_the_library_then_torch_exits_cleanly -- with
+    librccl's dependencies in the global symbol scope, the pytest run over this module and any torch-importing one
+    ended in exit status 134 with every test green)."""
+    import os
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mpi_bicgstab_amd import hipsolver as H\n"
+            "assert H.lib().bicg_comm_selftest_rccl(0) == 0\n"
+            "import torch\nassert torch.cuda.is_available()\nprint('rccl then torch')\n" % root)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "rccl then torch" in out.stdout, (out.returncode, out.stderr[-400:])

@@ -310,3 +310,19 @@ def test_persist_plan_decodes_back_to_the_matrix(kind, world):
     # a block too large for the workgroups on offer (more than 15 slices each) does not qualify
     big = H.single_rank_blocks(synth.from_offsets(64 * 16 * 3 + 1, (0, 1, -1), diag_base=4.0, seed=1))
     assert H.persist_plan(big, 1, 3) is None
+
+
+def test_rccl_loaded_by_the_library_then_torch_exits_cleanly():
+    """The RCCL transport dlopen()s librccl, which brings /opt/rocm's librocm_smi64 with it; PyTorch bundles its own
+    copy. With the first made RTLD_GLOBAL a later `import torch` bound the second copy's statics to it and the process
+    died at exit with "double free or corruption" -- exit status 134 from a test run in which everything had passed
+    (tests/test_comm_path_one_gpu.py followed by any module that imports torch). bicg_comm_rccl_loadable resolves the
+    entry points without a device call, so the load order can be exercised here."""
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from mpi_bicgstab_amd import hipsolver as H\n"
+            "assert H.lib().bicg_comm_rccl_loadable() == 1\n"
+            "import torch\nprint('loaded both')\n" % ROOT)
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0 and "loaded both" in out.stdout, (out.returncode, out.stderr[-400:])
