@@ -6,8 +6,10 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r03
 mkdir -p $OUT
 cd $R
+if [ -z "$PROFILES_ONLY" ]; then
 python bench.py --steps 20 --warmup 5 > $OUT/bench_n1_driver_flags.json 2> $OUT/bench_n1_driver_flags.err
 python bench.py --no-cpu-baseline > $OUT/bench_n1.json 2> $OUT/bench_n1.err
+fi
 BICG_STREAM_VERBOSE=1 python -c "
 import sys; sys.path.insert(0, '.')
 from mpi_bicgstab_amd import hipsolver as H
