@@ -170,7 +170,11 @@ typedef struct {
     int    quiet;        /* 1: no stdout lines */
     int    krr, nrr;     /* residual replacement period / count (src/solver.c:433) */
     int    record_trace; /* 1: keep per-iteration alpha/omega/beta/(r,r) on the device */
-    int    time_kernels; /* 1: give every SpMV kernel its own start/stop HIP events (roofline measurement) */
+    int    time_kernels; /* bit 0: give every SpMV kernel its own start/stop HIP events (roofline measurement);
+                            bit 1: section timing -- the reference's MEASURE_SECTION_TIME (src/shifted_switching_solver.c:9,
+                            src/shifted_solver.c:77-81, 230-247) on the device clock: an event wherever the kind of work changes
+                            (product / element-wise / shifted systems / reduction hand-over), read with bicg_section_times.
+                            Both keep the multi-launch forms (no persistent launch, no graph replay). */
     double rr_drift;     /* pipelined solvers, additive: > 0 enables ADAPTIVE residual
                             replacement -- at every host check the true residual b - A x is computed and, when
                             ||(b - A x) - r|| > rr_drift * ||r||, the next iteration is a replacement step
@@ -282,6 +286,16 @@ int bicg_stream_bench(int kind, unsigned long long bytes_per_array, int reps, do
 /* 1 after a peer-to-peer wait of this context timed out (only reachable with BICG_P2P_SOFT_FAIL=1; the
  * default is to print the error and exit like any other HIP/RCCL failure). The solve in progress stops. */
 int bicg_comm_failed(bicg_ctx *ctx);
+/* Section times of the last solve run with bicg_options.time_kernels & 2 (BICG_SECTION_TIME=1 in the drop-in path), in
+ * milliseconds on the compute stream: ms[0] element-wise kernels of the seed system (with their fused dots), ms[1] products
+ * A x (halo exchange and joins of overlapped all-reduces included), ms[2] the passes over the shifted systems (the shifted
+ * solvers print "Seed time" / "Shift time" like the reference: shift = ms[2], seed = total - shift,
+ * src/shifted_solver.c:230-247), ms[3] reduction hand-overs that are launches of their own (host / RCCL all-reduce + apply,
+ * peer-to-peer collect); with one rank the scalars are applied inside the producing kernels and ms[3] is 0.
+ * *iterations = iterations covered, *marks = events used (negative: the pool of 65536 ran out and timing stopped there).
+ * Returns 0, or 2 when the last solve was not timed. */
+int bicg_section_times(bicg_ctx *c, double ms[4], int *iterations, int *marks);
+
 /* plan facts: local rows, diag nnz, offd nnz, halo length, workgroups per SpMV, halo-touching
  * workgroups, rows on the sliced-ELL path, sliced-ELL padding entries */
 int bicg_plan_info(bicg_ctx *ctx, unsigned int out[8]);

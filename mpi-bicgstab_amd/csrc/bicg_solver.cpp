@@ -196,6 +196,17 @@ struct bicg_ctx {
     std::vector<hipEvent_t> tev;
     int tev_used = 0, spmv_calls_timed = 0;
 
+    // section timing (bicg_options.time_kernels & 2): an event on the compute stream wherever the kind of work
+    // changes; the time between two marks belongs to the section the first one opened. The counterpart of the
+    // reference's MEASURE_SECTION_TIME (src/shifted_switching_solver.c:77-81, 132-154, 230-247: MPI_Wtime around the
+    // shift loops, seed = total - shift), on the device's clock instead of the host's.
+    bool time_sections = false, sec_exhausted = false;
+    std::vector<hipEvent_t> sec_ev;
+    std::vector<unsigned char> sec_lab;
+    int sec_used = 0, sec_cur = 255;
+    double sec_ms[4] = {0, 0, 0, 0};
+    int sec_iters = 0;
+
     // BICG_FORCE_COMM=1 (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
     // apply kernels, two streams) even with one rank, so that it can be exercised on a one-GPU box
     bool force_comm = false;
@@ -258,6 +269,54 @@ namespace {
 // (the four solvers of reference src/solver.c; struct Finish in bicg_device.h). A group is PRODUCED by
 // one or two kernels (per-wavefront partials), then CONSUMED by the kernel that needs the scalars,
 // by an SpMV that only has to deposit the sums, or by the stand-alone finisher.
+// ---------------------------------------------------------------- section timing
+enum { SEC_VEC = 0, SEC_SPMV = 1, SEC_SHIFT = 2, SEC_REDUCE = 3, SEC_COUNT = 4, SEC_STOP = 255 };
+constexpr int kMaxSectionMarks = 1 << 16;
+
+void sec_mark(bicg_ctx *c, int label)
+{
+    if (!c->time_sections || label == c->sec_cur) return;
+    if (c->sec_used + 1 >= (int)c->sec_ev.size()) {      // pool used up: close the open section, stop marking
+        if (c->sec_cur != SEC_STOP && c->sec_used < (int)c->sec_ev.size()) {
+            BICG_HIP(hipEventRecord(c->sec_ev[c->sec_used], c->sc));
+            c->sec_lab[c->sec_used++] = SEC_STOP;
+        }
+        c->sec_cur = SEC_STOP; c->time_sections = false; c->sec_exhausted = true;
+        return;
+    }
+    BICG_HIP(hipEventRecord(c->sec_ev[c->sec_used], c->sc));
+    c->sec_lab[c->sec_used++] = (unsigned char)label;
+    c->sec_cur = label;
+}
+struct Section {       // the enclosed launches belong to `label`; afterwards the enclosing section continues
+    bicg_ctx *c; int prev;
+    Section(bicg_ctx *ctx, int label) : c(ctx), prev(ctx->sec_cur) { if (prev != SEC_STOP) sec_mark(c, label); }
+    ~Section() { if (prev != SEC_STOP) sec_mark(c, prev); }
+};
+void sec_begin(bicg_ctx *c, bool on)
+{
+    c->time_sections = on; c->sec_exhausted = false;
+    c->sec_used = 0; c->sec_cur = SEC_STOP; c->sec_iters = 0;
+    for (double &m : c->sec_ms) m = 0.0;
+    if (on && c->sec_ev.empty()) {
+        c->sec_ev.resize(kMaxSectionMarks);
+        c->sec_lab.resize(kMaxSectionMarks);
+        for (auto &e : c->sec_ev) BICG_HIP(hipEventCreate(&e));
+    }
+}
+// after the stream has been synchronised: sum the spans (sections marked so far), covering `iters` iterations
+void sec_collect(bicg_ctx *c, int iters)
+{
+    if (c->sec_used == 0) return;
+    for (double &m : c->sec_ms) m = 0.0;
+    for (int i = 0; i + 1 < c->sec_used; ++i) {
+        if (c->sec_lab[i] == SEC_STOP) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->sec_ev[i], c->sec_ev[i + 1]) == hipSuccess) c->sec_ms[c->sec_lab[i]] += ms;
+    }
+    c->sec_iters = iters;
+}
+
 Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg = 0)
 {
     if (c->grp.active) die("internal", "a dot group was produced while the previous one was still open");
@@ -358,6 +417,7 @@ void group_now(bicg_ctx *c, int n, int phase)
     if (c->wave_mode) {
         // single rank / peer-to-peer: the group stays open for the kernel that consumes it
         if (!hosted(c)) { c->grp.deferred = false; return; }
+        Section sec(c, SEC_REDUCE);
         const bicg_ctx::Group g = c->grp;
         grp_close(c, true);                                   // this rank's sums -> Scal::red
         c->comm->allreduce_sum(c->S->red + g.off, g.n, c->sc);
@@ -365,6 +425,7 @@ void group_now(bicg_ctx *c, int n, int phase)
         return;
     }
     if (c->single()) return;   // applied in-kernel by the finishing workgroup
+    Section sec(c, SEC_REDUCE);
     if (c->p2p) {              // the producers stored their sums into every rank's mailbox already
         if (c->open_inline) {  // ... and the last of them collects and applies (Reduce::p2p.n_collect)
             c->open_inline = false;
@@ -414,6 +475,7 @@ void group_defer(bicg_ctx *c, int n, int phase)
 void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{}, int epi = 0,
           Scal *S = nullptr, const FusedWindow *fw = nullptr)
 {
+    Section sec(c, SEC_SPMV);      // halo exchange and the joins of deferred all-reduces included
     SpmvArgs a;
     a.fw = fw ? *fw : FusedWindow{};
     a.fin = fin;
@@ -670,6 +732,7 @@ void group_flush(bicg_ctx *c)
 {
     if (c->wave_mode && !hosted(c)) return;      // consumed by the next element-wise kernel or by fetch_scal
     if (!c->pend) return;
+    Section sec(c, SEC_REDUCE);
     if (c->p2p) {
         c->pend = false;
         launch_apply_p2p(c->S, c->pend_phase, c->pend_n, c->p2p->red_desc(c->pend_seq), c->p2p->timeout_ticks, c->sc);
@@ -933,7 +996,8 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     // before writing them (src/solver.c:217-222, 352-360) and keeps halo tails finite
     const size_t st = c->stride;
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
-    c->time_kernels = o.time_kernels != 0;
+    c->time_kernels = (o.time_kernels & 1) != 0;
+    sec_begin(c, (o.time_kernels & 2) != 0);
     c->tev_used = 0; c->spmv_calls_timed = 0;
     if (c->time_kernels && c->tev.empty()) {
         c->tev.resize(kMaxTimed);
@@ -967,7 +1031,8 @@ bool graph_iteration(bicg_ctx *c, Driver &d)
     // consumer-side finish alternates between two scalar blocks: launch arguments change from one
     // iteration to the next unless the host enqueues the collectives itself
     if (c->wave_mode && !hosted(c)) return false;
-    if (!want || c->p2p || m == BICG_PIPE_BICGSTAB_RR || c->opt.rr_drift > 0.0 || c->time_kernels || !c->comm->stream_ordered()) return false;
+    if (!want || c->p2p || m == BICG_PIPE_BICGSTAB_RR || c->opt.rr_drift > 0.0 || c->time_kernels || c->time_sections || c->sec_exhausted ||
+        !c->comm->stream_ordered()) return false;
     if (c->graph_exec[m] && c->graph_nt[m] != c->sell_nt) {     // captured with the other streaming policy
         (void)hipGraphExecDestroy(c->graph_exec[m]);
         c->graph_exec[m] = nullptr;
@@ -1008,9 +1073,11 @@ int run_iterate(bicg_ctx *c, int nsteps)
             force = true;
             c->adaptive_rr++;
         }
-        const bool persist = c->persist_on && !c->time_kernels &&
+        // (section marks are host-side events between launches: the multi-launch forms are what they can time)
+        const bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
                              ((c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0) ||
                               ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain));
+        sec_mark(c, SEC_VEC);
         if (persist) persist_chunk(c, chunk);         // one launch for the whole chunk (bicg_persist.hip)
         for (int j = 0; j < chunk && !persist; ++j) {
             // the last iteration before the caller (or the drift check) reads x / r leaves them as the reference would
@@ -1019,6 +1086,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
             if (!graph_iteration(c, d)) d.iterate(c->it + j, false, last);
         }
         c->it += chunk;
+        sec_mark(c, SEC_STOP);
         fetch_scal(c);
         if (talk && o.out_iter > 0) {   // reference src/solver.c:122-126
             const int k = c->hS->k;
@@ -1052,6 +1120,7 @@ int run_end(bicg_ctx *c, bicg_result *res)
         }
         spmv_n = c->spmv_calls_timed;
     }
+    sec_collect(c, k);
     const double total = c->t_init + c->t_iter;
     if (res) {
         res->iterations = k;
@@ -1095,6 +1164,16 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
 // kernel for the stop flags. A seed switch needs new vector pointers and a rescaled r from the
 // host, so the device raises done/paused, the launches already queued fall through, and the host
 // resumes with the new seed (switches are rare: at most one per shift).
+// "Seed time" / "Shift time" as the reference prints them under MEASURE_SECTION_TIME (src/shifted_solver.c:244-247,
+// src/shifted_switching_solver.c:563-...): shift = the passes over the shifted systems, seed = total - shift
+void print_sections(const bicg_ctx *c, double total_seconds)
+{
+    if (c->sec_used == 0) return;
+    const double shift = c->sec_ms[SEC_SHIFT] * 1.0e-3;
+    printf("Seed time    : %e [sec.]\n", total_seconds - shift);
+    printf("Shift time   : %e [sec.]\n", shift);
+}
+
 int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
                   const bicg_options *opt_in, bicg_result *res)
 {
@@ -1156,6 +1235,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = false;
+    sec_begin(c, (o.time_kernels & 2) != 0);
     for (int j = 0; j < nsig; ++j)          // p[sigma] <- b for EVERY shift, src/shifted_switching_solver.c:348
         BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
     {   // streaming policy: matrix + 7 work vectors + the two sets
@@ -1193,6 +1273,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
         double *p_seed = c->p_set + (size_t)seed * st, *x_seed = c->x_set + (size_t)seed * st;
         c->cur_shift = sigma[seed];
         const int chunk = std::min(o.check_every, o.max_iter - c->hS->k);
+        sec_mark(c, SEC_VEC);
         for (int j = 0; j < chunk; ++j) {
             spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SW_ALPHA, true, 1));           // s = (A + sigma I) p[seed], (r#,s)
             group_now(c, 1, PH_SW_ALPHA);
@@ -1201,15 +1282,20 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
             group_now(c, 2, PH_SW_OMEGA);
             launch_sw_seed(v, x_seed, p_seed, c->S, c->red(0, PH_SW_END, true, 2), c->sc);   // x[seed], r, (r,r), (r#,r)
             group_now(c, 2, PH_SW_END);
-            launch_sw_shifts(v, qc, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->sc);
+            {
+                Section sec(c, SEC_SHIFT);       // the shift loops of src/shifted_switching_solver.c:425-480
+                launch_sw_shifts(v, qc, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->sc);
+            }
             launch_apply(c->S, PH_SW_STOP, c->sc);                                    // identical on every rank: no sums
         }
+        sec_mark(c, SEC_STOP);
     }
     c->cur_has_shift = false; c->cur_shift = 0.0;
     const double t1 = now_sec();
 
     const int its = c->hS->k;
     c->last_iters = its;
+    sec_collect(c, its);
     for (int j = 0; j < nsig; ++j)
         BICG_HIP(hipMemcpy(x_set_host + (size_t)j * n, c->x_set + (size_t)j * st, sizeof(double) * n, hipMemcpyDeviceToHost));
     BICG_HIP(hipMemcpy(r_host, c->v.r, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -1225,6 +1311,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
         if (mode == SH_SWITCH) printf("Total iter   : %d\n", k_ref - 1);
         printf("Total time   : %e [sec.] \n", t1 - t0);
         printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / (k_ref > 0 ? k_ref : 1));
+        print_sections(c, t1 - t0);
         fflush(stdout);
     }
     return k_ref;
@@ -1283,6 +1370,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = false;
+    sec_begin(c, (o.time_kernels & 2) != 0);
     if (mode == SH_XI)                      // p[sigma] <- b for every shift, src/shifted_solver.c:72
         for (int j = 0; j < nsig; ++j)
             BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
@@ -1311,12 +1399,16 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     int it = 0;
     while (!c->hS->done && it < o.max_iter) {
         const int chunk = std::min(o.check_every, o.max_iter - it);
+        sec_mark(c, SEC_VEC);
         for (int j = 0; j < chunk; ++j) {
             if (mode == SH_PIPE) {
                 launch_shift_pipe1(v, p_seed, c->S, c->red(0, PH_SHP_OMEGA), c->sc);    // p, s, z, r_old, q, y, 2 dots
                 group_defer(c, 2, PH_SHP_OMEGA);
                 spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));                      // v = (A + sigma I) z
-                launch_shift_pipe2(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SHP_END), c->sc);
+                {   // the shift loops of src/shifted_solver.c:850-905, with the seed system's x / r / w and the five dots in the same pass
+                    Section sec(c, SEC_SHIFT);
+                    launch_shift_pipe2(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SHP_END), c->sc);
+                }
                 group_defer(c, 5, PH_SHP_END);
                 spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));                      // t = (A + sigma I) w
                 group_flush(c);
@@ -1328,11 +1420,15 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
             // lop: (q,y), (q,q) ; shifted_bicgstab: (q,y), (y,y)
             spmv(c, v.r, v.y, mode == SH_XI ? 2 : 3, v.r, c->red(0, PH_SH_OMEGA, true, 2));
             group_now(c, 2, PH_SH_OMEGA);
-            launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END, true, 2), c->sc);
+            {   // the shift loops of src/shifted_solver.c:132-154 and 180-208, with the seed system's x / r and two dots in the same pass
+                Section sec(c, SEC_SHIFT);
+                launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END, true, 2), c->sc);
+            }
             group_now(c, 2, PH_SH_END);
             launch_shift_pseed(v, p_seed, c->S, c->sc);                     // p[seed] = r + beta (p[seed] - omega s)
         }
         it += chunk;
+        sec_mark(c, SEC_STOP);
         fetch_scal(c);
     }
     c->cur_has_shift = false; c->cur_shift = 0.0;
@@ -1340,6 +1436,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
 
     const int k = c->hS->k;
     c->last_iters = k;
+    sec_collect(c, k);
     for (int j = 0; j < nsig; ++j)
         BICG_HIP(hipMemcpy(x_set_host + (size_t)j * n, c->x_set + (size_t)j * st, sizeof(double) * n, hipMemcpyDeviceToHost));
     BICG_HIP(hipMemcpy(r_host, c->v.r, sizeof(double) * n, hipMemcpyDeviceToHost));
@@ -1353,6 +1450,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
         printf("Final r      : %e\n", sqrt(c->hS->dot_r / c->hS->dot_zero));
         printf("Total time   : %e [sec.] \n", t1 - t0);
         printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / k);
+        print_sections(c, t1 - t0);
         fflush(stdout);
     }
     return k;
@@ -1375,6 +1473,7 @@ void env_options(bicg_options *o)
     if (const char *s = getenv("BICG_CHECK_EVERY")) o->check_every = atoi(s);
     if (const char *s = getenv("BICG_QUIET")) o->quiet = atoi(s);
     if (const char *s = getenv("BICG_RR_DRIFT")) o->rr_drift = atof(s);
+    if (const char *s = getenv("BICG_SECTION_TIME")) o->time_kernels = atoi(s) ? 2 : 0;     // the reference's MEASURE_SECTION_TIME
 }
 
 // ---------------------------------------------------------------- matrix residency across drop-in calls
@@ -2339,6 +2438,7 @@ void bicg_destroy(bicg_ctx *c)
             if (e) (void)hipEventDestroy(e);      // a context that failed early in bicg_create has none
     }
     for (auto &e : c->tev) (void)hipEventDestroy(e);
+    for (auto &e : c->sec_ev) (void)hipEventDestroy(e);
     for (auto &ge : c->graph_exec) if (ge) (void)hipGraphExecDestroy(ge);
     if (c->sc) (void)hipStreamDestroy(c->sc);
     if (c->sm) (void)hipStreamDestroy(c->sm);
@@ -2540,6 +2640,15 @@ int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
 }
 
 int bicg_comm_failed(bicg_ctx *c) { return c->comm_failed ? 1 : 0; }
+
+int bicg_section_times(bicg_ctx *c, double ms[4], int *iterations, int *marks)
+{
+    if (!c) return 1;
+    for (int i = 0; i < SEC_COUNT; ++i) ms[i] = c->sec_ms[i];
+    if (iterations) *iterations = c->sec_iters;
+    if (marks) *marks = c->sec_exhausted ? -c->sec_used : c->sec_used;
+    return c->sec_used > 0 ? 0 : 2;
+}
 
 int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
 {

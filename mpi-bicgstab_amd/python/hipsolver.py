@@ -58,7 +58,7 @@ EXPORTS = [
     "bicg_partition_nnz", "bicg_mtx_load_block_part", "bicg_mtx_cache_save", "bicg_mtx_cache_load",
     "bicg_coo_to_blocks_device", "bicg_mtx_set_block_builder",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
-    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_comm_rank", "bicg_comm_size",
+    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan",
@@ -93,6 +93,7 @@ def lib():
         L.bicg_dot.restype = C.c_double
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
+        L.bicg_section_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bicg_comm_failed.argtypes = [C.c_void_p]
         L.bicg_dropin_context.restype = C.c_void_p
         L.bicg_dropin_context.argtypes = [C.POINTER(CSRMatrix), C.POINTER(CSRMatrix), C.POINTER(InfoMatrix)]
@@ -289,6 +290,15 @@ class Context:
                                      C.byref(res))
         return dict(k=k, x=x, r=r, dot_r=res.dot_r, dot_zero=res.dot_zero, result=res,
                     iterations=res.iterations, switches=res.adaptive_replacements)
+
+    def section_times(self):
+        """Section times of the last solve run with time_kernels=2 (the reference's MEASURE_SECTION_TIME, on the device
+        clock): dict(vec_ms, spmv_ms, shift_ms, reduce_ms, iterations, marks) or None when that solve was not timed."""
+        ms = (C.c_double * 4)()
+        it, marks = C.c_int(0), C.c_int(0)
+        if lib().bicg_section_times(self.h, ms, C.byref(it), C.byref(marks)) != 0:
+            return None
+        return dict(vec_ms=ms[0], spmv_ms=ms[1], shift_ms=ms[2], reduce_ms=ms[3], iterations=it.value, marks=marks.value)
 
     def shifted_residuals(self, x_set, b, sigma):
         """|| (A + sigma_j I) x_j - b || / || b || for every shift (reference src/test_shifted.c:129-154)"""

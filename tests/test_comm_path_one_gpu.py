@@ -201,3 +201,26 @@ def test_process_with_rccl_and_torch_exits_cleanly():
             "import torch\nassert torch.cuda.is_available()\nprint('rccl then torch')\n" % root)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "rccl then torch" in out.stdout, (out.returncode, out.stderr[-400:])
+
+
+@pytest.mark.parametrize("overlap", [0, 1])
+def test_section_times_on_the_multi_rank_path(problem, overlap, monkeypatch):
+    """Section timing (bicg_options.time_kernels & 2) on the N > 1 code path: the all-reduce + apply hand-overs are
+    launches of their own there and must show up as the reduction section (the reference's `ared` column,
+    src/shifted_switching_solver.c:884-892); the marks must not change a bit of the result."""
+    A, b, ref = problem
+    H.lib().bicg_comm_init_single(0)
+    for k, v in dict(BICG_FORCE_COMM=1, BICG_GRAPH=0, BICG_OVERLAP=overlap, BICG_PERSIST=0).items():
+        monkeypatch.setenv(k, str(v))
+    ctx = H.Context(H.single_rank_blocks(A))
+    for m, tol in METHODS:
+        r = ctx.solve(m, b, tol=tol, krr=10, nrr=3, check_every=5, time_kernels=2)
+        assert r["k"] == ref[m][0] and np.array_equal(r["x"], ref[m][1]) and np.array_equal(r["r"], ref[m][2]), m
+        t = ctx.section_times()
+        assert t is not None and t["iterations"] == r["k"], (m, t)
+        assert t["spmv_ms"] > 0.0 and t["vec_ms"] > 0.0 and t["shift_ms"] == 0.0, (m, t)
+        # two-stream mode hides the pipelined solvers' all-reduces behind the next product (src/solver.c:363-367): they are
+        # started and joined inside spmv() and counted there
+        if not (overlap and m.startswith("pipe")):
+            assert t["reduce_ms"] > 0.0, (m, t)
+    ctx.close()

@@ -331,3 +331,53 @@ def test_window_fused_plain_iteration_is_bit_identical(monkeypatch):
     for key in ("alpha", "omega", "beta", "dotr"):
         assert np.array_equal(out["0"][3][key], out["1"][3][key]), key
     assert np.abs(out["1"][1] - 1.0).max() <= 1e-8
+
+
+def test_section_times_account_for_the_iteration(capfd):
+    """bicg_options.time_kernels & 2 -- the reference's MEASURE_SECTION_TIME (src/shifted_solver.c:77-81, 132-154, 230-247;
+    src/shifted_switching_solver.c:9) on the device clock. Timing must not change the arithmetic (same kernels: the
+    multi-launch forms), the sections must add up to about the device time of the loop, products and element-wise
+    kernels must both be seen, and the shifted solvers must attribute time to the passes over the shifted systems."""
+    H.lib().bicg_comm_init_single(0)
+    import os
+    A = synth.stencil7(40, synth.LAPLACE_WEIGHTS)
+    saved = os.environ.get("BICG_PERSIST")
+    os.environ["BICG_PERSIST"] = "0"          # (read by bicg_create) the untimed run takes the same multi-launch form
+    try:
+        ctx = H.Context(H.single_rank_blocks(A))
+        b = ctx.spmv(np.ones(A.rows))
+        for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
+            plain = ctx.solve(method, b, tol=0.0, max_iter=48, check_every=16)
+            assert ctx.section_times() is None
+            timed = ctx.solve(method, b, tol=0.0, max_iter=48, check_every=16, time_kernels=2)
+            assert np.array_equal(plain["x"], timed["x"]) and np.array_equal(plain["r"], timed["r"]), method
+            t = ctx.section_times()
+            assert t is not None and t["iterations"] == 48 and t["marks"] > 3 * 48, (method, t)
+            assert t["spmv_ms"] > 0.0 and t["vec_ms"] > 0.0 and t["shift_ms"] == 0.0 and t["reduce_ms"] == 0.0, (method, t)
+            total = t["spmv_ms"] + t["vec_ms"]
+            assert total <= 1.05e3 * timed["result"].iter_seconds, (method, t, timed["result"].iter_seconds)
+    finally:
+        if saved is None:
+            os.environ.pop("BICG_PERSIST", None)
+        else:
+            os.environ["BICG_PERSIST"] = saved
+    sigma = (np.arange(8) + 1.0) * 0.01
+    for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab", "shifted_lopbicg_switching"):
+        plain = ctx.solve_shifted(b, sigma, 3, tol=0.0, max_iter=32, check_every=16, which=which)
+        timed = ctx.solve_shifted(b, sigma, 3, tol=0.0, max_iter=32, check_every=16, which=which, time_kernels=2)
+        assert np.array_equal(plain["x"], timed["x"]), which
+        t = ctx.section_times()
+        assert t is not None and t["shift_ms"] > 0.0 and t["spmv_ms"] > 0.0, (which, t)
+    # the two lines the reference prints under MEASURE_SECTION_TIME (src/shifted_solver.c:244-247): seed = total - shift
+    capfd.readouterr()
+    ctx.solve_shifted(b, sigma, 3, tol=0.0, max_iter=32, check_every=16, which="shifted_lopbicgstab", time_kernels=2, quiet=0)
+    H.lib().bicg_sync(ctx.h)
+    import re
+    out = capfd.readouterr().out
+    total = float(re.search(r"Total time   : (\S+) \[sec.\]", out).group(1))
+    seed_t = float(re.search(r"Seed time    : (\S+) \[sec.\]", out).group(1))
+    shift_t = float(re.search(r"Shift time   : (\S+) \[sec.\]", out).group(1))
+    assert shift_t > 0.0 and seed_t > 0.0 and abs(seed_t + shift_t - total) <= 1e-6 * total + 1e-9, out
+    ctx.solve_shifted(b, sigma, 3, tol=0.0, max_iter=32, check_every=16, which="shifted_lopbicgstab", quiet=0)
+    assert "Seed time" not in capfd.readouterr().out
+    ctx.close()
