@@ -308,7 +308,11 @@ enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FL
        BICG_FLAG_ROWSPLIT = 256   /* long rows: a row is spread over 8..64 lanes (k_spmv_rows); row sums then agree with the
                                      reference's to 1e-13 x sum |a_ij x_j| instead of bit for bit */,
        BICG_FLAG_PERSIST = 512    /* pipe_bicgstab runs as ONE persistent launch per chunk of iterations (latency-bound ranks:
-                                     matrix slices and x window in LDS, vectors in registers; bicg_persist.hip) */ };
+                                     matrix slices and x window in LDS, vectors in registers; bicg_persist.hip) */,
+       BICG_FLAG_FUSE_PIPE = 1024 /* multi-launch pipelined iterations run their element-wise phases in the SpMV epilogues (two
+                                     launches per iteration) rather than as separate kernels */,
+       BICG_FLAG_PIPE_PROBED = 2048 /* ... and that was MEASURED on this matrix by the first pipelined solve (BICG_PIPE_PROBE=1)
+                                     instead of decided by the size / layout rule of bicg_create */ };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 /* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);

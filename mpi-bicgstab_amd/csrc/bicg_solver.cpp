@@ -139,6 +139,9 @@ struct bicg_ctx {
                                  // separate flow exchange their dot groups differently: the choice is collective)
     bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues (BICG_FUSE_PIPE=0/1 overrides)
     bool fuse_small = true;      // ... the average block has < 6 M non-zeros: fused whatever the layout
+    int  pipe_probe = 0;         // BICG_PIPE_PROBE=1: the first pipelined solve TIMES both forms on this matrix and keeps the faster
+    bool pipe_probed = false;    // ... done (the choice holds for the life of the context)
+    double probe_ms[2] = {0, 0}; // ... ms per iteration measured for {separate kernels, phases in the SpMV epilogues}
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
     // persistent pipelined iteration (bicg_persist.hip, struct PersistArgs): plan + LL buffers; persist.nwg == 0: not available
     PersistArgs persist{};
@@ -1145,8 +1148,56 @@ int run_end(bicg_ctx *c, bicg_result *res)
     return k;
 }
 
+// Which pipelined form? By default a constant decides (fuse_small / x windows, set in bicg_create): the same program then
+// takes the same form on every run, which keeps results bit-reproducible from run to run -- the two forms associate the dot
+// sums differently. BICG_PIPE_PROBE=1 measures instead: the first pipelined solve on a context runs 2 + 6 iterations of each
+// form on the caller's own x0 / b (restored afterwards), all ranks agree on the slower rank's times, the faster form stays.
+void probe_pipe_form(bicg_ctx *c, int method, const bicg_options *opt_in)
+{
+    c->pipe_probed = true;
+    bicg_options o;
+    if (opt_in) o = *opt_in; else bicg_default_options(&o);
+    const bool persist = c->persist_on && method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0 && !(o.time_kernels & 3);
+    if (persist || !c->fuse_plan_ok || hosted(c) || o.max_iter < 16) return;      // one form only / nothing to amortise
+    use_device(c);
+    const size_t n = c->n_loc;
+    double *keep = dev_alloc<double>(2 * n);
+    BICG_HIP(hipMemcpy(keep, c->v.x, sizeof(double) * n, hipMemcpyDeviceToDevice));
+    BICG_HIP(hipMemcpy(keep + n, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice));
+    o.quiet = 1; o.tol = 0.0; o.max_iter = 8; o.check_every = 8; o.out_iter = 0; o.time_kernels = 0; o.record_trace = 0;
+    double t[2] = {0.0, 0.0};
+    for (int form = 1; form >= 0; --form) {
+        c->fuse_pipe = form != 0;
+        BICG_HIP(hipMemcpy(c->v.x, keep, sizeof(double) * n, hipMemcpyDeviceToDevice));
+        BICG_HIP(hipMemcpy(c->v.r, keep + n, sizeof(double) * n, hipMemcpyDeviceToDevice));
+        run_begin(c, method, &o);
+        run_iterate(c, 2);
+        const double t0 = now_sec();
+        run_iterate(c, 6);
+        t[form] = (now_sec() - t0) / 6.0 * 1.0e3;
+    }
+    if (c->nranks > 1) {      // the slower rank's time counts, and every rank must take the same decision
+        const int P = c->nranks;
+        std::vector<int> cnt(P, 2 * (int)sizeof(double)), off(P);
+        std::vector<double> mine(2 * (size_t)P), all(2 * (size_t)P, 0.0);
+        for (int p = 0; p < P; ++p) { off[p] = 2 * p * (int)sizeof(double); mine[2 * p] = t[0]; mine[2 * p + 1] = t[1]; }
+        c->comm->alltoallv_host(mine.data(), cnt.data(), off.data(), all.data(), cnt.data(), off.data());
+        all[2 * c->rank] = t[0]; all[2 * c->rank + 1] = t[1];
+        for (int p = 0; p < P; ++p) { t[0] = std::max(t[0], all[2 * p]); t[1] = std::max(t[1], all[2 * p + 1]); }
+    }
+    c->probe_ms[0] = t[0]; c->probe_ms[1] = t[1];
+    c->fuse_pipe = t[1] <= t[0];
+    BICG_HIP(hipMemcpy(c->v.x, keep, sizeof(double) * n, hipMemcpyDeviceToDevice));
+    BICG_HIP(hipMemcpy(c->v.r, keep + n, sizeof(double) * n, hipMemcpyDeviceToDevice));
+    BICG_HIP(hipFree(keep));
+    if (c->rank == 0 && getenv("BICG_PIPE_PROBE_VERBOSE"))
+        fprintf(stderr, "bicgstab_hip: pipelined form probe: separate kernels %.4f ms, SpMV epilogues %.4f ms per iteration -> %s\n", t[0], t[1],
+                c->fuse_pipe ? "epilogues" : "separate kernels");
+}
+
 int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result *res)
 {
+    if (c->pipe_probe && !c->pipe_probed && method >= BICG_PIPE_BICGSTAB) probe_pipe_form(c, method, opt_in);
     run_begin(c, method, opt_in);
     run_iterate(c, c->opt.max_iter);
     return run_end(c, res);
@@ -2280,6 +2331,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
     c->fuse_pipe = c->fuse_small || all_ranks(comm, c->win_slots == 0);
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
+    else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
     c->spmm_ok = all_ranks(comm, spmm_possible(c));
     c->fuse_plan_ok = all_ranks(comm, c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused)));
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
@@ -2386,6 +2438,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
     c->fuse_pipe = true;
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
+    else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
     c->spmm_ok = spmm_possible(c);
     c->fuse_plan_ok = true;
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
@@ -2689,6 +2742,8 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
     if (c->rowsplit) f |= BICG_FLAG_ROWSPLIT;
     if (c->persist_on) f |= BICG_FLAG_PERSIST;
+    if (c->fuse_pipe && c->fuse_plan_ok && !hosted(c)) f |= BICG_FLAG_FUSE_PIPE;
+    if (c->pipe_probed && (c->probe_ms[0] > 0.0 || c->probe_ms[1] > 0.0)) f |= BICG_FLAG_PIPE_PROBED;
     return f;
 }
 

@@ -377,7 +377,8 @@ class Context:
     def comm_failed(self) -> bool:
         return bool(lib().bicg_comm_failed(self.h))
 
-    FLAGS = {"p2p": 1, "ll_fused": 2, "overlap": 4, "col16": 8, "all_sell": 16, "jagged": 32, "spmm": 64, "window": 128, "rowsplit": 256, "persist": 512}
+    FLAGS = {"p2p": 1, "ll_fused": 2, "overlap": 4, "col16": 8, "all_sell": 16, "jagged": 32, "spmm": 64, "window": 128, "rowsplit": 256, "persist": 512,
+             "fuse_pipe": 1024, "pipe_probed": 2048}
 
     def flags(self):
         f = int(lib().bicg_ctx_flags(self.h))

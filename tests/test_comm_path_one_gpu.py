@@ -224,3 +224,35 @@ def test_section_times_on_the_multi_rank_path(problem, overlap, monkeypatch):
         if not (overlap and m.startswith("pipe")):
             assert t["reduce_ms"] > 0.0, (m, t)
     ctx.close()
+
+
+def test_pipelined_form_chosen_by_measurement(monkeypatch):
+    """BICG_PIPE_PROBE=1: the first pipelined solve on a context times both multi-launch forms (phases as separate kernels /
+    in the SpMV epilogues) on the caller's own system and keeps the faster one -- instead of the size / layout rule of
+    bicg_create. The probe must leave x0 and b untouched: the solve that follows is bit for bit the solve of a context
+    pinned to the chosen form (BICG_FUSE_PIPE), also for a second call and for the replacement variant."""
+    H.lib().bicg_comm_init_single(0)
+    A = synth.fem_like(300_000, scale_decades=1.0)
+    monkeypatch.setenv("BICG_PERSIST", "0")
+    monkeypatch.delenv("BICG_FUSE_PIPE", raising=False)
+    monkeypatch.setenv("BICG_PIPE_PROBE", "1")
+    ctx = H.Context(H.single_rank_blocks(A))
+    b = ctx.spmv(np.ones(A.rows))
+    x0 = np.random.default_rng(2).standard_normal(A.rows) * 1e-3
+    assert not ctx.flags()["pipe_probed"]
+    got = ctx.solve("pipe_bicgstab", b, x0=x0, tol=0.0, max_iter=40, check_every=8)
+    fl = ctx.flags()
+    assert fl["pipe_probed"], fl
+    again = ctx.solve("pipe_bicgstab", b, x0=x0, tol=0.0, max_iter=40, check_every=8)
+    rr = ctx.solve("pipe_bicgstab_rr", b, x0=x0, tol=0.0, max_iter=40, check_every=8, krr=10, nrr=2)
+    assert ctx.flags()["fuse_pipe"] == fl["fuse_pipe"]          # decided once per context
+    ctx.close()
+    monkeypatch.delenv("BICG_PIPE_PROBE")
+    monkeypatch.setenv("BICG_FUSE_PIPE", "1" if fl["fuse_pipe"] else "0")
+    pinned = H.Context(H.single_rank_blocks(A))
+    assert not pinned.flags()["pipe_probed"] and pinned.flags()["fuse_pipe"] == fl["fuse_pipe"]
+    want = pinned.solve("pipe_bicgstab", b, x0=x0, tol=0.0, max_iter=40, check_every=8)
+    want_rr = pinned.solve("pipe_bicgstab_rr", b, x0=x0, tol=0.0, max_iter=40, check_every=8, krr=10, nrr=2)
+    pinned.close()
+    for a, w in ((got, want), (again, want), (rr, want_rr)):
+        assert a["k"] == w["k"] == 40 and np.array_equal(a["x"], w["x"]) and np.array_equal(a["r"], w["r"])
