@@ -25,6 +25,7 @@ namespace {
 
 constexpr int kEvRing = 16;
 constexpr int kMaxTimed = 8192;
+constexpr int kPersistChunk = 128;   // iterations per persistent launch, at least (run_iterate)
 
 double now_sec()
 {
@@ -1070,16 +1071,20 @@ int run_iterate(bicg_ctx *c, int nsteps)
     const double t0 = now_sec();
     const int stop = std::min(o.max_iter, c->it + std::max(nsteps, 0));
     while (!c->hS->done && c->it < stop) {
-        const int chunk = std::min(o.check_every, stop - c->it);
+        // (section marks are host-side events between launches: the multi-launch forms are what they can time)
+        const bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
+                             ((c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0) ||
+                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain));
+        // A persistent launch costs ~27 us of set-up (matrix slices and x window into LDS) and stops by itself at
+        // convergence: it covers at least kPersistChunk iterations whatever the host check interval (200 k-row rank,
+        // pipelined: 12.5 us per iteration at 16 per launch, 11.0 at 128, 10.9 at 512 -- tools/persist_chunk_times.py)
+        const int persist_chunk_min = getenv("BICG_PERSIST_CHUNK") ? std::max(1, atoi(getenv("BICG_PERSIST_CHUNK"))) : kPersistChunk;
+        const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, stop - c->it);
         bool force = false;
         if (o.rr_drift > 0.0 && c->method >= BICG_PIPE_BICGSTAB && c->it > 0 && d.drift() > o.rr_drift) {
             force = true;
             c->adaptive_rr++;
         }
-        // (section marks are host-side events between launches: the multi-launch forms are what they can time)
-        const bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
-                             ((c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0) ||
-                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain));
         sec_mark(c, SEC_VEC);
         if (persist) persist_chunk(c, chunk);         // one launch for the whole chunk (bicg_persist.hip)
         for (int j = 0; j < chunk && !persist; ++j) {

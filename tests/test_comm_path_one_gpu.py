@@ -133,8 +133,14 @@ def test_persistent_iterations(problem, monkeypatch):
     tols = dict(METHODS)
     methods = ("pipe_bicgstab", "bicgstab", "ca_bicgstab")
     runs = []
-    for check_every in (5, 5, 1, 64):
+    # (BICG_PERSIST_CHUNK: a persistent launch covers at least that many iterations whatever check_every says -- 128 by
+    # default; 1 = exactly check_every, the last run takes the default)
+    for check_every, least in ((5, 1), (5, 1), (1, 1), (64, 1), (5, None)):
         monkeypatch.setenv("BICG_PERSIST", "1")
+        if least is None:
+            monkeypatch.delenv("BICG_PERSIST_CHUNK", raising=False)
+        else:
+            monkeypatch.setenv("BICG_PERSIST_CHUNK", str(least))
         ctx = H.Context(H.single_rank_blocks(A))
         assert ctx.flags()["persist"], ctx.flags()
         out = {}
