@@ -12,13 +12,32 @@
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
+#include <fcntl.h>
 #include <sys/stat.h>
+#include <sys/types.h>
+#include <time.h>
 
 #ifdef BICG_HAVE_MPI
 #include <mpi.h>
 #endif
 
 typedef struct { unsigned r, c; double v; } triplet;
+
+/* BICG_MTX_VERBOSE=1: seconds per phase of the serial-mode loader on stderr */
+static double wall(void)
+{
+    struct timespec ts;
+    clock_gettime(CLOCK_MONOTONIC, &ts);
+    return (double)ts.tv_sec + 1.0e-9 * (double)ts.tv_nsec;
+}
+static void phase(const char *what, double *t0)
+{
+    static int on = -1;
+    if (on < 0) { const char *e = getenv("BICG_MTX_VERBOSE"); on = e && atoi(e); }
+    const double t1 = wall();
+    if (on) fprintf(stderr, "bicg_mtx: %-28s %.3f s\n", what, t1 - *t0);
+    *t0 = t1;
+}
 
 typedef struct {
     unsigned long m, n, nz;
@@ -83,8 +102,68 @@ void bicg_partition_nnz(const unsigned int *row_nnz, unsigned int n, int nranks,
     for (int k = 0; k < nranks; ++k) counts[k] = (k + 1 < nranks ? displs[k + 1] : (int)n) - displs[k];
 }
 
+/* worker threads of the serial-mode loader: BICG_MTX_THREADS, else the cores this process may use (at most 16);
+ * small inputs stay on the calling thread */
+static long loader_threads(size_t work_bytes)
+{
+    long nt = sysconf(_SC_NPROCESSORS_ONLN);
+    cpu_set_t set;
+    if (sched_getaffinity(0, sizeof set, &set) == 0) nt = CPU_COUNT(&set);
+    if (nt > 16) nt = 16;
+    if (work_bytes < ((size_t)1 << 22)) nt = 1;
+    const char *env = getenv("BICG_MTX_THREADS");
+    if (env) nt = atol(env);
+    return nt < 1 ? 1 : nt;
+}
+/* fn(arg + t * stride) on nt threads (the last one on the caller's); a thread that cannot be created runs inline */
+static void run_threads(long nt, void *(*fn)(void *), void *args, size_t stride)
+{
+    pthread_t *tid = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
+    for (long t = 0; t + 1 < nt; ++t)
+        if (pthread_create(&tid[t], NULL, fn, (char *)args + (size_t)t * stride) != 0) { fn((char *)args + (size_t)t * stride); tid[t] = 0; }
+    fn((char *)args + (size_t)(nt - 1) * stride);
+    for (long t = 0; t + 1 < nt; ++t) if (tid[t]) pthread_join(tid[t], NULL);
+    free(tid);
+}
+
+typedef struct { int fd; char *dst; size_t off, len, got; } read_job;
+static void *read_job_run(void *arg)
+{
+    read_job *j = (read_job *)arg;
+    j->got = 0;
+    while (j->got < j->len) {
+        const ssize_t r = pread(j->fd, j->dst + j->got, j->len - j->got, (off_t)(j->off + j->got));
+        if (r <= 0) break;
+        j->got += (size_t)r;
+    }
+    return NULL;
+}
+
 static char *slurp_range(const char *path, size_t off, size_t len, size_t *got)
 {
+    if (len == (size_t)-1 && off == 0) {        /* the whole file: byte ranges read (and their pages touched) by several threads */
+        struct stat st;
+        const int fd = open(path, O_RDONLY);
+        if (fd < 0) return NULL;
+        if (fstat(fd, &st) != 0) { close(fd); return NULL; }
+        const size_t sz = (size_t)st.st_size;
+        char *buf = (char *)malloc(sz + 1);
+        if (!buf) { close(fd); return NULL; }
+        long nt = loader_threads(sz);
+        read_job *jobs = (read_job *)calloc((size_t)nt, sizeof(read_job));
+        for (long t = 0; t < nt; ++t) {
+            const size_t a = sz * (size_t)t / (size_t)nt, b = sz * (size_t)(t + 1) / (size_t)nt;
+            jobs[t].fd = fd; jobs[t].dst = buf + a; jobs[t].off = a; jobs[t].len = b - a;
+        }
+        run_threads(nt, read_job_run, jobs, sizeof(read_job));
+        size_t rd = 0;
+        for (long t = 0; t < nt; ++t) { rd += jobs[t].got; if (jobs[t].got < jobs[t].len) break; }   /* a short range ends the data */
+        free(jobs);
+        close(fd);
+        buf[rd] = 0;
+        *got = rd;
+        return buf;
+    }
     FILE *f = fopen(path, "rb");
     if (!f) return NULL;
     if (len == (size_t)-1) {
@@ -179,23 +258,6 @@ static int parse_entries(const char *p, const char *end, mtx_header *h, unsigned
     return 0;
 }
 
-static void csr_from_triplets(const triplet *t, size_t nt, unsigned rows, unsigned cols, CSR_Matrix *A)
-{
-    A->rows = rows; A->cols = cols; A->nz = (unsigned)nt;
-    A->ptr = (unsigned *)calloc((size_t)rows + 1, sizeof(unsigned));
-    A->col = (unsigned *)malloc(sizeof(unsigned) * (nt ? nt : 1));
-    A->val = (double *)malloc(sizeof(double) * (nt ? nt : 1));
-    for (size_t e = 0; e < nt; ++e) A->ptr[t[e].r + 1]++;
-    for (unsigned i = 0; i < rows; ++i) A->ptr[i + 1] += A->ptr[i];
-    unsigned *cur = (unsigned *)malloc(sizeof(unsigned) * ((size_t)rows + 1));
-    memcpy(cur, A->ptr, sizeof(unsigned) * ((size_t)rows + 1));
-    for (size_t e = 0; e < nt; ++e) {        /* arrival (= file) order inside every row */
-        unsigned k = cur[t[e].r]++;
-        A->col[k] = t[e].c; A->val[k] = t[e].v;
-    }
-    free(cur);
-}
-
 static void fill_info(const mtx_header *h, int nranks, INFO_Matrix *info)
 {   /* equal-rows partition; the nnz-balanced loaders overwrite recvcounts/displs afterwards */
     info->rows = (unsigned)h->m; info->cols = (unsigned)h->n; info->nz = (unsigned)h->nz;
@@ -209,26 +271,79 @@ static void fill_info(const mtx_header *h, int nranks, INFO_Matrix *info)
 static bicg_block_builder_fn g_builder = NULL;
 void bicg_mtx_set_block_builder(bicg_block_builder_fn fn) { g_builder = fn; }
 
-/* split this rank's triplets (global row/col) into the diag (local columns) and offd (global columns) blocks */
-static void build_blocks(const triplet *t, size_t nt, unsigned lo, unsigned hi, unsigned ncols, CSR_Matrix *diag, CSR_Matrix *offd)
+/* The triplets of rows [lo, hi) arrive as a few lists ("segments") whose concatenation is file order. Assembly into the
+ * two CSR blocks is split by ROW range: thread k owns local rows [r0, r1), walks every segment twice (count, then
+ * scatter) and keeps what falls into its rows -- no shared counters, no histogram per thread, and the arrival (= file)
+ * order inside a row survives because every thread walks the segments in order. 24 M triplets are 383 MB: the passes
+ * stream at memory speed. */
+typedef struct { triplet *t; size_t n; } tseg;
+typedef struct { const tseg *seg; int nseg; unsigned lo, hi, r0, r1; CSR_Matrix *d, *o; unsigned *cur_d, *cur_o; int pass; } asm_job;
+static void *asm_job_run(void *arg)
 {
+    asm_job *j = (asm_job *)arg;
+    const unsigned lo = j->lo, hi = j->hi, a = j->lo + j->r0, b = j->lo + j->r1;
+    if (j->pass == 1) {
+        for (unsigned r = j->r0; r < j->r1; ++r) { j->cur_d[r] = j->d->ptr[r]; j->cur_o[r] = j->o->ptr[r]; }
+    }
+    for (int s = 0; s < j->nseg; ++s) {
+        const triplet *t = j->seg[s].t;
+        const size_t n = j->seg[s].n;
+        if (j->pass == 0) {
+            for (size_t e = 0; e < n; ++e) {
+                if (t[e].r < a || t[e].r >= b) continue;
+                if (t[e].c >= lo && t[e].c < hi) j->d->ptr[t[e].r - lo + 1]++; else j->o->ptr[t[e].r - lo + 1]++;
+            }
+        } else {
+            for (size_t e = 0; e < n; ++e) {
+                if (t[e].r < a || t[e].r >= b) continue;
+                const unsigned r = t[e].r - lo;
+                if (t[e].c >= lo && t[e].c < hi) { const unsigned k = j->cur_d[r]++; j->d->col[k] = t[e].c - lo; j->d->val[k] = t[e].v; }
+                else { const unsigned k = j->cur_o[r]++; j->o->col[k] = t[e].c; j->o->val[k] = t[e].v; }
+            }
+        }
+    }
+    return NULL;
+}
+
+static void build_blocks(const tseg *seg, int nseg, unsigned lo, unsigned hi, unsigned ncols, CSR_Matrix *diag, CSR_Matrix *offd)
+{
+    size_t nt_all = 0;
+    for (int s = 0; s < nseg; ++s) nt_all += seg[s].n;
     if (g_builder) {            /* e.g. bicg_coo_to_blocks_device: sort / scan / scatter on the GPU */
-        unsigned *r = (unsigned *)malloc(sizeof(unsigned) * (nt ? nt : 1)), *c = (unsigned *)malloc(sizeof(unsigned) * (nt ? nt : 1));
-        double *v = (double *)malloc(sizeof(double) * (nt ? nt : 1));
-        for (size_t e = 0; e < nt; ++e) { r[e] = t[e].r; c[e] = t[e].c; v[e] = t[e].v; }
-        const int rc = g_builder(r, c, v, (unsigned long)nt, lo, hi, ncols, diag, offd);
+        unsigned *r = (unsigned *)malloc(sizeof(unsigned) * (nt_all ? nt_all : 1)), *c = (unsigned *)malloc(sizeof(unsigned) * (nt_all ? nt_all : 1));
+        double *v = (double *)malloc(sizeof(double) * (nt_all ? nt_all : 1));
+        size_t at = 0;
+        for (int s = 0; s < nseg; ++s)
+            for (size_t e = 0; e < seg[s].n; ++e, ++at) { r[at] = seg[s].t[e].r; c[at] = seg[s].t[e].c; v[at] = seg[s].t[e].v; }
+        const int rc = g_builder(r, c, v, (unsigned long)nt_all, lo, hi, ncols, diag, offd);
         free(r); free(c); free(v);
         if (rc == 0) return;
         fprintf(stderr, "bicg_mtx: block builder failed (%d), using the host path\n", rc);
     }
-    tvec d = {0, 0, 0}, o = {0, 0, 0};
-    for (size_t e = 0; e < nt; ++e) {
-        if (t[e].c >= lo && t[e].c < hi) tpush(&d, t[e].r - lo, t[e].c - lo, t[e].v);
-        else tpush(&o, t[e].r - lo, t[e].c, t[e].v);
+    const unsigned rows = hi - lo;
+    diag->rows = rows; diag->cols = rows;        /* cols = local rows, src/matrix.c:343-345 */
+    offd->rows = rows; offd->cols = ncols;       /* cols = n,          src/matrix.c:350-352 */
+    diag->ptr = (unsigned *)calloc((size_t)rows + 1, sizeof(unsigned));
+    offd->ptr = (unsigned *)calloc((size_t)rows + 1, sizeof(unsigned));
+    unsigned *cur = (unsigned *)malloc(sizeof(unsigned) * 2 * ((size_t)rows + 1));
+    long nt = loader_threads(nt_all * sizeof(triplet));
+    if ((unsigned)nt > rows) nt = rows ? (long)rows : 1;
+    asm_job *jobs = (asm_job *)calloc((size_t)nt, sizeof(asm_job));
+    for (long t = 0; t < nt; ++t) {
+        jobs[t].seg = seg; jobs[t].nseg = nseg; jobs[t].lo = lo; jobs[t].hi = hi;
+        jobs[t].r0 = (unsigned)((unsigned long long)rows * (unsigned long long)t / (unsigned long long)nt);
+        jobs[t].r1 = (unsigned)((unsigned long long)rows * (unsigned long long)(t + 1) / (unsigned long long)nt);
+        jobs[t].d = diag; jobs[t].o = offd; jobs[t].cur_d = cur; jobs[t].cur_o = cur + rows + 1; jobs[t].pass = 0;
     }
-    csr_from_triplets(d.t, d.n, hi - lo, hi - lo, diag);      /* cols = local rows, src/matrix.c:343-345 */
-    csr_from_triplets(o.t, o.n, hi - lo, ncols, offd);        /* cols = n,          src/matrix.c:350-352 */
-    free(d.t); free(o.t);
+    run_threads(nt, asm_job_run, jobs, sizeof(asm_job));                      /* entries per row */
+    for (unsigned i = 0; i < rows; ++i) { diag->ptr[i + 1] += diag->ptr[i]; offd->ptr[i + 1] += offd->ptr[i]; }
+    const size_t nd = diag->ptr[rows], no = offd->ptr[rows];
+    diag->nz = (unsigned)nd; offd->nz = (unsigned)no;
+    diag->col = (unsigned *)malloc(sizeof(unsigned) * (nd ? nd : 1)); diag->val = (double *)malloc(sizeof(double) * (nd ? nd : 1));
+    offd->col = (unsigned *)malloc(sizeof(unsigned) * (no ? no : 1)); offd->val = (double *)malloc(sizeof(double) * (no ? no : 1));
+    for (long t = 0; t < nt; ++t) jobs[t].pass = 1;
+    run_threads(nt, asm_job_run, jobs, sizeof(asm_job));                      /* arrival (= file) order inside every row */
+    free(jobs); free(cur);
 }
 
 typedef struct { tvec mine; unsigned lo, hi; } serial_ctx;
@@ -239,60 +354,44 @@ static void emit_serial(void *c, unsigned long i, unsigned long j, double v)
 }
 
 /* The entry lines tokenised by several threads: the text is cut into byte ranges at line boundaries, every thread keeps
- * the triplets of [lo, hi) it finds in its own list, and the lists are joined in range order -- file order, like the
- * one-thread pass (the reference has every rank fscanf() the whole file twice, src/matrix.c:315-341, 357-393; a
- * Transport-sized file -- 840 MB, 23.9 M lines -- took the single tokeniser 2.1 s of a 2.9 s run). BICG_MTX_THREADS
- * overrides the count (default: the cores the process may use, at most 16; 1 = the serial pass). */
-typedef struct { const char *p, *end; mtx_header h; serial_ctx s; int rc; } parse_job;
+ * the triplets of [lo, hi) it finds in its own list, and the lists -- in range order: file order, like the one-thread
+ * pass -- go to build_blocks as they are (the reference has every rank fscanf() the whole file twice,
+ * src/matrix.c:315-341, 357-393; a Transport-sized file -- 840 MB, 23.9 M lines -- took the single tokeniser 2.1 s of a
+ * 2.9 s run). BICG_MTX_THREADS overrides the count (default: the cores the process may use, at most 16; 1 = serial). */
+typedef struct { const char *p, *end; mtx_header h; serial_ctx s; int rc; unsigned long max_entries; } parse_job;
 static void *parse_job_run(void *arg)
 {
     parse_job *j = (parse_job *)arg;
-    j->rc = parse_entries(j->p, j->end, &j->h, (unsigned long)-1, emit_serial, &j->s);
+    j->rc = parse_entries(j->p, j->end, &j->h, j->max_entries, emit_serial, &j->s);
     return NULL;
 }
-static int parse_threaded(const char *p, const char *end, mtx_header *h, serial_ctx *out)
+/* on success *segs (malloc'ed, *nseg lists, each malloc'ed) holds the triplets of rows [lo, hi) in file order */
+static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigned lo, unsigned hi, tseg **segs, int *nseg)
 {
-    long nt = sysconf(_SC_NPROCESSORS_ONLN);
-    cpu_set_t set;
-    if (sched_getaffinity(0, sizeof set, &set) == 0) nt = CPU_COUNT(&set);
-    if (nt > 16) nt = 16;
-    if ((size_t)(end - p) < ((size_t)1 << 22)) nt = 1;           /* small files: not worth the threads */
-    const char *env = getenv("BICG_MTX_THREADS");
-    if (env) nt = atol(env);
-    if (nt <= 1) return parse_entries(p, end, h, h->nz, emit_serial, out);
+    long nt = loader_threads((size_t)(end - p));
     parse_job *jobs = (parse_job *)calloc((size_t)nt, sizeof(parse_job));
-    pthread_t *tid = (pthread_t *)calloc((size_t)nt, sizeof(pthread_t));
     const size_t len = (size_t)(end - p);
     const char *cut = p;
     for (long t = 0; t < nt; ++t) {
         const char *stop = t == nt - 1 ? end : p + len * (size_t)(t + 1) / (size_t)nt;
+        if (stop < cut) stop = cut;                                        /* the previous range ran past this one's end: empty */
         while (stop < end && stop > cut && stop[-1] != '\n') ++stop;      /* a range ends after a newline */
-        jobs[t].p = cut; jobs[t].end = stop; jobs[t].h = *h; jobs[t].s = *out; jobs[t].s.mine.t = NULL; jobs[t].s.mine.n = jobs[t].s.mine.cap = 0;
+        jobs[t].p = cut; jobs[t].end = stop; jobs[t].h = *h; jobs[t].s.lo = lo; jobs[t].s.hi = hi;
+        jobs[t].max_entries = nt == 1 ? h->nz : (unsigned long)-1;        /* one thread: stop after the banner's count like the reference */
         cut = stop;
     }
-    for (long t = 0; t < nt; ++t)
-        if (pthread_create(&tid[t], NULL, parse_job_run, &jobs[t]) != 0) { parse_job_run(&jobs[t]); tid[t] = 0; }
+    run_threads(nt, parse_job_run, jobs, sizeof(parse_job));
     int rc = 0;
-    size_t total = 0;
     h->emitted = 0;
+    *segs = (tseg *)calloc((size_t)nt, sizeof(tseg));
+    *nseg = (int)nt;
     for (long t = 0; t < nt; ++t) {
-        if (tid[t]) pthread_join(tid[t], NULL);
         if (jobs[t].rc) rc = jobs[t].rc;
-        total += jobs[t].s.mine.n;
         h->emitted += jobs[t].h.emitted;
+        (*segs)[t].t = jobs[t].s.mine.t; (*segs)[t].n = jobs[t].s.mine.n;
     }
-    if (!rc) {
-        out->mine.t = (triplet *)realloc(out->mine.t, sizeof(triplet) * (total ? total : 1));
-        out->mine.cap = total ? total : 1;
-        size_t at = out->mine.n;
-        for (long t = 0; t < nt; ++t) {
-            if (jobs[t].s.mine.n) memcpy(out->mine.t + at, jobs[t].s.mine.t, sizeof(triplet) * jobs[t].s.mine.n);
-            at += jobs[t].s.mine.n;
-        }
-        out->mine.n = at;
-    }
-    for (long t = 0; t < nt; ++t) free(jobs[t].s.mine.t);
-    free(jobs); free(tid);
+    free(jobs);
+    if (rc) { for (int i = 0; i < *nseg; ++i) free((*segs)[i].t); free(*segs); *segs = NULL; *nseg = 0; }
     return rc;
 }
 
@@ -306,8 +405,10 @@ int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, C
                              INFO_Matrix *info)
 {
     size_t len = 0;
+    double t0 = wall();
     char *buf = slurp_range(path, 0, (size_t)-1, &len);
     if (!buf) { fprintf(stderr, "ERROR: can't open file \"%s\"\n", path); return 1; }
+    phase("read the file", &t0);
     mtx_header h;
     int rc = parse_header(buf, &h);
     if (rc) { free(buf); return rc; }
@@ -319,8 +420,12 @@ int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, C
         bicg_partition_nnz(cnt, (unsigned)h.m, nranks, info->recvcounts, info->displs);
         free(cnt);
     }
-    serial_ctx s = {{0, 0, 0}, (unsigned)info->displs[rank], (unsigned)(info->displs[rank] + info->recvcounts[rank])};
-    rc = parse_threaded(buf + h.data_off, buf + len, &h, &s);
+    const unsigned lo = (unsigned)info->displs[rank], hi = (unsigned)(info->displs[rank] + info->recvcounts[rank]);
+    tseg *segs = NULL;
+    int nseg = 0;
+    t0 = wall();
+    rc = parse_threaded(buf + h.data_off, buf + len, &h, lo, hi, &segs, &nseg);
+    phase("tokenise", &t0);
     free(buf);
     if (rc) return rc;
     /* nz = entries of the matrix that is actually solved: for 'symmetric' storage the banner counts one
@@ -329,8 +434,11 @@ int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, C
     if (h.symmetric && rank == 0)
         fprintf(stderr, "bicg_mtx: 'symmetric' storage: mirrored to %llu entries (the reference's block loader keeps the stored triangle only)\n",
                 h.emitted);
-    build_blocks(s.mine.t, s.mine.n, s.lo, s.hi, (unsigned)h.n, diag, offd);
-    free(s.mine.t);
+    t0 = wall();
+    build_blocks(segs, nseg, lo, hi, (unsigned)h.n, diag, offd);
+    phase("diag / offd CSR blocks", &t0);
+    for (int i = 0; i < nseg; ++i) free(segs[i].t);
+    free(segs);
     return 0;
 }
 
@@ -555,7 +663,8 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     MPI_Type_free(&trip);
     free(sbuf);
     const unsigned lo = (unsigned)info->displs[me], hi = lo + (unsigned)info->recvcounts[me];
-    build_blocks(rbuf, rtot, lo, hi, (unsigned)h.n, diag, offd);
+    const tseg all = {rbuf, rtot};
+    build_blocks(&all, 1, lo, hi, (unsigned)h.n, diag, offd);
     free(rbuf); free(scnt); free(sdsp); free(rcnt); free(rdsp);
     return 0;
 }

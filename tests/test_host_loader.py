@@ -269,3 +269,31 @@ def test_block_builder_hook(tmp_path):
         if nz:
             assert np.array_equal(np.ctypeslib.as_array(a.col, shape=(nz,)), np.ctypeslib.as_array(b.col, shape=(nz,)))
             assert np.array_equal(np.ctypeslib.as_array(a.val, shape=(nz,)), np.ctypeslib.as_array(b.val, shape=(nz,)))
+
+
+@pytest.mark.parametrize("world", [1, 2])
+def test_loader_more_threads_than_rows_and_duplicates(tmp_path, world):
+    """The serial-mode loader reads, tokenises and assembles with BICG_MTX_THREADS workers: byte ranges for the first two,
+    ROW ranges for the assembly (a thread keeps what falls into its rows, walking the per-thread triplet lists in file
+    order). Edge of that scheme: more workers than rows, rows without entries, repeated (row, col) pairs -- which the
+    reference keeps as separate entries in file order (src/matrix.c:357-393)."""
+    n = 5
+    row = np.array([4, 0, 4, 2, 0, 4, 2, 0], dtype=np.int64)
+    col = np.array([0, 3, 4, 2, 3, 0, 0, 0], dtype=np.int64)          # (0,3) and (4,0) twice; rows 1 and 3 empty
+    val = np.array([1.5, -2.0, 3.25, 4.0, 5.0, 6.0, 7.0, 8.0])
+    mtx = str(tmp_path / "tiny.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{n} {n} {len(val)}\n")
+        for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
+            f.write(f"{i + 1} {j + 1} {v!r}\n")
+    prefix = str(tmp_path / "out")
+    for threads in ("1", "3", "16"):
+        subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, "serial"], check=True, timeout=120,
+                       env=dict(os.environ, BICG_MTX_THREADS=threads))
+        for rank in range(world):
+            rows, ncols, d, o = _read(prefix, rank)
+            ed, eo, counts, _ = _expected(n, row, col, val, world, rank)
+            assert rows == counts[rank] and ncols == n
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[1], ed.col) and np.array_equal(d[2], ed.val), threads
+            assert np.array_equal(o[0], eo.ptr) and np.array_equal(o[1], eo.col) and np.array_equal(o[2], eo.val), threads
