@@ -574,6 +574,17 @@ static void emit_par(void *c, unsigned long i, unsigned long j, double v)
     tpush(&p->bins[owner], (unsigned)i, (unsigned)j, v);
 }
 
+/* this rank's byte range tokenised by several threads: sub-ranges cut at line ends, one set of per-owner bins per
+ * thread; bin[owner] of thread 0, 1, ... in that order is the file order of the range */
+typedef struct { const char *p, *end; mtx_header h; par_ctx pc; int rc; } par_job;
+static void *par_job_run(void *arg)
+{
+    par_job *j = (par_job *)arg;
+    j->rc = j->p < j->end ? parse_entries(j->p, j->end, &j->h, (unsigned long)-1, emit_par, &j->pc) : 0;
+    if (!(j->p < j->end)) j->h.emitted = 0;
+    return NULL;
+}
+
 int bicg_mtx_load_block_mpi(const char *path, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
 {
     return bicg_mtx_load_block_mpi_part(path, BICG_PART_ROWS, diag, offd, info);
@@ -611,7 +622,7 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     const char *q = stop;
     if (q > buf && q[-1] != '\n') { while (q < buf + len && *q != '\n') ++q; }
     par_ctx pc;
-    pc.bins = (tvec *)calloc((size_t)np, sizeof(tvec)); pc.m = h.m; pc.np = np; pc.counts = NULL; pc.displs = NULL;
+    pc.bins = NULL; pc.m = h.m; pc.np = np; pc.counts = NULL; pc.displs = NULL;
     if (part == BICG_PART_NNZ) {
         /* non-zeros per row: every rank counts its byte range, one all-reduce, same cuts everywhere */
         unsigned *cnt = (unsigned *)calloc(h.m ? h.m : 1, sizeof(unsigned));
@@ -621,9 +632,34 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
         free(cnt);
         pc.counts = info->recvcounts; pc.displs = info->displs;
     }
-    if (!rc && p < q) rc = parse_entries(p, q, &h, (unsigned long)-1, emit_par, &pc);
+    /* the ranks of a node share its cores: BICG_MTX_THREADS, else (cores this process may use) / ranks, at most 16 */
+    long nt = 1;
+    if (p < q) {
+        nt = loader_threads((size_t)(q - p));
+        if (!getenv("BICG_MTX_THREADS")) { nt /= np; if (nt < 1) nt = 1; }
+    }
+    par_job *jobs = (par_job *)calloc((size_t)nt, sizeof(par_job));
+    {
+        const size_t blen = p < q ? (size_t)(q - p) : 0;
+        const char *cut = p;
+        for (long t = 0; t < nt; ++t) {
+            const char *stop = t == nt - 1 ? q : p + blen * (size_t)(t + 1) / (size_t)nt;
+            if (stop < cut) stop = cut;
+            while (stop < q && stop > cut && stop[-1] != '\n') ++stop;
+            jobs[t].p = cut; jobs[t].end = stop; jobs[t].h = h; jobs[t].pc = pc;
+            jobs[t].pc.bins = (tvec *)calloc((size_t)np, sizeof(tvec));
+            cut = stop;
+        }
+    }
+    if (!rc) run_threads(nt, par_job_run, jobs, sizeof(par_job));
+    h.emitted = 0;
+    for (long t = 0; t < nt; ++t) { if (jobs[t].rc) rc = jobs[t].rc; h.emitted += jobs[t].h.emitted; }
     free(buf);
-    if (rc) return rc;
+    if (rc) {
+        for (long t = 0; t < nt; ++t) { for (int r = 0; r < np; ++r) free(jobs[t].pc.bins[r].t); free(jobs[t].pc.bins); }
+        free(jobs);
+        return rc;
+    }
     {   /* see the serial loader: nz = entries actually emitted, over all byte ranges */
         unsigned long long tot = p < q ? h.emitted : 0ull;
         MPI_Allreduce(MPI_IN_PLACE, &tot, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
@@ -640,8 +676,10 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     size_t stot = 0;
     int too_big = 0;
     for (int r = 0; r < np; ++r) {
-        if (pc.bins[r].n > (size_t)INT_MAX || stot > (size_t)INT_MAX) too_big = 1;
-        scnt[r] = (int)pc.bins[r].n; sdsp[r] = (int)stot; stot += pc.bins[r].n;
+        size_t to_r = 0;
+        for (long t = 0; t < nt; ++t) to_r += jobs[t].pc.bins[r].n;
+        if (to_r > (size_t)INT_MAX || stot > (size_t)INT_MAX) too_big = 1;
+        scnt[r] = (int)to_r; sdsp[r] = (int)stot; stot += to_r;
     }
     MPI_Alltoall(scnt, 1, MPI_INT, rcnt, 1, MPI_INT, MPI_COMM_WORLD);
     size_t rtot = 0;
@@ -649,16 +687,25 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     MPI_Allreduce(MPI_IN_PLACE, &too_big, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
     if (too_big) {
         if (me == 0) fprintf(stderr, "ERROR: bicg_mtx: more than 2^31 entries to or from one rank: use more ranks or the serial loader\n");
-        for (int r = 0; r < np; ++r) free(pc.bins[r].t);
-        free(pc.bins); free(scnt); free(sdsp); free(rcnt); free(rdsp);
+        for (long t = 0; t < nt; ++t) { for (int r = 0; r < np; ++r) free(jobs[t].pc.bins[r].t); free(jobs[t].pc.bins); }
+        free(jobs); free(scnt); free(sdsp); free(rcnt); free(rdsp);
         return 7;
     }
     MPI_Datatype trip;
     MPI_Type_contiguous((int)sizeof(triplet), MPI_BYTE, &trip);
     MPI_Type_commit(&trip);
     triplet *sbuf = (triplet *)malloc(sizeof(triplet) * (stot ? stot : 1)), *rbuf = (triplet *)malloc(sizeof(triplet) * (rtot ? rtot : 1));
-    for (int r = 0; r < np; ++r) { if (scnt[r]) memcpy(sbuf + sdsp[r], pc.bins[r].t, sizeof(triplet) * (size_t)scnt[r]); free(pc.bins[r].t); }
-    free(pc.bins);
+    for (int r = 0; r < np; ++r) {
+        size_t at = (size_t)sdsp[r];
+        for (long t = 0; t < nt; ++t) {          /* thread order = file order inside this rank's byte range */
+            const tvec *b = &jobs[t].pc.bins[r];
+            if (b->n) memcpy(sbuf + at, b->t, sizeof(triplet) * b->n);
+            at += b->n;
+            free(b->t);
+        }
+    }
+    for (long t = 0; t < nt; ++t) free(jobs[t].pc.bins);
+    free(jobs);
     MPI_Alltoallv(sbuf, scnt, sdsp, trip, rbuf, rcnt, rdsp, trip, MPI_COMM_WORLD);
     MPI_Type_free(&trip);
     free(sbuf);

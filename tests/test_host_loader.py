@@ -67,9 +67,9 @@ def test_loader_blocks(tmp_path, world, mode, order):
         for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
             f.write(f"{i + 1} {j + 1} {v!r}\n")
     prefix = str(tmp_path / "out")
-    # serial mode: the entry lines tokenised by one thread, and by several (byte ranges cut at line boundaries, lists joined
-    # in range order: the file order inside every row must survive)
-    for threads in (("1", "5") if mode == "serial" else ("1",)):
+    # the entry lines (serial mode: all of them; MPI mode: this rank's byte range) tokenised by one thread, and by several
+    # (sub-ranges cut at line boundaries, lists taken in range order: the file order inside every row must survive)
+    for threads in ("1", "5"):
         subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode], check=True, timeout=120,
                        env=dict(os.environ, BICG_MTX_THREADS=threads))
         for rank in range(world):
@@ -159,7 +159,8 @@ def test_loader_nnz_balanced_partition_and_cache(tmp_path, world, mode):
     prefix = str(tmp_path / "out")
     cache = tmp_path / "cache"
     cache.mkdir()
-    subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode, "nnz", str(cache)], check=True, timeout=120)
+    subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, mode, "nnz", str(cache)], check=True, timeout=120,
+                   env=dict(os.environ, BICG_MTX_THREADS="3"))
     lens = np.diff(A.ptr.astype(np.int64))
     displs, counts = _read_partition(prefix, 0, world)
     assert displs[0] == 0 and np.array_equal(displs[1:], np.cumsum(counts)[:-1]) and counts.sum() == A.rows
