@@ -643,12 +643,12 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
         const size_t blen = p < q ? (size_t)(q - p) : 0;
         const char *cut = p;
         for (long t = 0; t < nt; ++t) {
-            const char *stop = t == nt - 1 ? q : p + blen * (size_t)(t + 1) / (size_t)nt;
-            if (stop < cut) stop = cut;
-            while (stop < q && stop > cut && stop[-1] != '\n') ++stop;
-            jobs[t].p = cut; jobs[t].end = stop; jobs[t].h = h; jobs[t].pc = pc;
+            const char *sub_end = t == nt - 1 ? q : p + blen * (size_t)(t + 1) / (size_t)nt;
+            if (sub_end < cut) sub_end = cut;
+            while (sub_end < q && sub_end > cut && sub_end[-1] != '\n') ++sub_end;
+            jobs[t].p = cut; jobs[t].end = sub_end; jobs[t].h = h; jobs[t].pc = pc;
             jobs[t].pc.bins = (tvec *)calloc((size_t)np, sizeof(tvec));
-            cut = stop;
+            cut = sub_end;
         }
     }
     if (!rc) run_threads(nt, par_job_run, jobs, sizeof(par_job));
@@ -698,10 +698,10 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     for (int r = 0; r < np; ++r) {
         size_t at = (size_t)sdsp[r];
         for (long t = 0; t < nt; ++t) {          /* thread order = file order inside this rank's byte range */
-            const tvec *b = &jobs[t].pc.bins[r];
-            if (b->n) memcpy(sbuf + at, b->t, sizeof(triplet) * b->n);
-            at += b->n;
-            free(b->t);
+            const tvec *bin = &jobs[t].pc.bins[r];
+            if (bin->n) memcpy(sbuf + at, bin->t, sizeof(triplet) * bin->n);
+            at += bin->n;
+            free(bin->t);
         }
     }
     for (long t = 0; t < nt; ++t) free(jobs[t].pc.bins);
