@@ -379,8 +379,12 @@ int bicg_mtx_load_block(const char *path, int rank, int nranks, CSR_Matrix *diag
  *   bicg_mtx_load_block_part  the loader above with part = BICG_PART_ROWS | BICG_PART_NNZ
  *   bicg_mtx_cache_save/load  checksummed binary copy of one rank's parsed blocks; load returns 0 on a
  *                             valid hit for exactly this (rank, nranks, part) and unchanged source file */
+/*   bicg_mtx_parse_double    the loader's conversion of one value: returns 0 when its own exact fast path (Eisel-Lemire,
+ *                             <= 19 significant digits) produced it, 1 when it was handed to strtod; either way *value is
+ *                             what fscanf("%lg") gives (src/matrix.c:333) and *consumed the characters used */
 enum { BICG_PART_ROWS = 0, BICG_PART_NNZ = 1 };
 void bicg_partition_nnz(const unsigned int *row_nnz, unsigned int n, int nranks, int *counts, int *displs);
+int bicg_mtx_parse_double(const char *text, double *value, int *consumed);
 int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, CSR_Matrix *diag, CSR_Matrix *offd,
                              INFO_Matrix *info);
 int bicg_mtx_cache_save(const char *cache_path, const char *src_path, int rank, int nranks, int part,

@@ -55,7 +55,7 @@ EXPORTS = [
     "shifted_pipe_lopbicgstab", "shifted_pipe_lopbicgstab_nooverlap", "bicg_solve_shifted",
     "shifted_lopbicg", "shifted_lopbicg_switching", "shifted_lopbicg_switching_noovlp", "bicg_shifted_residuals",
     "bicg_comm_enable_p2p", "bicg_comm_p2p_active", "bicg_comm_failed",
-    "bicg_partition_nnz", "bicg_mtx_load_block_part", "bicg_mtx_cache_save", "bicg_mtx_cache_load",
+    "bicg_partition_nnz", "bicg_mtx_load_block_part", "bicg_mtx_parse_double", "bicg_mtx_cache_save", "bicg_mtx_cache_load",
     "bicg_coo_to_blocks_device", "bicg_mtx_set_block_builder",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",

@@ -298,3 +298,110 @@ def test_loader_more_threads_than_rows_and_duplicates(tmp_path, world):
             assert rows == counts[rank] and ncols == n
             assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[1], ed.col) and np.array_equal(d[2], ed.val), threads
             assert np.array_equal(o[0], eo.ptr) and np.array_equal(o[1], eo.col) and np.array_equal(o[2], eo.val), threads
+
+
+def test_value_conversion_is_correctly_rounded():
+    """The tokeniser converts values with its own routines (host/bicg_mtx.c: Clinger's exact case, Eisel-Lemire with a
+    truncated 128-bit power-of-ten table, strtod for whatever those decline) where the reference uses fscanf("%lg")
+    (src/matrix.c:333, 366). Every spelling must give the correctly rounded double -- bit for bit what Python's float()
+    gives -- and stop at the same character as strtod: random doubles in several print formats, random digit strings over
+    the whole exponent range, the neighbourhoods of half-way points between adjacent doubles (where a conversion that is
+    merely accurate goes wrong), and the spellings only libc understands."""
+    import ctypes as C
+    import random
+    import struct
+    from decimal import Decimal, getcontext
+    from mpi_bicgstab_amd import hipsolver as H
+    L = H.lib()
+    L.bicg_mtx_parse_double.argtypes = [C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int)]
+    v, n = C.c_double(), C.c_int()
+    handled = {"own": 0, "libc": 0}
+
+    def check(s, consumed=None, want=None):
+        rc = L.bicg_mtx_parse_double(s.encode() + b"\n9 9 9.5\n", C.byref(v), C.byref(n))
+        handled["own" if rc == 0 else "libc"] += 1
+        used = len(s) if consumed is None else consumed
+        assert n.value == used, (s, n.value, used)
+        w = float(s[:used]) if want is None else want
+        assert struct.pack("<d", v.value) == struct.pack("<d", w), (s, v.value, w, rc)
+        return rc
+
+    rng = random.Random(1234)
+    # 1. random finite doubles, printed the ways matrix files are written
+    for _ in range(60000):
+        bits = rng.getrandbits(64)
+        if (bits >> 52) & 0x7FF == 0x7FF:
+            continue
+        d = struct.unpack("<d", struct.pack("<Q", bits))[0]
+        for fmt in ("%r", "%.17g", "%.16e", "%.15g", "%.9g"):
+            check(fmt % d)
+    # ... and doubles of ordinary magnitude (what a matrix holds)
+    own_before = dict(handled)
+    for _ in range(60000):
+        d = rng.uniform(-1, 1) * 10.0 ** rng.randint(-12, 12)
+        for fmt in ("%r", "%.17g", "%.16e", "%.12f", "%.6g"):
+            check(fmt % d)
+    own = handled["own"] - own_before["own"]
+    assert own >= 0.999 * 300000, handled          # the fast routines, not libc, carry a real file
+    # 2. random digit strings: 1..19 digits, a point anywhere, exponents over the whole range
+    for _ in range(120000):
+        nd = rng.randint(1, 19)
+        digits = "".join(rng.choice("0123456789") for _ in range(nd))
+        pt = rng.randint(0, nd)
+        body = digits[:pt] + ("." if rng.random() < 0.7 else "") + digits[pt:]
+        if body in (".", ""):
+            continue
+        if "." not in body and pt < nd:
+            body = digits
+        s = rng.choice(("", "-", "+")) + body
+        if rng.random() < 0.8:
+            s += rng.choice("eE") + rng.choice(("", "-", "+")) + str(rng.randint(0, 330))
+        check(s)
+    # 3. half-way neighbourhoods: m = (d + next(d)) / 2 exactly, written with 17..19 digits, and one unit either side
+    getcontext().prec = 800
+    for _ in range(20000):
+        bits = rng.getrandbits(63) & ~(0x7FF << 52) | (rng.randint(1, 2045) << 52)
+        d = struct.unpack("<d", struct.pack("<Q", bits))[0]
+        up = struct.unpack("<d", struct.pack("<Q", bits + 1))[0]
+        mid = (Decimal(d) + Decimal(up)) / 2
+        for nd in (17, 18, 19):
+            t = mid.as_tuple()
+            lead = int("".join(map(str, t.digits[:nd])))
+            e10 = len(t.digits) + t.exponent - nd
+            for delta in (-1, 0, 1):
+                check(f"{lead + delta}e{e10}")
+    # 3b. more than 19 digits: 20..40 random digits, and half-way points written out to 25 / 40 digits (and one unit either
+    #     side of them): decided by the routine only when both ends of the truncation interval round alike, else libc
+    for _ in range(30000):
+        nd = rng.randint(20, 40)
+        digits = str(rng.randint(1, 9)) + "".join(rng.choice("0123456789") for _ in range(nd - 1))
+        pt = rng.randint(0, nd)
+        s = rng.choice(("", "-")) + digits[:pt] + "." + digits[pt:] + "e" + str(rng.randint(-320, 300))
+        check(s)
+    for _ in range(5000):
+        bits = rng.getrandbits(63) & ~(0x7FF << 52) | (rng.randint(1, 2045) << 52)
+        d = struct.unpack("<d", struct.pack("<Q", bits))[0]
+        up = struct.unpack("<d", struct.pack("<Q", bits + 1))[0]
+        t = ((Decimal(d) + Decimal(up)) / 2).as_tuple()
+        for nd in (25, 40):
+            dg = list(t.digits[:nd]) + [0] * max(0, nd - len(t.digits))
+            lead = int("".join(map(str, dg)))
+            e10 = len(t.digits) + t.exponent - nd
+            for delta in (-1, 0, 1):
+                check(f"{lead + delta}e{e10}")
+    # 4. particular spellings
+    for s in ("0", "-0", "0.0", "-0.0e5", "00012.5000", ".5", "5.", "+1.5", "1E+05", "1e22", "1e23", "1e-22", "8.5e-23",
+              "9007199254740993", "9007199254740992", "4503599627370497.5", "123456789012345678e-5", "1.7976931348623157e308",
+              "2.2250738585072014e-308", "2.2250738585072011e-308", "4.9e-324", "1e-330", "1e400", "-1e400",
+              "12345678901234567890", "0.000000000000000000000000000000000012345678901234567890123"):
+        check(s)
+    check("1e", consumed=1)
+    check("1e+", consumed=1)
+    check("2.5e-x", consumed=3)
+    check("7.25 ", consumed=4)
+    check("  \t3.5", want=3.5)
+    check("0x10", want=16.0)                 # strtod reads hexadecimal floats; so does the loader, through strtod
+    check("inf", want=float("inf"))
+    rc = L.bicg_mtx_parse_double(b"nan", C.byref(v), C.byref(n))
+    assert rc == 1 and v.value != v.value and n.value == 3
+    assert handled["own"] > 10 * handled["libc"], handled
