@@ -1159,11 +1159,12 @@ int run_end(bicg_ctx *c, bicg_result *res)
 // form on the caller's own x0 / b (restored afterwards), all ranks agree on the slower rank's times, the faster form stays.
 void probe_pipe_form(bicg_ctx *c, int method, const bicg_options *opt_in)
 {
-    c->pipe_probed = true;
     bicg_options o;
     if (opt_in) o = *opt_in; else bicg_default_options(&o);
     const bool persist = c->persist_on && method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0 && !(o.time_kernels & 3);
-    if (persist || !c->fuse_plan_ok || hosted(c) || o.max_iter < 16) return;      // one form only / nothing to amortise
+    if (!c->fuse_plan_ok || hosted(c)) { c->pipe_probed = true; return; }      // this context has one form only
+    if (persist || o.max_iter < 16) return;      // this solve takes the persistent form / is too short to pay for it: a later one may probe
+    c->pipe_probed = true;
     use_device(c);
     const size_t n = c->n_loc;
     double *keep = dev_alloc<double>(2 * n);
