@@ -11,7 +11,10 @@
  * Set-up follows reference src/main.c:81-117: load blocks, b = A*1, x0 = 0.
  * Output: <out_prefix>.rank<p>.bin = int32 k, int32 n_loc, double x[n_loc], double r[n_loc].
  * With method "spmv" it writes y = A*(1 + 0.001*global_row) instead (k = 0, r unused = 0);
- * with method "rhs" it writes x = 0 and r = b = A*1 without solving.
+ * with method "rhs" it writes x = 0 and r = b = A*1 without solving;
+ * with method "blocks" it writes what MPI_csr_load_matrix_block produced (src/matrix.c:402-419) in the layout of
+ * mpi-bicgstab_amd/host/bicg_mtx_dump: uint32 {local rows, global cols, nnz diag, nnz offd}, diag ptr / col / val,
+ * offd ptr / col / val, int32 displs[P], recvcounts[P] -- the pin of the C host's loader (tests/test_host_loader.py).
  */
 #include "solver.h"
 
@@ -39,6 +42,20 @@ int main(int argc, char **argv)
     double *full = (double *)malloc(sizeof(double) * n);
     const char *method = argv[2];
 
+    if (strcmp(method, "blocks") == 0) {
+        char bpath[4096];
+        snprintf(bpath, sizeof bpath, "%s.rank%d.bin", argv[3], me);
+        FILE *bf = fopen(bpath, "wb");
+        if (!bf) { fprintf(stderr, "cannot write %s\n", bpath); MPI_Abort(MPI_COMM_WORLD, 1); }
+        unsigned hdr[4] = {diag.rows, offd.cols, diag.ptr[diag.rows], offd.ptr[offd.rows]};
+        fwrite(hdr, 4, 4, bf);
+        fwrite(diag.ptr, 4, diag.rows + 1, bf); fwrite(diag.col, 4, hdr[2], bf); fwrite(diag.val, 8, hdr[2], bf);
+        fwrite(offd.ptr, 4, offd.rows + 1, bf); fwrite(offd.col, 4, hdr[3], bf); fwrite(offd.val, 8, hdr[3], bf);
+        fwrite(info.displs, 4, (size_t)np, bf); fwrite(info.recvcounts, 4, (size_t)np, bf);
+        fclose(bf);
+        MPI_Finalize();
+        return 0;
+    }
     if (strcmp(method, "spmv") == 0) {
         for (int i = 0; i < nl; ++i) { x[i] = 1.0 + 0.001 * (double)(info.displs[me] + i); r[i] = 0.0; }
         double *y = (double *)malloc(sizeof(double) * nl);

@@ -405,3 +405,40 @@ def test_value_conversion_is_correctly_rounded():
     rc = L.bicg_mtx_parse_double(b"nan", C.byref(v), C.byref(n))
     assert rc == 1 and v.value != v.value and n.value == 3
     assert handled["own"] > 10 * handled["libc"], handled
+
+
+REF_DUMP = os.path.join(ROOT, "oracle", "_ref", "ref_dump")
+
+
+@pytest.mark.skipif(not os.path.exists(REF_DUMP), reason="oracle/_ref not built (needs /root/reference at build time)")
+@pytest.mark.parametrize("world", [1, 2, 3])
+def test_loader_against_the_reference_loader_itself(tmp_path, world):
+    """The pin of SURVEY.md section 8f N1: the blocks of the C host's loader, in all its modes (serial with 1 and 4
+    threads, MPI with 1 and 3 threads per rank), against the blocks the REFERENCE's own MPI_csr_load_matrix_block builds
+    from the same file (oracle/_ref/ref_dump, the real src/matrix.c:268-419 compiled by oracle/Makefile) -- row pointers,
+    columns in stored order, values bit for bit, partition arrays. The file is in shuffled order with 17-digit values,
+    short values, exponents and a comment block, on an irregular matrix."""
+    A = synth.fem_like(4000, seed=11, scale_decades=1.5)
+    row, col, val = A.to_coo()
+    rng = np.random.default_rng(8)
+    perm = rng.permutation(len(val))
+    row, col, val = row[perm], col[perm], val[perm]
+    val = np.where(rng.random(len(val)) < 0.2, np.round(val, 3), val)          # some short spellings
+    mtx = str(tmp_path / "m.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n% written by tests/test_host_loader.py\n%\n")
+        f.write(f"{A.rows} {A.cols} {len(val)}\n")
+        for k, (i, j, v) in enumerate(zip(row.tolist(), col.tolist(), val.tolist())):
+            f.write(f"{i + 1} {j + 1} {v!r}\n" if k % 3 else f"{i + 1}  {j + 1}\t{v:.16e}\n")
+    ref = str(tmp_path / "ref")
+    subprocess.run([MPIEXEC, "-n", str(world), REF_DUMP, mtx, "blocks", ref], check=True, timeout=300)
+    for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "1"), ("mpi", "3")):
+        if mode == "mpi" and world == 1:
+            continue
+        out = str(tmp_path / f"ours_{mode}_{threads}")
+        subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, out, mode], check=True, timeout=300,
+                       env=dict(os.environ, BICG_MTX_THREADS=threads))
+        for rank in range(world):
+            want = open(f"{ref}.rank{rank}.bin", "rb").read()
+            got = open(f"{out}.rank{rank}.bin", "rb").read()
+            assert got == want, (mode, threads, rank)
