@@ -490,9 +490,9 @@ static void *parse_job_run(void *arg)
     return NULL;
 }
 /* on success *segs (malloc'ed, *nseg lists, each malloc'ed) holds the triplets of rows [lo, hi) in file order */
-static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigned lo, unsigned hi, tseg **segs, int *nseg)
+static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigned lo, unsigned hi, long threads, tseg **segs, int *nseg)
 {
-    long nt = loader_threads((size_t)(end - p));
+    long nt = threads > 0 ? threads : loader_threads((size_t)(end - p));
     parse_job *jobs = (parse_job *)calloc((size_t)nt, sizeof(parse_job));
     const size_t len = (size_t)(end - p);
     const char *cut = p;
@@ -519,12 +519,6 @@ static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigne
     return rc;
 }
 
-static void emit_count(void *c, unsigned long i, unsigned long j, double v)
-{
-    (void)j; (void)v;
-    ((unsigned *)c)[i]++;
-}
-
 int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, CSR_Matrix *diag, CSR_Matrix *offd,
                              INFO_Matrix *info)
 {
@@ -537,18 +531,23 @@ int bicg_mtx_load_block_part(const char *path, int rank, int nranks, int part, C
     int rc = parse_header(buf, &h);
     if (rc) { free(buf); return rc; }
     fill_info(&h, nranks, info);
-    if (part == BICG_PART_NNZ) {             /* one more pass over the text: non-zeros per row */
-        unsigned *cnt = (unsigned *)calloc(h.m ? h.m : 1, sizeof(unsigned));
-        rc = parse_entries(buf + h.data_off, buf + len, &h, h.nz, emit_count, cnt);
-        if (rc) { free(cnt); free(buf); return rc; }
-        bicg_partition_nnz(cnt, (unsigned)h.m, nranks, info->recvcounts, info->displs);
-        free(cnt);
-    }
-    const unsigned lo = (unsigned)info->displs[rank], hi = (unsigned)(info->displs[rank] + info->recvcounts[rank]);
     tseg *segs = NULL;
     int nseg = 0;
     t0 = wall();
-    rc = parse_threaded(buf + h.data_off, buf + len, &h, lo, hi, &segs, &nseg);
+    if (part == BICG_PART_NNZ) {
+        /* the cuts depend on every row's length: the text is still tokenised ONCE -- all rows are kept, counted from the
+         * lists, and build_blocks picks this rank's range out of them */
+        rc = parse_threaded(buf + h.data_off, buf + len, &h, 0u, (unsigned)h.m, 0, &segs, &nseg);
+        if (!rc) {
+            unsigned *cnt = (unsigned *)calloc(h.m ? h.m : 1, sizeof(unsigned));
+            for (int sg = 0; sg < nseg; ++sg)
+                for (size_t e = 0; e < segs[sg].n; ++e) cnt[segs[sg].t[e].r]++;
+            bicg_partition_nnz(cnt, (unsigned)h.m, nranks, info->recvcounts, info->displs);
+            free(cnt);
+        }
+    }
+    const unsigned lo = (unsigned)info->displs[rank], hi = (unsigned)(info->displs[rank] + info->recvcounts[rank]);
+    if (part != BICG_PART_NNZ) rc = parse_threaded(buf + h.data_off, buf + len, &h, lo, hi, 0, &segs, &nseg);
     phase("tokenise", &t0);
     free(buf);
     if (rc) return rc;
@@ -690,25 +689,6 @@ out:
 }
 
 #ifdef BICG_HAVE_MPI
-typedef struct { tvec *bins; unsigned long m; int np; const int *counts, *displs; } par_ctx;
-static void emit_par(void *c, unsigned long i, unsigned long j, double v)
-{
-    par_ctx *p = (par_ctx *)c;
-    const int owner = p->counts ? owner_in(i, p->counts, p->displs, p->np) : owner_of(i, p->m, p->np);
-    tpush(&p->bins[owner], (unsigned)i, (unsigned)j, v);
-}
-
-/* this rank's byte range tokenised by several threads: sub-ranges cut at line ends, one set of per-owner bins per
- * thread; bin[owner] of thread 0, 1, ... in that order is the file order of the range */
-typedef struct { const char *p, *end; mtx_header h; par_ctx pc; int rc; } par_job;
-static void *par_job_run(void *arg)
-{
-    par_job *j = (par_job *)arg;
-    j->rc = j->p < j->end ? parse_entries(j->p, j->end, &j->h, (unsigned long)-1, emit_par, &j->pc) : 0;
-    if (!(j->p < j->end)) j->h.emitted = 0;
-    return NULL;
-}
-
 int bicg_mtx_load_block_mpi(const char *path, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info)
 {
     return bicg_mtx_load_block_mpi_part(path, BICG_PART_ROWS, diag, offd, info);
@@ -745,47 +725,40 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     /* lines starting before `end` are ours even if they finish after it */
     const char *q = stop;
     if (q > buf && q[-1] != '\n') { while (q < buf + len && *q != '\n') ++q; }
-    par_ctx pc;
-    pc.bins = NULL; pc.m = h.m; pc.np = np; pc.counts = NULL; pc.displs = NULL;
+    /* This rank's byte range is tokenised ONCE, by several threads (sub-ranges cut at line ends; the ranks of a node share
+     * its cores: BICG_MTX_THREADS, else the cores this process may use / ranks, at most 16), into lists that keep every
+     * triplet; lists in thread order = file order of the range. The non-zero balanced cuts are computed from those lists
+     * (one all-reduce of the per-row counts), then the triplets are packed by owner for the exchange. */
+    tseg *segs = NULL;
+    int nseg = 0;
+    if (p < q) {
+        long nt = loader_threads((size_t)(q - p));
+        if (!getenv("BICG_MTX_THREADS")) { nt /= np; if (nt < 1) nt = 1; }
+        const unsigned long banner_nz = h.nz;
+        h.nz = (unsigned long)-1;                       /* a byte range has no entry count of its own */
+        rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);
+        h.nz = banner_nz;
+    } else {
+        h.emitted = 0;
+    }
+    free(buf);
+    {   /* a malformed range must stop every rank, not leave the others in the collectives below */
+        int any = rc;
+        MPI_Allreduce(MPI_IN_PLACE, &any, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+        if (any) { for (int i = 0; i < nseg; ++i) free(segs[i].t); free(segs); return any; }
+    }
+    const int *pcounts = NULL, *pdispls = NULL;
     if (part == BICG_PART_NNZ) {
-        /* non-zeros per row: every rank counts its byte range, one all-reduce, same cuts everywhere */
         unsigned *cnt = (unsigned *)calloc(h.m ? h.m : 1, sizeof(unsigned));
-        if (p < q) rc = parse_entries(p, q, &h, (unsigned long)-1, emit_count, cnt);
+        for (int sg = 0; sg < nseg; ++sg)
+            for (size_t e = 0; e < segs[sg].n; ++e) cnt[segs[sg].t[e].r]++;
         MPI_Allreduce(MPI_IN_PLACE, cnt, (int)h.m, MPI_UNSIGNED, MPI_SUM, MPI_COMM_WORLD);
         bicg_partition_nnz(cnt, (unsigned)h.m, np, info->recvcounts, info->displs);
         free(cnt);
-        pc.counts = info->recvcounts; pc.displs = info->displs;
-    }
-    /* the ranks of a node share its cores: BICG_MTX_THREADS, else (cores this process may use) / ranks, at most 16 */
-    long nt = 1;
-    if (p < q) {
-        nt = loader_threads((size_t)(q - p));
-        if (!getenv("BICG_MTX_THREADS")) { nt /= np; if (nt < 1) nt = 1; }
-    }
-    par_job *jobs = (par_job *)calloc((size_t)nt, sizeof(par_job));
-    {
-        const size_t blen = p < q ? (size_t)(q - p) : 0;
-        const char *cut = p;
-        for (long t = 0; t < nt; ++t) {
-            const char *sub_end = t == nt - 1 ? q : p + blen * (size_t)(t + 1) / (size_t)nt;
-            if (sub_end < cut) sub_end = cut;
-            while (sub_end < q && sub_end > cut && sub_end[-1] != '\n') ++sub_end;
-            jobs[t].p = cut; jobs[t].end = sub_end; jobs[t].h = h; jobs[t].pc = pc;
-            jobs[t].pc.bins = (tvec *)calloc((size_t)np, sizeof(tvec));
-            cut = sub_end;
-        }
-    }
-    if (!rc) run_threads(nt, par_job_run, jobs, sizeof(par_job));
-    h.emitted = 0;
-    for (long t = 0; t < nt; ++t) { if (jobs[t].rc) rc = jobs[t].rc; h.emitted += jobs[t].h.emitted; }
-    free(buf);
-    if (rc) {
-        for (long t = 0; t < nt; ++t) { for (int r = 0; r < np; ++r) free(jobs[t].pc.bins[r].t); free(jobs[t].pc.bins); }
-        free(jobs);
-        return rc;
+        pcounts = info->recvcounts; pdispls = info->displs;
     }
     {   /* see the serial loader: nz = entries actually emitted, over all byte ranges */
-        unsigned long long tot = p < q ? h.emitted : 0ull;
+        unsigned long long tot = h.emitted;
         MPI_Allreduce(MPI_IN_PLACE, &tot, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
         info->nz = (unsigned)tot;
         if (h.symmetric && me == 0)
@@ -797,13 +770,17 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
      * (> 2^31 entries to or from one rank) the int-based MPI interface cannot express the exchange at all */
     int *scnt = (int *)malloc(sizeof(int) * np), *sdsp = (int *)malloc(sizeof(int) * np);
     int *rcnt = (int *)malloc(sizeof(int) * np), *rdsp = (int *)malloc(sizeof(int) * np);
+    size_t *to = (size_t *)calloc((size_t)np, sizeof(size_t));
+    for (int sg = 0; sg < nseg; ++sg)
+        for (size_t e = 0; e < segs[sg].n; ++e) {
+            const unsigned long r = segs[sg].t[e].r;
+            to[pcounts ? owner_in(r, pcounts, pdispls, np) : owner_of(r, h.m, np)]++;
+        }
     size_t stot = 0;
     int too_big = 0;
     for (int r = 0; r < np; ++r) {
-        size_t to_r = 0;
-        for (long t = 0; t < nt; ++t) to_r += jobs[t].pc.bins[r].n;
-        if (to_r > (size_t)INT_MAX || stot > (size_t)INT_MAX) too_big = 1;
-        scnt[r] = (int)to_r; sdsp[r] = (int)stot; stot += to_r;
+        if (to[r] > (size_t)INT_MAX || stot > (size_t)INT_MAX) too_big = 1;
+        scnt[r] = (int)to[r]; sdsp[r] = (int)stot; stot += to[r];
     }
     MPI_Alltoall(scnt, 1, MPI_INT, rcnt, 1, MPI_INT, MPI_COMM_WORLD);
     size_t rtot = 0;
@@ -811,25 +788,23 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     MPI_Allreduce(MPI_IN_PLACE, &too_big, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
     if (too_big) {
         if (me == 0) fprintf(stderr, "ERROR: bicg_mtx: more than 2^31 entries to or from one rank: use more ranks or the serial loader\n");
-        for (long t = 0; t < nt; ++t) { for (int r = 0; r < np; ++r) free(jobs[t].pc.bins[r].t); free(jobs[t].pc.bins); }
-        free(jobs); free(scnt); free(sdsp); free(rcnt); free(rdsp);
+        for (int i = 0; i < nseg; ++i) free(segs[i].t);
+        free(segs); free(to); free(scnt); free(sdsp); free(rcnt); free(rdsp);
         return 7;
     }
     MPI_Datatype trip;
     MPI_Type_contiguous((int)sizeof(triplet), MPI_BYTE, &trip);
     MPI_Type_commit(&trip);
     triplet *sbuf = (triplet *)malloc(sizeof(triplet) * (stot ? stot : 1)), *rbuf = (triplet *)malloc(sizeof(triplet) * (rtot ? rtot : 1));
-    for (int r = 0; r < np; ++r) {
-        size_t at = (size_t)sdsp[r];
-        for (long t = 0; t < nt; ++t) {          /* thread order = file order inside this rank's byte range */
-            const tvec *bin = &jobs[t].pc.bins[r];
-            if (bin->n) memcpy(sbuf + at, bin->t, sizeof(triplet) * bin->n);
-            at += bin->n;
-            free(bin->t);
+    for (int r = 0; r < np; ++r) to[r] = (size_t)sdsp[r];              /* cursors: lists walked in order = file order per owner */
+    for (int sg = 0; sg < nseg; ++sg) {
+        for (size_t e = 0; e < segs[sg].n; ++e) {
+            const unsigned long r = segs[sg].t[e].r;
+            sbuf[to[pcounts ? owner_in(r, pcounts, pdispls, np) : owner_of(r, h.m, np)]++] = segs[sg].t[e];
         }
+        free(segs[sg].t);
     }
-    for (long t = 0; t < nt; ++t) free(jobs[t].pc.bins);
-    free(jobs);
+    free(segs); free(to);
     MPI_Alltoallv(sbuf, scnt, sdsp, trip, rbuf, rcnt, rdsp, trip, MPI_COMM_WORLD);
     MPI_Type_free(&trip);
     free(sbuf);
