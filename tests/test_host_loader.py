@@ -431,7 +431,10 @@ def test_loader_against_the_reference_loader_itself(tmp_path, world):
         for k, (i, j, v) in enumerate(zip(row.tolist(), col.tolist(), val.tolist())):
             f.write(f"{i + 1} {j + 1} {v!r}\n" if k % 3 else f"{i + 1}  {j + 1}\t{v:.16e}\n")
     ref = str(tmp_path / "ref")
-    subprocess.run([MPIEXEC, "-n", str(world), REF_DUMP, mtx, "blocks", ref], check=True, timeout=300)
+    done = subprocess.run([MPIEXEC, "-n", str(world), REF_DUMP, mtx, "blocks", ref], capture_output=True, text=True, timeout=300)
+    if done.returncode != 0 and "unknown method" in done.stderr:
+        pytest.skip("oracle/_ref/ref_dump predates the 'blocks' mode: rebuild with make -C oracle")
+    assert done.returncode == 0, done.stderr[-400:]
     for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "1"), ("mpi", "3")):
         if mode == "mpi" and world == 1:
             continue
