@@ -141,3 +141,51 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
         want = [np.linalg.norm(b - (ctx.spmv(X[j]) + sigma[j] * X[j])) / np.linalg.norm(b) for j in range(nvec)]
         np.testing.assert_allclose(r1, want, rtol=1e-12)
     ctx.close()
+
+
+@pytest.mark.gpu
+def test_hip_shifted_dropin_symbols():
+    """The reference call surface of src/shifted_solver.h:16-21 itself -- the six functions on host CSR blocks and host
+    vectors, x_loc_set laid out [shift][row] -- not only the handle API the other tests use: every symbol returns the
+    iteration count and the bits of the corresponding bicg_solve_shifted call (same kernels underneath), the re-ordered
+    spellings of one algorithm agree with each other like the reference's do (fixtures: variants_bit_identical), and the
+    solution is the reference's to 1e-9."""
+    import ctypes as C
+    from mpi_bicgstab_amd import hipsolver as H
+    H.lib().bicg_comm_init_single(0)
+    g, A = _load(GOLDEN[0])          # 3001 rows, 16 shifts, seed 7
+    sigma = np.ascontiguousarray(g["sigma"], dtype=np.float64)
+    seed = int(g["seed"])
+    ctx = H.Context(H.single_rank_blocks(A))
+    want = {"lop": ctx.solve_shifted(g["b"], sigma, seed, which="shifted_lopbicgstab"),
+            "pipe": ctx.solve_shifted(g["b"], sigma, seed, which="shifted_pipe_lopbicgstab"),
+            "xi": ctx.solve_shifted(g["xi_b"], sigma, 0, which="shifted_bicgstab")}
+    ctx.close()
+    blocks = H.single_rank_blocks(A)
+    dp = C.POINTER(C.c_double)
+    calls = [("shifted_lopbicgstab", "lop", "b", True), ("shifted_lopbicgstab_v2", "lop", "b", True),
+             ("shifted_lopbicgstab_nooverlap", "lop", "b", True), ("shifted_pipe_lopbicgstab", "pipe", "b", True),
+             ("shifted_pipe_lopbicgstab_nooverlap", "pipe", "b", True), ("shifted_bicgstab", "xi", "xi_b", False)]
+    os.environ["BICG_QUIET"] = "1"
+    try:
+        for name, key, rhs, has_seed in calls:
+            fn = getattr(H.lib(), name)
+            fn.restype = C.c_int
+            x = np.zeros(len(sigma) * A.rows)
+            r = np.array(g[rhs], dtype=np.float64)
+            args = [C.byref(blocks.diag), C.byref(blocks.offd), C.byref(blocks.info), x.ctypes.data_as(dp), r.ctypes.data_as(dp),
+                    sigma.ctypes.data_as(dp), C.c_int(len(sigma))]
+            if has_seed:
+                args.append(C.c_int(seed))
+            k = fn(*args)
+            w = want[key]
+            assert k == w["k"], (name, k, w["k"])
+            assert np.array_equal(x.reshape(len(sigma), A.rows), w["x"]) and np.array_equal(r, w["r"]), name
+    finally:
+        os.environ.pop("BICG_QUIET", None)
+        H.lib().bicg_dropin_release()
+    pre = {"lop": "", "pipe": "pipe_", "xi": "xi_"}
+    for key, w in want.items():
+        ref = g[pre[key] + "x"]
+        assert abs(w["k"] - int(g[pre[key] + "k"])) <= 2, key
+        assert np.abs(w["x"] - ref).max() <= 1e-8 * max(1.0, np.abs(ref).max()), key
