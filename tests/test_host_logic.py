@@ -326,3 +326,25 @@ def test_rccl_loaded_by_the_library_then_torch_exits_cleanly():
             "import torch\nprint('loaded both')\n" % ROOT)
     out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=600)
     assert out.returncode == 0 and "loaded both" in out.stdout, (out.returncode, out.stderr[-400:])
+
+
+def test_reference_shifted_driver_links_against_the_library():
+    """oracle/_ref/shifted_dropin: the reference's main_shifted.c (driver of BASELINE.json configs[4]) with its own
+    matrix.c / vector.c / mmio.c, the solver taken from libbicgstab_hip.so. Checked here without a GPU: it links, the only
+    solver symbol it imports is the one src/main_shifted.c:126 calls, and the library defines nothing that the
+    reference's own translation units define (no interposition of csr_*, my_*, MPI_csr_* by accident)."""
+    import subprocess
+    exe = os.path.join(ROOT, "oracle", "_ref", "shifted_dropin")
+    lib = os.path.join(ROOT, "mpi-bicgstab_amd", "libbicgstab_hip.so")
+    if not os.path.exists(exe):
+        pytest.skip("oracle/_ref not built (needs /root/reference at build time)")
+    und = subprocess.run(["nm", "-D", "--undefined-only", exe], capture_output=True, text=True, check=True).stdout
+    wanted = {ln.split()[-1] for ln in und.splitlines() if ln.split() and re.match(r"(shifted_|bicg|ca_bicg|pipe_bicg)", ln.split()[-1])}
+    assert wanted == {"shifted_lopbicg_switching"}, wanted
+    exported = subprocess.run(["nm", "-D", "--defined-only", lib], capture_output=True, text=True, check=True).stdout
+    lib_syms = {ln.split()[-1] for ln in exported.splitlines() if ln.split()}
+    assert "shifted_lopbicg_switching" in lib_syms
+    own = subprocess.run(["nm", "--defined-only", exe], capture_output=True, text=True, check=True).stdout
+    exe_syms = {ln.split()[-1] for ln in own.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TD"}
+    clash = {s for s in exe_syms & lib_syms if not s.startswith("_")}
+    assert not clash, clash
