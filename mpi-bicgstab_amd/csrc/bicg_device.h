@@ -298,6 +298,8 @@ struct SpmvArgs {
     int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
     int     xcd_map;        // sliced-ELL: XCD-contiguous order of the groups (workgroup b runs on XCD b % 8; measurement knob)
+    int     reverse;        // sliced-ELL: workgroup b takes group nlist - 1 - b. Consecutive products of a solve alternate
+                            // direction, so each starts on the part of the matrix the previous one left in the Infinity Cache
     HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only
     Finish  fin;            // a dot group of earlier kernels to finish in this launch (seq 0: none)
     Vecs    epi;            // launch_spmv_sell_epi: the vectors of the element-wise phase in the epilogue
@@ -346,9 +348,11 @@ struct PersistArgs {
     int xcd_map;                         // XCD-contiguous assignment of row ranges to workgroups
     unsigned long long *dbg;             // BICG_PERSIST_TRACE: 100 MHz time stamps of one row workgroup and the helper, [it][16]
 };
-void launch_pipe_persist(const PersistArgs &a, hipStream_t st);
-void launch_plain_persist(const PersistArgs &a, hipStream_t st);    // plain BiCGStab: three groups per iteration
-void launch_ca_persist(const PersistArgs &a, hipStream_t st);       // CA-BiCGStab: two groups per iteration
+// each returns hipSuccess or the reason the launch did not happen (launch error, workgroups cannot be co-resident): the
+// caller then runs the chunk with the multi-launch kernels
+hipError_t launch_pipe_persist(const PersistArgs &a, hipStream_t st);
+hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st);    // plain BiCGStab: three groups per iteration
+hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st);       // CA-BiCGStab: two groups per iteration
 unsigned persist_lds_bytes(const PersistArgs &a);
 constexpr unsigned kPersistMaxLds = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for (static part: < 1 KiB)
 

@@ -1408,6 +1408,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
     for (unsigned gi0 = bid; gi0 < a.nlist; gi0 += nblocks) {
         unsigned gi = gi0;
         if (a.xcd_map && !LL && nblocks == a.nlist && gi0 < (a.nlist / 8u) * 8u) gi = (gi0 % 8u) * (a.nlist / 8u) + gi0 / 8u;
+        if (a.reverse && !LL) gi = a.nlist - 1u - gi;
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);

@@ -16,6 +16,8 @@
 
 #include <cstdio>
 #include <cstdlib>
+#include <set>
+#include <utility>
 
 namespace bicg {
 
@@ -772,37 +774,54 @@ unsigned persist_lds_bytes(const PersistArgs &a)
                       8u * (size_t)a.max_runs + 8u * threads);
 }
 
-static void launch_persist(const PersistArgs &a, hipStream_t st, int method)
+// Returns hipSuccess, or why the launch did not happen (the caller falls back to the multi-launch iteration): launch errors
+// are ALWAYS looked at -- a persistent launch that silently failed would leave the solve at k = 0 --, and before a kernel's
+// first launch on a device the runtime is asked whether nwg + 1 workgroups of this size and LDS footprint can be resident
+// together (the workgroups spin-wait on each other: co-residency is a correctness condition, not a performance one).
+static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int method)
 {
     const unsigned lds = persist_lds_bytes(a);
     const dim3 g(a.nwg + 1u), b(64u * (a.spw + 1u));        // + the communication wavefront
-    auto go = [&](auto kernel, int slot) {
-        static bool raised[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
+    auto go = [&](auto kernel, int slot) -> hipError_t {
+        static std::set<std::pair<int, int>> ready;        // (device, instantiation)
+        int dev = 0;
+        (void)hipGetDevice(&dev);
         const int idx = slot * 4 + (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0);
-        if (!raised[idx]) {       // (the runtime answers "invalid argument" and launches with > 64 KiB of LDS all the same)
+        if (!ready.count({dev, idx})) {       // (the runtime answers "invalid argument" and launches with > 64 KiB of LDS all the same)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
             (void)hipGetLastError();
-            raised[idx] = true;
+            int per_cu = 0, cus = 0;
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&per_cu, kernel, (int)b.x, lds) == hipSuccess &&
+                hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) == hipSuccess) {
+                if (per_cu < 1 || (long long)per_cu * cus < (long long)g.x) {
+                    fprintf(stderr, "bicgstab_hip: persistent kernel: %u workgroups of %u threads with %u bytes of LDS cannot be co-resident "
+                                    "(%d per CU x %d CUs)\n", g.x, b.x, lds, per_cu, cus);
+                    return hipErrorCooperativeLaunchTooLarge;
+                }
+            } else {
+                (void)hipGetLastError();      // no answer: the launch itself will tell
+            }
+            ready.insert({dev, idx});
         }
         hipLaunchKernelGGL(kernel, g, b, lds, st, a);
+        return hipGetLastError();
     };
+    hipError_t err;
     if (method == 0) {
-        if (a.mat_entries) { if (a.multi) go(k_pipe_persist<true, true>, 0); else go(k_pipe_persist<true, false>, 0); }
-        else { if (a.multi) go(k_pipe_persist<false, true>, 0); else go(k_pipe_persist<false, false>, 0); }
+        if (a.mat_entries) { err = a.multi ? go(k_pipe_persist<true, true>, 0) : go(k_pipe_persist<true, false>, 0); }
+        else { err = a.multi ? go(k_pipe_persist<false, true>, 0) : go(k_pipe_persist<false, false>, 0); }
     } else if (method == 1) {
-        if (a.mat_entries) { if (a.multi) go(k_plain_persist<true, true>, 1); else go(k_plain_persist<true, false>, 1); }
-        else { if (a.multi) go(k_plain_persist<false, true>, 1); else go(k_plain_persist<false, false>, 1); }
+        if (a.mat_entries) { err = a.multi ? go(k_plain_persist<true, true>, 1) : go(k_plain_persist<true, false>, 1); }
+        else { err = a.multi ? go(k_plain_persist<false, true>, 1) : go(k_plain_persist<false, false>, 1); }
     } else {
-        if (a.mat_entries) { if (a.multi) go(k_ca_persist<true, true>, 2); else go(k_ca_persist<true, false>, 2); }
-        else { if (a.multi) go(k_ca_persist<false, true>, 2); else go(k_ca_persist<false, false>, 2); }
+        if (a.mat_entries) { err = a.multi ? go(k_ca_persist<true, true>, 2) : go(k_ca_persist<true, false>, 2); }
+        else { err = a.multi ? go(k_ca_persist<false, true>, 2) : go(k_ca_persist<false, false>, 2); }
     }
-    if (getenv("BICG_DEBUG")) {
-        const hipError_t err = hipGetLastError();
-        if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: HIP error \"%s\" noticed at: persistent kernel\n", hipGetErrorString(err));
-    }
+    if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: persistent kernel launch failed: %s\n", hipGetErrorString(err));
+    return err;
 }
-void launch_pipe_persist(const PersistArgs &a, hipStream_t st) { launch_persist(a, st, 0); }
-void launch_plain_persist(const PersistArgs &a, hipStream_t st) { launch_persist(a, st, 1); }
-void launch_ca_persist(const PersistArgs &a, hipStream_t st) { launch_persist(a, st, 2); }
+hipError_t launch_pipe_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 0); }
+hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 1); }
+hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 2); }
 
 }  // namespace bicg

@@ -77,6 +77,9 @@ struct bicg_ctx {
     short *d_col16 = nullptr;              // ... with CSR-order 16-bit column offsets when they fit
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
+    int spmv_dir = 0;                      // direction of the last sliced-ELL product (SpmvArgs::reverse)
+    int sell_alt = 0;                      // BICG_SELL_ALT: consecutive products alternate direction
+    int sell_xcd = 0;                      // BICG_SELL_XCD: XCD-contiguous group order (measurement knob, SpmvArgs::xcd_map)
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
     bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
     uint64_t matrix_bytes = 0;             // bytes one SpMV streams from the matrix arrays
@@ -498,8 +501,13 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
     // order): {sliced-ELL groups, CSR row blocks} x {interior, halo-touching}.
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
-    static const int xcd_map_env = getenv("BICG_SELL_XCD") ? atoi(getenv("BICG_SELL_XCD")) : 0;
-    a.xcd_map = xcd_map_env;
+    a.xcd_map = c->sell_xcd;
+    // Consecutive products of a solve run over the matrix in alternating directions (BICG_SELL_ALT=0: always forward): matrix +
+    // vectors of a Transport-sized system exceed the 256 MiB Infinity Cache by a quarter, so a product that starts where the
+    // previous one ended finds the most recently streamed part of the matrix still cached, while cyclic forward passes
+    // evict it just before it is needed. Rows, hence results of the product, are unaffected; the dot partials of a
+    // reversed launch land in mirrored slots (a different, equally fixed association).
+    a.reverse = (c->sell_alt && c->single() && !epi && !fw) ? (c->spmv_dir ^= 1) : 0;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
     const bool fused = c->p2p && c->ll_fused;
@@ -752,7 +760,7 @@ void group_flush(bicg_ctx *c)
 
 void fetch_scal(bicg_ctx *c);
 }  // namespace
-void persist_chunk(bicg_ctx *c, int niter);
+bool persist_chunk(bicg_ctx *c, int niter);
 namespace {
 
 // ---------------------------------------------------------------- the four iterations
@@ -966,6 +974,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     c->grp = bicg_ctx::Group{};
     c->f1_done = false;
     c->pl_flip = 0;
+    c->spmv_dir = 0;             // every solve starts with a forward product: run-to-run bit reproducibility
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -1072,7 +1081,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
     const int stop = std::min(o.max_iter, c->it + std::max(nsteps, 0));
     while (!c->hS->done && c->it < stop) {
         // (section marks are host-side events between launches: the multi-launch forms are what they can time)
-        const bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
+        bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
                              ((c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0) ||
                               ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain));
         // A persistent launch costs ~27 us of set-up (matrix slices and x window into LDS) and stops by itself at
@@ -1086,7 +1095,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
             c->adaptive_rr++;
         }
         sec_mark(c, SEC_VEC);
-        if (persist) persist_chunk(c, chunk);         // one launch for the whole chunk (bicg_persist.hip)
+        if (persist) persist = persist_chunk(c, chunk);   // one launch for the whole chunk (bicg_persist.hip); false: it could not be launched
         for (int j = 0; j < chunk && !persist; ++j) {
             // the last iteration before the caller (or the drift check) reads x / r leaves them as the reference would
             const bool last = j == chunk - 1 && (c->it + chunk >= stop || o.rr_drift > 0.0);
@@ -1781,7 +1790,7 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
 }
 
 // niter iterations of pipe_bicgstab in one launch (the open dot group has been closed: fetch_scal precedes every chunk)
-void persist_chunk(bicg_ctx *c, int niter)
+bool persist_chunk(bicg_ctx *c, int niter)
 {
     if (c->grp.active) die("internal", "persistent chunk with an open dot group");
     if (c->f1_done) die("internal", "persistent chunk after phase 1 of the next iteration has run");
@@ -1810,9 +1819,20 @@ void persist_chunk(bicg_ctx *c, int niter)
         BICG_HIP(hipMemset(dbg, 0, 64 * 16 * sizeof(unsigned long long)));
         a.dbg = dbg;
     }
-    if (plain) launch_plain_persist(a, c->sc);
-    else if (c->method == BICG_CA_BICGSTAB) launch_ca_persist(a, c->sc);
-    else launch_pipe_persist(a, c->sc);
+    hipError_t err;
+    if (plain) err = launch_plain_persist(a, c->sc);
+    else if (c->method == BICG_CA_BICGSTAB) err = launch_ca_persist(a, c->sc);
+    else err = launch_pipe_persist(a, c->sc);
+    if (err != hipSuccess) {
+        // nothing ran: hand the chunk back to the multi-launch kernels (every rank sees the same failure: same kernel, same
+        // plan limits; the sequence numbers reserved above are simply skipped on all of them)
+        if (dbg) (void)hipFree(dbg);
+        if (c->nranks > 1) die("persistent kernel", "launch failed on a multi-rank run (BICG_PERSIST=0 selects the multi-launch iteration)");
+        fprintf(stderr, "bicgstab_hip: falling back to the multi-launch iteration\n");
+        c->persist_on = false;
+        return false;
+    }
+    if (want_trace && c->method != BICG_PIPE_BICGSTAB) { BICG_HIP(hipStreamSynchronize(c->sc)); BICG_HIP(hipFree(dbg)); }
     if (want_trace && c->method == BICG_PIPE_BICGSTAB) {
         // 10 ns ticks of one row workgroup (0 start, 1 z and partials published, 2 window staged, 3 product done, 4 omega here,
         // 5 w and partials published, 6 window, 7 product, 8 scalars here) and of the helper (10 / 11: group 1 / 2 published)
@@ -1831,6 +1851,7 @@ void persist_chunk(bicg_ctx *c, int niter)
                 fprintf(stderr, "\n");
             }
     }
+    return true;
 }
 
 // vectors, reduction scratch and scalar blocks of a context whose plan (n_loc, halo, nblk) is known
@@ -1917,6 +1938,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
 
     bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
+    if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
@@ -2407,6 +2430,8 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     g_live.push_back(c);
     c->n_loc = rows; c->n_glob = rows; c->nnz_d = nnz;
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
+    if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
     c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;

@@ -194,6 +194,23 @@ def stencil7_nnz(m: int) -> int:
     return 7 * m ** 3 - 6 * m * m
 
 
+def stencil7_matvec(m: int, weights, x: np.ndarray) -> np.ndarray:
+    """y = A x for stencil7(m, weights) WITHOUT the matrix: every row's products added in stored (ascending column) order,
+    one rounding per product and per sum -- the arithmetic of the reference's mult() (src/matrix.c:506-515) without FMA,
+    so the result is bit-identical to it (a missing neighbour adds nothing; 0 + p = p). Grid-sized temporaries only:
+    this is how the 512^3 SpMV (134 M rows; no CPU oracle run fits a test) is checked."""
+    X = np.ascontiguousarray(x, dtype=np.float64).reshape(m, m, m)      # [z][y][x]
+    Y = np.zeros_like(X)
+    Y[1:, :, :] += weights[5] * X[:-1, :, :]        # z-   (column - m^2)
+    Y[:, 1:, :] += weights[3] * X[:, :-1, :]        # y-   (column - m)
+    Y[:, :, 1:] += weights[1] * X[:, :, :-1]        # x-   (column - 1)
+    Y += weights[0] * X                             # centre
+    Y[:, :, :-1] += weights[2] * X[:, :, 1:]        # x+
+    Y[:, :-1, :] += weights[4] * X[:, 1:, :]        # y+
+    Y[:-1, :, :] += weights[6] * X[1:, :, :]        # z+
+    return Y.reshape(-1)
+
+
 def random_rows(n: int, max_row: int, seed: int = 1, empty_frac: float = 0.1, long_rows=()) -> CSR:
     """Ragged test matrix: random row lengths in [0, max_row], some empty rows, optional very long
     rows (row index -> length); diagonal made dominant where present."""

@@ -255,6 +255,10 @@ def fullsize_worker(rank, world, port, kind, outdir):
         assert flags["p2p"] == p2p
         if p2p:
             assert flags["ll_fused"], "banded slab: the halo exchange must be folded into the SpMV launch"
+        if "expect_persist" in ref and int(ref["expect_persist"]):
+            # ranks small enough for one persistent launch per chunk of iterations (bicg_persist.hip) AND with neighbours:
+            # halo pushes by the communication wavefronts, window loads from the landing ring, sums through the mailboxes
+            assert flags["persist"] and info["halo"] > 0 and p2p, (flags, info)
         # distributed SpMV: every row bit for bit; enough back-to-back exchanges to wrap the landing ring
         for rep in range(11 if p2p else 2):
             x = ref["x_in"] * (1.0 + 0.125 * rep)
@@ -286,6 +290,19 @@ def fullsize_worker(rank, world, port, kind, outdir):
             relres = np.sqrt(got["result"].dot_r / got["result"].dot_zero)
             assert relres <= tol, (method, relres)
             assert np.abs(got["x"] - 1.0).max() <= 3.0 * float(ref[f"{method}_conv_err"]), (method, np.abs(got["x"] - 1.0).max())
+        # BASELINE.json configs[4] across ranks: 16 shifts, seed 7 (reference src/shifted_solver.c:257-319, 794-848); the oracle's
+        # seed scalars and a few of its x_j come from the parent
+        for which in ([str(m) for m in ref["shifted_methods"]] if "shifted_methods" in ref else []):
+            sigma, seed = ref["shifted_sigma"], int(ref["shifted_seed"])
+            bs = b + sigma[seed] * np.ones(nl)
+            got = ctx.solve_shifted(bs, sigma, seed, tol=0.0, max_iter=k_fix, check_every=k_fix, which=which)
+            assert got["k"] == k_fix, (which, got["k"])
+            tr = ctx.trace(k_fix)
+            for key in ("alpha", "omega", "beta", "dotr"):
+                np.testing.assert_allclose(tr[key], ref[f"{which}_{key}"], rtol=1e-7, err_msg=f"{which} {key}")
+            for j in ref["shifted_sel"]:
+                xo = ref[f"{which}_x{int(j)}"]
+                assert np.abs(got["x"][int(j)] - xo[lo:lo + nl]).max() <= 1e-8 * np.abs(xo).max(), (which, int(j))
         assert not ctx.comm_failed()
         ctx.close()
         dist.barrier()

@@ -136,3 +136,22 @@ def test_config5_as_benchmarked(which):
     want = np.array([np.linalg.norm(O.spmv(A.rows, row, col, val, orc["x"][j]) + sigma[j] * orc["x"][j] - b) / nb for j in range(nsh)])
     np.testing.assert_allclose(rel, want, rtol=1e-6)
     ctx.close()
+
+
+def test_transport_rank_of_8_as_benchmarked():
+    """extras.transport_rank_of_8 (BASELINE.json configs[2]: what ONE of 8 GPUs holds): bench.py build("transport", n=(N+7)//8)
+    = 200 264 rows. This size takes the LDS-resident instantiation of the persistent kernels (k_pipe_persist / k_plain_persist /
+    k_ca_persist<LDSMAT = true>: 241 workgroups, matrix slices + window in 155 KB of LDS) -- the `persist` flag is asserted,
+    and the first 12 iterations of the three solvers that have the form against the oracle's trajectory (reference
+    src/solver.c:351-398, 86-120, 216-251); pipe_bicgstab_rr runs through its own one-launch form with replacement steps
+    (krr = 5)."""
+    H.lib().bicg_comm_init_single(0)
+    n8 = (synth.TRANSPORT_N + 7) // 8
+    A = synth.transport_like(n=n8, scale_decades=SCALE)
+    coo = A.to_coo()
+    ctx = H.Context(H.single_rank_blocks(A))
+    fl = ctx.flags()
+    assert fl["persist"] and fl["all_sell"] and fl["col16"], fl
+    _spmv_check(ctx, A, coo, seed=8)
+    _trajectory_check(ctx, A, coo, ("pipe_bicgstab", "bicgstab", "ca_bicgstab", "pipe_bicgstab_rr"))
+    ctx.close()

@@ -255,7 +255,9 @@ def test_device_side_plan_matches_host_plan():
     to the oracle (hence to the host-planned context), CA-BiCGStab on the oracle's trajectory; the non-symmetric test
     weights too (every one of the seven positions carries its own value)."""
     H.lib().bicg_comm_init_single(0)
-    for m, weights in ((96, synth.LAPLACE_WEIGHTS), (33, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0))):
+    # m = 192: m^2 = 36 864 > 32 767, the z neighbours need 32-BIT columns -- the branch the 512^3 bench leg takes
+    # (the two smaller grids take the packed 16-bit offsets)
+    for m, weights in ((96, synth.LAPLACE_WEIGHTS), (33, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)), (192, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0))):
         A = synth.stencil7(m, weights)
         row, col, val = A.to_coo()
         ctx, nnz, plan_s, gen_s = H.Context.stencil7_on_device(m, weights)
@@ -266,6 +268,7 @@ def test_device_side_plan_matches_host_plan():
             assert pi[key] == pr[key], (key, pi, pr)
         assert ctx.flags() == ref.flags() or {k: v for k, v in ctx.flags().items() if k != "persist"} == {k: v for k, v in ref.flags().items() if k != "persist"}
         assert ctx.device_matrix_bytes() <= ref.device_matrix_bytes() + 8 * A.rows + 64
+        assert ctx.flags()["col16"] == ref.flags()["col16"] == (m * m <= 32767), (m, ctx.flags())
         x = np.random.default_rng(m).standard_normal(A.rows)
         y = ctx.spmv(x)
         assert np.array_equal(y, O.spmv(A.rows, row, col, val, x)) and np.array_equal(y, ref.spmv(x))
@@ -278,3 +281,37 @@ def test_device_side_plan_matches_host_plan():
         assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
         print(f"stencil {m}^3: generated on the device in {gen_s:.3f} s, planned in {plan_s:.3f} s")
         ctx.close(); ref.close()
+
+
+def test_laplace512_device_plan_at_bench_size():
+    """BASELINE.json configs[3] at its stated size, the very calls of bench.py's laplace512(): 134 M rows / 938 M non-zeros
+    generated and planned on the GPU with 32-bit columns. No CPU oracle run fits a test at this size, so the SpMV is compared
+    with the CLOSED FORM of the stencil (synth.stencil7_matvec: stored-order sums without FMA, bit-identical to the oracle's
+    mult() -- tests/test_host_logic.py) -- every one of the seven positions with its own weight -- and the solvers through
+    size-independent properties: b = A 1 vanishes in the interior, after 6 iterations of CA-BiCGStab and plain BiCGStab the
+    TRUE residual b - A x (closed form) equals the recursive one, and the (r,r) the device reports is that of the r it
+    returns (reference src/solver.c:160-278, 35-146; src/matrix.c:498-516)."""
+    H.lib().bicg_comm_init_single(0)
+    m = 512
+    n = m ** 3
+    w = (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)
+    ctx, nnz, plan_s, gen_s = H.Context.stencil7_on_device(m, w)
+    assert nnz == synth.stencil7_nnz(m) and ctx.plan_info()["sell_rows"] == n and not ctx.flags()["col16"]
+    x = np.random.default_rng(512).standard_normal(n)
+    assert np.array_equal(ctx.spmv(x), synth.stencil7_matvec(m, w, x))           # 134 M rows, bit for bit
+    ctx.close()
+    ctx, nnz, plan_s, gen_s = H.Context.stencil7_on_device(m, synth.LAPLACE_WEIGHTS)
+    ones = np.ones(n)
+    b = ctx.spmv(ones)
+    assert np.array_equal(b, synth.stencil7_matvec(m, synth.LAPLACE_WEIGHTS, ones))
+    assert np.all(b.reshape(m, m, m)[1:-1, 1:-1, 1:-1] == 0.0) and b.reshape(m, m, m)[0, 0, 0] == 3.0
+    nb = float(np.sqrt(b @ b))
+    for method in ("ca_bicgstab", "bicgstab"):
+        got = ctx.solve(method, b, tol=0.0, max_iter=6, check_every=6)
+        assert got["k"] == 6 and got["result"].breakdown_iteration == 0
+        true_r = b - synth.stencil7_matvec(m, synth.LAPLACE_WEIGHTS, got["x"])
+        assert float(np.sqrt(((true_r - got["r"]) ** 2).sum())) <= 1e-12 * nb, method
+        rr = float(got["r"] @ got["r"])
+        assert abs(got["result"].dot_r - rr) <= 1e-12 * rr and 0.0 < rr < float(b @ b), method
+    print(f"stencil 512^3: generated on the device in {gen_s:.3f} s, planned in {plan_s:.3f} s")
+    ctx.close()

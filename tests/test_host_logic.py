@@ -348,3 +348,18 @@ def test_reference_shifted_driver_links_against_the_library():
     exe_syms = {ln.split()[-1] for ln in own.splitlines() if len(ln.split()) == 3 and ln.split()[1] in "TD"}
     clash = {s for s in exe_syms & lib_syms if not s.startswith("_")}
     assert not clash, clash
+
+
+def test_stencil7_closed_form_is_the_oracles_spmv():
+    """synth.stencil7_matvec (no matrix: shifted grid views, stored-order sums) is bit-identical to the oracle's mult() on
+    the assembled stencil -- the checker of the 512^3 legs, where no CPU oracle run fits (tests/test_full_size.py)"""
+    import oracle_lib as O
+    from mpi_bicgstab_amd import synth
+    for m, w in ((12, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)), (17, synth.LAPLACE_WEIGHTS), (2, (3.0, 1.0, 2.0, 4.0, 5.0, 6.0, 7.0))):
+        A = synth.stencil7(m, w)
+        row, col, val = A.to_coo()
+        for seed in (0, 1):
+            x = np.random.default_rng(seed + m).standard_normal(A.rows)
+            assert np.array_equal(synth.stencil7_matvec(m, w, x), O.spmv(A.rows, row, col, val, x))
+        ones = synth.stencil7_matvec(m, synth.LAPLACE_WEIGHTS, np.ones(m ** 3)).reshape(m, m, m)
+        assert np.all(ones[1:-1, 1:-1, 1:-1] == 0.0) and ones[0, 0, 0] == 3.0      # b = A 1: zero in the interior

@@ -33,6 +33,23 @@ def matrix():
 _oracle_cache = {}
 
 
+def shifted_outputs(out, A, coo, world):
+    """config 5 across ranks: 16 shifts sigma_j = (j+1) 0.01/16, seed 7 (bench.py's leg; reference src/main_shifted.c:99 pattern)"""
+    row, col, val = coo
+    nsh, seed = 16, 7
+    sigma = (np.arange(nsh) + 1.0) * 0.01 / nsh
+    out["shifted_methods"] = np.array(["shifted_lopbicgstab", "shifted_pipe_lopbicgstab"])
+    out["shifted_sigma"], out["shifted_seed"], out["shifted_sel"] = sigma, seed, np.array([0, 7, 15])
+    bs = out["b"] + sigma[seed] * np.ones(A.rows)
+    for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab"):
+        orc = O.solve_shifted(A.rows, row, col, val, bs, sigma, seed, nranks=world, tol=0.0, max_iter=K_FIX, which=which)
+        assert orc["k"] == K_FIX
+        for key in ("alpha", "omega", "beta", "dotr"):
+            out[f"{which}_{key}"] = orc[key]
+        for j in (0, 7, 15):
+            out[f"{which}_x{j}"] = orc["x"][j]
+
+
 def oracle_outputs(matrix, world):
     """one CPU run of the oracle per rank count (its dot products associate per rank, src/solver.c:89-91)"""
     if world in _oracle_cache:
@@ -61,6 +78,7 @@ def oracle_outputs(matrix, world):
             ks = [gold["runs"][f"{method}_P{P}"]["k"] for P in (1, 2, 4, 8)]
             out[f"{method}_conv_kmin"], out[f"{method}_conv_kmax"] = min(ks), max(ks)
             out[f"{method}_conv_err"] = max(gold["runs"][f"{method}_P{P}"]["max_err_vs_ones"] for P in (1, 2, 4, 8))
+        shifted_outputs(out, A, (row, col, val), world)
     _oracle_cache[world] = out
     return out
 
@@ -70,8 +88,8 @@ def oracle_outputs(matrix, world):
 def test_fullsize_partition_against_oracle(matrix, world, kind):
     with tempfile.TemporaryDirectory() as td:
         out = dict(oracle_outputs(matrix, world))
-        if kind != "host-p2p":        # the runs to convergence (8 ranks time-slicing one GPU: ~1 minute) once, on the production data path
-            out = {k: v for k, v in out.items() if "conv" not in k}
+        if kind != "host-p2p":        # the runs to convergence (8 ranks time-slicing one GPU: ~1 minute) and the 16-shift leg once, on the production data path
+            out = {k: v for k, v in out.items() if "conv" not in k and "shifted" not in k}
         np.savez(os.path.join(td, "oracle.npz"), **out)
         mp.start_processes(W.fullsize_worker, args=(world, _free_port(), kind, td), nprocs=world, join=True,
                            start_method="spawn")
@@ -96,6 +114,35 @@ def test_laplace7_slabs_8_ranks_ca_bicgstab():
         orc = O.solve(method, A.rows, row, col, val, out["b"], nranks=world, tol=0.0, max_iter=K_FIX)
         for key in ("alpha", "omega", "beta", "dotr", "x"):
             out[f"{method}_{key}"] = orc[key]
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "oracle.npz"), **out)
+        mp.start_processes(W.fullsize_worker, args=(world, _free_port(), "host-p2p", td), nprocs=world, join=True, start_method="spawn")
+        fails = glob.glob(os.path.join(td, "fail*"))
+        assert not fails, open(fails[0]).read()
+        assert len(glob.glob(os.path.join(td, "ok*"))) == world
+
+
+def test_two_small_ranks_persistent_with_halo():
+    """The form an 8-GPU run of BASELINE.json configs[2] takes -- ONE persistent launch per chunk of iterations with the
+    neighbours' halo values arriving as LL words in the landing ring and the dot sums crossing the mailboxes -- at a rank size
+    the one-GPU box can hold TWICE: two processes x 100 132 rows of a 200 264-row Transport-shaped matrix (each fits the 127
+    workgroups a rank gets when two share the 256 CUs; the 8-rank full-size tests above get 31 and fall back to the two-launch
+    form). `persist` AND halo > 0 asserted on both ranks; distributed SpMV bit-exact, the first 12 iterations of all four
+    solvers and of the two 16-shift solvers against the oracle at P = 2 (reference src/matrix.c:428-441, src/solver.c:351-398,
+    src/shifted_solver.c:257-319)."""
+    world = 2
+    n = (synth.TRANSPORT_N + 7) // 8
+    A = synth.transport_like(n=n, scale_decades=SCALE_DECADES)
+    row, col, val = A.to_coo()
+    out = dict(n=n, k_fix=K_FIX, scale_decades=SCALE_DECADES, expect_persist=1)
+    out["x_in"] = np.random.default_rng(31).standard_normal(n)
+    out["y"] = O.spmv(n, row, col, val, out["x_in"], nranks=world)
+    out["b"] = O.spmv(n, row, col, val, np.ones(n), nranks=world)
+    for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
+        orc = O.solve(method, n, row, col, val, out["b"], nranks=world, tol=0.0, max_iter=K_FIX, krr=5, nrr=1)
+        for key in ("alpha", "omega", "beta", "dotr", "x"):
+            out[f"{method}_{key}"] = orc[key]
+    shifted_outputs(out, A, (row, col, val), world)
     with tempfile.TemporaryDirectory() as td:
         np.savez(os.path.join(td, "oracle.npz"), **out)
         mp.start_processes(W.fullsize_worker, args=(world, _free_port(), "host-p2p", td), nprocs=world, join=True, start_method="spawn")
