@@ -53,6 +53,7 @@ enum Phase : int {
     PH_SW_END,      // red[0]=(r,r), red[1]=(r#,r): beta archive[k]; eta, pi, alpha_j, omega_j, the
                     // update coefficients, zeta, beta_j of every active shift                       (:416-446)
     PH_SW_STOP,     // no sums: stop flags, largest |1/(zeta pi)|, k++, seed switching (pauses)      (:451-536)
+    PH_DRIFT,       // persistent kernels: red[0]=||(b - A x) - r||^2, red[1]=||r||^2: replacement iteration next?
 };
 
 enum ShiftMode : int {
@@ -101,6 +102,11 @@ struct Scal {
     int    comm_error;           // peer-to-peer transport: a wait for a peer timed out (sets done as well)
     int    paused;               // seed switching: done was raised only to hand control to the host (new seed pointers)
 };
+// A persistent pipelined launch (bicg_persist.hip) reports what it consumed and decided in the three slots of Scal::red no dot
+// group uses (the block itself must not grow: every consumer-side kernel holds a private copy of it):
+constexpr int kRedUsedV = 5;     // hand-offs (image tags, halo exchange numbers)
+constexpr int kRedUsedG = 6;     // dot groups (table tags, mailbox numbers)
+constexpr int kRedAdaptive = 7;  // replacement iterations the in-kernel drift check asked for
 
 // Direct peer-to-peer transport (bicg_p2p.cpp). Values travel as "LL" words -- 8 bytes holding 32
 // payload bits and the 32-bit sequence number of the operation, written with ONE store into
@@ -193,6 +199,7 @@ struct Launch {
     Scal *S;
     Finish fin;
     hipStream_t st;
+    int rev = 0;         // element-wise kernels (ticket mode): sweep the vectors from the end (Infinity-Cache reuse, see SpmvArgs::reverse)
 };
 
 struct CsrDev {
@@ -317,7 +324,8 @@ struct SpmvArgs {
 // alpha / beta / omega / done). Halo values of other ranks arrive in the landing ring as LL words exactly as in the
 // multi-launch path and are read by the same window loads.
 struct PersistArgs {
-    uint32_t nrows, nslices, nwg, spw;   // nwg row workgroups (+ 1 helper) of 64 * spw threads
+    uint32_t nrows, nslices, nwg, spw;   // nwg row workgroups (+ 1 helper) of 64 * (spw + 1) threads: spw row wavefronts ...
+    uint32_t rpt;                        // ... whose threads own rpt rows each: a workgroup holds spw * rpt consecutive slices
     // matrix, padded slices with diag entries first, then offd entries (x_ext numbering): entry k of lane l of slice s
     // at pbase[s] + k * 64 + l; pslot = slot of the entry's column in the workgroup's window
     const double         *pval;
@@ -328,14 +336,21 @@ struct PersistArgs {
     const uint2    *win_runs;            // {first column (>= nrows: halo position + nrows), (first slot << 16) | length}
     uint32_t win_slots, max_runs;        // LDS doubles of the largest window; most runs of one workgroup
     uint32_t mat_entries;                // > 0: the workgroup's matrix entries are copied into LDS (at most this many)
-    llword *llv[2];                      // [nrows][2] local LL images of z and w
+    llword *llv[4];                      // [nrows][2] local LL images of the vectors handed over (2 and 3: replacement iterations)
     llword *dtab[2];                     // [nwg][kRedSlots][2] dot partials of the two groups
     llword *arow[2];                     // [4][2] applied scalars after each group: alpha, beta, omega, done
-    unsigned seq0;                       // tags of this launch: seq0 + 2 it + 1 (z group), + 2 (w group)
+    unsigned seq0;                       // table tags of this launch: group g (1, 2, ...) carries seq0 + g
+    unsigned vseq0;                      // pipelined kernel: hand-off n (1, 2, ...) carries image tag vseq0 + n
     int niter;
+    // pipelined kernel: residual replacement (src/solver.c:494-548) inside the launch
+    int it0;                             // iterations completed before this launch (the reference's k)
+    int krr, nrr;                        // pipe_bicgstab_rr's schedule: k % krr == 0, 0 < k <= krr nrr (krr = 0: none)
+    int force_first;                     // the first iteration of this launch is a replacement iteration
+    int drift_every;                     // > 0: every drift_every iterations compare b - A x with r (adaptive replacement) ...
+    double drift_tol2;                   // ... and replace when ||(b - A x) - r||^2 > drift_tol2 ||r||^2
     // halo (multi rank, peer-to-peer transport)
     int multi;
-    const llword *ring; uint32_t halo; unsigned halo_seq0;        // exchange numbers halo_seq0 + 2 it + 1 / + 2
+    const llword *ring; uint32_t halo; unsigned halo_seq0;        // exchange numbers halo_seq0 + 1, + 2, ...
     const uint32_t *snd_ptr;             // [nwg + 1] send-list entries of workgroup g
     const unsigned short *snd_row;       // row within the workgroup
     const unsigned long long *snd_dst0, *snd_stride;

@@ -1512,7 +1512,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         }                                                                                                 \
         have = true;                                                                                      \
     } while (0)
-    for (unsigned gi = bid; gi < a.nlist; gi += nblocks) {
+    for (unsigned gi0 = bid; gi0 < a.nlist; gi0 += nblocks) {
+        const unsigned gi = (a.reverse && !LL) ? a.nlist - 1u - gi0 : gi0;
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
@@ -2352,8 +2353,13 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
         if (S->done) return;
         __shared__ double sm[5 * ND];
         f.load(S);
-        for (uint32_t i = i0; i < npair; i += stride) f.template apply<d2>(2 * i, acc);
-        if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
+        // ticket modes: bit 31 of n = sweep the vectors from the end (Launch::rev; the sign bit instead of one more kernel
+        // argument, which cost the consumer-side instantiations four registers and a wave per SIMD)
+        const bool rev = (n >> 31) != 0u;
+        const uint32_t nn = n & 0x7fffffffu, np = nn >> 1;
+        if (rev) { for (uint32_t i = i0; i < np; i += stride) f.template apply<d2>(2 * (np - 1u - i), acc); }
+        else { for (uint32_t i = i0; i < np; i += stride) f.template apply<d2>(2 * i, acc); }
+        if ((nn & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(nn - 1, acc);
         if (F::ND > 0) reduce_publish<ND, MODE == RED_TICKET_HEAVY>(acc, S, red, blockIdx.x, sm);
     }
 }
@@ -2384,6 +2390,7 @@ static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
     red.slot_base = 0;
     constexpr int modes = vec_modes<F>::value;
     const int mode = modes == kWaveOnly ? RED_WAVE : red_mode(red, L.fin, F::ND > 0);
+    const uint32_t nrev = L.rev ? (n | 0x80000000u) : n;      // ticket modes only (k_vec)
     if (!((modes >> mode) & 1)) {
         fprintf(stderr, "ERROR: bicgstab_hip: element-wise kernel launched in reduction mode %d it is not built for\n", mode);
         abort();
@@ -2391,9 +2398,9 @@ static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
     if constexpr ((modes >> RED_WAVE) & 1)
         if (mode == RED_WAVE) { BICG_LAUNCH((k_vec<F, RED_WAVE>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
     if constexpr (((modes >> RED_TICKET_HEAVY) & 1) && F::ND > 0)
-        if (mode == RED_TICKET_HEAVY) { BICG_LAUNCH((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+        if (mode == RED_TICKET_HEAVY) { BICG_LAUNCH((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, nrev, L.S, red, L.fin); return; }
     if constexpr ((modes >> RED_TICKET) & 1)
-        BICG_LAUNCH((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin);
+        BICG_LAUNCH((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, nrev, L.S, red, L.fin);
 }
 // shifted solvers and kernel-level entry points: scalar block updated in place, ticket reductions
 template <class F>

@@ -32,6 +32,8 @@ struct PersistLds {
     double sc[4];                         // alpha, beta, omega, done as received
     double pv[kRedSlots * kMaxRanksP2p];  // helper, multi rank: every rank's sums
     int    fail;
+    int    drift_flag;                    // helper: the drift group just applied asks for a replacement iteration
+    int    adaptive;                      // helper: replacement iterations asked for by the drift check in this launch
 };
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also waits for the wavefront's outstanding GLOBAL
@@ -358,12 +360,21 @@ __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword 
     if (tid == 0) {
 #pragma unroll
         for (int d = 0; d < N; ++d) L.priv.red[d] = L.sums[d];
-        apply_phase(&L.priv, phase, true);
+        L.drift_flag = 0;
+        if (phase == PH_DRIFT) {
+            // adaptive residual replacement: ||(b - A x) - r|| > rr_drift ||r||  (the host's test of the multi-launch form,
+            // Driver::drift, without the square root)
+            if (L.sums[1] > 0.0 && L.sums[0] > a.drift_tol2 * L.sums[1]) { L.drift_flag = 1; L.adaptive += 1; }
+        } else {
+            apply_phase(&L.priv, phase, true);
+        }
     }
     lds_barrier();
     HSTAMP(2);
     if (tid < 4) {
-        const double v = tid == 0 ? L.priv.alpha : tid == 1 ? L.priv.beta : tid == 2 ? L.priv.omega : (double)L.priv.done;
+        // fourth value: 1 = the reference's loop has ended, 2 = the iteration that follows is a replacement iteration
+        const double v = tid == 0 ? L.priv.alpha : tid == 1 ? L.priv.beta : tid == 2 ? L.priv.omega
+                                  : L.priv.done ? 1.0 : L.drift_flag ? 2.0 : 0.0;
         ll_store16_agent(row + 2 * tid, v, seq);
     }
 #undef HSTAMP
@@ -379,12 +390,15 @@ __device__ __forceinline__ unsigned persist_wg(const PersistArgs &a)
     return (a.xcd_map && b < (a.nwg / 8u) * 8u) ? (b % 8u) * (a.nwg / 8u) + b / 8u : b;
 }
 
+__device__ __forceinline__ unsigned blockIdxWg(const PersistArgs &a) { return persist_wg(a); }
+
 // the helper workgroup's last act: the scalar block goes back to memory (the host reads k, (r,r), done from it)
-__device__ __forceinline__ void helper_finish(const PersistArgs &a, PersistLds &L)
+__device__ __forceinline__ void helper_finish(const PersistArgs &a, PersistLds &L, double used_v = 0.0, double used_g = 0.0)
 {
     lds_barrier();
     if (threadIdx.x == 0) {
         if (L.fail) { L.priv.done = 1; L.priv.comm_error = 1; }
+        L.priv.red[kRedUsedV] = used_v; L.priv.red[kRedUsedG] = used_g; L.priv.red[kRedAdaptive] = (double)L.adaptive;
         *a.S = L.priv;
     }
 }
@@ -441,115 +455,381 @@ __device__ __forceinline__ RowWg row_setup(const PersistArgs &a, unsigned wg, do
     return R;
 }
 
-template <bool LDSMAT, bool MULTI>
-__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_pipe_persist(PersistArgs a)
+// ------------------------------------------------------------------------------------------------------------------
+// Pipelined BiCGStab, R rows per thread.
+//   R = 1: the form above -- 15 row wavefronts + the communication wavefront, 4 wavefronts per SIMD (128 registers each),
+//          matrix slices in LDS when they fit (ranks up to ~245 k rows);
+//   R = 2, 4, 8: ranks of 2 and 4 GPUs (400 k / 800 k rows of Transport = 1 565 / 3 130 rows per CU): 7 row wavefronts +
+//          the communication wavefront = 2 wavefronts per SIMD (256 registers each), every thread keeps the ten vector
+//          entries of its R rows in registers, the matrix slices are streamed from memory (they fit the Infinity Cache:
+//          60 / 120 MB) and only the window and the published values live in LDS. The protocol between workgroups and
+//          GPUs is the same; thread (wavefront w, lane l) owns rows (s0 + j nrw + w) 64 + l, j < R, i.e. positions
+//          j nrt + tid of the workgroup's row range -- the index of its values in `zs`.
+// Besides the plain iteration (src/solver.c:352-390) the kernel runs the residual-replacement iteration of
+// pipe_bicgstab_rr (src/solver.c:494-548: p update, s = A p, z = A s, q / y and their dots, v = A z, x update, r = b - A x,
+// w = A r, the five dots, t = A w -- six hand-offs instead of two, the same two dot groups) at the iterations the
+// reference's schedule names (k % krr == 0, 0 < k <= krr nrr), at the first iteration of a launch when the host asks for
+// it, and -- adaptive form, rr_drift > 0 -- whenever the true residual b - A x, recomputed every `drift_every` iterations
+// with one more hand-off and a two-value group, has drifted from the recursive one by more than rr_drift (decided by the
+// helper, so every workgroup and every rank takes the same branch).
+// Sequence numbers run densely through a launch: hand-off n carries image tag vseq0 + n and halo exchange number
+// halo_seq0 + n; dot group g carries table tag seq0 + g and mailbox number p2p.seq + g - 1 and uses table / scalar row
+// g & 1. The helper reports how many of each the launch consumed (Scal::used_v / used_g).
+// Image buffers: plain iterations alternate llv[0] / llv[1]; a replacement iteration uses 0, 1, 2 | 0, 1, 3 -- a buffer is
+// rewritten only after a dot group has been applied in between, i.e. after EVERY workgroup has finished reading it.
+// ------------------------------------------------------------------------------------------------------------------
+template <int R> struct RowState {
+    uint32_t sbase[R], slen[R];           // wave-uniform: first entry / padded length of sub-row j's slice
+    uint32_t lens[R];                     // per lane: entries of the row | entries of its diag part << 16
+    uint32_t row[R];
+    bool live[R];
+};
+
+struct WgCtx {
+    double *win, *zs, *mval;
+    unsigned short *mslot;
+    const uint2 *runs;
+    unsigned nrw, nrt, nruns, nslots, ns0, ns1, wave, lane;
+    bool comm;
+    uint32_t row0, nmine, e0;
+};
+
+template <int R, bool LDSMAT, bool MULTI>
+__device__ __forceinline__ void wg_setup(const PersistArgs &a, unsigned wg, double *dyn, WgCtx &W, RowState<R> &rs)
+{
+    const unsigned tid = threadIdx.x, nt = blockDim.x;
+    W.lane = tid & 63u;
+    W.wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    W.win = dyn;
+    W.mval = dyn + a.win_slots;
+    W.mslot = reinterpret_cast<unsigned short *>(W.mval + a.mat_entries);
+    uint2 *runs = reinterpret_cast<uint2 *>(W.mslot + ((a.mat_entries + 3u) & ~3u));
+    W.runs = runs;
+    W.zs = reinterpret_cast<double *>(runs + a.max_runs);          // [64 * spw * R] the workgroup's values of the vector being published
+    W.nrw = a.spw; W.nrt = 64u * a.spw;
+    W.comm = W.wave == W.nrw;
+    const uint32_t per = a.spw * (uint32_t)R;                       // slices per workgroup
+    const uint32_t s0 = wg * per, s1 = min(a.nslices, s0 + per);
+    W.row0 = s0 * kSliceRows; W.nmine = min(a.nrows, s1 * kSliceRows) - W.row0;
+    W.e0 = a.pbase[s0];
+    const uint32_t e1 = a.pbase[s1];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t slice = s0 + (uint32_t)j * W.nrw + W.wave;
+        const bool have = !W.comm && slice < s1;
+        rs.sbase[j] = 0u; rs.slen[j] = 0u;
+        if (have) { rs.sbase[j] = a.pbase[slice]; rs.slen[j] = (a.pbase[slice + 1] - rs.sbase[j]) / kSliceRows; }
+        rs.row[j] = slice * kSliceRows + W.lane;
+        rs.live[j] = have && rs.row[j] < a.nrows;
+        rs.lens[j] = rs.live[j] ? ((uint32_t)a.rlen[rs.row[j]] | ((uint32_t)a.rdiag[rs.row[j]] << 16)) : 0u;
+    }
+    const unsigned r0w = a.win_ptr[wg];
+    W.nruns = a.win_ptr[wg + 1] - r0w;
+    for (unsigned i = tid; i < W.nruns; i += nt) runs[i] = a.win_runs[r0w + i];
+    W.nslots = 0;
+    if (W.nruns) { const uint2 last = a.win_runs[r0w + W.nruns - 1]; W.nslots = (last.y >> 16) + (last.y & 0xFFFFu); }
+    if (LDSMAT)
+        for (uint32_t j = W.e0 + tid; j < e1; j += nt) { W.mval[j - W.e0] = a.pval[j]; W.mslot[j - W.e0] = a.pslot[j]; }
+    W.ns0 = MULTI ? a.snd_ptr[wg] : 0u; W.ns1 = MULTI ? a.snd_ptr[wg + 1] : 0u;
+}
+
+// One hand-off and the product that consumes it: every row publishes val (LL image `buf`, tag vseq0 + nv; this workgroup's
+// own copy in zs), optionally together with the N dot partials of group g (table and scalar row g & 1); the communication
+// wavefront sends partials and halo values and -- wait_scal -- fetches the group's applied scalars into L.sc while the row
+// wavefronts stage their window and multiply. out = A val on the thread's rows. Ends with a barrier: L.sc / L.fail are
+// valid for everybody.
+template <int R, int N, bool LDSMAT, bool MULTI>
+__device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, const RowState<R> &rs, PersistLds &L, const double (&val)[R],
+                                      double (&acc)[N > 0 ? N : 1], unsigned buf, unsigned nv, unsigned g, bool wait_scal, double (&out)[R])
+{
+    const unsigned vtag = a.vseq0 + nv, htag = a.halo_seq0 + nv, gtag = a.seq0 + g;
+    llword *const img = a.llv[buf];
+    if (!W.comm) {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            if (rs.live[j]) ll_store16_agent(img + 2 * (size_t)rs.row[j], val[j], vtag);
+            W.zs[(unsigned)j * W.nrt + threadIdx.x] = val[j];
+        }
+        if (N > 0) {
+#pragma unroll
+            for (int d = 0; d < N; ++d) acc[d] = wave_sum(acc[d]);
+            if (W.lane == 0) {
+#pragma unroll
+                for (int d = 0; d < N; ++d) L.wsum[W.wave * kMaxDots + d] = acc[d];
+            }
+        }
+    }
+    lds_barrier();
+    if (W.comm) {
+        // the dot partials first: the helper's chain (table -> sums -> recurrence -> scalars back) is the longest of the phase
+        if (N > 0) comm_partials<(N > 0 ? N : 1)>(W.lane, W.nrw, a.dtab[g & 1u] + (size_t)blockIdxWg(a) * kRedSlots * 2, gtag, L);
+        comm_halo<MULTI>(a, W.lane, W.zs, htag, W.ns0, W.ns1);
+    } else {
+        stage_window<MULTI>(a, W.runs, W.nruns, W.nslots, img, vtag, htag, W.win, W.nrt, L, W.zs, W.row0, W.nmine);
+    }
+    lds_barrier();
+    if (W.comm) {
+        if (wait_scal) comm_scalars(a, W.lane, a.arow[g & 1u], gtag, L);
+    } else {
+#pragma unroll
+        for (int j = 0; j < R; ++j) {
+            const double *mv = LDSMAT ? W.mval + (rs.sbase[j] - W.e0) : a.pval + rs.sbase[j];
+            const unsigned short *ms = LDSMAT ? W.mslot + (rs.sbase[j] - W.e0) : a.pslot + rs.sbase[j];
+            out[j] = persist_row<MULTI>(mv, ms, rs.slen[j], rs.lens[j] & 0xFFFFu, rs.lens[j] >> 16, W.win);
+            if (R > 1) __builtin_amdgcn_sched_barrier(0);      // one row's batches at a time: interleaved, R products' loads do not fit the registers
+        }
+    }
+    lds_barrier();
+}
+
+// dot partials that exist only AFTER a product (the drift check): published and answered at once
+template <int N>
+__device__ __forceinline__ void group_now(const PersistArgs &a, const WgCtx &W, PersistLds &L, double (&acc)[N], unsigned g)
+{
+    if (!W.comm) {
+#pragma unroll
+        for (int d = 0; d < N; ++d) acc[d] = wave_sum(acc[d]);
+        if (W.lane == 0) {
+#pragma unroll
+            for (int d = 0; d < N; ++d) L.wsum[W.wave * kMaxDots + d] = acc[d];
+        }
+    }
+    lds_barrier();
+    if (W.comm) {
+        comm_partials<N>(W.lane, W.nrw, a.dtab[g & 1u] + (size_t)blockIdxWg(a) * kRedSlots * 2, a.seq0 + g, L);
+        comm_scalars(a, W.lane, a.arow[g & 1u], a.seq0 + g, L);
+    }
+    lds_barrier();
+}
+
+// the reference's schedule (src/solver.c:498, 522) and the host's request for the first iteration of the launch
+__device__ __forceinline__ bool replaces_fixed(const PersistArgs &a, int it)
+{
+    const int k = a.it0 + it;
+    return (it == 0 && a.force_first) || (a.krr > 0 && k > 0 && k % a.krr == 0 && k <= a.krr * a.nrr);
+}
+__device__ __forceinline__ bool drift_due(const PersistArgs &a, int it)
+{
+    return a.drift_every > 0 && a.it0 + it > 0 && it % a.drift_every == 0;
+}
+
+template <int R, bool LDSMAT, bool MULTI>
+__global__ void __launch_bounds__(R <= 2 ? 1024 : 512) __attribute__((amdgpu_waves_per_eu(R <= 2 ? 4 : 2, R <= 2 ? 4 : 2)))
+k_pipe_persist(PersistArgs a)
 {
     extern __shared__ double dyn[];
     __shared__ PersistLds L;
-    const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x;
     const unsigned wg = persist_wg(a);
-    if (tid == 0) { L.priv = *a.S; L.fail = 0; }
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
     lds_barrier();
 
     if (wg == a.nwg) {
-        // ---------------- helper: no rows. Turns dot partials into applied scalars, twice per iteration.
+        // ---------------- helper: no rows. Turns dot partials into applied scalars: [drift group,] omega group, end group
+        unsigned g = 0, nv = 0;
         for (int it = 0; it < a.niter; ++it) {
             if (L.priv.done) break;
-            const unsigned sz = a.seq0 + 2u * (unsigned)it + 1u, sw = sz + 1u;
+            bool replace = replaces_fixed(a, it);
+            if (drift_due(a, it)) {
+                ++g; ++nv;
+                if (!helper_group<2>(a, a.dtab[g & 1u], a.arow[g & 1u], a.seq0 + g, a.p2p.seq + g - 1u, PH_DRIFT, L, nullptr)) break;
+                replace = replace || L.drift_flag != 0;
+            }
             unsigned long long *st = a.dbg && it < 32 ? a.dbg + it * 32 + 16 : nullptr;
-            if (!helper_group<2>(a, a.dtab[0], a.arow[0], sz, a.p2p.seq + 2u * (unsigned)it, PH_OMEGA, L, st ? st + 12 : nullptr)) break;
+            ++g;
+            if (!helper_group<2>(a, a.dtab[g & 1u], a.arow[g & 1u], a.seq0 + g, a.p2p.seq + g - 1u, PH_OMEGA, L, st ? st + 12 : nullptr)) break;
             if (a.dbg && tid == 0 && it < 32) a.dbg[it * 32 + 10] = wall_clock64();
-            if (!helper_group<5>(a, a.dtab[1], a.arow[1], sw, a.p2p.seq + 2u * (unsigned)it + 1u, PH_RECUR_END, L, nullptr)) break;
+            ++g;
+            if (!helper_group<5>(a, a.dtab[g & 1u], a.arow[g & 1u], a.seq0 + g, a.p2p.seq + g - 1u, PH_RECUR_END, L, nullptr)) break;
             if (a.dbg && tid == 0 && it < 32) a.dbg[it * 32 + 11] = wall_clock64();
+            nv += replace ? 6u : 2u;
         }
-        helper_finish(a, L);
+        helper_finish(a, L, (double)nv, (double)g);
         return;
     }
 
-    // ---------------- row workgroup: spw row wavefronts (slices wg * spw ..., lane = row) + one communication wavefront
-    const RowWg R = row_setup<LDSMAT, MULTI>(a, wg, dyn);
-    double *const win = R.win, *const zs = R.zs;
-    const uint2 *const runs = R.runs;
-    const unsigned nrw = R.nrw, nrt = R.nrt, nruns = R.nruns, nslots = R.nslots, ns0 = R.ns0, ns1 = R.ns1;
-    const bool comm = R.comm, live = R.live;
-    const uint32_t row0 = R.row0, nmine = R.nmine, row = R.row, slen = R.slen, mylen = R.mylen, mydiag = R.mydiag;
-    const double *const gval = R.gval;
-    const unsigned short *const gslot = R.gslot;
+    // ---------------- row workgroup: spw row wavefronts (lane = row, R rows per thread) + one communication wavefront
+    WgCtx W;
+    RowState<R> rs;
+    wg_setup<R, LDSMAT, MULTI>(a, wg, dyn, W, rs);
+    const bool comm = W.comm;
     const Vecs &e = a.v;
-    const uint32_t rr_ = live ? row : 0u;
-    double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], z = e.z[rr_], w = e.w[rr_], v = e.v[rr_], t = e.t[rr_];
-    const double h = e.rh[rr_];
-    double y = 0.0;
+    // x and r# are touched once per iteration: with R >= 4 rows per thread they stay in memory (the rank's vectors sit in the
+    // Infinity Cache) and are read / written where phase 2 needs them; y = w - alpha z is formed again in phase 2 from the
+    // same operands (same bits) instead of being carried across the product.
+    constexpr bool XMEM = R >= 4;
+    constexpr bool RRP = R == 1;          // replacement iterations and the drift check: one row per thread only (latency-bound ranks)
+    constexpr int RX = XMEM ? 1 : R;
+    double xr[RX], hr[RX];
+    constexpr bool PMEM = R >= 7;         // ... and so does p (read and written in phase 1, read in phase 2)
+    constexpr int RP = PMEM ? 1 : R;
+    double pr[RP];
+    double r[R], s[R], z[R], w[R], v[R], t[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t q = rs.live[j] ? rs.row[j] : 0u;
+        if (!XMEM) { xr[j % RX] = e.x[q]; hr[j % RX] = e.rh[q]; }
+        if (!PMEM) pr[j % RP] = e.p[q];
+        r[j] = e.r[q]; s[j] = e.s[q]; z[j] = e.z[q]; w[j] = e.w[q]; v[j] = e.v[q]; t[j] = e.t[q];
+    }
+    auto ldp = [&](int j) -> double { return PMEM ? (rs.live[j] ? e.p[rs.row[j]] : 0.0) : pr[j % RP]; };
+    auto stp = [&](int j, double val) { if (PMEM) { if (rs.live[j]) e.p[rs.row[j]] = val; } else pr[j % RP] = val; };
+    auto ldx = [&](int j) -> double { return XMEM ? (rs.live[j] ? e.x[rs.row[j]] : 0.0) : xr[j % RX]; };
+    auto ldh = [&](int j) -> double { return XMEM ? (rs.live[j] ? e.rh[rs.row[j]] : 0.0) : hr[j % RX]; };
+    auto stx = [&](int j, double val) { if (XMEM) { if (rs.live[j]) e.x[rs.row[j]] = val; } else xr[j % RX] = val; };
     double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
     int done = L.priv.done;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     lds_barrier();
 
-    const bool trace = a.dbg && wg == a.nwg / 2 && (tid == 0 || tid == nrt);
+    const bool trace = a.dbg && wg == a.nwg / 2 && (tid == 0 || tid == W.nrt);
     const int tr0 = tid == 0 ? 0 : 32;
 #define STAMP(i) do { if (trace && it < 32) a.dbg[(it * 2 + (tr0 ? 1 : 0)) * 16 + (i)] = wall_clock64(); } while (0)
-    llword *const tab0 = R.tab0, *const tab1 = R.tab1;
+    unsigned g = 0, nv = 0;
+    double none[1] = {0.0};
     for (int it = 0; it < a.niter && !done; ++it) {
-        const unsigned sz = a.seq0 + 2u * (unsigned)it + 1u, sw = sz + 1u;
-        const unsigned hz = a.halo_seq0 + 2u * (unsigned)it + 1u, hw = hz + 1u;
+        bool replace = RRP && replaces_fixed(a, it);
+        if (RRP && drift_due(a, it)) {
+            // ---- adaptive replacement: ||(b - A x) - r||^2 against ||r||^2 (FDrift); the helper decides
+            double ax[R], xv_[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) xv_[j] = comm ? 0.0 : ldx(j);
+            xprod<R, 0, LDSMAT, MULTI>(a, W, rs, L, xv_, none, 0u, ++nv, 0u, false, ax);
+            if (L.fail) break;
+            double acc[2] = {0.0, 0.0};
+            if (!comm) {
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (rs.live[j]) {
+                        const double dlt = (e.b[rs.row[j]] + (-1.0) * ax[j]) - r[j];
+                        acc[0] += dlt * dlt; acc[1] += r[j] * r[j];
+                    }
+            }
+            group_now<2>(a, W, L, acc, ++g);
+            if (L.fail) break;
+            replace = replace || L.sc[3] == 2.0;
+        }
         STAMP(0);
-        // ---- phase 1: p, s, z recurrences, q (kept in r), y, (q,y), (y,y)            (src/solver.c:352-364, FPipe1)
-        if (!comm) {
-            p = recur3<double>(p, s, r, omega, beta);
-            const double s1n = recur3<double>(s, z, w, omega, beta);
-            const double z1n = recur3<double>(z, v, t, omega, beta);
-            s = s1n; z = z1n;
-            r = r + (-alpha) * s;             // q
-            y = w + (-alpha) * z;
-            double acc[2] = {live ? r * y : 0.0, live ? y * y : 0.0};
-            hand_over<2>(z, acc, zs, L, live ? a.llv[0] + 2 * (size_t)row : nullptr, sz);
+        if (!RRP || !replace) {
+            // ---- phase 1: p, s, z recurrences, q (kept in r), y, (q,y), (y,y)            (src/solver.c:352-364, FPipe1)
+            double acc2[2] = {0.0, 0.0};
+            if (!comm) {
+                double pin[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) pin[j] = ldp(j);
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    stp(j, recur3<double>(pin[j], s[j], r[j], omega, beta));
+                    const double s1n = recur3<double>(s[j], z[j], w[j], omega, beta);
+                    const double z1n = recur3<double>(z[j], v[j], t[j], omega, beta);
+                    s[j] = s1n; z[j] = z1n;
+                    r[j] = r[j] + (-alpha) * s[j];             // q
+                    const double y = w[j] + (-alpha) * z[j];
+                    if (rs.live[j]) { acc2[0] += r[j] * y; acc2[1] += y * y; }
+                }
+            }
+            STAMP(1);
+            // ---- v = A z  ||  publish z, halo, partials; wait for omega                  (src/solver.c:363-369)
+            xprod<R, 2, LDSMAT, MULTI>(a, W, rs, L, z, acc2, 0u, ++nv, ++g, true, v);
+            STAMP(3);
+            if (L.fail) break;
+            omega = L.sc[2];
+            STAMP(4);
+            // ---- phase 2: x, r, w, five dots                                             (src/solver.c:370-380, FPipe2)
+            double acc5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (!comm) {
+                double xin[R], hin[R], pin[R];
+#pragma unroll
+                for (int j = 0; j < R; ++j) { xin[j] = ldx(j); hin[j] = ldh(j); pin[j] = ldp(j); }      // (in memory: all loads in flight together)
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const double q = r[j];
+                    const double y = w[j] + (-alpha) * z[j];           // phase 1's y, bit for bit (w, z, alpha unchanged since)
+                    double xx = xin[j] + alpha * pin[j];
+                    xx = xx + omega * q;
+                    stx(j, xx);
+                    r[j] = q + (-omega) * y;
+                    const double tt = t[j] + (-alpha) * v[j];
+                    w[j] = y + (-omega) * tt;
+                    const double h = hin[j];
+                    if (rs.live[j]) { acc5[0] += r[j] * r[j]; acc5[1] += h * r[j]; acc5[2] += h * w[j]; acc5[3] += h * s[j]; acc5[4] += h * z[j]; }
+                }
+            }
+            STAMP(5);
+            // ---- t = A w  ||  publish w, halo, partials; wait for beta, alpha, done       (src/solver.c:377-390)
+            xprod<R, 5, LDSMAT, MULTI>(a, W, rs, L, w, acc5, 1u, ++nv, ++g, true, t);
+            STAMP(7);
+            if (L.fail) break;
+        } else {
+            // ---- residual replacement (src/solver.c:494-548; FPUpdate, FQY, FXUpdate, FTrueRes, FDots5)
+            double ax[R], pn[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) pn[j] = 0.0;
+            if (!comm) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) pn[j] = recur3<double>(ldp(j), s[j], r[j], omega, beta);
+#pragma unroll
+                for (int j = 0; j < R; ++j) stp(j, pn[j]);
+            }
+            xprod<R, 0, LDSMAT, MULTI>(a, W, rs, L, pn, none, 0u, ++nv, 0u, false, s);          // s = A p
+            if (L.fail) break;
+            xprod<R, 0, LDSMAT, MULTI>(a, W, rs, L, s, none, 1u, ++nv, 0u, false, z);           // z = A s
+            if (L.fail) break;
+            double acc2[2] = {0.0, 0.0};
+            if (!comm) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    r[j] = r[j] + (-alpha) * s[j];             // q
+                    w[j] = w[j] + (-alpha) * z[j];             // y (kept in w, as FQY does)
+                    if (rs.live[j]) { acc2[0] += r[j] * w[j]; acc2[1] += w[j] * w[j]; }
+                }
+            }
+            xprod<R, 2, LDSMAT, MULTI>(a, W, rs, L, z, acc2, 2u, ++nv, ++g, true, v);           // v = A z || (q,y), (y,y) -> omega
+            if (L.fail) break;
+            omega = L.sc[2];
+            double xn[R];
+#pragma unroll
+            for (int j = 0; j < R; ++j) xn[j] = 0.0;
+            if (!comm) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) {
+                    const double xx = ldx(j) + alpha * pn[j];
+                    xn[j] = xx + omega * r[j];
+                    stx(j, xn[j]);
+                }
+            }
+            xprod<R, 0, LDSMAT, MULTI>(a, W, rs, L, xn, none, 0u, ++nv, 0u, false, ax);         // A x
+            if (L.fail) break;
+            if (!comm) {
+#pragma unroll
+                for (int j = 0; j < R; ++j) r[j] = (rs.live[j] ? e.b[rs.row[j]] : 0.0) + (-1.0) * ax[j];   // r = b - A x
+            }
+            xprod<R, 0, LDSMAT, MULTI>(a, W, rs, L, r, none, 1u, ++nv, 0u, false, w);           // w = A r
+            if (L.fail) break;
+            double acc5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+            if (!comm) {
+#pragma unroll
+                for (int j = 0; j < R; ++j)
+                    if (rs.live[j]) {
+                        const double h = ldh(j);
+                        acc5[0] += r[j] * r[j]; acc5[1] += h * r[j]; acc5[2] += h * w[j]; acc5[3] += h * s[j]; acc5[4] += h * z[j];
+                    }
+            }
+            xprod<R, 5, LDSMAT, MULTI>(a, W, rs, L, w, acc5, 3u, ++nv, ++g, true, t);           // t = A w || the five -> beta, alpha, k++
+            if (L.fail) break;
         }
-        lds_barrier();                        // B1: values and partials are in LDS
-        STAMP(1);
-        // ---- v = A z (row wavefronts)  ||  publish z, halo, partials; wait for omega (communication wavefront)
-        if (comm) comm_phase<2, MULTI>(a, lane, row0, nmine, nrw, zs, a.llv[0], sz, hz, ns0, ns1, tab0, L);
-        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[0], sz, hz, win, nrt, L, zs, row0, nmine);
-        STAMP(2);
-        lds_barrier();                        // B2: window staged (the row wavefronts' concern)
-        if (comm) comm_scalars(a, lane, a.arow[0], sz, L);
-        else v = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
-        STAMP(3);
-        lds_barrier();                        // B3: omega from (q,y), (y,y) is in L.sc          (src/solver.c:363-369)
-        if (L.fail) break;
-        omega = L.sc[2];
-        STAMP(4);
-        // ---- phase 2: x, r, w, five dots                                             (src/solver.c:370-380, FPipe2)
-        if (!comm) {
-            const double q = r;
-            double xx = x + alpha * p;
-            xx = xx + omega * q;
-            x = xx;
-            r = q + (-omega) * y;
-            const double tt = t + (-alpha) * v;
-            w = y + (-omega) * tt;
-            double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
-            if (live) { acc[0] = r * r; acc[1] = h * r; acc[2] = h * w; acc[3] = h * s; acc[4] = h * z; }
-            hand_over<5>(w, acc, zs, L, live ? a.llv[1] + 2 * (size_t)row : nullptr, sw);
-        }
-        lds_barrier();                        // B4
-        STAMP(5);
-        // ---- t = A w  ||  publish w, halo, partials; wait for beta, alpha, done       (src/solver.c:377-390)
-        if (comm) comm_phase<5, MULTI>(a, lane, row0, nmine, nrw, zs, a.llv[1], sw, hw, ns0, ns1, tab1, L);
-        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[1], sw, hw, win, nrt, L, zs, row0, nmine);
-        STAMP(6);
-        lds_barrier();                        // B5
-        if (comm) comm_scalars(a, lane, a.arow[1], sw, L);
-        else t = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
-        STAMP(7);
-        lds_barrier();                        // B6
-        if (L.fail) break;
-        alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] != 0.0 ? 1 : 0;
+        alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] == 1.0 ? 1 : 0;
         STAMP(8);
     }
 #undef STAMP
-    if (live) {
-        e.x[row] = x; e.r[row] = r; e.p[row] = p; e.s[row] = s; e.z[row] = z; e.w[row] = w; e.v[row] = v; e.t[row] = t; e.y[row] = y;
-    }
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (rs.live[j]) {
+            const uint32_t q = rs.row[j];
+            if (!XMEM) e.x[q] = xr[j % RX];
+            if (!PMEM) e.p[q] = pr[j % RP];
+            e.r[q] = r[j]; e.s[q] = s[j]; e.z[q] = z[j]; e.w[q] = w[j]; e.v[q] = v[j]; e.t[q] = t[j];
+        }
 }
 
 
@@ -568,7 +848,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     __shared__ PersistLds L;
     const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned wg = persist_wg(a);
-    if (tid == 0) { L.priv = *a.S; L.fail = 0; }
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
     lds_barrier();
 
     if (wg == a.nwg) {
@@ -677,7 +957,7 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     __shared__ PersistLds L;
     const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6;
     const unsigned wg = persist_wg(a);
-    if (tid == 0) { L.priv = *a.S; L.fail = 0; }
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
     lds_barrier();
 
     if (wg == a.nwg) {
@@ -769,9 +1049,9 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
 
 unsigned persist_lds_bytes(const PersistArgs &a)
 {
-    const size_t threads = 64u * a.spw;       // row threads
+    const size_t rows = 64u * (size_t)a.spw * (a.rpt ? a.rpt : 1u);       // rows of a workgroup
     return (unsigned)(8u * (size_t)a.win_slots + 8u * (size_t)a.mat_entries + 2u * (((size_t)a.mat_entries + 3u) & ~(size_t)3u) +
-                      8u * (size_t)a.max_runs + 8u * threads);
+                      8u * (size_t)a.max_runs + 8u * rows);
 }
 
 // Returns hipSuccess, or why the launch did not happen (the caller falls back to the multi-launch iteration): launch errors
@@ -786,7 +1066,7 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
         static std::set<std::pair<int, int>> ready;        // (device, instantiation)
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const int idx = slot * 4 + (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0);
+        const int idx = slot * 4 + (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0) + 16 * (int)a.rpt;
         if (!ready.count({dev, idx})) {       // (the runtime answers "invalid argument" and launches with > 64 KiB of LDS all the same)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
             (void)hipGetLastError();
@@ -807,9 +1087,16 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
         return hipGetLastError();
     };
     hipError_t err;
+    if (method != 0 && a.rpt != 1u) return hipErrorInvalidValue;      // several rows per thread: the pipelined kernel only
     if (method == 0) {
-        if (a.mat_entries) { err = a.multi ? go(k_pipe_persist<true, true>, 0) : go(k_pipe_persist<true, false>, 0); }
-        else { err = a.multi ? go(k_pipe_persist<false, true>, 0) : go(k_pipe_persist<false, false>, 0); }
+        if (a.rpt == 1u) {
+            if (a.mat_entries) { err = a.multi ? go(k_pipe_persist<1, true, true>, 0) : go(k_pipe_persist<1, true, false>, 0); }
+            else { err = a.multi ? go(k_pipe_persist<1, false, true>, 0) : go(k_pipe_persist<1, false, false>, 0); }
+        } else if (a.mat_entries) {
+            return hipErrorInvalidValue;                              // (the matrix of such a rank does not fit LDS)
+        } else if (a.rpt == 2u) { err = a.multi ? go(k_pipe_persist<2, false, true>, 0) : go(k_pipe_persist<2, false, false>, 0);
+        } else if (a.rpt == 8u) { err = a.multi ? go(k_pipe_persist<8, false, true>, 0) : go(k_pipe_persist<8, false, false>, 0);
+        } else return hipErrorInvalidValue;
     } else if (method == 1) {
         if (a.mat_entries) { err = a.multi ? go(k_plain_persist<true, true>, 1) : go(k_plain_persist<true, false>, 1); }
         else { err = a.multi ? go(k_plain_persist<false, true>, 1) : go(k_plain_persist<false, false>, 1); }

@@ -175,8 +175,14 @@ bool persist_plan_host(const CSR_Matrix *diag, const unsigned *optr, const unsig
     P = PersistPlan{};
     P.nrows = nrows;
     P.nslices = (nrows + kSlice - 1) / kSlice;
-    P.spw = (P.nslices + gmax - 1) / gmax;
-    if (P.spw > 15) return false;                                  // 15 row wavefronts + the communication wavefront per workgroup
+    // slices per workgroup -> (row wavefronts, rows per thread): 15 row wavefronts + the communication wavefront with one or two
+    // rows per thread (4 wavefronts per SIMD), or 7 + 1 wavefronts with eight rows per thread (2 per SIMD: twice the registers)
+    const uint32_t per = (P.nslices + gmax - 1) / gmax;
+    if (per <= 15) { P.rpt = 1; P.nrw = per; }
+    else if (per <= 30) { P.rpt = 2; P.nrw = (per + 1) / 2; }
+    else if (per <= 56) { P.rpt = 8; P.nrw = (per + 7) / 8; }
+    else return false;
+    P.spw = P.nrw * P.rpt;
     P.nwg = (P.nslices + P.spw - 1) / P.spw;
     const uint32_t grows = P.spw * kSlice, nslices = P.nslices, nwg = P.nwg, spw = P.spw;
 
@@ -251,8 +257,8 @@ bool persist_plan_host(const CSR_Matrix *diag, const unsigned *optr, const unsig
 }
 }  // namespace bicg
 
-// C view for tests: summary = {spw, nwg, window slots, most runs of a workgroup, most matrix entries of a workgroup, entries,
-// runs, 0}; the arrays (sizes known from a first call with NULL arrays) are filled when given. offd_renumbered: columns =
+// C view for tests: summary = {slices per workgroup, nwg, window slots, most runs of a workgroup, most matrix entries of a
+// workgroup, entries, runs, rows per thread}; the arrays (sizes known from a first call with NULL arrays) are filled when given. offd_renumbered: columns =
 // rows + halo position (bicg_halo_plan), or NULL for one rank. Returns 0 when the block qualifies.
 extern "C" int bicg_persist_plan(const CSR_Matrix *diag, const CSR_Matrix *offd_renumbered, unsigned int gmax, unsigned int summary[8],
                                  unsigned int *pbase, unsigned short *pslot, double *pval, unsigned short *rlen, unsigned short *rdiag,
@@ -263,7 +269,7 @@ extern "C" int bicg_persist_plan(const CSR_Matrix *diag, const CSR_Matrix *offd_
     if (!bicg::persist_plan_host(diag, multi ? offd_renumbered->ptr : nullptr, multi ? offd_renumbered->col : nullptr,
                                  multi ? offd_renumbered->val : nullptr, gmax, P))
         return 1;
-    const unsigned s[8] = {P.spw, P.nwg, P.win_slots, P.max_runs, P.max_entries, P.pbase[P.nslices], (unsigned)(P.runs.size() / 2), 0u};
+    const unsigned s[8] = {P.spw, P.nwg, P.win_slots, P.max_runs, P.max_entries, P.pbase[P.nslices], (unsigned)(P.runs.size() / 2), P.rpt};
     for (int i = 0; i < 8; ++i) summary[i] = s[i];
     if (pbase) std::copy(P.pbase.begin(), P.pbase.end(), pbase);
     if (pslot) std::copy(P.pslot.begin(), P.pslot.begin() + P.pbase[P.nslices], pslot);

@@ -10,7 +10,8 @@ namespace bicg {
 
 // plan of the persistent iteration (bicg_persist.hip): see persist_plan_host in bicg_plan.cpp
 struct PersistPlan {
-    uint32_t nrows = 0, nslices = 0, spw = 0, nwg = 0;
+    uint32_t nrows = 0, nslices = 0, spw = 0, nwg = 0;     // spw: slices per workgroup = nrw * rpt
+    uint32_t nrw = 0, rpt = 1;                             // row wavefronts per workgroup, rows per thread
     uint32_t win_slots = 0, max_runs = 0, max_entries = 0;
     std::vector<unsigned short> rlen, rdiag;      // [nrows] entries of a row / of its diag part
     std::vector<uint32_t> wptr;                   // [nwg + 1] runs of workgroup g

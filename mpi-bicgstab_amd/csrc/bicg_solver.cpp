@@ -79,6 +79,7 @@ struct bicg_ctx {
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
     int spmv_dir = 0;                      // direction of the last sliced-ELL product (SpmvArgs::reverse)
     int sell_alt = 0;                      // BICG_SELL_ALT: consecutive products alternate direction
+    int vec_rev = 0;                       // BICG_VEC_REV: bit k = the k-th element-wise kernel of an iteration sweeps backwards
     int sell_xcd = 0;                      // BICG_SELL_XCD: XCD-contiguous group order (measurement knob, SpmvArgs::xcd_map)
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
     bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
@@ -151,7 +152,8 @@ struct bicg_ctx {
     PersistArgs persist{};
     bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0/1 overrides
     bool persist_plain = true;   // ... and for plain BiCGStab (BICG_PERSIST_PLAIN=0: the five-launch iteration)
-    unsigned persist_seq = 0;    // LL tags used so far
+    unsigned persist_seq = 0;    // LL tags used so far (dot tables)
+    unsigned persist_vseq = 0;   // ... by the pipelined kernel's vector images
     std::vector<void *> persist_mem;
     unsigned wg_cap = 0;         // ranks sharing this GPU (tests): workgroups per launch that may wait for another rank
     double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
@@ -507,7 +509,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // previous one ended finds the most recently streamed part of the matrix still cached, while cyclic forward passes
     // evict it just before it is needed. Rows, hence results of the product, are unaffected; the dot partials of a
     // reversed launch land in mirrored slots (a different, equally fixed association).
-    a.reverse = (c->sell_alt && c->single() && !epi && !fw) ? (c->spmv_dir ^= 1) : 0;
+    a.reverse = (c->sell_alt && c->single() && !fw) ? (c->spmv_dir ^= 1) : 0;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
     const bool fused = c->p2p && c->ll_fused;
@@ -761,6 +763,7 @@ void group_flush(bicg_ctx *c)
 void fetch_scal(bicg_ctx *c);
 }  // namespace
 bool persist_chunk(bicg_ctx *c, int niter);
+void persist_account(bicg_ctx *c);
 namespace {
 
 // ---------------------------------------------------------------- the four iterations
@@ -787,7 +790,8 @@ struct Driver {
     }
 
     // plain and CA-BiCGStab: ticket reductions, scalars applied in place by the producer's last workgroup
-    Launch here() const { return Launch{c->S, Finish{}, c->sc}; }
+    // bit: which element-wise kernel of the iteration (BICG_VEC_REV mask: that kernel sweeps from the end)
+    Launch here(int bit = -1) const { return Launch{c->S, Finish{}, c->sc, bit >= 0 && c->single() ? (c->vec_rev >> bit) & 1 : 0}; }
 
     void init()
     {
@@ -841,21 +845,21 @@ struct Driver {
         if (fused_plain()) { iter_plain_fused(); return; }
         spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
-        launch_plain_q(v, here());                               // q = r - alpha s
+        launch_plain_q(v, here(0));                              // q = r - alpha s
         spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA, true, 2));          // y = A q, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_plain_xr(v, here(), c->red(0, PH_PLAIN_END, true, 2));     // x, r, (r,r), (r#,r) -> beta, k++
+        launch_plain_xr(v, here(1), c->red(0, PH_PLAIN_END, true, 2));    // x, r, (r,r), (r#,r) -> beta, k++
         group_now(c, 2, PH_PLAIN_END);
-        launch_plain_p(v, here());                               // p = r + beta (p - omega s)
+        launch_plain_p(v, here(2));                              // p = r + beta (p - omega s)
     }
 
     void iter_ca()      // reference src/solver.c:217-251
     {
-        launch_ca_ps(v, here());                                 // p, s recurrences
+        launch_ca_ps(v, here(0));                                // p, s recurrences
         spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
-        launch_qy(v, here(), c->red(0, PH_OMEGA, true, 2));      // q, y, (q,y), (y,y) -> omega
+        launch_qy(v, here(1), c->red(0, PH_OMEGA, true, 2));     // q, y, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_ca_xr(v, here(), c->red(0, PH_NONE, false));      // x, r, (r,r), (r#,r), (r#,s), (r#,z)
+        launch_ca_xr(v, here(2), c->red(0, PH_NONE, false));     // x, r, (r,r), (r#,r), (r#,s), (r#,z)
         spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END, true, 5));     // w = A r, (r#,w) -> beta, alpha, k++
         group_now(c, 5, PH_RECUR_END);
     }
@@ -1082,15 +1086,16 @@ int run_iterate(bicg_ctx *c, int nsteps)
     while (!c->hS->done && c->it < stop) {
         // (section marks are host-side events between launches: the multi-launch forms are what they can time)
         bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
-                             ((c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0) ||
-                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain));
+                             ((c->method >= BICG_PIPE_BICGSTAB && (c->persist.rpt == 1u || (c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0))) ||
+                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain && c->persist.rpt == 1u));
         // A persistent launch costs ~27 us of set-up (matrix slices and x window into LDS) and stops by itself at
         // convergence: it covers at least kPersistChunk iterations whatever the host check interval (200 k-row rank,
         // pipelined: 12.5 us per iteration at 16 per launch, 11.0 at 128, 10.9 at 512 -- tools/persist_chunk_times.py)
         const int persist_chunk_min = getenv("BICG_PERSIST_CHUNK") ? std::max(1, atoi(getenv("BICG_PERSIST_CHUNK"))) : kPersistChunk;
         const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, stop - c->it);
         bool force = false;
-        if (o.rr_drift > 0.0 && c->method >= BICG_PIPE_BICGSTAB && c->it > 0 && d.drift() > o.rr_drift) {
+        // (the persistent kernel checks the drift itself, every check_every iterations inside the launch)
+        if (!persist && o.rr_drift > 0.0 && c->method >= BICG_PIPE_BICGSTAB && c->it > 0 && d.drift() > o.rr_drift) {
             force = true;
             c->adaptive_rr++;
         }
@@ -1105,6 +1110,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
         c->it += chunk;
         sec_mark(c, SEC_STOP);
         fetch_scal(c);
+        if (persist && c->method >= BICG_PIPE_BICGSTAB) persist_account(c);
         if (talk && o.out_iter > 0) {   // reference src/solver.c:122-126
             const int k = c->hS->k;
             const int upto = (k / o.out_iter) * o.out_iter;
@@ -1738,13 +1744,15 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
     for (size_t i = 0; i < P.runs.size() / 2; ++i) runs[i] = make_uint2(P.runs[2 * i], P.runs[2 * i + 1]);
     PersistArgs &a = c->persist;
     a = PersistArgs{};
-    a.nrows = nrows; a.nslices = nslices; a.nwg = nwg; a.spw = spw;
+    a.nrows = nrows; a.nslices = nslices; a.nwg = nwg; a.spw = P.nrw; a.rpt = P.rpt;
     a.win_slots = slots_used; a.max_runs = max_runs;
     // the matrix goes to LDS when everything fits next to the window
-    a.mat_entries = max_entries;
+    a.mat_entries = P.rpt == 1 ? max_entries : 0;
     if (getenv("BICG_PERSIST_LDSMAT") && atoi(getenv("BICG_PERSIST_LDSMAT")) == 0) a.mat_entries = 0;
-    if (persist_lds_bytes(a) > kPersistMaxLds) a.mat_entries = 0;
-    if (persist_lds_bytes(a) > kPersistMaxLds) { a = PersistArgs{}; return false; }
+    // what a workgroup may ask for on THIS device (gfx950: 160 KiB per CU; the static part of the kernels is < 6 KiB)
+    const unsigned lds_max = std::min<unsigned>(kPersistMaxLds, prop.sharedMemPerBlock > 8192 ? (unsigned)prop.sharedMemPerBlock - 6144u : 0u);
+    if (persist_lds_bytes(a) > lds_max) a.mat_entries = 0;
+    if (persist_lds_bytes(a) > lds_max) { a = PersistArgs{}; return false; }
     auto keep = [&](void *p) { c->persist_mem.push_back(p); return p; };
     a.pval = (const double *)keep(dev_upload(pval.data(), pval.size()));
     a.pslot = (const unsigned short *)keep(dev_upload(pslot.data(), pslot.size()));
@@ -1753,9 +1761,11 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
     a.rdiag = (const unsigned short *)keep(dev_upload(rdiag.data(), rdiag.size()));
     a.win_ptr = (const uint32_t *)keep(dev_upload(wptr.data(), wptr.size()));
     a.win_runs = (const uint2 *)keep(dev_upload(runs.data(), runs.size()));
-    for (int i = 0; i < 2; ++i) {
+    for (int i = 0; i < 4; ++i) {
         a.llv[i] = (llword *)keep(dev_alloc<llword>(2 * (size_t)nrows));
         BICG_HIP(hipMemset(a.llv[i], 0, sizeof(llword) * 2 * (size_t)nrows));
+    }
+    for (int i = 0; i < 2; ++i) {
         a.dtab[i] = (llword *)keep(dev_alloc<llword>((size_t)nwg * kRedSlots * 2));
         BICG_HIP(hipMemset(a.dtab[i], 0, sizeof(llword) * (size_t)nwg * kRedSlots * 2));
         a.arow[i] = (llword *)keep(dev_alloc<llword>(8));
@@ -1783,8 +1793,8 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
     a.v = c->v;
     a.alarm = c->alarm;
     if (getenv("BICG_DEBUG"))
-        fprintf(stderr, "bicgstab_hip: rank %d: persistent plan: %u workgroups x (%u + 64) threads (+1 helper), window %u slots (%u runs at most), "
-                        "matrix %s (%u entries per workgroup), %u bytes of LDS\n", c->rank, nwg, 64 * spw, slots_used, max_runs,
+        fprintf(stderr, "bicgstab_hip: rank %d: persistent plan: %u workgroups x (%u + 64) threads x %u rows (+1 helper), window %u slots (%u runs at most), "
+                        "matrix %s (%u entries per workgroup), %u bytes of LDS\n", c->rank, nwg, 64 * P.nrw, P.rpt, slots_used, max_runs,
                 a.mat_entries ? "in LDS" : "in memory", max_entries, persist_lds_bytes(a));
     return true;
 }
@@ -1795,11 +1805,20 @@ bool persist_chunk(bicg_ctx *c, int niter)
     if (c->grp.active) die("internal", "persistent chunk with an open dot group");
     if (c->f1_done) die("internal", "persistent chunk after phase 1 of the next iteration has run");
     const bool plain = c->method == BICG_BICGSTAB;
+    const bool pipe = c->method >= BICG_PIPE_BICGSTAB;
     const unsigned groups = plain ? 3u : 2u;                  // dot groups (tags, mailbox numbers) per iteration
     PersistArgs a = c->persist;
     a.v = c->v; a.S = c->S; a.alarm = c->alarm; a.niter = niter;
     a.seq0 = c->persist_seq;
-    c->persist_seq += groups * (unsigned)niter;
+    a.vseq0 = c->persist_vseq;
+    // the pipelined kernel numbers hand-offs and groups densely and reports what it used (replacement iterations and drift
+    // checks make the count data dependent): persist_account() advances the counters after the launch
+    if (!pipe) c->persist_seq += groups * (unsigned)niter;
+    a.it0 = c->it;
+    a.krr = c->method == BICG_PIPE_BICGSTAB_RR ? c->opt.krr : 0; a.nrr = c->opt.nrr;
+    a.force_first = 0;
+    a.drift_every = (pipe && c->opt.rr_drift > 0.0) ? c->opt.check_every : 0;
+    a.drift_tol2 = c->opt.rr_drift * c->opt.rr_drift;
     a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;          // 2 s inside one GPU
     static const int xcd_map = getenv("BICG_PERSIST_XCD") ? atoi(getenv("BICG_PERSIST_XCD")) : 1;
     a.xcd_map = xcd_map;
@@ -1807,8 +1826,9 @@ bool persist_chunk(bicg_ctx *c, int niter)
     a.first_sleep = (unsigned)first_sleep;
     if (a.multi) {
         // every rank advances its exchange and group numbers by the whole chunk, converged early or not
-        a.halo_seq0 = c->halo_seq; c->halo_seq += 2u * (unsigned)niter;
-        a.p2p = c->p2p->red_desc(c->p2p->red_seq); c->p2p->red_seq += groups * (unsigned)niter;
+        a.halo_seq0 = c->halo_seq;
+        a.p2p = c->p2p->red_desc(c->p2p->red_seq);
+        if (!pipe) { c->halo_seq += 2u * (unsigned)niter; c->p2p->red_seq += groups * (unsigned)niter; }
         a.ring = c->halo_ring;
         c->halo_unsynced = 0;
     }
@@ -1852,6 +1872,17 @@ bool persist_chunk(bicg_ctx *c, int niter)
             }
     }
     return true;
+}
+
+// after a pipelined persistent launch (fetch_scal has brought the scalar block back): advance the sequence counters by what
+// the launch consumed. Identical on every rank -- the decisions inside the launch depend on globally reduced sums only.
+void persist_account(bicg_ctx *c)
+{
+    const unsigned nv = (unsigned)c->hS->red[kRedUsedV], ng = (unsigned)c->hS->red[kRedUsedG];
+    c->persist_seq += ng;
+    c->persist_vseq += nv;
+    if (!c->single()) { c->halo_seq += nv; c->p2p->red_seq += ng; }
+    c->adaptive_rr += (int)c->hS->red[kRedAdaptive];
 }
 
 // vectors, reduction scratch and scalar blocks of a context whose plan (n_loc, halo, nblk) is known
@@ -1940,6 +1971,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
+    if (const char *sv = getenv("BICG_VEC_REV")) c->vec_rev = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
@@ -2432,6 +2464,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
+    if (const char *sv = getenv("BICG_VEC_REV")) c->vec_rev = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
     c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;

@@ -424,7 +424,7 @@ def persist_plan(blocks: HostBlocks, nranks: int, gmax: int):
     summ = (C.c_uint * 8)()
     if L.bicg_persist_plan(C.byref(blocks.diag), offd_p, gmax, summ, None, None, None, None, None, None, None) != 0:
         return None
-    spw, nwg, win_slots, max_runs, max_entries, entries, nruns, _ = list(summ)
+    spw, nwg, win_slots, max_runs, max_entries, entries, nruns, rpt = list(summ)      # spw: slices per workgroup; rpt: rows per thread
     n = blocks.n_loc
     nslices = (n + 63) // 64
     pbase = np.zeros(nslices + 1, dtype=np.uint32)
@@ -437,7 +437,7 @@ def persist_plan(blocks: HostBlocks, nranks: int, gmax: int):
     rc2 = L.bicg_persist_plan(C.byref(blocks.diag), offd_p, gmax, summ, pbase.ctypes.data_as(_up), pslot.ctypes.data_as(_usp), _d(pval),
                               rlen.ctypes.data_as(_usp), rdiag.ctypes.data_as(_usp), wptr.ctypes.data_as(_up), runs.ctypes.data_as(_up))
     assert rc2 == 0
-    return dict(spw=spw, nwg=nwg, win_slots=win_slots, max_runs=max_runs, max_entries=max_entries, entries=entries, halo=halo,
+    return dict(spw=spw, rpt=rpt, nwg=nwg, win_slots=win_slots, max_runs=max_runs, max_entries=max_entries, entries=entries, halo=halo,
                 pbase=pbase, pslot=pslot[:entries], pval=pval[:entries], rlen=rlen, rdiag=rdiag, wptr=wptr, runs=runs[:2 * nruns].reshape(-1, 2))
 
 

@@ -201,10 +201,15 @@ def test_hot_kernels_stay_lean():
         assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
     # round 3. The persistent kernels: up to 16 wavefronts of one workgroup per CU = 4 per SIMD = 128 VGPRs each; the
     # rows-over-lanes SpMV and the window-fused SpMV at full occupancy
+    # round 4: the pipelined kernel with one or two rows per thread (16 wavefronts per CU, 128 registers) and with eight (8
+    # wavefronts per CU = 2 per SIMD, 256 registers)
     persist = [k for k in kernels if re.search(r"k_(pipe|plain|ca)_persist", k)]
-    assert len(persist) == 12, persist
+    assert len(persist) == 16, persist
     for k in persist:
-        assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
+        if "k_pipe_persistILi8E" in k:
+            assert kernels[k]["Occupancy [waves/SIMD]"] >= 2 and kernels[k]["ScratchSize [bytes/lane]"] <= 256, (k, kernels[k])
+        else:
+            assert kernels[k]["VGPRs"] <= 128 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
     rows = [k for k in kernels if re.search(r"k_spmv_rowsILi[0-3]ELb0ELb[01]ELb[01]ELi0EEEv", k)]      # no offd, ticket / tail epilogue
     assert len(rows) >= 12, len(rows)
     for k in rows:
@@ -276,7 +281,7 @@ def test_persist_plan_decodes_back_to_the_matrix(kind, world):
         assert P is not None
         n = diag.rows
         nslices = (n + 63) // 64
-        assert P["spw"] == -(-nslices // gmax) and P["nwg"] == -(-nslices // P["spw"]) <= gmax
+        assert P["rpt"] == 1 and P["spw"] == -(-nslices // gmax) and P["nwg"] == -(-nslices // P["spw"]) <= gmax
         halo = P["halo"]
         if world > 1:
             _, halo_cols, _, ren = H.halo_plan(blk, world)
@@ -307,9 +312,15 @@ def test_persist_plan_decodes_back_to_the_matrix(kind, world):
         # padding: everything that is not an entry of some row is zero
         total = sum(int(P["rlen"][r]) for r in range(n))
         assert np.count_nonzero(P["pval"]) <= total and P["entries"] >= total
-    # a block too large for the workgroups on offer (more than 15 slices each) does not qualify
+    # more than 15 slices per workgroup: two rows per thread up to 30, eight (on 7 row wavefronts) up to 56 -- the plan is the
+    # same structure with spw = row wavefronts x rows per thread; beyond that the block does not qualify
     big = H.single_rank_blocks(synth.from_offsets(64 * 16 * 3 + 1, (0, 1, -1), diag_base=4.0, seed=1))
-    assert H.persist_plan(big, 1, 3) is None
+    P2 = H.persist_plan(big, 1, 3)             # 49 slices over 3 workgroups: 17 each -> 9 row wavefronts x 2 rows
+    assert P2 is not None and P2["rpt"] == 2 and P2["spw"] == 18 and P2["nwg"] == 3
+    P8 = H.persist_plan(big, 1, 1)             # 49 slices in one workgroup -> 7 row wavefronts x 8 rows
+    assert P8 is not None and P8["rpt"] == 8 and P8["spw"] == 56 and P8["nwg"] == 1
+    huge = H.single_rank_blocks(synth.from_offsets(64 * 57 + 1, (0, 1, -1), diag_base=4.0, seed=1))
+    assert H.persist_plan(huge, 1, 1) is None
 
 
 def test_rccl_loaded_by_the_library_then_torch_exits_cleanly():
