@@ -71,6 +71,27 @@ def shifted_iteration_bytes(nshift, nnz, rows, pipelined):
     return 2 * spmv_bytes(nnz, rows) + (nshift - 1) * 32 * rows + (192 if pipelined else 120) * rows
 
 
+MALL_BYTES = 256 * 1048576      # Infinity Cache
+NVEC = {"bicgstab": 6, "ca_bicgstab": 8, "pipe_bicgstab": 10, "pipe_bicgstab_rr": 11}
+
+
+def roof(gbps, matrix_bytes, rows, nvec, flags, stream, spmv_only=False):
+    """Which resource bounds a leg, and `frac` against THAT bound only (never a fraction of the HBM peak for an iteration
+    whose matrix sits in LDS or in the Infinity Cache):
+      latency: a rank the persistent kernels hold in LDS / registers (one launch per chunk of iterations): its time is a chain
+               of dependent hand-offs between workgroups, not bytes -- no bandwidth fraction is claimed (frac null);
+      mall:    matrix + vectors fit the 256 MiB Infinity Cache: peak = this GPU's read rate out of the Infinity Cache, measured
+               in this run (bicg_stream_bench on a 96 MiB array); frac null when that probe did not run;
+      hbm:     everything else: peak = 8 TB/s (MI355X_MICROARCH.md)."""
+    ws = matrix_bytes + 8 * rows * nvec
+    if not spmv_only and "persist" in flags and rows <= 250_000:
+        return dict(bound="latency", peak=None, frac=None)
+    if ws <= MALL_BYTES:
+        peak = stream.get("mall_read8") if isinstance(stream, dict) else None
+        return dict(bound="mall", peak=peak, frac=(gbps / peak) if peak else None)
+    return dict(bound="hbm", peak=HBM_PEAK_GBS, frac=gbps / HBM_PEAK_GBS)
+
+
 def measure_traffic(argv_inner, note):
     """HBM bytes per SpMV launch of THIS run's kernel, from rocprofv3 PMC counters collected now: two
     separate passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; the TCC block cannot hold both) over a short
@@ -289,12 +310,15 @@ def main():
                 dist.barrier()
             if not shared or rank == 0:
                 stream = {k: max(H.stream_bench(k, 1 << 30, 10) for _ in range(2)) for k in ("copy", "triad", "read8", "read16")}
+                # the same read loop on an array that fits the Infinity Cache: the denominator of the "mall"-bound legs
+                stream["mall_read8"] = max(H.stream_bench("read8", 96 << 20, 40) for _ in range(2))
             if dist is not None:
                 dist.barrier()
             if stream is None:
                 raise RuntimeError("measured by rank 0 only (ranks share the device)")
             stream["note"] = ("GB/s of bytes read + written, 1 GiB per array (4 x the Infinity Cache), fastest of {grid-stride, one "
-                              "workgroup per 16 KiB tile} x {ordinary, non-temporal} accesses; libbicgstab_hip.so bicg_stream_bench")
+                              "workgroup per 16 KiB tile} x {ordinary, non-temporal} accesses; mall_read8: the read loop on a 96 MiB "
+                              "array (served by the Infinity Cache); libbicgstab_hip.so bicg_stream_bench")
             note("STREAM on this GPU: " + ", ".join(f"{k} {v:.0f} GB/s" for k, v in stream.items() if k != "note"))
         except Exception as e:  # reported, never required
             stream = {"error": repr(e)}
@@ -440,6 +464,7 @@ def main():
         plan = leg.plan
         dt, res = leg.timed(a.method)
         ok, true_relres = leg.check()
+    head_flags_all = [k for k, v in leg.ctx.flags().items() if v]
     ms_step = 1e3 * dt / K
     relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
     genuine = res.iterations == W + K and np.isfinite(relres) and ok
@@ -450,6 +475,7 @@ def main():
         return
 
     stage[0] = "variant legs"
+    head_flags = [k for k, v in leg.ctx.flags().items() if v]
     variants, variant_roof = {}, {}
     if not a.no_variants:
         for m in ITER_VECTOR_BYTES_PER_ROW:
@@ -459,8 +485,9 @@ def main():
                 dtv, _ = leg.best(m)
                 variants[m] = 1e3 * dtv / K
             ib = iteration_bytes(m, nnz_global, n)
-            variant_roof[m] = dict(ms_per_iteration=variants[m], algorithmic_bytes=ib, gbps=ib / (variants[m] * 1e-3) / 1e9,
-                                   frac=ib / (variants[m] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            gb = ib / (variants[m] * 1e-3) / 1e9
+            variant_roof[m] = dict(ms_per_iteration=variants[m], algorithmic_bytes=ib, gbps=gb,
+                                   **roof(gb / world, leg.ctx.device_matrix_bytes(), plan["rows"], NVEC[m], head_flags, stream))
     if not a.no_variants and a.workload == "transport":
         # BASELINE.json configs[4] family: 16 shifts, seed 7, sigma_j = (j+1) 0.01/16 (reference
         # src/main_shifted.c:99 pattern); 2 SpMV + one batched update over all shifts per iteration
@@ -472,8 +499,9 @@ def main():
             key = f"{which}_{nsh}shifts"
             variants[key] = 1e3 * rs["result"].seconds / max(rs["k"], 1)
             ib = shifted_iteration_bytes(nsh, nnz_global, n, "pipe" in which)
-            variant_roof[key] = dict(ms_per_iteration=variants[key], algorithmic_bytes=ib, gbps=ib / (variants[key] * 1e-3) / 1e9,
-                                     frac=ib / (variants[key] * 1e-3) / 1e9 / HBM_PEAK_GBS)
+            gb = ib / (variants[key] * 1e-3) / 1e9
+            variant_roof[key] = dict(ms_per_iteration=variants[key], algorithmic_bytes=ib, gbps=gb,
+                                     **roof(gb / world, leg.ctx.device_matrix_bytes(), plan["rows"], 2 * nsh + 6, [], stream))
     spmv_alone_ms = leg.ctx.spmv_bench(200)
     # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
     # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps. It comes after
@@ -527,19 +555,21 @@ def main():
             stage[0] = f"extra workload {name}"
             lg = Leg(wl2)
             out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v])
+            mbytes = lg.ctx.device_matrix_bytes()
             for m in methods:
                 dtv, rv = lg.best(m, steps=steps, warm=min(W, 10))
                 ms = 1e3 * dtv / steps
                 ib = iteration_bytes(m, wl2["nnz"], wl2["rows"])
                 # genuine: every timed iteration was an unconverged one (a converged or broken-down solve idles)
                 out[m] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9,
-                              frac=ib / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, iterations=int(rv.iterations),
+                              **roof(ib / (ms * 1e-3) / 1e9 / world, mbytes, lg.plan["rows"], NVEC[m], out["flags"], stream),
+                              iterations=int(rv.iterations),
                               iterations_genuine=bool(int(rv.iterations) == steps + min(W, 10) and rv.breakdown_iteration == 0
                                                       and np.isfinite(rv.dot_r) and rv.dot_r > 0.0))
             sp = lg.ctx.spmv_bench(100)
             bs = spmv_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"], lg.plan["halo"])
-            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, frac=bs / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                            algorithmic_bytes_rank0=bs)
+            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, algorithmic_bytes_rank0=bs,
+                                            **roof(bs / (sp * 1e-3) / 1e9, mbytes, lg.plan["rows"], 2, out["flags"], stream, spmv_only=True))
             lg.close()
             note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods))
             return out
@@ -565,17 +595,48 @@ def main():
                 dtv, rv = lg.best(mth, steps=steps, warm=3, tries=1)
                 ms = 1e3 * dtv / steps
                 ib = iteration_bytes(mth, nnz, rows)
-                out[mth] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9, frac=ib / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
-                                iterations=int(rv.iterations),
+                # the TRUE residual b - A x (one more product on the device) against the recursive one the iterations carried:
+                # the check of the headline leg, at 134 M rows
+                okv, true_rel = lg.check()
+                out[mth] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9, bound="hbm", peak=HBM_PEAK_GBS,
+                                frac=ib / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, iterations=int(rv.iterations),
+                                true_relres_after_timed_region=true_rel,
                                 iterations_genuine=bool(int(rv.iterations) == steps + 3 and rv.breakdown_iteration == 0
-                                                        and np.isfinite(rv.dot_r) and rv.dot_r > 0.0))
+                                                        and np.isfinite(rv.dot_r) and rv.dot_r > 0.0 and okv))
             sp = ctx.spmv_bench(20)
             bs = spmv_bytes(nnz, rows)
-            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, frac=bs / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_rank0=bs)
+            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, bound="hbm", peak=HBM_PEAK_GBS,
+                                            frac=bs / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_rank0=bs)
             out["set_up_seconds_total"] = time.perf_counter() - t0
             ctx.close()
             note(f"laplace7 512^3: generated {gen_s:.2f} s, planned {plan_s:.2f} s, ca_bicgstab {out['ca_bicgstab']['ms_per_iteration']:.3f} ms, "
                  f"bicgstab {out['bicgstab']['ms_per_iteration']:.3f} ms per iteration")
+            return out
+        def small_rank_with_halo(nrows):
+            """The 8-GPU form with traffic in it, on what one GPU can hold twice: TWO processes share this GPU, each holds half of a
+            200 264-row Transport-shaped matrix (100 k rows + a 13 807-column halo towards the neighbour), pipelined BiCGStab as ONE
+            persistent launch per chunk with the halo values pushed into the neighbour's landing ring and the dot sums crossing the
+            mailboxes (this script under torch.distributed.run, transport host-p2p). Not a multi-GPU number: both ranks compete
+            for the same CUs and fabric; what it measures is the LL protocol carrying real halos."""
+            stage[0] = "extra workload small_rank_with_halo"
+            import socket
+            sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+            cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr", "127.0.0.1",
+                   "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", str(nrows), "--method", "pipe_bicgstab",
+                   "--steps", "400", "--warmup", "40", "--transport", "host-p2p", "--no-cpu-baseline", "--no-variants", "--no-extras",
+                   "--no-traffic", "--no-stream", "--no-rccl-leg", "--scale-decades", str(a.scale_decades)]
+            try:
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT,
+                                   env=dict(os.environ, BENCH_WATCHDOG_S="240", OMP_NUM_THREADS="2"))
+                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                out = dict(ranks=2, rows_per_rank=nrows // 2, ms_per_iteration=d["value"], bound="latency", frac=None,
+                           transport=d["config"]["transport"], flags=d["config"].get("flags"), halo=d["config"].get("halo"),
+                           iterations_genuine=d["config"]["iterations_genuine"],
+                           true_relres_after_timed_region=d["config"]["true_relres_after_timed_region"],
+                           note="two ranks SHARING this GPU (half the CUs each): the persistent kernel with real halos, not a 2-GPU time")
+            except Exception as e:      # reported, never required
+                out = {"error": repr(e)}
+            note(f"small_rank_with_halo: {out}")
             return out
         ke = min(K, 100)
         for hb in (8, 64, 512):
@@ -588,6 +649,7 @@ def main():
             n8 = (synth.TRANSPORT_N + 7) // 8
             wl8 = dict(build("transport", n=n8), desc=f"1/8 of the Transport-shaped matrix as one rank holds it at 8 GPUs ({n8} rows)")
             extras["transport_rank_of_8"] = extra("1/8 Transport rank", wl8, ("pipe_bicgstab", "bicgstab"), max(ke, 200))
+            extras["small_rank_with_halo"] = small_rank_with_halo(n8)
             extras["fem_like"] = extra("fem_like", build("fem_like"), ("bicgstab", "pipe_bicgstab"), ke)
             extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
             extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "
@@ -650,7 +712,7 @@ def main():
             "config": {"workload": wl["desc"],
                        "rows": n, "nnz": nnz_global, "scale_decades": a.scale_decades, "method": a.method,
                        "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
-                       "transport": transport_name,
+                       "transport": transport_name, "flags": head_flags_all, "halo": int(plan["halo"]),
                        "iterations_genuine": bool(genuine), "relres_after_timed_region": relres,
                        "true_relres_after_timed_region": true_relres},
             "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,

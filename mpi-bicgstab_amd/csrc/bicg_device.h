@@ -305,6 +305,7 @@ struct SpmvArgs {
     int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
     int     xcd_map;        // sliced-ELL: XCD-contiguous order of the groups (workgroup b runs on XCD b % 8; measurement knob)
+    int     vnt;            // sliced-ELL: the result and the dot operand are streamed (non-temporal): BICG_VEC_NT & 2
     int     reverse;        // sliced-ELL: workgroup b takes group nlist - 1 - b. Consecutive products of a solve alternate
                             // direction, so each starts on the part of the matrix the previous one left in the Infinity Cache
     HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only

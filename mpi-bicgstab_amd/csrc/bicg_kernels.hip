@@ -526,8 +526,14 @@ __device__ __forceinline__ unsigned shard_population(unsigned expected, unsigned
 }
 
 template <int ND, bool HEAVY>
-__device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const Reduce &red, unsigned slot, double *sm)
+__device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const Reduce &red, unsigned slot, double *sm,
+                                               unsigned order = 0xFFFFFFFFu)
 {
+    // slot: where this workgroup's partial goes (fixes the association of the group's sum); order: its position in LAUNCH
+    // order, which decides who stays behind to finish (tail finish: the workgroups launched last). They differ when a launch
+    // visits its row groups in another order than its workgroups are numbered (SpmvArgs::reverse / xcd_map): the partial of a
+    // row group lands in the same slot whatever the order, so the sums keep their bits.
+    if (order == 0xFFFFFFFFu) order = slot;
     __shared__ unsigned s_last;
     const unsigned shard = slot % kShards;
     block_sum<ND>(acc, sm);
@@ -535,8 +541,8 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
         // ---- tail finish: LL-tagged partials, producers leave at once (struct Reduce)
         const unsigned seq = red.tail_seq, nsh = red.expected < (unsigned)kShards ? red.expected : (unsigned)kShards;
         if (threadIdx.x < ND) ll_store_agent(red.tail_tab + (size_t)slot * kTailStride + 2 * threadIdx.x, acc[threadIdx.x], seq);
-        if (slot + nsh < red.expected) return;
-        const unsigned sh = red.expected - 1u - slot;                        // this workgroup's shard: 0 = the very last workgroup
+        if (order + nsh < red.expected) return;
+        const unsigned sh = red.expected - 1u - order;                       // this workgroup's shard: 0 = the very last workgroup
         const unsigned long long patience = 400000000ull;                   // 4 s: a lost workgroup must not hang the GPU
         double tot[ND];
 #pragma unroll
@@ -1405,10 +1411,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
     // 10 us per SpMV on Transport; a few groups per workgroup amortise it. Round-robin placement
     // over the XCDs is kept: an XCD-contiguous mapping cuts the fabric reads from 386 to 309 MB
     // (x is then fetched by one L2 instead of eight) but is 3-5 % SLOWER in wall time.
+    unsigned slot = bid;                  // the partial of a row group goes to the group's slot, whichever workgroup computed it
     for (unsigned gi0 = bid; gi0 < a.nlist; gi0 += nblocks) {
         unsigned gi = gi0;
         if (a.xcd_map && !LL && nblocks == a.nlist && gi0 < (a.nlist / 8u) * 8u) gi = (gi0 % 8u) * (a.nlist / 8u) + gi0 / 8u;
         if (a.reverse && !LL) gi = a.nlist - 1u - gi;
+        if (nblocks == a.nlist) slot = gi;
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
@@ -1416,9 +1424,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
         // batches; after it, it was a dependent round trip at the very end of every workgroup)
         double upre = 0.0;
         const uint32_t rguess = (a.glist ? a.glist[gi] : gi) * kGroupRows + threadIdx.x;
-        if (NDOT >= 1 && rguess < a.nrows) upre = a.u[rguess];
+        if (NDOT >= 1 && rguess < a.nrows) upre = a.vnt ? __builtin_nontemporal_load(a.u + rguess) : a.u[rguess];
         const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed, dyn_lds);
-        if (live && !done) a.y[row] = yi;
+        if (live && !done) { if (a.vnt) __builtin_nontemporal_store(yi, a.y + row); else a.y[row] = yi; }
         if (NDOT >= 1 && live) {
             const double ume = row == rguess ? upre : a.u[row];
             acc[0] += ume * yi;
@@ -1428,8 +1436,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
     }
     if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
     if (NDOT > 0 && !done) {
-        if (MODE == RED_WAVE) wave_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.red.partial, a.red.slot_base + bid);
-        else reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + bid, sm);
+        if (MODE == RED_WAVE) wave_publish<(NDOT > 0 ? NDOT : 1)>(acc, a.red.partial, a.red.slot_base + slot);
+        else reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + slot, sm, a.red.slot_base + bid);
     }
 }
 
@@ -1512,8 +1520,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         }                                                                                                 \
         have = true;                                                                                      \
     } while (0)
+    unsigned slot = bid;
     for (unsigned gi0 = bid; gi0 < a.nlist; gi0 += nblocks) {
         const unsigned gi = (a.reverse && !LL) ? a.nlist - 1u - gi0 : gi0;
+        if (nblocks == a.nlist) slot = gi;
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
@@ -1557,8 +1567,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     if (!have && fin_bid == 0) EPI_SCALARS();  // the publishing workgroup writes the scalar block even without rows
 #undef EPI_SCALARS
     if (LL && ll_failed) { a.S->comm_error = 1; a.S->done = 1; }
-    if (have && !sdone) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + bid);
-    else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + bid);
+    if (have && !sdone) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + slot);
+    else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + slot);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -2375,9 +2385,18 @@ unsigned vec_grid(uint32_t n)
         const int g = v ? atoi(v) : kMaxGrid;
         return (unsigned)(g >= 1 && g <= kMaxGrid ? g : kMaxGrid);
     }();
-    const unsigned cap = g_vec_grid_cap && g_vec_grid_cap < env_cap ? g_vec_grid_cap : env_cap;
+    // BICG_VEC_PPT=p (measurement knob): one workgroup per tile of p element pairs per thread (p x 4 KiB per stream) instead of
+    // <= 2048 persistent workgroups striding through the vectors -- on a pure read stream short workgroups measured 12 %
+    // faster than the grid-stride form (profiles/NOTES.md, STREAM); capped at the partial-sum slots every context has
+    static const unsigned ppt = [] { const char *v = getenv("BICG_VEC_PPT"); const int p = v ? atoi(v) : 0; return (unsigned)(p > 0 ? p : 0); }();
     unsigned g = ((n >> 1) + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
+    if (ppt && !g_vec_grid_cap) {
+        g = (g + ppt - 1) / ppt;
+        const unsigned slots = std::max<unsigned>(kMaxGrid, (n + kGroupRows - 1) / kGroupRows);      // ctx_state: nslots >= row groups
+        return g < slots ? g : slots;
+    }
+    const unsigned cap = g_vec_grid_cap && g_vec_grid_cap < env_cap ? g_vec_grid_cap : env_cap;
     if (g > cap) g = cap;
     return g;
 }
@@ -2430,25 +2449,36 @@ void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, const Launch 
     run_vec(FInit{v.r, v.rh, copy_p ? v.p : nullptr, save_b ? v.b : nullptr, v.ax}, v.n, L, red);
 }
 
+// BICG_VEC_NT=1 (plain BiCGStab): EVERY vector stream of the element-wise kernels is non-temporal, so that the 256 MiB
+// Infinity Cache is left to the matrix (245 MB on Transport), which the two products of an iteration sweep in opposite
+// directions
+static bool stream_all() { static const bool on = getenv("BICG_VEC_NT") && (atoi(getenv("BICG_VEC_NT")) & 1); return on; }
+template <bool NT, class T> __device__ __forceinline__ T ldx(const double *p, uint32_t i) { return NT ? ldnt<T>(p, i) : ld<T>(p, i); }
+template <bool NT, class T> __device__ __forceinline__ void stx(double *p, uint32_t i, T v) { if (NT) stnt(p, i, v); else st(p, i, v); }
+
 // ---- plain: q = r - alpha s (kept in r)                               (src/solver.c:94)
-struct FPlainQ {
+template <bool NT> struct FPlainQ {
     static constexpr int ND = 0;
     static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *r; const double *s; double alpha;
     template <class T> struct In { T r, s; };
     __device__ void load(const Scal *S) { alpha = S->alpha; }
-    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(r, i), ld<T>(s, i)}; }
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ldx<NT, T>(r, i), ldx<NT, T>(s, i)}; }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
     {
-        st(r, i, in.r + (-alpha) * in.s);
+        st(r, i, in.r + (-alpha) * in.s);       // q is the next product's input: cached
     }
     template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_q(const Vecs &v, const Launch &L) { run_vec(FPlainQ{v.r, v.s, 0.0}, v.n, L, Reduce{}); }
+void launch_plain_q(const Vecs &v, const Launch &L)
+{
+    if (stream_all()) run_vec(FPlainQ<true>{v.r, v.s, 0.0}, v.n, L, Reduce{});
+    else run_vec(FPlainQ<false>{v.r, v.s, 0.0}, v.n, L, Reduce{});
+}
 
 // ---- plain: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r)   (src/solver.c:105-111)
-template <bool XNT> struct FPlainXR {
+template <bool XNT, bool NT = false> struct FPlainXR {
     static constexpr int ND = 2;
     static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
@@ -2457,7 +2487,7 @@ template <bool XNT> struct FPlainXR {
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
     template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        return {ld<T>(q, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(y, i), ld<T>(rh, i)};
+        return {ldx<NT, T>(q, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ldx<NT, T>(p, i), ldx<NT, T>(y, i), ldx<NT, T>(rh, i)};
     }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
     {
@@ -2465,7 +2495,7 @@ template <bool XNT> struct FPlainXR {
         xx = xx + omega * in.q;
         if (XNT) stnt(x, i, xx); else st(x, i, xx);
         T rr = in.q + (-omega) * in.y;
-        st(r, i, rr);
+        stx<NT, T>(r, i, rr);
         acc[0] += hsum(rr * rr);
         acc[1] += hsum(in.rh * rr);
     }
@@ -2473,19 +2503,20 @@ template <bool XNT> struct FPlainXR {
 };
 void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red, const double *q)
 {
-    if (stream_x()) run_vec(FPlainXR<true>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
+    if (stream_all()) run_vec(FPlainXR<true, true>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
+    else if (stream_x()) run_vec(FPlainXR<true>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
     else run_vec(FPlainXR<false>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- plain: p = beta p ; p += r ; p += (-beta*omega) s                (src/solver.c:117-119)
-struct FPlainP {
+template <bool NT> struct FPlainP {
     static constexpr int ND = 0;
     static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *p; const double *r, *s; double beta, c;
     template <class T> struct In { T p, r, s; };
     __device__ void load(const Scal *S) { beta = S->beta; c = -S->beta * S->omega; }
-    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(p, i), ld<T>(r, i), ld<T>(s, i)}; }
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ldx<NT, T>(p, i), ldx<NT, T>(r, i), ldx<NT, T>(s, i)}; }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
     {
         T pp = beta * in.p;
@@ -2495,7 +2526,11 @@ struct FPlainP {
     }
     template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_p(const Vecs &v, const Launch &L) { run_vec(FPlainP{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{}); }
+void launch_plain_p(const Vecs &v, const Launch &L)
+{
+    if (stream_all()) run_vec(FPlainP<true>{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{});
+    else run_vec(FPlainP<false>{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{});
+}
 
 // ---- CA: p = r + beta(p - omega s) ; s = w + beta(s - omega z)         (src/solver.c:217-222)
 struct FCaPS {

@@ -78,9 +78,9 @@ struct bicg_ctx {
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
     int spmv_dir = 0;                      // direction of the last sliced-ELL product (SpmvArgs::reverse)
-    int sell_alt = 0;                      // BICG_SELL_ALT: consecutive products alternate direction
+    int sell_alt = 1;                      // BICG_SELL_ALT=0: every product forward; default: consecutive products alternate direction
     int vec_rev = 0;                       // BICG_VEC_REV: bit k = the k-th element-wise kernel of an iteration sweeps backwards
-    int sell_xcd = 0;                      // BICG_SELL_XCD: XCD-contiguous group order (measurement knob, SpmvArgs::xcd_map)
+    int sell_xcd = 1;                      // BICG_SELL_XCD=0: round robin; default: XCD-contiguous group order (SpmvArgs::xcd_map)
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
     bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
     uint64_t matrix_bytes = 0;             // bytes one SpMV streams from the matrix arrays
@@ -510,6 +510,8 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // evict it just before it is needed. Rows, hence results of the product, are unaffected; the dot partials of a
     // reversed launch land in mirrored slots (a different, equally fixed association).
     a.reverse = (c->sell_alt && c->single() && !fw) ? (c->spmv_dir ^= 1) : 0;
+    static const int vnt_env = getenv("BICG_VEC_NT") ? atoi(getenv("BICG_VEC_NT")) : 0;
+    a.vnt = (vnt_env & 2) && c->single() && c->method == BICG_BICGSTAB ? 1 : 0;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
     const bool fused = c->p2p && c->ll_fused;
@@ -987,7 +989,9 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     {
         static const int nvec[4] = {6, 8, 10, 11};
         const double ws = (double)c->matrix_bytes + 8.0 * c->stride * nvec[method];
-        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
+        // (round 4: with the products alternating direction, ordinary loads pay up to 35 % over the cache -- CA-BiCGStab
+        // 166.9 -> 150.6 us per iteration; the pipelined solvers' ten vectors are past that: 157.2 vs 160.9)
+        c->sell_nt = ws > (c->sell_alt ? 1.35 : 1.25) * 256.0 * 1048576.0;
         if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
     }
 
@@ -1334,6 +1338,10 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
             seed = now.seed;
             ++switches;
             const bool finished = c->hS->paused == 2;
+            // the reference's line at every switch (src/shifted_switching_solver.c:526; its k counts from 1). Its per-shift
+            // "sigma[j] eta: ..." debug lines (:522) are not reproduced.
+            if (c->rank == 0 && !o.quiet && !finished)
+                printf("k: %d, seed: %d, remain: %d\n", c->hS->k + 1, seed, nsig - now.stop_count);
             const int zero2[2] = {0, 0};
             if (!finished) BICG_HIP(hipMemcpyAsync(&c->S->done, &zero2[0], sizeof(int), hipMemcpyHostToDevice, c->sc));
             BICG_HIP(hipMemcpyAsync(&c->S->paused, &zero2[1], sizeof(int), hipMemcpyHostToDevice, c->sc));

@@ -46,6 +46,18 @@ def test_bench_json_keys_are_the_contract():
         assert re.search(rf'\b{key}=|"{key}"', open(os.path.join(ROOT, "tools", "cpu_baseline.py")).read()), key
 
 
+def test_bench_names_the_bound_of_every_leg():
+    """round 4: every variant / extra entry carries `bound` (hbm | mall | lds | latency) and `frac` against that bound only
+    (bench.py roof()); the latency-bound persistent iterations claim no bandwidth fraction; the two-ranks-with-halo leg and the
+    512^3 residual check are part of the default line"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    for key in ('bound="latency"', 'bound="mall"', 'bound="hbm"', "mall_read8", "small_rank_with_halo", "true_relres_after_timed_region"):
+        assert key in src, key
+    assert "frac=None" in src
+    # no entry is computed against the HBM peak outside roof() and the two legs that are HBM-sized by construction (512^3)
+    assert src.count("/ HBM_PEAK_GBS") <= 6, src.count("/ HBM_PEAK_GBS")
+
+
 def test_graft_entry_has_build_and_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g

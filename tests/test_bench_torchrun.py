@@ -15,6 +15,25 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 pytestmark = pytest.mark.gpu
 
 
+def _roof_ok(r):
+    """every leg names the resource that bounds it and claims a fraction of THAT bound only -- never above 1, and none at all
+    for the latency-bound persistent iterations"""
+    if r["bound"] == "latency":
+        return r["frac"] is None
+    if r["bound"] == "mall":
+        return r["frac"] is None or 0 < r["frac"] <= 1.0
+    return r["bound"] == "hbm" and 0 < r["frac"] < 1.0 and r["peak"] == 8000.0
+
+
+def _walk_roofs(d, path=""):
+    """(path, entry) of every dict below d that carries a `frac`"""
+    if isinstance(d, dict):
+        if "frac" in d and "bound" in d:
+            yield path, d
+        for k, v in d.items():
+            yield from _walk_roofs(v, f"{path}/{k}")
+
+
 def run_bench(n, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5",
@@ -52,7 +71,11 @@ def test_bench_under_torchrun(n, transport, extras):
             e = d["extras"][f"banded_b{hb}"]
             assert e["nnz"] > 20_000_000
             for m in ("bicgstab", "pipe_bicgstab"):
-                assert math.isfinite(e[m]["ms_per_iteration"]) and 0 < e[m]["frac"] < 1.0
+                assert math.isfinite(e[m]["ms_per_iteration"]) and _roof_ok(e[m]), e[m]
+
+
+def rfst(d):
+    return d["roofline"]["stream_measured_gbps"]
 
 
 def test_bench_single_gpu_line_has_every_leg():
@@ -66,7 +89,18 @@ def test_bench_single_gpu_line_has_every_leg():
     assert d["n_gpus"] == 1 and d["config"]["iterations_genuine"] is True and "configs[1]" in d["config"]["workload"]
     for m in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr", "shifted_lopbicgstab_16shifts", "shifted_pipe_lopbicgstab_16shifts"):
         r = d["variant_rooflines"][m]
-        assert 0.3 < r["frac"] < 1.0 and r["algorithmic_bytes"] > 8e8, (m, r)
+        assert r["bound"] == "hbm" and 0.3 < r["frac"] < 1.0 and r["algorithmic_bytes"] > 8e8, (m, r)
+    # no fraction of the HBM peak for legs that do not run out of HBM; nothing above 1 anywhere in the line
+    roofs = list(_walk_roofs(d))
+    assert len(roofs) >= 20 and all(_roof_ok(r) for _, r in roofs), [(p_, r) for p_, r in roofs if not _roof_ok(r)]
+    assert d["extras"]["transport_rank_of_8"]["pipe_bicgstab"]["bound"] == "latency"
+    assert d["extras"]["banded_b8"]["bicgstab"]["bound"] == "hbm" and d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["bound"] == "hbm"
+    assert rfst(d)["mall_read8"] > rfst(d)["read8"]
+    # the 8-GPU form with traffic in it: two ranks sharing this GPU, persistent launches, a real halo between them
+    sh = d["extras"]["small_rank_with_halo"]
+    assert "error" not in sh and sh["iterations_genuine"] is True and "persist" in sh["flags"] and sh["halo"] > 10000, sh
+    assert "peer-to-peer" in sh["transport"] and 0 < sh["ms_per_iteration"] < 0.1
+    assert math.isfinite(d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["true_relres_after_timed_region"])
     for key in ("banded_b8", "banded_b64", "banded_b512", "fem_like", "laplace7_256_ca", "laplace7_512_ca", "transport_rank_of_8"):
         assert key in d["extras"], key
         legs = [v for v in d["extras"][key].values() if isinstance(v, dict) and "ms_per_iteration" in v]

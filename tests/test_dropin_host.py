@@ -156,3 +156,35 @@ def test_c_host_falls_back_when_the_peer_to_peer_path_fails_in_a_solve(mtx, tmp_
         xs.append(np.frombuffer(raw[8:8 + 8 * nl], dtype=np.float64))
     assert np.abs(np.concatenate(xs) - 1.0).max() <= 1e-9
     assert float(re.search(r"Final r\s*:\s*(\S+)", out.stdout).group(1)) <= 1e-15
+
+
+@need
+@pytest.mark.parametrize("np_", [1, 2])
+def test_reference_shifted_driver_linked_against_hip_library(tmp_path, np_):
+    """BASELINE.json configs[4]'s own driver: the reference's UNMODIFIED main_shifted.c (512 shifts sigma_j = (j+1) 0.01/512,
+    seed 255, shifted_lopbicg_switching; src/main_shifted.c:13-14, 95-126) linked against libbicgstab_hip.so
+    (oracle/_ref/shifted_dropin), next to the all-reference build of the same file (oracle/_ref/shifted_ref) under mpiexec:
+    the iteration count the solver reports within +-3, the same seed switches (the reference's "k: .., seed: .., remain: .."
+    line, src/shifted_switching_solver.c:526, which the drop-in prints too) -- 512 shift systems of 30 k rows each resident
+    on the GPU (2 x 123 MB of x_j / p_j), every one advanced by the one batched kernel per iteration."""
+    dropin, ref = os.path.join(REF, "shifted_dropin"), os.path.join(REF, "shifted_ref")
+    if not (os.path.exists(dropin) and os.path.exists(ref)):
+        pytest.skip("shifted_dropin / shifted_ref not built")
+    path = str(tmp_path / "shifted.mtx")
+    synth.write_mtx(path, synth.from_offsets(30011, (0, 1, -1, 170, -170, 171, -171), diag_base=4.6, seed=5))
+
+    def run(binary):
+        out = subprocess.run([MPIEXEC, "-n", str(np_), binary, path], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, BICG_CHECK_EVERY="4"))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        k = int(re.search(r"Total iter\s*:\s*(\d+)", out.stdout).group(1))
+        sw = re.findall(r"^k: (\d+), seed: (\d+), remain: (\d+)", out.stdout, flags=re.M)
+        return k, sw, out.stdout
+
+    k_ref, sw_ref, out_ref = run(ref)
+    k, sw, out = run(dropin)
+    assert 0 < k_ref < 1000, out_ref[-2000:]                      # the reference converged all 512 systems inside MAX_ITER
+    assert abs(k - k_ref) <= 3, (k, k_ref, out[-2000:])
+    assert len(sw) == len(sw_ref), (sw, sw_ref)
+    for (ka, sa, ra), (kb, sb, rb) in zip(sw, sw_ref):
+        assert sa == sb and abs(int(ka) - int(kb)) <= 3 and abs(int(ra) - int(rb)) <= 32, (sw, sw_ref)
