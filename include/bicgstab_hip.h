@@ -312,10 +312,18 @@ enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FL
        BICG_FLAG_FUSE_PIPE = 1024 /* multi-launch pipelined iterations run their element-wise phases in the SpMV epilogues (two
                                      launches per iteration) rather than as separate kernels */,
        BICG_FLAG_PIPE_PROBED = 2048 /* ... and that was MEASURED on this matrix by the first pipelined solve (BICG_PIPE_PROBE=1)
-                                     instead of decided by the size / layout rule of bicg_create */ };
+                                     instead of decided by the size / layout rule of bicg_create */,
+       BICG_FLAG_UNIFORM = 4096   /* some 64-row slices are UNIFORM -- all rows present, equally long, entry k at the same distance
+                                     from its row in every row (the interior of a banded or stencil matrix): the SpMV takes their
+                                     columns from one shared list of distances and reads no column index for them (8 instead of
+                                     10 / 12 bytes per non-zero); bicg_uniform_entries counts those entries */ };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 /* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);
+/* sliced-ELL entries (padding included) whose column indices the SpMV does not read (BICG_FLAG_UNIFORM), and the bytes one
+ * SpMV streams from the matrix arrays (values + the column indices it does read + row pointers) */
+unsigned long long bicg_uniform_entries(bicg_ctx *ctx);
+unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------
  * 5. Host-only helpers (no GPU needed; unit-tested on CPU).

@@ -199,7 +199,6 @@ struct Launch {
     Scal *S;
     Finish fin;
     hipStream_t st;
-    int rev = 0;         // element-wise kernels (ticket mode): sweep the vectors from the end (Infinity-Cache reuse, see SpmvArgs::reverse)
 };
 
 struct CsrDev {
@@ -238,6 +237,13 @@ struct SellDev {
     // 256-row group are dealt to the lanes by decreasing length (perm[g * 256 + lane] = row within the group),
     // which makes the four slices of a group as long as their own longest row instead of the group's (null: lane = row)
     const unsigned char *perm;
+    // Uniform slices (padded layouts): when all 64 rows of a slice are present, equally long and entry k of every row sits at
+    // the SAME distance from its row -- every interior slice of a banded or stencil matrix -- the slice's columns are the list
+    // uoff[ubase[slice] + k] (shared by all slices with the same list) and the SpMV does not read its col / col16 entries at
+    // all: 8 instead of 10 (12) bytes per non-zero, the offsets arrive as scalar loads. ubase[slice] = 0xFFFFFFFF: not uniform.
+    // (col / col16 stay complete: the SpMM and the window-fused product read them.)
+    const uint32_t *ubase;
+    const int      *uoff;
 };
 enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4 };
 constexpr uint32_t kWinMaxSlots = 4096;      // 32 KB of LDS per workgroup: 4 workgroups per CU
@@ -305,7 +311,6 @@ struct SpmvArgs {
     int     nt;             // stream the matrix arrays with non-temporal loads (Infinity-Cache policy)
     int     groups_per_wg;  // sliced-ELL: 256-row groups handled by one workgroup
     int     xcd_map;        // sliced-ELL: XCD-contiguous order of the groups (workgroup b runs on XCD b % 8; measurement knob)
-    int     vnt;            // sliced-ELL: the result and the dot operand are streamed (non-temporal): BICG_VEC_NT & 2
     int     reverse;        // sliced-ELL: workgroup b takes group nlist - 1 - b. Consecutive products of a solve alternate
                             // direction, so each starts on the part of the matrix the previous one left in the Infinity Cache
     HaloLL  ll;             // launch_spmv_sell(..., fused_halo = true) only
@@ -476,6 +481,7 @@ void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce re
 // device-side sliced-ELL plan (bicg_plan_device.hip): slice lengths + "some column is further than 32767 from its row",
 // then the column-major padded copy (32-bit columns or packed 16-bit offsets)
 void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far, hipStream_t st);
+void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, uint32_t rows, unsigned long long *uhash, hipStream_t st);
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st);
 

@@ -1318,7 +1318,27 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
                 if (mine[e]) sum += v[e] * xv[e];             // stored order
         }
     }
-    for (uint32_t k0 = 0; !JAG && k0 < len; k0 += U) {
+    // uniform slice: the columns are row + uoff[k], one list for the whole slice (scalar loads) -- no col / col16 traffic
+    uint32_t ub = 0xFFFFFFFFu;
+    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
+    if (!JAG && ub != 0xFFFFFFFFu) {
+        const int *__restrict__ uo = a.sell.uoff + ub;            // padded with zeros to a multiple of U (+ U)
+        for (uint32_t k0 = 0; k0 < len; k0 += U) {
+            double v[U], xv[U];
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const bool ok = k0 + e < len;                     // wave-uniform
+                const uint32_t j = base + (k0 + e) * kSliceRows + lane;
+                v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
+            }
+#pragma unroll
+            for (int e = 0; e < U; ++e) xv[e] = x[(int)row + uo[k0 + e]];      // every row of a uniform slice is live
+#pragma unroll
+            for (int e = 0; e < U; ++e)
+                if (k0 + e < mylen) sum += v[e] * xv[e];          // stored order; padding never added
+        }
+    }
+    for (uint32_t k0 = 0; !JAG && ub == 0xFFFFFFFFu && k0 < len; k0 += U) {
         uint32_t c[U];
         double   v[U];
         if (C16) {
@@ -1424,9 +1444,9 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
         // batches; after it, it was a dependent round trip at the very end of every workgroup)
         double upre = 0.0;
         const uint32_t rguess = (a.glist ? a.glist[gi] : gi) * kGroupRows + threadIdx.x;
-        if (NDOT >= 1 && rguess < a.nrows) upre = a.vnt ? __builtin_nontemporal_load(a.u + rguess) : a.u[rguess];
+        if (NDOT >= 1 && rguess < a.nrows) upre = a.u[rguess];
         const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed, dyn_lds);
-        if (live && !done) { if (a.vnt) __builtin_nontemporal_store(yi, a.y + row); else a.y[row] = yi; }
+        if (live && !done) a.y[row] = yi;
         if (NDOT >= 1 && live) {
             const double ume = row == rguess ? upre : a.u[row];
             acc[0] += ume * yi;
@@ -2363,13 +2383,8 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
         if (S->done) return;
         __shared__ double sm[5 * ND];
         f.load(S);
-        // ticket modes: bit 31 of n = sweep the vectors from the end (Launch::rev; the sign bit instead of one more kernel
-        // argument, which cost the consumer-side instantiations four registers and a wave per SIMD)
-        const bool rev = (n >> 31) != 0u;
-        const uint32_t nn = n & 0x7fffffffu, np = nn >> 1;
-        if (rev) { for (uint32_t i = i0; i < np; i += stride) f.template apply<d2>(2 * (np - 1u - i), acc); }
-        else { for (uint32_t i = i0; i < np; i += stride) f.template apply<d2>(2 * i, acc); }
-        if ((nn & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(nn - 1, acc);
+        for (uint32_t i = i0; i < npair; i += stride) f.template apply<d2>(2 * i, acc);
+        if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
         if (F::ND > 0) reduce_publish<ND, MODE == RED_TICKET_HEAVY>(acc, S, red, blockIdx.x, sm);
     }
 }
@@ -2385,12 +2400,15 @@ unsigned vec_grid(uint32_t n)
         const int g = v ? atoi(v) : kMaxGrid;
         return (unsigned)(g >= 1 && g <= kMaxGrid ? g : kMaxGrid);
     }();
-    // BICG_VEC_PPT=p (measurement knob): one workgroup per tile of p element pairs per thread (p x 4 KiB per stream) instead of
-    // <= 2048 persistent workgroups striding through the vectors -- on a pure read stream short workgroups measured 12 %
-    // faster than the grid-stride form (profiles/NOTES.md, STREAM); capped at the partial-sum slots every context has
-    static const unsigned ppt = [] { const char *v = getenv("BICG_VEC_PPT"); const int p = v ? atoi(v) : 0; return (unsigned)(p > 0 ? p : 0); }();
+    // Vectors far beyond the caches (>= 64 M rows): one workgroup per tile of 4 element pairs per thread (16 KiB per stream)
+    // instead of <= 2048 persistent workgroups striding through the vectors -- short workgroups stream faster (STREAM read:
+    // +12 %, profiles/NOTES.md; 512^3 Laplacian: plain 9.12 -> 8.65 ms, CA 10.86 -> 10.10 ms per iteration, round 4). At
+    // 16.8 M rows (256^3) and at Transport size the two forms tie. BICG_VEC_PPT=p forces p pairs per thread everywhere
+    // (0: never); the grid is capped at the partial-sum slots every context has.
+    static const int ppt_env = [] { const char *v = getenv("BICG_VEC_PPT"); return v ? atoi(v) : -1; }();
     unsigned g = ((n >> 1) + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
+    const unsigned ppt = ppt_env >= 0 ? (unsigned)ppt_env : (n >= (1u << 26) ? 4u : 0u);
     if (ppt && !g_vec_grid_cap) {
         g = (g + ppt - 1) / ppt;
         const unsigned slots = std::max<unsigned>(kMaxGrid, (n + kGroupRows - 1) / kGroupRows);      // ctx_state: nslots >= row groups
@@ -2409,7 +2427,6 @@ static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
     red.slot_base = 0;
     constexpr int modes = vec_modes<F>::value;
     const int mode = modes == kWaveOnly ? RED_WAVE : red_mode(red, L.fin, F::ND > 0);
-    const uint32_t nrev = L.rev ? (n | 0x80000000u) : n;      // ticket modes only (k_vec)
     if (!((modes >> mode) & 1)) {
         fprintf(stderr, "ERROR: bicgstab_hip: element-wise kernel launched in reduction mode %d it is not built for\n", mode);
         abort();
@@ -2417,9 +2434,9 @@ static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
     if constexpr ((modes >> RED_WAVE) & 1)
         if (mode == RED_WAVE) { BICG_LAUNCH((k_vec<F, RED_WAVE>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
     if constexpr (((modes >> RED_TICKET_HEAVY) & 1) && F::ND > 0)
-        if (mode == RED_TICKET_HEAVY) { BICG_LAUNCH((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, nrev, L.S, red, L.fin); return; }
+        if (mode == RED_TICKET_HEAVY) { BICG_LAUNCH((k_vec<F, RED_TICKET_HEAVY>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
     if constexpr ((modes >> RED_TICKET) & 1)
-        BICG_LAUNCH((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, nrev, L.S, red, L.fin);
+        BICG_LAUNCH((k_vec<F, RED_TICKET>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin);
 }
 // shifted solvers and kernel-level entry points: scalar block updated in place, ticket reductions
 template <class F>
@@ -2449,36 +2466,25 @@ void launch_init_residual(const Vecs &v, bool copy_p, bool save_b, const Launch 
     run_vec(FInit{v.r, v.rh, copy_p ? v.p : nullptr, save_b ? v.b : nullptr, v.ax}, v.n, L, red);
 }
 
-// BICG_VEC_NT=1 (plain BiCGStab): EVERY vector stream of the element-wise kernels is non-temporal, so that the 256 MiB
-// Infinity Cache is left to the matrix (245 MB on Transport), which the two products of an iteration sweep in opposite
-// directions
-static bool stream_all() { static const bool on = getenv("BICG_VEC_NT") && (atoi(getenv("BICG_VEC_NT")) & 1); return on; }
-template <bool NT, class T> __device__ __forceinline__ T ldx(const double *p, uint32_t i) { return NT ? ldnt<T>(p, i) : ld<T>(p, i); }
-template <bool NT, class T> __device__ __forceinline__ void stx(double *p, uint32_t i, T v) { if (NT) stnt(p, i, v); else st(p, i, v); }
-
 // ---- plain: q = r - alpha s (kept in r)                               (src/solver.c:94)
-template <bool NT> struct FPlainQ {
+struct FPlainQ {
     static constexpr int ND = 0;
     static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *r; const double *s; double alpha;
     template <class T> struct In { T r, s; };
     __device__ void load(const Scal *S) { alpha = S->alpha; }
-    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ldx<NT, T>(r, i), ldx<NT, T>(s, i)}; }
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(r, i), ld<T>(s, i)}; }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
     {
-        st(r, i, in.r + (-alpha) * in.s);       // q is the next product's input: cached
+        st(r, i, in.r + (-alpha) * in.s);
     }
     template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_q(const Vecs &v, const Launch &L)
-{
-    if (stream_all()) run_vec(FPlainQ<true>{v.r, v.s, 0.0}, v.n, L, Reduce{});
-    else run_vec(FPlainQ<false>{v.r, v.s, 0.0}, v.n, L, Reduce{});
-}
+void launch_plain_q(const Vecs &v, const Launch &L) { run_vec(FPlainQ{v.r, v.s, 0.0}, v.n, L, Reduce{}); }
 
 // ---- plain: x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r)   (src/solver.c:105-111)
-template <bool XNT, bool NT = false> struct FPlainXR {
+template <bool XNT> struct FPlainXR {
     static constexpr int ND = 2;
     static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
@@ -2487,7 +2493,7 @@ template <bool XNT, bool NT = false> struct FPlainXR {
     __device__ void load(const Scal *S) { alpha = S->alpha; omega = S->omega; }
     template <class T> __device__ In<T> fetch(uint32_t i) const
     {
-        return {ldx<NT, T>(q, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ldx<NT, T>(p, i), ldx<NT, T>(y, i), ldx<NT, T>(rh, i)};
+        return {ld<T>(q, i), XNT ? ldnt<T>(x, i) : ld<T>(x, i), ld<T>(p, i), ld<T>(y, i), ld<T>(rh, i)};
     }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *acc) const
     {
@@ -2495,7 +2501,7 @@ template <bool XNT, bool NT = false> struct FPlainXR {
         xx = xx + omega * in.q;
         if (XNT) stnt(x, i, xx); else st(x, i, xx);
         T rr = in.q + (-omega) * in.y;
-        stx<NT, T>(r, i, rr);
+        st(r, i, rr);
         acc[0] += hsum(rr * rr);
         acc[1] += hsum(in.rh * rr);
     }
@@ -2503,20 +2509,19 @@ template <bool XNT, bool NT = false> struct FPlainXR {
 };
 void launch_plain_xr(const Vecs &v, const Launch &L, Reduce red, const double *q)
 {
-    if (stream_all()) run_vec(FPlainXR<true, true>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
-    else if (stream_x()) run_vec(FPlainXR<true>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
+    if (stream_x()) run_vec(FPlainXR<true>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
     else run_vec(FPlainXR<false>{v.x, v.r, q ? q : v.r, v.p, v.y, v.rh, 0.0, 0.0}, v.n, L, red);
 }
 
 // ---- plain: p = beta p ; p += r ; p += (-beta*omega) s                (src/solver.c:117-119)
-template <bool NT> struct FPlainP {
+struct FPlainP {
     static constexpr int ND = 0;
     static constexpr int kModes = kAnyMode;
     static constexpr bool kSplit = true;
     double *p; const double *r, *s; double beta, c;
     template <class T> struct In { T p, r, s; };
     __device__ void load(const Scal *S) { beta = S->beta; c = -S->beta * S->omega; }
-    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ldx<NT, T>(p, i), ldx<NT, T>(r, i), ldx<NT, T>(s, i)}; }
+    template <class T> __device__ In<T> fetch(uint32_t i) const { return {ld<T>(p, i), ld<T>(r, i), ld<T>(s, i)}; }
     template <class T> __device__ void compute(uint32_t i, const In<T> &in, double *) const
     {
         T pp = beta * in.p;
@@ -2526,11 +2531,7 @@ template <bool NT> struct FPlainP {
     }
     template <class T> __device__ void apply(uint32_t i, double *acc) const { compute<T>(i, fetch<T>(i), acc); }
 };
-void launch_plain_p(const Vecs &v, const Launch &L)
-{
-    if (stream_all()) run_vec(FPlainP<true>{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{});
-    else run_vec(FPlainP<false>{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{});
-}
+void launch_plain_p(const Vecs &v, const Launch &L) { run_vec(FPlainP{v.p, v.r, v.s, 0.0, 0.0}, v.n, L, Reduce{}); }
 
 // ---- CA: p = r + beta(p - omega s) ; s = w + beta(s - omega z)         (src/solver.c:217-222)
 struct FCaPS {

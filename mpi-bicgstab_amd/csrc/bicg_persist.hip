@@ -165,11 +165,10 @@ __device__ __forceinline__ void stage_window(const PersistArgs &a, const uint2 *
 }
 
 // y_i of this lane's row: diag entries in stored order, then the offd entries (reference src/matrix.c:434-440, 506-515)
-template <bool MULTI>
+template <bool MULTI, int U = 8>
 __device__ __forceinline__ double persist_row(const double *mval, const unsigned short *mslot, uint32_t slen, uint32_t mylen, uint32_t mydiag,
                                               const double *win)
 {
-    constexpr int U = 8;
     const unsigned lane = threadIdx.x & 63u;
     double sd = 0.0, so = 0.0;
     for (uint32_t k0 = 0; k0 < slen; k0 += U) {
@@ -575,8 +574,9 @@ __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, cons
         for (int j = 0; j < R; ++j) {
             const double *mv = LDSMAT ? W.mval + (rs.sbase[j] - W.e0) : a.pval + rs.sbase[j];
             const unsigned short *ms = LDSMAT ? W.mslot + (rs.sbase[j] - W.e0) : a.pslot + rs.sbase[j];
-            out[j] = persist_row<MULTI>(mv, ms, rs.slen[j], rs.lens[j] & 0xFFFFu, rs.lens[j] >> 16, W.win);
-            if (R > 1) __builtin_amdgcn_sched_barrier(0);      // one row's batches at a time: interleaved, R products' loads do not fit the registers
+            // eight rows per thread: 16 entries of a row in flight -- a Transport row in ONE round trip; a product is a chain
+            // of R x (batches per row) dependent round trips
+            out[j] = persist_row<MULTI, (R > 2 ? 16 : 8)>(mv, ms, rs.slen[j], rs.lens[j] & 0xFFFFu, rs.lens[j] >> 16, W.win);
         }
     }
     lds_barrier();

@@ -41,6 +41,27 @@ __global__ void __launch_bounds__(kThreads) k_plan_rowstats(const uint32_t *ptr,
     if (__any(is_far) && (threadIdx.x & 63u) == 0) atomicOr(far, 1);
 }
 
+// uniform slices (SellDev::ubase): uhash[s] != 0 when all 64 rows of slice s are present, equally long, and entry k sits at
+// the same distance from its row in every row; its value is a 64-bit hash of the distances (the host groups slices by hash
+// and fetches one list per group). One wavefront per slice, lane = row.
+__global__ void __launch_bounds__(kThreads) k_plan_uniform(const uint32_t *ptr, const uint32_t *col, uint32_t rows, unsigned long long *uhash)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    const bool live = r < rows;
+    const uint32_t a = live ? ptr[r] : 0u, len = live ? ptr[r + 1] - a : 0u;
+    const uint32_t len0 = (uint32_t)__builtin_amdgcn_readfirstlane((int)len);
+    bool uni = __all(live && len == len0) && len0 > 0;
+    unsigned long long h = 0xcbf29ce484222325ull ^ len0;
+    for (uint32_t k = 0; uni && k < len0; ++k) {
+        const int d = (int)((long long)col[a + k] - (long long)r);
+        const int d0 = __builtin_amdgcn_readfirstlane(d);
+        uni = __all(d == d0);
+        h = (h ^ (unsigned long long)(unsigned)d0) * 0x100000001b3ull;
+        h ^= h >> 29;
+    }
+    if ((threadIdx.x & 63u) == 0 && live) uhash[r / kSliceRows] = uni ? (h | 1ull) : 0ull;
+}
+
 // entry k of row r -> slice_base[r / 64] + k * 64 + r % 64 (padding stays zero); 16-bit offsets four to a word
 __global__ void __launch_bounds__(kThreads) k_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
                                                         const uint32_t *slice_base, const uint32_t *slice_base16, double *sval,
@@ -94,6 +115,10 @@ __global__ void __launch_bounds__(kThreads) k_stencil_fill(unsigned m, uint32_t 
 void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far, hipStream_t st)
 {
     hipLaunchKernelGGL(k_plan_rowstats, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, rows, slice_len, far);
+}
+void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, uint32_t rows, unsigned long long *uhash, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_plan_uniform, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, rows, uhash);
 }
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st)

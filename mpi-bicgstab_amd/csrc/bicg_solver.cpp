@@ -13,6 +13,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <map>
 #include <vector>
 
 #include "bicg_comm.h"
@@ -79,7 +80,6 @@ struct bicg_ctx {
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
     int spmv_dir = 0;                      // direction of the last sliced-ELL product (SpmvArgs::reverse)
     int sell_alt = 1;                      // BICG_SELL_ALT=0: every product forward; default: consecutive products alternate direction
-    int vec_rev = 0;                       // BICG_VEC_REV: bit k = the k-th element-wise kernel of an iteration sweeps backwards
     int sell_xcd = 1;                      // BICG_SELL_XCD=0: round robin; default: XCD-contiguous group order (SpmvArgs::xcd_map)
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
     bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
@@ -89,6 +89,9 @@ struct bicg_ctx {
     double *s_val = nullptr;
     uint32_t *s_col = nullptr, *s_base = nullptr, *s_len = nullptr, *s_base16 = nullptr;
     short *s_col16 = nullptr;
+    uint32_t *s_ubase = nullptr;           // uniform slices (SellDev::ubase / uoff): BICG_SELL_UNIFORM=0 switches them off
+    int *s_uoff = nullptr;
+    uint64_t uniform_entries = 0;          // sliced-ELL entries whose columns the SpMV does not read
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
     uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
     uint32_t win_max_runs = 0;             // most runs of one group's window
@@ -490,6 +493,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.fin = fin;
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
+    a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -510,8 +514,6 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // evict it just before it is needed. Rows, hence results of the product, are unaffected; the dot partials of a
     // reversed launch land in mirrored slots (a different, equally fixed association).
     a.reverse = (c->sell_alt && c->single() && !fw) ? (c->spmv_dir ^= 1) : 0;
-    static const int vnt_env = getenv("BICG_VEC_NT") ? atoi(getenv("BICG_VEC_NT")) : 0;
-    a.vnt = (vnt_env & 2) && c->single() && c->method == BICG_BICGSTAB ? 1 : 0;
     const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
     const bool fused = c->p2p && c->ll_fused;
@@ -792,8 +794,7 @@ struct Driver {
     }
 
     // plain and CA-BiCGStab: ticket reductions, scalars applied in place by the producer's last workgroup
-    // bit: which element-wise kernel of the iteration (BICG_VEC_REV mask: that kernel sweeps from the end)
-    Launch here(int bit = -1) const { return Launch{c->S, Finish{}, c->sc, bit >= 0 && c->single() ? (c->vec_rev >> bit) & 1 : 0}; }
+    Launch here() const { return Launch{c->S, Finish{}, c->sc}; }
 
     void init()
     {
@@ -847,21 +848,21 @@ struct Driver {
         if (fused_plain()) { iter_plain_fused(); return; }
         spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
-        launch_plain_q(v, here(0));                              // q = r - alpha s
+        launch_plain_q(v, here());                              // q = r - alpha s
         spmv(c, v.r, v.y, 2, v.r, c->red(0, PH_OMEGA, true, 2));          // y = A q, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_plain_xr(v, here(1), c->red(0, PH_PLAIN_END, true, 2));    // x, r, (r,r), (r#,r) -> beta, k++
+        launch_plain_xr(v, here(), c->red(0, PH_PLAIN_END, true, 2));    // x, r, (r,r), (r#,r) -> beta, k++
         group_now(c, 2, PH_PLAIN_END);
-        launch_plain_p(v, here(2));                              // p = r + beta (p - omega s)
+        launch_plain_p(v, here());                              // p = r + beta (p - omega s)
     }
 
     void iter_ca()      // reference src/solver.c:217-251
     {
-        launch_ca_ps(v, here(0));                                // p, s recurrences
+        launch_ca_ps(v, here());                                // p, s recurrences
         spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
-        launch_qy(v, here(1), c->red(0, PH_OMEGA, true, 2));     // q, y, (q,y), (y,y) -> omega
+        launch_qy(v, here(), c->red(0, PH_OMEGA, true, 2));     // q, y, (q,y), (y,y) -> omega
         group_now(c, 2, PH_OMEGA);
-        launch_ca_xr(v, here(2), c->red(0, PH_NONE, false));     // x, r, (r,r), (r#,r), (r#,s), (r#,z)
+        launch_ca_xr(v, here(), c->red(0, PH_NONE, false));     // x, r, (r,r), (r#,r), (r#,s), (r#,z)
         spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END, true, 5));     // w = A r, (r#,w) -> beta, alpha, k++
         group_now(c, 5, PH_RECUR_END);
     }
@@ -1979,7 +1980,6 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
-    if (const char *sv = getenv("BICG_VEC_REV")) c->vec_rev = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
@@ -2279,6 +2279,41 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         }
     }
 
+    // Uniform slices (SellDev::ubase): all 64 rows present, equally long, entry k at the same distance from its row in
+    // every row. Lists are shared between slices (a banded matrix has ONE for its whole interior) and padded with zeros.
+    std::vector<uint32_t> ubase;
+    std::vector<int> uoff;
+    uint64_t uniform_entries = 0;
+    if (!jag && sell_entries > 0 && !(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
+        ubase.assign(nslices, 0xFFFFFFFFu);
+        std::map<std::vector<int>, uint32_t> lists;
+        std::vector<int> cur;
+        for (uint32_t sl = 0; sl < nslices; ++sl) {
+            if (!group_is_sell[sl / (kGroupRows / kSliceRows)] || (sl + 1) * kSliceRows > nrows || slice_len[sl] == 0) continue;
+            const uint32_t r0 = sl * kSliceRows, len = slice_len[sl];
+            bool uni = true;
+            for (uint32_t l = 0; l < kSliceRows && uni; ++l) uni = diag->ptr[r0 + l + 1] - diag->ptr[r0 + l] == len;
+            if (!uni) continue;
+            cur.assign(len, 0);
+            for (uint32_t k = 0; k < len; ++k) cur[k] = (int)((int64_t)diag->col[diag->ptr[r0] + k] - (int64_t)r0);
+            for (uint32_t l = 1; l < kSliceRows && uni; ++l)
+                for (uint32_t k = 0; k < len; ++k)
+                    if ((int64_t)diag->col[diag->ptr[r0 + l] + k] - (int64_t)(r0 + l) != cur[k]) { uni = false; break; }
+            if (!uni) continue;
+            auto it = lists.find(cur);
+            if (it == lists.end()) {
+                if (uoff.size() + len + 32 > (1u << 24)) continue;            // the table stays small (scalar cache)
+                it = lists.emplace(cur, (uint32_t)uoff.size()).first;
+                uoff.insert(uoff.end(), cur.begin(), cur.end());
+                uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);               // batches of up to 16 entries read past the list
+            }
+            ubase[sl] = it->second;
+            uniform_entries += (uint64_t)len * kSliceRows;
+        }
+        if (uniform_entries == 0) { ubase.clear(); uoff.clear(); }
+    }
+    c->uniform_entries = uniform_entries;
+
     // CSR row blocks over the maximal runs of non-SELL groups
     std::vector<uint32_t> rb(nrows + 1);
     for (uint32_t g = 0; g < ngroups;) {
@@ -2330,8 +2365,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // (jagged slices: lanes whose row has ended read up to one entry past the last -- kPadEntries of slack)
     c->s_val = dev_upload_padded(sval.data(), (size_t)sell_entries, kPadEntries);
     c->s_col = dev_upload_padded(scol.data(), c16 ? 0 : (size_t)sell_entries, kPadEntries);
-    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) + 8ull * nslices + 4ull * (nrows + 1) +
+    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) + 8ull * nslices + 4ull * (nrows + 1) +
                       (uint64_t)(c->nnz_d - c->sell_nnz) * (csr16 ? 10 : 12) + (uint64_t)c->nnz_o * 12;
+    if (!ubase.empty()) {
+        c->s_ubase = dev_upload(ubase.data(), ubase.size());
+        c->s_uoff = dev_upload(uoff.data(), uoff.size());
+    }
     c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
@@ -2472,7 +2511,6 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
     if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
-    if (const char *sv = getenv("BICG_VEC_REV")) c->vec_rev = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
     c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;
@@ -2492,6 +2530,43 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->s_base = dev_upload(sbase.data(), sbase.size());
     c->s_len = slen_d;
     launch_plan_fill(ptr_d, col_d, val_d, rows, c->s_base, c->s_base16, c->s_val, c16 ? nullptr : c->s_col, c16 ? c->s_col16 : nullptr, nullptr);
+    // uniform slices (SellDev::ubase): found by a kernel, grouped by the hash of their distance lists here; one list per group
+    // is fetched from the CSR (a stencil has a few dozen)
+    uint64_t uniform_entries = 0;
+    if (!(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
+        unsigned long long *uh_d = dev_alloc<unsigned long long>(nslices);
+        BICG_HIP(hipMemset(uh_d, 0, sizeof(unsigned long long) * nslices));
+        launch_plan_uniform(ptr_d, col_d, rows, uh_d, nullptr);
+        std::vector<unsigned long long> uh(nslices);
+        BICG_HIP(hipMemcpy(uh.data(), uh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
+        BICG_HIP(hipFree(uh_d));
+        std::vector<uint32_t> ubase(nslices, 0xFFFFFFFFu);
+        std::vector<int> uoff;
+        std::map<unsigned long long, uint32_t> lists;
+        std::vector<uint32_t> cols;
+        for (uint32_t sl = 0; sl < nslices; ++sl) {
+            if (!uh[sl]) continue;
+            auto it = lists.find(uh[sl]);
+            if (it == lists.end()) {
+                if (lists.size() >= 4096) continue;                           // not a structured matrix: leave the rest to col / col16
+                const uint32_t r0 = sl * kSliceRows, len = slen[sl];
+                uint32_t p0 = 0;
+                BICG_HIP(hipMemcpy(&p0, ptr_d + r0, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                cols.resize(len);
+                BICG_HIP(hipMemcpy(cols.data(), col_d + p0, sizeof(uint32_t) * len, hipMemcpyDeviceToHost));
+                it = lists.emplace(uh[sl], (uint32_t)uoff.size()).first;
+                for (uint32_t k = 0; k < len; ++k) uoff.push_back((int)((int64_t)cols[k] - (int64_t)r0));
+                uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);
+            }
+            ubase[sl] = it->second;
+            uniform_entries += (uint64_t)slen[sl] * kSliceRows;
+        }
+        if (uniform_entries) {
+            c->s_ubase = dev_upload(ubase.data(), ubase.size());
+            c->s_uoff = dev_upload(uoff.data(), uoff.size());
+        }
+    }
+    c->uniform_entries = uniform_entries;
     c->d_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
     BICG_HIP(hipMemcpy(c->d_ptr, ptr_d, sizeof(uint32_t) * ((size_t)rows + 1), hipMemcpyDeviceToDevice));
     c->d_val = dev_alloc<double>(kPadEntries); c->d_col = dev_alloc<uint32_t>(kPadEntries);
@@ -2503,7 +2578,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->send_idx = dev_alloc<uint32_t>(1); c->sendbuf = dev_alloc<double>(1);
     c->ng_int = ngroups; c->ng_bnd = 0; c->n_int = c->n_bnd = c->nblk = 0;
     c->glist_int_identity = true; c->glist_all = true;
-    c->matrix_bytes = entries * (c16 ? 10 : 12) + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
+    c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
     c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
     BICG_HIP(hipFree(far_d));
     ctx_state(c, comm, ngroups);
@@ -2547,7 +2622,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -2794,6 +2869,8 @@ void bicg_dropin_release(void)
     if (g_dropin.ctx) { bicg_destroy(g_dropin.ctx); g_dropin.ctx = nullptr; }
 }
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matrix_bytes; }
+unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
+unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return c->matrix_bytes; }
 
 void bicg_dropin_stats(unsigned int *hits, unsigned int *misses)
 {
@@ -2816,6 +2893,7 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->persist_on) f |= BICG_FLAG_PERSIST;
     if (c->fuse_pipe && c->fuse_plan_ok && !hosted(c)) f |= BICG_FLAG_FUSE_PIPE;
     if (c->pipe_probed && (c->probe_ms[0] > 0.0 || c->probe_ms[1] > 0.0)) f |= BICG_FLAG_PIPE_PROBED;
+    if (c->uniform_entries) f |= BICG_FLAG_UNIFORM;
     return f;
 }
 

@@ -381,3 +381,41 @@ def test_section_times_account_for_the_iteration(capfd):
     ctx.solve_shifted(b, sigma, 3, tol=0.0, max_iter=32, check_every=16, which="shifted_lopbicgstab", quiet=0)
     assert "Seed time" not in capfd.readouterr().out
     ctx.close()
+
+
+def test_uniform_slices_give_the_same_bits():
+    """Uniform slices (BICG_FLAG_UNIFORM, SellDev::ubase): in the interior of a banded / stencil matrix the SpMV takes the columns
+    of a 64-row slice from ONE shared list of distances instead of reading col / col16 -- fewer bytes, the same arithmetic in the
+    same order: y is bit-identical to the oracle AND to a context planned without them (BICG_SELL_UNIFORM=0), 16- and 32-bit
+    column layouts, boundary slices (clipped bands, grid faces) stay on the column arrays; the solver trajectories of the two
+    contexts are identical to the last bit (reference src/matrix.c:498-516)."""
+    import os
+    H.lib().bicg_comm_init_single(0)
+    cases = [("transport-shaped 16-bit", synth.transport_like(n=150_001, scale_decades=2.0)),
+             ("stencil 32-bit offsets", synth.stencil7(70, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0))),          # 70^2 < 32768: 16-bit
+             ("stencil far planes", synth.stencil7(200, synth.LAPLACE_WEIGHTS, rows=(0, 200 * 200 * 6)))]
+    for name, A in cases:
+        if A.cols != A.rows:      # a slab: keep the columns inside (drop the plane above)
+            keep = A.col < A.rows
+            ptr = np.concatenate(([0], np.cumsum(np.add.reduceat(keep.astype(np.int64), A.ptr[:-1].astype(np.int64))))).astype(np.uint32)
+            A = synth.CSR(A.rows, A.rows, ptr, A.col[keep], A.val[keep])
+        row, col, val = A.to_coo()
+        ctx = H.Context(H.single_rank_blocks(A))
+        os.environ["BICG_SELL_UNIFORM"] = "0"
+        try:
+            ref = H.Context(H.single_rank_blocks(A))
+        finally:
+            os.environ.pop("BICG_SELL_UNIFORM")
+        assert ctx.flags()["uniform"] and not ref.flags()["uniform"], name
+        ue = ctx.uniform_entries()
+        assert 0.5 * A.nnz < ue <= A.nnz + 64 * 32, (name, ue, A.nnz)
+        assert ctx.spmv_matrix_bytes() < ref.spmv_matrix_bytes() - 1.5 * ue, name
+        x = np.random.default_rng(11).standard_normal(A.rows)
+        y = ctx.spmv(x)
+        assert np.array_equal(y, O.spmv(A.rows, row, col, val, x)) and np.array_equal(y, ref.spmv(x)), name
+        b = ctx.spmv(np.ones(A.rows))
+        for method in ("bicgstab", "pipe_bicgstab"):
+            g1 = ctx.solve(method, b, tol=0.0, max_iter=20, check_every=20)
+            g2 = ref.solve(method, b, tol=0.0, max_iter=20, check_every=20)
+            assert np.array_equal(g1["x"], g2["x"]) and np.array_equal(g1["r"], g2["r"]), (name, method)
+        ctx.close(); ref.close()

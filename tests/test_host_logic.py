@@ -188,7 +188,7 @@ def test_hot_kernels_stay_lean():
     for k in spmv:
         r = kernels[k]
         assert r["VGPRs"] <= 64 and r["Occupancy [waves/SIMD]"] == 8 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
-    vec = [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]ELb[01]E|7FPlainQILb[01]E|7FPlainPILb[01]E|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELi2EEEv", k)]
+    vec = [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELi2EEEv", k)]
     assert len(vec) >= 11, sorted(kernels)[:5]
     for k in vec:
         r = kernels[k]
