@@ -361,6 +361,13 @@ struct PersistArgs {
     const unsigned short *snd_row;       // row within the workgroup
     const unsigned long long *snd_dst0, *snd_stride;
     P2pRed p2p;                          // mailboxes; group numbers p2p.seq + 2 it / + 1
+    // shifted pipelined kernel (k_shpipe_persist): v.x / v.p are x[seed] / p[seed]; every other shift's x_j, p_j are streamed
+    // through in phase 2 with the coefficients the helper publishes as LL pairs together with omega
+    double *pset, *xset;                 // [nsig][set_stride]
+    uint32_t set_stride;
+    int nsig, seed;
+    double shift; int has_shift;         // products are (A + shift I) x                              (src/shifted_solver.c:259-260)
+    llword *crow[2];                     // [6][kPersistMaxShifts][2] beta_j, alpha_j, cp, cx, c1, c2 of the group's iteration
     Vecs v;
     Scal *S;
     int *alarm;
@@ -374,6 +381,8 @@ struct PersistArgs {
 hipError_t launch_pipe_persist(const PersistArgs &a, hipStream_t st);
 hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st);    // plain BiCGStab: three groups per iteration
 hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st);       // CA-BiCGStab: two groups per iteration
+hipError_t launch_shpipe_persist(const PersistArgs &a, hipStream_t st);   // shifted_pipe_lopbicgstab (src/shifted_solver.c:794-866), <= kPersistMaxShifts shifts
+constexpr int kPersistMaxShifts = 32;
 unsigned persist_lds_bytes(const PersistArgs &a);
 constexpr unsigned kPersistMaxLds = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for (static part: < 1 KiB)
 

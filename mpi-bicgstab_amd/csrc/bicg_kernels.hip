@@ -64,166 +64,6 @@ static void launch_timed(K kernel, dim3 g, dim3 b, hipStream_t st, hipEvent_t e0
     launch_timed_lds(kernel, g, b, 0u, st, e0, e1, args...);
 }
 
-// ---- shifted solvers: per-shift scalar recurrences, one thread per shift (whole workgroup calls)
-// lop / pipe: the per-shift block of reference src/shifted_solver.c:264-301 (= :803-839)
-__device__ __forceinline__ void shift_beta_cp(ShiftDev *H, int j, double beta_seed)
-{
-    const double po = H->pi_old[j], pn = H->pi_new[j];
-    H->beta[j] = (po / pn) * (po / pn) * beta_seed;                  // (:264)
-    H->cp[j] = 1.0 / (pn * H->zeta[j]);                              // (:266)
-    H->pi_old[j] = pn;                                               // (:268)
-}
-__device__ __forceinline__ void shift_eta_alpha(ShiftDev *H, int j, double a_seed, double sg_seed)
-{
-    const double pn = H->pi_old[j];                                  // already copied
-    const double e = (H->beta_old / H->alpha_old) * a_seed * H->eta[j] - (sg_seed - H->sigma[j]) * a_seed * pn;   // (:283)
-    H->eta[j] = e;
-    const double pnew = e + pn;                                      // (:285)
-    H->pi_new[j] = pnew;
-    H->alpha[j] = (pn / pnew) * a_seed;                              // (:286)
-}
-__device__ __forceinline__ void shift_omega_coeffs(ShiftDev *H, int j, double w_seed, double sg_seed)
-{
-    const double dsg = sg_seed - H->sigma[j];
-    const double wj = w_seed / (1.0 - w_seed * dsg);                 // (:295)
-    H->omega[j] = wj;
-    const double pn = H->pi_new[j], po = H->pi_old[j], z = H->zeta[j], aj = H->alpha[j];
-    H->cx[j] = wj / (pn * z);                                        // (:296)
-    H->c1[j] = wj / (aj * z * pn);                                   // (:298)
-    H->c2[j] = -wj / (aj * z * po);                                  // (:299)
-    H->zeta[j] = (1.0 - w_seed * dsg) * z;                           // (:300)
-}
-
-__device__ __forceinline__ void apply_phase_shifted(Scal *S, int phase)
-{
-    ShiftDev *H = S->sh;
-    const double *d = S->red;
-    const int nsig = H->nsig, seed = H->seed, mode = H->mode;
-    __shared__ double s_max[kBlock];
-    if (threadIdx.x == 0) {
-        switch (phase) {
-        case PH_SH_INIT:
-            S->rTr = d[0]; S->dot_r = d[0]; S->dot_zero = d[0];
-            S->alpha = 1.0; S->beta = 0.0; S->omega = 0.0; S->rTr_old = 0.0;
-            H->max_zeta_pi = 1.0; H->alpha_old = 1.0; H->beta_old = 0.0;
-            if (!(1.0 * 1.0 * S->dot_r > S->tol2 * S->dot_zero && 0 < S->max_iter)) S->done = 1;
-            break;
-        case PH_SH_ALPHA:
-            H->alpha_old = S->alpha;                  // alpha_old <- alpha[seed]   (:270 / :96)
-            H->beta_old = S->beta;                    // beta_old  <- beta[seed]    (:271 / :97)
-            S->alpha = S->rTr / d[0];                 // alpha[seed] <- (r#,r)/(r#,s)  (:274 / :100)
-            break;
-        case PH_SH_OMEGA:
-            S->omega = mode == SH_XI ? d[0] / d[1]    // (q,y)/(y,y)                (:115)
-                                     : d[1] / d[0];   // (q,q)/(q,y)                (:291)
-            break;
-        case PH_SH_END:
-            S->dot_r = d[0];
-            S->rTr_old = S->rTr;
-            S->rTr = d[1];
-            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);      // (:310 / :135)
-            break;
-        case PH_SHP_INIT_ALPHA:
-            H->alpha_old = 1.0;                       // (:785)
-            S->alpha = S->rTr / d[0];                 // (:786)
-            break;
-        case PH_SHP_OMEGA:
-            H->beta_old = S->beta;                    // (:817)
-            S->omega = d[0] / d[1];                   // (q,y)/(y,y)                (:828)
-            break;
-        case PH_SHP_END: {
-            S->dot_r = d[0];
-            S->rTr_old = S->rTr;
-            S->rTr = d[1];
-            S->beta = (S->alpha / S->omega) * (S->rTr / S->rTr_old);      // (:856)
-            H->alpha_old = S->alpha;                                      // (:857)
-            S->alpha = S->rTr / (d[2] + S->beta * (d[3] - S->omega * d[4]));   // (:858)
-            break;
-        }
-        default: break;
-        }
-    }
-    __syncthreads();
-    const double a_seed = S->alpha, w_seed = S->omega, sg_seed = H->sigma[seed];
-    double local_max = 1.0;
-    for (int j = threadIdx.x; j < nsig; j += kBlock) {
-        if (phase == PH_SH_INIT) {
-            H->beta[j] = 0.0; H->alpha[j] = 1.0; H->eta[j] = 0.0; H->pi_old[j] = 1.0; H->pi_new[j] = 1.0; H->zeta[j] = 1.0;
-            H->cp[j] = 0.0; H->cx[j] = 0.0; H->c1[j] = 0.0; H->c2[j] = 0.0; H->omega[j] = 0.0;
-            continue;
-        }
-        if (j == seed) {
-            if (mode != SH_XI && (phase == PH_SH_ALPHA || phase == PH_SHP_OMEGA)) H->pi_old[j] = H->pi_new[j];   // my_dcopy copies every entry
-            continue;
-        }
-        if (mode == SH_XI) {
-            // xi_old = pi_old, xi_curr = pi_new, xi_new = eta, tau = zeta      (src/shifted_solver.c:90-142)
-            const double xo = H->pi_old[j], xc = H->pi_new[j], tau = H->zeta[j], sg = H->sigma[j];
-            if (phase == PH_SH_ALPHA) {
-                H->beta[j] = (xc / xo) * (xc / xo) * H->beta_old;                        // (:91)
-                H->cp[j] = tau * xc;                                                     // (:93)
-            } else if (phase == PH_SH_OMEGA) {
-                const double xn = (xc * xo * H->alpha_old) /
-                                  (a_seed * H->beta_old * (xo - xc) + xo * H->alpha_old * (1.0 + a_seed * sg));   // (:108)
-                H->eta[j] = xn;
-                const double aj = (xn / xc) * a_seed;                                    // (:110)
-                H->alpha[j] = aj;
-                const double wj = w_seed / (1.0 + w_seed * sg);                          // (:119)
-                H->omega[j] = wj;
-                H->cx[j] = wj * tau * xn;                                                // (:120)
-                H->c1[j] = wj * tau * xn / aj;                                           // (:122)
-                H->c2[j] = -wj * tau * xc / aj;                                          // (:123)
-            } else if (phase == PH_SH_END) {
-                const double tn = tau / (1.0 + w_seed * sg);                             // (:130)
-                H->zeta[j] = tn;
-                double a = xc * tn;                                                      // (:138)
-                if (a < 0.0) a = -a;
-                if (a > local_max) local_max = a;
-                H->pi_old[j] = xc;                                                       // (:141)
-                H->pi_new[j] = H->eta[j];                                                // (:142)
-            }
-            continue;
-        }
-        if (phase == PH_SH_ALPHA) {
-            shift_beta_cp(H, j, H->beta_old);        // beta[seed] of the previous iteration
-            shift_eta_alpha(H, j, a_seed, sg_seed);
-        } else if (phase == PH_SH_OMEGA) {
-            shift_omega_coeffs(H, j, w_seed, sg_seed);
-        } else if (phase == PH_SHP_OMEGA) {
-            shift_beta_cp(H, j, H->beta_old);        // (:805-807), beta_old == beta[seed] here
-            shift_eta_alpha(H, j, a_seed, sg_seed);  // (:820-823)
-            shift_omega_coeffs(H, j, w_seed, sg_seed);   // (:833-838)
-        } else if (phase == PH_SH_END || phase == PH_SHP_END) {
-            double a = 1.0 / (H->zeta[j] * H->pi_new[j]);                // (:314 / :862)
-            if (a < 0.0) a = -a;
-            if (a > local_max) local_max = a;
-        }
-    }
-    if (phase == PH_SH_END || phase == PH_SHP_END) {
-        s_max[threadIdx.x] = local_max;
-        __syncthreads();
-        for (int w = kBlock / 2; w > 0; w >>= 1) {
-            if ((int)threadIdx.x < w && s_max[threadIdx.x + w] > s_max[threadIdx.x]) s_max[threadIdx.x] = s_max[threadIdx.x + w];
-            __syncthreads();
-        }
-        if (threadIdx.x == 0) {
-            const double m = s_max[0];
-            H->max_zeta_pi = m;
-            S->k += 1;
-            const int k = S->k;
-            if (S->tr_dotr && k <= S->max_iter) {
-                S->tr_alpha[k - 1] = phase == PH_SHP_END ? H->alpha_old : S->alpha;
-                S->tr_omega[k - 1] = S->omega; S->tr_beta[k - 1] = S->beta; S->tr_dotr[k - 1] = S->dot_r;
-            }
-            // reference loop condition, src/shifted_solver.c:86 / 257 / 792
-            if (!(m * m * S->dot_r > S->tol2 * S->dot_zero && k < S->max_iter)) S->done = 1;
-            if (!(isfinite(S->alpha) && isfinite(S->beta) && isfinite(S->omega) && isfinite(S->dot_r)) && !S->breakdown_k)
-                S->breakdown_k = k;
-        }
-    }
-}
-
-
 // ---- shifted solvers with stop flags and seed switching (reference src/shifted_switching_solver.c).
 // One implementation serves shifted_lopbicg (:20-257, SH_FLAG) and shifted_lopbicg_switching
 // (:260-608, SH_SWITCH; _noovlp :611-1016 is an arithmetic twin): the per-shift recurrences are the
@@ -387,7 +227,7 @@ template <bool HEAVY>
 __device__ __forceinline__ void apply_phase_block(Scal *S, int phase)
 {
     if (HEAVY && phase >= PH_SW_INIT) apply_phase_switching(S, phase);
-    else if (phase >= PH_SH_INIT && phase < PH_SW_INIT) apply_phase_shifted(S, phase);
+    else if (phase >= PH_SH_INIT && phase < PH_SW_INIT) apply_phase_shifted<kBlock>(S, phase);
     else if (phase < PH_SH_INIT && threadIdx.x == 0) apply_phase(S, phase);
 }
 

@@ -34,6 +34,7 @@ struct PersistLds {
     int    fail;
     int    drift_flag;                    // helper: the drift group just applied asks for a replacement iteration
     int    adaptive;                      // helper: replacement iterations asked for by the drift check in this launch
+    double coef[6 * kPersistMaxShifts];   // shifted kernel: beta_j, alpha_j, cp, cx, c1, c2 of the iteration as received
 };
 
 // Workgroup barrier that orders LDS traffic only. __syncthreads() also waits for the wavefront's outstanding GLOBAL
@@ -274,11 +275,33 @@ __device__ __forceinline__ void comm_scalars(const PersistArgs &a, unsigned lane
     }
 }
 
+// ... and (shifted kernel) the 6 x nsig coefficients of the iteration, published by the helper right after omega
+__device__ __forceinline__ void comm_coefs(const PersistArgs &a, unsigned lane, const llword *crow, unsigned seq, PersistLds &L)
+{
+    for (int idx = (int)lane; idx < 6 * a.nsig; idx += 64) {
+        const int q = idx / a.nsig, j = idx % a.nsig;
+        const llword *src = crow + 2 * (size_t)(q * kPersistMaxShifts + j);
+        double v = 0.0;
+        const unsigned long long t0 = wall_clock64();
+        for (unsigned spin = 0;; ++spin) {
+            u32x4 w;
+            ll_load16_x1<false>(src, w);
+            if (ll_decode(w, seq, &v)) break;
+            __builtin_amdgcn_s_sleep(2);
+            if ((spin & 15u) == 15u && (wall_clock64() - t0 > a.timeout_ticks || alarm_raised(a.alarm))) {
+                L.fail = 1; raise_alarm(a.alarm); v = 0.0;
+                break;
+            }
+        }
+        L.coef[q * kPersistMaxShifts + j] = v;
+    }
+}
+
 // helper workgroup: sums of group `seq` over the table (workgroup order, fixed tree), exchanged with the other ranks,
 // recurrence applied on L.priv, scalars published.
-template <int N>
+template <int N, bool SH = false>
 __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword *tab, llword *row, unsigned seq, unsigned mseq, int phase,
-                                             PersistLds &L, unsigned long long *stamp)
+                                             PersistLds &L, unsigned long long *stamp, double *smax = nullptr, llword *crow = nullptr)
 {
 #define HSTAMP(i) do { if (stamp && threadIdx.x == 0) stamp[i] = wall_clock64(); } while (0)
     const unsigned tid = threadIdx.x, nt = blockDim.x, lane = tid & 63u, wave = tid >> 6, nw = nt >> 6;
@@ -356,7 +379,25 @@ __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword 
         if ((int)tid < N) L.sums[tid] = rank_tree_sum(L.pv + tid, P);
         lds_barrier();
     }
-    if (tid == 0) {
+    if (SH) {
+        // shifted solvers: the seed's scalars by thread 0, the per-shift recurrences one thread per shift (bicg_devfn.h),
+        // then every shift's coefficients of this iteration travel with omega as LL pairs (written by the thread that formed them)
+        if (tid == 0) {
+#pragma unroll
+            for (int d = 0; d < N; ++d) L.priv.red[d] = L.sums[d];
+        }
+        __syncthreads();
+        apply_phase_shifted<1024>(&L.priv, phase, smax);
+        __syncthreads();
+        if (crow) {
+            const ShiftDev *H = L.priv.sh;
+            for (int j = (int)tid; j < a.nsig; j += (int)nt) {
+                const double cv[6] = {H->beta[j], H->alpha[j], H->cp[j], H->cx[j], H->c1[j], H->c2[j]};
+#pragma unroll
+                for (int q = 0; q < 6; ++q) ll_store16_agent(crow + 2 * (size_t)(q * kPersistMaxShifts + j), cv[q], seq);
+            }
+        }
+    } else if (tid == 0) {
 #pragma unroll
         for (int d = 0; d < N; ++d) L.priv.red[d] = L.sums[d];
         L.drift_flag = 0;
@@ -537,7 +578,7 @@ __device__ __forceinline__ void wg_setup(const PersistArgs &a, unsigned wg, doub
 // wavefront sends partials and halo values and -- wait_scal -- fetches the group's applied scalars into L.sc while the row
 // wavefronts stage their window and multiply. out = A val on the thread's rows. Ends with a barrier: L.sc / L.fail are
 // valid for everybody.
-template <int R, int N, bool LDSMAT, bool MULTI>
+template <int R, int N, bool LDSMAT, bool MULTI, bool COEF = false>
 __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, const RowState<R> &rs, PersistLds &L, const double (&val)[R],
                                       double (&acc)[N > 0 ? N : 1], unsigned buf, unsigned nv, unsigned g, bool wait_scal, double (&out)[R])
 {
@@ -569,6 +610,7 @@ __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, cons
     lds_barrier();
     if (W.comm) {
         if (wait_scal) comm_scalars(a, W.lane, a.arow[g & 1u], gtag, L);
+        if (COEF && wait_scal) comm_coefs(a, W.lane, a.crow[g & 1u], gtag, L);
     } else {
 #pragma unroll
         for (int j = 0; j < R; ++j) {
@@ -577,6 +619,7 @@ __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, cons
             // eight rows per thread: 16 entries of a row in flight -- a Transport row in ONE round trip; a product is a chain
             // of R x (batches per row) dependent round trips
             out[j] = persist_row<MULTI, (R > 2 ? 16 : 8)>(mv, ms, rs.slen[j], rs.lens[j] & 0xFFFFu, rs.lens[j] >> 16, W.win);
+            if (a.has_shift && rs.live[j]) out[j] += a.shift * val[j];         // (A + sigma I) x, as sell_row does     (src/shifted_solver.c:260)
         }
     }
     lds_barrier();
@@ -830,6 +873,122 @@ k_pipe_persist(PersistArgs a)
             if (!PMEM) e.p[q] = pr[j % RP];
             e.r[q] = r[j]; e.s[q] = s[j]; e.z[q] = z[j]; e.w[q] = w[j]; e.v[q] = v[j]; e.t[q] = t[j];
         }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
+// shifted_pipe_lopbicgstab (reference src/shifted_solver.c:794-866; FShPipe1 / FShPipe2 / apply_phase_shifted, operation for
+// operation) in the persistent form: the SEED system's recurrence is the pipelined iteration above with products of
+// A + sigma_seed I; per iteration the helper also runs the per-shift scalar recurrences (one thread per shift) and sends every
+// shift's six coefficients along with omega; phase 2 then streams each other shift's p_j, x_j of the thread's row through
+// registers (read once, written once: 32 bytes per shift and row, from the Infinity Cache on a latency-bound rank). One row
+// per thread, <= kPersistMaxShifts shifts. Two hand-offs and two groups per iteration, numbered like the pipelined kernel's.
+// ------------------------------------------------------------------------------------------------------------------
+template <bool LDSMAT, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shpipe_persist(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x;
+    const unsigned wg = persist_wg(a);
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        unsigned g = 0, nv = 0;
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            ++g;
+            if (!helper_group<2, true>(a, a.dtab[g & 1u], a.arow[g & 1u], a.seq0 + g, a.p2p.seq + g - 1u, PH_SHP_OMEGA, L, nullptr, dyn, a.crow[g & 1u])) break;
+            ++g;
+            if (!helper_group<5, true>(a, a.dtab[g & 1u], a.arow[g & 1u], a.seq0 + g, a.p2p.seq + g - 1u, PH_SHP_END, L, nullptr, dyn, nullptr)) break;
+            nv += 2u;
+        }
+        helper_finish(a, L, (double)nv, (double)g);
+        return;
+    }
+
+    WgCtx W;
+    RowState<1> rs;
+    wg_setup<1, LDSMAT, MULTI>(a, wg, dyn, W, rs);
+    const bool comm = W.comm, live = rs.live[0];
+    const uint32_t row = live ? rs.row[0] : 0u;
+    const Vecs &e = a.v;
+    double x = e.x[row], r[1] = {e.r[row]}, p = e.p[row], s = e.s[row], z[1] = {e.z[row]}, w[1] = {e.w[row]}, v[1] = {e.v[row]}, t[1] = {e.t[row]};
+    const double h = e.rh[row];
+    double ro = 0.0;
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    unsigned g = 0, nv = 0;
+    for (int it = 0; it < a.niter && !done; ++it) {
+        // ---- phase 1: p[seed], s, z recurrences ; r_old = r ; q (in r), y (in w) ; (q,y), (y,y)      (:794-813, FShPipe1)
+        double acc2[2] = {0.0, 0.0};
+        if (!comm) {
+            p = recur3<double>(p, s, r[0], omega, beta);
+            const double s1 = recur3<double>(s, z[0], w[0], omega, beta);
+            const double z1 = recur3<double>(z[0], v[0], t[0], omega, beta);
+            s = s1; z[0] = z1;
+            ro = r[0];
+            r[0] = r[0] + (-alpha) * s;
+            w[0] = w[0] + (-alpha) * z[0];
+            if (live) { acc2[0] = r[0] * w[0]; acc2[1] = w[0] * w[0]; }
+        }
+        // ---- v = (A + sigma I) z  ||  omega and every shift's coefficients                          (:814-839)
+        xprod<1, 2, LDSMAT, MULTI, true>(a, W, rs, L, z, acc2, 0u, ++nv, ++g, true, v);
+        if (L.fail) break;
+        omega = L.sc[2];
+        // ---- phase 2: x[seed] ; every p_j, x_j ; r ; w ; five dots                                   (:829-848, FShPipe2)
+        double acc5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        if (!comm) {
+            const double q = r[0], y = w[0];
+            const double xx = x + alpha * p;
+            x = xx + omega * q;
+            if (live) {
+                constexpr int B = 4;                  // shifts in flight per thread
+                for (int j0 = 0; j0 < a.nsig; j0 += B) {
+                    double pj[B], xj[B];
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const int j = j0 + b;
+                        const bool on = j < a.nsig && j != a.seed;
+                        pj[b] = on ? __builtin_nontemporal_load(a.pset + (size_t)j * a.set_stride + row) : 0.0;
+                        xj[b] = on ? __builtin_nontemporal_load(a.xset + (size_t)j * a.set_stride + row) : 0.0;
+                    }
+#pragma unroll
+                    for (int b = 0; b < B; ++b) {
+                        const int j = j0 + b;
+                        if (j >= a.nsig || j == a.seed) continue;
+                        const double bj = L.coef[0 * kPersistMaxShifts + j], aj = L.coef[1 * kPersistMaxShifts + j];
+                        const double cp = L.coef[2 * kPersistMaxShifts + j], cx = L.coef[3 * kPersistMaxShifts + j];
+                        const double c1 = L.coef[4 * kPersistMaxShifts + j], c2 = L.coef[5 * kPersistMaxShifts + j];
+                        double pp = bj * pj[b];                  // (:806)
+                        pp = pp + cp * ro;                       // (:807)
+                        double xv = xj[b] + cx * q;              // (:834)
+                        xv = xv + aj * pp;                       // (:835)
+                        __builtin_nontemporal_store(xv, a.xset + (size_t)j * a.set_stride + row);
+                        pp = pp + c1 * q;                        // (:836)
+                        pp = pp + c2 * ro;                       // (:837)
+                        __builtin_nontemporal_store(pp, a.pset + (size_t)j * a.set_stride + row);
+                    }
+                }
+            }
+            r[0] = q + (-omega) * y;                             // (:840)
+            const double tt = t[0] + (-alpha) * v[0];            // (:842)
+            w[0] = y + (-omega) * tt;                            // (:843)
+            if (live) { acc5[0] = r[0] * r[0]; acc5[1] = h * r[0]; acc5[2] = h * w[0]; acc5[3] = h * s; acc5[4] = h * z[0]; }
+        }
+        // ---- t = (A + sigma I) w  ||  beta, alpha, the stopping test                                 (:849-866)
+        xprod<1, 5, LDSMAT, MULTI>(a, W, rs, L, w, acc5, 1u, ++nv, ++g, true, t);
+        if (L.fail) break;
+        alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] == 1.0 ? 1 : 0;
+    }
+    if (live) {
+        e.x[row] = x; e.r[row] = r[0]; e.p[row] = p; e.s[row] = s; e.z[row] = z[0]; e.w[row] = w[0]; e.v[row] = v[0]; e.t[row] = t[0];
+        e.ax[row] = ro;                                          // r_old lives in ax (launch_shift_pipe1)
+    }
 }
 
 
@@ -1097,6 +1256,10 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
         } else if (a.rpt == 2u) { err = a.multi ? go(k_pipe_persist<2, false, true>, 0) : go(k_pipe_persist<2, false, false>, 0);
         } else if (a.rpt == 8u) { err = a.multi ? go(k_pipe_persist<8, false, true>, 0) : go(k_pipe_persist<8, false, false>, 0);
         } else return hipErrorInvalidValue;
+    } else if (method == 3) {
+        if (a.nsig < 1 || a.nsig > kPersistMaxShifts) return hipErrorInvalidValue;
+        if (a.mat_entries) { err = a.multi ? go(k_shpipe_persist<true, true>, 3) : go(k_shpipe_persist<true, false>, 3); }
+        else { err = a.multi ? go(k_shpipe_persist<false, true>, 3) : go(k_shpipe_persist<false, false>, 3); }
     } else if (method == 1) {
         if (a.mat_entries) { err = a.multi ? go(k_plain_persist<true, true>, 1) : go(k_plain_persist<true, false>, 1); }
         else { err = a.multi ? go(k_plain_persist<false, true>, 1) : go(k_plain_persist<false, false>, 1); }
@@ -1108,6 +1271,7 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
     return err;
 }
 hipError_t launch_pipe_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 0); }
+hipError_t launch_shpipe_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 3); }
 hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 1); }
 hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 2); }
 
