@@ -57,6 +57,11 @@ def spmv_bytes(nnz, rows, halo=0):
     return 12 * nnz + 4 * (rows + 1) + 8 * rows + 8 * rows + 16 * halo
 
 
+def csr_bytes(nnz, rows):
+    """the matrix arrays of section 8d's product: val + col + ptr"""
+    return 12 * nnz + 4 * (rows + 1)
+
+
 # fused-minimum vector bytes per row and iteration (SURVEY.md section 8d "Algorithmic bytes, iteration")
 ITER_VECTOR_BYTES_PER_ROW = {"bicgstab": 120, "ca_bicgstab": 184, "pipe_bicgstab": 192, "pipe_bicgstab_rr": 192}
 
@@ -75,21 +80,28 @@ MALL_BYTES = 256 * 1048576      # Infinity Cache
 NVEC = {"bicgstab": 6, "ca_bicgstab": 8, "pipe_bicgstab": 10, "pipe_bicgstab_rr": 11}
 
 
-def roof(gbps, matrix_bytes, rows, nvec, flags, stream, spmv_only=False):
-    """Which resource bounds a leg, and `frac` against THAT bound only (never a fraction of the HBM peak for an iteration
-    whose matrix sits in LDS or in the Infinity Cache):
+def roof(alg_bytes, seconds, csr_bytes, spmv_stream_bytes, nspmv, rows, nvec, flags, stream, world=1, spmv_only=False):
+    """Which resource bounds a leg, and `frac` against THAT bound only. `frac` is claimed on the bytes the STORED FORMAT has to
+    move (`format_bytes`: the matrix arrays one product streams -- bicg_spmv_matrix_bytes: values + whatever index the layout
+    keeps, 16-bit offsets or none at all in uniform slices -- plus the vector traffic of SURVEY.md section 8d), never on the CSR
+    figure of section 8d (`algorithmic_bytes` / `gbps`, kept beside it): a layout that stores no column index moves fewer bytes
+    than 12 per non-zero, and a fraction formed with the CSR figure would exceed 1.
       latency: a rank the persistent kernels hold in LDS / registers (one launch per chunk of iterations): its time is a chain
                of dependent hand-offs between workgroups, not bytes -- no bandwidth fraction is claimed (frac null);
       mall:    matrix + vectors fit the 256 MiB Infinity Cache: peak = this GPU's read rate out of the Infinity Cache, measured
                in this run (bicg_stream_bench on a 96 MiB array); frac null when that probe did not run;
       hbm:     everything else: peak = 8 TB/s (MI355X_MICROARCH.md)."""
-    ws = matrix_bytes + 8 * rows * nvec
+    # csr_bytes: 12 nnz + 4 (n + 1) of the whole matrix (section 8d); spmv_stream_bytes: what this rank's layout streams per product
+    fmt = alg_bytes - nspmv * max(0, csr_bytes - world * spmv_stream_bytes)
+    fgb = fmt / seconds / 1e9 / world
+    ws = spmv_stream_bytes + 8 * rows * nvec
+    out = dict(format_bytes=int(fmt), format_gbps=fgb * world)
     if not spmv_only and "persist" in flags and rows <= 250_000:
-        return dict(bound="latency", peak=None, frac=None)
+        return dict(out, bound="latency", peak=None, frac=None)
     if ws <= MALL_BYTES:
         peak = stream.get("mall_read8") if isinstance(stream, dict) else None
-        return dict(bound="mall", peak=peak, frac=(gbps / peak) if peak else None)
-    return dict(bound="hbm", peak=HBM_PEAK_GBS, frac=gbps / HBM_PEAK_GBS)
+        return dict(out, bound="mall", peak=peak, frac=(fgb / peak) if peak else None)
+    return dict(out, bound="hbm", peak=HBM_PEAK_GBS, frac=fgb / HBM_PEAK_GBS)
 
 
 def measure_traffic(argv_inner, note):
@@ -487,7 +499,7 @@ def main():
             ib = iteration_bytes(m, nnz_global, n)
             gb = ib / (variants[m] * 1e-3) / 1e9
             variant_roof[m] = dict(ms_per_iteration=variants[m], algorithmic_bytes=ib, gbps=gb,
-                                   **roof(gb / world, leg.ctx.device_matrix_bytes(), plan["rows"], NVEC[m], head_flags, stream))
+                                   **roof(ib, variants[m] * 1e-3, csr_bytes(nnz_global, n), leg.ctx.spmv_matrix_bytes(), 2, plan["rows"], NVEC[m], head_flags, stream, world))
     if not a.no_variants and a.workload == "transport":
         # BASELINE.json configs[4] family: 16 shifts, seed 7, sigma_j = (j+1) 0.01/16 (reference
         # src/main_shifted.c:99 pattern); 2 SpMV + one batched update over all shifts per iteration
@@ -501,7 +513,7 @@ def main():
             ib = shifted_iteration_bytes(nsh, nnz_global, n, "pipe" in which)
             gb = ib / (variants[key] * 1e-3) / 1e9
             variant_roof[key] = dict(ms_per_iteration=variants[key], algorithmic_bytes=ib, gbps=gb,
-                                     **roof(gb / world, leg.ctx.device_matrix_bytes(), plan["rows"], 2 * nsh + 6, [], stream))
+                                     **roof(ib, variants[key] * 1e-3, csr_bytes(nnz_global, n), leg.ctx.spmv_matrix_bytes(), 2, plan["rows"], 2 * nsh + 6, [], stream, world))
     spmv_alone_ms = leg.ctx.spmv_bench(200)
     # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
     # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps. It comes after
@@ -512,6 +524,8 @@ def main():
     spmv_ms = res_ev.spmv_ms_total / max(res_ev.spmv_launches, 1)
     b_spmv = spmv_bytes(plan["nnz_diag"] + plan["nnz_offd"], plan["rows"], plan["halo"])
     achieved = b_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
+    fmt_spmv = min(b_spmv, leg.ctx.spmv_matrix_bytes() + 16 * plan["rows"] + 16 * plan["halo"])
+    fmt_gbps = fmt_spmv / (spmv_ms * 1e-3) / 1e9 if spmv_ms > 0 else 0.0
     leg.timed(a.method, steps=4, warm=0)       # back to ordinary launches before the next matrix is timed
     leg.close()
     comm_info["transport_used"] = transport_name
@@ -555,21 +569,21 @@ def main():
             stage[0] = f"extra workload {name}"
             lg = Leg(wl2)
             out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v])
-            mbytes = lg.ctx.device_matrix_bytes()
+            mbytes = lg.ctx.spmv_matrix_bytes()
             for m in methods:
                 dtv, rv = lg.best(m, steps=steps, warm=min(W, 10))
                 ms = 1e3 * dtv / steps
                 ib = iteration_bytes(m, wl2["nnz"], wl2["rows"])
                 # genuine: every timed iteration was an unconverged one (a converged or broken-down solve idles)
                 out[m] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9,
-                              **roof(ib / (ms * 1e-3) / 1e9 / world, mbytes, lg.plan["rows"], NVEC[m], out["flags"], stream),
+                              **roof(ib, ms * 1e-3, csr_bytes(wl2["nnz"], wl2["rows"]), mbytes, 2, lg.plan["rows"], NVEC[m], out["flags"], stream, world),
                               iterations=int(rv.iterations),
                               iterations_genuine=bool(int(rv.iterations) == steps + min(W, 10) and rv.breakdown_iteration == 0
                                                       and np.isfinite(rv.dot_r) and rv.dot_r > 0.0))
             sp = lg.ctx.spmv_bench(100)
             bs = spmv_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"], lg.plan["halo"])
             out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, algorithmic_bytes_rank0=bs,
-                                            **roof(bs / (sp * 1e-3) / 1e9, mbytes, lg.plan["rows"], 2, out["flags"], stream, spmv_only=True))
+                                            **roof(bs, sp * 1e-3, csr_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"]), mbytes, 1, lg.plan["rows"], 2, out["flags"], stream, 1, spmv_only=True))
             lg.close()
             note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods))
             return out
@@ -598,15 +612,16 @@ def main():
                 # the TRUE residual b - A x (one more product on the device) against the recursive one the iterations carried:
                 # the check of the headline leg, at 134 M rows
                 okv, true_rel = lg.check()
-                out[mth] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9, bound="hbm", peak=HBM_PEAK_GBS,
-                                frac=ib / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, iterations=int(rv.iterations),
+                out[mth] = dict(ms_per_iteration=ms, algorithmic_bytes=ib, gbps=ib / (ms * 1e-3) / 1e9,
+                                **roof(ib, ms * 1e-3, csr_bytes(nnz, rows), ctx.spmv_matrix_bytes(), 2, rows, NVEC[mth], out["flags"], stream),
+                                iterations=int(rv.iterations),
                                 true_relres_after_timed_region=true_rel,
                                 iterations_genuine=bool(int(rv.iterations) == steps + 3 and rv.breakdown_iteration == 0
                                                         and np.isfinite(rv.dot_r) and rv.dot_r > 0.0 and okv))
             sp = ctx.spmv_bench(20)
             bs = spmv_bytes(nnz, rows)
-            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, bound="hbm", peak=HBM_PEAK_GBS,
-                                            frac=bs / (sp * 1e-3) / 1e9 / HBM_PEAK_GBS, algorithmic_bytes_rank0=bs)
+            out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, algorithmic_bytes_rank0=bs,
+                                            **roof(bs, sp * 1e-3, csr_bytes(nnz, rows), ctx.spmv_matrix_bytes(), 1, rows, 2, out["flags"], stream, 1, spmv_only=True))
             out["set_up_seconds_total"] = time.perf_counter() - t0
             ctx.close()
             note(f"laplace7 512^3: generated {gen_s:.2f} s, planned {plan_s:.2f} s, ca_bicgstab {out['ca_bicgstab']['ms_per_iteration']:.3f} ms, "
@@ -721,13 +736,17 @@ def main():
                          "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                          "traffic": traffic, "traffic_detail": traffic_detail, "algorithmic_bytes_per_launch": b_spmv,
                          "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,
+                         # what the STORED layout streams per launch (values + the index it keeps: 16-bit offsets, none in uniform
+                         # slices) + x + y: below the CSR figure `achieved` is formed from whenever the layout compresses the index
+                         "format_bytes_per_launch": fmt_spmv, "format_gbps": fmt_gbps, "frac_of_format_bytes": fmt_gbps / HBM_PEAK_GBS,
                          "ms_per_step_with_events": 1e3 * dt_ev / K,
                          "back_to_back_spmv_ms": spmv_alone_ms,
                          # the denominators north_star asks for, measured on THIS GPU in this run (stream leg above)
                          "stream_measured_gbps": stream,
-                         "frac_of_measured_stream": (achieved / stream["triad"]) if stream and "triad" in stream else None,
-                         "frac_of_measured_copy": (achieved / stream["copy"]) if stream and "copy" in stream else None,
-                         "frac_of_measured_read": (achieved / stream["read8"]) if stream and "read8" in stream else None},
+                         # (of the bytes the layout moves: the CSR figure over a measured rate would exceed 1)
+                         "frac_of_measured_stream": (fmt_gbps / stream["triad"]) if stream and "triad" in stream else None,
+                         "frac_of_measured_copy": (fmt_gbps / stream["copy"]) if stream and "copy" in stream else None,
+                         "frac_of_measured_read": (fmt_gbps / stream["read8"]) if stream and "read8" in stream else None},
             "comm": dict(comm_info, rccl_leg=rccl_leg),
             "cpu_baseline": cpu,
             "cpu_baseline_multicore": cpu_all,

@@ -1158,30 +1158,23 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
                 if (mine[e]) sum += v[e] * xv[e];             // stored order
         }
     }
-    // uniform slice: the columns are row + uoff[k], one list for the whole slice (scalar loads) -- no col / col16 traffic
-    uint32_t ub = 0xFFFFFFFFu;
-    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
-    if (!JAG && ub != 0xFFFFFFFFu) {
-        const int *__restrict__ uo = a.sell.uoff + ub;            // padded with zeros to a multiple of U (+ U)
-        for (uint32_t k0 = 0; k0 < len; k0 += U) {
-            double v[U], xv[U];
-#pragma unroll
-            for (int e = 0; e < U; ++e) {
-                const bool ok = k0 + e < len;                     // wave-uniform
-                const uint32_t j = base + (k0 + e) * kSliceRows + lane;
-                v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
-            }
-#pragma unroll
-            for (int e = 0; e < U; ++e) xv[e] = x[(int)row + uo[k0 + e]];      // every row of a uniform slice is live
-#pragma unroll
-            for (int e = 0; e < U; ++e)
-                if (k0 + e < mylen) sum += v[e] * xv[e];          // stored order; padding never added
-        }
+    // uniform slice: the columns are row + uoff[k], one list for the whole slice (scalar loads) -- no col / col16 traffic.
+    // Same loop as the padded slices (one body: a second copy of it cost the ticket-mode kernels three spilled registers)
+    const int *__restrict__ uo = nullptr;                         // padded with zeros to a multiple of U (+ U)
+    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) {
+        const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
+        if (ub != 0xFFFFFFFFu) uo = a.sell.uoff + ub;
     }
-    for (uint32_t k0 = 0; !JAG && ub == 0xFFFFFFFFu && k0 < len; k0 += U) {
+    for (uint32_t k0 = 0; !JAG && k0 < len; k0 += U) {
         uint32_t c[U];
         double   v[U];
-        if (C16) {
+        // lanes past the last row hold padding only: their offsets are 0 and must not turn into
+        // reads of x[row >= nrows] (the vector may end before the 64-row slice does)
+        const uint32_t rb = live ? row : 0u;
+        if (uo) {
+#pragma unroll
+            for (int e = 0; e < U; ++e) c[e] = rb + (uint32_t)uo[k0 + e];
+        } else if (C16) {
             static_assert(U % 4 == 0, "packed 16-bit columns come four at a time");
 #pragma unroll
             for (int q = 0; q < U / 4; ++q) {
@@ -1190,9 +1183,6 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
                                  ((size_t)base16 / 4 + (size_t)((k0 / 4) + q) * kSliceRows + lane);
                 i16x4 dq = (i16x4)(0);
                 if (ok) dq = NT ? __builtin_nontemporal_load(p) : *p;
-                // lanes past the last row hold padding only: their offsets are 0 and must not turn into
-                // reads of x[row >= nrows] (the vector may end before the 64-row slice does)
-                const uint32_t rb = live ? row : 0u;
                 c[4 * q + 0] = rb + (int)dq.x; c[4 * q + 1] = rb + (int)dq.y;
                 c[4 * q + 2] = rb + (int)dq.z; c[4 * q + 3] = rb + (int)dq.w;
             }
@@ -1201,7 +1191,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
         for (int e = 0; e < U; ++e) {
             const bool ok = k0 + e < len;                     // wave-uniform
             const uint32_t j = base + (k0 + e) * kSliceRows + lane;
-            if (!C16) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
+            if (!C16 && !uo) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
             v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
         }
         double xv[U];
