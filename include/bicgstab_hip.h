@@ -323,6 +323,13 @@ unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);
 /* sliced-ELL entries (padding included) whose column indices the SpMV does not read (BICG_FLAG_UNIFORM), and the bytes one
  * SpMV streams from the matrix arrays (values + the column indices it does read + row pointers) */
 unsigned long long bicg_uniform_entries(bicg_ctx *ctx);
+/* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
+ * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST_SHIFTED=0 keeps the multi-launch form) */
+int bicg_last_shifted_persistent(bicg_ctx *ctx);
+/* 1 when the last bicg_spmm / bicg_shifted_residuals pass on this context ran the windowed kernel (k_spmm_win: the vectors stay
+ * shift-major, the x values a 256-row group touches are staged in LDS for up to 16 vectors at a time and X is read once;
+ * BICG_SPMM_WIN=0 selects the row-major kernel k_spmm_sell, which is also what layouts without cluster or window runs take) */
+int bicg_last_spmm_windowed(bicg_ctx *ctx);
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *ctx);
 
 /* ---------------------------------------------------------------------------------------------

@@ -366,6 +366,7 @@ struct PersistArgs {
     double *pset, *xset;                 // [nsig][set_stride]
     uint32_t set_stride;
     int nsig, seed;
+    int set_nt;                          // stream the sets past the Infinity Cache (they do not fit it)
     double shift; int has_shift;         // products are (A + shift I) x                              (src/shifted_solver.c:259-260)
     llword *crow[2];                     // [6][kPersistMaxShifts][2] beta_j, alpha_j, cp, cx, c1, c2 of the group's iteration
     Vecs v;
@@ -399,6 +400,15 @@ struct SpmmArgs {
     const double *sigma;    // [kSpmmCols] or null: y_j += sigma_j x_j
     double *partial;
     int xcd_map;            // XCD-contiguous assignment of row groups
+    // windowed form (k_spmm_win): the vectors stay SHIFT-MAJOR (x_j = xs + j * vstride, halo tails filled); the x values a
+    // 256-row group touches are staged in LDS for NV vectors at a time -- from the cluster runs of padded 16-bit layouts
+    // (cl.ncl > 0, struct FusedWindow) or from the window runs of the layout with LDS slots (sell.win_runs)
+    const double *xs;
+    double *ys;             // [nvec][vstride] or null
+    size_t vstride;
+    int nvec;
+    FusedWindow cl;
+    unsigned wslots;        // LDS doubles per vector
 };
 
 
@@ -410,6 +420,9 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
                       bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
 bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // a.fw.wf = 1 / 2
 void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
+// vectors per LDS window of the windowed form for `wslots` doubles per vector (0: the window does not fit, use launch_spmm_sell)
+int spmm_win_vectors(unsigned wslots);
+hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st);
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st);          // out[col] = sum_wg partial[wg][col]
 void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st);

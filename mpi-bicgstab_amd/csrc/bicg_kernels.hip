@@ -1874,6 +1874,168 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Windowed SpMM (round 4): the same product with X read ONCE and no layout change. The row-major kernel above pulls a
+// 128-byte line of X through the vector L1 for every matrix entry (2.4 GB per launch on Transport, 1.6 x the algorithmic
+// bytes from memory, + 97 us of transposes). Here a workgroup owns a 256-row group like the SpMV does (lane = row), stages the
+// x values the group touches for NV vectors at a time in LDS -- straight from the shift-major vectors, every run of
+// consecutive columns one coalesced copy per vector, exactly what sell_stage_window does for one vector -- and then walks
+// its rows once per pass: every matrix entry is loaded once per NV vectors and multiplies NV LDS reads (consecutive lanes
+// read consecutive slots: conflict-free). Y goes back shift-major. Where the columns come from:
+//   MODE 0  padded slices with 16-bit offsets (banded / stencil-like matrices): the offsets fall into <= 4 clusters (struct
+//           FusedWindow), cluster k of every group is the run [g0 + lo_k, g0 + 255 + hi_k], slot = thread + offset + bias_k;
+//   MODE 1  jagged slices with x windows (ragged rows): the stored 16-bit value IS the slot, the runs are the SpMV's.
+// Per row and vector the sum runs in stored order like mult() (reference src/matrix.c:506-515): every column is bit-identical
+// to bicg_spmv of that vector. The matrix is read nvec / NV times (NV = 8 on Transport: 79 KB of LDS, two workgroups per CU).
+// ------------------------------------------------------------------------------------------
+template <int MODE, bool OFFD, int NV>
+__global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
+{
+    constexpr bool WIN = MODE == 1;
+    constexpr int U = 8;
+    __shared__ double sm[(kBlock / 64) * NV];
+    double *const win = dyn_lds;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    unsigned g = blockIdx.x;
+    if (a.xcd_map) {
+        const unsigned per = (a.ngroups + 7u) / 8u;
+        g = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
+    if (a.b && tid < (unsigned)kSpmmCols && (g >= a.ngroups || (int)tid >= a.nvec)) a.partial[(size_t)blockIdx.x * kSpmmCols + tid] = 0.0;
+    if (g >= a.ngroups) return;                               // (grid padded to a multiple of 8: workgroup-uniform)
+    const unsigned W = a.wslots;
+    const uint32_t g0 = g * kGroupRows;
+    const uint32_t row = g0 + ((WIN && a.sell.perm) ? (uint32_t)a.sell.perm[(size_t)g0 + tid] : tid);
+    const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
+    const bool live = row < a.nrows;
+    uint32_t base = 0u, len = 0u, base16 = 0u;
+    if (slice * kSliceRows < a.nrows) {
+        base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
+        if (!WIN) base16 = a.sell.slice_base16[slice];
+    }
+    const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
+    uint32_t oa = 0u, ob = 0u;
+    if (OFFD && live) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
+    const double bi = (a.b && live) ? a.b[row] : 0.0;
+    const unsigned short *const slots16 = reinterpret_cast<const unsigned short *>(a.sell.col16);
+
+    for (int v0 = 0; v0 < a.nvec; v0 += NV) {
+        const int nv = a.nvec - v0 < NV ? a.nvec - v0 : NV;
+        __syncthreads();                                      // the previous pass has finished reading the window (and sm)
+        // ---- stage the group's window of vectors v0 .. v0 + nv - 1
+        if (WIN) {
+            const uint32_t r0 = a.sell.win_ptr[g], r1 = a.sell.win_ptr[g + 1];
+            for (uint32_t r = r0; r < r1; ++r) {
+                const uint2 run = a.sell.win_runs[r];         // wave-uniform
+                const uint32_t rl = run.y & 0xFFFFu, slot0 = run.y >> 16;
+                for (int v = 0; v < nv; ++v) {
+                    const double *xv = a.xs + (size_t)(v0 + v) * a.vstride + run.x;
+                    for (uint32_t i = tid; i < rl; i += kBlock) win[(unsigned)v * W + slot0 + i] = xv[i];
+                }
+            }
+        } else {
+            for (int k = 0; k < a.cl.ncl; ++k) {
+                const int c0 = (int)g0 + a.cl.lo[k], cnt = kGroupRows + a.cl.hi[k] - a.cl.lo[k], slot0 = a.cl.bias[k] + a.cl.lo[k];
+                for (int v = 0; v < nv; ++v) {
+                    const double *xv = a.xs + (size_t)(v0 + v) * a.vstride;
+                    for (int i = (int)tid; i < cnt; i += kBlock) {
+                        const int c = c0 + i;                 // columns clipped by the matrix boundary are never referenced
+                        win[(unsigned)v * W + (unsigned)(slot0 + i)] = (c >= 0 && c < (int)a.nrows) ? xv[c] : 0.0;
+                    }
+                }
+            }
+        }
+        __syncthreads();
+        // ---- the rows, NV sums per lane
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        if (WIN) {
+            uint32_t pos = base;                              // jagged: first entry of step k (wave-uniform), as in sell_row
+            for (uint32_t k0 = 0; k0 < len; k0 += U) {
+                double val[U];
+                unsigned sl[U];
+                bool mine[U];
+#pragma unroll
+                for (int e = 0; e < U; ++e) {
+                    mine[e] = k0 + e < mylen;
+                    const unsigned long long m = __ballot(mine[e]);
+                    const uint32_t j = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                    pos += (uint32_t)__builtin_popcountll(m);
+                    sl[e] = 0u; val[e] = 0.0;
+                    if (mine[e]) { sl[e] = slots16[j]; val[e] = a.sell.val[j]; }
+                }
+#pragma unroll
+                for (int e = 0; e < U; ++e) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const double x = win[(unsigned)v * W + sl[e]];
+                        if (mine[e]) acc[v] += val[e] * x;    // stored order
+                    }
+                }
+            }
+        } else {
+            const i16x4 *const q16 = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + lane);
+            for (uint32_t k0 = 0; k0 < len; k0 += U) {
+                double val[U];
+                int d[U];
+#pragma unroll
+                for (int q = 0; q < U / 4; ++q) {
+                    i16x4 dq = (i16x4)(0);
+                    if (k0 + 4 * q < len) dq = q16[(size_t)(k0 / 4 + q) * kSliceRows];       // wave-uniform test; the quad is padded
+                    d[4 * q + 0] = dq.x; d[4 * q + 1] = dq.y; d[4 * q + 2] = dq.z; d[4 * q + 3] = dq.w;
+                }
+#pragma unroll
+                for (int e = 0; e < U; ++e) val[e] = k0 + e < len ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
+#pragma unroll
+                for (int e = 0; e < U; ++e) {
+                    int bias = a.cl.bias[0];
+                    if (a.cl.ncl > 1 && d[e] >= a.cl.lo[1]) bias = a.cl.bias[1];
+                    if (a.cl.ncl > 2 && d[e] >= a.cl.lo[2]) bias = a.cl.bias[2];
+                    if (a.cl.ncl > 3 && d[e] >= a.cl.lo[3]) bias = a.cl.bias[3];
+                    const unsigned slot = (unsigned)((int)tid + d[e] + bias);     // padding: offset 0, the row's own column
+                    const bool on = k0 + e < mylen;
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) {
+                        const double x = win[(unsigned)v * W + slot];
+                        if (on) acc[v] += val[e] * x;         // stored order; padding never added
+                    }
+                }
+            }
+        }
+        double r2[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            r2[v] = 0.0;
+            if (v < nv && live) {
+                const double *xv = a.xs + (size_t)(v0 + v) * a.vstride;
+                double y = 0.0 + acc[v];                      // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+                if (OFFD) {
+                    double so = 0.0;
+                    for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * xv[a.offd.col[k]];
+                    y += so;                                  // second mult() call, src/matrix.c:440
+                }
+                if (a.sigma) y += a.sigma[v0 + v] * xv[row];  // += sigma_j x_j (src/test_shifted.c:133)
+                if (a.ys) a.ys[(size_t)(v0 + v) * a.vstride + row] = y;
+                if (a.b) { const double dd = (bi + (-1.0) * y) - 0.0; r2[v] = dd * dd; }
+            }
+        }
+        if (a.b) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double t = wave_sum(r2[v]);
+                if (lane == 0) sm[wave * NV + v] = t;
+            }
+            __syncthreads();
+            if ((int)tid < nv) {
+                double t = sm[tid];
+                for (int w = 1; w < kBlock / 64; ++w) t += sm[w * NV + tid];
+                a.partial[(size_t)blockIdx.x * kSpmmCols + v0 + tid] = t;
+            }
+        }
+    }
+}
+
 // out[col] = sum over workgroups of partial[wg][col], fixed order; one workgroup per column
 __global__ void __launch_bounds__(kBlock) k_colsum(const double *partial, unsigned nwg, double *out)
 {
@@ -1942,6 +2104,36 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
     default:        SPMM_GO(LAY_PAD32); break;
     }
 #undef SPMM_GO
+}
+// vectors per window: as many as leave room for two workgroups per CU (80 KB each), else whatever fits one
+int spmm_win_vectors(unsigned wslots)
+{
+    if (wslots == 0) return 0;
+    for (int nv : {16, 8, 4}) if ((size_t)nv * wslots * 8u <= 80u * 1024u) return nv;
+    for (int nv : {8, 4}) if ((size_t)nv * wslots * 8u <= 156u * 1024u) return nv;
+    return 0;
+}
+hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
+{
+    if (a.ngroups == 0) return hipSuccess;
+    const int nv = spmm_win_vectors(a.wslots);
+    if (!nv) return hipErrorInvalidValue;
+    const unsigned grid = a.xcd_map ? ((a.ngroups + 7u) / 8u) * 8u : a.ngroups;
+    const unsigned lds = (unsigned)nv * a.wslots * 8u;
+    const bool runs = a.cl.ncl == 0;
+    auto go = [&](auto kernel) {
+        // (the runtime answers "invalid argument" and launches with > 64 KiB of dynamic LDS all the same: bicg_persist.hip)
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, a);
+        return hipGetLastError();
+    };
+#define WIN_GO(NVV)                                                                                                   \
+    (runs ? (with_offd ? go(k_spmm_win<1, true, NVV>) : go(k_spmm_win<1, false, NVV>))                                 \
+          : (with_offd ? go(k_spmm_win<0, true, NVV>) : go(k_spmm_win<0, false, NVV>)))
+    const hipError_t err = nv == 16 ? WIN_GO(16) : nv == 8 ? WIN_GO(8) : WIN_GO(4);
+#undef WIN_GO
+    return err;
 }
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)

@@ -947,15 +947,19 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
             const double xx = x + alpha * p;
             x = xx + omega * q;
             if (live) {
-                constexpr int B = 4;                  // shifts in flight per thread
+                // B shifts in flight per thread (2 B loads of 8 bytes). On a latency-bound rank the two sets (2 x nsig x rows x 8
+                // bytes: 51 MB for 16 shifts on 200 k rows) live in the Infinity Cache between iterations -- ordinary loads and
+                // stores; non-temporal ones (set_nt) bypass it and are for sets that do not fit
+                constexpr int B = 8;
                 for (int j0 = 0; j0 < a.nsig; j0 += B) {
                     double pj[B], xj[B];
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
                         const int j = j0 + b;
                         const bool on = j < a.nsig && j != a.seed;
-                        pj[b] = on ? __builtin_nontemporal_load(a.pset + (size_t)j * a.set_stride + row) : 0.0;
-                        xj[b] = on ? __builtin_nontemporal_load(a.xset + (size_t)j * a.set_stride + row) : 0.0;
+                        const double *pp = a.pset + (size_t)j * a.set_stride + row, *xp = a.xset + (size_t)j * a.set_stride + row;
+                        pj[b] = !on ? 0.0 : a.set_nt ? __builtin_nontemporal_load(pp) : *pp;
+                        xj[b] = !on ? 0.0 : a.set_nt ? __builtin_nontemporal_load(xp) : *xp;
                     }
 #pragma unroll
                     for (int b = 0; b < B; ++b) {
@@ -968,10 +972,11 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
                         pp = pp + cp * ro;                       // (:807)
                         double xv = xj[b] + cx * q;              // (:834)
                         xv = xv + aj * pp;                       // (:835)
-                        __builtin_nontemporal_store(xv, a.xset + (size_t)j * a.set_stride + row);
                         pp = pp + c1 * q;                        // (:836)
                         pp = pp + c2 * ro;                       // (:837)
-                        __builtin_nontemporal_store(pp, a.pset + (size_t)j * a.set_stride + row);
+                        double *xo = a.xset + (size_t)j * a.set_stride + row, *po = a.pset + (size_t)j * a.set_stride + row;
+                        if (a.set_nt) { __builtin_nontemporal_store(xv, xo); __builtin_nontemporal_store(pp, po); }
+                        else { *xo = xv; *po = pp; }
                     }
                 }
             }
@@ -1219,7 +1224,8 @@ unsigned persist_lds_bytes(const PersistArgs &a)
 // together (the workgroups spin-wait on each other: co-residency is a correctness condition, not a performance one).
 static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int method)
 {
-    const unsigned lds = persist_lds_bytes(a);
+    // (shifted kernel: the helper workgroup's maximum over the shifts runs in the first 8 KiB of the dynamic part)
+    const unsigned lds = method == 3 ? std::max(persist_lds_bytes(a), 8192u) : persist_lds_bytes(a);
     const dim3 g(a.nwg + 1u), b(64u * (a.spw + 1u));        // + the communication wavefront
     auto go = [&](auto kernel, int slot) -> hipError_t {
         static std::set<std::pair<int, int>> ready;        // (device, instantiation)

@@ -155,6 +155,7 @@ struct bicg_ctx {
     PersistArgs persist{};
     bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0/1 overrides
     bool persist_plain = true;   // ... and for plain BiCGStab (BICG_PERSIST_PLAIN=0: the five-launch iteration)
+    bool last_shifted_persist = false;   // the last shifted solve ran as persistent launches (bicg_result.flags of bicg_solve_shifted)
     unsigned persist_seq = 0;    // LL tags used so far (dot tables)
     unsigned persist_vseq = 0;   // ... by the pipelined kernel's vector images
     std::vector<void *> persist_mem;
@@ -197,6 +198,8 @@ struct bicg_ctx {
     // image [rows + halo][kSpmmCols], the row-major result and the per-workgroup column sums
     double *mm_in = nullptr, *mm_xt = nullptr, *mm_yt = nullptr, *mm_part = nullptr, *mm_out = nullptr, *mm_sigma = nullptr;
     bool mm_xcd = true;          // XCD-contiguous row groups in the SpMM (BICG_SPMM_XCD=0: round robin like the SpMV)
+    bool mm_win = false;         // the last SpMM pass ran the windowed kernel (vectors stay shift-major, X staged in LDS)
+    int  mm_win_env = 1;         // BICG_SPMM_WIN=0: the row-major kernel
 
     // state of the solve in progress (run_begin / run_iterate / run_end)
     bicg_options opt{};
@@ -696,7 +699,10 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
 {
     const size_t st = c->stride;
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
-    launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
+    // the windowed form (k_spmm_win) reads the shift-major vectors directly and writes Y shift-major into mm_yt
+    const unsigned wslots = c->win_slots ? c->win_slots : (c->s_col16 && !c->sell_jag && c->fw.ncl > 0 ? c->fw.slots : 0u);
+    c->mm_win = c->mm_win_env != 0 && spmm_win_vectors(wslots) > 0;
+    if (!c->mm_win) launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
@@ -710,7 +716,13 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
         BICG_HIP(hipStreamSynchronize(c->sc));     // sg lives on this stack frame
         a.sigma = c->mm_sigma;
     }
-    launch_spmm_sell(a, !c->single(), c->sc);
+    if (c->mm_win) {
+        a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
+        if (!c->win_slots) a.cl = c->fw;
+        if (launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_SPMM_WIN=0 selects the row-major form)");
+    } else {
+        launch_spmm_sell(a, !c->single(), c->sc);
+    }
     if (with_b) launch_colsum(c->mm_part, spmm_grid(a.ngroups, a.xcd_map != 0), c->mm_out, c->sc);
 }
 
@@ -734,6 +746,7 @@ void spmm_buffers(bicg_ctx *c)
     BICG_HIP(hipMemset(c->mm_in, 0, sizeof(double) * kSpmmCols * st));
     BICG_HIP(hipDeviceSynchronize());      // the memset ran on the null stream: c->sc does not wait for it
     c->mm_xcd = !(getenv("BICG_SPMM_XCD") && atoi(getenv("BICG_SPMM_XCD")) == 0);
+    c->mm_win_env = getenv("BICG_SPMM_WIN") ? atoi(getenv("BICG_SPMM_WIN")) : 1;
 }
 
 // SpMV whose epilogue runs a pipelined phase on the workgroup's own rows (k_spmv_sell_epi): the open dot group is
@@ -767,6 +780,7 @@ void group_flush(bicg_ctx *c)
 void fetch_scal(bicg_ctx *c);
 }  // namespace
 bool persist_chunk(bicg_ctx *c, int niter);
+bool persist_chunk_shifted(bicg_ctx *c, int niter, int it0, int nsig, int seed, double shift);
 void persist_account(bicg_ctx *c);
 namespace {
 
@@ -1478,10 +1492,21 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     }
     fetch_scal(c);
     int it = 0;
+    // latency-bound ranks: the pipelined shifted iteration as ONE persistent launch per chunk (bicg_persist.hip, k_shpipe_persist);
+    // section timing needs the launch boundaries and keeps the multi-launch form
+    const int persist_shifted_env = getenv("BICG_PERSIST_SHIFTED") ? atoi(getenv("BICG_PERSIST_SHIFTED")) : 1;
+    bool persist = mode == SH_PIPE && c->persist_on && c->persist.rpt == 1u && nsig <= kPersistMaxShifts && persist_shifted_env != 0 &&
+                   !(o.time_kernels & 3) && !c->time_sections;
+    c->last_shifted_persist = false;
     while (!c->hS->done && it < o.max_iter) {
-        const int chunk = std::min(o.check_every, o.max_iter - it);
+        const int persist_chunk_min = getenv("BICG_PERSIST_CHUNK") ? std::max(1, atoi(getenv("BICG_PERSIST_CHUNK"))) : kPersistChunk;
+        const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, o.max_iter - it);
         sec_mark(c, SEC_VEC);
-        for (int j = 0; j < chunk; ++j) {
+        if (persist) {
+            persist = persist_chunk_shifted(c, chunk, it, nsig, seed, sigma[seed]);
+            if (persist) c->last_shifted_persist = true;
+        }
+        for (int j = 0; j < chunk && !persist; ++j) {
             if (mode == SH_PIPE) {
                 launch_shift_pipe1(v, p_seed, c->S, c->red(0, PH_SHP_OMEGA), c->sc);    // p, s, z, r_old, q, y, 2 dots
                 group_defer(c, 2, PH_SHP_OMEGA);
@@ -1511,6 +1536,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
         it += chunk;
         sec_mark(c, SEC_STOP);
         fetch_scal(c);
+        if (persist) persist_account(c);
     }
     c->cur_has_shift = false; c->cur_shift = 0.0;
     const double t1 = now_sec();
@@ -1779,6 +1805,8 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
         BICG_HIP(hipMemset(a.dtab[i], 0, sizeof(llword) * (size_t)nwg * kRedSlots * 2));
         a.arow[i] = (llword *)keep(dev_alloc<llword>(8));
         BICG_HIP(hipMemset(a.arow[i], 0, sizeof(llword) * 8));
+        a.crow[i] = (llword *)keep(dev_alloc<llword>(6 * kPersistMaxShifts * 2));      // shifted kernel: per-shift coefficients
+        BICG_HIP(hipMemset(a.crow[i], 0, sizeof(llword) * 6 * kPersistMaxShifts * 2));
     }
     a.multi = multi ? 1 : 0;
     if (multi) {
@@ -1879,6 +1907,46 @@ bool persist_chunk(bicg_ctx *c, int niter)
                              0.01 * (double)(long long)(q[13] - q0[0]), 0.01 * (double)(long long)(q[14] - q0[0]));
                 fprintf(stderr, "\n");
             }
+    }
+    return true;
+}
+
+// niter iterations of shifted_pipe_lopbicgstab (reference src/shifted_solver.c:794-866) in one launch: the seed system's
+// pipelined recurrence with products of A + sigma_seed I, every other shift's p_j / x_j streamed through in phase 2. Sequence
+// numbers as for the pipelined kernel (dense, reported back: persist_account).
+bool persist_chunk_shifted(bicg_ctx *c, int niter, int it0, int nsig, int seed, double shift)
+{
+    if (c->grp.active) die("internal", "persistent chunk with an open dot group");
+    const size_t st = c->stride;
+    PersistArgs a = c->persist;
+    a.v = c->v;
+    a.v.x = c->x_set + (size_t)seed * st; a.v.p = c->p_set + (size_t)seed * st;      // x[seed], p[seed]
+    a.S = c->S; a.alarm = c->alarm; a.niter = niter;
+    a.seq0 = c->persist_seq; a.vseq0 = c->persist_vseq;
+    a.it0 = it0; a.krr = 0; a.nrr = 0; a.force_first = 0; a.drift_every = 0; a.drift_tol2 = 0.0;
+    a.pset = c->p_set; a.xset = c->x_set; a.set_stride = (uint32_t)st; a.nsig = nsig; a.seed = seed;
+    a.shift = shift; a.has_shift = 1;
+    {   // the sets stay in the Infinity Cache when they (and the matrix, if it is not in LDS) fit half of it
+        const double ws = 16.0 * (double)nsig * (double)st + (a.mat_entries ? 0.0 : (double)c->matrix_bytes);
+        a.set_nt = ws > 0.5 * 256.0 * 1048576.0;
+        if (const char *e = getenv("BICG_SHP_NT")) a.set_nt = atoi(e) != 0;
+    }
+    a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;
+    static const int xcd_map = getenv("BICG_PERSIST_XCD") ? atoi(getenv("BICG_PERSIST_XCD")) : 1;
+    a.xcd_map = xcd_map;
+    static const int first_sleep = getenv("BICG_PERSIST_SLEEP") ? atoi(getenv("BICG_PERSIST_SLEEP")) : 1;
+    a.first_sleep = (unsigned)first_sleep;
+    if (a.multi) {
+        a.halo_seq0 = c->halo_seq;
+        a.p2p = c->p2p->red_desc(c->p2p->red_seq);
+        a.ring = c->halo_ring;
+        c->halo_unsynced = 0;
+    }
+    const hipError_t err = launch_shpipe_persist(a, c->sc);
+    if (err != hipSuccess) {
+        if (c->nranks > 1) die("persistent kernel", "launch failed on a multi-rank run (BICG_PERSIST=0 selects the multi-launch iteration)");
+        fprintf(stderr, "bicgstab_hip: falling back to the multi-launch iteration\n");
+        return false;
     }
     return true;
 }
@@ -2231,8 +2299,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     }
     // Fused-window clusters (struct FusedWindow): the offsets fall into <= 4 clusters (gaps of more than 512 columns separate
     // them) and a group's window -- 256 + span columns per cluster -- fits 2048 LDS slots. Padded slices with 16-bit offsets,
-    // every row on the sliced-ELL path, one rank.
-    if (c16 && !jag && !win && offsets_few && P == 1 && sell_entries > 0) {
+    // every row on the sliced-ELL path. (The fused product itself is a one-rank form; the windowed SpMM uses the clusters on every rank.)
+    if (c16 && !jag && !win && offsets_few && sell_entries > 0) {
         offsets_seen.push_back(0);
         std::sort(offsets_seen.begin(), offsets_seen.end());
         FusedWindow f{};
@@ -2437,7 +2505,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
 
     ctx_state(c, comm, ngroups);
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
-    c->fuse_pipe = c->fuse_small || all_ranks(comm, c->win_slots == 0);
+    // Round 4: with the products alternating direction and reading no column index in uniform slices, a big block is faster
+    // as two plain products + two element-wise kernels (Transport-shaped, one GPU: 139.0 vs 152.0 us per pipelined iteration;
+    // profiles/NOTES.md): the fused two-launch form stays what it was built for -- the latency-bound ranks.
+    c->fuse_pipe = c->fuse_small;
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
     else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
     c->spmm_ok = all_ranks(comm, spmm_possible(c));
@@ -2583,7 +2654,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     BICG_HIP(hipFree(far_d));
     ctx_state(c, comm, ngroups);
     if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
-    c->fuse_pipe = true;
+    c->fuse_pipe = c->fuse_small;
     if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
     else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
     c->spmm_ok = spmm_possible(c);
@@ -2802,9 +2873,10 @@ int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nve
         BICG_HIP(hipEventRecord(e0, c->sc));
         spmm_pass(c, nv, sigma ? sigma + j0 : nullptr, false);
         BICG_HIP(hipEventRecord(e1, c->sc));
-        launch_vectors_from_rows(c->mm_yt, c->stride, nv, c->n_loc, c->mm_in, c->sc);     // result back to shift-major (reuses mm_in)
+        if (!c->mm_win) launch_vectors_from_rows(c->mm_yt, c->stride, nv, c->n_loc, c->mm_in, c->sc);     // result back to shift-major (reuses mm_in)
+        const double *ysrc = c->mm_win ? c->mm_yt : c->mm_in;
         for (int j = 0; j < nv; ++j)
-            BICG_HIP(hipMemcpyAsync(y_loc_set + (size_t)(j0 + j) * n, c->mm_in + (size_t)j * c->stride, sizeof(double) * n,
+            BICG_HIP(hipMemcpyAsync(y_loc_set + (size_t)(j0 + j) * n, ysrc + (size_t)j * c->stride, sizeof(double) * n,
                                     hipMemcpyDeviceToHost, c->sc));
         fetch_scal(c);
         float ms = 0.f;
@@ -2871,6 +2943,8 @@ void bicg_dropin_release(void)
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matrix_bytes; }
 unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return c->matrix_bytes; }
+int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
+int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }
 
 void bicg_dropin_stats(unsigned int *hits, unsigned int *misses)
 {

@@ -94,7 +94,8 @@ def test_bench_single_gpu_line_has_every_leg():
     roofs = list(_walk_roofs(d))
     assert len(roofs) >= 20 and all(_roof_ok(r) for _, r in roofs), [(p_, r) for p_, r in roofs if not _roof_ok(r)]
     assert d["extras"]["transport_rank_of_8"]["pipe_bicgstab"]["bound"] == "latency"
-    assert d["extras"]["banded_b8"]["bicgstab"]["bound"] == "hbm" and d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["bound"] == "hbm"
+    # (banded b = 8 without column indices: 192 MB of values + six vectors sit at the edge of the 256 MiB Infinity Cache)
+    assert d["extras"]["banded_b8"]["bicgstab"]["bound"] in ("hbm", "mall") and d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["bound"] == "hbm"
     assert rfst(d)["mall_read8"] > rfst(d)["read8"]
     # the 8-GPU form with traffic in it: two ranks sharing this GPU, persistent launches, a real halo between them
     sh = d["extras"]["small_rank_with_halo"]

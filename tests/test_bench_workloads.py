@@ -93,6 +93,11 @@ def test_fem_like_as_benchmarked():
     Y, _ = ctx.spmm(X, sigma)
     for j in (0, 9, 15):
         assert np.array_equal(Y[j], O.spmv(A.rows, row, col, val, X[j]) + sigma[j] * X[j]), j
+    # round 4: the windowed kernel on the SpMV's own x windows (slots and runs), 16 vectors for the price of a few products
+    ms = min(ctx.spmm(X, sigma)[1] for _ in range(3))
+    one = ctx.spmv_bench(50)
+    print(f"fem_like: SpMM 16 vectors {1e3 * ms:.1f} us, one SpMV {1e3 * one:.1f} us")
+    assert ctx.last_spmm_windowed() and ms <= 6.0 * one
     ctx.close()
 
 
@@ -154,4 +159,51 @@ def test_transport_rank_of_8_as_benchmarked():
     assert fl["persist"] and fl["all_sell"] and fl["col16"], fl
     _spmv_check(ctx, A, coo, seed=8)
     _trajectory_check(ctx, A, coo, ("pipe_bicgstab", "bicgstab", "ca_bicgstab", "pipe_bicgstab_rr"))
+    ctx.close()
+
+
+def test_shifted_pipe_on_a_rank_of_8_is_one_persistent_launch():
+    """BASELINE.json configs[4] on what ONE of 8 GPUs holds (200 264 rows, 16 shifts, seed 7): shifted_pipe_lopbicgstab runs as
+    persistent launches (k_shpipe_persist: seed vectors in registers, the 15 other shifts' p_j / x_j streamed through phase 2, the
+    per-shift coefficients published by the helper workgroup with omega) -- asserted --, its first K iterations against the oracle's
+    trajectory and its iterates against the multi-launch form (BICG_PERSIST_SHIFTED=0; dot sums associate differently: 1e-9),
+    run-to-run bit-identical (reference src/shifted_solver.c:794-866)."""
+    import os
+    H.lib().bicg_comm_init_single(0)
+    n8 = (synth.TRANSPORT_N + 7) // 8
+    A = synth.transport_like(n=n8, scale_decades=SCALE)
+    row, col, val = A.to_coo()
+    nsh, seed = 16, 7
+    sigma = (np.arange(nsh) + 1.0) * 0.01 / nsh
+    ones = np.ones(A.rows)
+    ctx = H.Context(H.single_rank_blocks(A))
+    assert ctx.flags()["persist"]
+    b = ctx.spmv(ones) + sigma[seed] * ones
+    which = "shifted_pipe_lopbicgstab"
+    orc = O.solve_shifted(A.rows, row, col, val, b, sigma, seed, tol=0.0, max_iter=K, which=which)
+    got = ctx.solve_shifted(b, sigma, seed, tol=0.0, max_iter=K, check_every=K, which=which)
+    assert ctx.last_shifted_persistent() and got["k"] == orc["k"] == K
+    tr = ctx.trace(K)
+    for key in ("alpha", "omega", "beta", "dotr"):
+        np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=f"{which} {key}")
+    assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
+    again = ctx.solve_shifted(b, sigma, seed, tol=0.0, max_iter=K, check_every=K, which=which)
+    assert np.array_equal(again["x"], got["x"]) and np.array_equal(again["r"], got["r"])
+    # to a tolerance the system reaches (the oracle needs 711 iterations for 1e-10 on this matrix): every shift's true residual,
+    # and the multi-launch form beside it (pipelined recurrences: the two forms round their dot sums differently and part ways
+    # slowly -- same convergence, not the same bits)
+    full = ctx.solve_shifted(b, sigma, seed, tol=1e-5, max_iter=600, which=which)
+    assert ctx.last_shifted_persistent() and 100 < full["k"] < 600
+    rel = ctx.shifted_residuals(full["x"], b, sigma)
+    assert rel.max() < 1e-4, rel
+    os.environ["BICG_PERSIST_SHIFTED"] = "0"
+    try:
+        ref = H.Context(H.single_rank_blocks(A))
+        multi = ref.solve_shifted(b, sigma, seed, tol=1e-5, max_iter=600, which=which)
+        assert not ref.last_shifted_persistent()
+        ref.close()
+    finally:
+        os.environ.pop("BICG_PERSIST_SHIFTED")
+    assert abs(full["k"] - multi["k"]) <= 0.1 * multi["k"], (full["k"], multi["k"])
+    assert np.abs(full["x"] - multi["x"]).max() <= 1e-3 * np.abs(multi["x"]).max()
     ctx.close()

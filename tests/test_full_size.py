@@ -84,10 +84,11 @@ def test_spmm_16_vectors_reads_the_matrix_once(big):
     for j in (0, 7, 15):
         assert np.array_equal(Y[j], O.spmv(A.rows, row, col, val, X[j]) + sigma[j] * X[j])
     ctx.spmm(X, sigma)
-    ms = min(ctx.spmm(X, sigma)[1] for _ in range(3))          # device time: layout change + SpMM kernel
+    ms = min(ctx.spmm(X, sigma)[1] for _ in range(3))          # device time of the pass (windowed kernel: no layout change)
     one = ctx.spmv_bench(100)
     print(f"SpMM 16 vectors {1e3 * ms:.1f} us, one SpMV {1e3 * one:.1f} us")
-    assert ms <= 0.65 * 16 * one
+    # round 4: X staged in LDS per 256-row group, 8 vectors per pass over A (k_spmm_win) -- 16 vectors for the price of a few SpMVs
+    assert ctx.last_spmm_windowed() and ms <= 5.0 * one
 
 
 @pytest.mark.parametrize("method", ["bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"])

@@ -391,10 +391,12 @@ def test_uniform_slices_give_the_same_bits():
     contexts are identical to the last bit (reference src/matrix.c:498-516)."""
     import os
     H.lib().bicg_comm_init_single(0)
-    cases = [("transport-shaped 16-bit", synth.transport_like(n=150_001, scale_decades=2.0)),
-             ("stencil 32-bit offsets", synth.stencil7(70, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0))),          # 70^2 < 32768: 16-bit
-             ("stencil far planes", synth.stencil7(200, synth.LAPLACE_WEIGHTS, rows=(0, 200 * 200 * 6)))]
-    for name, A in cases:
+    # (a 64-row slice of a stencil matrix is uniform only when it holds no row of a grid face: with lines of 70 points almost
+    # every slice does, with lines of 200 about half of them; 512-point lines -- the 512^3 leg of bench.py -- give 6 of 8)
+    cases = [("transport-shaped 16-bit", synth.transport_like(n=150_001, scale_decades=2.0), 0.5),
+             ("stencil 32-bit offsets", synth.stencil7(70, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)), 0.02),    # 70^2 < 32768: 16-bit
+             ("stencil far planes", synth.stencil7(200, synth.LAPLACE_WEIGHTS, rows=(0, 200 * 200 * 6)), 0.2)]
+    for name, A, share in cases:
         if A.cols != A.rows:      # a slab: keep the columns inside (drop the plane above)
             keep = A.col < A.rows
             ptr = np.concatenate(([0], np.cumsum(np.add.reduceat(keep.astype(np.int64), A.ptr[:-1].astype(np.int64))))).astype(np.uint32)
@@ -408,7 +410,7 @@ def test_uniform_slices_give_the_same_bits():
             os.environ.pop("BICG_SELL_UNIFORM")
         assert ctx.flags()["uniform"] and not ref.flags()["uniform"], name
         ue = ctx.uniform_entries()
-        assert 0.5 * A.nnz < ue <= A.nnz + 64 * 32, (name, ue, A.nnz)
+        assert share * A.nnz < ue <= A.nnz + 64 * 32, (name, ue, A.nnz)
         assert ctx.spmv_matrix_bytes() < ref.spmv_matrix_bytes() - 1.5 * ue, name
         x = np.random.default_rng(11).standard_normal(A.rows)
         y = ctx.spmv(x)

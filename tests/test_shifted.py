@@ -119,6 +119,17 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
     H.lib().bicg_comm_init_single(0)
     A = synth.from_offsets(30011, (0, 1, -1, 37, -37, 2999, -2999), diag_base=9.0, seed=5)
     ctx = H.Context(H.single_rank_blocks(A))
+    os.environ["BICG_SPMM_WIN"] = "0"                 # the row-major kernel (round 2) beside the windowed one (round 4)
+    try:
+        rowmajor = H.Context(H.single_rank_blocks(A))
+        Xr = np.random.default_rng(3).standard_normal((16, A.rows))
+        Yr, _ = rowmajor.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
+        assert not rowmajor.last_spmm_windowed()
+        rowmajor.close()
+    finally:
+        del os.environ["BICG_SPMM_WIN"]
+    Yw, _ = ctx.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
+    assert ctx.last_spmm_windowed() and np.array_equal(Yw, Yr)      # three clusters of offsets: staged per 256-row group in LDS
     rng = np.random.default_rng(8)
     for nvec in (1, 5, 16, 21):                       # less than, exactly and more than one pass of 16
         X = rng.standard_normal((nvec, A.rows))
