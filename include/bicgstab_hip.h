@@ -316,13 +316,18 @@ enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FL
        BICG_FLAG_UNIFORM = 4096   /* some 64-row slices are UNIFORM -- all rows present, equally long, entry k at the same distance
                                      from its row in every row (the interior of a banded or stencil matrix): the SpMV takes their
                                      columns from one shared list of distances and reads no column index for them (8 instead of
-                                     10 / 12 bytes per non-zero); bicg_uniform_entries counts those entries */ };
+                                     10 / 12 bytes per non-zero); bicg_uniform_entries counts those entries */,
+       BICG_FLAG_CONSTANT = 8192  /* ... and some of them are CONSTANT: entry k also holds the same value in all 64 rows (the interior
+                                     of a constant-coefficient stencil such as the 7-point Laplacian of BASELINE.json configs[3]):
+                                     the values come from a shared list too and the slice streams nothing from the matrix arrays;
+                                     bicg_constant_entries counts those entries. Same products, same order: bit-identical */ };
 unsigned int bicg_ctx_flags(bicg_ctx *ctx);
 /* bytes of MATRIX storage this context keeps on the GPU (CSR and/or sliced-ELL arrays, row pointers, offd block) */
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);
 /* sliced-ELL entries (padding included) whose column indices the SpMV does not read (BICG_FLAG_UNIFORM), and the bytes one
  * SpMV streams from the matrix arrays (values + the column indices it does read + row pointers) */
 unsigned long long bicg_uniform_entries(bicg_ctx *ctx);
+unsigned long long bicg_constant_entries(bicg_ctx *ctx);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
  * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST_SHIFTED=0 keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);

@@ -244,6 +244,11 @@ struct SellDev {
     // (col / col16 stay complete: the SpMM and the window-fused product read them.)
     const uint32_t *ubase;
     const int      *uoff;
+    // Constant slices: a uniform slice whose 64 rows also hold the SAME VALUE in entry k (the interior of a constant-coefficient
+    // stencil, e.g. the 7-point Laplacian of BASELINE.json configs[3]): its values are the list uval[vbase[slice] + k], scalar
+    // loads like the distances -- the slice streams NOTHING from the matrix arrays. vbase[slice] = 0xFFFFFFFF: values from val.
+    const uint32_t *vbase;
+    const double   *uval;
 };
 enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4 };
 constexpr uint32_t kWinMaxSlots = 4096;      // 32 KB of LDS per workgroup: 4 workgroups per CU
@@ -383,6 +388,7 @@ hipError_t launch_pipe_persist(const PersistArgs &a, hipStream_t st);
 hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st);    // plain BiCGStab: three groups per iteration
 hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st);       // CA-BiCGStab: two groups per iteration
 hipError_t launch_shpipe_persist(const PersistArgs &a, hipStream_t st);   // shifted_pipe_lopbicgstab (src/shifted_solver.c:794-866), <= kPersistMaxShifts shifts
+hipError_t launch_shlop_persist(const PersistArgs &a, hipStream_t st);    // shifted_lopbicgstab (src/shifted_solver.c:257-319), same limits
 constexpr int kPersistMaxShifts = 32;
 unsigned persist_lds_bytes(const PersistArgs &a);
 constexpr unsigned kPersistMaxLds = 160u * 1024u - 1024u;     // dynamic LDS a launch may ask for (static part: < 1 KiB)
@@ -503,7 +509,8 @@ void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce re
 // device-side sliced-ELL plan (bicg_plan_device.hip): slice lengths + "some column is further than 32767 from its row",
 // then the column-major padded copy (32-bit columns or packed 16-bit offsets)
 void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far, hipStream_t st);
-void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, uint32_t rows, unsigned long long *uhash, hipStream_t st);
+void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, unsigned long long *uhash,
+                         unsigned long long *vhash, hipStream_t st);
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st);
 

@@ -1161,9 +1161,16 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
     // uniform slice: the columns are row + uoff[k], one list for the whole slice (scalar loads) -- no col / col16 traffic.
     // Same loop as the padded slices (one body: a second copy of it cost the ticket-mode kernels three spilled registers)
     const int *__restrict__ uo = nullptr;                         // padded with zeros to a multiple of U (+ U)
+    const double *__restrict__ uv = nullptr;                      // constant slice: the values too (padded with zeros alike)
     if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) {
         const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
-        if (ub != 0xFFFFFFFFu) uo = a.sell.uoff + ub;
+        if (ub != 0xFFFFFFFFu) {
+            uo = a.sell.uoff + ub;
+            if (a.sell.vbase) {
+                const uint32_t vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.vbase[slice]);
+                if (vb != 0xFFFFFFFFu) uv = a.sell.uval + vb;
+            }
+        }
     }
     for (uint32_t k0 = 0; !JAG && k0 < len; k0 += U) {
         uint32_t c[U];
@@ -1192,7 +1199,8 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
             const bool ok = k0 + e < len;                     // wave-uniform
             const uint32_t j = base + (k0 + e) * kSliceRows + lane;
             if (!C16 && !uo) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
-            v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
+            if (uv) v[e] = uv[k0 + e];                        // (wave-uniform branch, scalar load)
+            else v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
         }
         double xv[U];
 #pragma unroll
@@ -1886,7 +1894,8 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
 //           FusedWindow), cluster k of every group is the run [g0 + lo_k, g0 + 255 + hi_k], slot = thread + offset + bias_k;
 //   MODE 1  jagged slices with x windows (ragged rows): the stored 16-bit value IS the slot, the runs are the SpMV's.
 // Per row and vector the sum runs in stored order like mult() (reference src/matrix.c:506-515): every column is bit-identical
-// to bicg_spmv of that vector. The matrix is read nvec / NV times (NV = 8 on Transport: 79 KB of LDS, two workgroups per CU).
+// to bicg_spmv of that vector. NV = 8 on Transport (79 KB of LDS, two workgroups per CU); the first 16 entries of every row
+// stay in registers across the passes, so the matrix is read once per launch whatever NV.
 // ------------------------------------------------------------------------------------------
 template <int MODE, bool OFFD, int NV>
 __global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
@@ -1918,88 +1927,151 @@ __global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
     if (OFFD && live) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
     const double bi = (a.b && live) ? a.b[row] : 0.0;
     const unsigned short *const slots16 = reinterpret_cast<const unsigned short *>(a.sell.col16);
+    __shared__ uint2 wruns[WIN ? 64 : 1];                    // the group's window runs (spmm_possible: at most 64)
+    unsigned nwr = 0;
+    if (WIN) {
+        const uint32_t r0 = a.sell.win_ptr[g];
+        nwr = a.sell.win_ptr[g + 1] - r0;
+        if (tid < nwr && tid < 64u) wruns[tid] = a.sell.win_runs[r0 + tid];
+    }
+
+    // ---- the head of the row -- its first K entries, all of it for most matrices -- is loaded ONCE and kept in registers for
+    // every pass (value, LDS slot, "counts" bit): the matrix is then read once per launch, not once per NV vectors
+    constexpr int K = 16;
+    double hv[K];
+    unsigned hs[K];
+    unsigned hon = 0u;
+    uint32_t pos = base;                                      // jagged: first entry of step k (wave-uniform), as in sell_row
+    auto slot_of = [&](int d) -> unsigned {                   // padded layout: slot = thread + distance + bias of the distance's cluster
+        int bias = a.cl.bias[0];
+        if (a.cl.ncl > 1 && d >= a.cl.lo[1]) bias = a.cl.bias[1];
+        if (a.cl.ncl > 2 && d >= a.cl.lo[2]) bias = a.cl.bias[2];
+        if (a.cl.ncl > 3 && d >= a.cl.lo[3]) bias = a.cl.bias[3];
+        return (unsigned)((int)tid + d + bias);               // padding: distance 0, the row's own column
+    };
+    const i16x4 *const q16 = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + lane);
+    if (WIN) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            hs[e] = 0u; hv[e] = 0.0;
+            if ((uint32_t)e < len) {                          // wave-uniform
+                const bool mine = (uint32_t)e < mylen;
+                const unsigned long long m = __ballot(mine);
+                const uint32_t j = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+                pos += (uint32_t)__builtin_popcountll(m);
+                if (mine) { hs[e] = slots16[j]; hv[e] = a.sell.val[j]; hon |= 1u << e; }
+            }
+        }
+    } else {
+#pragma unroll
+        for (int q = 0; q < K / 4; ++q) {
+            i16x4 dq = (i16x4)(0);
+            if ((uint32_t)(4 * q) < len) dq = q16[(size_t)q * kSliceRows];        // wave-uniform test; the quad is padded
+            hs[4 * q + 0] = slot_of(dq.x); hs[4 * q + 1] = slot_of(dq.y); hs[4 * q + 2] = slot_of(dq.z); hs[4 * q + 3] = slot_of(dq.w);
+        }
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            hv[e] = (uint32_t)e < len ? a.sell.val[base + (uint32_t)e * kSliceRows + lane] : 0.0;
+            if ((uint32_t)e < mylen) hon |= 1u << e;
+        }
+    }
+    const uint32_t pos_tail = pos;
 
     for (int v0 = 0; v0 < a.nvec; v0 += NV) {
         const int nv = a.nvec - v0 < NV ? a.nvec - v0 : NV;
         __syncthreads();                                      // the previous pass has finished reading the window (and sm)
-        // ---- stage the group's window of vectors v0 .. v0 + nv - 1
-        if (WIN) {
-            const uint32_t r0 = a.sell.win_ptr[g], r1 = a.sell.win_ptr[g + 1];
-            for (uint32_t r = r0; r < r1; ++r) {
-                const uint2 run = a.sell.win_runs[r];         // wave-uniform
-                const uint32_t rl = run.y & 0xFFFFu, slot0 = run.y >> 16;
-                for (int v = 0; v < nv; ++v) {
-                    const double *xv = a.xs + (size_t)(v0 + v) * a.vstride + run.x;
-                    for (uint32_t i = tid; i < rl; i += kBlock) win[(unsigned)v * W + slot0 + i] = xv[i];
+        // ---- stage the group's window of vectors v0 .. v0 + nv - 1: JB slots per thread and round, all their NV values
+        // requested before the first is stored (one dependent round trip per run and vector: 743 us per launch on Transport;
+        // one slot per round: 430 us)
+        constexpr int JB = 32 / NV;
+        for (unsigned s0 = 0; s0 < W; s0 += JB * kBlock) {
+            int c[JB];                                        // column of the slot; -1: unused slot / clipped by the matrix boundary
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const unsigned sl = s0 + (unsigned)j * kBlock + tid;
+                c[j] = -1;
+                if (sl < W) {
+                    if (WIN) {
+                        unsigned r = 0;
+                        while (r + 1 < nwr && (wruns[r + 1].y >> 16) <= sl) ++r;      // runs are few and ordered by slot
+                        const unsigned off = sl - (wruns[r].y >> 16);
+                        if (nwr && off < (wruns[r].y & 0xFFFFu)) c[j] = (int)(wruns[r].x + off);
+                    } else {
+                        int k = 0;
+                        if (a.cl.ncl > 1 && (int)sl >= a.cl.bias[1] + a.cl.lo[1]) k = 1;
+                        if (a.cl.ncl > 2 && (int)sl >= a.cl.bias[2] + a.cl.lo[2]) k = 2;
+                        if (a.cl.ncl > 3 && (int)sl >= a.cl.bias[3] + a.cl.lo[3]) k = 3;
+                        const int bk = k == 0 ? a.cl.bias[0] : k == 1 ? a.cl.bias[1] : k == 2 ? a.cl.bias[2] : a.cl.bias[3];
+                        const int cc = (int)g0 + (int)sl - bk;                      // slot = (column - g0) + bias_k
+                        if (cc >= 0 && cc < (int)a.nrows) c[j] = cc;
+                    }
                 }
             }
-        } else {
-            for (int k = 0; k < a.cl.ncl; ++k) {
-                const int c0 = (int)g0 + a.cl.lo[k], cnt = kGroupRows + a.cl.hi[k] - a.cl.lo[k], slot0 = a.cl.bias[k] + a.cl.lo[k];
-                for (int v = 0; v < nv; ++v) {
-                    const double *xv = a.xs + (size_t)(v0 + v) * a.vstride;
-                    for (int i = (int)tid; i < cnt; i += kBlock) {
-                        const int c = c0 + i;                 // columns clipped by the matrix boundary are never referenced
-                        win[(unsigned)v * W + (unsigned)(slot0 + i)] = (c >= 0 && c < (int)a.nrows) ? xv[c] : 0.0;
-                    }
+            double t[JB][NV];
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) t[j][v] = (c[j] >= 0 && v < nv) ? a.xs[(size_t)(v0 + v) * a.vstride + (unsigned)c[j]] : 0.0;
+            }
+#pragma unroll
+            for (int j = 0; j < JB; ++j) {
+                const unsigned sl = s0 + (unsigned)j * kBlock + tid;
+                if (sl < W) {
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) win[(unsigned)v * W + sl] = t[j][v];
                 }
             }
         }
         __syncthreads();
-        // ---- the rows, NV sums per lane
+        // ---- the rows, NV sums per lane: the head from registers, whatever follows streamed
         double acc[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = 0.0;
-        if (WIN) {
-            uint32_t pos = base;                              // jagged: first entry of step k (wave-uniform), as in sell_row
-            for (uint32_t k0 = 0; k0 < len; k0 += U) {
-                double val[U];
-                unsigned sl[U];
-                bool mine[U];
+#pragma unroll
+        for (int e = 0; e < K; ++e) {
+            if ((uint32_t)e < len) {                          // wave-uniform
+                const bool on = (hon >> e) & 1u;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double x = win[(unsigned)v * W + hs[e]];
+                    if (on) acc[v] += hv[e] * x;              // stored order; padding never added
+                }
+            }
+        }
+        pos = pos_tail;
+        for (uint32_t k0 = K; k0 < len; k0 += U) {
+            double val[U];
+            unsigned sl[U];
+            bool on[U];
+            if (WIN) {
 #pragma unroll
                 for (int e = 0; e < U; ++e) {
-                    mine[e] = k0 + e < mylen;
-                    const unsigned long long m = __ballot(mine[e]);
+                    on[e] = k0 + e < mylen;
+                    const unsigned long long m = __ballot(on[e]);
                     const uint32_t j = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
                     pos += (uint32_t)__builtin_popcountll(m);
                     sl[e] = 0u; val[e] = 0.0;
-                    if (mine[e]) { sl[e] = slots16[j]; val[e] = a.sell.val[j]; }
+                    if (on[e]) { sl[e] = slots16[j]; val[e] = a.sell.val[j]; }
                 }
-#pragma unroll
-                for (int e = 0; e < U; ++e) {
-#pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const double x = win[(unsigned)v * W + sl[e]];
-                        if (mine[e]) acc[v] += val[e] * x;    // stored order
-                    }
-                }
-            }
-        } else {
-            const i16x4 *const q16 = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + lane);
-            for (uint32_t k0 = 0; k0 < len; k0 += U) {
-                double val[U];
-                int d[U];
+            } else {
 #pragma unroll
                 for (int q = 0; q < U / 4; ++q) {
                     i16x4 dq = (i16x4)(0);
-                    if (k0 + 4 * q < len) dq = q16[(size_t)(k0 / 4 + q) * kSliceRows];       // wave-uniform test; the quad is padded
-                    d[4 * q + 0] = dq.x; d[4 * q + 1] = dq.y; d[4 * q + 2] = dq.z; d[4 * q + 3] = dq.w;
+                    if (k0 + 4 * q < len) dq = q16[(size_t)(k0 / 4 + q) * kSliceRows];
+                    sl[4 * q + 0] = slot_of(dq.x); sl[4 * q + 1] = slot_of(dq.y); sl[4 * q + 2] = slot_of(dq.z); sl[4 * q + 3] = slot_of(dq.w);
                 }
 #pragma unroll
-                for (int e = 0; e < U; ++e) val[e] = k0 + e < len ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
-#pragma unroll
                 for (int e = 0; e < U; ++e) {
-                    int bias = a.cl.bias[0];
-                    if (a.cl.ncl > 1 && d[e] >= a.cl.lo[1]) bias = a.cl.bias[1];
-                    if (a.cl.ncl > 2 && d[e] >= a.cl.lo[2]) bias = a.cl.bias[2];
-                    if (a.cl.ncl > 3 && d[e] >= a.cl.lo[3]) bias = a.cl.bias[3];
-                    const unsigned slot = (unsigned)((int)tid + d[e] + bias);     // padding: offset 0, the row's own column
-                    const bool on = k0 + e < mylen;
+                    val[e] = k0 + e < len ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
+                    on[e] = k0 + e < mylen;
+                }
+            }
 #pragma unroll
-                    for (int v = 0; v < NV; ++v) {
-                        const double x = win[(unsigned)v * W + slot];
-                        if (on) acc[v] += val[e] * x;         // stored order; padding never added
-                    }
+            for (int e = 0; e < U; ++e) {
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double x = win[(unsigned)v * W + sl[e]];
+                    if (on[e]) acc[v] += val[e] * x;          // stored order
                 }
             }
         }
@@ -2109,7 +2181,9 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
 int spmm_win_vectors(unsigned wslots)
 {
     if (wslots == 0) return 0;
-    for (int nv : {16, 8, 4}) if ((size_t)nv * wslots * 8u <= 80u * 1024u) return nv;
+    // (the head of every row stays in registers across the passes, so more vectors per window save barriers, not matrix traffic:
+    // 16 per window was dropped -- its 256 LDS reads per thread in flight cost the occupancy)
+    for (int nv : {8, 4}) if ((size_t)nv * wslots * 8u <= 80u * 1024u) return nv;
     for (int nv : {8, 4}) if ((size_t)nv * wslots * 8u <= 156u * 1024u) return nv;
     return 0;
 }
@@ -2131,7 +2205,7 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
 #define WIN_GO(NVV)                                                                                                   \
     (runs ? (with_offd ? go(k_spmm_win<1, true, NVV>) : go(k_spmm_win<1, false, NVV>))                                 \
           : (with_offd ? go(k_spmm_win<0, true, NVV>) : go(k_spmm_win<0, false, NVV>)))
-    const hipError_t err = nv == 16 ? WIN_GO(16) : nv == 8 ? WIN_GO(8) : WIN_GO(4);
+    const hipError_t err = nv == 8 ? WIN_GO(8) : WIN_GO(4);
 #undef WIN_GO
     return err;
 }

@@ -578,9 +578,14 @@ __device__ __forceinline__ void wg_setup(const PersistArgs &a, unsigned wg, doub
 // wavefront sends partials and halo values and -- wait_scal -- fetches the group's applied scalars into L.sc while the row
 // wavefronts stage their window and multiply. out = A val on the thread's rows. Ends with a barrier: L.sc / L.fail are
 // valid for everybody.
-template <int R, int N, bool LDSMAT, bool MULTI, bool COEF = false>
+struct NoMid { __device__ __forceinline__ void operator()() const {} };
+// MID: work of the row wavefronts that needs nothing from the hand-off (the shifted kernel's pass over the other shifts' vectors):
+// it runs after the values and partials have left -- the neighbours' values and the helper's chain travel meanwhile -- and before
+// the window is staged.
+template <int R, int N, bool LDSMAT, bool MULTI, bool COEF = false, class MID = NoMid>
 __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, const RowState<R> &rs, PersistLds &L, const double (&val)[R],
-                                      double (&acc)[N > 0 ? N : 1], unsigned buf, unsigned nv, unsigned g, bool wait_scal, double (&out)[R])
+                                      double (&acc)[N > 0 ? N : 1], unsigned buf, unsigned nv, unsigned g, bool wait_scal, double (&out)[R],
+                                      MID mid = MID())
 {
     const unsigned vtag = a.vseq0 + nv, htag = a.halo_seq0 + nv, gtag = a.seq0 + g;
     llword *const img = a.llv[buf];
@@ -605,6 +610,7 @@ __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, cons
         if (N > 0) comm_partials<(N > 0 ? N : 1)>(W.lane, W.nrw, a.dtab[g & 1u] + (size_t)blockIdxWg(a) * kRedSlots * 2, gtag, L);
         comm_halo<MULTI>(a, W.lane, W.zs, htag, W.ns0, W.ns1);
     } else {
+        mid();
         stage_window<MULTI>(a, W.runs, W.nruns, W.nslots, img, vtag, htag, W.win, W.nrt, L, W.zs, W.row0, W.nmine);
     }
     lds_barrier();
@@ -876,6 +882,44 @@ k_pipe_persist(PersistArgs a)
 }
 
 
+// The pass over the other shifts' vectors of one row (reference src/shifted_solver.c:264-269, 296-299 / 806-807, 834-837;
+// FShiftUpdate / FShPipe2 of bicg_kernels.hip, operation for operation): p_j and x_j of the row are read once and written once
+// with the coefficients the helper published (L.coef). B shifts in flight per thread (2 B loads of 8 bytes). On a
+// latency-bound rank the two sets (2 x nsig x rows x 8 bytes: 51 MB for 16 shifts on 200 k rows) live in the Infinity Cache
+// between iterations -- ordinary loads and stores; non-temporal ones (set_nt) bypass it and are for sets that do not fit.
+__device__ __forceinline__ void shift_pass(const PersistArgs &a, const PersistLds &L, uint32_t row, double q, double ro)
+{
+    constexpr int B = 8;
+    for (int j0 = 0; j0 < a.nsig; j0 += B) {
+        double pj[B], xj[B];
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int j = j0 + b;
+            const bool on = j < a.nsig && j != a.seed;
+            const double *pp = a.pset + (size_t)j * a.set_stride + row, *xp = a.xset + (size_t)j * a.set_stride + row;
+            pj[b] = !on ? 0.0 : a.set_nt ? __builtin_nontemporal_load(pp) : *pp;
+            xj[b] = !on ? 0.0 : a.set_nt ? __builtin_nontemporal_load(xp) : *xp;
+        }
+#pragma unroll
+        for (int b = 0; b < B; ++b) {
+            const int j = j0 + b;
+            if (j >= a.nsig || j == a.seed) continue;
+            const double bj = L.coef[0 * kPersistMaxShifts + j], aj = L.coef[1 * kPersistMaxShifts + j];
+            const double cp = L.coef[2 * kPersistMaxShifts + j], cx = L.coef[3 * kPersistMaxShifts + j];
+            const double c1 = L.coef[4 * kPersistMaxShifts + j], c2 = L.coef[5 * kPersistMaxShifts + j];
+            double pp = bj * pj[b];                  // (:265 / :806)
+            pp = pp + cp * ro;                       // (:266 / :807)
+            double xv = xj[b] + cx * q;              // (:296 / :834)
+            xv = xv + aj * pp;                       // (:297 / :835)
+            pp = pp + c1 * q;                        // (:298 / :836)
+            pp = pp + c2 * ro;                       // (:299 / :837)
+            double *xo = a.xset + (size_t)j * a.set_stride + row, *po = a.pset + (size_t)j * a.set_stride + row;
+            if (a.set_nt) { __builtin_nontemporal_store(xv, xo); __builtin_nontemporal_store(pp, po); }
+            else { *xo = xv; *po = pp; }
+        }
+    }
+}
+
 // ------------------------------------------------------------------------------------------------------------------
 // shifted_pipe_lopbicgstab (reference src/shifted_solver.c:794-866; FShPipe1 / FShPipe2 / apply_phase_shifted, operation for
 // operation) in the persistent form: the SEED system's recurrence is the pipelined iteration above with products of
@@ -940,53 +984,22 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
         xprod<1, 2, LDSMAT, MULTI, true>(a, W, rs, L, z, acc2, 0u, ++nv, ++g, true, v);
         if (L.fail) break;
         omega = L.sc[2];
-        // ---- phase 2: x[seed] ; every p_j, x_j ; r ; w ; five dots                                   (:829-848, FShPipe2)
+        // ---- phase 2: x[seed] ; r ; w ; five dots -- then, while w and the partials travel, every p_j, x_j     (:829-848, FShPipe2)
         double acc5[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+        const double q = r[0];
         if (!comm) {
-            const double q = r[0], y = w[0];
+            const double y = w[0];
             const double xx = x + alpha * p;
             x = xx + omega * q;
-            if (live) {
-                // B shifts in flight per thread (2 B loads of 8 bytes). On a latency-bound rank the two sets (2 x nsig x rows x 8
-                // bytes: 51 MB for 16 shifts on 200 k rows) live in the Infinity Cache between iterations -- ordinary loads and
-                // stores; non-temporal ones (set_nt) bypass it and are for sets that do not fit
-                constexpr int B = 8;
-                for (int j0 = 0; j0 < a.nsig; j0 += B) {
-                    double pj[B], xj[B];
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const int j = j0 + b;
-                        const bool on = j < a.nsig && j != a.seed;
-                        const double *pp = a.pset + (size_t)j * a.set_stride + row, *xp = a.xset + (size_t)j * a.set_stride + row;
-                        pj[b] = !on ? 0.0 : a.set_nt ? __builtin_nontemporal_load(pp) : *pp;
-                        xj[b] = !on ? 0.0 : a.set_nt ? __builtin_nontemporal_load(xp) : *xp;
-                    }
-#pragma unroll
-                    for (int b = 0; b < B; ++b) {
-                        const int j = j0 + b;
-                        if (j >= a.nsig || j == a.seed) continue;
-                        const double bj = L.coef[0 * kPersistMaxShifts + j], aj = L.coef[1 * kPersistMaxShifts + j];
-                        const double cp = L.coef[2 * kPersistMaxShifts + j], cx = L.coef[3 * kPersistMaxShifts + j];
-                        const double c1 = L.coef[4 * kPersistMaxShifts + j], c2 = L.coef[5 * kPersistMaxShifts + j];
-                        double pp = bj * pj[b];                  // (:806)
-                        pp = pp + cp * ro;                       // (:807)
-                        double xv = xj[b] + cx * q;              // (:834)
-                        xv = xv + aj * pp;                       // (:835)
-                        pp = pp + c1 * q;                        // (:836)
-                        pp = pp + c2 * ro;                       // (:837)
-                        double *xo = a.xset + (size_t)j * a.set_stride + row, *po = a.pset + (size_t)j * a.set_stride + row;
-                        if (a.set_nt) { __builtin_nontemporal_store(xv, xo); __builtin_nontemporal_store(pp, po); }
-                        else { *xo = xv; *po = pp; }
-                    }
-                }
-            }
             r[0] = q + (-omega) * y;                             // (:840)
             const double tt = t[0] + (-alpha) * v[0];            // (:842)
             w[0] = y + (-omega) * tt;                            // (:843)
             if (live) { acc5[0] = r[0] * r[0]; acc5[1] = h * r[0]; acc5[2] = h * w[0]; acc5[3] = h * s; acc5[4] = h * z[0]; }
         }
-        // ---- t = (A + sigma I) w  ||  beta, alpha, the stopping test                                 (:849-866)
-        xprod<1, 5, LDSMAT, MULTI>(a, W, rs, L, w, acc5, 1u, ++nv, ++g, true, t);
+        auto shifts = [&]() { if (live) shift_pass(a, L, row, q, ro); };
+        // ---- t = (A + sigma I) w  ||  the other shifts  ||  beta, alpha, the stopping test            (:849-866)
+        // (round 4, first form: the pass over the shifts BEFORE the hand-off: 31.4 us per iteration for 16 shifts on 200 k rows)
+        xprod<1, 5, LDSMAT, MULTI, false>(a, W, rs, L, w, acc5, 1u, ++nv, ++g, true, t, shifts);
         if (L.fail) break;
         alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] == 1.0 ? 1 : 0;
     }
@@ -1109,6 +1122,123 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// shifted_lopbicgstab (reference src/shifted_solver.c:257-319) in the persistent form: the SEED system's iteration is plain
+// BiCGStab on A + sigma_seed I -- three exposed groups, PH_SH_ALPHA / PH_SH_OMEGA / PH_SH_END, numbered like the plain kernel's
+// -- and the helper runs the per-shift scalar recurrences with them (one thread per shift) and publishes every shift's six
+// coefficients together with omega. The pass over the other shifts' p_j / x_j (shift_pass) runs while the third group's sums
+// travel to the helper and back. Expressions: FShiftQ / FShiftUpdate / FShiftPSeed, operation for operation.
+// v.x / v.p are x[seed] / p[seed]; r_old lives in registers (and goes back to v.ax like the multi-launch form leaves it).
+// ------------------------------------------------------------------------------------------------------------------
+template <bool LDSMAT, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_shlop_persist(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wg = persist_wg(a);
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            const unsigned s1 = a.seq0 + 3u * (unsigned)it + 1u, m1 = a.p2p.seq + 3u * (unsigned)it;
+            if (!helper_group<1, true>(a, a.dtab[0], a.arow[0], s1, m1, PH_SH_ALPHA, L, nullptr, dyn, nullptr)) break;
+            if (!helper_group<2, true>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_SH_OMEGA, L, nullptr, dyn, a.crow[1])) break;
+            if (!helper_group<2, true>(a, a.dtab[0], a.arow[0], s1 + 2u, m1 + 2u, PH_SH_END, L, nullptr, dyn, nullptr)) break;
+        }
+        helper_finish(a, L);
+        return;
+    }
+
+    const RowWg R = row_setup<LDSMAT, MULTI>(a, wg, dyn);
+    double *const win = R.win, *const zs = R.zs;
+    const uint2 *const runs = R.runs;
+    const unsigned nrw = R.nrw, nrt = R.nrt, nruns = R.nruns, nslots = R.nslots, ns0 = R.ns0, ns1 = R.ns1;
+    const bool comm = R.comm, live = R.live;
+    const uint32_t row0 = R.row0, nmine = R.nmine, row = R.row, slen = R.slen, mylen = R.mylen, mydiag = R.mydiag;
+    const double *const gval = R.gval;
+    const unsigned short *const gslot = R.gslot;
+    const Vecs &e = a.v;
+    const uint32_t rr_ = live ? row : 0u;
+    double x = e.x[rr_], r = e.r[rr_], p = e.p[rr_], s = e.s[rr_], y = e.y[rr_], q = 0.0, ro = e.ax[rr_];
+    const double h = e.rh[rr_];
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    llword *const tab0 = R.tab0, *const tab1 = R.tab1;
+    llword *const img0 = R.img0, *const img1 = R.img1;
+    for (int it = 0; it < a.niter && !done; ++it) {
+        const unsigned g1 = a.seq0 + 3u * (unsigned)it + 1u, g2 = g1 + 1u, g3 = g1 + 2u;
+        const unsigned hp = a.halo_seq0 + 2u * (unsigned)it + 1u, hq = hp + 1u;
+        // ---- s = (A + sigma I) p[seed] ; (r#,s) -> alpha[seed], every beta_j, alpha_j                 (:259-287)
+        if (!comm) { publish_only(p, zs, img0, g1); }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, zs, hp, ns0, ns1);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[0], g1, hp, win, nrt, L, zs, row0, nmine);
+        lds_barrier();
+        if (!comm) {
+            s = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+            if (a.has_shift && live) s += a.shift * p;                       // (:260)
+            double acc[1] = {live ? h * s : 0.0};
+            hand_over<1>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<1>(lane, nrw, tab0, g1, L); comm_scalars(a, lane, a.arow[0], g1, L); }
+        lds_barrier();
+        if (L.fail) break;
+        alpha = L.sc[0];
+        // ---- r_old = r ; q = r - alpha s ; y = (A + sigma I) q ; (q,y), (q,q) -> omega and the coefficients   (:269-300)
+        if (!comm) { ro = r; q = r + (-alpha) * s; publish_only(q, zs, img1, g2); }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, zs, hq, ns0, ns1);
+        else stage_window<MULTI>(a, runs, nruns, nslots, a.llv[1], g2, hq, win, nrt, L, zs, row0, nmine);
+        lds_barrier();
+        if (!comm) {
+            y = persist_row<MULTI>(gval, gslot, slen, mylen, mydiag, win);
+            if (a.has_shift && live) y += a.shift * q;                       // (:278)
+            double acc[2] = {live ? q * y : 0.0, live ? q * q : 0.0};
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) {
+            comm_partials<2>(lane, nrw, tab1, g2, L);
+            comm_scalars(a, lane, a.arow[1], g2, L);
+            comm_coefs(a, lane, a.crow[1], g2, L);
+        }
+        lds_barrier();
+        if (L.fail) break;
+        omega = L.sc[2];
+        // ---- x[seed] += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r) -> beta, k++ ; meanwhile every p_j, x_j   (:292-315)
+        if (!comm) {
+            double xx = x + alpha * p;
+            x = xx + omega * q;
+            r = q + (-omega) * y;
+            double acc[2] = {live ? r * r : 0.0, live ? h * r : 0.0};
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, nrw, tab0, g3, L); comm_scalars(a, lane, a.arow[0], g3, L); }
+        else if (live) shift_pass(a, L, row, q, ro);
+        lds_barrier();
+        if (L.fail) break;
+        beta = L.sc[1]; done = L.sc[3] != 0.0 ? 1 : 0;
+        // ---- p[seed] = beta p ; += r ; += (-beta omega) s                                            (:317-319)
+        if (!comm) {
+            double pp = beta * p;
+            pp = pp + 1.0 * r;
+            pp = pp + (-beta * omega) * s;
+            p = pp;
+        }
+        lds_barrier();                        // L.sc is rewritten by the next group
+    }
+    if (live) { e.x[row] = x; e.r[row] = r; e.p[row] = p; e.s[row] = s; e.y[row] = y; e.ax[row] = ro; }
+}
+
+
+// ------------------------------------------------------------------------------------------------------------------
 // CA-BiCGStab (reference src/solver.c:216-251) in the persistent form: z = A s and w = A r per iteration, two groups --
 // (q,y),(y,y) -> omega, needed at once by the x / r update, and (r,r),(r#,r),(r#,w),(r#,s),(r#,z) -> beta, alpha, k++ after
 // the second product -- both exposed. Expressions: FCaPS / FQY / FCaXR, operation for operation. The helper's schedule is
@@ -1225,13 +1355,13 @@ unsigned persist_lds_bytes(const PersistArgs &a)
 static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int method)
 {
     // (shifted kernel: the helper workgroup's maximum over the shifts runs in the first 8 KiB of the dynamic part)
-    const unsigned lds = method == 3 ? std::max(persist_lds_bytes(a), 8192u) : persist_lds_bytes(a);
+    const unsigned lds = method >= 3 ? std::max(persist_lds_bytes(a), 8192u) : persist_lds_bytes(a);
     const dim3 g(a.nwg + 1u), b(64u * (a.spw + 1u));        // + the communication wavefront
     auto go = [&](auto kernel, int slot) -> hipError_t {
         static std::set<std::pair<int, int>> ready;        // (device, instantiation)
         int dev = 0;
         (void)hipGetDevice(&dev);
-        const int idx = slot * 4 + (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0) + 16 * (int)a.rpt;
+        const int idx = slot * 4 + (a.mat_entries ? 2 : 0) + (a.multi ? 1 : 0) + 64 * (int)a.rpt;
         if (!ready.count({dev, idx})) {       // (the runtime answers "invalid argument" and launches with > 64 KiB of LDS all the same)
             (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kPersistMaxLds);
             (void)hipGetLastError();
@@ -1266,6 +1396,10 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
         if (a.nsig < 1 || a.nsig > kPersistMaxShifts) return hipErrorInvalidValue;
         if (a.mat_entries) { err = a.multi ? go(k_shpipe_persist<true, true>, 3) : go(k_shpipe_persist<true, false>, 3); }
         else { err = a.multi ? go(k_shpipe_persist<false, true>, 3) : go(k_shpipe_persist<false, false>, 3); }
+    } else if (method == 4) {
+        if (a.nsig < 1 || a.nsig > kPersistMaxShifts) return hipErrorInvalidValue;
+        if (a.mat_entries) { err = a.multi ? go(k_shlop_persist<true, true>, 4) : go(k_shlop_persist<true, false>, 4); }
+        else { err = a.multi ? go(k_shlop_persist<false, true>, 4) : go(k_shlop_persist<false, false>, 4); }
     } else if (method == 1) {
         if (a.mat_entries) { err = a.multi ? go(k_plain_persist<true, true>, 1) : go(k_plain_persist<true, false>, 1); }
         else { err = a.multi ? go(k_plain_persist<false, true>, 1) : go(k_plain_persist<false, false>, 1); }
@@ -1278,6 +1412,7 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
 }
 hipError_t launch_pipe_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 0); }
 hipError_t launch_shpipe_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 3); }
+hipError_t launch_shlop_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 4); }
 hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 1); }
 hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 2); }
 

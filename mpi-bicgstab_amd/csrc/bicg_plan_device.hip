@@ -44,7 +44,8 @@ __global__ void __launch_bounds__(kThreads) k_plan_rowstats(const uint32_t *ptr,
 // uniform slices (SellDev::ubase): uhash[s] != 0 when all 64 rows of slice s are present, equally long, and entry k sits at
 // the same distance from its row in every row; its value is a 64-bit hash of the distances (the host groups slices by hash
 // and fetches one list per group). One wavefront per slice, lane = row.
-__global__ void __launch_bounds__(kThreads) k_plan_uniform(const uint32_t *ptr, const uint32_t *col, uint32_t rows, unsigned long long *uhash)
+__global__ void __launch_bounds__(kThreads) k_plan_uniform(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
+                                                           unsigned long long *uhash, unsigned long long *vhash)
 {
     const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
     const bool live = r < rows;
@@ -60,6 +61,19 @@ __global__ void __launch_bounds__(kThreads) k_plan_uniform(const uint32_t *ptr, 
         h ^= h >> 29;
     }
     if ((threadIdx.x & 63u) == 0 && live) uhash[r / kSliceRows] = uni ? (h | 1ull) : 0ull;
+    // ... and constant: entry k holds the same value in every row (SellDev::vbase); hash of the value bits AND the distances
+    if (!vhash) return;
+    bool con = uni;
+    unsigned long long hv = h ^ 0x9E3779B97F4A7C15ull;
+    for (uint32_t k = 0; con && k < len0; ++k) {
+        const unsigned long long b = (unsigned long long)__double_as_longlong(val[a + k]);
+        const unsigned lo0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)b), hi0 = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(b >> 32));
+        const unsigned long long b0 = ((unsigned long long)hi0 << 32) | lo0;
+        con = __all(b == b0);
+        hv = (hv ^ b0) * 0x100000001b3ull;
+        hv ^= hv >> 31;
+    }
+    if ((threadIdx.x & 63u) == 0 && live) vhash[r / kSliceRows] = con ? (hv | 1ull) : 0ull;
 }
 
 // entry k of row r -> slice_base[r / 64] + k * 64 + r % 64 (padding stays zero); 16-bit offsets four to a word
@@ -116,9 +130,10 @@ void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t row
 {
     hipLaunchKernelGGL(k_plan_rowstats, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, rows, slice_len, far);
 }
-void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, uint32_t rows, unsigned long long *uhash, hipStream_t st)
+void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, unsigned long long *uhash,
+                         unsigned long long *vhash, hipStream_t st)
 {
-    hipLaunchKernelGGL(k_plan_uniform, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, rows, uhash);
+    hipLaunchKernelGGL(k_plan_uniform, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, val, rows, uhash, vhash);
 }
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st)

@@ -92,6 +92,9 @@ struct bicg_ctx {
     uint32_t *s_ubase = nullptr;           // uniform slices (SellDev::ubase / uoff): BICG_SELL_UNIFORM=0 switches them off
     int *s_uoff = nullptr;
     uint64_t uniform_entries = 0;          // sliced-ELL entries whose columns the SpMV does not read
+    uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
+    double *s_uval = nullptr;
+    uint64_t constant_entries = 0;         // ... whose values it does not read either
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
     uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
     uint32_t win_max_runs = 0;             // most runs of one group's window
@@ -198,6 +201,13 @@ struct bicg_ctx {
     // image [rows + halo][kSpmmCols], the row-major result and the per-workgroup column sums
     double *mm_in = nullptr, *mm_xt = nullptr, *mm_yt = nullptr, *mm_part = nullptr, *mm_out = nullptr, *mm_sigma = nullptr;
     bool mm_xcd = true;          // XCD-contiguous row groups in the SpMM (BICG_SPMM_XCD=0: round robin like the SpMV)
+    // A rank WITHOUT rows (more ranks than rows, or an empty block of a non-zero balanced partition; the reference's loops simply
+    // run over zero rows there, src/matrix.c:295-298) holds ONE phantom row here -- the 1 x 1 block [1.0], decoupled from every
+    // other row, with x = b = 0: all its vector entries stay 0, it adds 0.0 to every dot sum, sends and receives nothing, and so
+    // takes part in every exchange and every launch path without a zero-row form of any kernel. The caller's vectors are empty:
+    // host reads come from / host writes go to a scratch (host_in / host_out below).
+    bool phantom = false;
+    std::vector<double> ph_scratch;
     bool mm_win = false;         // the last SpMM pass ran the windowed kernel (vectors stay shift-major, X staged in LDS)
     int  mm_win_env = 1;         // BICG_SPMM_WIN=0: the row-major kernel
 
@@ -269,6 +279,20 @@ namespace {
 // so replacing the communicator (bicg_comm_init_*, bicg_comm_finalize) orphans them -- they can still be
 // destroyed, nothing else
 std::vector<bicg_ctx *> g_live;
+
+// host vectors of a rank without rows (bicg_ctx::phantom): `count` zeros to read / a place to write
+const double *host_in(bicg_ctx *c, const double *p, size_t count = 1)
+{
+    if (!c->phantom) return p;
+    c->ph_scratch.assign(std::max<size_t>(count, 1), 0.0);
+    return c->ph_scratch.data();
+}
+double *host_out(bicg_ctx *c, double *p, size_t count = 1)
+{
+    if (!c->phantom || !p) return p;
+    if (c->ph_scratch.size() < count) c->ph_scratch.assign(count, 0.0);
+    return c->ph_scratch.data();
+}
 
 void use_device(const bicg_ctx *c)
 {
@@ -496,7 +520,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.fin = fin;
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
-    a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff;
+    a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -780,7 +804,7 @@ void group_flush(bicg_ctx *c)
 void fetch_scal(bicg_ctx *c);
 }  // namespace
 bool persist_chunk(bicg_ctx *c, int niter);
-bool persist_chunk_shifted(bicg_ctx *c, int niter, int it0, int nsig, int seed, double shift);
+bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, int seed, double shift);
 void persist_account(bicg_ctx *c);
 namespace {
 
@@ -1268,6 +1292,8 @@ void print_sections(const bicg_ctx *c, double total_seconds)
 int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
                   const bicg_options *opt_in, bicg_result *res)
 {
+    std::vector<double> ph_x, ph_r;      // a rank without rows: the caller's vectors are empty (bicg_ctx::phantom)
+    if (c->phantom && nsig > 0) { ph_x.assign((size_t)nsig, 0.0); ph_r.assign(1, 0.0); x_set_host = ph_x.data(); r_host = ph_r.data(); }
     bicg_options o;
     if (opt_in) o = *opt_in; else { bicg_default_options(&o); o.tol = 1.0e-12; }   // EPS of src/shifted_switching_solver.c:5
     if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
@@ -1415,6 +1441,8 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
 int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
                 const bicg_options *opt_in, bicg_result *res)
 {
+    std::vector<double> ph_x, ph_r;      // a rank without rows: the caller's vectors are empty (bicg_ctx::phantom)
+    if (c->phantom && nsig > 0) { ph_x.assign((size_t)nsig, 0.0); ph_r.assign(1, 0.0); x_set_host = ph_x.data(); r_host = ph_r.data(); }
     if (mode == SH_FLAG || mode == SH_SWITCH) return run_switching(c, mode, x_set_host, r_host, sigma, nsig, seed, opt_in, res);
     if (mode < SH_LOP || mode > SH_XI) die("bicg_solve_shifted", "unknown variant");
     if (mode == SH_XI) seed = 0;          // shifted_bicgstab: the seed system is A itself, shift index 0
@@ -1495,7 +1523,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     // latency-bound ranks: the pipelined shifted iteration as ONE persistent launch per chunk (bicg_persist.hip, k_shpipe_persist);
     // section timing needs the launch boundaries and keeps the multi-launch form
     const int persist_shifted_env = getenv("BICG_PERSIST_SHIFTED") ? atoi(getenv("BICG_PERSIST_SHIFTED")) : 1;
-    bool persist = mode == SH_PIPE && c->persist_on && c->persist.rpt == 1u && nsig <= kPersistMaxShifts && persist_shifted_env != 0 &&
+    bool persist = (mode == SH_PIPE || mode == SH_LOP) && c->persist_on && c->persist.rpt == 1u && nsig <= kPersistMaxShifts && persist_shifted_env != 0 &&
                    !(o.time_kernels & 3) && !c->time_sections;
     c->last_shifted_persist = false;
     while (!c->hS->done && it < o.max_iter) {
@@ -1503,7 +1531,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
         const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, o.max_iter - it);
         sec_mark(c, SEC_VEC);
         if (persist) {
-            persist = persist_chunk_shifted(c, chunk, it, nsig, seed, sigma[seed]);
+            persist = persist_chunk_shifted(c, mode, chunk, it, nsig, seed, sigma[seed]);
             if (persist) c->last_shifted_persist = true;
         }
         for (int j = 0; j < chunk && !persist; ++j) {
@@ -1536,7 +1564,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
         it += chunk;
         sec_mark(c, SEC_STOP);
         fetch_scal(c);
-        if (persist) persist_account(c);
+        if (persist && mode == SH_PIPE) persist_account(c);
     }
     c->cur_has_shift = false; c->cur_shift = 0.0;
     const double t1 = now_sec();
@@ -1703,7 +1731,8 @@ bool p2p_guard(bicg_ctx *c, const double *x, const double *r, std::vector<double
 {
     if (!c->p2p || !c->comm->p2p_auto) return false;
     c->soft_fail = true;
-    x0.assign(x, x + c->n_loc); b.assign(r, r + c->n_loc);
+    const size_t nuser = c->phantom ? 0 : c->n_loc;      // a rank without rows: the caller's vectors are empty
+    x0.assign(x, x + nuser); b.assign(r, r + nuser);
     return true;
 }
 bool p2p_fell_back(bicg_ctx *c)
@@ -1914,8 +1943,10 @@ bool persist_chunk(bicg_ctx *c, int niter)
 // niter iterations of shifted_pipe_lopbicgstab (reference src/shifted_solver.c:794-866) in one launch: the seed system's
 // pipelined recurrence with products of A + sigma_seed I, every other shift's p_j / x_j streamed through in phase 2. Sequence
 // numbers as for the pipelined kernel (dense, reported back: persist_account).
-bool persist_chunk_shifted(bicg_ctx *c, int niter, int it0, int nsig, int seed, double shift)
+bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, int seed, double shift)
 {
+    const bool pipe = mode == SH_PIPE;          // else shifted_lopbicgstab: three groups and two products per iteration, numbered
+                                                // like the plain kernel's (fixed counts, advanced here)
     if (c->grp.active) die("internal", "persistent chunk with an open dot group");
     const size_t st = c->stride;
     PersistArgs a = c->persist;
@@ -1936,13 +1967,15 @@ bool persist_chunk_shifted(bicg_ctx *c, int niter, int it0, int nsig, int seed, 
     a.xcd_map = xcd_map;
     static const int first_sleep = getenv("BICG_PERSIST_SLEEP") ? atoi(getenv("BICG_PERSIST_SLEEP")) : 1;
     a.first_sleep = (unsigned)first_sleep;
+    if (!pipe) c->persist_seq += 3u * (unsigned)niter;
     if (a.multi) {
         a.halo_seq0 = c->halo_seq;
         a.p2p = c->p2p->red_desc(c->p2p->red_seq);
+        if (!pipe) { c->halo_seq += 2u * (unsigned)niter; c->p2p->red_seq += 3u * (unsigned)niter; }
         a.ring = c->halo_ring;
         c->halo_unsynced = 0;
     }
-    const hipError_t err = launch_shpipe_persist(a, c->sc);
+    const hipError_t err = pipe ? launch_shpipe_persist(a, c->sc) : launch_shlop_persist(a, c->sc);
     if (err != hipSuccess) {
         if (c->nranks > 1) die("persistent kernel", "launch failed on a multi-rank run (BICG_PERSIST=0 selects the multi-launch iteration)");
         fprintf(stderr, "bicgstab_hip: falling back to the multi-launch iteration\n");
@@ -2040,6 +2073,16 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     bicg_ctx *c = new bicg_ctx;
     c->comm = comm; c->device = comm->device; c->nranks = comm->nranks; c->rank = comm->rank;
     g_live.push_back(c);
+    // a rank without rows: one phantom row (see bicg_ctx::phantom)
+    static double ph_val[1] = {1.0};
+    static unsigned ph_col[1] = {0u}, ph_ptr1[2] = {0u, 1u}, ph_ptr0[2] = {0u, 0u};
+    CSR_Matrix ph_d, ph_o;
+    if (diag->rows == 0 && info->rows > 0 && comm->nranks > 1) {
+        c->phantom = true;
+        ph_d.val = ph_val; ph_d.col = ph_col; ph_d.ptr = ph_ptr1; ph_d.nz = 1; ph_d.rows = 1; ph_d.cols = 1;
+        ph_o.val = ph_val; ph_o.col = ph_col; ph_o.ptr = ph_ptr0; ph_o.nz = 0; ph_o.rows = 1; ph_o.cols = info->cols;
+        diag = &ph_d; offd = &ph_o;
+    }
     c->n_loc = diag->rows; c->n_glob = info->rows;
     c->nnz_d = diag->rows ? diag->ptr[diag->rows] : 0u;
     const int P = c->nranks;
@@ -2053,9 +2096,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
     {   // Every rank learns every rank's (non-zeros, rows). The enqueue mode changes the ORDER of RCCL calls,
         // so all ranks must take the same decision: it is based on the average number of local non-zeros.
-        // A rank WITHOUT rows (more ranks than rows, or an empty block of a non-zero balanced partition) is not
-        // supported -- the reference's loops simply run over zero rows there (src/matrix.c:295-298); here such
-        // a rank would still have to take part in every exchange. All ranks see it and give up together.
+        // (a rank without rows carries a phantom row and counts as a rank like any other; only an EMPTY MATRIX is refused)
         uint64_t total = c->nnz_d;
         bool empty = c->n_loc == 0;
         if (P > 1) {
@@ -2068,7 +2109,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             for (int p = 0; p < P; ++p) { total += all[2 * p]; empty = empty || all[2 * p + 1] == 0; }
         }
         if (empty) {
-            if (c->rank == 0) fprintf(stderr, "ERROR: bicg_create: a rank without rows is not supported (%u rows over %d ranks)\n", info->rows, P);
+            if (c->rank == 0) fprintf(stderr, "ERROR: bicg_create: empty matrix (%u rows over %d ranks)\n", info->rows, P);
             bicg_destroy(c);          // nothing is allocated yet; takes the context out of the registry of live ones
             return nullptr;
         }
@@ -2349,13 +2390,15 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
 
     // Uniform slices (SellDev::ubase): all 64 rows present, equally long, entry k at the same distance from its row in
     // every row. Lists are shared between slices (a banded matrix has ONE for its whole interior) and padded with zeros.
-    std::vector<uint32_t> ubase;
+    std::vector<uint32_t> ubase, vbase;
     std::vector<int> uoff;
-    uint64_t uniform_entries = 0;
+    std::vector<double> uval;
+    uint64_t uniform_entries = 0, constant_entries = 0;
+    const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
     if (!jag && sell_entries > 0 && !(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
         ubase.assign(nslices, 0xFFFFFFFFu);
-        std::map<std::vector<int>, uint32_t> lists;
-        std::vector<int> cur;
+        std::map<std::vector<int>, uint32_t> lists, vlists;
+        std::vector<int> cur, vkey;
         for (uint32_t sl = 0; sl < nslices; ++sl) {
             if (!group_is_sell[sl / (kGroupRows / kSliceRows)] || (sl + 1) * kSliceRows > nrows || slice_len[sl] == 0) continue;
             const uint32_t r0 = sl * kSliceRows, len = slice_len[sl];
@@ -2377,10 +2420,30 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             }
             ubase[sl] = it->second;
             uniform_entries += (uint64_t)len * kSliceRows;
+            // constant slice: entry k holds the same value in all 64 rows (SellDev::vbase)
+            if (!want_constant) continue;
+            const double *v0 = diag->val + diag->ptr[r0];
+            bool con = true;
+            for (uint32_t l = 1; l < kSliceRows && con; ++l)
+                con = memcmp(diag->val + diag->ptr[r0 + l], v0, sizeof(double) * len) == 0;
+            if (!con) continue;
+            vkey.assign(cur.begin(), cur.end());                                  // distances, then the value bits
+            for (uint32_t k = 0; k < len; ++k) { long long b; memcpy(&b, v0 + k, 8); vkey.push_back((int)(b & 0xFFFFFFFF)); vkey.push_back((int)(b >> 32)); }
+            auto vt = vlists.find(vkey);
+            if (vt == vlists.end()) {
+                if (uval.size() + len + 32 > (1u << 22)) continue;
+                vt = vlists.emplace(vkey, (uint32_t)uval.size()).first;
+                uval.insert(uval.end(), v0, v0 + len);
+                uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
+            }
+            if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
+            vbase[sl] = vt->second;
+            constant_entries += (uint64_t)len * kSliceRows;
         }
         if (uniform_entries == 0) { ubase.clear(); uoff.clear(); }
     }
     c->uniform_entries = uniform_entries;
+    c->constant_entries = constant_entries;
 
     // CSR row blocks over the maximal runs of non-SELL groups
     std::vector<uint32_t> rb(nrows + 1);
@@ -2433,8 +2496,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // (jagged slices: lanes whose row has ended read up to one entry past the last -- kPadEntries of slack)
     c->s_val = dev_upload_padded(sval.data(), (size_t)sell_entries, kPadEntries);
     c->s_col = dev_upload_padded(scol.data(), c16 ? 0 : (size_t)sell_entries, kPadEntries);
-    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) + 8ull * nslices + 4ull * (nrows + 1) +
+    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 8ull * nslices + 4ull * (nrows + 1) +
                       (uint64_t)(c->nnz_d - c->sell_nnz) * (csr16 ? 10 : 12) + (uint64_t)c->nnz_o * 12;
+    if (!vbase.empty()) {
+        c->s_vbase = dev_upload(vbase.data(), vbase.size());
+        c->s_uval = dev_upload(uval.data(), uval.size());
+    }
     if (!ubase.empty()) {
         c->s_ubase = dev_upload(ubase.data(), ubase.size());
         c->s_uoff = dev_upload(uoff.data(), uoff.size());
@@ -2603,14 +2670,19 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     launch_plan_fill(ptr_d, col_d, val_d, rows, c->s_base, c->s_base16, c->s_val, c16 ? nullptr : c->s_col, c16 ? c->s_col16 : nullptr, nullptr);
     // uniform slices (SellDev::ubase): found by a kernel, grouped by the hash of their distance lists here; one list per group
     // is fetched from the CSR (a stencil has a few dozen)
-    uint64_t uniform_entries = 0;
+    uint64_t uniform_entries = 0, constant_entries = 0;
     if (!(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
-        unsigned long long *uh_d = dev_alloc<unsigned long long>(nslices);
-        BICG_HIP(hipMemset(uh_d, 0, sizeof(unsigned long long) * nslices));
-        launch_plan_uniform(ptr_d, col_d, rows, uh_d, nullptr);
-        std::vector<unsigned long long> uh(nslices);
+        const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
+        unsigned long long *uh_d = dev_alloc<unsigned long long>(2 * (size_t)nslices), *vh_d = uh_d + nslices;
+        BICG_HIP(hipMemset(uh_d, 0, sizeof(unsigned long long) * 2 * (size_t)nslices));
+        launch_plan_uniform(ptr_d, col_d, val_d, rows, uh_d, want_constant ? vh_d : nullptr, nullptr);
+        std::vector<unsigned long long> uh(nslices), vh(nslices);
         BICG_HIP(hipMemcpy(uh.data(), uh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
+        BICG_HIP(hipMemcpy(vh.data(), vh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
         BICG_HIP(hipFree(uh_d));
+        std::vector<uint32_t> vbase;
+        std::vector<double> uval, vals;
+        std::map<unsigned long long, uint32_t> vlists;
         std::vector<uint32_t> ubase(nslices, 0xFFFFFFFFu);
         std::vector<int> uoff;
         std::map<unsigned long long, uint32_t> lists;
@@ -2631,13 +2703,34 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
             }
             ubase[sl] = it->second;
             uniform_entries += (uint64_t)slen[sl] * kSliceRows;
+            if (!vh[sl]) continue;                                                // constant slice (SellDev::vbase)
+            auto vt = vlists.find(vh[sl]);
+            if (vt == vlists.end()) {
+                if (vlists.size() >= 4096) continue;
+                const uint32_t r0 = sl * kSliceRows, len = slen[sl];
+                uint32_t p0 = 0;
+                BICG_HIP(hipMemcpy(&p0, ptr_d + r0, sizeof(uint32_t), hipMemcpyDeviceToHost));
+                vals.resize(len);
+                BICG_HIP(hipMemcpy(vals.data(), val_d + p0, sizeof(double) * len, hipMemcpyDeviceToHost));
+                vt = vlists.emplace(vh[sl], (uint32_t)uval.size()).first;
+                uval.insert(uval.end(), vals.begin(), vals.end());
+                uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
+            }
+            if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
+            vbase[sl] = vt->second;
+            constant_entries += (uint64_t)slen[sl] * kSliceRows;
         }
         if (uniform_entries) {
             c->s_ubase = dev_upload(ubase.data(), ubase.size());
             c->s_uoff = dev_upload(uoff.data(), uoff.size());
         }
+        if (constant_entries) {
+            c->s_vbase = dev_upload(vbase.data(), vbase.size());
+            c->s_uval = dev_upload(uval.data(), uval.size());
+        }
     }
     c->uniform_entries = uniform_entries;
+    c->constant_entries = constant_entries;
     c->d_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
     BICG_HIP(hipMemcpy(c->d_ptr, ptr_d, sizeof(uint32_t) * ((size_t)rows + 1), hipMemcpyDeviceToDevice));
     c->d_val = dev_alloc<double>(kPadEntries); c->d_col = dev_alloc<uint32_t>(kPadEntries);
@@ -2649,7 +2742,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->send_idx = dev_alloc<uint32_t>(1); c->sendbuf = dev_alloc<double>(1);
     c->ng_int = ngroups; c->ng_bnd = 0; c->n_int = c->n_bnd = c->nblk = 0;
     c->glist_int_identity = true; c->glist_all = true;
-    c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
+    c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
     c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
     BICG_HIP(hipFree(far_d));
     ctx_state(c, comm, ngroups);
@@ -2693,7 +2786,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -2719,6 +2812,7 @@ void bicg_destroy(bicg_ctx *c)
 int bicg_load(bicg_ctx *c, const double *x0, const double *b)
 {
     use_device(c);
+    x0 = host_in(c, x0); b = host_in(c, b);
     BICG_HIP(hipMemcpy(c->v.x, x0, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
     BICG_HIP(hipMemcpy(c->v.r, b, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
     return 0;
@@ -2728,6 +2822,7 @@ int bicg_fetch(bicg_ctx *c, double *x, double *r)
 {
     use_device(c);
     BICG_HIP(hipStreamSynchronize(c->sc));
+    x = host_out(c, x); r = host_out(c, r);
     if (x) BICG_HIP(hipMemcpy(x, c->v.x, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
     if (r) BICG_HIP(hipMemcpy(r, c->v.r, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
     return 0;
@@ -2775,6 +2870,7 @@ int bicg_spmv(bicg_ctx *c, const double *x, double *y)
 {
     use_device(c);
     reset_scal(c);
+    x = host_in(c, x); y = host_out(c, y);
     BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
     c->time_kernels = false;
     spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
@@ -2788,6 +2884,7 @@ double bicg_dot(bicg_ctx *c, const double *x, const double *y)
 {
     use_device(c);
     reset_scal(c);
+    if (c->phantom) { x = host_in(c, x); y = x; }
     BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemcpyAsync(c->v.s, y, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
     launch_dot(c->v.p, c->v.s, c->n_loc, c->S, c->red(0, PH_NONE, true, 1), c->sc);
@@ -2804,6 +2901,7 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
 {
     use_device(c);
     reset_scal(c);
+    x_loc_set = host_in(c, x_loc_set, (size_t)nsig); if (c->phantom) b_loc = x_loc_set;
     const size_t n = c->n_loc;
     BICG_HIP(hipMemcpyAsync(c->v.b, b_loc, sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemsetAsync(c->v.t, 0, sizeof(double) * c->stride, c->sc));
@@ -2861,6 +2959,8 @@ int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nve
     if (!c->spmm_ok) return 1;
     reset_scal(c);
     spmm_buffers(c);
+    std::vector<double> ph_y;
+    if (c->phantom) { x_loc_set = host_in(c, x_loc_set, (size_t)nvec); ph_y.assign((size_t)nvec, 0.0); y_loc_set = ph_y.data(); }
     const size_t n = c->n_loc;
     hipEvent_t e0, e1;
     BICG_HIP(hipEventCreate(&e0)); BICG_HIP(hipEventCreate(&e1));
@@ -2942,6 +3042,7 @@ void bicg_dropin_release(void)
 }
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matrix_bytes; }
 unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
+unsigned long long bicg_constant_entries(bicg_ctx *c) { return c->constant_entries; }
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return c->matrix_bytes; }
 int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
 int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }
@@ -2968,6 +3069,7 @@ unsigned int bicg_ctx_flags(bicg_ctx *c)
     if (c->fuse_pipe && c->fuse_plan_ok && !hosted(c)) f |= BICG_FLAG_FUSE_PIPE;
     if (c->pipe_probed && (c->probe_ms[0] > 0.0 || c->probe_ms[1] > 0.0)) f |= BICG_FLAG_PIPE_PROBED;
     if (c->uniform_entries) f |= BICG_FLAG_UNIFORM;
+    if (c->constant_entries) f |= BICG_FLAG_CONSTANT;
     return f;
 }
 

@@ -219,6 +219,56 @@ def gpu_worker(rank, world, port, kind, outdir):
         raise
 
 
+def empty_rank_worker(rank, world, port, kind, outdir):
+    """More ranks than rows (reference src/matrix.c:295-298: the trailing ranks get ZERO rows and its loops run empty): a
+    6-row matrix over 8 ranks, ranks 6 and 7 own nothing. Every rank creates its context (the empty ones hold a phantom row,
+    bicg_ctx::phantom), takes part in every exchange, and the four solvers + a shifted solve give the oracle's iterates at
+    P = 8; the empty ranks pass and get back empty vectors."""
+    try:
+        import numpy as np
+        dist = _init(rank, world, port)
+        import oracle_lib as O
+        from mpi_bicgstab_amd import hipsolver as H, synth
+        from mpi_bicgstab_amd import dist_transport as T
+
+        T.init_host_transport(0)
+        if kind == "p2p":
+            assert H.lib().bicg_comm_enable_p2p() == 0, "peer-to-peer transport did not come up"
+        A = synth.from_offsets(6, (0, 1, -1, 2), diag_base=5.0, seed=1)
+        diag, offd, counts, displs = synth.split_blocks(A, world, rank)
+        lo, nl = int(displs[rank]), int(counts[rank])
+        assert counts[-1] == 0 and counts[-2] == 0 and (nl == 0) == (rank >= 6)
+        ctx = H.Context(H.HostBlocks(diag, offd, A.rows, counts, displs))
+        row, col, val = A.to_coo()
+        x = np.random.default_rng(3).standard_normal(A.rows)
+        y = ctx.spmv(x[lo:lo + nl])
+        assert y.shape == (nl,) and np.array_equal(y, O.spmv(A.rows, row, col, val, x, nranks=world)[lo:lo + nl])
+        d = ctx.dot(x[lo:lo + nl], x[lo:lo + nl])
+        assert abs(d - float(np.dot(x, x))) <= 1e-13 * float(np.dot(x, x))
+        b_full = O.spmv(A.rows, row, col, val, np.ones(A.rows), nranks=world)
+        b = ctx.spmv(np.ones(nl))
+        for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
+            orc = O.solve(method, A.rows, row, col, val, b_full, nranks=world, tol=1e-12, krr=10, nrr=3)
+            got = ctx.solve(method, b, tol=1e-12, krr=10, nrr=3, check_every=2)
+            assert abs(got["k"] - orc["k"]) <= 1, (method, got["k"], orc["k"])
+            assert got["x"].shape == (nl,) and (nl == 0 or np.abs(got["x"] - 1.0).max() <= 1e-9), method
+        sigma, seed = 0.01 * (np.arange(3) + 1.0), 1
+        bs_full = b_full + sigma[seed] * np.ones(A.rows)
+        for which in ("shifted_lopbicgstab", "shifted_pipe_lopbicgstab"):
+            orc = O.solve_shifted(A.rows, row, col, val, bs_full, sigma, seed, nranks=world, which=which)
+            got = ctx.solve_shifted(bs_full[lo:lo + nl], sigma, seed, check_every=2, which=which)
+            assert abs(got["k"] - orc["k"]) <= 1, (which, got["k"], orc["k"])
+            assert got["x"].shape == (3, nl) and (nl == 0 or np.abs(got["x"] - orc["x"][:, lo:lo + nl]).max() <= 1e-9), which
+        ctx.close()
+        dist.barrier()
+        H.lib().bicg_comm_finalize()
+        dist.destroy_process_group()
+        open(os.path.join(outdir, f"ok{rank}"), "w").write("ok")
+    except Exception:
+        open(os.path.join(outdir, f"fail{rank}"), "w").write(traceback.format_exc())
+        raise
+
+
 def fullsize_worker(rank, world, port, kind, outdir):
     """GPU box: `world` ranks (4 or 8) share cuda:0 and hold the reference's row partition
     (src/matrix.c:295-308) of the FULL-SIZE Transport-shaped matrix -- 200 k-row slabs with their

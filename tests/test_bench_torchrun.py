@@ -123,7 +123,8 @@ def test_bench_single_gpu_line_has_every_leg():
     # fractions are claimed on the bytes the stored layout moves (uniform slices keep no column index: fewer than CSR's 12 per
     # non-zero); the CSR figure of SURVEY 8d stays beside it as `achieved` / `algorithmic_bytes`
     assert rf["format_bytes_per_launch"] <= rf["algorithmic_bytes_per_launch"] and 0.4 < rf["frac_of_format_bytes"] <= rf["frac"] < 1.0, rf
-    assert all("format_bytes" in r and r["format_bytes"] <= r.get("algorithmic_bytes", r.get("algorithmic_bytes_rank0")) for _, r in roofs if "format_bytes" in r or "ms_per_iteration" in r)
+    fmt = [r for _, r in roofs if "format_bytes" in r]
+    assert len(fmt) >= 20 and all(r["format_bytes"] <= r.get("algorithmic_bytes", r.get("algorithmic_bytes_rank0")) for r in fmt)
     assert d["comm"]["world"] == 1 and d["comm"]["rccl_leg"] is None
     assert rf["traffic"] is not None, "rocprofv3 counter passes did not deliver"
     assert 0.85 * rf["format_bytes_per_launch"] < rf["traffic"] < 1.5 * rf["format_bytes_per_launch"], rf

@@ -185,6 +185,10 @@ def test_reference_shifted_driver_linked_against_hip_library(tmp_path, np_):
     k, sw, out = run(dropin)
     assert 0 < k_ref < 1000, out_ref[-2000:]                      # the reference converged all 512 systems inside MAX_ITER
     assert abs(k - k_ref) <= 3, (k, k_ref, out[-2000:])
-    assert len(sw) == len(sw_ref), (sw, sw_ref, out[-2500:], out_ref[-1500:])
-    for (ka, sa, ra), (kb, sb, rb) in zip(sw, sw_ref):
+    # the same seed switches -- except one that falls into the last three iterations of either run: whether the seed crosses
+    # the tolerance an iteration before or together with the last of the other systems depends on the association of the dot
+    # sums (the reference's own P = 1 and P = 2 runs differ there)
+    late = lambda lst, kk: [t for t in lst if int(t[0]) < kk - 3]
+    assert abs(len(sw) - len(sw_ref)) <= 1 and len(late(sw, k)) == len(late(sw_ref, k_ref)), (sw, sw_ref, out[-2500:], out_ref[-1500:])
+    for (ka, sa, ra), (kb, sb, rb) in zip(late(sw, k), late(sw_ref, k_ref)):
         assert sa == sb and abs(int(ka) - int(kb)) <= 3 and abs(int(ra) - int(rb)) <= 32, (sw, sw_ref)

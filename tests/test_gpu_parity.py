@@ -409,6 +409,22 @@ def test_uniform_slices_give_the_same_bits():
         finally:
             os.environ.pop("BICG_SELL_UNIFORM")
         assert ctx.flags()["uniform"] and not ref.flags()["uniform"], name
+        # constant slices (round 4): a stencil with one weight per direction repeats its VALUES in every row of an interior
+        # slice as well -- those come from a shared list too (no matrix stream at all); random values never qualify
+        if name.startswith("stencil"):
+            assert ctx.flags()["constant"] and 0 < ctx.constant_entries() <= ctx.uniform_entries(), name
+            os.environ["BICG_SELL_CONSTANT"] = "0"
+            try:
+                noc = H.Context(H.single_rank_blocks(A))
+            finally:
+                os.environ.pop("BICG_SELL_CONSTANT")
+            assert noc.flags()["uniform"] and not noc.flags()["constant"] and noc.constant_entries() == 0
+            assert ctx.spmv_matrix_bytes() <= noc.spmv_matrix_bytes() - 8 * ctx.constant_entries() + 64, name
+            xx = np.random.default_rng(12).standard_normal(A.rows)
+            assert np.array_equal(ctx.spmv(xx), noc.spmv(xx)), name
+            noc.close()
+        else:
+            assert not ctx.flags()["constant"] and ctx.constant_entries() == 0, name
         ue = ctx.uniform_entries()
         assert share * A.nnz < ue <= A.nnz + 64 * 32, (name, ue, A.nnz)
         assert ctx.spmv_matrix_bytes() < ref.spmv_matrix_bytes() - 1.5 * ue, name

@@ -188,12 +188,12 @@ def test_hot_kernels_stay_lean():
     for k in spmv:
         r = kernels[k]
         # ticket mode is pinned to 8 waves per SIMD; since round 4 (slots per row group, XCD-contiguous and alternating order,
-        # uniform slices: more kernel arguments live across the launch) the compiler parks up to 5 registers per lane in scratch.
+        # uniform and constant slices: more kernel arguments live across the launch) the compiler parks up to 9 registers per lane in scratch.
         # Checked in the disassembly: one store before the group loop, one reload per 256-row group, nothing inside the
         # loop over a row's entries (profiles/NOTES.md, round 4)
         ticket = k.endswith("ELi0EEEvNS_8SpmvArgsE")
-        assert r["VGPRs"] <= (64 if ticket else 72) and r["Occupancy [waves/SIMD]"] >= (8 if ticket else 7), (k, r)
-        assert r["ScratchSize [bytes/lane]"] <= (20 if ticket else 0), (k, r)
+        assert r["VGPRs"] <= (64 if ticket else 80) and r["Occupancy [waves/SIMD]"] >= (8 if ticket else 6), (k, r)
+        assert r["ScratchSize [bytes/lane]"] <= (40 if ticket else 0), (k, r)
     vec = [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELi2EEEv", k)]
     assert len(vec) >= 11, sorted(kernels)[:5]
     for k in vec:
@@ -211,6 +211,8 @@ def test_hot_kernels_stay_lean():
     # wavefronts per CU = 2 per SIMD, 256 registers)
     persist = [k for k in kernels if re.search(r"k_(pipe|plain|ca)_persist", k)]
     assert len(persist) == 16, persist
+    shifted = [k for k in kernels if re.search(r"k_sh(pipe|lop)_persist", k)]      # the shifted solvers' forms: same budget
+    assert len(shifted) == 8 and all(kernels[k]["VGPRs"] <= 128 and kernels[k]["ScratchSize [bytes/lane]"] <= 24 for k in shifted), shifted
     for k in persist:
         if "k_pipe_persistILi8E" in k:
             assert kernels[k]["Occupancy [waves/SIMD]"] >= 2 and kernels[k]["ScratchSize [bytes/lane]"] <= 384, (k, kernels[k])

@@ -53,6 +53,13 @@ def test_multirank_solver_peer_to_peer(kind, world):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["host", "p2p"])
+def test_ranks_without_rows_take_part(kind):
+    """6 rows over 8 ranks (reference src/matrix.c:295-298 gives ranks 6 and 7 nothing and runs): bicg_create no longer refuses"""
+    _run(W.empty_rank_worker, 8, kind)
+
+
+@pytest.mark.gpu
 def test_rccl_single_rank_roundtrip():
     from mpi_bicgstab_amd import hipsolver as H
     assert H.lib().bicg_comm_selftest_rccl(0) == 0
