@@ -250,7 +250,10 @@ struct SellDev {
     const uint32_t *vbase;
     const double   *uval;
 };
-enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4 };
+// (PAD32C / PAD16C: padded slices of a block that has CONSTANT slices -- SellDev::vbase. Instantiations of their own: with the
+// value list as a run-time branch in every kernel, the dot-carrying products of blocks WITHOUT such slices paid 11 us each for
+// the registers it took, 45 -> 56 us on Transport)
+enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4, LAY_PAD32C = 6, LAY_PAD16C = 7 };
 constexpr uint32_t kWinMaxSlots = 4096;      // 32 KB of LDS per workgroup: 4 workgroups per CU
 
 // Peer-to-peer halo exchange folded into the sliced-ELL SpMV launch: the first `npush` workgroups

@@ -26,7 +26,7 @@
 
 // This file is compiled several times (Makefile: BICG_PART = 0..5, in parallel): the sliced-ELL launchers instantiate
 // several hundred kernels and would otherwise serialise the build. Part 0 holds everything that is not a template
-// (kernels and launch wrappers), parts 1-5 one group of sliced-ELL instantiations each; without BICG_PART the
+// (kernels and launch wrappers), parts 1-7 one group of sliced-ELL instantiations each; without BICG_PART the
 // file is one translation unit.
 #ifndef BICG_PART
 #define BICG_PART -1
@@ -405,6 +405,9 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
                 if ((spin & 63u) == 63u && wall_clock64() - t0 > patience) { lost = true; break; }
             }
         }
+        // a producer that never delivered: the error is raised by the very thread that gave up (any thread of any shard
+        // workgroup, not only thread 0 of the last one), and its shard total is poisoned -- a NaN cannot pass for a sum
+        if (lost) { S->comm_error = 1; S->done = 1; tot[0] = __builtin_nan(""); }
         block_sum<ND>(tot, sm);
         if (threadIdx.x < ND) ll_store_agent(red.tail_shard + ((size_t)sh * kRedSlots + threadIdx.x) * 2, tot[threadIdx.x], seq);
         if (sh != 0) return;
@@ -426,11 +429,11 @@ __device__ __forceinline__ void reduce_publish(double (&acc)[ND], Scal *S, const
                 if ((spin & 63u) == 63u && wall_clock64() - t0 > patience) { lost = true; break; }
             }
         }
+        if (lost) { S->comm_error = 1; S->done = 1; tot[0] = __builtin_nan(""); }      // any thread's wait, not only thread 0's
         block_sum<ND>(tot, sm);
         if (threadIdx.x == 0) {
 #pragma unroll
             for (int d = 0; d < ND; ++d) S->red[red.red_off + d] = tot[d];
-            if (lost) { S->comm_error = 1; S->done = 1; }
         }
         if (red.apply_now) {
             __syncthreads();
@@ -1092,7 +1095,7 @@ template <bool OFFD, bool NT, int LAY, bool LL, int U = 8>      // U entries per
 __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed,
                                            const double *win = nullptr)
 {
-    constexpr bool WIN = LAY == LAY_JAGW, C16 = (LAY & 1) != 0 || WIN, JAG = LAY >= LAY_JAG32;
+    constexpr bool WIN = LAY == LAY_JAGW, C16 = (LAY & 1) != 0 || WIN, JAG = LAY >= LAY_JAG32 && LAY <= LAY_JAGW, CONSTV = LAY >= LAY_PAD32C;
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
     const double *__restrict__ x = a.x;
     const unsigned g = a.glist ? a.glist[gi] : gi;
@@ -1166,7 +1169,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
         const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
         if (ub != 0xFFFFFFFFu) {
             uo = a.sell.uoff + ub;
-            if (a.sell.vbase) {
+            if (CONSTV) {
                 const uint32_t vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.vbase[slice]);
                 if (vb != 0xFFFFFFFFu) uv = a.sell.uval + vb;
             }
@@ -1199,7 +1202,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
             const bool ok = k0 + e < len;                     // wave-uniform
             const uint32_t j = base + (k0 + e) * kSliceRows + lane;
             if (!C16 && !uo) c[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.col + j) : a.sell.col[j]) : 0u;
-            if (uv) v[e] = uv[k0 + e];                        // (wave-uniform branch, scalar load)
+            if (CONSTV && uv) v[e] = uv[k0 + e];              // (wave-uniform branch, scalar load)
             else v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
         }
         double xv[U];
@@ -1264,17 +1267,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
 #pragma unroll
     for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
 
-    // A workgroup handles groups blockIdx.x, blockIdx.x + gridDim.x, ...: with one group per
-    // workgroup the fused dot epilogue (one partial + one arrival ticket per workgroup) costs
-    // 10 us per SpMV on Transport; a few groups per workgroup amortise it. Round-robin placement
-    // over the XCDs is kept: an XCD-contiguous mapping cuts the fabric reads from 386 to 309 MB
-    // (x is then fetched by one L2 instead of eight) but is 3-5 % SLOWER in wall time.
-    unsigned slot = bid;                  // the partial of a row group goes to the group's slot, whichever workgroup computed it
-    for (unsigned gi0 = bid; gi0 < a.nlist; gi0 += nblocks) {
-        unsigned gi = gi0;
-        if (a.xcd_map && !LL && nblocks == a.nlist && gi0 < (a.nlist / 8u) * 8u) gi = (gi0 % 8u) * (a.nlist / 8u) + gi0 / 8u;
-        if (a.reverse && !LL) gi = a.nlist - 1u - gi;
-        if (nblocks == a.nlist) slot = gi;
+    // Which groups: workgroup bid stands for VIRTUAL workgroup vb of the canonical order -- XCD-contiguous (workgroup b runs on
+    // XCD b % 8: XCD x gets the x-th eighth of the virtual workgroups, so one L2 fetches what neighbouring groups share) and,
+    // every other product, reversed -- and takes the CONTIGUOUS groups vb * each ... of the list. Its partial sums go to slot vb
+    // whichever physical workgroup computed them: the association of a dot sum does not depend on direction or placement.
+    // (Launches with the halo exchange inside keep the strided assignment: their leading workgroups are the senders.)
+    unsigned vb = bid;
+    if (a.xcd_map && !LL && bid < (nblocks / 8u) * 8u) vb = (bid % 8u) * (nblocks / 8u) + bid / 8u;
+    if (a.reverse && !LL) vb = nblocks - 1u - vb;
+    const unsigned each = LL ? 1u : (a.nlist + nblocks - 1u) / nblocks;
+    const unsigned slot = LL ? bid : vb;
+    const unsigned gfirst = LL ? bid : vb * each, gend = LL ? a.nlist : (gfirst + each < a.nlist ? gfirst + each : a.nlist);
+    for (unsigned gq = gfirst; gq < gend; gq += LL ? nblocks : 1u) {
+        const unsigned gi = (a.reverse && !LL) ? gfirst + (gend - 1u - gq) : gq;      // a reversed product walks its groups backwards too
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
@@ -1548,6 +1553,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_fw(SpmvArgs a)
 static inline int sell_layout(const SellDev &d)
 {
     if (d.win_slots) return LAY_JAGW;
+    if (!d.jag && d.vbase) return d.col16 ? LAY_PAD16C : LAY_PAD32C;
     return (d.jag ? LAY_JAG32 : LAY_PAD32) + (d.col16 ? 1 : 0);
 }
 
@@ -1629,6 +1635,10 @@ bool launch_spmv_sell_epi_pad16(SELL_PART_ARGS);
 bool launch_spmv_sell_epi_jag32(SELL_PART_ARGS);
 bool launch_spmv_sell_epi_jag16(SELL_PART_ARGS);
 bool launch_spmv_sell_jagw(SELL_PART_ARGS);
+bool launch_spmv_sell_pad32c(SELL_PART_ARGS);
+bool launch_spmv_sell_pad16c(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_pad32c(SELL_PART_ARGS);
+bool launch_spmv_sell_epi_pad16c(SELL_PART_ARGS);
 bool launch_spmv_sell_epi_jagw(SELL_PART_ARGS);
 #if PART_IS(1)
 bool launch_spmv_sell_pad32(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
@@ -1666,6 +1676,14 @@ bool launch_spmv_sell_epi_jag16(SELL_PART_ARGS) { return sell_epi_launch_layout<
 bool launch_spmv_sell_jagw(SELL_PART_ARGS) { return sell_launch_layout<LAY_JAGW>(a, n, with_offd, st, e0, e1, fused_halo); }
 bool launch_spmv_sell_epi_jagw(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_JAGW>(a, n, with_offd, st, e0, e1, fused_halo); }
 #endif
+#if PART_IS(6)
+bool launch_spmv_sell_pad32c(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD32C>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_pad32c(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD32C>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
+#if PART_IS(7)
+bool launch_spmv_sell_pad16c(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD16C>(a, n, with_offd, st, e0, e1, fused_halo); }
+bool launch_spmv_sell_epi_pad16c(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD16C>(a, n, with_offd, st, e0, e1, fused_halo); }
+#endif
 #undef SELL_PART_ARGS
 
 #if PART_IS(0)
@@ -1676,6 +1694,8 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     case LAY_JAG32: return launch_spmv_sell_jag32(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG16: return launch_spmv_sell_jag16(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAGW:  return launch_spmv_sell_jagw(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_PAD32C: return launch_spmv_sell_pad32c(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_PAD16C: return launch_spmv_sell_pad16c(a, ndot, with_offd, st, e0, e1, fused_halo);
     default:        return launch_spmv_sell_pad32(a, ndot, with_offd, st, e0, e1, fused_halo);
     }
 }
@@ -1687,6 +1707,8 @@ bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_
     case LAY_JAG32: return launch_spmv_sell_epi_jag32(a, epi, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG16: return launch_spmv_sell_epi_jag16(a, epi, with_offd, st, e0, e1, fused_halo);
     case LAY_JAGW:  return launch_spmv_sell_epi_jagw(a, epi, with_offd, st, e0, e1, fused_halo);
+    case LAY_PAD32C: return launch_spmv_sell_epi_pad32c(a, epi, with_offd, st, e0, e1, fused_halo);
+    case LAY_PAD16C: return launch_spmv_sell_epi_pad16c(a, epi, with_offd, st, e0, e1, fused_halo);
     default:        return launch_spmv_sell_epi_pad32(a, epi, with_offd, st, e0, e1, fused_halo);
     }
 }
@@ -1898,7 +1920,7 @@ __global__ void __launch_bounds__(kBlock) k_spmm_sell(SpmmArgs a)
 // stay in registers across the passes, so the matrix is read once per launch whatever NV.
 // ------------------------------------------------------------------------------------------
 template <int MODE, bool OFFD, int NV>
-__global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_win(SpmmArgs a)      // (the LDS window allows two workgroups per CU)
 {
     constexpr bool WIN = MODE == 1;
     constexpr int U = 8;
@@ -1983,7 +2005,7 @@ __global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
         // ---- stage the group's window of vectors v0 .. v0 + nv - 1: JB slots per thread and round, all their NV values
         // requested before the first is stored (one dependent round trip per run and vector: 743 us per launch on Transport;
         // one slot per round: 430 us)
-        constexpr int JB = 32 / NV;
+        constexpr int JB = 40 / NV;                           // Transport's 1 240 slots in ONE round: two waves per SIMD hide no second trip
         for (unsigned s0 = 0; s0 < W; s0 += JB * kBlock) {
             int c[JB];                                        // column of the slot; -1: unused slot / clipped by the matrix boundary
 #pragma unroll
@@ -2027,17 +2049,31 @@ __global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
         double acc[NV];
 #pragma unroll
         for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+        // Straight-line code per half of the head: with a (wave-uniform) branch around every entry the compiler waited for each
+        // LDS read before issuing the next -- 120 exposed LDS latencies per pass and lane, 412 us per launch on Transport. Entries
+        // past the slice's length read slot 0 and are never added.
+        // (the slots are made opaque once per pass: otherwise the 16 x NV LDS addresses slot + v W are hoisted out of the pass
+        // loop as invariants and held in 128 registers)
 #pragma unroll
-        for (int e = 0; e < K; ++e) {
-            if ((uint32_t)e < len) {                          // wave-uniform
+        for (int e = 0; e < K; ++e) asm volatile("" : "+v"(hs[e]));
+        auto half = [&](int e0) {
+#pragma unroll
+            for (int e = e0; e < e0 + K / 2; ++e) {
+                double xr[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) xr[v] = win[(unsigned)v * W + hs[e]];
                 const bool on = (hon >> e) & 1u;
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const double x = win[(unsigned)v * W + hs[e]];
-                    if (on) acc[v] += hv[e] * x;              // stored order; padding never added
+                    const double t = acc[v] + hv[e] * xr[v];  // stored order; padding never added
+                    acc[v] = on ? t : acc[v];
                 }
+                // (two entries = 16 reads in flight are enough; left alone the scheduler hoists all 64 of a half: 256 registers)
+                if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
-        }
+        };
+        half(0);
+        if (len > (uint32_t)(K / 2)) half(K / 2);
         pos = pos_tail;
         for (uint32_t k0 = K; k0 < len; k0 += U) {
             double val[U];
@@ -2068,10 +2104,13 @@ __global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
             }
 #pragma unroll
             for (int e = 0; e < U; ++e) {
+                double xr[NV];
+#pragma unroll
+                for (int v = 0; v < NV; ++v) xr[v] = win[(unsigned)v * W + sl[e]];
 #pragma unroll
                 for (int v = 0; v < NV; ++v) {
-                    const double x = win[(unsigned)v * W + sl[e]];
-                    if (on[e]) acc[v] += val[e] * x;          // stored order
+                    const double t = acc[v] + val[e] * xr[v]; // stored order
+                    acc[v] = on[e] ? t : acc[v];
                 }
             }
         }
@@ -2087,7 +2126,9 @@ __global__ void __launch_bounds__(kBlock) k_spmm_win(SpmmArgs a)
                     for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * xv[a.offd.col[k]];
                     y += so;                                  // second mult() call, src/matrix.c:440
                 }
-                if (a.sigma) y += a.sigma[v0 + v] * xv[row];  // += sigma_j x_j (src/test_shifted.c:133)
+                // += sigma_j x_j (src/test_shifted.c:133); with clusters the row's own column is in the window (distance 0 is always
+                // part of a cluster): no trip to memory at the end of the pass
+                if (a.sigma) y += a.sigma[v0 + v] * (WIN ? xv[row] : win[(unsigned)v * W + slot_of(0)]);
                 if (a.ys) a.ys[(size_t)(v0 + v) * a.vstride + row] = y;
                 if (a.b) { const double dd = (bi + (-1.0) * y) - 0.0; r2[v] = dd * dd; }
             }

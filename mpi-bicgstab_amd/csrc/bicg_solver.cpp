@@ -78,6 +78,7 @@ struct bicg_ctx {
     short *d_col16 = nullptr;              // ... with CSR-order 16-bit column offsets when they fit
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
     int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
+    uint32_t sell_blocked = 0;             // the groups are taken plane block by plane block (sell_order_for_big_grids): block size
     int spmv_dir = 0;                      // direction of the last sliced-ELL product (SpmvArgs::reverse)
     int sell_alt = 1;                      // BICG_SELL_ALT=0: every product forward; default: consecutive products alternate direction
     int sell_xcd = 1;                      // BICG_SELL_XCD=0: round robin; default: XCD-contiguous group order (SpmvArgs::xcd_map)
@@ -92,6 +93,7 @@ struct bicg_ctx {
     uint32_t *s_ubase = nullptr;           // uniform slices (SellDev::ubase / uoff): BICG_SELL_UNIFORM=0 switches them off
     int *s_uoff = nullptr;
     uint64_t uniform_entries = 0;          // sliced-ELL entries whose columns the SpMV does not read
+    uint32_t far_rows = 0;                 // farthest column distance of a uniform slice, in rows (a grid's plane size)
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
     double *s_uval = nullptr;
     uint64_t constant_entries = 0;         // ... whose values it does not read either
@@ -803,6 +805,7 @@ void group_flush(bicg_ctx *c)
 
 void fetch_scal(bicg_ctx *c);
 }  // namespace
+void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups);
 bool persist_chunk(bicg_ctx *c, int niter);
 bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, int seed, double shift);
 void persist_account(bicg_ctx *c);
@@ -979,6 +982,16 @@ struct Driver {
     }
 };
 
+// a fresh scalar block and ticket counters for a stand-alone kernel (bicg_spmv, bicg_dot, the form probe)
+void scal_reset(bicg_ctx *c)
+{
+    c->wave_mode = false;
+    c->grp = bicg_ctx::Group{};
+    BICG_HIP(hipMemsetAsync(c->S, 0, sizeof(Scal), c->sc));
+    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
+}
+bool all_ranks(Comm *comm, bool mine);
+
 void fetch_scal(bicg_ctx *c)
 {
     if (c->wave_mode) grp_close(c);      // the host wants the scalars: finish the open group now
@@ -991,6 +1004,11 @@ void fetch_scal(bicg_ctx *c)
         // BICG_P2P_SOFT_FAIL=1: report through bicg_comm_failed() and stop iterating instead of
         // exiting (bench.py then falls back to the RCCL collectives)
         const char *soft = getenv("BICG_P2P_SOFT_FAIL");
+        // one rank, no peer-to-peer path: the only waits are those between the workgroups of a persistent launch (they spin on each
+        // other and need to be co-resident: another long-running kernel on the same GPU can starve them) or on a dot group's producers
+        if (!c->p2p && !c->soft_fail && (!soft || atoi(soft) == 0))
+            die("persistent kernel", "workgroups waited for each other longer than the time-out -- is another kernel holding CUs of this GPU? "
+                                     "(BICG_PERSIST=0 selects the multi-launch iteration)");
         if (!c->soft_fail && (!soft || atoi(soft) == 0))
             die("peer-to-peer transport", "timed out waiting for another rank (BICG_P2P_TIMEOUT_MS)");
         if (!c->comm_failed)
@@ -1214,7 +1232,9 @@ int run_end(bicg_ctx *c, bicg_result *res)
 // Which pipelined form? By default a constant decides (fuse_small / x windows, set in bicg_create): the same program then
 // takes the same form on every run, which keeps results bit-reproducible from run to run -- the two forms associate the dot
 // sums differently. BICG_PIPE_PROBE=1 measures instead: the first pipelined solve on a context runs 2 + 6 iterations of each
-// form on the caller's own x0 / b (restored afterwards), all ranks agree on the slower rank's times, the faster form stays.
+// form on the system A x = A 1, x0 = 0 (the caller's x0 / b are restored afterwards), all ranks agree on the slower rank's times, the
+// faster form stays. The extra solves advance the exchange sequence numbers: a probed solve is not bit-identical to an unprobed one
+// whenever the chosen form differs from the rule's (probing trades away that reproducibility; it is opt-in).
 void probe_pipe_form(bicg_ctx *c, int method, const bicg_options *opt_in)
 {
     bicg_options o;
@@ -1229,17 +1249,34 @@ void probe_pipe_form(bicg_ctx *c, int method, const bicg_options *opt_in)
     BICG_HIP(hipMemcpy(keep, c->v.x, sizeof(double) * n, hipMemcpyDeviceToDevice));
     BICG_HIP(hipMemcpy(keep + n, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice));
     o.quiet = 1; o.tol = 0.0; o.max_iter = 8; o.check_every = 8; o.out_iter = 0; o.time_kernels = 0; o.record_trace = 0;
+    // The probe does not iterate on the caller's data (an x0 that already solves the system would make the recurrences divide by
+    // ~0 inside the probe): it solves A x = A 1 from x0 = 0, the reference's own test system (src/main.c:109-117). A breakdown all
+    // the same counts as a tie: the rule's form stays.
+    const bool rule_form = c->fuse_pipe;
+    double *bsyn = dev_alloc<double>(n ? n : 1);
+    {
+        std::vector<double> ones(n ? n : 1, 1.0);
+        scal_reset(c);
+        BICG_HIP(hipMemcpyAsync(c->v.p, ones.data(), sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
+        c->time_kernels = false;
+        spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
+        BICG_HIP(hipMemcpyAsync(bsyn, c->v.s, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
+        BICG_HIP(hipStreamSynchronize(c->sc));
+    }
     double t[2] = {0.0, 0.0};
+    bool broke = false;
     for (int form = 1; form >= 0; --form) {
         c->fuse_pipe = form != 0;
-        BICG_HIP(hipMemcpy(c->v.x, keep, sizeof(double) * n, hipMemcpyDeviceToDevice));
-        BICG_HIP(hipMemcpy(c->v.r, keep + n, sizeof(double) * n, hipMemcpyDeviceToDevice));
+        BICG_HIP(hipMemset(c->v.x, 0, sizeof(double) * n));
+        BICG_HIP(hipMemcpy(c->v.r, bsyn, sizeof(double) * n, hipMemcpyDeviceToDevice));
         run_begin(c, method, &o);
         run_iterate(c, 2);
         const double t0 = now_sec();
         run_iterate(c, 6);
         t[form] = (now_sec() - t0) / 6.0 * 1.0e3;
+        broke = broke || c->hS->breakdown_k != 0 || c->hS->comm_error != 0;
     }
+    BICG_HIP(hipFree(bsyn));
     if (c->nranks > 1) {      // the slower rank's time counts, and every rank must take the same decision
         const int P = c->nranks;
         std::vector<int> cnt(P, 2 * (int)sizeof(double)), off(P);
@@ -1250,7 +1287,8 @@ void probe_pipe_form(bicg_ctx *c, int method, const bicg_options *opt_in)
         for (int p = 0; p < P; ++p) { t[0] = std::max(t[0], all[2 * p]); t[1] = std::max(t[1], all[2 * p + 1]); }
     }
     c->probe_ms[0] = t[0]; c->probe_ms[1] = t[1];
-    c->fuse_pipe = t[1] <= t[0];
+    if (c->nranks > 1) broke = !all_ranks(c->comm, !broke);
+    c->fuse_pipe = broke ? rule_form : t[1] <= t[0];
     BICG_HIP(hipMemcpy(c->v.x, keep, sizeof(double) * n, hipMemcpyDeviceToDevice));
     BICG_HIP(hipMemcpy(c->v.r, keep + n, sizeof(double) * n, hipMemcpyDeviceToDevice));
     BICG_HIP(hipFree(keep));
@@ -1776,6 +1814,43 @@ int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, do
 }
 
 }  // namespace
+
+// Very large structured blocks (the 512^3 Laplacian: 524 288 row groups, z neighbours 262 144 rows = 2 MB of x away).
+//  * groups per workgroup: with one 256-row group of 7-entry rows per workgroup the per-workgroup part of a product with dots
+//    (block sum, hand-over of the partials) is a third of the kernel (2.16 ms without dots, 2.76 / 3.13 ms with one / two);
+//    workgroups take ceil(groups / 65536) contiguous groups each.
+//  * order of the groups: an XCD sweeps its eighth of the rows plane by plane, and the three planes a sweep front touches (6 MB
+//    of x) do not fit its 4 MB L2 -- every x value comes from the Infinity Cache three times. The groups of an XCD's share are
+//    therefore taken block by block through the planes: B consecutive groups of plane z, the same B of plane z + 1, ... so that
+//    what a block fetched as its far neighbours is still in the L2 when it becomes the block's own rows. Only the ORDER of the
+//    list changes (SpmvArgs::glist): rows, sums of a row and results are those of the natural order; the dot partials are
+//    added in list order (a different, equally fixed association).
+// BICG_SELL_BLOCK = B (groups, default 256; 0: natural order).
+void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups)
+{
+    if (!getenv("BICG_SELL_GPW") && !getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw = c->sell_gpw_dots = (int)std::max<uint32_t>(1u, (ngroups + 65535u) / 65536u);
+    const uint32_t B = getenv("BICG_SELL_BLOCK") ? (uint32_t)atoi(getenv("BICG_SELL_BLOCK")) : 256u;
+    const uint32_t P = (c->far_rows + kGroupRows / 2) / kGroupRows;          // groups per plane
+    if (B == 0 || P < 4 * B || c->sell_gpw != c->sell_gpw_dots || (uint64_t)c->far_rows * 24ull <= (3ull << 19)) return;   // three planes fit half an L2
+    const uint32_t nblocks = sell_grid(ngroups, c->sell_gpw), each = (ngroups + nblocks - 1) / nblocks;
+    std::vector<uint32_t> list(ngroups);
+    std::vector<uint32_t> seg;
+    for (uint32_t x = 0; x <= 8; ++x) {
+        const uint32_t s0 = std::min<uint64_t>(ngroups, (uint64_t)x * (nblocks / 8u) * each);
+        const uint32_t s1 = x == 8 ? ngroups : std::min<uint64_t>(ngroups, (uint64_t)(x + 1) * (nblocks / 8u) * each);
+        seg.resize(s1 - s0);
+        for (uint32_t i = 0; i < s1 - s0; ++i) seg[i] = s0 + i;
+        std::stable_sort(seg.begin(), seg.end(), [&](uint32_t ga, uint32_t gb) {
+            const uint32_t ya = ((ga - s0) % P) / B, yb = ((gb - s0) % P) / B;
+            return ya != yb ? ya < yb : ga < gb;
+        });
+        std::copy(seg.begin(), seg.end(), list.begin() + s0);
+    }
+    if (c->glist_int) BICG_HIP(hipFree(c->glist_int));
+    c->glist_int = dev_upload(list.data(), list.size());
+    c->glist_int_identity = false;
+    c->sell_blocked = B;
+}
 
 // ---------------------------------------------------------------- persistent pipelined iteration: plan
 // Which rows a workgroup owns, its part of the matrix in padded slices (diag entries first, then offd entries in the
@@ -2671,6 +2746,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     // uniform slices (SellDev::ubase): found by a kernel, grouped by the hash of their distance lists here; one list per group
     // is fetched from the CSR (a stencil has a few dozen)
     uint64_t uniform_entries = 0, constant_entries = 0;
+    uint32_t far_rows = 0;
     if (!(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
         const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
         unsigned long long *uh_d = dev_alloc<unsigned long long>(2 * (size_t)nslices), *vh_d = uh_d + nslices;
@@ -2720,6 +2796,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
             vbase[sl] = vt->second;
             constant_entries += (uint64_t)slen[sl] * kSliceRows;
         }
+        for (int d : uoff) far_rows = std::max<uint32_t>(far_rows, (uint32_t)std::abs(d));      // the farthest distance of a uniform slice
         if (uniform_entries) {
             c->s_ubase = dev_upload(ubase.data(), ubase.size());
             c->s_uoff = dev_upload(uoff.data(), uoff.size());
@@ -2731,6 +2808,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     }
     c->uniform_entries = uniform_entries;
     c->constant_entries = constant_entries;
+    c->far_rows = far_rows;
     c->d_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
     BICG_HIP(hipMemcpy(c->d_ptr, ptr_d, sizeof(uint32_t) * ((size_t)rows + 1), hipMemcpyDeviceToDevice));
     c->d_val = dev_alloc<double>(kPadEntries); c->d_col = dev_alloc<uint32_t>(kPadEntries);
@@ -2742,6 +2820,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->send_idx = dev_alloc<uint32_t>(1); c->sendbuf = dev_alloc<double>(1);
     c->ng_int = ngroups; c->ng_bnd = 0; c->n_int = c->n_bnd = c->nblk = 0;
     c->glist_int_identity = true; c->glist_all = true;
+    sell_order_for_big_grids(c, ngroups);
     c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
     c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
     BICG_HIP(hipFree(far_d));
@@ -2858,13 +2937,7 @@ int bicg_trace(bicg_ctx *c, double *alpha, double *omega, double *beta, double *
     return k;
 }
 
-static void reset_scal(bicg_ctx *c)
-{
-    c->wave_mode = false;
-    c->grp = bicg_ctx::Group{};
-    BICG_HIP(hipMemsetAsync(c->S, 0, sizeof(Scal), c->sc));
-    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
-}
+static void reset_scal(bicg_ctx *c) { scal_reset(c); }
 
 int bicg_spmv(bicg_ctx *c, const double *x, double *y)
 {

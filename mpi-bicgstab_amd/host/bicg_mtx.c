@@ -43,6 +43,7 @@ typedef struct {
     unsigned long m, n, nz;
     int pattern, integer, symmetric;
     unsigned long long emitted;      /* entries handed to emit() by parse_entries (mirrored ones included) */
+    unsigned long long lines;        /* entry lines parse_entries consumed */
     size_t data_off;      /* byte offset of the first entry line */
 } mtx_header;
 
@@ -374,11 +375,16 @@ static int parse_entries(const char *p, const char *end, mtx_header *h, unsigned
         double v = 1.0;
         if (!h->pattern && !fast_double(p, &v, &p)) { v = strtod(p, &q); p = q; }
         --i; --j;
+        if (i >= h->m || j >= h->n) {    /* (0 wraps around: also caught) the reference would index outside its arrays */
+            fprintf(stderr, "ERROR: matrix entry (%lu, %lu) lies outside the %lu x %lu matrix.\n", i + 1, j + 1, (unsigned long)h->m, (unsigned long)h->n);
+            return 7;
+        }
         emit(ctx, i, j, v);
         h->emitted++;
         if (h->symmetric && i != j) { emit(ctx, j, i, v); h->emitted++; }
         ++seen;
     }
+    h->lines = seen;
     return 0;
 }
 
@@ -506,6 +512,26 @@ static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigne
     }
     run_threads(nt, parse_job_run, jobs, sizeof(parse_job));
     int rc = 0;
+    /* The reference reads exactly the banner's nz entry lines (src/matrix.c:315: fewer is an error, more are never looked at).
+     * Several ranges: lines past the nz-th are dropped -- the range that holds the nz-th line is parsed again up to it -- so the
+     * loaded matrix does not depend on the number of threads. */
+    {
+        unsigned long long before = 0;
+        for (long t = 0; t < nt && !rc; ++t) {
+            if (jobs[t].rc) { rc = jobs[t].rc; break; }
+            const unsigned long long mine = jobs[t].h.lines;
+            if (before >= h->nz && mine) {                        /* entirely past the last entry */
+                free(jobs[t].s.mine.t); memset(&jobs[t].s.mine, 0, sizeof jobs[t].s.mine); jobs[t].h.emitted = 0; jobs[t].h.lines = 0;
+            } else if (before + mine > h->nz) {
+                free(jobs[t].s.mine.t); memset(&jobs[t].s.mine, 0, sizeof jobs[t].s.mine);
+                jobs[t].max_entries = (unsigned long)(h->nz - before);
+                parse_job_run(&jobs[t]);
+            }
+            before += mine;
+        }
+        if (!rc && h->nz != (unsigned long)-1 && before < h->nz) { fprintf(stderr, "ERROR: reading matrix data.\n"); rc = 6; }     /* the reference's message, src/matrix.c:318 */
+        h->lines = before < h->nz ? before : h->nz;
+    }
     h->emitted = 0;
     *segs = (tseg *)calloc((size_t)nt, sizeof(tseg));
     *nseg = (int)nt;
@@ -733,18 +759,34 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     int nseg = 0;
     if (p < q) {
         long nt = loader_threads((size_t)(q - p));
-        if (!getenv("BICG_MTX_THREADS")) { nt /= np; if (nt < 1) nt = 1; }
+        if (!getenv("BICG_MTX_THREADS")) {              /* the ranks of THIS node share its cores */
+            MPI_Comm node;
+            int on_node = np;
+            if (MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, me, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
+                MPI_Comm_size(node, &on_node);
+                MPI_Comm_free(&node);
+            }
+            nt /= on_node > 0 ? on_node : 1; if (nt < 1) nt = 1;
+        }
         const unsigned long banner_nz = h.nz;
         h.nz = (unsigned long)-1;                       /* a byte range has no entry count of its own */
         rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);
         h.nz = banner_nz;
     } else {
-        h.emitted = 0;
+        h.emitted = 0; h.lines = 0;
     }
     free(buf);
-    {   /* a malformed range must stop every rank, not leave the others in the collectives below */
+    {   /* a malformed range must stop every rank, not leave the others in the collectives below; so must a file whose number of
+         * entry lines is not the banner's (byte ranges cannot tell which line is the nz-th: the serial loader, like the
+         * reference, reads the first nz and ignores the rest -- here the file is refused, on every rank) */
+        unsigned long long lines = rc ? 0ull : h.lines;
+        MPI_Allreduce(MPI_IN_PLACE, &lines, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
         int any = rc;
         MPI_Allreduce(MPI_IN_PLACE, &any, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
+        if (!any && lines != (unsigned long long)h.nz) {
+            if (me == 0) fprintf(stderr, "ERROR: reading matrix data: %llu entry lines, the banner says %lu.\n", lines, (unsigned long)h.nz);
+            any = 6;
+        }
         if (any) { for (int i = 0; i < nseg; ++i) free(segs[i].t); free(segs); return any; }
     }
     const int *pcounts = NULL, *pdispls = NULL;

@@ -111,7 +111,8 @@ def test_bench_single_gpu_line_has_every_leg():
     big = d["extras"]["laplace7_512_ca"]
     assert big["rows"] == 512 ** 3 and big["nnz"] == 7 * 512 ** 3 - 6 * 512 ** 2
     assert big["plan_seconds"] < 3.0 and big["generate_seconds"] < 3.0, big
-    assert 0.5 < big["ca_bicgstab"]["frac"] < 1.0 and big["ca_bicgstab"]["ms_per_iteration"] < 10 * d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"]
+    # (frac is claimed on the bytes the layout moves: with constant slices the interior of the Laplacian streams no matrix at all)
+    assert 0.35 < big["ca_bicgstab"]["frac"] < 1.0 and "constant" in big["flags"] and big["ca_bicgstab"]["ms_per_iteration"] < 10 * d["extras"]["laplace7_256_ca"]["ca_bicgstab"]["ms_per_iteration"]
     # the rank one of 8 GPUs holds (configs[2]): the pipelined solver takes it as one persistent launch per chunk
     r8 = d["extras"]["transport_rank_of_8"]
     assert "persist" in r8["flags"] and r8["pipe_bicgstab"]["ms_per_iteration"] < 0.020, r8

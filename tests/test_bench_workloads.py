@@ -97,7 +97,7 @@ def test_fem_like_as_benchmarked():
     ms = min(ctx.spmm(X, sigma)[1] for _ in range(3))
     one = ctx.spmv_bench(50)
     print(f"fem_like: SpMM 16 vectors {1e3 * ms:.1f} us, one SpMV {1e3 * one:.1f} us")
-    assert ctx.last_spmm_windowed() and ms <= 6.0 * one
+    assert ctx.last_spmm_windowed() and ms <= 0.5 * 16 * one
     ctx.close()
 
 

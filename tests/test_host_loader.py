@@ -272,6 +272,49 @@ def test_block_builder_hook(tmp_path):
             assert np.array_equal(np.ctypeslib.as_array(a.val, shape=(nz,)), np.ctypeslib.as_array(b.val, shape=(nz,)))
 
 
+def test_entry_count_and_index_range_do_not_depend_on_threads(tmp_path):
+    """The reference reads exactly the banner's nz entry lines (src/matrix.c:315-331: fewer is "ERROR: reading matrix data",
+    lines after the nz-th are never looked at) and would index outside its arrays for an entry outside the matrix. Here: the
+    serial-mode loader keeps the FIRST nz lines whatever the number of tokeniser threads, a short file fails with the
+    reference's message, an index outside m x n (0 included) is an error everywhere; the MPI byte-range mode cannot tell which
+    line is the nz-th and refuses a file whose line count differs from the banner -- on every rank."""
+    A = synth.from_offsets(300, (0, 1, -1, 17, -17), diag_base=5.0, seed=2)
+    row, col, val = synth.colmajor_coo(A)
+    lines = [f"{i + 1} {j + 1} {v!r}\n" for i, j, v in zip(row.tolist(), col.tolist(), val.tolist())]
+    extra = ["1 1 99.5\n", "300 300 -3.0\n", "2 1 7.0\n"]
+
+    def write(name, body, nz=A.nnz):
+        path = str(tmp_path / name)
+        with open(path, "w") as f:
+            f.write("%%MatrixMarket matrix coordinate real general\n")
+            f.write(f"{A.rows} {A.cols} {nz}\n")
+            f.writelines(body)
+        return path
+
+    def run(path, world, mode, threads):
+        return subprocess.run([MPIEXEC, "-n", str(world), DUMP, path, str(tmp_path / "o"), mode], capture_output=True, text=True, timeout=120,
+                              env=dict(os.environ, BICG_MTX_THREADS=threads))
+    more = write("more.mtx", lines + extra)
+    for threads in ("1", "4", "16"):
+        out = run(more, 2, "serial", threads)
+        assert out.returncode == 0, out.stderr
+        for rank in range(2):
+            rows, ncols, d, o = _read(str(tmp_path / "o"), rank)
+            ed, eo, counts, _ = _expected(A.rows, row, col, val, 2, rank)
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[2], ed.val) and np.array_equal(o[2], eo.val), threads
+    out = run(more, 2, "mpi", "2")
+    assert out.returncode != 0 and "entry lines, the banner says" in out.stderr, out.stderr
+    short = write("short.mtx", lines[:-5])
+    for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "2")):
+        out = run(short, 2, mode, threads)
+        assert out.returncode != 0 and "ERROR: reading matrix data" in out.stderr, (mode, threads, out.stderr)
+    for bad in ("0 5 1.0\n", "301 1 1.0\n", "4 301 1.0\n"):
+        path = write("bad.mtx", lines[:100] + [bad] + lines[101:])
+        for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "2")):
+            out = run(path, 2, mode, threads)
+            assert out.returncode != 0 and "outside the 300 x 300 matrix" in out.stderr, (bad, mode, threads, out.stderr)
+
+
 @pytest.mark.parametrize("world", [1, 2])
 def test_loader_more_threads_than_rows_and_duplicates(tmp_path, world):
     """The serial-mode loader reads, tokenises and assembles with BICG_MTX_THREADS workers: byte ranges for the first two,
