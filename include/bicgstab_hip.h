@@ -328,6 +328,10 @@ unsigned long long bicg_device_matrix_bytes(bicg_ctx *ctx);
  * SpMV streams from the matrix arrays (values + the column indices it does read + row pointers) */
 unsigned long long bicg_uniform_entries(bicg_ctx *ctx);
 unsigned long long bicg_constant_entries(bicg_ctx *ctx);
+/* rows of MASKED slices: slices next to a grid face, whose rows are sub-sequences of one list of <= 16 (distance, value) pairs;
+ * the product reads one 16-bit word per row for them (which pairs the row has) instead of values and columns. Counted in
+ * bicg_uniform_entries / bicg_constant_entries too (with their padded entries). BICG_SELL_MASKED=0 switches them off */
+unsigned long long bicg_masked_rows(bicg_ctx *ctx);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
  * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST_SHIFTED=0 keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);

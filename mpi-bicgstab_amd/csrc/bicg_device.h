@@ -249,6 +249,15 @@ struct SellDev {
     // loads like the distances -- the slice streams NOTHING from the matrix arrays. vbase[slice] = 0xFFFFFFFF: values from val.
     const uint32_t *vbase;
     const double   *uval;
+    // Masked slices: the 64 rows of a slice next to a grid face are NOT equally long -- a row on the face lacks the neighbour
+    // beyond it -- but every row is a sub-sequence of one list of (distance, value) pairs (at most 16, ascending columns, equal
+    // values where present). Such a slice keeps that list in uoff / uval like a constant slice and ONE 16-bit word per row, the
+    // set of list entries the row has: its product reads 2 bytes per row from the matrix side instead of 10-12 per entry, and
+    // adds the present entries in list = stored order. mbase[slice] = list length << 26 | index of the slice in rmask (64 words
+    // per slice), 0xFFFFFFFF: not masked. With this the whole 7-point Laplacian of BASELINE.json configs[3] streams no values
+    // and no columns at all.
+    const uint32_t *mbase;
+    const unsigned short *rmask;
 };
 // (PAD32C / PAD16C: padded slices of a block that has CONSTANT slices -- SellDev::vbase. Instantiations of their own: with the
 // value list as a run-time branch in every kernel, the dot-carrying products of blocks WITHOUT such slices paid 11 us each for
@@ -514,6 +523,10 @@ void launch_dot(const double *x, const double *y, uint32_t n, Scal *S, Reduce re
 void launch_plan_rowstats(const uint32_t *ptr, const uint32_t *col, uint32_t rows, uint32_t *slice_len, int *far, hipStream_t st);
 void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, unsigned long long *uhash,
                          unsigned long long *vhash, hipStream_t st);
+// masked slices (SellDev::mbase): mhash[s] = hash of the slice's list of (distance, value bits) with its length in the low 5 bits
+// (0: not masked); second call with mbase given: the rows' masks of the masked slices into rmask
+void launch_plan_masked(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, unsigned long long *mhash,
+                        const uint32_t *mbase, unsigned short *rmask, hipStream_t st);
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st);
 

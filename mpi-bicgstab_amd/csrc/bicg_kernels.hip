@@ -1096,7 +1096,9 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
                                            const double *win = nullptr)
 {
     constexpr bool WIN = LAY == LAY_JAGW, C16 = (LAY & 1) != 0 || WIN, JAG = LAY >= LAY_JAG32 && LAY <= LAY_JAGW, CONSTV = LAY >= LAY_PAD32C;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    // (the wavefront's number as a SCALAR: the slice's base, length and list positions then come through the scalar cache and the
+    // tests on them are scalar branches -- as a vector value the compiler masked and unmasked lanes around every entry)
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const double *__restrict__ x = a.x;
     const unsigned g = a.glist ? a.glist[gi] : gi;
     row = g * kGroupRows + tid;                                // = slice * 64 + lane
@@ -1175,13 +1177,27 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
             }
         }
     }
+    // masked slice (SellDev::mbase): list of (distance, value) pairs + one word per row saying which of them the row has
+    bool masked = false;
+    uint32_t pm = 0u;
+    if (CONSTV && uv && a.sell.mbase) {
+        const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.mbase[slice]);
+        if (mb != 0xFFFFFFFFu) {
+            masked = true;
+            len = mb >> 26;                                       // the list's length, not the longest row's
+            pm = a.sell.rmask[(size_t)(mb & 0x03FFFFFFu) * kSliceRows + lane];
+        }
+    }
     for (uint32_t k0 = 0; !JAG && k0 < len; k0 += U) {
         uint32_t c[U];
         double   v[U];
         // lanes past the last row hold padding only: their offsets are 0 and must not turn into
         // reads of x[row >= nrows] (the vector may end before the 64-row slice does)
         const uint32_t rb = live ? row : 0u;
-        if (uo) {
+        if (CONSTV && masked) {
+#pragma unroll
+            for (int e = 0; e < U; ++e) c[e] = rb + (((pm >> (k0 + e)) & 1u) ? (uint32_t)uo[k0 + e] : 0u);   // an absent neighbour may lie outside the vector
+        } else if (uo) {
 #pragma unroll
             for (int e = 0; e < U; ++e) c[e] = rb + (uint32_t)uo[k0 + e];
         } else if (C16) {
@@ -1210,7 +1226,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
         for (int e = 0; e < U; ++e) xv[e] = x[c[e]];
 #pragma unroll
         for (int e = 0; e < U; ++e)
-            if (k0 + e < mylen) sum += v[e] * xv[e];          // stored order; padding never added
+            if ((CONSTV && masked) ? ((pm >> (k0 + e)) & 1u) != 0u : k0 + e < mylen) sum += v[e] * xv[e];   // stored order; padding never added
     }
     double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
     if (OFFD) {
@@ -1244,7 +1260,7 @@ __device__ __forceinline__ void sell_halo_push(const SpmvArgs &a, unsigned bid, 
 }
 
 template <int NDOT, bool OFFD, bool NT, int LAY, bool LL, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MODE == RED_TICKET ? 8 : 4, 8))) k_spmv_sell(SpmvArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MODE == RED_TICKET && LAY < LAY_PAD32C) ? 8 : 4, 8))) k_spmv_sell(SpmvArgs a)   // (layouts with list-driven slices: no pin, they spilled 200 bytes per lane at 64 registers)
 {
     const int done = a.S->done;       // consumed at the stores only (see k_spmv)
     __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];

@@ -76,6 +76,51 @@ __global__ void __launch_bounds__(kThreads) k_plan_uniform(const uint32_t *ptr, 
     if ((threadIdx.x & 63u) == 0 && live) vhash[r / kSliceRows] = con ? (hv | 1ull) : 0ull;
 }
 
+// masked slices (SellDev::mbase): all 64 rows present, every row at most 16 entries with ascending columns, and the rows'
+// (distance, value) pairs all sub-sequences of ONE ascending list of at most 16 pairs with equal values wherever a pair occurs.
+// The list is built by the wavefront: the smallest distance any row still has to place becomes the next list entry, the rows
+// that hold it must agree on its value and move on. Pass 1 (rmask == nullptr): mhash[s] = hash of the list, its length in the
+// low 5 bits, 0 when the slice does not qualify. Pass 2: the rows' masks of the slices the host kept (mbase[s] != ~0).
+__global__ void __launch_bounds__(kThreads) k_plan_masked(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
+                                                          unsigned long long *mhash, const uint32_t *mbase, unsigned short *rmask)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t slice = r / kSliceRows;
+    const bool live = r < rows;
+    if (rmask) {                                              // pass 2: only the slices that were kept
+        const uint32_t first = (slice * kSliceRows < rows) ? mbase[slice] : 0xFFFFFFFFu;       // wave-uniform
+        if (first == 0xFFFFFFFFu) return;
+    }
+    const uint32_t a = live ? ptr[r] : 0u, len = live ? ptr[r + 1] - a : 0u;
+    bool ok = __all(live && len > 0 && len <= 16u);
+    unsigned long long h = 0x84222325cbf29ce4ull;
+    uint32_t pos = 0, mask = 0;
+    int n = 0, prev = 0;
+    while (ok) {
+        const int cand = pos < len ? (int)((long long)col[a + pos] - (long long)r) : 0x7FFFFFFF;
+        int m = cand;
+        for (int off = 32; off > 0; off >>= 1) { const int o = __shfl_xor(m, off, 64); m = o < m ? o : m; }
+        if (m == 0x7FFFFFFF) break;                           // every row has placed all its entries
+        if (n == 16 || (n > 0 && m <= prev)) { ok = false; break; }      // list too long / a row whose columns do not ascend
+        const bool has = cand == m;
+        const unsigned long long vb = has ? (unsigned long long)__double_as_longlong(val[a + pos]) : 0ull;
+        const unsigned long long who = __ballot(has);
+        const int firstlane = __builtin_ctzll(who);
+        const unsigned lo0 = (unsigned)__shfl((int)(unsigned)vb, firstlane, 64), hi0 = (unsigned)__shfl((int)(unsigned)(vb >> 32), firstlane, 64);
+        const unsigned long long v0 = ((unsigned long long)hi0 << 32) | lo0;
+        if (!__all(!has || vb == v0)) { ok = false; break; }  // the rows disagree on the value at this distance
+        if (has) { mask |= 1u << n; ++pos; }
+        h = (h ^ (unsigned long long)(unsigned)m) * 0x100000001b3ull; h ^= h >> 29;
+        h = (h ^ v0) * 0x100000001b3ull; h ^= h >> 31;
+        prev = m; ++n;
+    }
+    if (rmask) {
+        if (ok && live) rmask[(size_t)(mbase[slice] & 0x03FFFFFFu) * kSliceRows + (r % kSliceRows)] = (unsigned short)mask;
+        return;
+    }
+    if ((threadIdx.x & 63u) == 0 && live) mhash[slice] = (ok && n > 0) ? ((h << 5) | (unsigned long long)n) : 0ull;
+}
+
 // entry k of row r -> slice_base[r / 64] + k * 64 + r % 64 (padding stays zero); 16-bit offsets four to a word
 __global__ void __launch_bounds__(kThreads) k_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
                                                         const uint32_t *slice_base, const uint32_t *slice_base16, double *sval,
@@ -134,6 +179,11 @@ void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, const double 
                          unsigned long long *vhash, hipStream_t st)
 {
     hipLaunchKernelGGL(k_plan_uniform, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, val, rows, uhash, vhash);
+}
+void launch_plan_masked(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, unsigned long long *mhash,
+                        const uint32_t *mbase, unsigned short *rmask, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_plan_masked, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, val, rows, mhash, mbase, rmask);
 }
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st)

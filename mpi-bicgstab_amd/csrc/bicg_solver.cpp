@@ -94,6 +94,9 @@ struct bicg_ctx {
     int *s_uoff = nullptr;
     uint64_t uniform_entries = 0;          // sliced-ELL entries whose columns the SpMV does not read
     uint32_t far_rows = 0;                 // farthest column distance of a uniform slice, in rows (a grid's plane size)
+    uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_SELL_MASKED=0 switches them off
+    unsigned short *s_rmask = nullptr;
+    uint64_t masked_rows = 0;
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
     double *s_uval = nullptr;
     uint64_t constant_entries = 0;         // ... whose values it does not read either
@@ -522,7 +525,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.fin = fin;
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
-    a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval;
+    a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval; a.sell.mbase = c->s_mbase; a.sell.rmask = c->s_rmask;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -2465,11 +2468,13 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
 
     // Uniform slices (SellDev::ubase): all 64 rows present, equally long, entry k at the same distance from its row in
     // every row. Lists are shared between slices (a banded matrix has ONE for its whole interior) and padded with zeros.
-    std::vector<uint32_t> ubase, vbase;
+    std::vector<uint32_t> ubase, vbase, mbase;
     std::vector<int> uoff;
     std::vector<double> uval;
-    uint64_t uniform_entries = 0, constant_entries = 0;
+    std::vector<unsigned short> rmask;
+    uint64_t uniform_entries = 0, constant_entries = 0, masked_rows = 0;
     const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
+    const bool want_masked = !(getenv("BICG_SELL_MASKED") && atoi(getenv("BICG_SELL_MASKED")) == 0);
     if (!jag && sell_entries > 0 && !(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
         ubase.assign(nslices, 0xFFFFFFFFu);
         std::map<std::vector<int>, uint32_t> lists, vlists;
@@ -2479,13 +2484,67 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             const uint32_t r0 = sl * kSliceRows, len = slice_len[sl];
             bool uni = true;
             for (uint32_t l = 0; l < kSliceRows && uni; ++l) uni = diag->ptr[r0 + l + 1] - diag->ptr[r0 + l] == len;
-            if (!uni) continue;
-            cur.assign(len, 0);
-            for (uint32_t k = 0; k < len; ++k) cur[k] = (int)((int64_t)diag->col[diag->ptr[r0] + k] - (int64_t)r0);
-            for (uint32_t l = 1; l < kSliceRows && uni; ++l)
-                for (uint32_t k = 0; k < len; ++k)
-                    if ((int64_t)diag->col[diag->ptr[r0 + l] + k] - (int64_t)(r0 + l) != cur[k]) { uni = false; break; }
-            if (!uni) continue;
+            if (uni) {
+                cur.assign(len, 0);
+                for (uint32_t k = 0; k < len; ++k) cur[k] = (int)((int64_t)diag->col[diag->ptr[r0] + k] - (int64_t)r0);
+                for (uint32_t l = 1; l < kSliceRows && uni; ++l)
+                    for (uint32_t k = 0; k < len; ++k)
+                        if ((int64_t)diag->col[diag->ptr[r0 + l] + k] - (int64_t)(r0 + l) != cur[k]) { uni = false; break; }
+            }
+            if (!uni) {
+                // masked slice (SellDev::mbase): the rows are sub-sequences of one ascending list of <= 16 (distance, value) pairs
+                if (!want_constant || !want_masked) continue;
+                std::map<int, long long> un;                                      // distance -> value bits
+                bool ok = true;
+                for (uint32_t l = 0; l < kSliceRows && ok; ++l) {
+                    const uint32_t p0 = diag->ptr[r0 + l], p1 = diag->ptr[r0 + l + 1];
+                    ok = p1 > p0 && p1 - p0 <= 16u;
+                    for (uint32_t j = p0; j < p1 && ok; ++j) {
+                        if (j > p0 && diag->col[j] <= diag->col[j - 1]) { ok = false; break; }      // ascending columns
+                        const int d = (int)((int64_t)diag->col[j] - (int64_t)(r0 + l));
+                        long long b; memcpy(&b, diag->val + j, 8);
+                        auto f = un.find(d);
+                        if (f == un.end()) un.emplace(d, b); else ok = f->second == b;
+                    }
+                    ok = ok && un.size() <= 16u;
+                }
+                if (!ok) continue;
+                const uint32_t ulen = (uint32_t)un.size();
+                cur.clear(); vkey.clear();
+                std::vector<double> uv_list;
+                for (auto &kv : un) { cur.push_back(kv.first); double v; memcpy(&v, &kv.second, 8); uv_list.push_back(v); }
+                vkey.assign(cur.begin(), cur.end());
+                for (auto &kv : un) { vkey.push_back((int)(kv.second & 0xFFFFFFFF)); vkey.push_back((int)(kv.second >> 32)); }
+                auto it = lists.find(cur);
+                if (it == lists.end()) {
+                    if (uoff.size() + ulen + 32 > (1u << 24)) continue;
+                    it = lists.emplace(cur, (uint32_t)uoff.size()).first;
+                    uoff.insert(uoff.end(), cur.begin(), cur.end());
+                    uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);
+                }
+                auto vt = vlists.find(vkey);
+                if (vt == vlists.end()) {
+                    if (uval.size() + ulen + 32 > (1u << 22)) continue;
+                    vt = vlists.emplace(vkey, (uint32_t)uval.size()).first;
+                    uval.insert(uval.end(), uv_list.begin(), uv_list.end());
+                    uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
+                }
+                if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
+                if (mbase.empty()) mbase.assign(nslices, 0xFFFFFFFFu);
+                ubase[sl] = it->second; vbase[sl] = vt->second;
+                mbase[sl] = (ulen << 26) | (uint32_t)(rmask.size() / kSliceRows);
+                for (uint32_t l = 0; l < kSliceRows; ++l) {
+                    unsigned m = 0;
+                    for (uint32_t j = diag->ptr[r0 + l]; j < diag->ptr[r0 + l + 1]; ++j) {
+                        const int d = (int)((int64_t)diag->col[j] - (int64_t)(r0 + l));
+                        m |= 1u << (unsigned)std::distance(un.begin(), un.find(d));
+                    }
+                    rmask.push_back((unsigned short)m);
+                }
+                uniform_entries += (uint64_t)len * kSliceRows; constant_entries += (uint64_t)len * kSliceRows;     // (padded entries the product no longer reads)
+                masked_rows += kSliceRows;
+                continue;
+            }
             auto it = lists.find(cur);
             if (it == lists.end()) {
                 if (uoff.size() + len + 32 > (1u << 24)) continue;            // the table stays small (scalar cache)
@@ -2519,6 +2578,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     }
     c->uniform_entries = uniform_entries;
     c->constant_entries = constant_entries;
+    c->masked_rows = masked_rows;
 
     // CSR row blocks over the maximal runs of non-SELL groups
     std::vector<uint32_t> rb(nrows + 1);
@@ -2571,11 +2631,15 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // (jagged slices: lanes whose row has ended read up to one entry past the last -- kPadEntries of slack)
     c->s_val = dev_upload_padded(sval.data(), (size_t)sell_entries, kPadEntries);
     c->s_col = dev_upload_padded(scol.data(), c16 ? 0 : (size_t)sell_entries, kPadEntries);
-    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 8ull * nslices + 4ull * (nrows + 1) +
+    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 2ull * masked_rows + 8ull * nslices + 4ull * (nrows + 1) +
                       (uint64_t)(c->nnz_d - c->sell_nnz) * (csr16 ? 10 : 12) + (uint64_t)c->nnz_o * 12;
     if (!vbase.empty()) {
         c->s_vbase = dev_upload(vbase.data(), vbase.size());
         c->s_uval = dev_upload(uval.data(), uval.size());
+    }
+    if (!mbase.empty()) {
+        c->s_mbase = dev_upload(mbase.data(), mbase.size());
+        c->s_rmask = dev_upload(rmask.data(), rmask.size());
     }
     if (!ubase.empty()) {
         c->s_ubase = dev_upload(ubase.data(), ubase.size());
@@ -2797,6 +2861,57 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
             constant_entries += (uint64_t)slen[sl] * kSliceRows;
         }
         for (int d : uoff) far_rows = std::max<uint32_t>(far_rows, (uint32_t)std::abs(d));      // the farthest distance of a uniform slice
+        // masked slices (SellDev::mbase): the slices next to a grid face. Found by a kernel (hash of the slice's list of
+        // (distance, value) pairs), one representative per hash is fetched and its list rebuilt here, the rows' masks are
+        // written by a second pass over the slices that were kept.
+        if (want_constant && !(getenv("BICG_SELL_MASKED") && atoi(getenv("BICG_SELL_MASKED")) == 0)) {
+            unsigned long long *mh_d = dev_alloc<unsigned long long>(nslices);
+            BICG_HIP(hipMemset(mh_d, 0, sizeof(unsigned long long) * nslices));
+            launch_plan_masked(ptr_d, col_d, val_d, rows, mh_d, nullptr, nullptr, nullptr);
+            std::vector<unsigned long long> mh(nslices);
+            BICG_HIP(hipMemcpy(mh.data(), mh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
+            BICG_HIP(hipFree(mh_d));
+            std::vector<uint32_t> mbase;
+            std::map<unsigned long long, std::pair<uint32_t, uint32_t>> mlists;       // hash -> (position in uoff, position in uval)
+            std::vector<uint32_t> rp(kSliceRows + 1), rc;
+            std::vector<double> rv;
+            uint32_t nmasked = 0;
+            for (uint32_t sl = 0; sl < nslices; ++sl) {
+                if (ubase[sl] != 0xFFFFFFFFu || !mh[sl] || (sl + 1) * kSliceRows > rows) continue;
+                const uint32_t ulen = (uint32_t)(mh[sl] & 31ull);
+                auto it = mlists.find(mh[sl]);
+                if (it == mlists.end()) {
+                    if (mlists.size() >= 4096) continue;
+                    const uint32_t r0 = sl * kSliceRows;
+                    BICG_HIP(hipMemcpy(rp.data(), ptr_d + r0, sizeof(uint32_t) * (kSliceRows + 1), hipMemcpyDeviceToHost));
+                    const uint32_t ne = rp[kSliceRows] - rp[0];
+                    rc.resize(ne); rv.resize(ne);
+                    BICG_HIP(hipMemcpy(rc.data(), col_d + rp[0], sizeof(uint32_t) * ne, hipMemcpyDeviceToHost));
+                    BICG_HIP(hipMemcpy(rv.data(), val_d + rp[0], sizeof(double) * ne, hipMemcpyDeviceToHost));
+                    std::map<int, double> un;
+                    for (uint32_t l = 0; l < kSliceRows; ++l)
+                        for (uint32_t j = rp[l]; j < rp[l + 1]; ++j) un.emplace((int)((int64_t)rc[j - rp[0]] - (int64_t)(r0 + l)), rv[j - rp[0]]);
+                    if (un.size() != ulen) continue;                              // (cannot happen: the kernel built the same list)
+                    it = mlists.emplace(mh[sl], std::make_pair((uint32_t)uoff.size(), (uint32_t)uval.size())).first;
+                    for (auto &kv : un) { uoff.push_back(kv.first); uval.push_back(kv.second); far_rows = std::max<uint32_t>(far_rows, (uint32_t)std::abs(kv.first)); }
+                    uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);
+                    uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
+                }
+                if (mbase.empty()) mbase.assign(nslices, 0xFFFFFFFFu);
+                if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
+                ubase[sl] = it->second.first; vbase[sl] = it->second.second;
+                mbase[sl] = (ulen << 26) | nmasked++;
+                uniform_entries += (uint64_t)slen[sl] * kSliceRows; constant_entries += (uint64_t)slen[sl] * kSliceRows;
+            }
+            if (nmasked) {
+                c->s_mbase = dev_upload(mbase.data(), mbase.size());
+                c->s_rmask = dev_alloc<unsigned short>((size_t)nmasked * kSliceRows);
+                BICG_HIP(hipMemset(c->s_rmask, 0, sizeof(unsigned short) * (size_t)nmasked * kSliceRows));
+                launch_plan_masked(ptr_d, col_d, val_d, rows, nullptr, c->s_mbase, c->s_rmask, nullptr);
+                BICG_HIP(hipDeviceSynchronize());
+                c->masked_rows = (uint64_t)nmasked * kSliceRows;
+            }
+        }
         if (uniform_entries) {
             c->s_ubase = dev_upload(ubase.data(), ubase.size());
             c->s_uoff = dev_upload(uoff.data(), uoff.size());
@@ -2821,7 +2936,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->ng_int = ngroups; c->ng_bnd = 0; c->n_int = c->n_bnd = c->nblk = 0;
     c->glist_int_identity = true; c->glist_all = true;
     sell_order_for_big_grids(c, ngroups);
-    c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
+    c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 2ull * c->masked_rows + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
     c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
     BICG_HIP(hipFree(far_d));
     ctx_state(c, comm, ngroups);
@@ -2865,7 +2980,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -3116,6 +3231,7 @@ void bicg_dropin_release(void)
 unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matrix_bytes; }
 unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
 unsigned long long bicg_constant_entries(bicg_ctx *c) { return c->constant_entries; }
+unsigned long long bicg_masked_rows(bicg_ctx *c) { return c->masked_rows; }
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return c->matrix_bytes; }
 int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
 int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }

@@ -418,15 +418,27 @@ def test_uniform_slices_give_the_same_bits():
                 noc = H.Context(H.single_rank_blocks(A))
             finally:
                 os.environ.pop("BICG_SELL_CONSTANT")
-            assert noc.flags()["uniform"] and not noc.flags()["constant"] and noc.constant_entries() == 0
-            assert ctx.spmv_matrix_bytes() <= noc.spmv_matrix_bytes() - 8 * ctx.constant_entries() + 64, name
             xx = np.random.default_rng(12).standard_normal(A.rows)
+            assert noc.flags()["uniform"] and not noc.flags()["constant"] and noc.constant_entries() == 0
+            assert ctx.spmv_matrix_bytes() <= noc.spmv_matrix_bytes() - 8 * ctx.constant_entries() + 2 * ctx.masked_rows() + 64, name
+            # masked slices (round 4): the slices next to a grid face -- rows of different length, all sub-sequences of ONE list of
+            # (distance, value) pairs -- keep one 16-bit word per row: with them (almost) the whole stencil streams no values and no
+            # columns; switched off, the same bits
+            assert ctx.masked_rows() > 0 and ctx.masked_rows() % 64 == 0 and ctx.constant_entries() > 0.8 * A.nnz, (name, ctx.masked_rows(), ctx.constant_entries(), A.nnz)
+            os.environ["BICG_SELL_MASKED"] = "0"
+            try:
+                nom = H.Context(H.single_rank_blocks(A))
+            finally:
+                os.environ.pop("BICG_SELL_MASKED")
+            assert nom.masked_rows() == 0 and nom.constant_entries() < ctx.constant_entries()
+            assert np.array_equal(ctx.spmv(xx), nom.spmv(xx)), name
+            nom.close()
             assert np.array_equal(ctx.spmv(xx), noc.spmv(xx)), name
             noc.close()
         else:
             assert not ctx.flags()["constant"] and ctx.constant_entries() == 0, name
         ue = ctx.uniform_entries()
-        assert share * A.nnz < ue <= A.nnz + 64 * 32, (name, ue, A.nnz)
+        assert share * A.nnz < ue <= 1.15 * A.nnz + 64 * 32, (name, ue, A.nnz)      # (padded entries: masked slices count the absent neighbours too)
         assert ctx.spmv_matrix_bytes() < ref.spmv_matrix_bytes() - 1.5 * ue, name
         x = np.random.default_rng(11).standard_normal(A.rows)
         y = ctx.spmv(x)

@@ -9,8 +9,8 @@ H.lib().bicg_comm_init_single(0)
 m = int(sys.argv[1]) if len(sys.argv) > 1 else 512
 ctx, nnz, ps, gs = H.Context.stencil7_on_device(m, synth.LAPLACE_WEIGHTS)
 n = m ** 3
-print(m, "plan %.3f s, generate %.3f s, uniform entries %d, constant entries %d of %d, bytes one product streams from the matrix arrays %d, flags %s"
-      % (ps, gs, ctx.uniform_entries(), ctx.constant_entries(), nnz, ctx.spmv_matrix_bytes(), [k for k, v in ctx.flags().items() if v]), flush=True)
+print(m, "plan %.3f s, generate %.3f s, uniform entries %d, constant entries %d of %d, masked rows %d, bytes one product streams from the matrix arrays %d, flags %s"
+      % (ps, gs, ctx.uniform_entries(), ctx.constant_entries(), nnz, ctx.masked_rows(), ctx.spmv_matrix_bytes(), [k for k, v in ctx.flags().items() if v]), flush=True)
 b = ctx.spmv(np.ones(n))
 for method in ("bicgstab", "ca_bicgstab"):
     ctx.load(np.zeros(n), b)
