@@ -717,6 +717,7 @@ def main():
 
     if rank == 0:
         iter_bytes = iteration_bytes(a.method, nnz_global, n)
+        iter_fmt_bytes = min(iter_bytes, iter_bytes - 2 * world * max(0, b_spmv - fmt_spmv))
         shape = {"transport": "Transport-shaped CSR", "laplace7": f"7-point Laplacian {a.m}^3", "banded": f"banded CSR b={a.half_bandwidth}",
                  "fem_like": "FEM-like irregular CSR"}[a.workload]
         line = {
@@ -730,14 +731,20 @@ def main():
                        "transport": transport_name, "flags": head_flags_all, "halo": int(plan["halo"]),
                        "iterations_genuine": bool(genuine), "relres_after_timed_region": relres,
                        "true_relres_after_timed_region": true_relres},
-            "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,
-            "iteration_algorithmic_bytes": iter_bytes,
+            # bytes one iteration has to move with the stored layout (2 products + the fused-minimum vector traffic of SURVEY.md 8d)
+            "hbm_gbps_iteration": iter_fmt_bytes / (ms_step * 1e-3) / 1e9,
+            "iteration_algorithmic_bytes": iter_fmt_bytes,
+            "iteration_csr_bytes": iter_bytes,
+            # `achieved` / `frac`: the ALGORITHMIC bytes of one launch of this kernel on this matrix -- what the stored layout has to
+            # move (values + the index the layout keeps, 16-bit distances for slices that are not uniform, none for
+            # those that are, + row lengths + x + y; `traffic` from the counters agrees within 2 %) -- over the launch time. The CSR
+            # figure of SURVEY.md 8d (12 bytes per non-zero) stays beside it: a layout that stores no column index moves fewer bytes
+            # than CSR, and the CSR bytes over the launch time (`csr_equivalent_gbps`) can exceed the HBM peak.
             "roofline": {"kernel": "k_spmv_sell (sliced-ELL SpMV with fused dot epilogue), rank 0 share", "bound": "hbm",
-                         "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                         "traffic": traffic, "traffic_detail": traffic_detail, "algorithmic_bytes_per_launch": b_spmv,
+                         "achieved": fmt_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fmt_gbps / HBM_PEAK_GBS,
+                         "traffic": traffic, "traffic_detail": traffic_detail, "algorithmic_bytes_per_launch": fmt_spmv,
                          "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,
-                         # what the STORED layout streams per launch (values + the index it keeps: 16-bit offsets, none in uniform
-                         # slices) + x + y: below the CSR figure `achieved` is formed from whenever the layout compresses the index
+                         "csr_bytes_per_launch": b_spmv, "csr_equivalent_gbps": achieved, "csr_equivalent_frac": achieved / HBM_PEAK_GBS,
                          "format_bytes_per_launch": fmt_spmv, "format_gbps": fmt_gbps, "frac_of_format_bytes": fmt_gbps / HBM_PEAK_GBS,
                          "ms_per_step_with_events": 1e3 * dt_ev / K,
                          "back_to_back_spmv_ms": spmv_alone_ms,

@@ -1111,9 +1111,35 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
         base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
         if (C16 && !JAG) base16 = a.sell.slice_base16[slice];
     }
+    // uniform slice: the columns are row + uoff[k], one list for the whole slice (scalar loads) -- no col / col16 traffic.
+    // Same loop as the padded slices (one body: a second copy of it cost the ticket-mode kernels three spilled registers)
+    const int *__restrict__ uo = nullptr;                         // padded with zeros to a multiple of U (+ U)
+    const double *__restrict__ uv = nullptr;                      // constant slice: the values too (padded with zeros alike)
+    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) {
+        const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
+        if (ub != 0xFFFFFFFFu) {
+            uo = a.sell.uoff + ub;
+            if (CONSTV) {
+                const uint32_t vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.vbase[slice]);
+                if (vb != 0xFFFFFFFFu) uv = a.sell.uval + vb;
+            }
+        }
+    }
+    // masked slice (SellDev::mbase): list of (distance, value) pairs + one word per row saying which of them the row has
+    bool masked = false;
+    uint32_t pm = 0u;
+    if (CONSTV && uv && a.sell.mbase) {
+        const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.mbase[slice]);
+        if (mb != 0xFFFFFFFFu) {
+            masked = true;
+            len = mb >> 26;                                       // the list's length, not the longest row's
+            pm = a.sell.rmask[(size_t)(mb & 0x03FFFFFFu) * kSliceRows + lane];
+        }
+    }
+    // (a list-driven slice knows its rows' lengths: all equal to the slice's, or given by the masks -- no row-pointer loads)
     uint32_t mylen = 0u, oa = 0u, ob = 0u;
     if (live) {
-        mylen = a.diag.ptr[row + 1] - a.diag.ptr[row];
+        mylen = uo ? len : a.diag.ptr[row + 1] - a.diag.ptr[row];
         if (OFFD && (!LL || gi >= a.ll.first_bnd)) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
     }
 
@@ -1161,31 +1187,6 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
 #pragma unroll
             for (int e = 0; e < U; ++e)
                 if (mine[e]) sum += v[e] * xv[e];             // stored order
-        }
-    }
-    // uniform slice: the columns are row + uoff[k], one list for the whole slice (scalar loads) -- no col / col16 traffic.
-    // Same loop as the padded slices (one body: a second copy of it cost the ticket-mode kernels three spilled registers)
-    const int *__restrict__ uo = nullptr;                         // padded with zeros to a multiple of U (+ U)
-    const double *__restrict__ uv = nullptr;                      // constant slice: the values too (padded with zeros alike)
-    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) {
-        const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
-        if (ub != 0xFFFFFFFFu) {
-            uo = a.sell.uoff + ub;
-            if (CONSTV) {
-                const uint32_t vb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.vbase[slice]);
-                if (vb != 0xFFFFFFFFu) uv = a.sell.uval + vb;
-            }
-        }
-    }
-    // masked slice (SellDev::mbase): list of (distance, value) pairs + one word per row saying which of them the row has
-    bool masked = false;
-    uint32_t pm = 0u;
-    if (CONSTV && uv && a.sell.mbase) {
-        const uint32_t mb = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.mbase[slice]);
-        if (mb != 0xFFFFFFFFu) {
-            masked = true;
-            len = mb >> 26;                                       // the list's length, not the longest row's
-            pm = a.sell.rmask[(size_t)(mb & 0x03FFFFFFu) * kSliceRows + lane];
         }
     }
     for (uint32_t k0 = 0; !JAG && k0 < len; k0 += U) {
@@ -1942,7 +1943,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     constexpr int U = 8;
     __shared__ double sm[(kBlock / 64) * NV];
     double *const win = dyn_lds;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     unsigned g = blockIdx.x;
     if (a.xcd_map) {
         const unsigned per = (a.ngroups + 7u) / 8u;

@@ -123,7 +123,8 @@ def test_bench_single_gpu_line_has_every_leg():
     assert 0.5 < rf["frac_of_measured_stream"] < 1.1 and 0.5 < rf["frac_of_measured_read"] < 1.0, rf
     # fractions are claimed on the bytes the stored layout moves (uniform slices keep no column index: fewer than CSR's 12 per
     # non-zero); the CSR figure of SURVEY 8d stays beside it as `achieved` / `algorithmic_bytes`
-    assert rf["format_bytes_per_launch"] <= rf["algorithmic_bytes_per_launch"] and 0.4 < rf["frac_of_format_bytes"] <= rf["frac"] < 1.0, rf
+    assert rf["algorithmic_bytes_per_launch"] == rf["format_bytes_per_launch"] <= rf["csr_bytes_per_launch"] and 0.4 < rf["frac"] < 1.0, rf
+    assert abs(rf["frac"] - rf["achieved"] / rf["peak"]) < 1e-12 and rf["csr_equivalent_gbps"] >= rf["achieved"], rf
     fmt = [r for _, r in roofs if "format_bytes" in r]
     assert len(fmt) >= 20 and all(r["format_bytes"] <= r.get("algorithmic_bytes", r.get("algorithmic_bytes_rank0")) for r in fmt)
     assert d["comm"]["world"] == 1 and d["comm"]["rccl_leg"] is None
