@@ -751,7 +751,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv(SpmvArgs a)
 {
     if (MODE == RED_WAVE) {
         __shared__ FinishLds fl;
-        if (a.fin.seq) (void)finish_group(a.S, a.fin, a.fin.roles, blockIdx.x, gridDim.x, fl, nullptr);
+        if (a.fin.seq && (blockIdx.x < (unsigned)kShards || (a.fin.roles & FIN_APPLY))) (void)finish_group(a.S, a.fin, a.fin.roles, blockIdx.x, gridDim.x, fl, nullptr);
     }
     // The sticky convergence flag is requested here but only consumed where state would be
     // modified (y stores, dot publication): an early `if (done) return` would put one more
@@ -988,7 +988,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(MOD
 {
     if (MODE == RED_WAVE) {
         __shared__ FinishLds fl;
-        if (a.fin.seq) (void)finish_group(a.S, a.fin, a.fin.roles, blockIdx.x, gridDim.x, fl, nullptr);
+        if (a.fin.seq && (blockIdx.x < (unsigned)kShards || (a.fin.roles & FIN_APPLY))) (void)finish_group(a.S, a.fin, a.fin.roles, blockIdx.x, gridDim.x, fl, nullptr);
     }
     const int done = a.S->done;
     __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
@@ -1276,8 +1276,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
     if (MODE == RED_WAVE) {
         // a dot group of EARLIER kernels rides on this launch: its first workgroups add up the shards
         // (and hand the sums to the other ranks) while everybody else already streams the matrix
+        // (only the workgroups that have a part in it: the others would still wait for `done` inside finish_group before their
+        // first row -- one round trip per workgroup, 40.4 instead of 33.1 us per product of the pipelined iteration)
         __shared__ FinishLds fl;
-        if (a.fin.seq) (void)finish_group(a.S, a.fin, a.fin.roles, bid, nblocks, fl, nullptr);
+        if (a.fin.seq && (bid < (unsigned)kShards || (a.fin.roles & FIN_APPLY))) (void)finish_group(a.S, a.fin, a.fin.roles, bid, nblocks, fl, nullptr);
     }
 
     double acc[NDOT > 0 ? NDOT : 1];
