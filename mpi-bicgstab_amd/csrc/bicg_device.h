@@ -258,7 +258,16 @@ struct SellDev {
     // and no columns at all.
     const uint32_t *mbase;
     const unsigned short *rmask;
+    // One descriptor per slice for the blocks that have list-driven slices (PAD32C / PAD16C), so that a constant or masked slice
+    // costs ONE scalar load of metadata instead of five from five arrays, and the product can request the next group's
+    // descriptor while it multiplies the current one (a 7-entry slice of the Laplacian is three dependent round trips otherwise):
+    //   x = length | kind << 16   (kSliceGeneral: columns and values streamed, kSliceUniform: values streamed,
+    //                               kSliceConstant: y = position in uoff, z = position in uval,
+    //                               kSliceMasked: the same + w = index of the slice in rmask; length = the LIST's length)
+    // null: no descriptors (BICG_SELL_DESC=0, or 2^29 rows and more: the fast paths address x by 32-bit byte offsets).
+    const uint4 *sdesc;
 };
+enum SliceKind { kSliceGeneral = 0, kSliceUniform = 1, kSliceConstant = 2, kSliceMasked = 3 };
 // (PAD32C / PAD16C: padded slices of a block that has CONSTANT slices -- SellDev::vbase. Instantiations of their own: with the
 // value list as a run-time branch in every kernel, the dot-carrying products of blocks WITHOUT such slices paid 11 us each for
 // the registers it took, 45 -> 56 us on Transport)
@@ -441,6 +450,8 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
 // vectors per LDS window of the windowed form for `wslots` doubles per vector (0: the window does not fit, use launch_spmm_sell)
 int spmm_win_vectors(unsigned wslots);
 hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st);
+// direct form (k_spmm_dir, padded slices): the row heads in registers, x gathered from the shift-major vectors, no LDS window
+hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st);
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st);          // out[col] = sum_wg partial[wg][col]
 void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st);

@@ -1091,23 +1091,91 @@ __device__ __forceinline__ void sell_stage_window(const SpmvArgs &a, unsigned g,
     __syncthreads();
 }
 
+// A list-driven slice whose descriptor is known (SellDev::sdesc): the sum of one row of a CONSTANT slice (MASKED = false: every
+// row has every entry of the list) or of a MASKED slice (pm = the entries this lane's row has). Distances and values arrive as
+// scalar loads of whole batches (the lists are padded with zeros to a multiple of 8 + 16), x is addressed as
+// (uniform base) + (32-bit byte offset of the row): two vector instructions of arithmetic per entry next to its load,
+// where the general loop spent twenty-odd on a slice of the 7-point Laplacian. The entries are added in list = stored order, the
+// ones a row does not have are not added: the same sum, bit for bit, as the general loop's (reference src/matrix.c:506-515).
+// (the lists, the descriptors and the group list are read-only for every launch: loads through the constant address space are
+// scalar loads whatever the compiler can prove about the stores of the kernel)
+#define BICG_KCONST __attribute__((address_space(4)))
+struct SellPre { unsigned g; uint4 d; uint32_t pm; };      // group, descriptor and row mask of the wavefront's slice, requested ahead by the product
+typedef int sell_i8 __attribute__((ext_vector_type(8)));
+typedef unsigned sell_u4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ uint4 sell_desc_load(const uint4 *p)       // (a native vector type: uint4's copy constructor would drop the address space)
+{
+    const sell_u4 v = *(const BICG_KCONST sell_u4 *)p;
+    return make_uint4(v.x, v.y, v.z, v.w);
+}
+template <bool MASKED>
+__device__ __forceinline__ double sell_list_row(const double *__restrict__ x, uint32_t row, uint32_t len, const int *uo_g, const double *uv_g,
+                                                uint32_t pm)
+{
+    const BICG_KCONST int *uo = (const BICG_KCONST int *)uo_g;
+    const BICG_KCONST double *uv = (const BICG_KCONST double *)uv_g;
+    const uint32_t boff = row << 3;                               // rows < 2^29 (build_slice_desc)
+    double sum = 0.0;
+    for (uint32_t k0 = 0; k0 < len; k0 += 8) {
+        const sell_i8 o = *(const BICG_KCONST sell_i8 *)(uo + k0);
+        double v[8], xv[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) v[e] = uv[k0 + e];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            if (MASKED) {
+                // an absent neighbour may lie outside the vector: the lane reads x of its own row instead
+                const uint32_t off = ((pm >> (k0 + e)) & 1u) ? (uint32_t)o[e] << 3 : 0u;
+                xv[e] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (uint32_t)(boff + off));
+            } else {
+                xv[e] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x + o[e]) + boff);   // (padding: distance 0)
+            }
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            if (MASKED ? ((pm >> (k0 + e)) & 1u) != 0u : k0 + e < len) sum += v[e] * xv[e];
+    }
+    return sum;
+}
+
 template <bool OFFD, bool NT, int LAY, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
 __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed,
-                                           const double *win = nullptr)
+                                           const double *win = nullptr, bool have_pre = false, SellPre pre = SellPre{0u, {0u, 0u, 0u, 0u}, 0u})
 {
     constexpr bool WIN = LAY == LAY_JAGW, C16 = (LAY & 1) != 0 || WIN, JAG = LAY >= LAY_JAG32 && LAY <= LAY_JAGW, CONSTV = LAY >= LAY_PAD32C;
     // (the wavefront's number as a SCALAR: the slice's base, length and list positions then come through the scalar cache and the
     // tests on them are scalar branches -- as a vector value the compiler masked and unmasked lanes around every entry)
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const double *__restrict__ x = a.x;
-    const unsigned g = a.glist ? a.glist[gi] : gi;
+    const unsigned g = have_pre ? pre.g : (a.glist ? a.glist[gi] : gi);
     row = g * kGroupRows + tid;                                // = slice * 64 + lane
     if (LAY == LAY_JAGW && a.sell.perm) row = g * kGroupRows + a.sell.perm[(size_t)g * kGroupRows + tid];
     const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
     live = row < a.nrows;
 
+    // constant and masked slices by their descriptor (SellDev::sdesc): all 64 rows exist, nothing else of the slice's
+    // metadata is read
+    bool listed = false;
+    double lsum = 0.0;
+    if (CONSTV && a.sell.sdesc && slice * kSliceRows < a.nrows) {
+        uint4 d;
+        if (have_pre) d = pre.d;
+        else {
+            d = sell_desc_load(a.sell.sdesc + slice);
+        }
+        const uint32_t kind = d.x >> 16, dlen = d.x & 0xFFFFu;
+        if (kind == kSliceConstant) {
+            listed = true;
+            lsum = sell_list_row<false>(x, row, dlen, a.sell.uoff + d.y, a.sell.uval + d.z, 0u);
+        } else if (kind == kSliceMasked) {
+            listed = true;
+            const uint32_t pm = have_pre ? pre.pm : (uint32_t)a.sell.rmask[(size_t)d.w * kSliceRows + lane];
+            lsum = sell_list_row<true>(x, row, dlen, a.sell.uoff + d.y, a.sell.uval + d.z, pm);
+        }
+    }
+
     uint32_t base = 0u, len = 0u, base16 = 0u;
-    if (slice * kSliceRows < a.nrows) {
+    if (slice * kSliceRows < a.nrows && !(CONSTV && listed)) {
         base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
         if (C16 && !JAG) base16 = a.sell.slice_base16[slice];
     }
@@ -1115,7 +1183,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
     // Same loop as the padded slices (one body: a second copy of it cost the ticket-mode kernels three spilled registers)
     const int *__restrict__ uo = nullptr;                         // padded with zeros to a multiple of U (+ U)
     const double *__restrict__ uv = nullptr;                      // constant slice: the values too (padded with zeros alike)
-    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows) {
+    if (!JAG && a.sell.ubase && slice * kSliceRows < a.nrows && !(CONSTV && listed)) {
         const uint32_t ub = (uint32_t)__builtin_amdgcn_readfirstlane((int)a.sell.ubase[slice]);
         if (ub != 0xFFFFFFFFu) {
             uo = a.sell.uoff + ub;
@@ -1139,7 +1207,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
     // (a list-driven slice knows its rows' lengths: all equal to the slice's, or given by the masks -- no row-pointer loads)
     uint32_t mylen = 0u, oa = 0u, ob = 0u;
     if (live) {
-        mylen = uo ? len : a.diag.ptr[row + 1] - a.diag.ptr[row];
+        mylen = (uo || (CONSTV && listed)) ? len : a.diag.ptr[row + 1] - a.diag.ptr[row];
         if (OFFD && (!LL || gi >= a.ll.first_bnd)) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
     }
 
@@ -1229,6 +1297,7 @@ __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int d
         for (int e = 0; e < U; ++e)
             if ((CONSTV && masked) ? ((pm >> (k0 + e)) & 1u) != 0u : k0 + e < mylen) sum += v[e] * xv[e];   // stored order; padding never added
     }
+    if (CONSTV && listed) sum = lsum;
     double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
     if (OFFD) {
         double so = 0.0;
@@ -1297,17 +1366,63 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
     const unsigned each = LL ? 1u : (a.nlist + nblocks - 1u) / nblocks;
     const unsigned slot = LL ? bid : vb;
     const unsigned gfirst = LL ? bid : vb * each, gend = LL ? a.nlist : (gfirst + each < a.nlist ? gfirst + each : a.nlist);
+    // Blocks with list-driven slices (SellDev::sdesc): what a wavefront needs to know about its next slices is requested while
+    // it multiplies the current one -- the group number three groups ahead, the descriptor two ahead, the row masks one ahead --
+    // so that a constant or masked slice is the scalar loads of its lists (scalar cache) and ONE vector round trip, the x gathers,
+    // instead of four dependent trips (group, metadata, lists / masks, x). The requests are VECTOR loads of wave-uniform
+    // addresses on purpose: vector loads return in order and are waited for by count, so they stay in flight across the product
+    // of the current slice; scalar loads can only be waited for all at once, i.e. at the very next scalar load.
+    constexpr bool PRE = LAY >= LAY_PAD32C && !LL;
+    const bool pre_on = PRE && a.sell.sdesc != nullptr;
+    unsigned vzero = 0u;
+    if (PRE) asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero the compiler takes for lane-dependent
+    const unsigned wvec = threadIdx.x >> 6;
+    auto group_idx = [&](unsigned q) -> unsigned { return a.reverse ? gfirst + (gend - 1u - q) : q; };      // (q < gend)
+    auto group_vec = [&](unsigned q) -> unsigned { return a.glist ? a.glist[group_idx(q) + vzero] : group_idx(q); };
+    auto desc_vec = [&](unsigned g) -> uint4 {
+        const uint32_t sl = g * (kGroupRows / kSliceRows) + wvec;
+        uint4 d = make_uint4(0u, 0u, 0u, 0u);
+        if (sl * kSliceRows < a.nrows) d = a.sell.sdesc[sl];
+        return d;
+    };
+    auto first_lane = [](uint4 v) -> uint4 {
+        return make_uint4((uint32_t)__builtin_amdgcn_readfirstlane((int)v.x), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.y),
+                          (uint32_t)__builtin_amdgcn_readfirstlane((int)v.z), (uint32_t)__builtin_amdgcn_readfirstlane((int)v.w));
+    };
+    auto mask_vec = [&](const uint4 &d) -> uint32_t {
+        return (d.x >> 16) == (uint32_t)kSliceMasked ? (uint32_t)a.sell.rmask[(size_t)d.w * kSliceRows + (threadIdx.x & 63u)] : 0u;
+    };
+    SellPre pcur = {0u, make_uint4(0u, 0u, 0u, 0u), 0u};
+    unsigned g1 = 0u, gv2 = 0u;                                   // group of the next slice (scalar), of the one after it (as loaded)
+    uint4 dv1 = make_uint4(0u, 0u, 0u, 0u);                       // descriptor of the next slice (as loaded)
+    if (PRE && pre_on && gfirst < gend) {
+        pcur.g = (unsigned)__builtin_amdgcn_readfirstlane((int)group_vec(gfirst));
+        pcur.d = first_lane(desc_vec(pcur.g));
+        pcur.pm = mask_vec(pcur.d);
+        if (gfirst + 1u < gend) { g1 = (unsigned)__builtin_amdgcn_readfirstlane((int)group_vec(gfirst + 1u)); dv1 = desc_vec(g1); }
+        if (gfirst + 2u < gend) gv2 = group_vec(gfirst + 2u);
+    }
     for (unsigned gq = gfirst; gq < gend; gq += LL ? nblocks : 1u) {
         const unsigned gi = (a.reverse && !LL) ? gfirst + (gend - 1u - gq) : gq;      // a reversed product walks its groups backwards too
         uint32_t row;
         bool live;
         if (LAY == LAY_JAGW) sell_stage_window(a, a.glist ? a.glist[gi] : gi, dyn_lds);
+        SellPre pnext = pcur;
+        unsigned g2 = 0u;
+        if (PRE && pre_on) {
+            pnext.g = g1; pnext.d = first_lane(dv1);              // (arrived during the previous slice)
+            g2 = (unsigned)__builtin_amdgcn_readfirstlane((int)gv2);
+            pnext.pm = gq + 1u < gend ? mask_vec(pnext.d) : 0u;
+            if (gq + 2u < gend) dv1 = desc_vec(g2);
+            if (gq + 3u < gend) gv2 = group_vec(gq + 3u);
+        }
         // the dot operand of this lane's row is requested BEFORE the row product (one load in front of the product's
         // batches; after it, it was a dependent round trip at the very end of every workgroup)
         double upre = 0.0;
-        const uint32_t rguess = (a.glist ? a.glist[gi] : gi) * kGroupRows + threadIdx.x;
+        const uint32_t rguess = ((PRE && pre_on) ? pcur.g : (a.glist ? a.glist[gi] : gi)) * kGroupRows + threadIdx.x;
         if (NDOT >= 1 && rguess < a.nrows) upre = a.u[rguess];
-        const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed, dyn_lds);
+        const double yi = sell_row<OFFD, NT, LAY, LL>(a, gi, done, row, live, ll_failed, dyn_lds, PRE && pre_on, pcur);
+        if (PRE && pre_on) { pcur = pnext; g1 = g2; }
         if (live && !done) a.y[row] = yi;
         if (NDOT >= 1 && live) {
             const double ume = row == rguess ? upre : a.u[row];
@@ -2168,6 +2283,160 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Direct SpMM (round 4, padded slices): the head of every row -- value and column of its first 16 entries, the whole row for
+// banded / stencil matrices -- is loaded ONCE into registers, and the row is then multiplied with one vector after the other
+// straight from the shift-major vectors: consecutive lanes gather consecutive x values (lane = row, as in the SpMV), so a
+// wavefront's gather is four or five cache lines, not sixty-four as in the row-major kernel, there is no LDS window to stage,
+// no barrier, and two vectors' gathers are in flight per lane. The matrix is read once, X once per row that touches it through
+// the caches, Y written once; per row and vector the sum runs in stored order like mult() (reference src/matrix.c:506-515):
+// every column is bit-identical to bicg_spmv of that vector. (BICG_SPMM_WIN=2; rows longer than 16 stream their tail per vector.)
+// ------------------------------------------------------------------------------------------
+template <bool C16, bool OFFD>
+__global__ void __launch_bounds__(kBlock) k_spmm_dir(SpmmArgs a)
+{
+    constexpr int K = 16, U = 8, NVD = 2;
+    __shared__ double sm[(kBlock / 64) * kSpmmCols];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    unsigned g = blockIdx.x;
+    if (a.xcd_map) {
+        const unsigned per = (a.ngroups + 7u) / 8u;
+        g = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
+    }
+    if (a.b && tid < (unsigned)kSpmmCols && (g >= a.ngroups || (int)tid >= a.nvec)) a.partial[(size_t)blockIdx.x * kSpmmCols + tid] = 0.0;
+    if (g >= a.ngroups) return;                               // (grid padded to a multiple of 8: workgroup-uniform)
+    const uint32_t row = g * kGroupRows + tid;
+    const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
+    const bool live = row < a.nrows;
+    const uint32_t rb = live ? row : 0u;                      // lanes past the last row hold padding: they read x of row 0, add nothing
+    uint32_t base = 0u, len = 0u, base16 = 0u;
+    if (slice * kSliceRows < a.nrows) {
+        base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
+        if (C16) base16 = a.sell.slice_base16[slice];
+    }
+    const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
+    uint32_t oa = 0u, ob = 0u;
+    if (OFFD && live) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
+    const double bi = (a.b && live) ? a.b[row] : 0.0;
+    const i16x4 *const q16 = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + lane);
+
+    // (x is addressed as uniform base + 32-bit byte offset -- spmm_possible: stride < 2^25 rows -- so the head's columns cost 16
+    // registers, not a 64-bit address per entry and vector)
+    auto at = [](const double *xb, uint32_t byte_off) -> double {
+        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xb) + byte_off);
+    };
+    double hv[K];
+    uint32_t hc[K];                                           // byte offsets
+    unsigned hon = 0u;
+    if (C16) {
+#pragma unroll
+        for (int q = 0; q < K / 4; ++q) {
+            i16x4 dq = (i16x4)(0);
+            if ((uint32_t)(4 * q) < len) dq = q16[(size_t)q * kSliceRows];        // wave-uniform test; the quad is padded
+            hc[4 * q + 0] = rb + (int)dq.x; hc[4 * q + 1] = rb + (int)dq.y; hc[4 * q + 2] = rb + (int)dq.z; hc[4 * q + 3] = rb + (int)dq.w;
+        }
+    }
+#pragma unroll
+    for (int e = 0; e < K; ++e) {
+        const bool in = (uint32_t)e < len;                    // wave-uniform
+        if (!C16) hc[e] = in ? a.sell.col[base + (uint32_t)e * kSliceRows + lane] : rb;
+        hv[e] = in ? a.sell.val[base + (uint32_t)e * kSliceRows + lane] : 0.0;
+        if ((uint32_t)e < mylen) hon |= 1u << e; else hc[e] = rb;      // padding: the row's own column, never added
+        hc[e] <<= 3;
+    }
+
+    for (int v0 = 0; v0 < a.nvec; v0 += NVD) {
+        const double *xv[NVD];
+#pragma unroll
+        for (int v = 0; v < NVD; ++v) xv[v] = a.xs + (size_t)(v0 + v < a.nvec ? v0 + v : a.nvec - 1) * a.vstride;
+        double acc[NVD];
+#pragma unroll
+        for (int v = 0; v < NVD; ++v) acc[v] = 0.0;
+        // (the offsets are made opaque once per pass: their 64-bit extensions are loop invariants otherwise, 32 more registers and
+        // an address addition per load instead of the base + 32-bit offset form)
+#pragma unroll
+        for (int e = 0; e < K; ++e) asm volatile("" : "+v"(hc[e]));
+        auto half = [&](int e0) {
+            double xr[NVD][K / 2];
+#pragma unroll
+            for (int v = 0; v < NVD; ++v)
+#pragma unroll
+                for (int e = 0; e < K / 2; ++e) xr[v][e] = at(xv[v], hc[e0 + e]);
+#pragma unroll
+            for (int e = 0; e < K / 2; ++e) {
+                const bool on = (hon >> (e0 + e)) & 1u;
+#pragma unroll
+                for (int v = 0; v < NVD; ++v) {
+                    const double t = acc[v] + hv[e0 + e] * xr[v][e];      // stored order; padding never added
+                    acc[v] = on ? t : acc[v];
+                }
+            }
+        };
+        half(0);
+        if (len > (uint32_t)(K / 2)) half(K / 2);
+        for (uint32_t k0 = K; k0 < len; k0 += U) {            // rows longer than the head: streamed once per pair of vectors
+            double val[U];
+            uint32_t cc[U];
+            if (C16) {
+#pragma unroll
+                for (int q = 0; q < U / 4; ++q) {
+                    i16x4 dq = (i16x4)(0);
+                    if (k0 + 4 * q < len) dq = q16[(size_t)(k0 / 4 + q) * kSliceRows];
+                    cc[4 * q + 0] = rb + (int)dq.x; cc[4 * q + 1] = rb + (int)dq.y; cc[4 * q + 2] = rb + (int)dq.z; cc[4 * q + 3] = rb + (int)dq.w;
+                }
+            }
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const bool in = k0 + e < len;
+                if (!C16) cc[e] = in ? a.sell.col[base + (k0 + e) * kSliceRows + lane] : rb;
+                val[e] = in ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
+                if (!(k0 + e < mylen)) cc[e] = rb;
+            }
+            double xr[NVD][U];
+#pragma unroll
+            for (int v = 0; v < NVD; ++v)
+#pragma unroll
+                for (int e = 0; e < U; ++e) xr[v][e] = at(xv[v], cc[e] << 3);
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const bool on = k0 + e < mylen;
+#pragma unroll
+                for (int v = 0; v < NVD; ++v) {
+                    const double t = acc[v] + val[e] * xr[v][e];          // stored order
+                    acc[v] = on ? t : acc[v];
+                }
+            }
+        }
+#pragma unroll
+        for (int v = 0; v < NVD; ++v) {
+            double r2 = 0.0;
+            if (v0 + v < a.nvec && live) {
+                double y = 0.0 + acc[v];                      // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+                if (OFFD) {
+                    double so = 0.0;
+                    for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * xv[v][a.offd.col[k]];
+                    y += so;                                  // second mult() call, src/matrix.c:440
+                }
+                if (a.sigma) y += a.sigma[v0 + v] * xv[v][row];            // += sigma_j x_j (src/test_shifted.c:133)
+                if (a.ys) a.ys[(size_t)(v0 + v) * a.vstride + row] = y;
+                if (a.b) { const double dd = (bi + (-1.0) * y) - 0.0; r2 = dd * dd; }
+            }
+            if (a.b) {
+                const double t = wave_sum(r2);
+                if (lane == 0 && v0 + v < a.nvec) sm[wave * kSpmmCols + v0 + v] = t;
+            }
+        }
+    }
+    if (a.b) {
+        __syncthreads();
+        if ((int)tid < a.nvec) {
+            double t = sm[tid];
+            for (int w = 1; w < kBlock / 64; ++w) t += sm[w * kSpmmCols + tid];
+            a.partial[(size_t)blockIdx.x * kSpmmCols + tid] = t;
+        }
+    }
+}
+
 // out[col] = sum over workgroups of partial[wg][col], fixed order; one workgroup per column
 __global__ void __launch_bounds__(kBlock) k_colsum(const double *partial, unsigned nwg, double *out)
 {
@@ -2268,6 +2537,16 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
     const hipError_t err = nv == 8 ? WIN_GO(8) : WIN_GO(4);
 #undef WIN_GO
     return err;
+}
+hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st)
+{
+    if (a.ngroups == 0) return hipSuccess;
+    if (a.sell.jag || a.sell.win_slots) return hipErrorInvalidValue;      // padded slices only
+    const unsigned grid = a.xcd_map ? ((a.ngroups + 7u) / 8u) * 8u : a.ngroups;
+    const bool c16 = a.sell.col16 != nullptr;
+    if (c16) { if (with_offd) hipLaunchKernelGGL((k_spmm_dir<true, true>), dim3(grid), dim3(kBlock), 0, st, a); else hipLaunchKernelGGL((k_spmm_dir<true, false>), dim3(grid), dim3(kBlock), 0, st, a); }
+    else     { if (with_offd) hipLaunchKernelGGL((k_spmm_dir<false, true>), dim3(grid), dim3(kBlock), 0, st, a); else hipLaunchKernelGGL((k_spmm_dir<false, false>), dim3(grid), dim3(kBlock), 0, st, a); }
+    return hipGetLastError();
 }
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)

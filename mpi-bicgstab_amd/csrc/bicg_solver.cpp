@@ -97,6 +97,7 @@ struct bicg_ctx {
     uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_SELL_MASKED=0 switches them off
     unsigned short *s_rmask = nullptr;
     uint64_t masked_rows = 0;
+    uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
     double *s_uval = nullptr;
     uint64_t constant_entries = 0;         // ... whose values it does not read either
@@ -526,6 +527,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval; a.sell.mbase = c->s_mbase; a.sell.rmask = c->s_rmask;
+    a.sell.sdesc = c->s_desc;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -730,7 +732,9 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
     // the windowed form (k_spmm_win) reads the shift-major vectors directly and writes Y shift-major into mm_yt
     const unsigned wslots = c->win_slots ? c->win_slots : (c->s_col16 && !c->sell_jag && c->fw.ncl > 0 ? c->fw.slots : 0u);
-    c->mm_win = c->mm_win_env != 0 && spmm_win_vectors(wslots) > 0;
+    // (BICG_SPMM_WIN=2: the direct form for padded slices -- row heads in registers, gathers from the shift-major vectors)
+    const bool direct = c->mm_win_env == 2 && !c->sell_jag && !c->win_slots;
+    c->mm_win = direct || (c->mm_win_env != 0 && spmm_win_vectors(wslots) > 0);
     if (!c->mm_win) launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
@@ -745,7 +749,10 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
         BICG_HIP(hipStreamSynchronize(c->sc));     // sg lives on this stack frame
         a.sigma = c->mm_sigma;
     }
-    if (c->mm_win) {
+    if (direct) {
+        a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec;
+        if (launch_spmm_dir(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the direct kernel could not be launched");
+    } else if (c->mm_win) {
         a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
         if (!c->win_slots) a.cl = c->fw;
         if (launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_SPMM_WIN=0 selects the row-major form)");
@@ -808,6 +815,29 @@ void group_flush(bicg_ctx *c)
 
 void fetch_scal(bicg_ctx *c);
 }  // namespace
+// One descriptor per slice (SellDev::sdesc) from the per-slice arrays of the plan: blocks with list-driven slices only
+static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const uint32_t *slice_len, const std::vector<uint32_t> &ubase,
+                             const std::vector<uint32_t> &vbase, const std::vector<uint32_t> &mbase)
+{
+    if (vbase.empty() || ubase.empty() || (uint64_t)nrows >= (1ull << 29)) return;
+    if (getenv("BICG_SELL_DESC") && atoi(getenv("BICG_SELL_DESC")) == 0) return;
+    std::vector<uint4> d(nslices);
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        const uint32_t ub = ubase[sl], vb = vbase[sl], mb = mbase.empty() ? 0xFFFFFFFFu : mbase[sl];
+        uint32_t len = slice_len[sl] & 0xFFFFu, kind = kSliceGeneral, w = 0;
+        if (ub != 0xFFFFFFFFu && slice_len[sl] <= 0xFFFFu) {
+            kind = kSliceUniform;
+            if (vb != 0xFFFFFFFFu) {
+                kind = kSliceConstant;
+                if (mb != 0xFFFFFFFFu) { kind = kSliceMasked; len = mb >> 26; w = mb & 0x03FFFFFFu; }
+            }
+        }
+        d[sl] = make_uint4(len | (kind << 16), kind >= kSliceConstant ? ub : 0u, kind >= kSliceConstant ? vb : 0u, w);
+    }
+    c->s_desc = dev_upload(d.data(), d.size());
+    c->matrix_bytes += 8ull * nslices;          // 16 bytes of descriptor per slice where base + length were counted
+}
+
 void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups);
 bool persist_chunk(bicg_ctx *c, int niter);
 bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, int seed, double shift);
@@ -1832,22 +1862,22 @@ int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, do
 void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups)
 {
     if (!getenv("BICG_SELL_GPW") && !getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw = c->sell_gpw_dots = (int)std::max<uint32_t>(1u, (ngroups + 65535u) / 65536u);
+    if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = std::max(1, atoi(sv));
+    if (const char *sv = getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = std::max(1, atoi(sv));
     const uint32_t B = getenv("BICG_SELL_BLOCK") ? (uint32_t)atoi(getenv("BICG_SELL_BLOCK")) : 256u;
     const uint32_t P = (c->far_rows + kGroupRows / 2) / kGroupRows;          // groups per plane
     if (B == 0 || P < 4 * B || c->sell_gpw != c->sell_gpw_dots || (uint64_t)c->far_rows * 24ull <= (3ull << 19)) return;   // three planes fit half an L2
     const uint32_t nblocks = sell_grid(ngroups, c->sell_gpw), each = (ngroups + nblocks - 1) / nblocks;
     std::vector<uint32_t> list(ngroups);
-    std::vector<uint32_t> seg;
     for (uint32_t x = 0; x <= 8; ++x) {
+        // XCD x's share of the list (the last segment: what the division left over); within it block y of every plane, plane
+        // after plane, then block y + 1 ... -- the order a sort by (block, group) would give, enumerated directly
         const uint32_t s0 = std::min<uint64_t>(ngroups, (uint64_t)x * (nblocks / 8u) * each);
         const uint32_t s1 = x == 8 ? ngroups : std::min<uint64_t>(ngroups, (uint64_t)(x + 1) * (nblocks / 8u) * each);
-        seg.resize(s1 - s0);
-        for (uint32_t i = 0; i < s1 - s0; ++i) seg[i] = s0 + i;
-        std::stable_sort(seg.begin(), seg.end(), [&](uint32_t ga, uint32_t gb) {
-            const uint32_t ya = ((ga - s0) % P) / B, yb = ((gb - s0) % P) / B;
-            return ya != yb ? ya < yb : ga < gb;
-        });
-        std::copy(seg.begin(), seg.end(), list.begin() + s0);
+        uint32_t o = s0;
+        for (uint32_t y0 = 0; y0 < P && o < s1; y0 += B)
+            for (uint64_t z0 = s0; z0 < s1; z0 += P)
+                for (uint64_t g = z0 + y0; g < std::min<uint64_t>({(uint64_t)s1, z0 + y0 + B, z0 + P}); ++g) list[o++] = (uint32_t)g;
     }
     if (c->glist_int) BICG_HIP(hipFree(c->glist_int));
     c->glist_int = dev_upload(list.data(), list.size());
@@ -2645,6 +2675,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->s_ubase = dev_upload(ubase.data(), ubase.size());
         c->s_uoff = dev_upload(uoff.data(), uoff.size());
     }
+    build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase);
     c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
@@ -2820,7 +2851,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         BICG_HIP(hipMemcpy(uh.data(), uh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
         BICG_HIP(hipMemcpy(vh.data(), vh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
         BICG_HIP(hipFree(uh_d));
-        std::vector<uint32_t> vbase;
+        std::vector<uint32_t> vbase, mbase;
         std::vector<double> uval, vals;
         std::map<unsigned long long, uint32_t> vlists;
         std::vector<uint32_t> ubase(nslices, 0xFFFFFFFFu);
@@ -2871,7 +2902,6 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
             std::vector<unsigned long long> mh(nslices);
             BICG_HIP(hipMemcpy(mh.data(), mh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
             BICG_HIP(hipFree(mh_d));
-            std::vector<uint32_t> mbase;
             std::map<unsigned long long, std::pair<uint32_t, uint32_t>> mlists;       // hash -> (position in uoff, position in uval)
             std::vector<uint32_t> rp(kSliceRows + 1), rc;
             std::vector<double> rv;
@@ -2919,6 +2949,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         if (constant_entries) {
             c->s_vbase = dev_upload(vbase.data(), vbase.size());
             c->s_uval = dev_upload(uval.data(), uval.size());
+            build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase);
         }
     }
     c->uniform_entries = uniform_entries;
@@ -2937,6 +2968,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->glist_int_identity = true; c->glist_all = true;
     sell_order_for_big_grids(c, ngroups);
     c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 2ull * c->masked_rows + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
+    if (c->s_desc) c->matrix_bytes += 8ull * nslices;
     c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
     BICG_HIP(hipFree(far_d));
     ctx_state(c, comm, ngroups);
@@ -2980,7 +3012,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);

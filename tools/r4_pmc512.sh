@@ -6,7 +6,7 @@ R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/r4pmc512
 rm -rf $OUT; mkdir -p $OUT
 cfg=0
-for env in "BICG_SELL_BLOCK=128" "BICG_SELL_BLOCK=0"; do
+for env in ${PMC512_ENVS:-"BICG_SELL_BLOCK=128" "BICG_SELL_BLOCK=0"}; do
   cfg=$((cfg+1)); i=0
   while read -r set; do
     [ -z "$set" ] && continue
@@ -24,7 +24,7 @@ SETS
 done
 python - > $OUT/summary.txt <<PY
 import csv, glob, collections
-names = {1: "plane-block order (B = 128)", 2: "natural order"}
+names = {1: "first setting of PMC512_ENVS (default: plane-block order, B = 128)", 2: "second setting (default: natural order)"}
 for cfg in (1, 2):
     print("==", names[cfg])
     for f in sorted(glob.glob("$OUT/c%d_p*/**/p_counter_collection.csv" % cfg, recursive=True)):
