@@ -266,6 +266,11 @@ struct SellDev {
     //                               kSliceMasked: the same + w = index of the slice in rmask; length = the LIST's length)
     // null: no descriptors (BICG_SELL_DESC=0, or 2^29 rows and more: the fast paths address x by 32-bit byte offsets).
     const uint4 *sdesc;
+    // whole 256-row groups only, and every slice is constant or masked with a list of at most 8 entries (a constant-coefficient stencil: the
+    // 7-point Laplacian of BASELINE.json configs[3]): the product runs a loop of its own over the descriptors -- list lengths
+    // as compile-time cases, the distances as byte offsets (uoff8[i] = 8 uoff[i]) added to the row's 32-bit byte offset
+    int all_lists;
+    const int *uoff8;
 };
 enum SliceKind { kSliceGeneral = 0, kSliceUniform = 1, kSliceConstant = 2, kSliceMasked = 3 };
 // (PAD32C / PAD16C: padded slices of a block that has CONSTANT slices -- SellDev::vbase. Instantiations of their own: with the

@@ -1138,6 +1138,47 @@ __device__ __forceinline__ double sell_list_row(const double *__restrict__ x, ui
     return sum;
 }
 
+// The same sum for a list of exactly N <= 8 entries (SellDev::all_lists): no loop, no tests of the length; the distances arrive as
+// byte offsets (SellDev::uoff8) and are added to the row's byte offset modulo 2^32 -- one vector addition per entry, the load
+// takes (uniform base of x) + (32-bit offset). o8 / v: the list, already in scalar registers (the caller keeps the list of the
+// previous slice: the interior of a stencil has ONE).
+template <int N, bool MASKED>
+__device__ __forceinline__ double sell_list_fixed(const double *x, uint32_t boff, const sell_i8 &o8, const double (&v)[8], uint32_t pm,
+                                                  double *yp, double yv)
+{
+    double xv[N];
+#pragma unroll
+    for (int e = 0; e < N; ++e) {
+        const uint32_t off = (!MASKED || ((pm >> e) & 1u)) ? (uint32_t)o8[e] : 0u;      // (an absent neighbour may lie outside the vector)
+        xv[e] = *reinterpret_cast<const double *>(reinterpret_cast<const char *>(x) + (uint32_t)(boff + off));
+    }
+    // the PREVIOUS slice's result is stored here, behind this slice's gathers: issued right after its own slice it would be the
+    // youngest request in flight when the loop comes round, and the wait for the next descriptor (vector loads return in order)
+    // a wait for the store's acknowledgement. (Unconditional: with a path that does not store, the wait for the last gather
+    // becomes a wait for everything.)
+    *yp = yv;
+    double sum = 0.0;
+#pragma unroll
+    for (int e = 0; e < N; ++e)
+        if (!MASKED || ((pm >> e) & 1u) != 0u) sum += v[e] * xv[e];                       // list = stored order
+    return sum;
+}
+template <bool MASKED>
+__device__ __forceinline__ double sell_list_switch(uint32_t len, const double *x, uint32_t boff, const sell_i8 &o8, const double (&v)[8], uint32_t pm,
+                                                   double *yp, double yv)
+{
+    switch (len) {                                                // wave-uniform
+    case 1: return sell_list_fixed<1, MASKED>(x, boff, o8, v, pm, yp, yv);
+    case 2: return sell_list_fixed<2, MASKED>(x, boff, o8, v, pm, yp, yv);
+    case 3: return sell_list_fixed<3, MASKED>(x, boff, o8, v, pm, yp, yv);
+    case 4: return sell_list_fixed<4, MASKED>(x, boff, o8, v, pm, yp, yv);
+    case 5: return sell_list_fixed<5, MASKED>(x, boff, o8, v, pm, yp, yv);
+    case 6: return sell_list_fixed<6, MASKED>(x, boff, o8, v, pm, yp, yv);
+    case 7: return sell_list_fixed<7, MASKED>(x, boff, o8, v, pm, yp, yv);
+    default: return sell_list_fixed<8, MASKED>(x, boff, o8, v, pm, yp, yv);
+    }
+}
+
 template <bool OFFD, bool NT, int LAY, bool LL, int U = 8>      // U entries per lane in flight (4, 8, 16 measured identical on Transport)
 __device__ __forceinline__ double sell_row(const SpmvArgs &a, unsigned gi, int done, uint32_t &row, bool &live, bool &ll_failed,
                                            const double *win = nullptr, bool have_pre = false, SellPre pre = SellPre{0u, {0u, 0u, 0u, 0u}, 0u})
@@ -1402,7 +1443,55 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
         if (gfirst + 1u < gend) { g1 = (unsigned)__builtin_amdgcn_readfirstlane((int)group_vec(gfirst + 1u)); dv1 = desc_vec(g1); }
         if (gfirst + 2u < gend) gv2 = group_vec(gfirst + 2u);
     }
-    for (unsigned gq = gfirst; gq < gend; gq += LL ? nblocks : 1u) {
+    // Every slice list-driven, lists of at most 8 entries (SellDev::all_lists -- a constant-coefficient stencil): a loop of its own.
+    // Per slice: the descriptor (requested two slices ahead), the lists only when they are not the previous slice's, N gathers of
+    // a compile-time N, N products; 85 vector + 134 scalar instructions per slice of the 7-point Laplacian went through
+    // sell_row (rocprofv3: the scalar unit busy half of the time, waves waiting for memory a fifth of theirs).
+    const bool lean = PRE && pre_on && a.sell.all_lists != 0 && !OFFD && !a.has_shift;
+    if (PRE && !OFFD && lean && !done && gfirst < gend) {         // (done: nothing is stored and nothing published -- nothing to do)
+        const double *__restrict__ x = a.x;
+        const unsigned last = gend - 1u;                          // (requests past the workgroup's last group repeat it: no tests)
+        uint32_t cy = 0xFFFFFFFFu, cz = 0xFFFFFFFFu;              // the lists in registers
+        sell_i8 o8 = (sell_i8)(0);
+        double lv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
+        double *yp = a.y + (pcur.g * kGroupRows + threadIdx.x);   // where the previous slice's result goes (first slice: a zero
+        double yv = 0.0;                                          // into its own row, overwritten by its result one slice later)
+        for (unsigned gq = gfirst; gq < gend; ++gq) {
+            SellPre pnext;
+            pnext.g = g1; pnext.d = first_lane(dv1);              // (arrived during the previous slice)
+            const unsigned g2 = (unsigned)__builtin_amdgcn_readfirstlane((int)gv2);
+            pnext.pm = mask_vec(pnext.d);
+            dv1 = desc_vec(g2);
+            gv2 = group_vec(gq + 3u < last ? gq + 3u : last);
+            const uint32_t row = pcur.g * kGroupRows + threadIdx.x;
+            const uint32_t kind = pcur.d.x >> 16, len = pcur.d.x & 0xFFFFu;
+            {                                                     // (no slice without rows: build_slice_desc -- a path that requests
+                                                                  // nothing would make every wait of the loop a wait for everything)
+                double upre = 0.0;
+                if (NDOT >= 1) upre = a.u[row];
+                if (pcur.d.y != cy || pcur.d.z != cz) {
+                    cy = pcur.d.y; cz = pcur.d.z;
+                    o8 = *(const BICG_KCONST sell_i8 *)(a.sell.uoff8 + cy);
+                    const BICG_KCONST double *uv = (const BICG_KCONST double *)(a.sell.uval + cz);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) lv[e] = uv[e];
+                }
+                const uint32_t boff = row << 3;
+                const double sum = kind == (uint32_t)kSliceMasked ? sell_list_switch<true>(len, x, boff, o8, lv, pcur.pm, yp, yv)
+                                                                  : sell_list_switch<false>(len, x, boff, o8, lv, 0u, yp, yv);
+                const double yi = 0.0 + sum;                      // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+                yp = a.y + row; yv = yi;
+                if (NDOT >= 1) {
+                    acc[0] += upre * yi;
+                    if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+                    if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += upre * upre;
+                }
+            }
+            pcur = pnext; g1 = g2;
+        }
+        *yp = yv;
+    }
+    for (unsigned gq = gfirst; gq < gend && !(PRE && !OFFD && lean); gq += LL ? nblocks : 1u) {
         const unsigned gi = (a.reverse && !LL) ? gfirst + (gend - 1u - gq) : gq;      // a reversed product walks its groups backwards too
         uint32_t row;
         bool live;

@@ -97,6 +97,8 @@ struct bicg_ctx {
     uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_SELL_MASKED=0 switches them off
     unsigned short *s_rmask = nullptr;
     uint64_t masked_rows = 0;
+    int *s_uoff8 = nullptr;                // SellDev::uoff8
+    bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
     uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
     double *s_uval = nullptr;
@@ -527,7 +529,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval; a.sell.mbase = c->s_mbase; a.sell.rmask = c->s_rmask;
-    a.sell.sdesc = c->s_desc;
+    a.sell.sdesc = c->s_desc; a.sell.all_lists = c->sell_all_lists ? 1 : 0; a.sell.uoff8 = c->s_uoff8;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -817,11 +819,12 @@ void fetch_scal(bicg_ctx *c);
 }  // namespace
 // One descriptor per slice (SellDev::sdesc) from the per-slice arrays of the plan: blocks with list-driven slices only
 static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const uint32_t *slice_len, const std::vector<uint32_t> &ubase,
-                             const std::vector<uint32_t> &vbase, const std::vector<uint32_t> &mbase)
+                             const std::vector<uint32_t> &vbase, const std::vector<uint32_t> &mbase, const std::vector<int> &uoff)
 {
     if (vbase.empty() || ubase.empty() || (uint64_t)nrows >= (1ull << 29)) return;
     if (getenv("BICG_SELL_DESC") && atoi(getenv("BICG_SELL_DESC")) == 0) return;
     std::vector<uint4> d(nslices);
+    bool all_lists = !(getenv("BICG_SELL_LISTS") && atoi(getenv("BICG_SELL_LISTS")) == 0) && nrows % kGroupRows == 0;
     for (uint32_t sl = 0; sl < nslices; ++sl) {
         const uint32_t ub = ubase[sl], vb = vbase[sl], mb = mbase.empty() ? 0xFFFFFFFFu : mbase[sl];
         uint32_t len = slice_len[sl] & 0xFFFFu, kind = kSliceGeneral, w = 0;
@@ -833,6 +836,13 @@ static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, cons
             }
         }
         d[sl] = make_uint4(len | (kind << 16), kind >= kSliceConstant ? ub : 0u, kind >= kSliceConstant ? vb : 0u, w);
+        if ((uint64_t)sl * kSliceRows < nrows && (kind < kSliceConstant || len == 0 || len > 8u)) all_lists = false;
+    }
+    if (all_lists) {                              // (SellDev::all_lists: the distances once more, as byte offsets)
+        std::vector<int> u8(uoff.size());
+        for (size_t i = 0; i < uoff.size(); ++i) u8[i] = (int)((uint32_t)uoff[i] * 8u);      // (modulo 2^32: the product adds it to the row's byte offset modulo 2^32)
+        c->s_uoff8 = dev_upload(u8.data(), u8.size());
+        c->sell_all_lists = true;
     }
     c->s_desc = dev_upload(d.data(), d.size());
     c->matrix_bytes += 8ull * nslices;          // 16 bytes of descriptor per slice where base + length were counted
@@ -2675,7 +2685,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->s_ubase = dev_upload(ubase.data(), ubase.size());
         c->s_uoff = dev_upload(uoff.data(), uoff.size());
     }
-    build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase);
+    build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase, uoff);
     c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
@@ -2949,7 +2959,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         if (constant_entries) {
             c->s_vbase = dev_upload(vbase.data(), vbase.size());
             c->s_uval = dev_upload(uval.data(), uval.size());
-            build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase);
+            build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase, uoff);
         }
     }
     c->uniform_entries = uniform_entries;
@@ -3012,7 +3022,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
