@@ -378,6 +378,10 @@ long bicg_window_plan(const unsigned int *ptr, const unsigned int *col, unsigned
                       const char *group_mask, unsigned int max_slots, unsigned int gap, unsigned int *win_ptr,
                       unsigned int *runs, unsigned int *slots_used);
 unsigned int bicg_window_slot(const unsigned int *runs, unsigned int first, unsigned int end, unsigned int c);
+/* Host threads of the set-up (bicg_create's plan and bicg_window_plan cut their loops over slices / groups / rows into one range
+ * per thread; the results do not depend on the number). 0 < n: use n threads from now on; returns the number in use. Default:
+ * BICG_PLAN_THREADS, else the hardware's threads divided by the ranks of the job, at most 32. */
+int bicg_set_plan_threads(int n);
 
 /* Plan of the persistent iteration (host only, what bicg_create builds for latency-bound ranks): the
  * workgroups' slices as padded entries {value, 16-bit slot of the column in the workgroup's window}, diag entries first, then

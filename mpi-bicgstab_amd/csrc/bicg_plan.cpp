@@ -6,6 +6,7 @@
 //   bicg_row_blocks  greedy row blocks for the row-block-stream SpMV
 #include "../../include/bicgstab_hip.h"
 #include "bicg_plan.h"
+#include "bicg_parallel.h"
 
 #include <algorithm>
 #include <cstdint>
@@ -104,52 +105,74 @@ extern "C" unsigned int bicg_row_blocks(const unsigned int *ptr, unsigned int ro
 // touch, merged into runs of consecutive columns; gaps of up to `gap` unused values are copied along (cheaper than
 // another run). A run is {first column, (first slot << 16) | length}. Returns the number of runs, or -1 when some
 // group needs more than max_slots (<= 65535) slots. runs == NULL: count only. Host-only, O(nnz + column span / 64).
+// (groups are planned independently, on several threads; their runs are put together in group order afterwards)
 extern "C" long bicg_window_plan(const unsigned int *ptr, const unsigned int *col, unsigned int rows, unsigned int group_rows,
                                  const char *group_mask, unsigned int max_slots, unsigned int gap, unsigned int *win_ptr,
                                  unsigned int *runs, unsigned int *slots_used)
 {
     const unsigned ngroups = (rows + group_rows - 1) / group_rows;
-    std::vector<unsigned long long> bm;
-    std::vector<unsigned> cols;
+    struct Part { std::vector<unsigned> runs; std::vector<unsigned> count; unsigned most = 0; bool fail = false; size_t g0 = 0; };
+    std::vector<Part> parts((size_t)bicg::plan_threads());
+    const int np = bicg::parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int part) {
+        Part &P = parts[(size_t)part];
+        P.g0 = ga; P.count.assign(gb - ga, 0u);
+        std::vector<unsigned long long> bm;
+        std::vector<unsigned> cols;
+        for (size_t g = ga; g < gb && !P.fail; ++g) {
+            if (group_mask && !group_mask[g]) continue;
+            const unsigned r0 = (unsigned)g * group_rows, r1 = std::min(rows, r0 + group_rows);
+            const unsigned j0 = ptr[r0], j1 = ptr[r1];
+            if (j0 == j1) continue;
+            unsigned lo = 0xFFFFFFFFu, hi = 0;
+            for (unsigned j = j0; j < j1; ++j) { lo = std::min(lo, col[j]); hi = std::max(hi, col[j]); }
+            cols.clear();
+            if ((unsigned long long)hi - lo < (1ull << 24)) {       // a bitmap over the group's column span
+                bm.assign(((size_t)hi - lo) / 64 + 1, 0ull);
+                for (unsigned j = j0; j < j1; ++j) { const unsigned d = col[j] - lo; bm[d >> 6] |= 1ull << (d & 63); }
+                for (size_t w = 0; w < bm.size(); ++w)
+                    for (unsigned long long bits = bm[w]; bits; bits &= bits - 1)
+                        cols.push_back(lo + (unsigned)(w * 64) + (unsigned)__builtin_ctzll(bits));
+            } else {
+                cols.assign(col + j0, col + j1);
+                std::sort(cols.begin(), cols.end());
+                cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+            }
+            unsigned slots = 0, n = 0;
+            for (size_t i = 0; i < cols.size();) {
+                size_t k = i;
+                while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= gap + 1 && cols[k + 1] - cols[i] < 65535u) ++k;
+                const unsigned len = cols[k] - cols[i] + 1;
+                if (slots + len > max_slots || slots + len > 65535u) { P.fail = true; break; }
+                if (runs) { P.runs.push_back(cols[i]); P.runs.push_back((slots << 16) | len); }
+                ++n;
+                slots += len;
+                i = k + 1;
+            }
+            P.count[g - ga] = n;
+            P.most = std::max(P.most, slots);
+        }
+    });
     long nruns = 0;
     unsigned most = 0;
     if (win_ptr) win_ptr[0] = 0;
-    for (unsigned g = 0; g < ngroups; ++g) {
-        if (win_ptr) win_ptr[g + 1] = (unsigned)nruns;
-        if (group_mask && !group_mask[g]) continue;
-        const unsigned r0 = g * group_rows, r1 = std::min(rows, r0 + group_rows);
-        const unsigned j0 = ptr[r0], j1 = ptr[r1];
-        if (j0 == j1) continue;
-        unsigned lo = 0xFFFFFFFFu, hi = 0;
-        for (unsigned j = j0; j < j1; ++j) { lo = std::min(lo, col[j]); hi = std::max(hi, col[j]); }
-        cols.clear();
-        if ((unsigned long long)hi - lo < (1ull << 24)) {       // a bitmap over the group's column span
-            bm.assign(((size_t)hi - lo) / 64 + 1, 0ull);
-            for (unsigned j = j0; j < j1; ++j) { const unsigned d = col[j] - lo; bm[d >> 6] |= 1ull << (d & 63); }
-            for (size_t w = 0; w < bm.size(); ++w)
-                for (unsigned long long bits = bm[w]; bits; bits &= bits - 1)
-                    cols.push_back(lo + (unsigned)(w * 64) + (unsigned)__builtin_ctzll(bits));
-        } else {
-            cols.assign(col + j0, col + j1);
-            std::sort(cols.begin(), cols.end());
-            cols.erase(std::unique(cols.begin(), cols.end()), cols.end());
+    for (int p = 0; p < np; ++p) {
+        const Part &P = parts[(size_t)p];
+        if (P.fail) return -1;
+        if (runs && !P.runs.empty()) std::copy(P.runs.begin(), P.runs.end(), runs + 2 * nruns);
+        for (size_t i = 0; i < P.count.size(); ++i) {
+            nruns += P.count[i];
+            if (win_ptr) win_ptr[P.g0 + i + 1] = (unsigned)nruns;
         }
-        unsigned slots = 0;
-        for (size_t i = 0; i < cols.size();) {
-            size_t k = i;
-            while (k + 1 < cols.size() && cols[k + 1] - cols[k] <= gap + 1 && cols[k + 1] - cols[i] < 65535u) ++k;
-            const unsigned len = cols[k] - cols[i] + 1;
-            if (slots + len > max_slots || slots + len > 65535u) return -1;
-            if (runs) { runs[2 * nruns] = cols[i]; runs[2 * nruns + 1] = (slots << 16) | len; }
-            ++nruns;
-            slots += len;
-            i = k + 1;
-        }
-        if (win_ptr) win_ptr[g + 1] = (unsigned)nruns;
-        most = std::max(most, slots);
+        most = std::max(most, P.most);
     }
     if (slots_used) *slots_used = most;
     return nruns;
+}
+
+extern "C" int bicg_set_plan_threads(int n)
+{
+    if (n > 0) bicg::plan_threads_setting() = n;
+    return bicg::plan_threads();
 }
 
 // the slot of column `c` in the window whose runs are runs[2*first .. 2*end): last run whose first column is <= c

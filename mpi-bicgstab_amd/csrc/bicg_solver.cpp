@@ -18,6 +18,8 @@
 
 #include "bicg_comm.h"
 #include "bicg_plan.h"
+#include "bicg_parallel.h"
+#include <memory>
 #include "bicg_device.h"
 
 using namespace bicg;
@@ -2271,6 +2273,16 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         for (int p = 1; p < P; ++p) c->sdsp[p] = c->sdsp[p - 1] + c->scnt[p - 1];
     }
 
+    // (BICG_PLAN_TRACE=1: seconds per part of the plan on stderr, rank 0)
+    const bool plan_trace = getenv("BICG_PLAN_TRACE") && atoi(getenv("BICG_PLAN_TRACE")) != 0 && comm->rank == 0;
+    double plan_t = now_sec();
+    auto plan_mark = [&](const char *what) {
+        if (!plan_trace) return;
+        const double t = now_sec();
+        fprintf(stderr, "bicgstab_hip: plan  %-34s %8.4f s\n", what, t - plan_t);
+        plan_t = t;
+    };
+    plan_mark("state, halo plan");
     // ---- SpMV plan. Rows are cut into groups of 256 (4 slices of 64 rows = one workgroup, lane = row).
     // Two layouts of a slice: PADDED to its longest row (banded matrices: nothing to pad, 8-byte loads of four
     // 16-bit column offsets) or JAGGED (ragged rows: step k stores the rows longer than k only; exactly the CSR's
@@ -2400,22 +2412,28 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     std::vector<unsigned char> perm;
     if (win && !(getenv("BICG_SELL_SORT") && atoi(getenv("BICG_SELL_SORT")) == 0)) {
         perm.assign((size_t)ngroups * kGroupRows, 0);
+        std::vector<uint32_t> slice_sum(nslices, 0u);             // entries of a slice after the rows were dealt out
+        parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int) {
+            for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g) {
+                unsigned char *pg = perm.data() + (size_t)g * kGroupRows;
+                for (uint32_t t = 0; t < kGroupRows; ++t) pg[t] = (unsigned char)t;
+                if (!group_is_sell[g]) continue;
+                const uint32_t r0 = g * kGroupRows;
+                auto len_of = [&](unsigned t) -> uint32_t { return r0 + t < nrows ? diag->ptr[r0 + t + 1] - diag->ptr[r0 + t] : 0u; };
+                std::stable_sort(pg, pg + kGroupRows, [&](unsigned char x, unsigned char y) { return len_of(x) > len_of(y); });
+                for (uint32_t w = 0; w < kGroupRows / kSliceRows; ++w) {
+                    const uint32_t sl = g * (kGroupRows / kSliceRows) + w;
+                    if (sl >= nslices) break;
+                    uint32_t longest = 0; uint64_t sum = 0;
+                    for (uint32_t l = 0; l < kSliceRows; ++l) { const uint32_t n = len_of(pg[w * kSliceRows + l]); longest = std::max(longest, n); sum += n; }
+                    slice_len[sl] = longest; slice_sum[sl] = (uint32_t)sum;
+                }
+            }
+        });
         uint64_t at = 0;
         for (uint32_t g = 0; g < ngroups; ++g) {
-            unsigned char *pg = perm.data() + (size_t)g * kGroupRows;
-            for (uint32_t t = 0; t < kGroupRows; ++t) pg[t] = (unsigned char)t;
             if (!group_is_sell[g]) continue;
-            const uint32_t r0 = g * kGroupRows;
-            auto len_of = [&](unsigned t) -> uint32_t { return r0 + t < nrows ? diag->ptr[r0 + t + 1] - diag->ptr[r0 + t] : 0u; };
-            std::stable_sort(pg, pg + kGroupRows, [&](unsigned char x, unsigned char y) { return len_of(x) > len_of(y); });
-            for (uint32_t w = 0; w < kGroupRows / kSliceRows; ++w) {
-                const uint32_t sl = g * (kGroupRows / kSliceRows) + w;
-                if (sl >= nslices) break;
-                uint32_t longest = 0; uint64_t sum = 0;
-                for (uint32_t l = 0; l < kSliceRows; ++l) { const uint32_t n = len_of(pg[w * kSliceRows + l]); longest = std::max(longest, n); sum += n; }
-                slice_len[sl] = longest; slice_base[sl] = (uint32_t)at;
-                at += sum;
-            }
+            for (uint32_t sl = g * (kGroupRows / kSliceRows); sl < std::min(nslices, (g + 1) * (kGroupRows / kSliceRows)); ++sl) { slice_base[sl] = (uint32_t)at; at += slice_sum[sl]; }
         }
         if (at != sell_entries) die("bicg_create", "internal: sorted slices do not add up");
     }
@@ -2424,10 +2442,14 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         const uint32_t g = sl / (kGroupRows / kSliceRows), w = sl % (kGroupRows / kSliceRows);
         return g * kGroupRows + perm[(size_t)g * kGroupRows + w * kSliceRows + lane];
     };
+    plan_mark("groups, windows, row order");
     c->sell_entries = sell_entries;
     c->sell_jag = jag && sell_entries > 0;
-    std::vector<double> sval(sell_entries ? sell_entries : 1, 0.0);
-    std::vector<uint32_t> scol(sell_entries ? sell_entries : 1, 0u);
+    // (allocated without a fill: the threads that write a slice also zero its padding -- 330 MB of zeros from one thread were a
+    // third of this part)
+    std::unique_ptr<double[]> sval_mem(new double[sell_entries ? sell_entries : 1]);
+    double *const sval = sval_mem.get();
+    std::unique_ptr<uint32_t[]> scol_mem;                          // filled once it is known whether the 32-bit columns are uploaded
     // 16-bit column offsets when every sliced-ELL entry is within +-32767 of its row
     bool c16 = sell_entries > 0 && (win || !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16"))));
     std::vector<uint32_t> slice_base16(nslices, 0u);
@@ -2441,19 +2463,30 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (n16 >= 0xFFFFFF00ull) c16 = false;
     std::vector<int> offsets_seen;          // distinct column offsets (col - row), while they stay few: the fused-window clusters
     bool offsets_few = true;
-    {
-        std::vector<unsigned char> mark(65536, 0);
-        for (uint32_t r = 0; c16 && !win && r < nrows; ++r) {
-            if (!group_is_sell[r / kGroupRows]) continue;
-            for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
-                const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
-                if (dlt < -32767 || dlt > 32767) { c16 = false; break; }
-                if (offsets_few && !mark[dlt + 32768]) {
+    if (c16 && !win) {
+        // row ranges on several threads, a map of the offsets seen per thread; merged below (ascending: the order does not matter,
+        // the clusters are formed from the sorted list)
+        std::vector<std::vector<unsigned char>> marks((size_t)plan_threads());
+        std::vector<char> bad((size_t)plan_threads(), 0);
+        const int np = parallel_ranges(nrows, 4096, [&](size_t ra, size_t rb, int part) {
+            std::vector<unsigned char> &mark = marks[(size_t)part];
+            mark.assign(65536, 0);
+            for (uint32_t r = (uint32_t)ra; r < (uint32_t)rb && !bad[(size_t)part]; ++r) {
+                if (!group_is_sell[r / kGroupRows]) continue;
+                for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
+                    const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
+                    if (dlt < -32767 || dlt > 32767) { bad[(size_t)part] = 1; break; }
                     mark[dlt + 32768] = 1;
-                    offsets_seen.push_back((int)dlt);
-                    if (offsets_seen.size() > 4096) offsets_few = false;
                 }
             }
+        });
+        for (int p = 0; p < np; ++p) if (bad[(size_t)p]) c16 = false;
+        for (int d = 0; c16 && d < 65536; ++d) {
+            bool any = false;
+            for (int p = 0; p < np && !any; ++p) any = marks[(size_t)p][(size_t)d] != 0;
+            if (!any) continue;
+            if (offsets_seen.size() >= 4096) { offsets_few = false; break; }
+            offsets_seen.push_back(d - 32768);
         }
     }
     // Fused-window clusters (struct FusedWindow): the offsets fall into <= 4 clusters (gaps of more than 512 columns separate
@@ -2477,35 +2510,52 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         }
         if (ok && slots <= 2048) { f.ncl = ncl; f.slots = (unsigned)slots; c->fw = f; }
     }
-    std::vector<short> scol16(c16 ? n16 : 1, 0);
-    if (jag) {
-        for (uint32_t sl = 0; sl < nslices; ++sl) {
-            if (!group_is_sell[sl / (kGroupRows / kSliceRows)]) continue;
-            size_t e = slice_base[sl];
-            for (uint32_t k = 0; k < slice_len[sl]; ++k)
-                for (uint32_t lane = 0; lane < kSliceRows; ++lane) {
-                    const uint32_t r = row_of(sl, lane);
-                    if (r >= nrows || diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
-                    const uint32_t j = diag->ptr[r] + k;
-                    sval[e] = diag->val[j]; scol[e] = diag->col[j];
-                    if (win) scol16[e] = (short)(unsigned short)slot_of(sl / (kGroupRows / kSliceRows), diag->col[j]);
-                    else if (c16) scol16[e] = (short)((int64_t)diag->col[j] - (int64_t)r);
-                    ++e;
+    plan_mark("column offsets, clusters");
+    const size_t n16_alloc = c16 ? (size_t)n16 : 1;
+    std::unique_ptr<short[]> scol16_mem(new short[n16_alloc]);
+    short *const scol16 = scol16_mem.get();
+    if (!c16) { scol16[0] = 0; scol_mem.reset(new uint32_t[sell_entries ? sell_entries : 1]); }
+    uint32_t *const scol = scol_mem.get();                        // null with 16-bit offsets: the 32-bit columns are not uploaded
+    if (sell_entries == 0) { sval[0] = 0.0; if (scol) scol[0] = 0u; }
+    // Slices on several threads: a slice's entries (and its padding, zeros) are its own range of the arrays.
+    parallel_ranges(nslices, 256, [&](size_t sa, size_t sb, int) {
+        for (uint32_t sl = (uint32_t)sa; sl < (uint32_t)sb; ++sl) {
+            const uint32_t g = sl / (kGroupRows / kSliceRows);
+            if (!group_is_sell[g]) continue;
+            if (jag) {
+                size_t e = slice_base[sl];
+                for (uint32_t k = 0; k < slice_len[sl]; ++k)
+                    for (uint32_t lane = 0; lane < kSliceRows; ++lane) {
+                        const uint32_t r = row_of(sl, lane);
+                        if (r >= nrows || diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
+                        const uint32_t j = diag->ptr[r] + k;
+                        sval[e] = diag->val[j];
+                        if (scol) scol[e] = diag->col[j];
+                        if (win) scol16[e] = (short)(unsigned short)slot_of(g, diag->col[j]);
+                        else if (c16) scol16[e] = (short)((int64_t)diag->col[j] - (int64_t)r);
+                        ++e;
+                    }
+                continue;
+            }
+            const size_t b0 = slice_base[sl], n = (size_t)slice_len[sl] * kSliceRows;
+            std::fill(sval + b0, sval + b0 + n, 0.0);
+            if (scol) std::fill(scol + b0, scol + b0 + n, 0u);
+            if (c16) std::fill(scol16 + slice_base16[sl], scol16 + slice_base16[sl] + (size_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows, (short)0);
+            for (uint32_t lane = 0; lane < kSliceRows; ++lane) {
+                const uint32_t r = sl * kSliceRows + lane;
+                if (r >= nrows) break;
+                for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
+                    const size_t e = b0 + (size_t)k * kSliceRows + lane;
+                    sval[e] = diag->val[j];
+                    if (scol) scol[e] = diag->col[j];
+                    if (c16) scol16[(size_t)slice_base16[sl] + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] =
+                                 (short)((int64_t)diag->col[j] - (int64_t)r);
                 }
-        }
-    } else {
-        for (uint32_t r = 0; r < nrows; ++r) {
-            if (!group_is_sell[r / kGroupRows]) continue;
-            const uint32_t sl = r / kSliceRows, lane = r % kSliceRows;
-            for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
-                const size_t e = (size_t)slice_base[sl] + (size_t)k * kSliceRows + lane;
-                sval[e] = diag->val[j]; scol[e] = diag->col[j];
-                if (c16) scol16[(size_t)slice_base16[sl] + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] =
-                             (short)((int64_t)diag->col[j] - (int64_t)r);
             }
         }
-    }
+    });
 
+    plan_mark("sliced-ELL arrays");
     // Uniform slices (SellDev::ubase): all 64 rows present, equally long, entry k at the same distance from its row in
     // every row. Lists are shared between slices (a banded matrix has ONE for its whole interior) and padded with zeros.
     std::vector<uint32_t> ubase, vbase, mbase;
@@ -2620,6 +2670,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->constant_entries = constant_entries;
     c->masked_rows = masked_rows;
 
+    plan_mark("uniform / constant / masked slices");
     // CSR row blocks over the maximal runs of non-SELL groups
     std::vector<uint32_t> rb(nrows + 1);
     for (uint32_t g = 0; g < ngroups;) {
@@ -2643,6 +2694,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->glist_int_identity = c->ng_int == ngroups;     // every group, in order: index directly
     c->glist_all = c->ng_int + c->ng_bnd == ngroups;
 
+    plan_mark("row blocks");
     // ---- upload
     // Only what some kernel reads goes to the GPU: the CSR val/col arrays when there are row blocks for the
     // CSR kernel (none for banded matrices: everything is on the sliced-ELL path), the 32-bit sliced-ELL
@@ -2669,8 +2721,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->desc_int = dev_upload(bint.data(), bint.size());
     c->desc_bnd = dev_upload(bbnd.data(), bbnd.size());
     // (jagged slices: lanes whose row has ended read up to one entry past the last -- kPadEntries of slack)
-    c->s_val = dev_upload_padded(sval.data(), (size_t)sell_entries, kPadEntries);
-    c->s_col = dev_upload_padded(scol.data(), c16 ? 0 : (size_t)sell_entries, kPadEntries);
+    c->s_val = dev_upload_padded(sval, (size_t)sell_entries, kPadEntries);
+    c->s_col = dev_upload_padded(scol, c16 ? 0 : (size_t)sell_entries, kPadEntries);
     c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 2ull * masked_rows + 8ull * nslices + 4ull * (nrows + 1) +
                       (uint64_t)(c->nnz_d - c->sell_nnz) * (csr16 ? 10 : 12) + (uint64_t)c->nnz_o * 12;
     if (!vbase.empty()) {
@@ -2689,7 +2741,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
-        c->s_col16 = dev_upload_padded(scol16.data(), scol16.size(), kPadEntries);
+        c->s_col16 = dev_upload_padded(scol16, n16_alloc, kPadEntries);
         c->s_base16 = dev_upload(slice_base16.data(), slice_base16.size());
     }
     if (win) {
@@ -2708,6 +2760,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->send_idx = dev_upload(send_idx.data(), c->nsend);
     c->sendbuf = dev_alloc<double>(c->nsend);
 
+    plan_mark("upload");
     // ---- peer-to-peer transport: publish this rank's halo landing ring, learn where every entry
     // of the send list lands in the ring of the rank that needs it (collective)
     c->p2p = comm->p2p;
@@ -2771,7 +2824,9 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
     }
 
+    plan_mark("transport, persistent plan");
     ctx_streams(c, P);
+    plan_mark("streams");
     return c;
 }
 

@@ -227,6 +227,23 @@ def test_hot_kernels_stay_lean():
         assert kernels[k]["VGPRs"] <= 88 and kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
 
 
+def test_window_plan_does_not_depend_on_the_number_of_threads():
+    """the set-up cuts its loops into one range per host thread (csrc/bicg_parallel.h): same runs, same slots for 1, 3 and 16"""
+    A = synth.fem_like(n=117 * 117 * 3)
+    L = H.lib()
+    L.bicg_set_plan_threads.argtypes = [C.c_int]; L.bicg_set_plan_threads.restype = C.c_int
+    before = L.bicg_set_plan_threads(0)
+    try:
+        plans = []
+        for nt in (1, 3, 16):
+            assert L.bicg_set_plan_threads(nt) == nt
+            plans.append(H.window_plan(A))
+        for p in plans[1:]:
+            assert np.array_equal(p[0], plans[0][0]) and np.array_equal(p[1], plans[0][1]) and p[2] == plans[0][2]
+    finally:
+        L.bicg_set_plan_threads(before)
+
+
 def test_window_plan_covers_every_column_once():
     """bicg_window_plan (x windows of the ragged-rows SpMV): per 256-row group the runs
     are sorted, disjoint, cover every column the group touches, their slots are consecutive, gaps of <= 8 unused
