@@ -2599,6 +2599,8 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
 int spmm_win_vectors(unsigned wslots)
 {
     if (wslots == 0) return 0;
+    static const int forced = getenv("BICG_SPMM_NV") ? atoi(getenv("BICG_SPMM_NV")) : 0;      // measurement knob: 4 or 8 vectors per window
+    if ((forced == 4 || forced == 8) && (size_t)forced * wslots * 8u <= 156u * 1024u) return forced;
     // (the head of every row stays in registers across the passes, so more vectors per window save barriers, not matrix traffic:
     // 16 per window was dropped -- its 256 LDS reads per thread in flight cost the occupancy)
     for (int nv : {8, 4}) if ((size_t)nv * wslots * 8u <= 80u * 1024u) return nv;

@@ -48,7 +48,8 @@ def test_spmv_bitexact_and_linear(big):
 
 def test_repeated_dropin_calls_cost_a_tenth(big):
     """matrix residency (tests/test_dropin_cache.py) at BASELINE.json's size: the second drop-in call on unchanged
-    blocks -- content hash of ~300 MB + the solve itself -- takes < 10 % of the first (plan + 250 MB upload)"""
+    blocks -- content hash of ~300 MB + the solve itself -- takes a fraction of the first (plan + 250 MB upload): a tenth
+    while the plan ran on one host thread, an eighth now that the first call itself is four times cheaper"""
     import ctypes as C
     import os
     import time
@@ -67,7 +68,9 @@ def test_repeated_dropin_calls_cost_a_tenth(big):
             L.bicgstab(C.byref(blk.diag), C.byref(blk.offd), C.byref(blk.info), x.ctypes.data_as(dp), r.ctypes.data_as(dp))
             t.append(time.perf_counter() - t0)
         print(f"drop-in call 1 {t[0]:.3f} s, later {min(t[1:]):.3f} s")
-        assert min(t[1:]) < 0.1 * t[0], t
+        # (round 4: the plan runs on several host threads -- the first call fell from 0.35 to 0.08 s on the GPU box, the later
+        # ones stay at 10 ms: a content hash of 300 MB and four iterations)
+        assert min(t[1:]) < 0.25 * t[0] and min(t[1:]) < 0.03, t
     finally:
         os.environ.pop("BICG_MAX_ITER", None); os.environ.pop("BICG_QUIET", None)
         L.bicg_dropin_release()
@@ -284,6 +287,44 @@ def test_device_side_plan_matches_host_plan():
         assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max()
         print(f"stencil {m}^3: generated on the device in {gen_s:.3f} s, planned in {plan_s:.3f} s")
         ctx.close(); ref.close()
+
+
+def test_list_driven_slices_same_bits_whichever_loop_runs(monkeypatch):
+    """Constant / masked slices (SellDev::vbase / mbase) have three forms of the product: the general loop of sell_row
+    (BICG_SELL_DESC=0), sell_row with one descriptor per slice and the next slices' metadata requested ahead
+    (BICG_SELL_LISTS=0), and the loop of its own for blocks whose slices are ALL list-driven (default; 64^3 and 96^3 qualify,
+    33^3 -- rows not a multiple of 256 -- does not). Same sums in the same order (reference src/matrix.c:506-515): SpMV, the
+    SpMV with fused dots inside the solvers (alpha / omega / (r,r) of 12 iterations) and the shifted product are bit-identical."""
+    H.lib().bicg_comm_init_single(0)
+    monkeypatch.setenv("BICG_PERSIST", "0")            # (the one-launch iterations keep the matrix in LDS: not these kernels)
+    for m, weights in ((64, synth.LAPLACE_WEIGHTS), (33, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)), (96, (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0))):
+        A = synth.stencil7(m, weights)
+        x = np.random.default_rng(m).standard_normal(A.rows)
+        b = None
+        results = []
+        for env in ({"BICG_SELL_DESC": "0"}, {"BICG_SELL_LISTS": "0"}, {}):
+            for k in ("BICG_SELL_DESC", "BICG_SELL_LISTS"):
+                monkeypatch.delenv(k, raising=False)
+            for k, v in env.items():
+                monkeypatch.setenv(k, v)
+            ctx = H.Context(H.single_rank_blocks(A))
+            assert ctx.flags()["constant"] and ctx.masked_rows() > 0
+            y = ctx.spmv(x)
+            if b is None:
+                b = ctx.spmv(np.ones(A.rows))
+            traces = []
+            for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
+                ctx.solve(method, b, tol=0.0, max_iter=12, check_every=12)
+                tr = ctx.trace(12)
+                traces.append(np.concatenate([tr[key] for key in ("alpha", "omega", "beta", "dotr")]))
+            sh = ctx.solve_shifted(b, np.array([0.0, 0.02, 0.05]), 1, tol=0.0, max_iter=8, check_every=8)
+            results.append((y, traces, sh["x"]))
+            ctx.close()
+        for y, traces, xs in results[1:]:
+            assert np.array_equal(y, results[0][0])
+            for t, t0 in zip(traces, results[0][1]):
+                assert np.array_equal(t, t0)
+            assert np.array_equal(xs, results[0][2])
 
 
 def test_laplace512_device_plan_at_bench_size():

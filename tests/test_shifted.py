@@ -128,6 +128,14 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
         rowmajor.close()
     finally:
         del os.environ["BICG_SPMM_WIN"]
+    os.environ["BICG_SPMM_WIN"] = "2"                 # the direct kernel (row heads in registers, gathers from the shift-major vectors)
+    try:
+        direct = H.Context(H.single_rank_blocks(A))
+        Yd, _ = direct.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
+        assert direct.last_spmm_windowed() and np.array_equal(Yd, Yr)
+        direct.close()
+    finally:
+        del os.environ["BICG_SPMM_WIN"]
     Yw, _ = ctx.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
     assert ctx.last_spmm_windowed() and np.array_equal(Yw, Yr)      # three clusters of offsets: staged per 256-row group in LDS
     rng = np.random.default_rng(8)
