@@ -391,6 +391,8 @@ def main():
         blocks = H.HostBlocks(diag, offd if world > 1 else None, rows, counts, displs)
         return dict(name=workload, rows=rows, nnz=nnz, blocks=blocks, lo=lo, hi=hi, data="synthetic", desc=desc)
 
+    regions_ms = {}            # every timed region of the variant / extra legs, per leg and method (ms per region)
+
     class Leg:
         """one resident matrix: context, right-hand side, timed solves"""
 
@@ -406,10 +408,14 @@ def main():
             self.ctx.close()
 
         def best(self, method, steps=None, warm=None, tries=2):
-            """the variant / extra legs: the faster of two timed regions. (The runtime occasionally stalls a queue for
-            10-80 ms -- seen in one leg per few runs, never twice in a row, not reproducible outside this script; the
-            headline `value` is a single region of exactly K iterations.)"""
+            """the variant / extra legs: the faster of two timed regions; BOTH go into the line (`timed_regions_ms`), so a
+            region that stalled is on record. (Rounds 2-3 saw one region per few runs take 10-80 ms longer, never twice in a
+            row. What was found in round 4: a translation unit's code object is loaded at the first look-up of one of its
+            kernels -- 4-10 ms, now paid inside bicg_create (preload_kernels) -- and nothing longer than that could be
+            provoked outside this script: profiles/r04/preload_check.txt. The headline `value` is a single region of
+            exactly K iterations.)"""
             runs = [self.timed(method, steps=steps, warm=warm) for _ in range(tries)]
+            regions_ms.setdefault(self.wl.get("desc", "headline")[:48] + " / " + method, []).extend(round(1e3 * r[0], 4) for r in runs)
             return min(runs, key=lambda r: r[0])
 
         def timed(self, method, kernel_events=False, steps=None, warm=None):
@@ -760,6 +766,7 @@ def main():
             "variants_ms_per_iteration": variants,
             "variant_rooflines": variant_roof,
             "extras": extras,
+            "timed_regions_ms": regions_ms,
         }
         print(json.dumps(line), file=result_out, flush=True)
 

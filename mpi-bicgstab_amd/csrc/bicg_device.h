@@ -458,6 +458,9 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st);
 // direct form (k_spmm_dir, padded slices): the row heads in registers, x gathered from the shift-major vectors, no LDS window
 hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st);
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
+// look up one kernel of every translation unit a context with this sliced-ELL plan launches from (loads their code objects now)
+void preload_kernels(const SellDev &d, bool sell);
+void preload_persist_kernels();
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st);          // out[col] = sum_wg partial[wg][col]
 void launch_rows_from_vectors(const double *x, size_t stride, int nvec, uint32_t n, double *xt, hipStream_t st);
 void launch_vectors_from_rows(const double *yt, size_t stride, int nvec, uint32_t n, double *y, hipStream_t st);

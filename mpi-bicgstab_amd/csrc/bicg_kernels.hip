@@ -1909,6 +1909,59 @@ bool launch_spmv_sell_epi_pad16c(SELL_PART_ARGS) { return sell_epi_launch_layout
 #endif
 #undef SELL_PART_ARGS
 
+// ---- code objects loaded at set-up, not at the first launch -------------------------------------------------------------
+// The runtime loads a translation unit's code object when the first of its kernels is looked up: 10-80 ms for a unit with a few
+// hundred sliced-ELL instantiations, paid in the MIDDLE of a solve whenever a kernel of a unit not used so far comes up (the
+// first replacement step of pipe_bicgstab_rr, the first product with two dots, a leg of bench.py that follows a leg with
+// another layout -- the "queue stall" of rounds 2-3). bicg_create looks up one kernel of every unit its context can launch
+// from; BICG_PRELOAD=0 leaves the loading to the first launch.
+template <int LAY> static void preload_layout()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmv_sell<0, false, false, LAY, false, RED_TICKET>));
+    (void)hipGetLastError();
+}
+void preload_part1(); void preload_part2(); void preload_part3(); void preload_part4(); void preload_part5(); void preload_part6(); void preload_part7();
+#if PART_IS(1)
+void preload_part1() { preload_layout<LAY_PAD32>(); }
+#endif
+#if PART_IS(2)
+void preload_part2() { preload_layout<LAY_PAD16>(); }
+#endif
+#if PART_IS(3)
+void preload_part3() { preload_layout<LAY_JAG32>(); }
+#endif
+#if PART_IS(4)
+void preload_part4() { preload_layout<LAY_JAG16>(); }
+#endif
+#if PART_IS(5)
+void preload_part5() { preload_layout<LAY_JAGW>(); }
+#endif
+#if PART_IS(6)
+void preload_part6() { preload_layout<LAY_PAD32C>(); }
+#endif
+#if PART_IS(7)
+void preload_part7() { preload_layout<LAY_PAD16C>(); }
+#endif
+#if PART_IS(0)
+void preload_kernels(const SellDev &d, bool sell)
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_apply));      // this unit: element-wise kernels, CSR products, SpMM
+    (void)hipGetLastError();
+    if (!sell) return;
+    switch (sell_layout(d)) {
+    case LAY_PAD16: preload_part2(); break;
+    case LAY_JAG32: preload_part3(); break;
+    case LAY_JAG16: preload_part4(); break;
+    case LAY_JAGW:  preload_part5(); break;
+    case LAY_PAD32C: preload_part6(); break;
+    case LAY_PAD16C: preload_part7(); break;
+    default:        preload_part1(); break;
+    }
+}
+#endif
+
 #if PART_IS(0)
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
 {

@@ -1416,4 +1416,11 @@ hipError_t launch_shlop_persist(const PersistArgs &a, hipStream_t st) { return l
 hipError_t launch_plain_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 1); }
 hipError_t launch_ca_persist(const PersistArgs &a, hipStream_t st) { return launch_persist(a, st, 2); }
 
+void preload_persist_kernels()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_plain_persist<true, false>));
+    (void)hipGetLastError();
+}
+
 }  // namespace bicg

@@ -2184,6 +2184,16 @@ void bicg_default_options(bicg_options *o)
     o->check_every = 16;
 }
 
+// the code objects this context launches from, loaded now (preload_kernels, bicg_kernels.hip)
+static void preload_for(bicg_ctx *c)
+{
+    if (getenv("BICG_PRELOAD") && atoi(getenv("BICG_PRELOAD")) == 0) return;
+    SellDev d = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
+    d.vbase = c->s_vbase;
+    preload_kernels(d, c->sell_entries > 0);
+    if (c->persist_on) preload_persist_kernels();
+}
+
 bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
 {
     Comm *comm = comm_get();
@@ -2827,6 +2837,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     plan_mark("transport, persistent plan");
     ctx_streams(c, P);
     plan_mark("streams");
+    preload_for(c);
+    plan_mark("code objects");
     return c;
 }
 
@@ -3046,6 +3058,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
     ctx_streams(c, 1);
+    preload_for(c);
     if (plan_seconds) *plan_seconds = now_sec() - t0;
     return c;
 }

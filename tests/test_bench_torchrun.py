@@ -128,6 +128,9 @@ def test_bench_single_gpu_line_has_every_leg():
     fmt = [r for _, r in roofs if "format_bytes" in r]
     assert len(fmt) >= 20 and all(r["format_bytes"] <= r.get("algorithmic_bytes", r.get("algorithmic_bytes_rank0")) for r in fmt)
     assert d["comm"]["world"] == 1 and d["comm"]["rccl_leg"] is None
+    # every timed region of the variant / extra legs is on record (the faster of two is what the leg reports)
+    tr = d["timed_regions_ms"]
+    assert len(tr) >= 15 and all(len(v) >= 1 and min(v) > 0 for v in tr.values()), tr
     assert rf["traffic"] is not None, "rocprofv3 counter passes did not deliver"
     assert 0.85 * rf["format_bytes_per_launch"] < rf["traffic"] < 1.5 * rf["format_bytes_per_launch"], rf
     assert 1.7 < rf["traffic_detail"]["fetch_factor_reproducing_k_vec_FPlainQ"] < 2.3
