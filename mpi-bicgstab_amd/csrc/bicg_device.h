@@ -271,6 +271,8 @@ struct SellDev {
     // as compile-time cases, the distances as byte offsets (uoff8[i] = 8 uoff[i]) added to the row's 32-bit byte offset
     int all_lists;
     const int *uoff8;
+    int ystride;            // all_lists: slices per grid line when the lists look like a grid's (second-largest distance 64 x a power of
+                            // two rows, slices a multiple of 4 x that), else 0 -- the four wavefronts of a workgroup take slices this far apart
 };
 enum SliceKind { kSliceGeneral = 0, kSliceUniform = 1, kSliceConstant = 2, kSliceMasked = 3 };
 // (PAD32C / PAD16C: padded slices of a block that has CONSTANT slices -- SellDev::vbase. Instantiations of their own: with the

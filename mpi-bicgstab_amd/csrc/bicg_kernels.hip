@@ -1418,10 +1418,21 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
     unsigned vzero = 0u;
     if (PRE) asm volatile("v_mov_b32 %0, 0" : "=v"(vzero));      // a zero the compiler takes for lane-dependent
     const unsigned wvec = threadIdx.x >> 6;
+    // Every slice list-driven, lists of at most 8 entries (SellDev::all_lists -- a constant-coefficient stencil): a loop of its own
+    // below. Its four wavefronts do not take four CONSECUTIVE slices but four slices `ystride` apart (SellDev::ystride = slices
+    // per grid line: the same x segment of four consecutive grid lines) -- the +line gather of one wavefront is then the own-row
+    // gather of the next, through the CU's L1 while both are in flight (56 instead of 80 cache lines per four slices of the
+    // 7-point Laplacian). Any ystride gives each slice to exactly one wavefront: slice = (g / S) 4 S + wave S + g % S.
+    const bool lean = PRE && pre_on && a.sell.all_lists != 0 && !OFFD && !a.has_shift;
+    const unsigned ys = lean ? (unsigned)a.sell.ystride : 0u;
+    auto slice_of = [&](unsigned g, unsigned w) -> uint32_t {
+        const unsigned sh = (unsigned)__builtin_ctz(ys | 0x80000000u);                         // ystride is a power of two (or 0)
+        return ys ? ((g >> sh) << (sh + 2u)) + (w << sh) + (g & (ys - 1u)) : g * (kGroupRows / kSliceRows) + w;
+    };
     auto group_idx = [&](unsigned q) -> unsigned { return a.reverse ? gfirst + (gend - 1u - q) : q; };      // (q < gend)
     auto group_vec = [&](unsigned q) -> unsigned { return a.glist ? a.glist[group_idx(q) + vzero] : group_idx(q); };
     auto desc_vec = [&](unsigned g) -> uint4 {
-        const uint32_t sl = g * (kGroupRows / kSliceRows) + wvec;
+        const uint32_t sl = slice_of(g, wvec);
         uint4 d = make_uint4(0u, 0u, 0u, 0u);
         if (sl * kSliceRows < a.nrows) d = a.sell.sdesc[sl];
         return d;
@@ -1443,18 +1454,18 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
         if (gfirst + 1u < gend) { g1 = (unsigned)__builtin_amdgcn_readfirstlane((int)group_vec(gfirst + 1u)); dv1 = desc_vec(g1); }
         if (gfirst + 2u < gend) gv2 = group_vec(gfirst + 2u);
     }
-    // Every slice list-driven, lists of at most 8 entries (SellDev::all_lists -- a constant-coefficient stencil): a loop of its own.
-    // Per slice: the descriptor (requested two slices ahead), the lists only when they are not the previous slice's, N gathers of
-    // a compile-time N, N products; 85 vector + 134 scalar instructions per slice of the 7-point Laplacian went through
-    // sell_row (rocprofv3: the scalar unit busy half of the time, waves waiting for memory a fifth of theirs).
-    const bool lean = PRE && pre_on && a.sell.all_lists != 0 && !OFFD && !a.has_shift;
+    // The loop of its own (SellDev::all_lists). Per slice: the descriptor (requested two slices ahead), the lists only when they
+    // are not the previous slice's, N gathers of a compile-time N, N products; 85 vector + 134 scalar instructions per slice of
+    // the 7-point Laplacian went through sell_row (rocprofv3: the scalar unit busy half of the time, waves waiting for memory a
+    // fifth of theirs).
     if (PRE && !OFFD && lean && !done && gfirst < gend) {         // (done: nothing is stored and nothing published -- nothing to do)
         const double *__restrict__ x = a.x;
         const unsigned last = gend - 1u;                          // (requests past the workgroup's last group repeat it: no tests)
         uint32_t cy = 0xFFFFFFFFu, cz = 0xFFFFFFFFu;              // the lists in registers
         sell_i8 o8 = (sell_i8)(0);
         double lv[8] = {0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0, 0.0};
-        double *yp = a.y + (pcur.g * kGroupRows + threadIdx.x);   // where the previous slice's result goes (first slice: a zero
+        const unsigned pw = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+        double *yp = a.y + (slice_of(pcur.g, pw) * kSliceRows + lane);   // where the previous slice's result goes (first slice: a zero
         double yv = 0.0;                                          // into its own row, overwritten by its result one slice later)
         for (unsigned gq = gfirst; gq < gend; ++gq) {
             SellPre pnext;
@@ -1463,7 +1474,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
             pnext.pm = mask_vec(pnext.d);
             dv1 = desc_vec(g2);
             gv2 = group_vec(gq + 3u < last ? gq + 3u : last);
-            const uint32_t row = pcur.g * kGroupRows + threadIdx.x;
+            const uint32_t row = slice_of(pcur.g, pw) * kSliceRows + lane;
             const uint32_t kind = pcur.d.x >> 16, len = pcur.d.x & 0xFFFFu;
             {                                                     // (no slice without rows: build_slice_desc -- a path that requests
                                                                   // nothing would make every wait of the loop a wait for everything)

@@ -100,6 +100,7 @@ struct bicg_ctx {
     unsigned short *s_rmask = nullptr;
     uint64_t masked_rows = 0;
     int *s_uoff8 = nullptr;                // SellDev::uoff8
+    int sell_ystride = 0;                  // SellDev::ystride (BICG_SELL_YGROUP=1; default: consecutive slices per workgroup)
     bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
     uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
@@ -531,7 +532,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval; a.sell.mbase = c->s_mbase; a.sell.rmask = c->s_rmask;
-    a.sell.sdesc = c->s_desc; a.sell.all_lists = c->sell_all_lists ? 1 : 0; a.sell.uoff8 = c->s_uoff8;
+    a.sell.sdesc = c->s_desc; a.sell.all_lists = c->sell_all_lists ? 1 : 0; a.sell.uoff8 = c->s_uoff8; a.sell.ystride = c->sell_ystride;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -845,6 +846,18 @@ static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, cons
         for (size_t i = 0; i < uoff.size(); ++i) u8[i] = (int)((uint32_t)uoff[i] * 8u);      // (modulo 2^32: the product adds it to the row's byte offset modulo 2^32)
         c->s_uoff8 = dev_upload(u8.data(), u8.size());
         c->sell_all_lists = true;
+        // SellDev::ystride from the longest list (the interior's): its second-largest distance is a grid line when it is a multiple
+        // of 64 rows. (Only the speed depends on the guess: any value gives every slice to exactly one wavefront.)
+        uint32_t best_len = 0, best_at = 0;
+        for (uint32_t sl = 0; sl < nslices; ++sl) { const uint32_t l = d[sl].x & 0xFFFFu; if ((d[sl].x >> 16) == kSliceConstant && l > best_len) { best_len = l; best_at = d[sl].y; } }
+        // (measured, 512^3: 0.923 against 0.929 ms per product, 256^3 0.146 against 0.123 ms -- off unless BICG_SELL_YGROUP=1)
+        if (best_len >= 5 && getenv("BICG_SELL_YGROUP") && atoi(getenv("BICG_SELL_YGROUP")) != 0) {
+            std::vector<int> dist(uoff.begin() + best_at, uoff.begin() + best_at + best_len);
+            std::sort(dist.begin(), dist.end());
+            const int line = dist[best_len - 2];
+            const uint32_t S = line > 0 ? (uint32_t)line / kSliceRows : 0u;
+            if (S >= 1 && (uint32_t)line % kSliceRows == 0 && (S & (S - 1u)) == 0 && nslices % (4u * S) == 0) c->sell_ystride = (int)S;   // (a power of two: shifts in the kernel)
+        }
     }
     c->s_desc = dev_upload(d.data(), d.size());
     c->matrix_bytes += 8ull * nslices;          // 16 bytes of descriptor per slice where base + length were counted
@@ -2120,6 +2133,9 @@ static void ctx_state(bicg_ctx *c, Comm *comm, uint32_t ngroups)
 {
     // ---- vectors: 12 x (rows + halo), each 256-byte aligned; order x r | rh p s y z w v t ax b
     c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
+    // (BICG_STRIDE_PAD = doubles added to the distance between two vectors, a multiple of 32: measurement knob for grids whose
+    // vectors would otherwise lie a power of two bytes apart -- 512^3: exactly 1 GiB)
+    if (const char *sv = getenv("BICG_STRIDE_PAD")) c->stride += ((uint32_t)std::max(0, atoi(sv)) / 32u) * 32u;
     c->slab = dev_alloc<double>(12 * (size_t)c->stride);
     BICG_HIP(hipMemset(c->slab, 0, sizeof(double) * 12 * (size_t)c->stride));
     double *base = c->slab;
