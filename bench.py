@@ -398,7 +398,9 @@ def main():
 
         def __init__(self, wl):
             self.wl = wl
-            self.ctx = H.Context(wl["blocks"])
+            t_setup = time.perf_counter()
+            self.ctx = H.Context(wl["blocks"])      # bicg_create: plan on the host's threads + upload + code objects
+            self.setup_s = time.perf_counter() - t_setup
             self.plan = self.ctx.plan_info()
             self.ones = np.ones(wl["hi"] - wl["lo"])
             self.x0 = np.zeros(wl["hi"] - wl["lo"])
@@ -574,7 +576,8 @@ def main():
         def extra(name, wl2, methods, steps):
             stage[0] = f"extra workload {name}"
             lg = Leg(wl2)
-            out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v])
+            out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v],
+                       setup_seconds=lg.setup_s)
             mbytes = lg.ctx.spmv_matrix_bytes()
             for m in methods:
                 dtv, rv = lg.best(m, steps=steps, warm=min(W, 10))
@@ -736,7 +739,8 @@ def main():
                        "partition": f"row blocks over {world} GPU(s), reference src/matrix.c:295-308",
                        "transport": transport_name, "flags": head_flags_all, "halo": int(plan["halo"]),
                        "iterations_genuine": bool(genuine), "relres_after_timed_region": relres,
-                       "true_relres_after_timed_region": true_relres},
+                       "true_relres_after_timed_region": true_relres,
+                       "setup_seconds_rank0": leg.setup_s},
             # bytes one iteration has to move with the stored layout (2 products + the fused-minimum vector traffic of SURVEY.md 8d)
             "hbm_gbps_iteration": iter_fmt_bytes / (ms_step * 1e-3) / 1e9,
             "iteration_algorithmic_bytes": iter_fmt_bytes,
