@@ -417,7 +417,7 @@ def main():
             provoked outside this script: profiles/r04/preload_check.txt. The headline `value` is a single region of
             exactly K iterations.)"""
             runs = [self.timed(method, steps=steps, warm=warm) for _ in range(tries)]
-            regions_ms.setdefault(self.wl.get("desc", "headline")[:48] + " / " + method, []).extend(round(1e3 * r[0], 4) for r in runs)
+            regions_ms.setdefault(f'{self.wl.get("desc", "headline")} / {method}', []).extend(round(1e3 * r[0], 4) for r in runs)
             return min(runs, key=lambda r: r[0])
 
         def timed(self, method, kernel_events=False, steps=None, warm=None):
