@@ -7,7 +7,10 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mpi_bicgstab_amd import hipsolver as H, synth
 H.lib().bicg_comm_init_single(0)
-A = synth.transport_like(n=int(os.environ.get("AB_N", synth.TRANSPORT_N)), scale_decades=2.0)
+if os.environ.get("AB_MATRIX") == "fem_like":          # the irregular matrix of bench.py's extras
+    A = synth.fem_like(scale_decades=2.0)
+else:
+    A = synth.transport_like(n=int(os.environ.get("AB_N", synth.TRANSPORT_N)), scale_decades=2.0)
 methods = os.environ.get("AB_METHODS", "bicgstab").split(",")
 ctxs = []
 for spec in sys.argv[1:]:
