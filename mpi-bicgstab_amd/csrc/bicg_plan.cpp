@@ -215,14 +215,18 @@ bool persist_plan_host(const CSR_Matrix *diag, const unsigned *optr, const unsig
     std::vector<uint32_t> mcol(mptr[nrows] ? mptr[nrows] : 1);
     std::vector<double> mval(mptr[nrows] ? mptr[nrows] : 1);
     P.rlen.assign(nrows, 0); P.rdiag.assign(nrows, 0);
-    for (uint32_t r = 0; r < nrows; ++r) {
-        uint32_t at = mptr[r];
-        const uint32_t dl = diag->ptr[r + 1] - diag->ptr[r], ol = multi ? optr[r + 1] - optr[r] : 0u;
-        if (dl + ol > 65535u) return false;
-        for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j, ++at) { mcol[at] = diag->col[j]; mval[at] = diag->val[j]; }
-        if (multi) for (uint32_t j = optr[r]; j < optr[r + 1]; ++j, ++at) { mcol[at] = ocol[j]; mval[at] = oval[j]; }
-        P.rlen[r] = (unsigned short)(dl + ol); P.rdiag[r] = (unsigned short)dl;
-    }
+    std::vector<char> too_long((size_t)bicg::plan_threads(), 0);
+    bicg::parallel_ranges(nrows, 4096, [&](size_t ra, size_t rb, int part) {       // (rows on several threads: each writes its own rows)
+        for (uint32_t r = (uint32_t)ra; r < (uint32_t)rb; ++r) {
+            uint32_t at = mptr[r];
+            const uint32_t dl = diag->ptr[r + 1] - diag->ptr[r], ol = multi ? optr[r + 1] - optr[r] : 0u;
+            if (dl + ol > 65535u) { too_long[(size_t)part] = 1; return; }
+            for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j, ++at) { mcol[at] = diag->col[j]; mval[at] = diag->val[j]; }
+            if (multi) for (uint32_t j = optr[r]; j < optr[r + 1]; ++j, ++at) { mcol[at] = ocol[j]; mval[at] = oval[j]; }
+            P.rlen[r] = (unsigned short)(dl + ol); P.rdiag[r] = (unsigned short)dl;
+        }
+    });
+    for (char t : too_long) if (t) return false;
     // windows: runs of consecutive columns per workgroup; a run never straddles the local / halo boundary
     const uint32_t max_slots = 16384;
     std::vector<uint32_t> wptr0(nwg + 1, 0u);
@@ -267,15 +271,20 @@ bool persist_plan_host(const CSR_Matrix *diag, const unsigned *optr, const unsig
     for (uint32_t g = 0; g < nwg; ++g) {
         const uint32_t s0 = g * spw, s1 = std::min(nslices, s0 + spw);
         P.max_entries = std::max(P.max_entries, P.pbase[s1] - P.pbase[s0]);
-        for (uint32_t r = s0 * kSlice; r < std::min(nrows, s1 * kSlice); ++r) {
-            const uint32_t sl = r / kSlice, lane = r % kSlice;
-            for (uint32_t j = mptr[r], k = 0; j < mptr[r + 1]; ++j, ++k) {
-                const size_t e = (size_t)P.pbase[sl] + (size_t)k * kSlice + lane;
-                P.pval[e] = mval[j];
-                P.pslot[e] = (unsigned short)slot_of(g, mcol[j]);
+    }
+    bicg::parallel_ranges(nwg, 4, [&](size_t ga, size_t gb, int) {                   // (a workgroup's slices are its own range of pval / pslot)
+        for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g) {
+            const uint32_t s0 = g * spw, s1 = std::min(nslices, s0 + spw);
+            for (uint32_t r = s0 * kSlice; r < std::min(nrows, s1 * kSlice); ++r) {
+                const uint32_t sl = r / kSlice, lane = r % kSlice;
+                for (uint32_t j = mptr[r], k = 0; j < mptr[r + 1]; ++j, ++k) {
+                    const size_t e = (size_t)P.pbase[sl] + (size_t)k * kSlice + lane;
+                    P.pval[e] = mval[j];
+                    P.pslot[e] = (unsigned short)slot_of(g, mcol[j]);
+                }
             }
         }
-    }
+    });
     return true;
 }
 }  // namespace bicg

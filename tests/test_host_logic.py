@@ -240,6 +240,14 @@ def test_window_plan_does_not_depend_on_the_number_of_threads():
             plans.append(H.window_plan(A))
         for p in plans[1:]:
             assert np.array_equal(p[0], plans[0][0]) and np.array_equal(p[1], plans[0][1]) and p[2] == plans[0][2]
+        # the plan of the persistent iteration (merged rows and padded slices filled by ranges of rows / workgroups)
+        B = H.single_rank_blocks(synth.from_offsets(40013, (0, 1, -1, 117, -117, 118, -118, 3689, -3689, 3807, -3807), diag_base=14.0, seed=9))
+        pp = []
+        for nt in (1, 8):
+            L.bicg_set_plan_threads(nt)
+            pp.append(H.persist_plan(B, 1, 60))
+        for key, v in pp[0].items():
+            assert np.array_equal(v, pp[1][key]) if isinstance(v, np.ndarray) else v == pp[1][key], key
     finally:
         L.bicg_set_plan_threads(before)
 
