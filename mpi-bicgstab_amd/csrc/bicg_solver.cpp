@@ -2595,17 +2595,31 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         ubase.assign(nslices, 0xFFFFFFFFu);
         std::map<std::vector<int>, uint32_t> lists, vlists;
         std::vector<int> cur, vkey;
+        // which slices are uniform (1) / uniform and constant (2): 64 rows x length comparisons per slice, on several threads; the
+        // lists themselves are numbered by the pass below, in slice order
+        std::vector<char> cls(nslices, 0);
+        parallel_ranges(nslices, 256, [&](size_t sa, size_t sb, int) {
+            for (uint32_t sl = (uint32_t)sa; sl < (uint32_t)sb; ++sl) {
+                if (!group_is_sell[sl / (kGroupRows / kSliceRows)] || (sl + 1) * kSliceRows > nrows || slice_len[sl] == 0) continue;
+                const uint32_t r0 = sl * kSliceRows, len = slice_len[sl], p0 = diag->ptr[r0];
+                bool uni = true;
+                for (uint32_t l = 0; l < kSliceRows && uni; ++l) uni = diag->ptr[r0 + l + 1] - diag->ptr[r0 + l] == len;
+                for (uint32_t l = 1; l < kSliceRows && uni; ++l)
+                    for (uint32_t k = 0; k < len; ++k)
+                        if ((int64_t)diag->col[diag->ptr[r0 + l] + k] - (int64_t)(r0 + l) != (int64_t)diag->col[p0 + k] - (int64_t)r0) { uni = false; break; }
+                if (!uni) continue;
+                bool con = want_constant;
+                for (uint32_t l = 1; l < kSliceRows && con; ++l) con = memcmp(diag->val + diag->ptr[r0 + l], diag->val + p0, sizeof(double) * len) == 0;
+                cls[sl] = con ? 2 : 1;
+            }
+        });
         for (uint32_t sl = 0; sl < nslices; ++sl) {
             if (!group_is_sell[sl / (kGroupRows / kSliceRows)] || (sl + 1) * kSliceRows > nrows || slice_len[sl] == 0) continue;
             const uint32_t r0 = sl * kSliceRows, len = slice_len[sl];
-            bool uni = true;
-            for (uint32_t l = 0; l < kSliceRows && uni; ++l) uni = diag->ptr[r0 + l + 1] - diag->ptr[r0 + l] == len;
+            const bool uni = cls[sl] != 0;
             if (uni) {
                 cur.assign(len, 0);
                 for (uint32_t k = 0; k < len; ++k) cur[k] = (int)((int64_t)diag->col[diag->ptr[r0] + k] - (int64_t)r0);
-                for (uint32_t l = 1; l < kSliceRows && uni; ++l)
-                    for (uint32_t k = 0; k < len; ++k)
-                        if ((int64_t)diag->col[diag->ptr[r0 + l] + k] - (int64_t)(r0 + l) != cur[k]) { uni = false; break; }
             }
             if (!uni) {
                 // masked slice (SellDev::mbase): the rows are sub-sequences of one ascending list of <= 16 (distance, value) pairs
@@ -2673,10 +2687,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             // constant slice: entry k holds the same value in all 64 rows (SellDev::vbase)
             if (!want_constant) continue;
             const double *v0 = diag->val + diag->ptr[r0];
-            bool con = true;
-            for (uint32_t l = 1; l < kSliceRows && con; ++l)
-                con = memcmp(diag->val + diag->ptr[r0 + l], v0, sizeof(double) * len) == 0;
-            if (!con) continue;
+            if (cls[sl] != 2) continue;
             vkey.assign(cur.begin(), cur.end());                                  // distances, then the value bits
             for (uint32_t k = 0; k < len; ++k) { long long b; memcpy(&b, v0 + k, 8); vkey.push_back((int)(b & 0xFFFFFFFF)); vkey.push_back((int)(b >> 32)); }
             auto vt = vlists.find(vkey);
