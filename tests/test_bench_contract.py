@@ -57,6 +57,9 @@ def test_bench_names_the_bound_of_every_leg():
     # fractions on the bytes the stored layout moves; the CSR figure beside them
     for key in ("format_bytes", "format_gbps", "format_bytes_per_launch", "frac_of_format_bytes", "csr_bytes_per_launch", "csr_equivalent_gbps"):
         assert key in src, key
+    # second half of round 4: every timed region of the variant / extra legs and the set-up seconds of every leg are in the line
+    for key in ("timed_regions_ms", "setup_seconds", "setup_seconds_rank0"):
+        assert key in src, key
     # no entry is computed against the HBM peak outside roof() and the two legs that are HBM-sized by construction (512^3)
     assert src.count("/ HBM_PEAK_GBS") <= 6, src.count("/ HBM_PEAK_GBS")
 
