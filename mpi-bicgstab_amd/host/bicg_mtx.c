@@ -103,19 +103,22 @@ void bicg_partition_nnz(const unsigned int *row_nnz, unsigned int n, int nranks,
     for (int k = 0; k < nranks; ++k) counts[k] = (k + 1 < nranks ? displs[k + 1] : (int)n) - displs[k];
 }
 
-/* worker threads of the serial-mode loader: BICG_MTX_THREADS, else the cores this process may use (at most 16);
+/* worker threads of the loader: BICG_MTX_THREADS, else the cores this process may use divided by the ranks that share them
+ * (at most 32 per rank: the cap is applied AFTER the division -- 8 ranks on a 256-thread host get 32 each, not 2);
  * small inputs stay on the calling thread */
-static long loader_threads(size_t work_bytes)
+static long loader_threads_shared(size_t work_bytes, int ranks_on_node)
 {
     long nt = sysconf(_SC_NPROCESSORS_ONLN);
     cpu_set_t set;
     if (sched_getaffinity(0, sizeof set, &set) == 0) nt = CPU_COUNT(&set);
-    if (nt > 16) nt = 16;
+    nt /= ranks_on_node > 0 ? ranks_on_node : 1;
+    if (nt > 32) nt = 32;
     if (work_bytes < ((size_t)1 << 22)) nt = 1;
     const char *env = getenv("BICG_MTX_THREADS");
     if (env) nt = atol(env);
     return nt < 1 ? 1 : nt;
 }
+static long loader_threads(size_t work_bytes) { return loader_threads_shared(work_bytes, 1); }
 /* fn(arg + t * stride) on nt threads (the last one on the caller's); a thread that cannot be created runs inline */
 static void run_threads(long nt, void *(*fn)(void *), void *args, size_t stride)
 {
@@ -487,7 +490,7 @@ static void emit_serial(void *c, unsigned long i, unsigned long j, double v)
  * the triplets of [lo, hi) it finds in its own list, and the lists -- in range order: file order, like the one-thread
  * pass -- go to build_blocks as they are (the reference has every rank fscanf() the whole file twice,
  * src/matrix.c:315-341, 357-393; a Transport-sized file -- 840 MB, 23.9 M lines -- took the single tokeniser 2.1 s of a
- * 2.9 s run). BICG_MTX_THREADS overrides the count (default: the cores the process may use, at most 16; 1 = serial). */
+ * 2.9 s run). BICG_MTX_THREADS overrides the count (default: the cores the process may use, at most 32; 1 = serial). */
 typedef struct { const char *p, *end; mtx_header h; serial_ctx s; int rc; unsigned long max_entries; } parse_job;
 static void *parse_job_run(void *arg)
 {
@@ -752,22 +755,21 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     const char *q = stop;
     if (q > buf && q[-1] != '\n') { while (q < buf + len && *q != '\n') ++q; }
     /* This rank's byte range is tokenised ONCE, by several threads (sub-ranges cut at line ends; the ranks of a node share
-     * its cores: BICG_MTX_THREADS, else the cores this process may use / ranks, at most 16), into lists that keep every
+     * its cores: BICG_MTX_THREADS, else the cores this process may use / ranks, at most 32), into lists that keep every
      * triplet; lists in thread order = file order of the range. The non-zero balanced cuts are computed from those lists
      * (one all-reduce of the per-row counts), then the triplets are packed by owner for the exchange. */
     tseg *segs = NULL;
     int nseg = 0;
     if (p < q) {
-        long nt = loader_threads((size_t)(q - p));
-        if (!getenv("BICG_MTX_THREADS")) {              /* the ranks of THIS node share its cores */
+        int on_node = np;                               /* the ranks of THIS node share its cores */
+        {
             MPI_Comm node;
-            int on_node = np;
             if (MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, me, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
                 MPI_Comm_size(node, &on_node);
                 MPI_Comm_free(&node);
             }
-            nt /= on_node > 0 ? on_node : 1; if (nt < 1) nt = 1;
         }
+        const long nt = loader_threads_shared((size_t)(q - p), on_node);
         const unsigned long banner_nz = h.nz;
         h.nz = (unsigned long)-1;                       /* a byte range has no entry count of its own */
         rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);
