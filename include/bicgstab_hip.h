@@ -332,6 +332,10 @@ unsigned long long bicg_constant_entries(bicg_ctx *ctx);
  * the product reads one 16-bit word per row for them (which pairs the row has) instead of values and columns. Counted in
  * bicg_uniform_entries / bicg_constant_entries too (with their padded entries). BICG_SELL_MASKED=0 switches them off */
 unsigned long long bicg_masked_rows(bicg_ctx *ctx);
+/* bicg_create_device_csr groups its list-driven slices by 64-bit hashes of their lists and then compares every slice with the
+ * list it was given: the number of slices that did NOT match (hash collisions) and were put back on their stored columns and
+ * values. 0 for contexts built by bicg_create (the host plan keys on the full lists). */
+unsigned int bicg_plan_collisions(bicg_ctx *ctx);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
  * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST_SHIFTED=0 keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);
@@ -379,8 +383,10 @@ long bicg_window_plan(const unsigned int *ptr, const unsigned int *col, unsigned
                       unsigned int *runs, unsigned int *slots_used);
 unsigned int bicg_window_slot(const unsigned int *runs, unsigned int first, unsigned int end, unsigned int c);
 /* Host threads of the set-up (bicg_create's plan and bicg_window_plan cut their loops over slices / groups / rows into one range
- * per thread; the results do not depend on the number). 0 < n: use n threads from now on; returns the number in use. Default:
- * BICG_PLAN_THREADS, else the hardware's threads divided by the ranks of the job, at most 32. */
+ * per thread; the results do not depend on the number). 0 < n: use n threads from now on; n < 0: back to the default; returns the
+ * number in use. Default: BICG_PLAN_THREADS, else the hardware threads this process may run on (its affinity mask) divided by the
+ * ranks that share the host (LOCAL_WORLD_SIZE / OMPI_COMM_WORLD_LOCAL_SIZE / MPI_LOCALNRANKS / SLURM_NTASKS_PER_NODE, else the
+ * communicator's size), at most 32. */
 int bicg_set_plan_threads(int n);
 
 /* Plan of the persistent iteration (host only, what bicg_create builds for latency-bound ranks): the

@@ -1,6 +1,7 @@
 // bicg_comm.cpp -- transports: single rank, RCCL over xGMI (dlopen'ed, one process per GPU),
 // host-staged callbacks. See bicg_comm.h.
 #include "bicg_comm.h"
+#include "bicg_parallel.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only; the functions are resolved with dlsym
@@ -255,6 +256,7 @@ void comm_set(Comm *c)
         delete g_comm;
     }
     g_comm = c;
+    plan_ranks_hint() = c ? c->nranks : 1;      // set-up threads per rank: the host's threads are shared (bicg_parallel.h)
 }
 
 // First use without an explicit bicg_comm_init_*: adopt MPI_COMM_WORLD when the host program has

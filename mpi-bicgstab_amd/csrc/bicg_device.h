@@ -548,6 +548,9 @@ void launch_plan_uniform(const uint32_t *ptr, const uint32_t *col, const double 
 // (0: not masked); second call with mbase given: the rows' masks of the masked slices into rmask
 void launch_plan_masked(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, unsigned long long *mhash,
                         const uint32_t *mbase, unsigned short *rmask, hipStream_t st);
+void launch_plan_verify(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_len,
+                        const uint32_t *ubase, const uint32_t *vbase, const uint32_t *mbase, const unsigned short *rmask, const int *uoff,
+                        const double *uval, unsigned char *bad, hipStream_t st);
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st);
 

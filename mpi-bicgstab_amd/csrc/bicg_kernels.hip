@@ -1399,7 +1399,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu((MO
     // Which groups: workgroup bid stands for VIRTUAL workgroup vb of the canonical order -- XCD-contiguous (workgroup b runs on
     // XCD b % 8: XCD x gets the x-th eighth of the virtual workgroups, so one L2 fetches what neighbouring groups share) and,
     // every other product, reversed -- and takes the CONTIGUOUS groups vb * each ... of the list. Its partial sums go to slot vb
-    // whichever physical workgroup computed them: the association of a dot sum does not depend on direction or placement.
+    // whichever physical workgroup computed them: the association of a dot sum does not depend on placement. Direction: with ONE
+    // group per workgroup it does not matter either; with several (each > 1, grids beyond 65 536 groups) a reversed launch adds a
+    // workgroup's groups in the opposite order -- a different, equally fixed association, and every solve / stand-alone call starts
+    // from the same direction (bicg_ctx::spmv_dir is reset there), so repeated calls on one context give the same bits.
     // (Launches with the halo exchange inside keep the strided assignment: their leading workgroups are the senders.)
     unsigned vb = bid;
     if (a.xcd_map && !LL && bid < (nblocks / 8u) * 8u) vb = (bid % 8u) * (nblocks / 8u) + bid / 8u;

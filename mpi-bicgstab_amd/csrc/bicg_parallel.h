@@ -3,6 +3,8 @@
 // number of threads (BICG_PLAN_THREADS; default: the hardware's threads divided by the ranks of the job, at most 32).
 #pragma once
 
+#include <sched.h>
+
 #include <algorithm>
 #include <cstddef>
 #include <cstdlib>
@@ -13,17 +15,38 @@ namespace bicg {
 
 inline int &plan_threads_setting()
 {
-    static int n = 0;                                  // 0: not set yet
+    static int n = 0;                                  // 0: not set (bicg_set_plan_threads / BICG_PLAN_THREADS)
     return n;
 }
-inline int plan_threads(int ranks_on_host = 1)
+// the ranks of the job as the communicator knows them (comm_set): the fallback when the launcher's environment does not say
+// how many ranks share this host
+inline int &plan_ranks_hint()
+{
+    static int n = 1;
+    return n;
+}
+inline int ranks_on_this_host()
+{
+    // torchrun, Open MPI, MPICH / hydra, Slurm -- in that order; else every rank of the communicator (one node)
+    for (const char *name : {"LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE"})
+        if (const char *sv = getenv(name)) { const int v = atoi(sv); if (v > 0) return v; }
+    return std::max(1, plan_ranks_hint());
+}
+// hardware threads THIS process may run on (affinity mask / cpuset, what the loader's threads honour too), not the machine's
+inline unsigned usable_hw_threads()
+{
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) { const int c = CPU_COUNT(&set); if (c > 0) return (unsigned)c; }
+    const unsigned hw = std::thread::hardware_concurrency();
+    return hw ? hw : 1u;
+}
+inline int plan_threads()
 {
     int &n = plan_threads_setting();
     if (n > 0) return n;
     if (const char *sv = getenv("BICG_PLAN_THREADS")) { n = std::max(1, atoi(sv)); return n; }
-    const unsigned hw = std::thread::hardware_concurrency();
-    n = (int)std::min<unsigned>(32u, std::max<unsigned>(1u, (hw ? hw : 1u) / (unsigned)std::max(1, ranks_on_host)));
-    return n;
+    return (int)std::min<unsigned>(32u, std::max<unsigned>(1u, usable_hw_threads() / (unsigned)ranks_on_this_host()));
 }
 
 // f(begin, end, part) over [0, n) cut into contiguous ranges, one per thread (part = 0 .. parts - 1; returns parts)

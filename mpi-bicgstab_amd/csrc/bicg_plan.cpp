@@ -172,6 +172,7 @@ extern "C" long bicg_window_plan(const unsigned int *ptr, const unsigned int *co
 extern "C" int bicg_set_plan_threads(int n)
 {
     if (n > 0) bicg::plan_threads_setting() = n;
+    if (n < 0) bicg::plan_threads_setting() = 0;        // back to the automatic count
     return bicg::plan_threads();
 }
 

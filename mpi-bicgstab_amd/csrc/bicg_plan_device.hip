@@ -121,6 +121,48 @@ __global__ void __launch_bounds__(kThreads) k_plan_masked(const uint32_t *ptr, c
     if ((threadIdx.x & 63u) == 0 && live) mhash[slice] = (ok && n > 0) ? ((h << 5) | (unsigned long long)n) : 0ull;
 }
 
+// The lists the host attached to the list-driven slices are found by HASH (k_plan_uniform / k_plan_masked above; the host
+// fetches one representative per hash value). A collision would hand a slice another slice's list -- a silently wrong product.
+// This pass compares every row of every list-driven slice with the list it was given: distances, the values of constant /
+// masked slices, the length, and for masked slices that the row's mask accounts for all its entries. bad[s] = 1 where
+// anything differs; the host puts those slices back on their stored columns and values. One wavefront per slice, lane = row.
+__global__ void __launch_bounds__(kThreads) k_plan_verify(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
+                                                          const uint32_t *slice_len, const uint32_t *ubase, const uint32_t *vbase,
+                                                          const uint32_t *mbase, const unsigned short *rmask, const int *uoff,
+                                                          const double *uval, unsigned char *bad)
+{
+    const uint32_t r = blockIdx.x * kThreads + threadIdx.x;
+    const uint32_t slice = r / kSliceRows;
+    if (slice * kSliceRows >= rows) return;                                       // (wave-uniform)
+    const uint32_t ub = ubase[slice];
+    if (ub == 0xFFFFFFFFu) return;
+    const uint32_t vb = vbase ? vbase[slice] : 0xFFFFFFFFu, mb = mbase ? mbase[slice] : 0xFFFFFFFFu;
+    const bool live = r < rows;
+    bool ok = live;                                                               // a list-driven slice has all its 64 rows
+    if (live) {
+        const uint32_t a = ptr[r], len = ptr[r + 1] - a;
+        if (mb != 0xFFFFFFFFu) {
+            const uint32_t ulen = mb >> 26, mask = rmask[(size_t)(mb & 0x03FFFFFFu) * kSliceRows + (r % kSliceRows)];
+            uint32_t pos = 0;
+            ok = vb != 0xFFFFFFFFu && ulen <= 16u && (mask >> ulen) == 0u;
+            for (uint32_t k = 0; ok && k < ulen; ++k) {
+                if (!((mask >> k) & 1u)) continue;
+                ok = pos < len && (int)((long long)col[a + pos] - (long long)r) == uoff[ub + k] &&
+                     __double_as_longlong(val[a + pos]) == __double_as_longlong(uval[vb + k]);
+                ++pos;
+            }
+            ok = ok && pos == len;
+        } else {
+            ok = len == slice_len[slice];
+            for (uint32_t k = 0; ok && k < len; ++k) {
+                ok = (int)((long long)col[a + k] - (long long)r) == uoff[ub + k];
+                if (ok && vb != 0xFFFFFFFFu) ok = __double_as_longlong(val[a + k]) == __double_as_longlong(uval[vb + k]);
+            }
+        }
+    }
+    if (!__all(ok) && (threadIdx.x & 63u) == 0) bad[slice] = 1;
+}
+
 // entry k of row r -> slice_base[r / 64] + k * 64 + r % 64 (padding stays zero); 16-bit offsets four to a word
 __global__ void __launch_bounds__(kThreads) k_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows,
                                                         const uint32_t *slice_base, const uint32_t *slice_base16, double *sval,
@@ -184,6 +226,13 @@ void launch_plan_masked(const uint32_t *ptr, const uint32_t *col, const double *
                         const uint32_t *mbase, unsigned short *rmask, hipStream_t st)
 {
     hipLaunchKernelGGL(k_plan_masked, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, val, rows, mhash, mbase, rmask);
+}
+void launch_plan_verify(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_len,
+                        const uint32_t *ubase, const uint32_t *vbase, const uint32_t *mbase, const unsigned short *rmask, const int *uoff,
+                        const double *uval, unsigned char *bad, hipStream_t st)
+{
+    hipLaunchKernelGGL(k_plan_verify, dim3((rows + kThreads - 1) / kThreads), dim3(kThreads), 0, st, ptr, col, val, rows, slice_len, ubase, vbase,
+                       mbase, rmask, uoff, uval, bad);
 }
 void launch_plan_fill(const uint32_t *ptr, const uint32_t *col, const double *val, uint32_t rows, const uint32_t *slice_base,
                       const uint32_t *slice_base16, double *sval, uint32_t *scol, short *scol16, hipStream_t st)

@@ -99,6 +99,7 @@ struct bicg_ctx {
     uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_SELL_MASKED=0 switches them off
     unsigned short *s_rmask = nullptr;
     uint64_t masked_rows = 0;
+    uint32_t plan_collisions = 0;          // list-driven slices the device plan's verification pass put back (bicg_plan_collisions)
     int *s_uoff8 = nullptr;                // SellDev::uoff8
     int sell_ystride = 0;                  // SellDev::ystride (BICG_SELL_YGROUP=1; default: consecutive slices per workgroup)
     bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
@@ -1045,6 +1046,7 @@ void scal_reset(bicg_ctx *c)
 {
     c->wave_mode = false;
     c->grp = bicg_ctx::Group{};
+    c->spmv_dir = 0;             // stand-alone products and dots: always the same direction, whatever ran before
     BICG_HIP(hipMemsetAsync(c->S, 0, sizeof(Scal), c->sc));
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
 }
@@ -1095,7 +1097,8 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     c->grp = bicg_ctx::Group{};
     c->f1_done = false;
     c->pl_flip = 0;
-    c->spmv_dir = 0;             // every solve starts with a forward product: run-to-run bit reproducibility
+    c->spmv_dir = 0;             // every solve starts in the same direction (its first product toggles this to 1 = reversed):
+                                 // run-to-run bit reproducibility, also with several groups per workgroup
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the
     // solver's vectors. If matrix + vectors exceed it by less than ~25 % ordinary loads win: a good
     // part of the matrix survives from one SpMV to the next (Transport, plain: 149.5 vs 155.0 us
@@ -1397,6 +1400,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     if (o.check_every < 1) o.check_every = 1;
     use_device(c);
     c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
+    c->spmv_dir = 0;                     // same first direction for every solve on this context (see run_begin)
     const size_t st = c->stride, n = c->n_loc;
 
     if (c->sh_cap < nsig) {
@@ -1549,6 +1553,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     if (o.check_every < 1) o.check_every = 1;
     use_device(c);
     c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
+    c->spmv_dir = 0;                     // same first direction for every solve on this context (see run_begin)
     const size_t st = c->stride, n = c->n_loc;
 
     if (c->sh_cap < nsig) {
@@ -2955,6 +2960,10 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         BICG_HIP(hipMemcpy(uh.data(), uh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
         BICG_HIP(hipMemcpy(vh.data(), vh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
         BICG_HIP(hipFree(uh_d));
+        // tests: every hash lands in one of TWO buckets -- slices with different lists collide in their thousands and
+        // k_plan_verify has to catch each one (tests/test_full_size.py::test_device_plan_survives_hash_collisions)
+        const bool collide = getenv("BICG_PLAN_TEST_COLLIDE") && atoi(getenv("BICG_PLAN_TEST_COLLIDE")) != 0;
+        if (collide) for (uint32_t sl = 0; sl < nslices; ++sl) { if (uh[sl]) uh[sl] = 1ull + (uh[sl] >> 63); if (vh[sl]) vh[sl] = 1ull + (vh[sl] >> 63); }
         std::vector<uint32_t> vbase, mbase;
         std::vector<double> uval, vals;
         std::map<unsigned long long, uint32_t> vlists;
@@ -3006,6 +3015,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
             std::vector<unsigned long long> mh(nslices);
             BICG_HIP(hipMemcpy(mh.data(), mh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
             BICG_HIP(hipFree(mh_d));
+            if (collide) for (uint32_t sl = 0; sl < nslices; ++sl) if (mh[sl]) mh[sl] = (mh[sl] & 31ull) | (32ull << (mh[sl] >> 63));
             std::map<unsigned long long, std::pair<uint32_t, uint32_t>> mlists;       // hash -> (position in uoff, position in uval)
             std::vector<uint32_t> rp(kSliceRows + 1), rc;
             std::vector<double> rv;
@@ -3053,8 +3063,36 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         if (constant_entries) {
             c->s_vbase = dev_upload(vbase.data(), vbase.size());
             c->s_uval = dev_upload(uval.data(), uval.size());
-            build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase, uoff);
         }
+        // The groups above are keyed by 64-bit hashes: every list-driven slice is now compared with the list it was given
+        // (k_plan_verify), and a slice that differs -- a collision -- goes back to its stored columns and values, which
+        // launch_plan_fill has written for every slice. (The host plan keys on the full lists and needs no such pass.)
+        if (uniform_entries) {
+            unsigned char *bad_d = dev_alloc<unsigned char>(nslices);
+            BICG_HIP(hipMemset(bad_d, 0, nslices));
+            launch_plan_verify(ptr_d, col_d, val_d, rows, slen_d, c->s_ubase, c->s_vbase, c->s_mbase, c->s_rmask, c->s_uoff, c->s_uval, bad_d, nullptr);
+            std::vector<unsigned char> bad(nslices);
+            BICG_HIP(hipMemcpy(bad.data(), bad_d, nslices, hipMemcpyDeviceToHost));
+            BICG_HIP(hipFree(bad_d));
+            uint32_t nbad = 0;
+            for (uint32_t sl = 0; sl < nslices; ++sl) {
+                if (!bad[sl]) continue;
+                ++nbad;
+                const uint64_t e = (uint64_t)slen[sl] * kSliceRows;
+                uniform_entries -= e;
+                if (!vbase.empty() && vbase[sl] != 0xFFFFFFFFu) { constant_entries -= e; vbase[sl] = 0xFFFFFFFFu; }
+                if (!mbase.empty() && mbase[sl] != 0xFFFFFFFFu) { c->masked_rows -= kSliceRows; mbase[sl] = 0xFFFFFFFFu; }
+                ubase[sl] = 0xFFFFFFFFu;
+            }
+            c->plan_collisions = nbad;
+            if (nbad) {
+                BICG_HIP(hipMemcpy(c->s_ubase, ubase.data(), sizeof(uint32_t) * nslices, hipMemcpyHostToDevice));
+                if (c->s_vbase) BICG_HIP(hipMemcpy(c->s_vbase, vbase.data(), sizeof(uint32_t) * nslices, hipMemcpyHostToDevice));
+                if (c->s_mbase) BICG_HIP(hipMemcpy(c->s_mbase, mbase.data(), sizeof(uint32_t) * nslices, hipMemcpyHostToDevice));
+                if (getenv("BICG_PLAN_TRACE")) fprintf(stderr, "bicgstab_hip: %u list-driven slices did not match their list (hash collision): stored as general slices\n", nbad);
+            }
+        }
+        if (constant_entries) build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase, uoff);
     }
     c->uniform_entries = uniform_entries;
     c->constant_entries = constant_entries;
@@ -3369,6 +3407,7 @@ unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matr
 unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
 unsigned long long bicg_constant_entries(bicg_ctx *c) { return c->constant_entries; }
 unsigned long long bicg_masked_rows(bicg_ctx *c) { return c->masked_rows; }
+unsigned int bicg_plan_collisions(bicg_ctx *c) { return c->plan_collisions; }
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return c->matrix_bytes; }
 int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
 int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }

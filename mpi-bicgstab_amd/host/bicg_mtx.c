@@ -45,6 +45,8 @@ typedef struct {
     unsigned long long emitted;      /* entries handed to emit() by parse_entries (mirrored ones included) */
     unsigned long long lines;        /* entry lines parse_entries consumed */
     size_t data_off;      /* byte offset of the first entry line */
+    char err[160];        /* parse_entries' message for a malformed line: printed by the caller once the error is final (a range
+                           * that turns out to lie behind the nz-th entry line is never looked at, like in the reference) */
 } mtx_header;
 
 /* the reference's equal-rows partition, src/matrix.c:295-308 (kept local so that the loader does
@@ -198,6 +200,7 @@ static size_t file_size(const char *path)
 static int parse_header(const char *buf, mtx_header *h)
 {
     const char *p = buf;
+    h->err[0] = 0; h->lines = 0;
     if (strncmp(p, "%%MatrixMarket", 14) != 0) { fprintf(stderr, "ERROR: Could not process Matrix Market banner.\n"); return 2; }
     const char *eol = strchr(p, '\n');
     if (!eol) return 2;
@@ -370,7 +373,7 @@ static int parse_entries(const char *p, const char *end, mtx_header *h, unsigned
         unsigned long i, j;
         if (!fast_uint(p, &i, &p)) {
             i = strtoul(p, &q, 10);
-            if (q == p) { fprintf(stderr, "ERROR: reading matrix data.\n"); return 6; }
+            if (q == p) { snprintf(h->err, sizeof h->err, "ERROR: reading matrix data.\n"); return 6; }
             p = q;
         }
         while (*p == ' ' || *p == '\t') ++p;
@@ -379,7 +382,7 @@ static int parse_entries(const char *p, const char *end, mtx_header *h, unsigned
         if (!h->pattern && !fast_double(p, &v, &p)) { v = strtod(p, &q); p = q; }
         --i; --j;
         if (i >= h->m || j >= h->n) {    /* (0 wraps around: also caught) the reference would index outside its arrays */
-            fprintf(stderr, "ERROR: matrix entry (%lu, %lu) lies outside the %lu x %lu matrix.\n", i + 1, j + 1, (unsigned long)h->m, (unsigned long)h->n);
+            snprintf(h->err, sizeof h->err, "ERROR: matrix entry (%lu, %lu) lies outside the %lu x %lu matrix.\n", i + 1, j + 1, (unsigned long)h->m, (unsigned long)h->n);
             return 7;
         }
         emit(ctx, i, j, v);
@@ -521,16 +524,21 @@ static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigne
     {
         unsigned long long before = 0;
         for (long t = 0; t < nt && !rc; ++t) {
-            if (jobs[t].rc) { rc = jobs[t].rc; break; }
-            const unsigned long long mine = jobs[t].h.lines;
-            if (before >= h->nz && mine) {                        /* entirely past the last entry */
-                free(jobs[t].s.mine.t); memset(&jobs[t].s.mine, 0, sizeof jobs[t].s.mine); jobs[t].h.emitted = 0; jobs[t].h.lines = 0;
-            } else if (before + mine > h->nz) {
+            if (before >= h->nz) {                                /* entirely past the last entry: never looked at, whatever it holds */
                 free(jobs[t].s.mine.t); memset(&jobs[t].s.mine, 0, sizeof jobs[t].s.mine);
+                jobs[t].h.emitted = 0; jobs[t].h.lines = 0; jobs[t].rc = 0;
+                continue;
+            }
+            if (h->nz != (unsigned long)-1 && (jobs[t].rc || before + jobs[t].h.lines > h->nz)) {
+                /* the range that holds the nz-th line (or a malformed line that may lie behind it): read again, up to the
+                 * nz-th line only, and judge THAT pass */
+                free(jobs[t].s.mine.t); memset(&jobs[t].s.mine, 0, sizeof jobs[t].s.mine);
+                jobs[t].h = *h; jobs[t].h.emitted = 0; jobs[t].h.lines = 0;
                 jobs[t].max_entries = (unsigned long)(h->nz - before);
                 parse_job_run(&jobs[t]);
             }
-            before += mine;
+            if (jobs[t].rc) { rc = jobs[t].rc; fputs(jobs[t].h.err, stderr); break; }
+            before += jobs[t].h.lines;
         }
         if (!rc && h->nz != (unsigned long)-1 && before < h->nz) { fprintf(stderr, "ERROR: reading matrix data.\n"); rc = 6; }     /* the reference's message, src/matrix.c:318 */
         h->lines = before < h->nz ? before : h->nz;
@@ -539,7 +547,6 @@ static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigne
     *segs = (tseg *)calloc((size_t)nt, sizeof(tseg));
     *nseg = (int)nt;
     for (long t = 0; t < nt; ++t) {
-        if (jobs[t].rc) rc = jobs[t].rc;
         h->emitted += jobs[t].h.emitted;
         (*segs)[t].t = jobs[t].s.mine.t; (*segs)[t].n = jobs[t].s.mine.n;
     }
@@ -760,35 +767,51 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
      * (one all-reduce of the per-row counts), then the triplets are packed by owner for the exchange. */
     tseg *segs = NULL;
     int nseg = 0;
-    if (p < q) {
-        int on_node = np;                               /* the ranks of THIS node share its cores */
-        {
-            MPI_Comm node;
-            if (MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, me, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
-                MPI_Comm_size(node, &on_node);
-                MPI_Comm_free(&node);
-            }
+    int on_node = np;                                   /* the ranks of THIS node share its cores */
+    {   /* a collective: EVERY rank calls it, also one whose byte range holds no line start (more ranks than entry lines) */
+        MPI_Comm node;
+        if (MPI_Comm_split_type(MPI_COMM_WORLD, MPI_COMM_TYPE_SHARED, me, MPI_INFO_NULL, &node) == MPI_SUCCESS) {
+            MPI_Comm_size(node, &on_node);
+            MPI_Comm_free(&node);
         }
-        const long nt = loader_threads_shared((size_t)(q - p), on_node);
-        const unsigned long banner_nz = h.nz;
+    }
+    const unsigned long banner_nz = h.nz;
+    long nt = 1;
+    if (p < q) {
+        nt = loader_threads_shared((size_t)(q - p), on_node);
         h.nz = (unsigned long)-1;                       /* a byte range has no entry count of its own */
         rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);
         h.nz = banner_nz;
     } else {
         h.emitted = 0; h.lines = 0;
     }
-    free(buf);
-    {   /* a malformed range must stop every rank, not leave the others in the collectives below; so must a file whose number of
-         * entry lines is not the banner's (byte ranges cannot tell which line is the nz-th: the serial loader, like the
-         * reference, reads the first nz and ignores the rest -- here the file is refused, on every rank) */
-        unsigned long long lines = rc ? 0ull : h.lines;
-        MPI_Allreduce(MPI_IN_PLACE, &lines, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+    {   /* A malformed range must stop every rank, not leave the others in the collectives below; so must a file with FEWER
+         * entry lines than its banner says (the reference's error, src/matrix.c:315-318). MORE lines: the reference reads the
+         * first nz and never looks at the rest -- a prefix sum of the ranks' line counts finds the rank whose range holds the
+         * nz-th line (it reads its range again up to that line); the ranks behind it drop theirs. (A malformed line behind the
+         * nz-th one is still refused in this mode: a range that failed does not know how many lines it held.) */
+        unsigned long long mine = rc ? 0ull : h.lines, before = 0, lines = 0;
+        MPI_Exscan(&mine, &before, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
+        if (me == 0) before = 0;
+        MPI_Allreduce(&mine, &lines, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
         int any = rc;
         MPI_Allreduce(MPI_IN_PLACE, &any, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);
-        if (!any && lines != (unsigned long long)h.nz) {
+        if (!any && lines < (unsigned long long)h.nz) {
             if (me == 0) fprintf(stderr, "ERROR: reading matrix data: %llu entry lines, the banner says %lu.\n", lines, (unsigned long)h.nz);
             any = 6;
         }
+        if (!any && lines > (unsigned long long)h.nz && before + mine > (unsigned long long)h.nz) {
+            for (int i = 0; i < nseg; ++i) free(segs[i].t);
+            free(segs); segs = NULL; nseg = 0;
+            h.emitted = 0; h.lines = 0;
+            if (before < (unsigned long long)h.nz) {
+                h.nz = (unsigned long)((unsigned long long)banner_nz - before);
+                rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);   /* lines it has read once already */
+                h.nz = banner_nz;
+                if (rc) { fprintf(stderr, "ERROR: reading matrix data (second pass of rank %d).\n", me); MPI_Abort(MPI_COMM_WORLD, 1); }
+            }
+        }
+        free(buf);
         if (any) { for (int i = 0; i < nseg; ++i) free(segs[i].t); free(segs); return any; }
     }
     const int *pcounts = NULL, *pdispls = NULL;

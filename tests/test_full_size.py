@@ -289,6 +289,34 @@ def test_device_side_plan_matches_host_plan():
         ctx.close(); ref.close()
 
 
+def test_device_plan_survives_hash_collisions(monkeypatch):
+    """bicg_create_device_csr groups uniform / constant / masked slices by a 64-bit hash of their lists and fetches ONE
+    representative per hash (nothing compared a slice with the list it got). k_plan_verify now does, and a
+    slice that differs goes back to its stored columns and values. BICG_PLAN_TEST_COLLIDE=1 throws every hash into one of two
+    buckets: thousands of slices get a foreign list, every one has to be caught -- the product stays bit-exact."""
+    H.lib().bicg_comm_init_single(0)
+    weights = (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)
+    for m in (96, 64):
+        A = synth.stencil7(m, weights)
+        row, col, val = A.to_coo()
+        x = np.random.default_rng(m).standard_normal(A.rows)
+        want = O.spmv(A.rows, row, col, val, x)
+        monkeypatch.delenv("BICG_PLAN_TEST_COLLIDE", raising=False)
+        ctx, _, _, _ = H.Context.stencil7_on_device(m, weights)
+        assert ctx.plan_collisions() == 0 and ctx.constant_entries() > 0
+        clean_constant = ctx.constant_entries()
+        assert np.array_equal(ctx.spmv(x), want)
+        ctx.close()
+        monkeypatch.setenv("BICG_PLAN_TEST_COLLIDE", "1")
+        ctx, _, _, _ = H.Context.stencil7_on_device(m, weights)
+        assert ctx.plan_collisions() > 0 and ctx.constant_entries() < clean_constant
+        assert np.array_equal(ctx.spmv(x), want)
+        b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+        got = ctx.solve("bicgstab", b, tol=1e-10, max_iter=200)
+        assert np.abs(got["x"] - 1.0).max() <= 1e-7
+        ctx.close()
+
+
 def test_list_driven_slices_same_bits_whichever_loop_runs(monkeypatch):
     """Constant / masked slices (SellDev::vbase / mbase) have three forms of the product: the general loop of sell_row
     (BICG_SELL_DESC=0), sell_row with one descriptor per slice and the next slices' metadata requested ahead

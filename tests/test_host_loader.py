@@ -276,8 +276,8 @@ def test_entry_count_and_index_range_do_not_depend_on_threads(tmp_path):
     """The reference reads exactly the banner's nz entry lines (src/matrix.c:315-331: fewer is "ERROR: reading matrix data",
     lines after the nz-th are never looked at) and would index outside its arrays for an entry outside the matrix. Here: the
     serial-mode loader keeps the FIRST nz lines whatever the number of tokeniser threads, a short file fails with the
-    reference's message, an index outside m x n (0 included) is an error everywhere; the MPI byte-range mode cannot tell which
-    line is the nz-th and refuses a file whose line count differs from the banner -- on every rank."""
+    reference's message, an index outside m x n (0 included) is an error everywhere; the MPI byte-range mode finds the nz-th
+    line with a prefix sum over the ranks and drops what lies behind it."""
     A = synth.from_offsets(300, (0, 1, -1, 17, -17), diag_base=5.0, seed=2)
     row, col, val = synth.colmajor_coo(A)
     lines = [f"{i + 1} {j + 1} {v!r}\n" for i, j, v in zip(row.tolist(), col.tolist(), val.tolist())]
@@ -302,8 +302,24 @@ def test_entry_count_and_index_range_do_not_depend_on_threads(tmp_path):
             rows, ncols, d, o = _read(str(tmp_path / "o"), rank)
             ed, eo, counts, _ = _expected(A.rows, row, col, val, 2, rank)
             assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[2], ed.val) and np.array_equal(o[2], eo.val), threads
-    out = run(more, 2, "mpi", "2")
-    assert out.returncode != 0 and "entry lines, the banner says" in out.stderr, out.stderr
+    # the byte-range (MPI) mode: a prefix sum of the ranks' line counts finds the nz-th line; what lies behind it is dropped
+    for world, threads in ((2, "2"), (4, "1"), (3, "5")):
+        out = run(more, world, "mpi", threads)
+        assert out.returncode == 0, out.stderr
+        for rank in range(world):
+            rows, ncols, d, o = _read(str(tmp_path / "o"), rank)
+            ed, eo, counts, _ = _expected(A.rows, row, col, val, world, rank)
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[2], ed.val) and np.array_equal(o[2], eo.val), (world, threads)
+    # garbage and out-of-range lines BEHIND the nz-th entry line are never read by the reference: no error, no message,
+    # whatever the number of tokeniser threads
+    junk = write("junk.mtx", lines + ["999 999 1.0\n", "this is not an entry\n", "0 0 0\n"] * 40)
+    for threads in ("1", "4", "16"):
+        out = run(junk, 2, "serial", threads)
+        assert out.returncode == 0 and "ERROR" not in out.stderr, (threads, out.stderr)
+        for rank in range(2):
+            rows, ncols, d, o = _read(str(tmp_path / "o"), rank)
+            ed, eo, counts, _ = _expected(A.rows, row, col, val, 2, rank)
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[2], ed.val) and np.array_equal(o[2], eo.val), threads
     short = write("short.mtx", lines[:-5])
     for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "2")):
         out = run(short, 2, mode, threads)
@@ -313,6 +329,30 @@ def test_entry_count_and_index_range_do_not_depend_on_threads(tmp_path):
         for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "2")):
             out = run(path, 2, mode, threads)
             assert out.returncode != 0 and "outside the 300 x 300 matrix" in out.stderr, (bad, mode, threads, out.stderr)
+
+
+def test_mpi_mode_with_more_ranks_than_entry_lines(tmp_path):
+    """Eight ranks, six entry lines: some byte ranges hold no line start. Every collective of the MPI-mode loader is called
+    by every rank (round 4's loader called MPI_Comm_split_type only on ranks WITH lines and hung here)."""
+    n = 6
+    row = np.arange(n, dtype=np.int64)
+    col = (np.arange(n, dtype=np.int64) * 5) % n
+    val = np.linspace(1.0, 2.0, n)
+    mtx = str(tmp_path / "six.mtx")
+    with open(mtx, "w") as f:
+        f.write("%%MatrixMarket matrix coordinate real general\n")
+        f.write(f"{n} {n} {n}\n")
+        for i, j, v in zip(row.tolist(), col.tolist(), val.tolist()):
+            f.write(f"{i + 1} {j + 1} {v!r}\n")
+    prefix = str(tmp_path / "out")
+    for world in (8, 7):
+        subprocess.run([MPIEXEC, "-n", str(world), DUMP, mtx, prefix, "mpi"], check=True, timeout=60)
+        for rank in range(world):
+            rows, ncols, d, o = _read(prefix, rank)
+            ed, eo, counts, _ = _expected(n, row, col, val, world, rank)
+            assert rows == counts[rank]
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[1], ed.col) and np.array_equal(d[2], ed.val)
+            assert np.array_equal(o[0], eo.ptr) and np.array_equal(o[1], eo.col) and np.array_equal(o[2], eo.val)
 
 
 @pytest.mark.parametrize("world", [1, 2])

@@ -4,6 +4,9 @@ include/bicgstab_hip.h declares, keeps the reference's struct layouts, and its h
 import ctypes as C
 import os
 import re
+import shutil
+import subprocess
+import sys
 
 import numpy as np
 import pytest
@@ -232,7 +235,7 @@ def test_window_plan_does_not_depend_on_the_number_of_threads():
     A = synth.fem_like(n=117 * 117 * 3)
     L = H.lib()
     L.bicg_set_plan_threads.argtypes = [C.c_int]; L.bicg_set_plan_threads.restype = C.c_int
-    before = L.bicg_set_plan_threads(0)
+    before = -1                                        # back to the automatic count afterwards
     try:
         plans = []
         for nt in (1, 3, 16):
@@ -250,6 +253,32 @@ def test_window_plan_does_not_depend_on_the_number_of_threads():
             assert np.array_equal(v, pp[1][key]) if isinstance(v, np.ndarray) else v == pp[1][key], key
     finally:
         L.bicg_set_plan_threads(before)
+
+
+def test_set_up_threads_are_the_host_threads_divided_by_the_ranks_of_the_node():
+    """every rank's bicg_create used min(32, all hardware threads) whatever the number of ranks on the host.
+    The automatic count is (threads this process may run on) / (ranks sharing the host), at most 32; the launcher's
+    environment says how many ranks there are (torchrun's LOCAL_WORLD_SIZE here), the affinity mask how many threads."""
+    code = ("import ctypes, os, sys; sys.path.insert(0, %r); from mpi_bicgstab_amd import hipsolver as H; L = H.lib(); "
+            "L.bicg_set_plan_threads.restype = ctypes.c_int; print(L.bicg_set_plan_threads(0), len(os.sched_getaffinity(0)))" % ROOT)
+    def ask(env_extra, cpus=None):
+        env = {k: v for k, v in os.environ.items() if k not in ("BICG_PLAN_THREADS", "LOCAL_WORLD_SIZE", "OMPI_COMM_WORLD_LOCAL_SIZE", "MPI_LOCALNRANKS", "SLURM_NTASKS_PER_NODE")}
+        env.update(env_extra)
+        cmd = [sys.executable, "-c", code]
+        if cpus:
+            cmd = ["taskset", "-c", cpus] + cmd
+        out = subprocess.run(cmd, capture_output=True, text=True, env=env, timeout=120, check=True).stdout.split()
+        return int(out[0]), int(out[1])
+    n1, hw = ask({})
+    assert n1 == max(1, min(32, hw))
+    n4, _ = ask({"LOCAL_WORLD_SIZE": "4"})
+    assert n4 == max(1, min(32, hw // 4))
+    n_env, _ = ask({"LOCAL_WORLD_SIZE": "4", "BICG_PLAN_THREADS": "3"})
+    assert n_env == 3
+    if hw >= 2 and shutil.which("taskset"):
+        first_two = ",".join(str(c) for c in sorted(os.sched_getaffinity(0))[:2])
+        n_pin, hw_pin = ask({}, cpus=first_two)
+        assert hw_pin == 2 and n_pin == 2
 
 
 def test_window_plan_covers_every_column_once():
