@@ -244,6 +244,11 @@ int bicg_fetch(bicg_ctx *ctx, double *x_loc, double *r_loc);
  *   end     = summary lines (src/solver.c:134-141) and result */
 int bicg_run_begin(bicg_ctx *ctx, int method, const bicg_options *opt);
 int bicg_run_iterate(bicg_ctx *ctx, int nsteps);
+/* bicg_run_iterate with three clocks around it (ms): [0] the device's -- an event recorded on the compute stream in front of the
+ * first launch and one behind the last (hipEventElapsedTime); [1] the host time spent enqueueing the launches (until the loop over
+ * the iterations returned, before the scalars are fetched); [2] the host's wall time of the whole call. A region whose wall time
+ * is long while [0] is not was held up on the host side (or between the queue and the device), not in the kernels. */
+int bicg_run_iterate_timed(bicg_ctx *ctx, int nsteps, double ms[3]);
 int bicg_run_end(bicg_ctx *ctx, bicg_result *res);
 int bicg_sync(bicg_ctx *ctx);
 /* shifted solve on a resident matrix; variant = BICG_SHIFTED_LOP / _PIPE / _XI / _FLAG / _SWITCH (semantics
@@ -332,6 +337,14 @@ unsigned long long bicg_constant_entries(bicg_ctx *ctx);
  * the product reads one 16-bit word per row for them (which pairs the row has) instead of values and columns. Counted in
  * bicg_uniform_entries / bicg_constant_entries too (with their padded entries). BICG_SELL_MASKED=0 switches them off */
 unsigned long long bicg_masked_rows(bicg_ctx *ctx);
+/* The plane-marching product (csrc/bicg_stencil.hip): when the plan finds the 7-point stencil of a grid in the lists of a block
+ * whose slices are all list-driven -- the interior's distances are (-sz, -sy, -1, 0, +1, +sy, +sz) with sy a multiple of 64 rows,
+ * sz a multiple of sy, the rows a multiple of sz, and every other list a sub-sequence of that one -- y = A x runs with every
+ * wavefront marching through the planes of its own grid lines (BASELINE.json configs[3]); same sums in the same order as
+ * mult() (reference src/matrix.c:506-515). out = {in use (0/1), sy, sz / sy, rows / sz, lines per wavefront, planes per tile,
+ * workgroups per product, x segments with masked slices}. BICG_STENCIL=0 switches it off (slice-by-slice product);
+ * BICG_STENCIL_LINES=2|4, BICG_STENCIL_ZL=n set the tile; BICG_CA_FUSE=0 keeps CA-BiCGStab's q / y phase a kernel of its own */
+int bicg_stencil_info(bicg_ctx *ctx, unsigned int out[8]);
 /* bicg_create_device_csr groups its list-driven slices by 64-bit hashes of their lists and then compares every slice with the
  * list it was given: the number of slices that did NOT match (hash collisions) and were put back on their stored columns and
  * values. 0 for contexts built by bicg_create (the host plan keys on the full lists). */

@@ -213,6 +213,34 @@ struct CsrDev {
 // a banded matrix are coalesced across the wavefront, each lane adds ITS row in stored order.
 constexpr int kSliceRows = 64;
 constexpr int kGroupRows = kBlock;          // one workgroup = 4 slices = 256 consecutive rows
+
+// Plane-marching product (bicg_stencil.hip) for blocks whose slices are ALL list-driven (SellDev::all_lists) and whose lists are
+// sub-sequences of ONE seven-entry list of distances (-sz, -sy, -1, 0, +1, +sy, +sz) in that (= stored, ascending column) order,
+// with sy a multiple of 64 rows, sz a multiple of sy and the rows a multiple of sz: the 7-point stencil of an nx x ny x nz grid
+// with nx = sy, whatever its coefficients and faces look like (BASELINE.json configs[3]). Nothing about the GRID is assumed
+// beyond that: every x value is read at its literal distance from the row; what the lists do not contain is not added.
+// A wavefront owns lines_per_wave consecutive grid lines of one 64-wide x segment and marches through `zl` planes: the values
+// of its own rows in the planes z - 1, z, z + 1 stay in registers (the +-sz neighbours), the +-sy neighbours are the registers
+// of the adjacent line or one halo load per side, the +-1 neighbours come from the adjacent lane (DPP wave shift) -- each x line
+// is filled into an L1 once per wavefront that owns it plus (2 halo lines + 2 edge lines) per wavefront step, 6-8 cache lines per
+// 64-row slice where the slice-by-slice product fills 20 (profiles/r04/laplace512_spmv_counters_lists_loop.txt).
+//   code[(z nxs + xs) ny + y]   index of the slice's (distance list, value list) pair in tab
+//   tab[i]                      {the seven values in canonical position (0.0 where the list has no entry), presence bits}
+//   cmask                       one byte per row (presence bits) for the x segments that have masked slices (bit xs of mcols),
+//                               at ((z ny + y) nmc + rank of xs among them) 64 + lane
+struct StencilTab { double v[7]; unsigned long long bits; };      // 64 bytes: one scalar load
+struct StencilDev {
+    int on;
+    uint32_t sy, sz;                // distances in rows
+    uint32_t nxs, ny, nz;           // x segments (sy / 64), lines per plane (sz / sy), planes (rows / sz)
+    uint32_t zl;                    // planes per wavefront tile
+    uint32_t lines;                 // lines per wavefront (2, 4 or 8)
+    uint32_t nmc;                   // x segments with masked slices
+    unsigned long long mcols;
+    const uint32_t *code;
+    const StencilTab *tab;
+    const unsigned char *cmask;
+};
 struct SellDev {
     const double   *val;
     const uint32_t *col;
@@ -273,6 +301,7 @@ struct SellDev {
     const int *uoff8;
     int ystride;            // all_lists: slices per grid line when the lists look like a grid's (second-largest distance 64 x a power of
                             // two rows, slices a multiple of 4 x that), else 0 -- the four wavefronts of a workgroup take slices this far apart
+    StencilDev st;          // all_lists and every list a sub-sequence of (-sz, -sy, -1, 0, +1, +sy, +sz): the plane-marching product
 };
 enum SliceKind { kSliceGeneral = 0, kSliceUniform = 1, kSliceConstant = 2, kSliceMasked = 3 };
 // (PAD32C / PAD16C: padded slices of a block that has CONSTANT slices -- SellDev::vbase. Instantiations of their own: with the
@@ -453,6 +482,11 @@ bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hi
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                       bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
 bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // a.fw.wf = 1 / 2
+// plane-marching product of a 7-point grid stencil (bicg_stencil.hip; a.sell.st.on). epi = 1: CA-BiCGStab's q = r - alpha s,
+// y = w - alpha z, (q,y), (y,y) (reference src/solver.c:225-232) on the wavefront's own rows behind z = A s (a.epi.r / a.epi.w)
+unsigned stencil_grid(const StencilDev &st);
+bool launch_spmv_stencil(const SpmvArgs &a, int ndot, int epi, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void preload_stencil_kernels();
 void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
 // vectors per LDS window of the windowed form for `wslots` doubles per vector (0: the window does not fit, use launch_spmm_sell)
 int spmm_win_vectors(unsigned wslots);

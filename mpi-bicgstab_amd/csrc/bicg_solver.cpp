@@ -14,6 +14,7 @@
 #include <cstdlib>
 #include <cstring>
 #include <map>
+#include <tuple>
 #include <vector>
 
 #include "bicg_comm.h"
@@ -87,6 +88,9 @@ struct bicg_ctx {
     int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
     bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
     uint64_t matrix_bytes = 0;             // bytes one SpMV streams from the matrix arrays
+    uint64_t stencil_matrix_bytes = 0;     // ... when the plane-marching product runs (StencilDev)
+    hipEvent_t region_ev[2] = {nullptr, nullptr};   // bicg_run_iterate_timed
+    double t_enq = 0.0;
     uint64_t device_matrix_bytes = 0;      // bytes of matrix storage resident on the GPU
     // sliced-ELL copy of the diag block (rows whose 256-row group pads by < 25 %)
     double *s_val = nullptr;
@@ -103,6 +107,9 @@ struct bicg_ctx {
     int *s_uoff8 = nullptr;                // SellDev::uoff8
     int sell_ystride = 0;                  // SellDev::ystride (BICG_SELL_YGROUP=1; default: consecutive slices per workgroup)
     bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
+    StencilDev st{};                       // SellDev::st: the plane-marching product of a 7-point grid stencil (BICG_STENCIL=0: off)
+    uint32_t *st_code = nullptr; StencilTab *st_tab = nullptr; unsigned char *st_cmask = nullptr;
+    bool ca_fuse = true;                   // CA-BiCGStab: q, y and their dots in the epilogue of z = A s (plane-marching product only; BICG_CA_FUSE=0)
     uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
     double *s_uval = nullptr;
@@ -517,6 +524,12 @@ void group_defer(bicg_ctx *c, int n, int phase)
     c->pend = true; c->pend_n = n; c->pend_off = 0; c->pend_phase = phase; c->pend_ev = e;
 }
 
+// one rank, every row on the sliced-ELL path, and the plan found a grid's 7-point stencil (build_stencil_plan)
+static inline bool stencil_product(const bicg_ctx *c)
+{
+    return c->st.on && c->single() && c->ng_bnd == 0 && c->nblk == 0 && c->glist_all;      // (whatever order the groups are listed in)
+}
+
 // ---------------------------------------------------------------- distributed SpMV
 // y = A x (+ fused dots). Replaces MPI_csr_spmv_ovlap (reference src/matrix.c:428-441): the halo
 // exchange runs on the communication stream while the interior row blocks are multiplied; row
@@ -534,6 +547,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval; a.sell.mbase = c->s_mbase; a.sell.rmask = c->s_rmask;
     a.sell.sdesc = c->s_desc; a.sell.all_lists = c->sell_all_lists ? 1 : 0; a.sell.uoff8 = c->s_uoff8; a.sell.ystride = c->sell_ystride;
+    a.sell.st = c->st;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -560,6 +574,10 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     const bool merged = !c->single() && (fused || (!c->p2p && !(c->comm->stream_ordered() && c->overlap) && c->glist_all));
     const unsigned g_sall = sell_grid(c->ng_int + c->ng_bnd, a.groups_per_wg);
     red.expected = merged ? g_sall + g_ci + g_cb : g_si + g_ci + g_sb + g_cb;
+    // the plane-marching product (bicg_stencil.hip) takes the whole block in one launch of its own tiling
+    const bool stencil = stencil_product(c) && !fw && (epi == 0 || epi == 3) && !a.has_shift;
+    if (epi == 3 && !stencil) die("internal", "CA-BiCGStab's fused q / y epilogue without the plane-marching product");
+    if (stencil) red.expected = stencil_grid(c->st);
     red.slot_base = 0;
     a.red = red;
     if (red.wave && (ndot > 0 || epi)) c->grp.nparts = red.expected * (kBlock / 64);   // one partial per wavefront
@@ -592,14 +610,17 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // iteration), so a workgroup takes several 256-row groups. Ranks sharing a GPU (tests): every row workgroup of
     // the launch waits for the scalars, all ranks' launches must fit on the GPU together.
     const unsigned epi_cap = c->wg_cap ? c->wg_cap : 8192u;
-    if (epi && c->ng_int + c->ng_bnd > epi_cap) {
+    if (epi && !stencil && c->ng_int + c->ng_bnd > epi_cap) {
         const unsigned ng = c->ng_int + c->ng_bnd;
         a.groups_per_wg = std::max<int>(a.groups_per_wg, (int)((ng + epi_cap - 1) / epi_cap));
         red.expected = sell_grid(ng, a.groups_per_wg) + g_ci;
         a.red.expected = red.expected;
         c->grp.nparts = red.expected * (kBlock / 64);
     }
-    if (c->single()) {
+    if (stencil) {
+        a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
+        took(launch_spmv_stencil(a, ndot, epi == 3 ? 1 : 0, c->sc, ev(0), ev(1)));
+    } else if (c->single()) {
         if (epi) {
             a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
             took(launch_spmv_sell_epi(a, epi, false, c->sc, ev(0), ev(1)));
@@ -822,8 +843,11 @@ void group_flush(bicg_ctx *c)
 void fetch_scal(bicg_ctx *c);
 }  // namespace
 // One descriptor per slice (SellDev::sdesc) from the per-slice arrays of the plan: blocks with list-driven slices only
+static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const std::vector<uint4> &d, const std::vector<int> &uoff,
+                               const std::vector<double> &uval, const unsigned short *rmask_host);
 static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const uint32_t *slice_len, const std::vector<uint32_t> &ubase,
-                             const std::vector<uint32_t> &vbase, const std::vector<uint32_t> &mbase, const std::vector<int> &uoff)
+                             const std::vector<uint32_t> &vbase, const std::vector<uint32_t> &mbase, const std::vector<int> &uoff,
+                             const std::vector<double> &uval, const unsigned short *rmask_host)
 {
     if (vbase.empty() || ubase.empty() || (uint64_t)nrows >= (1ull << 29)) return;
     if (getenv("BICG_SELL_DESC") && atoi(getenv("BICG_SELL_DESC")) == 0) return;
@@ -862,6 +886,118 @@ static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, cons
     }
     c->s_desc = dev_upload(d.data(), d.size());
     c->matrix_bytes += 8ull * nslices;          // 16 bytes of descriptor per slice where base + length were counted
+    if (all_lists) build_stencil_plan(c, nslices, nrows, d, uoff, uval, rmask_host);
+}
+
+// The plane-marching product (struct StencilDev, bicg_stencil.hip): is this block the 7-point stencil of a grid? Decided from the
+// lists alone -- the interior's list must be (-sz, -sy, -1, 0, +1, +sy, +sz) with sy a multiple of 64 rows, sz a multiple of sy,
+// the rows a multiple of sz, and every other list a sub-sequence of it in the same order. Values may differ from list to list
+// (every (distance list, value list) pair gets a table entry); rows of masked slices get their entries as canonical bits.
+static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const std::vector<uint4> &d, const std::vector<int> &uoff,
+                               const std::vector<double> &uval, const unsigned short *rmask_host)
+{
+    if (getenv("BICG_STENCIL") && atoi(getenv("BICG_STENCIL")) == 0) return;
+    uint32_t best_at = 0, best_len = 0;
+    // the interior's list: the longest one, of a constant slice or (a grid one x segment wide has no other) of a masked one
+    for (uint32_t sl = 0; sl < nslices; ++sl) { const uint32_t l = d[sl].x & 0xFFFFu; if ((d[sl].x >> 16) >= kSliceConstant && l > best_len) { best_len = l; best_at = d[sl].y; } }
+    if (best_len != 7) return;
+    const int *L = uoff.data() + best_at;
+    if (!(L[3] == 0 && L[2] == -1 && L[4] == 1 && L[5] > 1 && L[6] > L[5] && L[1] == -L[5] && L[0] == -L[6])) return;
+    const uint32_t sy = (uint32_t)L[5], sz = (uint32_t)L[6];
+    if (sy % kSliceRows || sz % sy || nrows % sz || sy / kSliceRows > 64u) return;
+    const uint32_t nxs = sy / kSliceRows, ny = sz / sy, nz = nrows / sz;
+    if (ny % 2u) return;
+    const int canon[7] = {-(int)sz, -(int)sy, -1, 0, 1, (int)sy, (int)sz};
+    struct Entry { StencilTab t; signed char pos[8]; };
+    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> pairs;
+    std::vector<Entry> entries;
+    std::vector<uint32_t> code(nslices), which(nslices);
+    unsigned long long mcols = 0;
+    for (uint32_t sl = 0; sl < nslices; ++sl) {
+        const uint32_t kind = d[sl].x >> 16, len = d[sl].x & 0xFFFFu;
+        const auto key = std::make_tuple(d[sl].y, d[sl].z, len);
+        auto it = pairs.find(key);
+        if (it == pairs.end()) {
+            if (entries.size() >= 65536u) return;
+            Entry e;
+            memset(&e, 0, sizeof e);
+            int cpos = -1;
+            for (uint32_t k = 0; k < len; ++k) {
+                int at = -1;
+                for (int q = cpos + 1; q < 7; ++q) if (canon[q] == uoff[d[sl].y + k]) { at = q; break; }
+                if (at < 0) return;                                   // a distance the grid does not have, or out of order: not this product
+                cpos = at;
+                e.t.v[at] = uval[d[sl].z + k];
+                e.t.bits |= 1ull << at;
+                e.pos[k] = (signed char)at;
+            }
+            it = pairs.emplace(key, (uint32_t)entries.size()).first;
+            entries.push_back(e);
+        }
+        const uint32_t xs = sl % nxs, line = sl / nxs, yy = line % ny, zz = line / ny;
+        which[sl] = it->second;
+        code[((size_t)zz * nxs + xs) * ny + yy] = it->second;
+        if (kind == kSliceMasked) mcols |= 1ull << xs;
+    }
+    const uint32_t nmc = (uint32_t)__builtin_popcountll(mcols);
+    std::vector<unsigned char> cmask;
+    if (nmc) {
+        std::vector<unsigned short> rm_dl;
+        if (!rmask_host) {                                            // the device plan wrote the rows' masks on the GPU
+            uint32_t top = 0;
+            for (uint32_t sl = 0; sl < nslices; ++sl) if ((d[sl].x >> 16) == kSliceMasked) top = std::max(top, d[sl].w + 1u);
+            rm_dl.resize((size_t)top * kSliceRows);
+            BICG_HIP(hipMemcpy(rm_dl.data(), c->s_rmask, sizeof(unsigned short) * rm_dl.size(), hipMemcpyDeviceToHost));
+            rmask_host = rm_dl.data();
+        }
+        cmask.assign((size_t)(nslices / nxs) * nmc * kSliceRows, 0);
+        parallel_ranges(nslices, 4096, [&](size_t s0, size_t s1, int) {
+            for (size_t sl = s0; sl < s1; ++sl) {
+                const uint32_t xs = (uint32_t)(sl % nxs);
+                if (!((mcols >> xs) & 1ull)) continue;
+                const uint32_t dense = (uint32_t)__builtin_popcountll(mcols & ((1ull << xs) - 1ull));
+                unsigned char *out = cmask.data() + ((sl / nxs) * nmc + dense) * kSliceRows;
+                const Entry &e = entries[which[sl]];
+                if ((d[sl].x >> 16) == kSliceMasked) {
+                    const unsigned short *pm = rmask_host + (size_t)d[sl].w * kSliceRows;
+                    const uint32_t len = d[sl].x & 0xFFFFu;
+                    for (uint32_t l = 0; l < kSliceRows; ++l) {
+                        unsigned bits = 0;
+                        for (uint32_t k = 0; k < len; ++k) if ((pm[l] >> k) & 1u) bits |= 1u << e.pos[k];
+                        out[l] = (unsigned char)bits;
+                    }
+                } else {
+                    for (uint32_t l = 0; l < kSliceRows; ++l) out[l] = (unsigned char)e.t.bits;
+                }
+            }
+        });
+    }
+    std::vector<StencilTab> tab(entries.size());
+    for (size_t i = 0; i < entries.size(); ++i) tab[i] = entries[i].t;
+    // lines per wavefront and planes per tile: enough workgroups for several rounds of the 1024 a GPU holds, tiles as deep as that allows
+    uint32_t lines = 0, zl = 0;
+    {
+        static const uint32_t cand[][2] = {{4, 32}, {4, 16}, {2, 32}, {2, 16}, {4, 8}, {2, 8}, {2, 4}};
+        uint64_t most = 0;
+        for (auto &cd : cand) {
+            if (ny % cd[0]) continue;
+            const uint64_t wgs = (uint64_t)nxs * ((ny + 4 * cd[0] - 1) / (4 * cd[0])) * ((nz + cd[1] - 1) / cd[1]);
+            if (wgs >= 3000) { lines = cd[0]; zl = cd[1]; break; }
+            if (wgs > most) { most = wgs; lines = cd[0]; zl = cd[1]; }
+        }
+        if (const char *v = getenv("BICG_STENCIL_LINES")) { const uint32_t r = (uint32_t)atoi(v); if ((r == 2 || r == 4) && ny % r == 0) lines = r; }
+        if (const char *v = getenv("BICG_STENCIL_ZL")) { const int z = atoi(v); if (z >= 1) zl = (uint32_t)z; }
+    }
+    c->st_code = dev_upload(code.data(), code.size());
+    c->st_tab = dev_upload(tab.data(), tab.size());
+    if (nmc) c->st_cmask = dev_upload(cmask.data(), cmask.size());
+    c->st = StencilDev{1, sy, sz, nxs, ny, nz, zl, lines, nmc, mcols, c->st_code, c->st_tab, c->st_cmask};
+    if (const char *v = getenv("BICG_CA_FUSE")) c->ca_fuse = atoi(v) != 0;
+    // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
+    c->stencil_matrix_bytes = 4ull * nslices + (uint64_t)cmask.size();
+    if (getenv("BICG_PLAN_TRACE"))
+        fprintf(stderr, "bicgstab_hip: plane-marching product: %u x %u x %u grid (x segments of 64 rows: %u), %zu list pairs, %u masked x segments, %u lines x %u planes per wavefront, %u workgroups\n",
+                sy, ny, nz, nxs, tab.size(), nmc, lines, zl, stencil_grid(c->st));
 }
 
 void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups);
@@ -959,8 +1095,13 @@ struct Driver {
     void iter_ca()      // reference src/solver.c:217-251
     {
         launch_ca_ps(v, here());                                // p, s recurrences
-        spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));       // z = A s
-        launch_qy(v, here(), c->red(0, PH_OMEGA, true, 2));     // q, y, (q,y), (y,y) -> omega
+        if (c->ca_fuse && stencil_product(c) && !c->cur_has_shift) {
+            // z = A s with q = r - alpha s, y = w - alpha z, (q,y), (y,y) on the product's own rows: s_i and z_i are registers there
+            spmv(c, v.s, v.z, 2, nullptr, c->red(0, PH_OMEGA, true, 2), Finish{}, 3);
+        } else {
+            spmv(c, v.s, v.z, 0, nullptr, c->red(0, PH_NONE));   // z = A s
+            launch_qy(v, here(), c->red(0, PH_OMEGA, true, 2)); // q, y, (q,y), (y,y) -> omega
+        }
         group_now(c, 2, PH_OMEGA);
         launch_ca_xr(v, here(), c->red(0, PH_NONE, false));     // x, r, (r,r), (r#,r), (r#,s), (r#,z)
         spmv(c, v.r, v.w, 1, v.rh, c->red(2, PH_RECUR_END, true, 5));     // w = A r, (r#,w) -> beta, alpha, k++
@@ -1222,6 +1363,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
             c->adaptive_rr++;
         }
         sec_mark(c, SEC_VEC);
+        const double t_chunk = now_sec();
         if (persist) persist = persist_chunk(c, chunk);   // one launch for the whole chunk (bicg_persist.hip); false: it could not be launched
         for (int j = 0; j < chunk && !persist; ++j) {
             // the last iteration before the caller (or the drift check) reads x / r leaves them as the reference would
@@ -1231,6 +1373,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
         }
         c->it += chunk;
         sec_mark(c, SEC_STOP);
+        c->t_enq += now_sec() - t_chunk;          // (bicg_run_iterate_timed: host time until the chunk's launches were enqueued)
         fetch_scal(c);
         if (persist && c->method >= BICG_PIPE_BICGSTAB) persist_account(c);
         if (talk && o.out_iter > 0) {   // reference src/solver.c:122-126
@@ -2213,6 +2356,7 @@ static void preload_for(bicg_ctx *c)
     d.vbase = c->s_vbase;
     preload_kernels(d, c->sell_entries > 0);
     if (c->persist_on) preload_persist_kernels();
+    if (c->st.on) preload_stencil_kernels();
 }
 
 bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
@@ -2779,7 +2923,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->s_ubase = dev_upload(ubase.data(), ubase.size());
         c->s_uoff = dev_upload(uoff.data(), uoff.size());
     }
-    build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase, uoff);
+    build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase, uoff, uval, rmask.empty() ? nullptr : rmask.data());
     c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {
@@ -3092,7 +3236,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
                 if (getenv("BICG_PLAN_TRACE")) fprintf(stderr, "bicgstab_hip: %u list-driven slices did not match their list (hash collision): stored as general slices\n", nbad);
             }
         }
-        if (constant_entries) build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase, uoff);
+        if (constant_entries) build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase, uoff, uval, nullptr);
     }
     c->uniform_entries = uniform_entries;
     c->constant_entries = constant_entries;
@@ -3155,7 +3299,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -3171,6 +3315,7 @@ void bicg_destroy(bicg_ctx *c)
             if (e) (void)hipEventDestroy(e);      // a context that failed early in bicg_create has none
     }
     for (auto &e : c->tev) (void)hipEventDestroy(e);
+    for (auto &e : c->region_ev) if (e) (void)hipEventDestroy(e);
     for (auto &e : c->sec_ev) (void)hipEventDestroy(e);
     for (auto &ge : c->graph_exec) if (ge) (void)hipGraphExecDestroy(ge);
     if (c->sc) (void)hipStreamDestroy(c->sc);
@@ -3200,6 +3345,21 @@ int bicg_fetch(bicg_ctx *c, double *x, double *r)
 int bicg_run(bicg_ctx *c, int method, const bicg_options *opt, bicg_result *res) { return run_solver(c, method, opt, res); }
 int bicg_run_begin(bicg_ctx *c, int method, const bicg_options *opt) { run_begin(c, method, opt); return 0; }
 int bicg_run_iterate(bicg_ctx *c, int nsteps) { return run_iterate(c, nsteps); }
+int bicg_run_iterate_timed(bicg_ctx *c, int nsteps, double ms[3])
+{
+    use_device(c);
+    if (!c->region_ev[0]) for (auto &e : c->region_ev) BICG_HIP(hipEventCreate(&e));
+    c->t_enq = 0.0;
+    const double t0 = now_sec();
+    BICG_HIP(hipEventRecord(c->region_ev[0], c->sc));
+    const int k = run_iterate(c, nsteps);
+    BICG_HIP(hipEventRecord(c->region_ev[1], c->sc));
+    BICG_HIP(hipEventSynchronize(c->region_ev[1]));
+    float dev = 0.f;
+    BICG_HIP(hipEventElapsedTime(&dev, c->region_ev[0], c->region_ev[1]));
+    ms[0] = dev; ms[1] = 1e3 * c->t_enq; ms[2] = 1e3 * (now_sec() - t0);
+    return k;
+}
 int bicg_run_end(bicg_ctx *c, bicg_result *res) { return run_end(c, res); }
 int bicg_sync(bicg_ctx *c)
 {
@@ -3407,8 +3567,16 @@ unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matr
 unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
 unsigned long long bicg_constant_entries(bicg_ctx *c) { return c->constant_entries; }
 unsigned long long bicg_masked_rows(bicg_ctx *c) { return c->masked_rows; }
+int bicg_stencil_info(bicg_ctx *c, unsigned int out[8])
+{
+    const bool on = stencil_product(c);
+    const StencilDev &t = c->st;
+    const unsigned int v[8] = {on ? 1u : 0u, t.sy, t.ny, t.nz, t.lines, t.zl, on ? stencil_grid(t) : 0u, t.nmc};
+    for (int i = 0; i < 8; ++i) out[i] = v[i];
+    return on ? 1 : 0;
+}
 unsigned int bicg_plan_collisions(bicg_ctx *c) { return c->plan_collisions; }
-unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return c->matrix_bytes; }
+unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return stencil_product(c) ? c->stencil_matrix_bytes : c->matrix_bytes; }
 int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
 int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }
 

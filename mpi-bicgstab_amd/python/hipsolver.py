@@ -60,7 +60,7 @@ EXPORTS = [
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_run_begin", "bicg_run_iterate", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_plan_collisions", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_plan_collisions", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
 ]
 
@@ -83,6 +83,7 @@ def lib():
                                          C.POINTER(Result)]
         L.bicg_run_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
         L.bicg_run_iterate.argtypes = [C.c_void_p, C.c_int]
+        L.bicg_run_iterate_timed.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_run_end.argtypes = [C.c_void_p, C.POINTER(Result)]
         L.bicg_sync.argtypes = [C.c_void_p]
         L.bicg_load.argtypes = [C.c_void_p, _dp, _dp]
@@ -93,6 +94,7 @@ def lib():
         L.bicg_dot.restype = C.c_double
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
+        L.bicg_stencil_info.argtypes = [C.c_void_p, _up]
         L.bicg_section_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bicg_comm_failed.argtypes = [C.c_void_p]
         L.bicg_dropin_context.restype = C.c_void_p
@@ -345,6 +347,12 @@ class Context:
     def run_iterate(self, nsteps: int) -> int:
         return lib().bicg_run_iterate(self.h, nsteps)
 
+    def run_iterate_timed(self, nsteps: int):
+        """run_iterate with three clocks (ms): device events around the launches, host time spent enqueueing, host wall time"""
+        ms = (C.c_double * 3)()
+        k = lib().bicg_run_iterate_timed(self.h, nsteps, ms)
+        return k, dict(device_ms=ms[0], enqueue_ms=ms[1], wall_ms=ms[2])
+
     def run_end(self) -> Result:
         res = Result()
         lib().bicg_run_end(self.h, C.byref(res))
@@ -400,6 +408,12 @@ class Context:
 
     def masked_rows(self) -> int:
         return int(lib().bicg_masked_rows(self.h))
+
+    def stencil_info(self):
+        """The plane-marching product of a 7-point grid stencil (csrc/bicg_stencil.hip): is it in use, and its tiling."""
+        out = (C.c_uint * 8)()
+        lib().bicg_stencil_info(self.h, out)
+        return dict(zip(("on", "sy", "ny", "nz", "lines", "planes", "workgroups", "masked_segments"), list(out)))
 
     def plan_collisions(self) -> int:
         return int(lib().bicg_plan_collisions(self.h))

@@ -190,6 +190,29 @@ def stencil7(m: int, weights=(6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0), rows=Non
     return CSR(hi - lo, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), vals[ok].copy())
 
 
+def grid7(nx: int, ny: int, nz: int, weights=(6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0), upper_weights=None, wrap_y: bool = False) -> CSR:
+    """7-point stencil on an nx x ny x nz grid (x fastest), weights as in stencil7. upper_weights: the coefficients of the planes
+    z >= nz // 2 (two value lists for one distance list). wrap_y: the rows of a plane's first / last line keep their -nx / +nx
+    entry where that row exists (it lies in the neighbouring plane) -- same distances, different rows have them."""
+    n = nx * ny * nz
+    idx = np.arange(n, dtype=np.int64)
+    ix, iy, iz = idx % nx, (idx // nx) % ny, idx // (nx * ny)
+    ylo = (idx - nx >= 0) if wrap_y else (iy > 0)
+    yhi = (idx + nx < n) if wrap_y else (iy < ny - 1)
+    order = (5, 3, 1, 0, 2, 4, 6)          # weights' positions in ascending column order
+    masks = (iz > 0, ylo, ix > 0, np.ones(n, bool), ix < nx - 1, yhi, iz < nz - 1)
+    offs = (-nx * ny, -nx, -1, 0, 1, nx, nx * ny)
+    cols = np.stack([idx + o for o in offs], axis=1)
+    ok = np.stack(masks, axis=1)
+    w_lo = np.array([weights[k] for k in order], dtype=np.float64)
+    vals = np.broadcast_to(w_lo[None, :], cols.shape).copy()
+    if upper_weights is not None:
+        vals[iz >= nz // 2, :] = np.array([upper_weights[k] for k in order], dtype=np.float64)[None, :]
+    ptr = np.zeros(n + 1, dtype=np.int64)
+    np.cumsum(ok.sum(axis=1), out=ptr[1:])
+    return CSR(n, n, ptr.astype(np.uint32), cols[ok].astype(np.uint32), vals[ok].copy())
+
+
 def stencil7_nnz(m: int) -> int:
     return 7 * m ** 3 - 6 * m * m
 

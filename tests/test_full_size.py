@@ -330,8 +330,10 @@ def test_list_driven_slices_same_bits_whichever_loop_runs(monkeypatch):
         x = np.random.default_rng(m).standard_normal(A.rows)
         b = None
         results = []
-        for env in ({"BICG_SELL_DESC": "0"}, {"BICG_SELL_LISTS": "0"}, {}):
-            for k in ("BICG_SELL_DESC", "BICG_SELL_LISTS"):
+        # (BICG_STENCIL=0: the 64^3 grid would otherwise go to the plane-marching product, whose dot sums are tiled differently --
+        # tests/test_stencil.py compares that one)
+        for env in ({"BICG_SELL_DESC": "0"}, {"BICG_SELL_LISTS": "0"}, {"BICG_STENCIL": "0"}):
+            for k in ("BICG_SELL_DESC", "BICG_SELL_LISTS", "BICG_STENCIL"):
                 monkeypatch.delenv(k, raising=False)
             for k, v in env.items():
                 monkeypatch.setenv(k, v)
