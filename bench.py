@@ -158,6 +158,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=200)
     ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--regions", type=int, default=3, help="timed regions of exactly --steps iterations each for the headline; "
+                    "`value` is their median, every region goes into the line with its three clocks (headline_regions)")
     ap.add_argument("--method", default="bicgstab", choices=list(ITER_VECTOR_BYTES_PER_ROW))
     ap.add_argument("--rows", dest="n", type=int, default=0, help="rows (default: 1602111; banded: ~24 M non-zeros)")
     ap.add_argument("--scale-decades", type=float, default=2.0)
@@ -253,6 +255,14 @@ def main():
 
     comm_info = {"world": world, "p2p_selftest": None, "rccl_nranks": None, "transport_used": None, "fallback_reason": None}
 
+    def p2p_label(mode, base):
+        """what the peer-to-peer data path crossed: xGMI links only when every rank has a GPU of its own"""
+        mem = "uncached" if mode == 2 else "device"
+        if world > torch.cuda.device_count():
+            return (f"peer-to-peer LL stores between processes SHARING one device (HIP IPC, {mem} memory; no xGMI link involved; "
+                    f"bootstrap {base})")
+        return f"peer-to-peer LL stores over xGMI (HIP IPC, {mem} memory; bootstrap {base})"
+
     def comm_setup(use_p2p, allow_rccl=True, want="auto"):
         """(Re)create the library's communicator; returns a description of the data path in use."""
         from mpi_bicgstab_amd import dist_transport
@@ -267,8 +277,7 @@ def main():
                 comm_info["p2p_selftest"] = "passed" if rc_p2p == 0 and int(L.bicg_comm_p2p_active()) else f"failed (code {rc_p2p})"
                 if int(L.bicg_comm_p2p_active()):
                     mode = int(L.bicg_comm_p2p_active())
-                    return mode, (f"peer-to-peer LL stores over xGMI (HIP IPC, {'uncached' if mode == 2 else 'device'} memory; "
-                                  "bootstrap gloo)")
+                    return mode, p2p_label(mode, "gloo")
                 L.bicg_comm_finalize()
                 use_p2p = False
             base = "gloo-staged"
@@ -306,8 +315,7 @@ def main():
             return 0, "none"
         mode = int(L.bicg_comm_p2p_active())
         if mode:
-            return mode, (f"peer-to-peer LL stores over xGMI (HIP IPC, {'uncached' if mode == 2 else 'device'} memory; "
-                          f"bootstrap {base})")
+            return mode, p2p_label(mode, base)
         return 0, base
 
     p2p_mode, transport_name = comm_setup(a.transport in ("auto", "host-p2p"))
@@ -392,6 +400,7 @@ def main():
         return dict(name=workload, rows=rows, nnz=nnz, blocks=blocks, lo=lo, hi=hi, data="synthetic", desc=desc)
 
     regions_ms = {}            # every timed region of the variant / extra legs, per leg and method (ms per region)
+    region_clocks = {}         # ... and its three clocks (host region, device events, host enqueue time)
 
     class Leg:
         """one resident matrix: context, right-hand side, timed solves"""
@@ -416,8 +425,12 @@ def main():
             kernels -- 4-10 ms, now paid inside bicg_create (preload_kernels) -- and nothing longer than that could be
             provoked outside this script: profiles/r04/preload_check.txt. The headline `value` is a single region of
             exactly K iterations.)"""
-            runs = [self.timed(method, steps=steps, warm=warm) for _ in range(tries)]
-            regions_ms.setdefault(f'{self.wl.get("desc", "headline")} / {method}', []).extend(round(1e3 * r[0], 4) for r in runs)
+            runs = []
+            for _ in range(tries):
+                runs.append(self.timed(method, steps=steps, warm=warm))
+                key = f'{self.wl.get("desc", "headline")} / {method}'
+                regions_ms.setdefault(key, []).append(round(1e3 * runs[-1][0], 4))
+                region_clocks.setdefault(key, []).append(self.last_clocks)
             return min(runs, key=lambda r: r[0])
 
         def timed(self, method, kernel_events=False, steps=None, warm=None):
@@ -430,7 +443,7 @@ def main():
                 ctx.run_iterate(w)
             barrier(); ctx.sync(); torch.cuda.synchronize()
             t0 = time.perf_counter()
-            ctx.run_iterate(k)
+            _, clocks = ctx.run_iterate_timed(k)      # the K iterations; device events + enqueue time + wall time taken inside the library
             ctx.sync(); torch.cuda.synchronize(); barrier()
             dt = time.perf_counter() - t0
             res = ctx.run_end()
@@ -438,6 +451,9 @@ def main():
                 t = torch.tensor([dt], dtype=torch.float64)
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 dt = float(t[0])
+            # a region that takes long on the host's clock but not between the device's events was held up outside the kernels
+            self.last_clocks = dict(region_ms=round(1e3 * dt, 4), device_ms=round(clocks["device_ms"], 4),
+                                    enqueue_ms=round(clocks["enqueue_ms"], 4), library_wall_ms=round(clocks["wall_ms"], 4))
             return dt, res
 
         def check(self):
@@ -466,8 +482,20 @@ def main():
                                  # matrix was generated on the host: a 20-iteration region right after 2.5 ms of warm-up read 3 % high)
     stage[0] = "timed iterations"
 
-    # main timed region: exactly K iterations after W warm-up iterations, no per-kernel instrumentation
-    dt, res = leg.timed(a.method)
+    # main timed regions: exactly K iterations after W warm-up iterations each, no per-kernel instrumentation. `value` is the MEDIAN
+    # region (an intermittent stall -- one region in a few dozen took 20 x as long in round 4, cause unknown -- must not become the
+    # headline, nor be hidden: every region is in the line with the device's clock beside the host's).
+    headline_regions = []
+
+    def headline(lg):
+        runs = []
+        for _ in range(max(1, a.regions)):
+            runs.append(lg.timed(a.method))
+            headline_regions.append(lg.last_clocks)
+        runs.sort(key=lambda r: r[0])
+        return runs[(len(runs) - 1) // 2]
+
+    dt, res = headline(leg)
     ok, true_relres = leg.check()
     if not ok and p2p_mode:
         # the peer-to-peer data path passed its self-test but not this check: measure with the collectives instead
@@ -482,7 +510,8 @@ def main():
         comm_info["fallback_reason"] = f"'{failed_name}' failed the residual check after the timed region (true relres {true_relres:.3e})"
         leg = Leg(wl)
         plan = leg.plan
-        dt, res = leg.timed(a.method)
+        del headline_regions[:]
+        dt, res = headline(leg)
         ok, true_relres = leg.check()
     head_flags_all = [k for k, v in leg.ctx.flags().items() if v]
     ms_step = 1e3 * dt / K
@@ -538,6 +567,33 @@ def main():
     leg.close()
     comm_info["transport_used"] = transport_name
 
+    # ------------------------------------------------------------------ how much of the headline is the synthetic's structure?
+    # The Transport-SHAPED matrix has 15 constant diagonals: its slices are "uniform" (one shared list of distances, no column
+    # index read: 8 instead of 10 bytes per non-zero). Transport.mtx itself (FEM) would not qualify. The same matrix once more
+    # with that layout switched off (BICG_SELL_UNIFORM=0: 16-bit column offsets for every entry) puts a number on the difference.
+    structure = None
+    if world == 1 and not a.inner and not a.no_variants and a.workload == "transport" and not a.matrix:
+        stage[0] = "headline without uniform slices"
+        os.environ["BICG_SELL_UNIFORM"] = "0"
+        try:
+            lg = Leg(wl)
+        finally:
+            os.environ.pop("BICG_SELL_UNIFORM", None)
+        dtu, _ = lg.best(a.method)
+        _, rese = lg.timed(a.method, kernel_events=True)
+        sp_u = rese.spmv_ms_total / max(rese.spmv_launches, 1)
+        fb_u = lg.ctx.spmv_matrix_bytes() + 16 * lg.plan["rows"]
+        structure = dict(setting="BICG_SELL_UNIFORM=0: every slice reads its 16-bit column offsets (10 bytes per non-zero)",
+                         flags=[k for k, v in lg.ctx.flags().items() if v],
+                         ms_per_iteration=1e3 * dtu / K, ms_per_iteration_default=ms_step,
+                         spmv_avg_launch_ms=sp_u, spmv_avg_launch_ms_default=spmv_ms,
+                         format_bytes_per_launch=fb_u, format_gbps=fb_u / (sp_u * 1e-3) / 1e9 if sp_u > 0 else None,
+                         frac_of_format_bytes=fb_u / (sp_u * 1e-3) / 1e9 / HBM_PEAK_GBS if sp_u > 0 else None,
+                         survey_8d_bytes_per_launch=b_spmv, survey_8d_frac=b_spmv / (sp_u * 1e-3) / 1e9 / HBM_PEAK_GBS if sp_u > 0 else None)
+        lg.timed(a.method, steps=4, warm=0)
+        lg.close()
+        note(f"headline without uniform slices: {structure['ms_per_iteration']:.4f} ms/iteration (default {ms_step:.4f}), product {sp_u:.4f} ms (default {spmv_ms:.4f})")
+
     # ------------------------------------------------------------------ N > 1: the same matrix over RCCL collectives
     # north_star names "halo exchange and dot-product all-reduce on RCCL over xGMI": whichever path produced `value`,
     # the headline method is timed once more with the library's RCCL transport (grouped ncclSend/ncclRecv halo exchange,
@@ -573,7 +629,7 @@ def main():
     # ------------------------------------------------------------------ the other workloads north_star names
     extras = {}
     if not a.no_extras and a.workload == "transport" and not a.n and not a.matrix:
-        def extra(name, wl2, methods, steps):
+        def extra(name, wl2, methods, steps, kernel_roofline=False):
             stage[0] = f"extra workload {name}"
             lg = Leg(wl2)
             out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v],
@@ -593,6 +649,15 @@ def main():
             bs = spmv_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"], lg.plan["halo"])
             out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, algorithmic_bytes_rank0=bs,
                                             **roof(bs, sp * 1e-3, csr_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"]), mbytes, 1, lg.plan["rows"], 2, out["flags"], stream, 1, spmv_only=True))
+            if kernel_roofline:
+                # the in-solver product of this matrix with its own start / stop events (as the headline's roofline leg)
+                _, rese = lg.timed(methods[0], kernel_events=True, steps=steps, warm=min(W, 10))
+                kms = rese.spmv_ms_total / max(rese.spmv_launches, 1)
+                fb = min(bs, mbytes + 16 * lg.plan["rows"])
+                out["kernel_roofline"] = dict(avg_launch_ms=kms, launches_timed=rese.spmv_launches,
+                                              survey_8d_bytes_per_launch=bs, survey_8d_gbps=bs / (kms * 1e-3) / 1e9, survey_8d_frac=bs / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                                              format_bytes_per_launch=fb, format_gbps=fb / (kms * 1e-3) / 1e9, format_frac=fb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS)
+                lg.timed(methods[0], steps=4, warm=0)
             lg.close()
             note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods))
             return out
@@ -608,9 +673,10 @@ def main():
             assert nnz_dev == nnz
             out = dict(rows=rows, nnz=nnz, workload="BASELINE.json configs[3]: 7-point Laplacian 512^3 (134 M rows), generated and planned "
                        "on the GPU, b = A*1, x0 = 0, one MI355X", plan=ctx.plan_info(), flags=[k for k, v in ctx.flags().items() if v],
-                       generate_seconds=gen_s, plan_seconds=plan_s, device_matrix_bytes=ctx.device_matrix_bytes())
+                       generate_seconds=gen_s, plan_seconds=plan_s, device_matrix_bytes=ctx.device_matrix_bytes(),
+                       plane_marching_product=ctx.stencil_info())
             lg = Leg.__new__(Leg)
-            lg.wl = dict(lo=0, hi=rows); lg.ctx = ctx; lg.plan = out["plan"]
+            lg.wl = dict(lo=0, hi=rows, desc="laplace7 512^3"); lg.ctx = ctx; lg.plan = out["plan"]
             lg.ones = np.ones(rows); lg.x0 = np.zeros(rows)
             lg.b = ctx.spmv(lg.ones)
             steps = min(K, 20)
@@ -674,7 +740,7 @@ def main():
             wl8 = dict(build("transport", n=n8), desc=f"1/8 of the Transport-shaped matrix as one rank holds it at 8 GPUs ({n8} rows)")
             extras["transport_rank_of_8"] = extra("1/8 Transport rank", wl8, ("pipe_bicgstab", "bicgstab"), max(ke, 200))
             extras["small_rank_with_halo"] = small_rank_with_halo(n8)
-            extras["fem_like"] = extra("fem_like", build("fem_like"), ("bicgstab", "pipe_bicgstab"), ke)
+            extras["fem_like"] = extra("fem_like", build("fem_like"), ("bicgstab", "pipe_bicgstab"), ke, kernel_roofline=True)
             extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
             extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "
                                                  "= 16.8 M rows per GPU), CA-BiCGStab")
@@ -698,6 +764,31 @@ def main():
                                   fetch_factor_reproducing_k_vec_FPlainQ=factor,
                                   caveat="the x2 is stated by the guide for wide coalesced reads and re-checked here on the element-wise "
                                          "kernel; the SpMV issues 8- and 16-byte loads")
+
+    # the same counters for the product of the FEM-like matrix (jagged slices with the x window in LDS): the second headline
+    roofline_unstructured = None
+    if "fem_like" in extras and "kernel_roofline" in extras.get("fem_like", {}):
+        kr = extras["fem_like"]["kernel_roofline"]
+        t_un, t_un_detail = None, None
+        if rank == 0 and world == 1 and not a.no_traffic:
+            stage[0] = "rocprofv3 counter passes, FEM-like matrix"
+            m = measure_traffic(["--inner", "--workload", "fem_like", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-variants", "--no-extras",
+                                 "--no-traffic", "--no-stream", "--method", "bicgstab", "--scale-decades", str(a.scale_decades)], note)
+            if m:
+                t_un = 2.0 * m["fetch_counter_bytes"] + m["write_counter_bytes"]
+                t_un_detail = dict(fetch_bytes_x2=2.0 * m["fetch_counter_bytes"], write_bytes=m["write_counter_bytes"], launches=m["launches"])
+        roofline_unstructured = dict(
+            kernel="k_spmv_sell<.., LAY_JAGW> (jagged slices, x window of each 256-row group staged in LDS, fused dot epilogue) on the "
+                   "FEM-like matrix: ragged rows (6..27), no shared lists -- the layout a real FEM matrix such as Transport.mtx gets",
+            bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s",
+            achieved=kr["format_gbps"], frac=kr["format_frac"], frac_basis="format bytes (values + 16-bit window slots + window runs + x + y)",
+            avg_launch_ms=kr["avg_launch_ms"], launches_timed=kr["launches_timed"],
+            format_bytes_per_launch=kr["format_bytes_per_launch"],
+            survey_8d_bytes_per_launch=kr["survey_8d_bytes_per_launch"], survey_8d_gbps=kr["survey_8d_gbps"], survey_8d_frac=kr["survey_8d_frac"],
+            traffic=t_un, traffic_detail=t_un_detail,
+            ms_per_iteration={m: extras["fem_like"][m]["ms_per_iteration"] for m in ("bicgstab", "pipe_bicgstab") if m in extras["fem_like"]},
+            back_to_back_spmv_ms=extras["fem_like"]["spmv_back_to_back"]["ms"],
+            frac_of_measured_copy=(kr["format_gbps"] / stream["copy"]) if stream and "copy" in stream else None)
 
     cpu = None
     cpu_all = None
@@ -742,9 +833,16 @@ def main():
                        "true_relres_after_timed_region": true_relres,
                        "setup_seconds_rank0": leg.setup_s},
             # bytes one iteration has to move with the stored layout (2 products + the fused-minimum vector traffic of SURVEY.md 8d)
-            "hbm_gbps_iteration": iter_fmt_bytes / (ms_step * 1e-3) / 1e9,
-            "iteration_algorithmic_bytes": iter_fmt_bytes,
-            "iteration_csr_bytes": iter_bytes,
+            # (keys as in rounds 1-3: the SURVEY.md 8d figure -- 2 CSR products + the fused-minimum vector traffic; the bytes of the
+            # stored layout have keys of their own)
+            "hbm_gbps_iteration": iter_bytes / (ms_step * 1e-3) / 1e9,
+            "iteration_algorithmic_bytes": iter_bytes,
+            "iteration_format_bytes": iter_fmt_bytes,
+            "hbm_gbps_iteration_format": iter_fmt_bytes / (ms_step * 1e-3) / 1e9,
+            "headline_regions": headline_regions,
+            "headline_regions_note": f"{len(headline_regions)} regions of exactly {K} iterations; value = the median region; per region the host's "
+                                     "bracket (barrier + synchronize on both sides), the device's events around the launches, the host time "
+                                     "spent enqueueing, the library's own wall time",
             # `achieved` / `frac`: the ALGORITHMIC bytes of one launch of this kernel on this matrix -- what the stored layout has to
             # move (values + the index the layout keeps, 16-bit distances for slices that are not uniform, none for
             # those that are, + row lengths + x + y; `traffic` from the counters agrees within 2 %) -- over the launch time. The CSR
@@ -752,6 +850,11 @@ def main():
             # than CSR, and the CSR bytes over the launch time (`csr_equivalent_gbps`) can exceed the HBM peak.
             "roofline": {"kernel": "k_spmv_sell (sliced-ELL SpMV with fused dot epilogue), rank 0 share", "bound": "hbm",
                          "achieved": fmt_gbps, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": fmt_gbps / HBM_PEAK_GBS,
+                         "frac_basis": "format bytes: what the stored layout has to move (uniform slices read no column index); the SURVEY.md "
+                                       "8d figure (12 bytes per non-zero) is survey_8d_frac, the same matrix without uniform slices is "
+                                       "structure_dependence",
+                         "survey_8d_bytes_per_launch": b_spmv, "survey_8d_gbps": achieved, "survey_8d_frac": achieved / HBM_PEAK_GBS,
+                         "structure_dependence": structure,
                          "traffic": traffic, "traffic_detail": traffic_detail, "algorithmic_bytes_per_launch": fmt_spmv,
                          "avg_launch_ms": spmv_ms, "launches_timed": res_ev.spmv_launches,
                          "csr_bytes_per_launch": b_spmv, "csr_equivalent_gbps": achieved, "csr_equivalent_frac": achieved / HBM_PEAK_GBS,
@@ -764,6 +867,7 @@ def main():
                          "frac_of_measured_stream": (fmt_gbps / stream["triad"]) if stream and "triad" in stream else None,
                          "frac_of_measured_copy": (fmt_gbps / stream["copy"]) if stream and "copy" in stream else None,
                          "frac_of_measured_read": (fmt_gbps / stream["read8"]) if stream and "read8" in stream else None},
+            "roofline_unstructured": roofline_unstructured,
             "comm": dict(comm_info, rccl_leg=rccl_leg),
             "cpu_baseline": cpu,
             "cpu_baseline_multicore": cpu_all,
@@ -771,6 +875,7 @@ def main():
             "variant_rooflines": variant_roof,
             "extras": extras,
             "timed_regions_ms": regions_ms,
+            "timed_region_clocks": region_clocks,
         }
         print(json.dumps(line), file=result_out, flush=True)
 

@@ -236,6 +236,8 @@ struct StencilDev {
     uint32_t zl;                    // planes per wavefront tile
     uint32_t lines;                 // lines per wavefront (2, 4 or 8)
     uint32_t nmc;                   // x segments with masked slices
+    int xcd;                        // XCD-contiguous order of the tiles (measurement knob BICG_STENCIL_XCD)
+    int nt_store;                   // y (and the epilogue's vectors) stored non-temporally (measurement knob BICG_STENCIL_NT)
     unsigned long long mcols;
     const uint32_t *code;
     const StencilTab *tab;

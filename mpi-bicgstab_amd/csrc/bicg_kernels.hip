@@ -2287,8 +2287,21 @@ __device__ __forceinline__ d2 operator*(double s, d2 q) { return {s * q.a, s * q
 __device__ __forceinline__ double hsum(d2 p) { return p.a + p.b; }
 __device__ __forceinline__ double hsum(double p) { return p; }
 
+// the same pair for launches over vectors far beyond the caches (tiled k_vec): every access of it is non-temporal
+struct d2n { double a, b; };
+__device__ __forceinline__ d2n operator+(d2n p, d2n q) { return {p.a + q.a, p.b + q.b}; }
+__device__ __forceinline__ d2n operator-(d2n p, d2n q) { return {p.a - q.a, p.b - q.b}; }
+__device__ __forceinline__ d2n operator*(d2n p, d2n q) { return {p.a * q.a, p.b * q.b}; }
+__device__ __forceinline__ d2n operator*(double s, d2n q) { return {s * q.a, s * q.b}; }
+__device__ __forceinline__ double hsum(d2n p) { return p.a + p.b; }
+
 template <class T> __device__ __forceinline__ T ld(const double *p, uint32_t i);
 template <> __device__ __forceinline__ double ld<double>(const double *p, uint32_t i) { return p[i]; }
+template <> __device__ __forceinline__ d2n ld<d2n>(const double *p, uint32_t i)
+{
+    const f64x2 t = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p + i));
+    return {t.x, t.y};
+}
 template <> __device__ __forceinline__ d2 ld<d2>(const double *p, uint32_t i)
 {
     const f64x2 t = *reinterpret_cast<const f64x2 *>(p + i);
@@ -2316,6 +2329,13 @@ template <> __device__ __forceinline__ d2 ldnt<d2>(const double *p, uint32_t i)
     const f64x2 t = __builtin_nontemporal_load(reinterpret_cast<const f64x2 *>(p + i));
     return {t.x, t.y};
 }
+template <> __device__ __forceinline__ d2n ldnt<d2n>(const double *p, uint32_t i) { return ld<d2n>(p, i); }
+__device__ __forceinline__ void stnt(double *p, uint32_t i, d2n v)
+{
+    f64x2 t; t.x = v.a; t.y = v.b;
+    __builtin_nontemporal_store(t, reinterpret_cast<f64x2 *>(p + i));
+}
+__device__ __forceinline__ void st(double *p, uint32_t i, d2n v) { stnt(p, i, v); }
 __device__ __forceinline__ void stnt(double *p, uint32_t i, double v) { __builtin_nontemporal_store(v, p + i); }
 __device__ __forceinline__ void stnt(double *p, uint32_t i, d2 v)
 {
@@ -2340,7 +2360,13 @@ template <class F, class = void> struct vec_split { static constexpr bool value 
 template <class F> struct vec_split<F, decltype((void)F::kSplit)> { static constexpr bool value = F::kSplit; };
 constexpr int kWaveOnly = 1 << RED_WAVE, kAnyMode = (1 << RED_TICKET) | (1 << RED_TICKET_HEAVY) | (1 << RED_WAVE);
 
-template <class F, int MODE>
+// TILE > 0 (vectors far beyond the caches, vec_tiled()): a workgroup takes ONE contiguous tile of TILE pairs per thread -- 16 KiB
+// of every stream for TILE = 4 --, all loads of the tile are in flight before the first store, every access is non-temporal
+// (pair type d2n) and the workgroup ends: the shape that streams fastest on this GPU (bicg_stream_bench: copy 4.5 TB/s as a
+// grid-stride loop, 5.9 as one workgroup per tile, 6.35 with non-temporal accesses on top). Same arithmetic per element;
+// the dot partials are summed over another set of rows per workgroup than in the strided form.
+constexpr int kVecTile = 4;
+template <class F, int MODE, int TILE = 0>
 __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce red, Finish fin)
 {
     constexpr int ND = F::ND > 0 ? F::ND : 1;
@@ -2349,6 +2375,47 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
     for (int d = 0; d < ND; ++d) acc[d] = 0.0;
     const uint32_t npair = n >> 1;
     const uint32_t i0 = blockIdx.x * kBlock + threadIdx.x, stride = gridDim.x * kBlock;
+    if constexpr (TILE > 0) {
+        static_assert(vec_split<F>::value, "tiled launches need the functor's fetch / compute split");
+        const uint32_t t0 = blockIdx.x * (uint32_t)(kBlock * TILE) + threadIdx.x;
+        typename F::template In<d2n> in[TILE];
+        auto fetch_tile = [&]() {
+#pragma unroll
+            for (int u = 0; u < TILE; ++u) {
+                const uint32_t i = t0 + (uint32_t)u * kBlock;
+                if (i < npair) in[u] = f.template fetch<d2n>(2 * i);
+            }
+        };
+        auto compute_tile = [&]() {
+#pragma unroll
+            for (int u = 0; u < TILE; ++u) {
+                const uint32_t i = t0 + (uint32_t)u * kBlock;
+                if (i < npair) f.template compute<d2n>(2 * i, in[u], acc);
+            }
+            if ((n & 1u) && blockIdx.x == 0 && threadIdx.x == 0) f.template apply<double>(n - 1, acc);
+        };
+        if constexpr (MODE == RED_WAVE) {
+            __shared__ FinishLds fl;
+            __shared__ Scal priv;
+            const Scal *sc = S;
+            const bool helper = fin.seq && (fin.roles & FIN_SHARDS) && blockIdx.x < (unsigned)kShards;      // (see below)
+            if (!helper) fetch_tile();
+            if (fin.seq) sc = finish_group(S, fin, fin.roles, blockIdx.x, gridDim.x, fl, &priv);
+            if (helper) fetch_tile();
+            if (sc->done) return;
+            f.load(sc);
+            compute_tile();
+            if (F::ND > 0) wave_publish<ND>(acc, red.partial, red.slot_base + blockIdx.x);
+        } else {
+            if (S->done) return;
+            __shared__ double sm[5 * ND];
+            f.load(S);
+            fetch_tile();
+            compute_tile();
+            if (F::ND > 0) reduce_publish<ND, MODE == RED_TICKET_HEAVY>(acc, S, red, blockIdx.x, sm);
+        }
+        return;
+    }
     if constexpr (MODE == RED_WAVE) {
         __shared__ FinishLds fl;
         __shared__ Scal priv;
@@ -2388,6 +2455,18 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
 static bool env_on(const char *name, bool dflt);
 static unsigned g_vec_grid_cap = 0;
 void set_vec_grid_cap(unsigned cap) { g_vec_grid_cap = cap; }
+// pairs per thread of an element-wise launch over n rows (0: grid-stride loop over <= kMaxGrid workgroups)
+static unsigned vec_ppt(uint32_t n)
+{
+    static const int ppt_env = [] { const char *v = getenv("BICG_VEC_PPT"); return v ? atoi(v) : -1; }();
+    return ppt_env >= 0 ? (unsigned)ppt_env : (n >= (1u << 26) ? (unsigned)kVecTile : 0u);
+}
+// ... as contiguous tiles with non-temporal accesses (k_vec<.., TILE>; BICG_VEC_TILE=0: the strided form of round 4)
+static bool vec_tiled(uint32_t n)
+{
+    static const bool on = env_on("BICG_VEC_TILE", true);
+    return on && !g_vec_grid_cap && vec_ppt(n) == (unsigned)kVecTile;
+}
 unsigned vec_grid(uint32_t n)
 {
     // 256 CUs x 8 resident workgroups, grid-stride beyond (BICG_VEC_GRID: measurement knob, <= kMaxGrid)
@@ -2401,10 +2480,9 @@ unsigned vec_grid(uint32_t n)
     // +12 %, profiles/NOTES.md; 512^3 Laplacian: plain 9.12 -> 8.65 ms, CA 10.86 -> 10.10 ms per iteration, round 4). At
     // 16.8 M rows (256^3) and at Transport size the two forms tie. BICG_VEC_PPT=p forces p pairs per thread everywhere
     // (0: never); the grid is capped at the partial-sum slots every context has.
-    static const int ppt_env = [] { const char *v = getenv("BICG_VEC_PPT"); return v ? atoi(v) : -1; }();
     unsigned g = ((n >> 1) + kBlock - 1) / kBlock;
     if (g < 1) g = 1;
-    const unsigned ppt = ppt_env >= 0 ? (unsigned)ppt_env : (n >= (1u << 26) ? 4u : 0u);
+    const unsigned ppt = vec_ppt(n);
     if (ppt && !g_vec_grid_cap) {
         g = (g + ppt - 1) / ppt;
         const unsigned slots = std::max<unsigned>(kMaxGrid, (n + kGroupRows - 1) / kGroupRows);      // ctx_state: nslots >= row groups
@@ -2426,6 +2504,16 @@ static void run_vec(F f, uint32_t n, const Launch &L, Reduce red)
     if (!((modes >> mode) & 1)) {
         fprintf(stderr, "ERROR: bicgstab_hip: element-wise kernel launched in reduction mode %d it is not built for\n", mode);
         abort();
+    }
+    if constexpr (vec_split<F>::value) {
+        if (vec_tiled(n)) {
+            if constexpr ((modes >> RED_WAVE) & 1)
+                if (mode == RED_WAVE) { BICG_LAUNCH((k_vec<F, RED_WAVE, kVecTile>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+            if constexpr (((modes >> RED_TICKET_HEAVY) & 1) && F::ND > 0)
+                if (mode == RED_TICKET_HEAVY) { BICG_LAUNCH((k_vec<F, RED_TICKET_HEAVY, kVecTile>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+            if constexpr ((modes >> RED_TICKET) & 1)
+                if (mode != RED_WAVE) { BICG_LAUNCH((k_vec<F, RED_TICKET, kVecTile>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }
+        }
     }
     if constexpr ((modes >> RED_WAVE) & 1)
         if (mode == RED_WAVE) { BICG_LAUNCH((k_vec<F, RED_WAVE>), dim3(g), dim3(kBlock), 0, L.st, f, n, L.S, red, L.fin); return; }

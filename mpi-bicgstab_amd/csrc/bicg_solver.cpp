@@ -991,7 +991,13 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
     c->st_code = dev_upload(code.data(), code.size());
     c->st_tab = dev_upload(tab.data(), tab.size());
     if (nmc) c->st_cmask = dev_upload(cmask.data(), cmask.size());
-    c->st = StencilDev{1, sy, sz, nxs, ny, nz, zl, lines, nmc, mcols, c->st_code, c->st_tab, c->st_cmask};
+    // Input + output vector far beyond the 256 MiB Infinity Cache (512^3: 2 x 1 GiB): y is stored non-temporally and the tiles go to
+    // the XCDs round-robin (product 0.480 -> 0.460 ms, CA-BiCGStab 5.40 -> 5.31 ms per iteration); a grid whose vectors the cache
+    // holds (256^3) keeps ordinary stores and the XCD-contiguous order (0.053 against 0.061 ms): profiles/r05/stencil_sweep_xcd_nt.txt
+    const bool st_big = 16.0 * (double)nrows > 2.0 * 256.0 * 1048576.0;
+    const int st_xcd = getenv("BICG_STENCIL_XCD") ? atoi(getenv("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
+    const int st_nt = getenv("BICG_STENCIL_NT") ? atoi(getenv("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
+    c->st = StencilDev{1, sy, sz, nxs, ny, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
     if (const char *v = getenv("BICG_CA_FUSE")) c->ca_fuse = atoi(v) != 0;
     // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
     c->stencil_matrix_bytes = 4ull * nslices + (uint64_t)cmask.size();
@@ -3612,6 +3618,27 @@ int bicg_solve_shifted(bicg_ctx *c, int variant, double *x_loc_set, double *r_lo
     return run_shifted(c, variant, x_loc_set, r_loc, sigma, sigma_len, seed, opt, res);
 }
 
+// BICG_DISPLAY_ERROR=1: what the reference prints when it is compiled with -DDISPLAY_ERROR (src/shifted_switching_solver.c:327-335,
+// 570-598): the right-hand side is formed once more as ans = (A + sigma[seed] I) 1 -- what its drivers pass as b, src/main_shifted.c
+// -- and every system's || (A + sigma_i I) x_i - ans || / || ans || is printed for the seed ("0, ...") and every tenth shift
+// ("1, ..."). Here: one product on the device for ans, then the batched residuals of bicg_shifted_residuals (the matrix read once
+// per 16 shifts). Collective like the solve itself.
+static void display_error(bicg_ctx *c, const double *x_set, const double *sigma, int nsig, int seed)
+{
+    const size_t n = c->phantom ? 0 : c->n_loc;
+    std::vector<double> ones(std::max<size_t>(n, 1), 1.0), ans(std::max<size_t>(n, 1), 0.0), err((size_t)nsig, 0.0);
+    bicg_spmv(c, ones.data(), ans.data());
+    for (size_t j = 0; j < n; ++j) ans[j] += sigma[seed] * ones[j];                        // my_daxpy(sigma[seed], temp, ans_loc)
+    bicg_shifted_residuals(c, x_set, ans.data(), sigma, nsig, err.data());
+    if (c->rank != 0) return;
+    printf("seed(0:seed, 1:shift), sigma, relative error\n");
+    for (int i = 0; i < nsig; ++i) {
+        if (i == seed) printf("0, %e, %e\n", sigma[i], err[i]);
+        else if (i % 10 == 0) printf("1, %e, %e\n", sigma[i], err[i]);
+    }
+    fflush(stdout);
+}
+
 static int dropin_shifted(int mode, CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x_set, double *r, double *sigma, int nsig, int seed)
 {
     check_square(i);
@@ -3632,6 +3659,7 @@ static int dropin_shifted(int mode, CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i
         if (!c) die("bicg_create", "failed");
         k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
     }
+    if (getenv("BICG_DISPLAY_ERROR") && atoi(getenv("BICG_DISPLAY_ERROR")) != 0) display_error(c, x_set, sigma, nsig, mode == SH_XI ? 0 : seed);
     dropin_release(c);
     return k;
 }

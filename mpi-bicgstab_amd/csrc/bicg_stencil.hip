@@ -44,7 +44,11 @@ __device__ __forceinline__ double st_wave_shift(double v, double edge)
 }
 
 __device__ __forceinline__ double st_ld(const char *base, uint32_t off) { return *reinterpret_cast<const double *>(base + off); }
-__device__ __forceinline__ void st_st(char *base, uint32_t off, double v) { *reinterpret_cast<double *>(base + off) = v; }
+__device__ __forceinline__ void st_st(char *base, uint32_t off, double v, int nt = 0)
+{
+    if (nt) __builtin_nontemporal_store(v, reinterpret_cast<double *>(base + off));
+    else *reinterpret_cast<double *>(base + off) = v;
+}
 
 // the seven products in canonical = stored order (src/matrix.c:506-515)
 __device__ __forceinline__ double st_sum_all(const double (&cv)[7], const double (&xv)[7])
@@ -87,6 +91,7 @@ template <int R, int ND> struct StWalk {
     uint32_t rz, mz, mline, mstep;          // first row of line 0 in the current plane; the same place in cmask
     uint32_t cstep;                         // codes per plane
     uint32_t cidx, cbits;
+    int nt;
     double cv[7];
     double alpha;
     double acc[ND];
@@ -153,12 +158,12 @@ __device__ __forceinline__ void st_plane(StWalk<R, ND> &w, unsigned z, const dou
         else sum = st_sum_bits(w.cv, xv, w.cbits);
         const double yi = 0.0 + sum;                                  // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
         const uint32_t off = ((w.rz + (uint32_t)j * w.sy) << 3) + w.lane8;
-        st_st(w.yb, off, yi);
+        st_st(w.yb, off, yi, w.nt);
         if (EPI) {
             const double qv = cur.r[j] + (-w.alpha) * pc[j];          // q = r - alpha s            (src/solver.c:225-226)
             const double yv = cur.w[j] + (-w.alpha) * yi;             // y = w - alpha z            (src/solver.c:227-228)
-            st_st(w.rb, off, qv);
-            st_st(w.wb, off, yv);
+            st_st(w.rb, off, qv, w.nt);
+            st_st(w.wb, off, yv, w.nt);
             w.acc[0] += qv * yv;
             w.acc[ND > 1 ? 1 : 0] += yv * yv;
         } else if (NDOT >= 1) {
@@ -184,6 +189,7 @@ __device__ __forceinline__ void stencil_tile(const SpmvArgs &a, unsigned xs, uns
     w.n = a.nrows; w.sy = g.sy; w.sz = g.sz; w.nz = g.nz;
     w.lane = lane; w.lane8 = lane << 3; w.hi_half = lane < 32u ? 0u : 0xFFFFFFFFu;
     w.alpha = EPI ? a.S->alpha : 0.0;
+    w.nt = g.nt_store;
     const unsigned dense = (unsigned)__builtin_popcountll(g.mcols & ((1ull << xs) - 1ull));
     // rows are scalars: rz = first row of the tile's line 0 in the current plane; line j is j sy rows further
     w.rz = (z0 * g.ny + y0) * g.sy + xs * (uint32_t)kSliceRows;
@@ -262,7 +268,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_stencil(SpmvArgs a)
     // share halo lines) and, every other product, reversed; its partial sums go to slot vb whichever physical workgroup it is.
     // vb -> (x segment, block of 4 R lines, block of zl planes), x segment fastest: neighbours in vb are neighbours in the grid.
     unsigned vb = bid;
-    if (a.xcd_map && bid < (nblocks / 8u) * 8u) vb = (bid % 8u) * (nblocks / 8u) + bid / 8u;
+    if (a.sell.st.xcd && bid < (nblocks / 8u) * 8u) vb = (bid % 8u) * (nblocks / 8u) + bid / 8u;
     if (a.reverse) vb = nblocks - 1u - vb;
     const StencilDev &g = a.sell.st;
     const unsigned wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;

@@ -192,3 +192,33 @@ def test_reference_shifted_driver_linked_against_hip_library(tmp_path, np_):
     assert abs(len(sw) - len(sw_ref)) <= 1 and len(late(sw, k)) == len(late(sw_ref, k_ref)), (sw, sw_ref, out[-2500:], out_ref[-1500:])
     for (ka, sa, ra), (kb, sb, rb) in zip(late(sw, k), late(sw_ref, k_ref)):
         assert sa == sb and abs(int(ka) - int(kb)) <= 3 and abs(int(ra) - int(rb)) <= 32, (sw, sw_ref)
+
+
+@need
+@pytest.mark.parametrize("np_", [1, 2])
+def test_display_error_lines_of_the_reference_on_the_dropin_path(tmp_path, np_):
+    """BICG_DISPLAY_ERROR=1: the reference's verification print (src/shifted_switching_solver.c:570-598, compiled in with
+    -DDISPLAY_ERROR: oracle/_ref/shifted_ref_err) from the drop-in build of the same driver -- header, one "0, sigma, error"
+    line for the seed, a "1, ..." line for every tenth shift; the relative errors || (A + sigma_i I) x_i - ans || / || ans ||
+    are those of two converged solves (EPS 1e-12): both small, and within 1e-8 of each other."""
+    dropin, ref = os.path.join(REF, "shifted_dropin"), os.path.join(REF, "shifted_ref_err")
+    if not (os.path.exists(dropin) and os.path.exists(ref)):
+        pytest.skip("shifted_dropin / shifted_ref_err not built")
+    path = str(tmp_path / "shifted.mtx")
+    synth.write_mtx(path, synth.from_offsets(20011, (0, 1, -1, 140, -140, 141, -141), diag_base=4.6, seed=5))
+
+    def run(binary, **env):
+        out = subprocess.run([MPIEXEC, "-n", str(np_), binary, path], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, BICG_CHECK_EVERY="4", **env))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        assert "seed(0:seed, 1:shift), sigma, relative error" in out.stdout, out.stdout[-2000:]
+        return [(int(f), float(sg), float(e)) for f, sg, e in re.findall(r"^([01]), (\S+), (\S+)$", out.stdout, flags=re.M)]
+
+    want = run(ref)
+    got = run(dropin, BICG_DISPLAY_ERROR="1")
+    assert len(want) >= 50 and [w[:2] for w in want] == [g[:2] for g in got], (want[:5], got[:5])
+    assert sum(1 for w in want if w[0] == 0) == 1
+    for (_, _, ew), (_, _, eg) in zip(want, got):
+        assert ew <= 1e-9 and eg <= 1e-9 and abs(ew - eg) <= 1e-8, (ew, eg)
+    silent = subprocess.run([MPIEXEC, "-n", "1", dropin, path], capture_output=True, text=True, timeout=600)
+    assert "relative error" not in silent.stdout                      # off unless asked for, like the reference's default build

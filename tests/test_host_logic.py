@@ -198,11 +198,25 @@ def test_hot_kernels_stay_lean():
         ticket = k.endswith("ELi0EEEvNS_8SpmvArgsE")
         assert r["VGPRs"] <= (64 if ticket else 80) and r["Occupancy [waves/SIMD]"] >= (8 if ticket else 6), (k, r)
         assert r["ScratchSize [bytes/lane]"] <= (48 if ticket else 0), (k, r)
-    vec = [k for k in kernels if re.search(r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*ELi2EEEv", k)]
+    names = r"k_vecINS_(8FPlainXRILb[01]E|7FPlainQ|7FPlainP|6FPipe1|6FPipe2ILb[01]E|5FCaXRILb[01]E|3FQY|5FCaPS)E*"
+    vec = [k for k in kernels if re.search(names + r"ELi2ELi0EEEv", k)]
     assert len(vec) >= 11, sorted(kernels)[:5]
     for k in vec:
         r = kernels[k]
         assert r["VGPRs"] <= 96 and r["Occupancy [waves/SIMD]"] >= 5 and r["ScratchSize [bytes/lane]"] == 0, (k, r)
+    # round 5: the tiled form for vectors far beyond the caches (k_vec<.., TILE = 4>: the loads of four element pairs per thread in
+    # flight before the first store): registers by design -- 16 streams' worth of them for the pipelined phases --, never scratch
+    tiled = [k for k in kernels if re.search(names + r"ELi[0-2]ELi4EEEv", k)]
+    assert len(tiled) >= 20, sorted(kernels)[:5]
+    for k in tiled:
+        r = kernels[k]
+        assert r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 2, (k, r)
+    # ... and the plane-marching product (bicg_stencil.hip): four sets of plane registers, never scratch, four wavefronts per SIMD
+    # with four lines per wavefront
+    st = [k for k in kernels if "k_spmv_stencil" in k]
+    assert len(st) >= 28
+    for k in st:
+        assert kernels[k]["ScratchSize [bytes/lane]"] == 0 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
     # the fused pipelined iteration: a 200k-row rank is 783 workgroups x 4 wavefronts = 3.06 per SIMD, so a
     # fifth VGPR over 128 (occupancy 3) buys a second round of workgroups: +5 us per iteration, measured
     epi = [k for k in kernels if "k_spmv_sell_epi" in k]
