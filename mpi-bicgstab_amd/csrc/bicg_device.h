@@ -267,6 +267,11 @@ struct SellDev {
     // 256-row group are dealt to the lanes by decreasing length (perm[g * 256 + lane] = row within the group),
     // which makes the four slices of a group as long as their own longest row instead of the group's (null: lane = row)
     const unsigned char *perm;
+    // ... and, for the product with the short dependency chain (bicg_jagw.hip), ONE 16-bit word per lane: its row within the group
+    // (low byte, = perm) and that row's length (high byte) -- no row pointers, no separate permutation load. win_max_runs: the most
+    // runs any group's window has. Null when some row of a sliced group has more than 255 entries.
+    const unsigned short *lane_info;
+    uint32_t win_max_runs;
     // Uniform slices (padded layouts): when all 64 rows of a slice are present, equally long and entry k of every row sits at
     // the SAME distance from its row -- every interior slice of a banded or stencil matrix -- the slice's columns are the list
     // uoff[ubase[slice] + k] (shared by all slices with the same list) and the SpMV does not read its col / col16 entries at
@@ -486,6 +491,10 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // a.fw.wf = 1 / 2
 // plane-marching product of a 7-point grid stencil (bicg_stencil.hip; a.sell.st.on). epi = 1: CA-BiCGStab's q = r - alpha s,
 // y = w - alpha z, (q,y), (y,y) (reference src/solver.c:225-232) on the wavefront's own rows behind z = A s (a.epi.r / a.epi.w)
+// the ragged-rows product with three dependent trips per group (bicg_jagw.hip); jagw_fast_ok: this launch qualifies
+bool jagw_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo);
+bool launch_spmv_jagw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+void preload_jagw_kernels();
 unsigned stencil_grid(const StencilDev &st);
 bool launch_spmv_stencil(const SpmvArgs &a, int ndot, int epi, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void preload_stencil_kernels();

@@ -1,0 +1,219 @@
+// bicg_jagw.hip -- the product of a block with RAGGED rows (jagged slices + x window in LDS, SellDev::win_*: the layout an
+// unstructured FEM matrix such as Transport.mtx gets) for one rank without halo, with the dependent memory trips of a 256-row
+// group cut from twelve to three.
+//
+// What the counters of k_spmv_sell<.., LAY_JAGW, ..> said on the FEM-like matrix (profiles/r05/fem_like_spmv_counters_before.txt):
+// waves waiting 64 % of their cycles, 658 cycles per L1 miss, the units busy 10 % -- and the work of a group is a CHAIN: group
+// number, window bounds, then per run of the window {descriptor, x values, LDS stores} one after the other, barrier, slice
+// metadata, row pointers of the lane's row (behind the row permutation), first batch of entries, second batch, ... Every link is
+// a round trip of 0.5-1 us; a workgroup lives for a dozen of them and the product's time is rounds of workgroups times that chain,
+// not bytes over bandwidth (4.5-4.8 TB/s of its 276 MB). Here:
+//   trip 1   window bounds, slice base / length (scalar), ONE 16-bit word per lane = its row in the group and that row's length
+//            (SellDev::lane_info: no row pointers, no separate permutation load);
+//   trip 2   every run descriptor of the window at once (one vector load, lane r = run r), the first TWO batches of the lane's
+//            entries (values + 16-bit window slots), the dot operand;
+//   trip 3   all x values of the window (<= 8 per thread, the slot -> column search runs over the run descriptors in registers),
+//            then the LDS stores, ONE barrier, and the gathers; further batches are requested two ahead of their use.
+// Arithmetic: each lane adds ITS row's products in stored order, one rounding per product and per sum, y_i = 0.0 + that sum --
+// bit for bit the sum of mult() (reference src/matrix.c:506-515) and of k_spmv_sell. The fused dots and their reduction are those
+// of k_spmv_sell (same slots, same order: the solvers' scalars do not change in a single bit against that kernel).
+#include "bicg_device.h"
+#include "bicg_devfn.h"
+#include "bicg_reduce.h"
+
+#include <hip/hip_ext.h>
+#include <cstdio>
+#include <cstdlib>
+
+namespace bicg {
+
+#define BICG_KCONST __attribute__((address_space(4)))
+extern __shared__ double jagw_win[];      // the x window of the group (SellDev::win_slots doubles)
+
+constexpr int kJagU = 8;                  // entries per lane and batch
+constexpr int kJagSlots = 8;              // window values per thread the kernel stages (win_slots <= 256 * kJagSlots)
+constexpr uint32_t kJagMaxRuns = 64;      // run descriptors one wavefront can hold (lane r = run r)
+
+struct JagBatch { double v[kJagU]; uint32_t s[kJagU]; };
+
+// the lane's entries k0 .. k0 + 7 of its row: step k of a jagged slice stores the entries of the lanes whose row is longer
+// than k, in lane order (ballot + population count, all from the row lengths: every load of the batch is issued back to back)
+template <bool NT>
+__device__ __forceinline__ void jag_load(const SpmvArgs &a, uint32_t k0, uint32_t mylen, uint32_t &pos, JagBatch &B)
+{
+    const unsigned short *sl = reinterpret_cast<const unsigned short *>(a.sell.col16);
+#pragma unroll
+    for (int e = 0; e < kJagU; ++e) {
+        const bool mine = k0 + (uint32_t)e < mylen;
+        const unsigned long long m = __ballot(mine);
+        const uint32_t j = pos + __builtin_amdgcn_mbcnt_hi((uint32_t)(m >> 32), __builtin_amdgcn_mbcnt_lo((uint32_t)m, 0u));
+        pos += (uint32_t)__builtin_popcountll(m);
+        B.s[e] = 0u; B.v[e] = 0.0;
+        if (mine) {       // (nothing that depends on a loaded value inside the predicated block: see k_spmv_sell)
+            B.s[e] = NT ? __builtin_nontemporal_load(sl + j) : sl[j];
+            B.v[e] = NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j];
+        }
+    }
+}
+__device__ __forceinline__ double jag_use(const JagBatch &B, uint32_t k0, uint32_t mylen, const double *win, double sum)
+{
+    double xv[kJagU];
+#pragma unroll
+    for (int e = 0; e < kJagU; ++e) xv[e] = win[B.s[e]];          // slot 0 for a lane whose row has ended
+#pragma unroll
+    for (int e = 0; e < kJagU; ++e)
+        if (k0 + (uint32_t)e < mylen) sum += B.v[e] * xv[e];      // stored order
+    return sum;
+}
+
+template <int NDOT, bool NT, int MODE>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_spmv_jagw(SpmvArgs a)
+{
+    constexpr int ND = NDOT > 0 ? NDOT : 1;
+    const int done = a.S->done;
+    __shared__ double sm[5 * ND];
+    const unsigned bid = blockIdx.x, nblocks = gridDim.x;
+    if (MODE == RED_WAVE) {
+        __shared__ FinishLds fl;
+        if (a.fin.seq && (bid < (unsigned)kShards || (a.fin.roles & FIN_APPLY))) (void)finish_group(a.S, a.fin, a.fin.roles, bid, nblocks, fl, nullptr);
+    }
+    double acc[ND];
+#pragma unroll
+    for (int d = 0; d < ND; ++d) acc[d] = 0.0;
+
+    // groups of this workgroup: the order, placement and slot rules of k_spmv_sell
+    unsigned vb = bid;
+    if (a.xcd_map && bid < (nblocks / 8u) * 8u) vb = (bid % 8u) * (nblocks / 8u) + bid / 8u;
+    if (a.reverse) vb = nblocks - 1u - vb;
+    const unsigned each = (a.nlist + nblocks - 1u) / nblocks;
+    const unsigned gfirst = vb * each, gend = gfirst + each < a.nlist ? gfirst + each : a.nlist;
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const double *__restrict__ x = a.x;
+    double *const win = jagw_win;
+
+    for (unsigned gq = gfirst; gq < gend && !done; ++gq) {
+        const unsigned gi = a.reverse ? gfirst + (gend - 1u - gq) : gq;
+        const unsigned g = a.glist ? a.glist[gi] : gi;
+        // ---- trip 1
+        const uint32_t w0 = a.sell.win_ptr[g], w1 = a.sell.win_ptr[g + 1];
+        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
+        const uint32_t base = a.sell.slice_base[slice], len = a.sell.slice_len[slice];
+        const uint32_t info = a.sell.lane_info[(size_t)g * kGroupRows + tid];
+        const uint32_t row = g * kGroupRows + (info & 0xFFu), mylen = info >> 8;          // (rows past the block's last: length 0)
+        const bool live = row < a.nrows;
+        // ---- trip 2
+        const uint32_t nruns = w1 - w0;
+        uint2 myrun = make_uint2(0u, 0u);
+        if (lane < nruns) myrun = a.sell.win_runs[w0 + lane];
+        uint32_t pos = base;
+        JagBatch A, B;
+        jag_load<NT>(a, 0u, mylen, pos, A);
+        jag_load<NT>(a, (uint32_t)kJagU, mylen, pos, B);
+        double upre = 0.0, xown = 0.0;
+        if (NDOT >= 1 && live) upre = a.u[row];
+        if (a.has_shift && live) xown = x[row];
+        // ---- trip 3: the window. Thread t stages slots t, t + 256, ...; slot -> column over the run descriptors
+        const uint32_t last = nruns ? nruns - 1u : 0u;
+        const uint32_t lrun_y = (uint32_t)__builtin_amdgcn_readlane((int)myrun.y, (int)last);
+        const uint32_t total = nruns ? (lrun_y >> 16) + (lrun_y & 0xFFFFu) : 0u;
+        double xw[kJagSlots];
+        uint32_t col[kJagSlots];
+#pragma unroll
+        for (int k = 0; k < kJagSlots; ++k) col[k] = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, 0) + tid + (uint32_t)k * kBlock;
+        for (uint32_t r = 1; r < nruns; ++r) {                    // wave-uniform: runs are in ascending slot order
+            const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, (int)r);
+            const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)myrun.y, (int)r) >> 16;
+#pragma unroll
+            for (int k = 0; k < kJagSlots; ++k) {
+                const uint32_t s = tid + (uint32_t)k * kBlock;
+                if (s >= slot0) col[k] = first + (s - slot0);
+            }
+        }
+#pragma unroll
+        for (int k = 0; k < kJagSlots; ++k) {
+            const uint32_t s = tid + (uint32_t)k * kBlock;
+            xw[k] = x[s < total ? col[k] : row < a.nrows ? row : 0u];       // (unconditional: a slot past the window reads a value that exists)
+        }
+        __syncthreads();                                          // the previous group's reads of the window are done
+#pragma unroll
+        for (int k = 0; k < kJagSlots; ++k) {
+            const uint32_t s = tid + (uint32_t)k * kBlock;
+            if (s < total) win[s] = xw[k];
+        }
+        __syncthreads();
+        // ---- the rows: batches requested two ahead of their use, no value moved between registers
+        double sum = 0.0;
+        for (uint32_t k0 = 0; k0 < len; k0 += 2u * (uint32_t)kJagU) {
+            sum = jag_use(A, k0, mylen, win, sum);
+            if (k0 + (uint32_t)kJagU >= len) break;
+            jag_load<NT>(a, k0 + 2u * (uint32_t)kJagU, mylen, pos, A);
+            sum = jag_use(B, k0 + (uint32_t)kJagU, mylen, win, sum);
+            if (k0 + 2u * (uint32_t)kJagU >= len) break;
+            jag_load<NT>(a, k0 + 3u * (uint32_t)kJagU, mylen, pos, B);
+        }
+        double yi = 0.0 + sum;                                    // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+        if (a.has_shift && live) yi += a.shift * xown;            // (A + sigma I) x, src/shifted_solver.c:260
+        if (live) a.y[row] = yi;
+        if (NDOT >= 1 && live) {
+            acc[0] += upre * yi;
+            if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
+            if (NDOT == 3) acc[NDOT >= 2 ? 1 : 0] += upre * upre;
+        }
+    }
+    if (NDOT > 0 && !done) {
+        if (MODE == RED_WAVE) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + vb);
+        else reduce_publish<ND, MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + vb, sm, a.red.slot_base + bid);
+    }
+}
+
+// can this launch go to k_spmv_jagw? (one rank's halo-free rows, the plan's per-lane words present, the window small enough)
+bool jagw_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo)
+{
+    return a.sell.win_slots > 0 && a.sell.lane_info != nullptr && !with_offd && !fused_halo && a.fw.wf == 0 &&
+           a.sell.win_slots <= (uint32_t)(kBlock * kJagSlots) && a.sell.win_max_runs >= 1 && a.sell.win_max_runs <= kJagMaxRuns;
+}
+
+template <class K>
+static void jagw_go(K kernel, const SpmvArgs &a, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
+{
+    const dim3 g(sell_grid(a.nlist, a.groups_per_wg)), b(kBlock);
+    const unsigned lds = a.sell.win_slots * (unsigned)sizeof(double);
+    if (e0 && e1) hipExtLaunchKernelGGL(kernel, g, b, lds, st, e0, e1, 0, a);
+    else hipLaunchKernelGGL(kernel, g, b, lds, st, a);
+    static const bool debug = getenv("BICG_DEBUG") != nullptr;
+    if (debug) {
+        const hipError_t err = hipGetLastError();
+        if (err != hipSuccess) fprintf(stderr, "bicgstab_hip: HIP error \"%s\" noticed at: k_spmv_jagw\n", hipGetErrorString(err));
+    }
+}
+
+bool launch_spmv_jagw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
+{
+    if (a.nlist == 0) return false;
+    const bool nt = a.nt != 0;
+    const int mode = red_mode(a.red, a.fin, ndot > 0);
+#define JAGW_MODE(ND, MD)                                                                 \
+    do {                                                                                  \
+        if (nt) jagw_go(k_spmv_jagw<ND, true, MD>, a, st, e0, e1);                        \
+        else jagw_go(k_spmv_jagw<ND, false, MD>, a, st, e0, e1);                          \
+    } while (0)
+#define JAGW_CASE(ND)                                                                     \
+    do {                                                                                  \
+        if (mode == RED_WAVE) JAGW_MODE(ND, RED_WAVE);                                    \
+        else if (mode == RED_TICKET_HEAVY) JAGW_MODE(ND, ((ND) > 0 ? RED_TICKET_HEAVY : RED_TICKET)); \
+        else JAGW_MODE(ND, RED_TICKET);                                                   \
+    } while (0)
+    if (ndot == 0) JAGW_CASE(0); else if (ndot == 1) JAGW_CASE(1); else if (ndot == 2) JAGW_CASE(2); else JAGW_CASE(3);
+#undef JAGW_CASE
+#undef JAGW_MODE
+    return true;
+}
+
+void preload_jagw_kernels()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmv_jagw<0, false, RED_TICKET>));
+    (void)hipGetLastError();
+}
+
+}  // namespace bicg

@@ -1386,7 +1386,9 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
     case LAY_PAD16: return launch_spmv_sell_pad16(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG32: return launch_spmv_sell_jag32(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG16: return launch_spmv_sell_jag16(a, ndot, with_offd, st, e0, e1, fused_halo);
-    case LAY_JAGW:  return launch_spmv_sell_jagw(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAGW:
+        if (jagw_fast_ok(a, with_offd, fused_halo)) return launch_spmv_jagw(a, ndot, st, e0, e1);
+        return launch_spmv_sell_jagw(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_PAD32C: return launch_spmv_sell_pad32c(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_PAD16C: return launch_spmv_sell_pad16c(a, ndot, with_offd, st, e0, e1, fused_halo);
     default:        return launch_spmv_sell_pad32(a, ndot, with_offd, st, e0, e1, fused_halo);

@@ -119,6 +119,8 @@ struct bicg_ctx {
     uint32_t win_max_runs = 0;             // most runs of one group's window
     uint2 *win_runs = nullptr;
     unsigned char *sell_perm = nullptr;    // SellDev::perm
+    unsigned short *lane_info = nullptr;   // SellDev::lane_info
+    bool jagw_fast = true;                 // the three-trip product of bicg_jagw.hip (BICG_JAGW=0: k_spmv_sell's loop)
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
     uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
     uint64_t sell_entries = 0, sell_nnz = 0;
@@ -548,6 +550,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.sell.ubase = c->s_ubase; a.sell.uoff = c->s_uoff; a.sell.vbase = c->s_vbase; a.sell.uval = c->s_uval; a.sell.mbase = c->s_mbase; a.sell.rmask = c->s_rmask;
     a.sell.sdesc = c->s_desc; a.sell.all_lists = c->sell_all_lists ? 1 : 0; a.sell.uoff8 = c->s_uoff8; a.sell.ystride = c->sell_ystride;
     a.sell.st = c->st;
+    a.sell.lane_info = c->jagw_fast ? c->lane_info : nullptr; a.sell.win_max_runs = c->win_max_runs;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};
@@ -2363,6 +2366,7 @@ static void preload_for(bicg_ctx *c)
     preload_kernels(d, c->sell_entries > 0);
     if (c->persist_on) preload_persist_kernels();
     if (c->st.on) preload_stencil_kernels();
+    if (c->lane_info && c->jagw_fast) preload_jagw_kernels();
 }
 
 bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
@@ -2942,6 +2946,28 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->win_slots = win_slots;
         for (uint32_t g = 0; g < ngroups; ++g) c->win_max_runs = std::max(c->win_max_runs, win_ptr[g + 1] - win_ptr[g]);
         if (!perm.empty()) c->sell_perm = dev_upload(perm.data(), perm.size());
+        // SellDev::lane_info: row in the group + its length per lane, in the order the lanes work (perm or natural)
+        {
+            std::vector<unsigned short> li((size_t)ngroups * kGroupRows, 0);
+            std::vector<char> too_long((size_t)plan_threads(), 0);
+            parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int part) {
+                for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g)
+                    for (uint32_t t = 0; t < kGroupRows; ++t) {
+                        const uint32_t in_group = perm.empty() ? t : perm[(size_t)g * kGroupRows + t], r = g * kGroupRows + in_group;
+                        const uint32_t n = (r < nrows && group_is_sell[g]) ? diag->ptr[r + 1] - diag->ptr[r] : 0u;
+                        if (n > 255u) too_long[(size_t)part] = 1;
+                        li[(size_t)g * kGroupRows + t] = (unsigned short)(in_group | (n << 8));
+                    }
+            });
+            bool ok = true;
+            for (char b : too_long) ok = ok && !b;
+            if (ok) {
+                c->lane_info = dev_upload(li.data(), li.size());
+                c->matrix_bytes += 2ull * li.size();
+                c->device_matrix_bytes += 2ull * li.size();
+            }
+            if (const char *v = getenv("BICG_JAGW")) c->jagw_fast = atoi(v) != 0;
+        }
         c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
         c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
     }
@@ -3305,7 +3331,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->lane_info, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);

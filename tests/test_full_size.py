@@ -185,6 +185,55 @@ def test_jagged_slices_on_fem_like_rows(monkeypatch):
     ctx.close()
 
 
+def test_ragged_rows_product_with_the_short_chain_gives_the_same_bits(monkeypatch):
+    """k_spmv_jagw (csrc/bicg_jagw.hip: window bounds + one 16-bit word per lane, then every run descriptor and the first two
+    batches of entries, then the whole window -- three dependent trips per 256-row group) against k_spmv_sell's loop over the same
+    jagged slices (BICG_JAGW=0): the product, the solvers' scalars (same partial-sum slots, same order) and a shifted solve are
+    identical in every bit; the product equals the oracle's mult() (reference src/matrix.c:506-515). Three shapes: FEM-like rows
+    (3 runs per group, rows not a multiple of 256), columns in seven separate runs per group, a Transport-sized one."""
+    H.lib().bicg_comm_init_single(0)
+    monkeypatch.setenv("BICG_PERSIST", "0")
+    rng = np.random.default_rng(77)
+    n2 = 40000
+    scattered = synth.from_offsets(n2, (0, 1, -1, 400, -400, 401, -401, 1500, -1500, 3000, -3000), diag_base=15.0, seed=9)
+    # drop entries at random: ragged rows whose columns fall into seven separate runs per 256-row group
+    keep = rng.random(scattered.nnz) < 0.6
+    keep[scattered.col == np.repeat(np.arange(n2), np.diff(scattered.ptr.astype(np.int64)))] = True
+    ptr = np.zeros(n2 + 1, dtype=np.int64)
+    np.add.at(ptr, np.repeat(np.arange(n2), np.diff(scattered.ptr.astype(np.int64)))[keep] + 1, 1)
+    ragged = synth.CSR(n2, n2, np.cumsum(ptr).astype(np.uint32), scattered.col[keep].copy(), scattered.val[keep].copy())
+    for name, A in (("fem", synth.fem_like(n=117 * 117 * 6)), ("scattered", ragged), ("fem_transport_size", synth.fem_like(scale_decades=2.0))):
+        row, col, val = A.to_coo()
+        x = rng.standard_normal(A.rows)
+        want = O.spmv(A.rows, row, col, val, x)
+        b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
+        results = []
+        for fast in ("0", "1"):
+            monkeypatch.setenv("BICG_JAGW", fast)
+            if name == "scattered":
+                monkeypatch.setenv("BICG_SELL_WINDOW", "1")
+            ctx = H.Context(H.single_rank_blocks(A))
+            fl = ctx.flags()
+            assert fl["jagged"] and fl["window"], (name, fl)
+            y = ctx.spmv(x)
+            assert np.array_equal(y, want), (name, fast)
+            traces = []
+            for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab"):
+                ctx.solve(method, b, tol=0.0, max_iter=10, check_every=10)
+                tr = ctx.trace(10)
+                traces.append(np.concatenate([tr[key] for key in ("alpha", "omega", "beta", "dotr")]))
+            sh = ctx.solve_shifted(b, np.array([0.0, 0.02, 0.05]), 1, tol=0.0, max_iter=6, check_every=6)
+            results.append((y, traces, sh["x"].copy()))
+            ctx.close()
+            monkeypatch.delenv("BICG_SELL_WINDOW", raising=False)
+        (y0, t0, s0), (y1, t1, s1) = results
+        assert np.array_equal(y0, y1), name
+        for a_, b_ in zip(t0, t1):
+            assert np.array_equal(a_, b_), name
+        assert np.array_equal(s0, s1), name
+    monkeypatch.delenv("BICG_JAGW")
+
+
 def test_x_window_for_columns_far_from_the_row(monkeypatch):
     """columns further than 32767 from the row (a 3-D stencil's z neighbours at full size): 16-bit offsets do not
     apply, the x window in LDS would -- 16-bit slots, 10 bytes per non-zero, SpMV bit-identical -- but with equal

@@ -1,0 +1,36 @@
+#!/bin/bash
+# round 5, fourth GPU call: the ragged-rows product with three dependent trips per group (bicg_jagw.hip): parity, time, counters
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r5c4
+rm -rf $OUT; mkdir -p $OUT
+cd $R
+timeout 600 python -m pytest tests/test_full_size.py -x -q -k "ragged_rows_product or jagged_slices or fem" 2>&1 | tail -25 > $OUT/pytest_jagw.txt; cat $OUT/pytest_jagw.txt
+timeout 300 python -m pytest tests/test_bench_workloads.py -x -q -k "fem_like" 2>&1 | tail -5
+python - > $OUT/fem_times.txt 2>&1 <<'PY'
+import os, sys, time
+import numpy as np
+sys.path.insert(0, '.')
+from mpi_bicgstab_amd import hipsolver as H, synth
+H.lib().bicg_comm_init_single(0)
+A = synth.fem_like(scale_decades=2.0)
+for env in ({"BICG_JAGW": "0"}, {"BICG_JAGW": "1"}):
+    os.environ.update(env)
+    ctx = H.Context(H.single_rank_blocks(A))
+    b = ctx.spmv(np.ones(A.rows))
+    sp = min(ctx.spmv_bench(100) for _ in range(3))
+    out = {}
+    for method in ("bicgstab", "pipe_bicgstab"):
+        best = 1e9
+        for rep in range(3):
+            ctx.load(np.zeros(A.rows), b)
+            ctx.run_begin(method, tol=0.0, max_iter=110, check_every=100)
+            ctx.run_iterate(10); ctx.sync()
+            t = time.perf_counter(); ctx.run_iterate(100); ctx.sync(); best = min(best, (time.perf_counter() - t) / 100 * 1e3)
+            ctx.run_end()
+        out[method] = best
+    print(env, "product back to back %.2f us, plain %.4f, pipelined %.4f ms/iteration, matrix-side bytes %d" % (sp * 1e3, out["bicgstab"], out["pipe_bicgstab"], ctx.spmv_matrix_bytes()), flush=True)
+    ctx.close()
+PY
+cat $OUT/fem_times.txt
+bash tools/r5/pmc_spmv.sh r5c4/pmc_fem SPMV_KIND=fem_like > $OUT/pmc_fem_stdout.txt 2>&1; tail -45 $OUT/pmc_fem_stdout.txt
