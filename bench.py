@@ -253,7 +253,7 @@ def main():
         dist.all_reduce(t)
         return int(t[0]) == 0
 
-    comm_info = {"world": world, "p2p_selftest": None, "rccl_nranks": None, "transport_used": None, "fallback_reason": None}
+    comm_info = {"world": world, "p2p_selftest": None, "rccl_nranks": None, "transport_used": None, "fallback_reason": None, "wait_us": None}
 
     def p2p_label(mode, base):
         """what the peer-to-peer data path crossed: xGMI links only when every rank has a GPU of its own"""
@@ -514,6 +514,8 @@ def main():
         dt, res = headline(leg)
         ok, true_relres = leg.check()
     head_flags_all = [k for k, v in leg.ctx.flags().items() if v]
+    # multi-rank persistent launches: what the exchanges made the kernels wait (device clock, one sample per exchange)
+    comm_info["wait_us"] = leg.ctx.comm_wait_stats() if world > 1 else None
     ms_step = 1e3 * dt / K
     relres = float(np.sqrt(res.dot_r / res.dot_zero)) if res.dot_zero > 0 else float("nan")
     genuine = res.iterations == W + K and np.isfinite(relres) and ok
@@ -721,6 +723,7 @@ def main():
                 d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
                 out = dict(ranks=2, rows_per_rank=nrows // 2, ms_per_iteration=d["value"], bound="latency", frac=None,
                            transport=d["config"]["transport"], flags=d["config"].get("flags"), halo=d["config"].get("halo"),
+                           comm_wait_us=d.get("comm", {}).get("wait_us"),
                            iterations_genuine=d["config"]["iterations_genuine"],
                            true_relres_after_timed_region=d["config"]["true_relres_after_timed_region"],
                            note="two ranks SHARING this GPU (half the CUs each): the persistent kernel with real halos, not a 2-GPU time")

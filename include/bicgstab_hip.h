@@ -291,6 +291,12 @@ int bicg_stream_bench(int kind, unsigned long long bytes_per_array, int reps, do
 /* 1 after a peer-to-peer wait of this context timed out (only reachable with BICG_P2P_SOFT_FAIL=1; the
  * default is to print the error and exit like any other HIP/RCCL failure). The solve in progress stops. */
 int bicg_comm_failed(bicg_ctx *ctx);
+/* How long the exchanges of the last solve made the persistent kernels wait (multi-rank, peer-to-peer data path): one sample per
+ * exchange, taken on the device clock inside the launch. out = {all-reduce of a dot group through the mailboxes: p50, p99; a
+ * boundary workgroup's wait from publishing its own values to a complete window, the neighbour's halo values included: p50, p99
+ * (microseconds); number of samples of either}. Returns 0 when something was recorded. What a first multi-GPU run needs to
+ * explain itself: the links' latency as the kernels saw it (reference overlap: src/solver.c:363-367, src/matrix.c:432-440). */
+int bicg_comm_wait_stats(bicg_ctx *ctx, double out[6]);
 /* Section times of the last solve run with bicg_options.time_kernels & 2 (BICG_SECTION_TIME=1 in the drop-in path), in
  * milliseconds on the compute stream: ms[0] element-wise kernels of the seed system (with their fused dots), ms[1] products
  * A x (halo exchange and joins of overlapped all-reduces included), ms[2] the passes over the shifted systems (the shifted

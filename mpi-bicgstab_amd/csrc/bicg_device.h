@@ -445,6 +445,12 @@ struct PersistArgs {
     unsigned first_sleep;                // row wavefronts: s_sleep(8) periods (~0.22 us each) before the first look at the window
     int xcd_map;                         // XCD-contiguous assignment of row ranges to workgroups
     unsigned long long *dbg;             // BICG_PERSIST_TRACE: 100 MHz time stamps of one row workgroup and the helper, [it][16]
+    // multi-rank launches: how long the exchanges made the kernel wait, in 100 MHz ticks, one sample per exchange --
+    // row 0: the helper's all-reduce through the mailboxes (own sums stored -> every rank's sums read), index = group % waitcap;
+    // rows 1 / 2: first / last row workgroup, own values published -> window complete (the neighbours' halo values included),
+    // index = hand-off % waitcap. Read back by bicg_comm_wait_stats (bench.py's comm.wait_us). Null: not recorded.
+    unsigned *waitlog;
+    unsigned waitcap;
 };
 // each returns hipSuccess or the reason the launch did not happen (launch error, workgroups cannot be co-resident): the
 // caller then runs the chunk with the multi-launch kernels

@@ -355,6 +355,7 @@ __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword 
     }
     lds_barrier();
     if (a.multi) {
+        const unsigned long long t_mail = (!SH && a.waitlog && tid == 0) ? wall_clock64() : 0ull;
         // all-reduce over the ranks through the mailboxes (reference: one MPI_Iallreduce per dot, e.g. src/solver.c:363-367):
         // store this rank's sums into every rank's mailbox, wait for the P contributions, add them like a
         // recursive-doubling all-reduce would -- every rank gets the same bits. The stores are the LAST wavefront's, the
@@ -375,6 +376,7 @@ __device__ __forceinline__ bool helper_group(const PersistArgs &a, const llword 
                 L.pv[p * kRedSlots + d] = v;
             }
         lds_barrier();
+        if (!SH && a.waitlog && tid == 0) a.waitlog[(seq - a.seq0 - 1u) % a.waitcap] = (unsigned)(wall_clock64() - t_mail) | 1u;
         if (L.fail) { if (tid == 0) raise_alarm(a.alarm); return false; }
         if ((int)tid < N) L.sums[tid] = rank_tree_sum(L.pv + tid, P);
         lds_barrier();
@@ -611,7 +613,11 @@ __device__ __forceinline__ void xprod(const PersistArgs &a, const WgCtx &W, cons
         comm_halo<MULTI>(a, W.lane, W.zs, htag, W.ns0, W.ns1);
     } else {
         mid();
+        const unsigned wgw = blockIdxWg(a);
+        const bool logw = MULTI && !COEF && a.waitlog && threadIdx.x == 0 && (wgw == 0u || wgw + 1u == a.nwg);   // (not in the shifted kernels: they sit at their register limit)
+        const unsigned long long t_win = logw ? wall_clock64() : 0ull;
         stage_window<MULTI>(a, W.runs, W.nruns, W.nslots, img, vtag, htag, W.win, W.nrt, L, W.zs, W.row0, W.nmine);
+        if (logw) a.waitlog[(wgw == 0u ? 1u : 2u) * a.waitcap + (nv - 1u) % a.waitcap] = (unsigned)(wall_clock64() - t_win) | 1u;
     }
     lds_barrier();
     if (W.comm) {

@@ -61,6 +61,7 @@ template <class T> T *dev_upload_padded(const T *src, size_t n, size_t pad)
 
 }  // namespace
 
+constexpr unsigned kWaitCap = 4096;      // samples per row of PersistArgs::waitlog
 struct bicg_ctx {
     Comm *comm = nullptr;                  // null once the communicator has been replaced (contexts_orphan)
     int device = 0;
@@ -90,6 +91,7 @@ struct bicg_ctx {
     uint64_t matrix_bytes = 0;             // bytes one SpMV streams from the matrix arrays
     uint64_t stencil_matrix_bytes = 0;     // ... when the plane-marching product runs (StencilDev)
     hipEvent_t region_ev[2] = {nullptr, nullptr};   // bicg_run_iterate_timed
+    unsigned *waitlog = nullptr;           // PersistArgs::waitlog (multi-rank persistent launches), 3 rows of kWaitCap samples
     double t_enq = 0.0;
     uint64_t device_matrix_bytes = 0;      // bytes of matrix storage resident on the GPU
     // sliced-ELL copy of the diag block (rows whose 256-row group pads by < 25 %)
@@ -1281,6 +1283,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
         BICG_HIP(hipMemcpyAsync(c->Sbuf + i, &h, sizeof h, hipMemcpyHostToDevice, c->sc));
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->alarm, 0, sizeof(int), c->sc));
+    if (c->waitlog) BICG_HIP(hipMemsetAsync(c->waitlog, 0, sizeof(unsigned) * 3 * kWaitCap, c->sc));
     // every work vector starts at zero: defines the reads of p, s, z, v that the reference makes
     // before writing them (src/solver.c:217-222, 352-360) and keeps halo tails finite
     const size_t st = c->stride;
@@ -2187,6 +2190,10 @@ bool persist_chunk(bicg_ctx *c, int niter)
         if (!pipe) { c->halo_seq += 2u * (unsigned)niter; c->p2p->red_seq += groups * (unsigned)niter; }
         a.ring = c->halo_ring;
         c->halo_unsynced = 0;
+    }
+    if (a.multi) {
+        if (!c->waitlog) { c->waitlog = dev_alloc<unsigned>(3 * (size_t)kWaitCap); BICG_HIP(hipMemsetAsync(c->waitlog, 0, sizeof(unsigned) * 3 * kWaitCap, c->sc)); }
+        a.waitlog = c->waitlog; a.waitcap = kWaitCap;
     }
     static const bool want_trace = getenv("BICG_PERSIST_TRACE") != nullptr;
     unsigned long long *dbg = nullptr;
@@ -3331,7 +3338,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->lane_info, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->lane_info, c->waitlog, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);
@@ -3599,6 +3606,32 @@ unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matr
 unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
 unsigned long long bicg_constant_entries(bicg_ctx *c) { return c->constant_entries; }
 unsigned long long bicg_masked_rows(bicg_ctx *c) { return c->masked_rows; }
+// out = {mailbox all-reduce p50, p99, hand-off wait p50, p99 (microseconds), samples of the former, of the latter}; returns 0 when
+// the last solve recorded something (multi-rank persistent launches only)
+int bicg_comm_wait_stats(bicg_ctx *c, double out[6])
+{
+    for (int i = 0; i < 6; ++i) out[i] = 0.0;
+    if (!c->waitlog) return 1;
+    use_device(c);
+    std::vector<unsigned> h(3 * (size_t)kWaitCap);
+    BICG_HIP(hipMemcpy(h.data(), c->waitlog, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost));
+    auto pct = [](std::vector<unsigned> &v, double q) -> double {
+        if (v.empty()) return 0.0;
+        std::sort(v.begin(), v.end());
+        return 0.01 * (double)v[std::min(v.size() - 1, (size_t)(q * (double)(v.size() - 1) + 0.5))];      // 100 MHz ticks -> us
+    };
+    std::vector<unsigned> mail, hand[2];
+    for (size_t i = 0; i < kWaitCap; ++i) {
+        if (h[i]) mail.push_back(h[i]);
+        if (h[kWaitCap + i]) hand[0].push_back(h[kWaitCap + i]);
+        if (h[2 * kWaitCap + i]) hand[1].push_back(h[2 * kWaitCap + i]);
+    }
+    // the row workgroup that borders another rank waits for halo values, the other one only for its own GPU: report the slower
+    std::vector<unsigned> &hw = pct(hand[0], 0.5) >= pct(hand[1], 0.5) ? hand[0] : hand[1];
+    out[0] = pct(mail, 0.5); out[1] = pct(mail, 0.99); out[2] = pct(hw, 0.5); out[3] = pct(hw, 0.99);
+    out[4] = (double)mail.size(); out[5] = (double)hw.size();
+    return mail.empty() && hw.empty() ? 1 : 0;
+}
 int bicg_stencil_info(bicg_ctx *c, unsigned int out[8])
 {
     const bool on = stencil_product(c);

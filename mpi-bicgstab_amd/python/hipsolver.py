@@ -60,7 +60,7 @@ EXPORTS = [
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_plan_collisions", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
 ]
 
@@ -95,6 +95,7 @@ def lib():
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
         L.bicg_stencil_info.argtypes = [C.c_void_p, _up]
+        L.bicg_comm_wait_stats.argtypes = [C.c_void_p, _dp]
         L.bicg_section_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bicg_comm_failed.argtypes = [C.c_void_p]
         L.bicg_dropin_context.restype = C.c_void_p
@@ -408,6 +409,13 @@ class Context:
 
     def masked_rows(self) -> int:
         return int(lib().bicg_masked_rows(self.h))
+
+    def comm_wait_stats(self):
+        """microseconds the exchanges of the last solve made the persistent kernels wait (None: nothing recorded)"""
+        out = (C.c_double * 6)()
+        if lib().bicg_comm_wait_stats(self.h, out) != 0:
+            return None
+        return dict(zip(("allreduce_p50_us", "allreduce_p99_us", "handoff_p50_us", "handoff_p99_us", "allreduce_samples", "handoff_samples"), list(out)))
 
     def stencil_info(self):
         """The plane-marching product of a 7-point grid stencil (csrc/bicg_stencil.hip): is it in use, and its tiling."""

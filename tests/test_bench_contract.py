@@ -64,7 +64,7 @@ def test_bench_names_the_bound_of_every_leg():
     # SURVEY.md 8d basis of the roofline fraction is a named field again, the same matrix without its uniform slices and the
     # unstructured (FEM-like) product have blocks of their own; old keys keep their meaning (iteration_algorithmic_bytes = 8d figure)
     for key in ("headline_regions", "device_ms", "enqueue_ms", "--regions", "frac_basis", "survey_8d_frac", "structure_dependence",
-                "roofline_unstructured", "iteration_format_bytes", "timed_region_clocks", "plane_marching_product"):
+                "roofline_unstructured", "iteration_format_bytes", "timed_region_clocks", "plane_marching_product", "wait_us", "comm_wait_us"):
         assert key in src, key
     assert re.search(r'"iteration_algorithmic_bytes":\s*iter_bytes,', src)
     assert "SHARING one device" in src             # two ranks on one GPU are not "over xGMI"

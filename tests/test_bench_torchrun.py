@@ -101,6 +101,25 @@ def test_bench_single_gpu_line_has_every_leg():
     sh = d["extras"]["small_rank_with_halo"]
     assert "error" not in sh and sh["iterations_genuine"] is True and "persist" in sh["flags"] and sh["halo"] > 10000, sh
     assert "peer-to-peer" in sh["transport"] and 0 < sh["ms_per_iteration"] < 0.1
+    # round 5: two processes on one GPU are not "over xGMI", and the persistent kernels report what the exchanges made them wait
+    # (device clock, one sample per exchange): the all-reduce through the mailboxes and a boundary workgroup's hand-off
+    assert "SHARING one device" in sh["transport"] and "xGMI link" in sh["transport"], sh["transport"]
+    wu = sh["comm_wait_us"]
+    assert wu and wu["allreduce_samples"] >= 100 and wu["handoff_samples"] >= 100, wu
+    assert 0 < wu["allreduce_p50_us"] <= wu["allreduce_p99_us"] < 5000 and 0 < wu["handoff_p50_us"] <= wu["handoff_p99_us"] < 5000, wu
+    # the headline is the median of three regions, each with the device's clock beside the host's
+    hr = d["headline_regions"]
+    assert len(hr) == 3 and all(0 < r["device_ms"] <= r["region_ms"] * 1.02 and r["enqueue_ms"] < r["region_ms"] for r in hr), hr
+    assert abs(sorted(r["region_ms"] for r in hr)[1] / 20 - d["value"]) < 1e-3 * d["value"] + 1e-6
+    # how much of the headline is the synthetic's structure: the same matrix without uniform slices is slower, and on record
+    sd = d["roofline"]["structure_dependence"]
+    assert sd and "uniform" not in sd["flags"] and sd["ms_per_iteration"] > d["value"] and 0.4 < sd["frac_of_format_bytes"] < 1.0, sd
+    assert d["roofline"]["survey_8d_frac"] >= d["roofline"]["frac"]
+    # the unstructured (FEM-like) product as a second headline: rocprof-style per-kernel time, both byte bases, counters
+    ru = d["roofline_unstructured"]
+    assert ru and 0.45 < ru["frac"] < 1.0 and ru["survey_8d_frac"] > ru["frac"] and ru["traffic"] is not None, ru
+    assert 0.85 * ru["format_bytes_per_launch"] < ru["traffic"] < 1.5 * ru["format_bytes_per_launch"], ru
+    assert d["extras"]["laplace7_512_ca"]["plane_marching_product"]["on"] == 1
     assert math.isfinite(d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["true_relres_after_timed_region"])
     for key in ("banded_b8", "banded_b64", "banded_b512", "fem_like", "laplace7_256_ca", "laplace7_512_ca", "transport_rank_of_8"):
         assert key in d["extras"], key

@@ -230,7 +230,7 @@ def test_hot_kernels_stay_lean():
     persist = [k for k in kernels if re.search(r"k_(pipe|plain|ca)_persist", k)]
     assert len(persist) == 16, persist
     shifted = [k for k in kernels if re.search(r"k_sh(pipe|lop)_persist", k)]      # the shifted solvers' forms: same budget
-    assert len(shifted) == 8 and all(kernels[k]["VGPRs"] <= 128 and kernels[k]["ScratchSize [bytes/lane]"] <= 24 for k in shifted), shifted
+    assert len(shifted) == 8 and all(kernels[k]["VGPRs"] <= 128 and kernels[k]["ScratchSize [bytes/lane]"] <= 32 for k in shifted), shifted      # (round 5: the launch arguments grew by the wait log's pointer: one more parked register in one of them)
     for k in persist:
         if "k_pipe_persistILi8E" in k:
             assert kernels[k]["Occupancy [waves/SIMD]"] >= 2 and kernels[k]["ScratchSize [bytes/lane]"] <= 384, (k, kernels[k])
