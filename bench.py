@@ -144,7 +144,8 @@ def measure_traffic(argv_inner, note):
         vals = [v for name, lst in out[ctr].items() if key(name) for v in lst]
         return (1024.0 * sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
-    dots = lambda nm: "k_spmv_sell<1" in nm or "k_spmv_sell<2" in nm          # the in-solver SpMV with its dot epilogue
+    # the in-solver SpMV with its dot epilogue (sliced-ELL kernel, or the ragged-rows product of bicg_jagw.hip)
+    dots = lambda nm: any(k in nm for k in ("k_spmv_sell<1", "k_spmv_sell<2", "k_spmv_jagw<1", "k_spmv_jagw<2"))
     fetch, nf = per_launch("FETCH_SIZE", dots)
     write, nw = per_launch("WRITE_SIZE", dots)
     qf, _ = per_launch("FETCH_SIZE", lambda nm: "FPlainQ" in nm)
@@ -781,8 +782,9 @@ def main():
                 t_un = 2.0 * m["fetch_counter_bytes"] + m["write_counter_bytes"]
                 t_un_detail = dict(fetch_bytes_x2=2.0 * m["fetch_counter_bytes"], write_bytes=m["write_counter_bytes"], launches=m["launches"])
         roofline_unstructured = dict(
-            kernel="k_spmv_sell<.., LAY_JAGW> (jagged slices, x window of each 256-row group staged in LDS, fused dot epilogue) on the "
-                   "FEM-like matrix: ragged rows (6..27), no shared lists -- the layout a real FEM matrix such as Transport.mtx gets",
+            kernel="k_spmv_jagw (csrc/bicg_jagw.hip: jagged slices, x window of each 256-row group staged in LDS, three dependent trips "
+                   "per group, fused dot epilogue) on the FEM-like matrix: ragged rows (6..27), no shared lists -- the layout a real "
+                   "FEM matrix such as Transport.mtx gets",
             bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s",
             achieved=kr["format_gbps"], frac=kr["format_frac"], frac_basis="format bytes (values + 16-bit window slots + window runs + x + y)",
             avg_launch_ms=kr["avg_launch_ms"], launches_timed=kr["launches_timed"],
