@@ -459,6 +459,9 @@ int bicg_coo_to_blocks_device(const unsigned int *row, const unsigned int *col, 
 void bicg_mtx_set_block_builder(bicg_block_builder_fn fn);
 
 const char *bicg_version(void);
+/* 1: the library was built with `make EXPERIMENTS=1` and reads the measurement knobs of the development rounds (csrc/bicg_knobs.h;
+ * the negative results they select -- window-fused plain iteration, direct SpMM -- are compiled in); 0: the default build */
+int bicg_has_experiments(void);
 
 #ifdef __cplusplus
 }

@@ -20,6 +20,7 @@
 #include "bicg_device.h"
 #include "bicg_devfn.h"
 #include "bicg_reduce.h"
+#include "bicg_knobs.h"
 
 #include <hip/hip_ext.h>   // hipExtLaunchKernelGGL: start/stop events bound to ONE kernel (roofline timing)
 #include <cstdio>
@@ -1074,6 +1075,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + slot);
 }
 
+#ifdef BICG_EXPERIMENTS      // negative result of round 3, kept for reference (bicg_knobs.h; make EXPERIMENTS=1)
 // ------------------------------------------------------------------------------------------
 // Window-fused SpMV of plain BiCGStab (struct FusedWindow, bicg_device.h): padded slices, 16-bit offsets, single rank.
 // The row product and the fused dot epilogue are those of k_spmv_sell (same per-lane order, same partial per
@@ -1189,6 +1191,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_sell_fw(SpmvArgs a)
     }
     if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
 }
+#endif
 
 static inline int sell_layout(const SellDev &d)
 {
@@ -1285,6 +1288,7 @@ bool launch_spmv_sell_pad32(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD3
 bool launch_spmv_sell_epi_pad32(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
 #endif
 #if PART_IS(2)
+#ifdef BICG_EXPERIMENTS
 bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.nlist == 0 || a.fw.wf == 0) return false;
@@ -1301,6 +1305,9 @@ bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t
 #undef FW_GO
     return true;
 }
+#else
+bool launch_spmv_sell_fw(const SpmvArgs &, int, hipStream_t, hipEvent_t, hipEvent_t) { return false; }      // (not in this build)
+#endif
 bool launch_spmv_sell_pad16(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD16>(a, n, with_offd, st, e0, e1, fused_halo); }
 bool launch_spmv_sell_epi_pad16(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD16>(a, n, with_offd, st, e0, e1, fused_halo); }
 #endif
@@ -1844,6 +1851,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
+#ifdef BICG_EXPERIMENTS      // one of three SpMM forms measured in round 4; the windowed one is the library's (bicg_knobs.h)
 // ------------------------------------------------------------------------------------------
 // Direct SpMM (round 4, padded slices): the head of every row -- value and column of its first 16 entries, the whole row for
 // banded / stencil matrices -- is loaded ONCE into registers, and the row is then multiplied with one vector after the other
@@ -1997,6 +2005,7 @@ __global__ void __launch_bounds__(kBlock) k_spmm_dir(SpmmArgs a)
         }
     }
 }
+#endif
 
 // out[col] = sum over workgroups of partial[wg][col], fixed order; one workgroup per column
 __global__ void __launch_bounds__(kBlock) k_colsum(const double *partial, unsigned nwg, double *out)
@@ -2068,10 +2077,11 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st)
 #undef SPMM_GO
 }
 // vectors per window: as many as leave room for two workgroups per CU (80 KB each), else whatever fits one
+
 int spmm_win_vectors(unsigned wslots)
 {
     if (wslots == 0) return 0;
-    static const int forced = getenv("BICG_SPMM_NV") ? atoi(getenv("BICG_SPMM_NV")) : 0;      // measurement knob: 4 or 8 vectors per window
+    static const int forced = knob_x("BICG_SPMM_NV") ? atoi(knob_x("BICG_SPMM_NV")) : 0;      // measurement knob: 4 or 8 vectors per window
     if ((forced == 4 || forced == 8) && (size_t)forced * wslots * 8u <= 156u * 1024u) return forced;
     // (the head of every row stays in registers across the passes, so more vectors per window save barriers, not matrix traffic:
     // 16 per window was dropped -- its 256 LDS reads per thread in flight cost the occupancy)
@@ -2101,6 +2111,7 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
 #undef WIN_GO
     return err;
 }
+#ifdef BICG_EXPERIMENTS
 hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st)
 {
     if (a.ngroups == 0) return hipSuccess;
@@ -2111,6 +2122,9 @@ hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st)
     else     { if (with_offd) hipLaunchKernelGGL((k_spmm_dir<false, true>), dim3(grid), dim3(kBlock), 0, st, a); else hipLaunchKernelGGL((k_spmm_dir<false, false>), dim3(grid), dim3(kBlock), 0, st, a); }
     return hipGetLastError();
 }
+#else
+hipError_t launch_spmm_dir(const SpmmArgs &, bool, hipStream_t) { return hipErrorNotSupported; }      // (not in this build)
+#endif
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)
 {
@@ -2314,13 +2328,13 @@ template <> __device__ __forceinline__ d2 ld<d2>(const double *p, uint32_t i)
 // Cache, which the matrix stream and the re-read work vectors use better. Measured on Transport:
 // plain 150.4 -> 145.6 us, CA 170 -> 166, pipelined 168 -> 163, 16 shifts 312 -> 294 us per
 // iteration. BICG_X_NT=0 / BICG_SET_NT=0 switch it off (read once).
-static bool env_on(const char *name, bool dflt)
+static bool env_on_x(const char *name, bool dflt)        // measurement knob (bicg_knobs.h): the default unless built with EXPERIMENTS=1
 {
-    const char *v = getenv(name);
+    const char *v = knob_x(name);
     return v ? atoi(v) != 0 : dflt;
 }
-static bool stream_x() { static const bool on = env_on("BICG_X_NT", true); return on; }
-static bool stream_sets() { static const bool on = env_on("BICG_SET_NT", true); return on; }
+static bool stream_x() { static const bool on = env_on_x("BICG_X_NT", true); return on; }
+static bool stream_sets() { static const bool on = env_on_x("BICG_SET_NT", true); return on; }
 
 // streaming variants for vectors touched once per iteration (x): keep the Infinity Cache for the
 // matrix and the vectors that are re-read soon
@@ -2454,26 +2468,25 @@ __global__ void __launch_bounds__(kBlock) k_vec(F f, uint32_t n, Scal *S, Reduce
     }
 }
 
-static bool env_on(const char *name, bool dflt);
 static unsigned g_vec_grid_cap = 0;
 void set_vec_grid_cap(unsigned cap) { g_vec_grid_cap = cap; }
 // pairs per thread of an element-wise launch over n rows (0: grid-stride loop over <= kMaxGrid workgroups)
 static unsigned vec_ppt(uint32_t n)
 {
-    static const int ppt_env = [] { const char *v = getenv("BICG_VEC_PPT"); return v ? atoi(v) : -1; }();
+    static const int ppt_env = [] { const char *v = knob_x("BICG_VEC_PPT"); return v ? atoi(v) : -1; }();
     return ppt_env >= 0 ? (unsigned)ppt_env : (n >= (1u << 26) ? (unsigned)kVecTile : 0u);
 }
 // ... as contiguous tiles with non-temporal accesses (k_vec<.., TILE>; BICG_VEC_TILE=0: the strided form of round 4)
 static bool vec_tiled(uint32_t n)
 {
-    static const bool on = env_on("BICG_VEC_TILE", true);
+    static const bool on = env_on_x("BICG_VEC_TILE", true);
     return on && !g_vec_grid_cap && vec_ppt(n) == (unsigned)kVecTile;
 }
 unsigned vec_grid(uint32_t n)
 {
     // 256 CUs x 8 resident workgroups, grid-stride beyond (BICG_VEC_GRID: measurement knob, <= kMaxGrid)
     static const unsigned env_cap = [] {
-        const char *v = getenv("BICG_VEC_GRID");
+        const char *v = knob_x("BICG_VEC_GRID");
         const int g = v ? atoi(v) : kMaxGrid;
         return (unsigned)(g >= 1 && g <= kMaxGrid ? g : kMaxGrid);
     }();

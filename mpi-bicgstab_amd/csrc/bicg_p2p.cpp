@@ -18,6 +18,7 @@
 // rank learns whether ALL ranks passed; if not, the path is left disabled and the solver keeps
 // using the transport's own collectives.
 #include "bicg_comm.h"
+#include "bicg_knobs.h"
 
 #include <unistd.h>
 
@@ -72,7 +73,7 @@ void *P2p::alloc(size_t bytes)
     // stale until the time-out. No silent fallback: if the runtime cannot provide (or export) uncached
     // memory the peer-to-peer path stays off and the transport's own collectives are used.
     // BICG_P2P_ALLOC=default asks for ordinary memory explicitly (single-GPU experiments only).
-    const char *mode = getenv("BICG_P2P_ALLOC");
+    const char *mode = knob_x("BICG_P2P_ALLOC");
     uncached = false;
     if (mode && strcmp(mode, "default") == 0) {
         BICG_HIP(hipMalloc(&p, bytes));

@@ -18,6 +18,7 @@
 #include <vector>
 
 #include "bicg_comm.h"
+#include "bicg_knobs.h"
 #include "bicg_plan.h"
 #include "bicg_parallel.h"
 #include <memory>
@@ -813,8 +814,9 @@ void spmm_buffers(bicg_ctx *c)
     c->mm_sigma = dev_alloc<double>(kSpmmCols);
     BICG_HIP(hipMemset(c->mm_in, 0, sizeof(double) * kSpmmCols * st));
     BICG_HIP(hipDeviceSynchronize());      // the memset ran on the null stream: c->sc does not wait for it
-    c->mm_xcd = !(getenv("BICG_SPMM_XCD") && atoi(getenv("BICG_SPMM_XCD")) == 0);
+    c->mm_xcd = !(knob_x("BICG_SPMM_XCD") && atoi(knob_x("BICG_SPMM_XCD")) == 0);
     c->mm_win_env = getenv("BICG_SPMM_WIN") ? atoi(getenv("BICG_SPMM_WIN")) : 1;
+    if (!kExperiments && c->mm_win_env == 2) c->mm_win_env = 1;      // (2 = the direct form: builds with EXPERIMENTS=1 only)
 }
 
 // SpMV whose epilogue runs a pipelined phase on the workgroup's own rows (k_spmv_sell_epi): the open dot group is
@@ -881,7 +883,7 @@ static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, cons
         uint32_t best_len = 0, best_at = 0;
         for (uint32_t sl = 0; sl < nslices; ++sl) { const uint32_t l = d[sl].x & 0xFFFFu; if ((d[sl].x >> 16) == kSliceConstant && l > best_len) { best_len = l; best_at = d[sl].y; } }
         // (measured, 512^3: 0.923 against 0.929 ms per product, 256^3 0.146 against 0.123 ms -- off unless BICG_SELL_YGROUP=1)
-        if (best_len >= 5 && getenv("BICG_SELL_YGROUP") && atoi(getenv("BICG_SELL_YGROUP")) != 0) {
+        if (best_len >= 5 && knob_x("BICG_SELL_YGROUP") && atoi(knob_x("BICG_SELL_YGROUP")) != 0) {
             std::vector<int> dist(uoff.begin() + best_at, uoff.begin() + best_at + best_len);
             std::sort(dist.begin(), dist.end());
             const int line = dist[best_len - 2];
@@ -1000,8 +1002,8 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
     // the XCDs round-robin (product 0.480 -> 0.460 ms, CA-BiCGStab 5.40 -> 5.31 ms per iteration); a grid whose vectors the cache
     // holds (256^3) keeps ordinary stores and the XCD-contiguous order (0.053 against 0.061 ms): profiles/r05/stencil_sweep_xcd_nt.txt
     const bool st_big = 16.0 * (double)nrows > 2.0 * 256.0 * 1048576.0;
-    const int st_xcd = getenv("BICG_STENCIL_XCD") ? atoi(getenv("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
-    const int st_nt = getenv("BICG_STENCIL_NT") ? atoi(getenv("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
+    const int st_xcd = knob_x("BICG_STENCIL_XCD") ? atoi(knob_x("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
+    const int st_nt = knob_x("BICG_STENCIL_NT") ? atoi(knob_x("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
     c->st = StencilDev{1, sy, sz, nxs, ny, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
     if (const char *v = getenv("BICG_CA_FUSE")) c->ca_fuse = atoi(v) != 0;
     // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
@@ -1508,7 +1510,7 @@ void probe_pipe_form(bicg_ctx *c, int method, const bicg_options *opt_in)
     BICG_HIP(hipMemcpy(c->v.x, keep, sizeof(double) * n, hipMemcpyDeviceToDevice));
     BICG_HIP(hipMemcpy(c->v.r, keep + n, sizeof(double) * n, hipMemcpyDeviceToDevice));
     BICG_HIP(hipFree(keep));
-    if (c->rank == 0 && getenv("BICG_PIPE_PROBE_VERBOSE"))
+    if (c->rank == 0 && knob_x("BICG_PIPE_PROBE_VERBOSE"))
         fprintf(stderr, "bicgstab_hip: pipelined form probe: separate kernels %.4f ms, SpMV epilogues %.4f ms per iteration -> %s\n", t[0], t[1],
                 c->fuse_pipe ? "epilogues" : "separate kernels");
 }
@@ -2046,10 +2048,10 @@ int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, do
 // BICG_SELL_BLOCK = B (groups, default 256; 0: natural order).
 void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups)
 {
-    if (!getenv("BICG_SELL_GPW") && !getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw = c->sell_gpw_dots = (int)std::max<uint32_t>(1u, (ngroups + 65535u) / 65536u);
-    if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = std::max(1, atoi(sv));
-    if (const char *sv = getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = std::max(1, atoi(sv));
-    const uint32_t B = getenv("BICG_SELL_BLOCK") ? (uint32_t)atoi(getenv("BICG_SELL_BLOCK")) : 256u;
+    if (!knob_x("BICG_SELL_GPW") && !knob_x("BICG_SELL_GPW_DOTS")) c->sell_gpw = c->sell_gpw_dots = (int)std::max<uint32_t>(1u, (ngroups + 65535u) / 65536u);
+    if (const char *sv = knob_x("BICG_SELL_GPW")) c->sell_gpw = std::max(1, atoi(sv));
+    if (const char *sv = knob_x("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = std::max(1, atoi(sv));
+    const uint32_t B = knob_x("BICG_SELL_BLOCK") ? (uint32_t)atoi(knob_x("BICG_SELL_BLOCK")) : 256u;
     const uint32_t P = (c->far_rows + kGroupRows / 2) / kGroupRows;          // groups per plane
     if (B == 0 || P < 4 * B || c->sell_gpw != c->sell_gpw_dots || (uint64_t)c->far_rows * 24ull <= (3ull << 19)) return;   // three planes fit half an L2
     const uint32_t nblocks = sell_grid(ngroups, c->sell_gpw), each = (ngroups + nblocks - 1) / nblocks;
@@ -2105,7 +2107,7 @@ bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32
     a.win_slots = slots_used; a.max_runs = max_runs;
     // the matrix goes to LDS when everything fits next to the window
     a.mat_entries = P.rpt == 1 ? max_entries : 0;
-    if (getenv("BICG_PERSIST_LDSMAT") && atoi(getenv("BICG_PERSIST_LDSMAT")) == 0) a.mat_entries = 0;
+    if (knob_x("BICG_PERSIST_LDSMAT") && atoi(knob_x("BICG_PERSIST_LDSMAT")) == 0) a.mat_entries = 0;
     // what a workgroup may ask for on THIS device (gfx950: 160 KiB per CU; the static part of the kernels is < 6 KiB)
     const unsigned lds_max = std::min<unsigned>(kPersistMaxLds, prop.sharedMemPerBlock > 8192 ? (unsigned)prop.sharedMemPerBlock - 6144u : 0u);
     if (persist_lds_bytes(a) > lds_max) a.mat_entries = 0;
@@ -2179,9 +2181,9 @@ bool persist_chunk(bicg_ctx *c, int niter)
     a.drift_every = (pipe && c->opt.rr_drift > 0.0) ? c->opt.check_every : 0;
     a.drift_tol2 = c->opt.rr_drift * c->opt.rr_drift;
     a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;          // 2 s inside one GPU
-    static const int xcd_map = getenv("BICG_PERSIST_XCD") ? atoi(getenv("BICG_PERSIST_XCD")) : 1;
+    static const int xcd_map = knob_x("BICG_PERSIST_XCD") ? atoi(knob_x("BICG_PERSIST_XCD")) : 1;
     a.xcd_map = xcd_map;
-    static const int first_sleep = getenv("BICG_PERSIST_SLEEP") ? atoi(getenv("BICG_PERSIST_SLEEP")) : 1;
+    static const int first_sleep = knob_x("BICG_PERSIST_SLEEP") ? atoi(knob_x("BICG_PERSIST_SLEEP")) : 1;
     a.first_sleep = (unsigned)first_sleep;
     if (a.multi) {
         // every rank advances its exchange and group numbers by the whole chunk, converged early or not
@@ -2195,7 +2197,7 @@ bool persist_chunk(bicg_ctx *c, int niter)
         if (!c->waitlog) { c->waitlog = dev_alloc<unsigned>(3 * (size_t)kWaitCap); BICG_HIP(hipMemsetAsync(c->waitlog, 0, sizeof(unsigned) * 3 * kWaitCap, c->sc)); }
         a.waitlog = c->waitlog; a.waitcap = kWaitCap;
     }
-    static const bool want_trace = getenv("BICG_PERSIST_TRACE") != nullptr;
+    static const bool want_trace = knob_x("BICG_PERSIST_TRACE") != nullptr;
     unsigned long long *dbg = nullptr;
     if (want_trace) {
         dbg = dev_alloc<unsigned long long>(64 * 16);
@@ -2257,12 +2259,12 @@ bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, 
     {   // the sets stay in the Infinity Cache when they (and the matrix, if it is not in LDS) fit half of it
         const double ws = 16.0 * (double)nsig * (double)st + (a.mat_entries ? 0.0 : (double)c->matrix_bytes);
         a.set_nt = ws > 0.5 * 256.0 * 1048576.0;
-        if (const char *e = getenv("BICG_SHP_NT")) a.set_nt = atoi(e) != 0;
+        if (const char *e = knob_x("BICG_SHP_NT")) a.set_nt = atoi(e) != 0;
     }
     a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;
-    static const int xcd_map = getenv("BICG_PERSIST_XCD") ? atoi(getenv("BICG_PERSIST_XCD")) : 1;
+    static const int xcd_map = knob_x("BICG_PERSIST_XCD") ? atoi(knob_x("BICG_PERSIST_XCD")) : 1;
     a.xcd_map = xcd_map;
-    static const int first_sleep = getenv("BICG_PERSIST_SLEEP") ? atoi(getenv("BICG_PERSIST_SLEEP")) : 1;
+    static const int first_sleep = knob_x("BICG_PERSIST_SLEEP") ? atoi(knob_x("BICG_PERSIST_SLEEP")) : 1;
     a.first_sleep = (unsigned)first_sleep;
     if (!pipe) c->persist_seq += 3u * (unsigned)niter;
     if (a.multi) {
@@ -2299,7 +2301,7 @@ static void ctx_state(bicg_ctx *c, Comm *comm, uint32_t ngroups)
     c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
     // (BICG_STRIDE_PAD = doubles added to the distance between two vectors, a multiple of 32: measurement knob for grids whose
     // vectors would otherwise lie a power of two bytes apart -- 512^3: exactly 1 GiB)
-    if (const char *sv = getenv("BICG_STRIDE_PAD")) c->stride += ((uint32_t)std::max(0, atoi(sv)) / 32u) * 32u;
+    if (const char *sv = knob_x("BICG_STRIDE_PAD")) c->stride += ((uint32_t)std::max(0, atoi(sv)) / 32u) * 32u;
     c->slab = dev_alloc<double>(12 * (size_t)c->stride);
     BICG_HIP(hipMemset(c->slab, 0, sizeof(double) * 12 * (size_t)c->stride));
     double *base = c->slab;
@@ -2316,7 +2318,7 @@ static void ctx_state(bicg_ctx *c, Comm *comm, uint32_t ngroups)
     BICG_HIP(hipMemset(c->tail_tab, 0, sizeof(llword) * (size_t)c->nslots * kTailStride));
     c->tail_shard = dev_alloc<llword>((size_t)kShards * kRedSlots * 2);
     BICG_HIP(hipMemset(c->tail_shard, 0, sizeof(llword) * kShards * kRedSlots * 2));
-    if (const char *sv = getenv("BICG_TAIL_FINISH")) c->tail_finish = atoi(sv) != 0;
+    if (const char *sv = knob_x("BICG_TAIL_FINISH")) c->tail_finish = atoi(sv) != 0;
     c->Sbuf = dev_alloc<Scal>(2);
     BICG_HIP(hipMemset(c->Sbuf, 0, 2 * sizeof(Scal)));
     c->S = c->Sbuf;
@@ -2353,6 +2355,7 @@ static void ctx_streams(bicg_ctx *c, int P)
 // =====================================================================================  C ABI
 extern "C" {
 
+int bicg_has_experiments(void) { return kExperiments ? 1 : 0; }
 const char *bicg_version(void) { return "bicgstab_hip 0.1 (gfx950)"; }
 
 void bicg_default_options(bicg_options *o)
@@ -2367,7 +2370,7 @@ void bicg_default_options(bicg_options *o)
 // the code objects this context launches from, loaded now (preload_kernels, bicg_kernels.hip)
 static void preload_for(bicg_ctx *c)
 {
-    if (getenv("BICG_PRELOAD") && atoi(getenv("BICG_PRELOAD")) == 0) return;
+    if (knob_x("BICG_PRELOAD") && atoi(knob_x("BICG_PRELOAD")) == 0) return;
     SellDev d = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     d.vbase = c->s_vbase;
     preload_kernels(d, c->sell_entries > 0);
@@ -2399,10 +2402,10 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     c->nnz_d = diag->rows ? diag->ptr[diag->rows] : 0u;
     const int P = c->nranks;
 
-    bool use_sell = !(getenv("BICG_NO_SELL") && atoi(getenv("BICG_NO_SELL")));
-    if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
-    if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
-    if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
+    bool use_sell = !(knob_x("BICG_NO_SELL") && atoi(knob_x("BICG_NO_SELL")));
+    if (const char *sv = knob_x("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
@@ -2435,8 +2438,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->fuse_small = total / (uint64_t)P < 6000000u;
     }
     if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;
-    if (const char *sv = getenv("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
-    if (const char *sv = getenv("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = atoi(sv);
 
     // ---- halo plan (multi rank): which of x's remote entries this rank needs, who needs ours
     std::vector<uint32_t> ocol, optr(c->n_loc + 1, 0u);
@@ -2492,7 +2495,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         const uint64_t mean_len = info->rows ? nnz_diag_all / info->rows : 0;     // (INFO_Matrix.nz is not always filled in)
         const uint64_t groups_per_rank = ((uint64_t)info->rows / (uint64_t)P + kGroupRows - 1) / kGroupRows;
         c->rowsplit = use_sell && (mean_len >= 256 || (mean_len >= 128 && groups_per_rank < 512));
-        if (const char *sv = getenv("BICG_ROWSPLIT")) c->rowsplit = atoi(sv) != 0;
+        if (const char *sv = knob_x("BICG_ROWSPLIT")) c->rowsplit = atoi(sv) != 0;
         if (c->rowsplit) use_sell = false;
     }
     std::vector<uint32_t> slice_len(nslices, 0u), slice_base(nslices, 0u);
@@ -2602,7 +2605,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // With windows: deal the rows of every group to the lanes by decreasing length (SellDev::perm). The group's
     // entries stay where they are as a whole; the slices inside it change length.
     std::vector<unsigned char> perm;
-    if (win && !(getenv("BICG_SELL_SORT") && atoi(getenv("BICG_SELL_SORT")) == 0)) {
+    if (win && !(knob_x("BICG_SELL_SORT") && atoi(knob_x("BICG_SELL_SORT")) == 0)) {
         perm.assign((size_t)ngroups * kGroupRows, 0);
         std::vector<uint32_t> slice_sum(nslices, 0u);             // entries of a slice after the rows were dealt out
         parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int) {
@@ -2995,7 +2998,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // ~3 % per SpMV): worth it unless the local problem is so large that 3 % exceeds the ~10 us per
     // iteration the separate apply kernels cost
     c->inline_apply = c->nnz_d < 40000000u;
-    if (const char *sv = getenv("BICG_P2P_INLINE_APPLY")) c->inline_apply = atoi(sv) != 0;
+    if (const char *sv = knob_x("BICG_P2P_INLINE_APPLY")) c->inline_apply = atoi(sv) != 0;
     if (c->p2p && !c->single()) {
         c->halo_ring = (llword *)c->p2p->alloc(sizeof(llword) * 2 * (size_t)kHaloRing * c->halo);
         std::vector<void *> rings;
@@ -3018,7 +3021,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->push_dst0 = dev_upload(dst0.data(), dst0.size());
         c->push_stride = dev_upload(dstride.data(), dstride.size());
         c->ll_fused = c->n_bnd == 0 && c->ng_int + c->ng_bnd > 0;
-        if (const char *sv = getenv("BICG_P2P_FUSED")) c->ll_fused = c->ll_fused && atoi(sv) != 0;
+        if (const char *sv = knob_x("BICG_P2P_FUSED")) c->ll_fused = c->ll_fused && atoi(sv) != 0;
         if (c->ll_fused) {
             std::vector<uint32_t> order(gl_int);
             order.insert(order.end(), gl_bnd.begin(), gl_bnd.end());
@@ -3044,8 +3047,8 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         const char *pe = getenv("BICG_PERSIST");
         bool mine = !(pe && atoi(pe) == 0) && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
         c->persist_on = all_ranks(comm, mine);
-        if (const char *pp = getenv("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
-        if (const char *pp = getenv("BICG_FUSE_PLAIN")) c->fuse_plain = atoi(pp) != 0;
+        if (const char *pp = knob_x("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
+        if (const char *pp = knob_x("BICG_FUSE_PLAIN")) c->fuse_plain = atoi(pp) != 0;
         if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
     }
 
@@ -3108,9 +3111,9 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->comm = comm; c->device = comm->device; c->nranks = 1; c->rank = 0;
     g_live.push_back(c);
     c->n_loc = rows; c->n_glob = rows; c->nnz_d = nnz;
-    if (const char *sv = getenv("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
-    if (const char *sv = getenv("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
-    if (const char *sv = getenv("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
+    if (const char *sv = knob_x("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
     if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
     if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
     c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;

@@ -5,6 +5,7 @@
 // bandwidth as a fraction of the measured copy / triad / read rates next to the fraction of the 8 TB/s spec.
 // Arrays are > 1 GB by default so that the 256 MiB Infinity Cache cannot serve them. gfx950 only.
 #include "bicg_comm.h"
+#include "bicg_knobs.h"
 #include "../../include/bicgstab_hip.h"
 
 #include <hip/hip_runtime.h>
@@ -118,7 +119,7 @@ extern "C" int bicg_stream_bench(int kind, unsigned long long bytes_per_array, i
         float t = 0.f;
         BICG_HIP(hipEventElapsedTime(&t, e0, e1));
         t /= (float)reps;
-        if (getenv("BICG_STREAM_VERBOSE")) fprintf(stderr, "bicg_stream_bench kind %d variant %d: %.4f ms\n", kind, variant, t);
+        if (knob_x("BICG_STREAM_VERBOSE")) fprintf(stderr, "bicg_stream_bench kind %d variant %d: %.4f ms\n", kind, variant, t);
         if (variant == 0 || t < ms) ms = t;
     }
     const double arrays = kind == 0 ? 2.0 : kind == 1 ? 3.0 : 1.0;     // bytes moved: read + written arrays

@@ -314,6 +314,8 @@ def test_window_fused_plain_iteration_is_bit_identical(monkeypatch):
     profiles/NOTES.md). Same expressions, same row sums, same dot partials: x, r and the alpha / omega / beta / (r,r) trace
     are bit-identical to the five-launch iteration, also across chunk boundaries."""
     from mpi_bicgstab_amd import hipsolver as H
+    if not H.lib().bicg_has_experiments():
+        pytest.skip("a negative result kept for reference: compiled in by `make EXPERIMENTS=1` only (csrc/bicg_knobs.h)")
     H.lib().bicg_comm_init_single(0)
     A = synth.from_offsets(300007, (0, 1, -1, 117, -117, 118, -118, 13689, -13689, 13807, -13807), diag_base=14.0, seed=6)
     out = {}
