@@ -174,7 +174,10 @@ typedef struct {
                             bit 1: section timing -- the reference's MEASURE_SECTION_TIME (src/shifted_switching_solver.c:9,
                             src/shifted_solver.c:77-81, 230-247) on the device clock: an event wherever the kind of work changes
                             (product / element-wise / shifted systems / reduction hand-over), read with bicg_section_times.
-                            Both keep the multi-launch forms (no persistent launch, no graph replay). */
+                            Both keep the multi-launch forms (no persistent launch, no graph replay);
+                            bit 2 (with bit 1; BICG_SECTION_TIME=2): the switching solvers also print the reference's
+                            DISPLAY_SECTION_TIME table, one line per iteration, and its ten totals incl. "Switch time"
+                            (src/shifted_switching_solver.c:884-892, 994-1005) */
     double rr_drift;     /* pipelined solvers, additive: > 0 enables ADAPTIVE residual
                             replacement -- at every host check the true residual b - A x is computed and, when
                             ||(b - A x) - r|| > rr_drift * ||r||, the next iteration is a replacement step

@@ -81,6 +81,7 @@ struct ShiftDev {
     double *pi_arc;                  // [nsig][arc_len]
     int    *stop;                    // [nsig] converged shifts (frozen)
     int    *skip;                    // [nsig] shifts the batched update of THIS iteration leaves alone
+    int    *unsolved_arc;            // [arc_len] systems still running after iteration k (the reference's DISPLAY_SECTION_TIME column)
     int     arc_len, stop_count, max_sigma, switches;
     double  r_scale;                 // seed switch: r <- r_scale * r, applied by the host while paused  (:499)
 };

@@ -96,8 +96,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
         const unsigned g = a.glist ? a.glist[gi] : gi;
         // ---- trip 1
         const uint32_t w0 = a.sell.win_ptr[g], w1 = a.sell.win_ptr[g + 1];
+        // (the block's last group may lack its last slices: their metadata does not exist -- no rows, no entries)
         const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
-        const uint32_t base = a.sell.slice_base[slice], len = a.sell.slice_len[slice];
+        const bool has_slice = slice * (uint32_t)kSliceRows < a.nrows;
+        const uint32_t base = has_slice ? a.sell.slice_base[slice] : 0u, len = has_slice ? a.sell.slice_len[slice] : 0u;
         const uint32_t info = a.sell.lane_info[(size_t)g * kGroupRows + tid];
         const uint32_t row = g * kGroupRows + (info & 0xFFu), mylen = info >> 8;          // (rows past the block's last: length 0)
         const bool live = row < a.nrows;

@@ -114,6 +114,7 @@ __device__ __forceinline__ void apply_phase_switching(Scal *S, int phase)
         if (s_val[0] > 1.0) H->max_sigma = s_idx[0];     // otherwise it keeps its previous value, as in the reference
         S->k += 1;                                       // (:536)
         const int k = S->k;
+        if (H->unsolved_arc && k < H->arc_len) H->unsolved_arc[k] = nsig - H->stop_count;
         if (S->tr_dotr && k <= S->max_iter) {
             S->tr_alpha[k - 1] = S->alpha; S->tr_omega[k - 1] = S->omega; S->tr_beta[k - 1] = S->beta; S->tr_dotr[k - 1] = S->dot_r;
         }

@@ -252,6 +252,13 @@ struct bicg_ctx {
     bool time_sections = false, sec_exhausted = false;
     std::vector<hipEvent_t> sec_ev;
     std::vector<unsigned char> sec_lab;
+    // finer attribution of a mark (the reference's ten sections, src/shifted_switching_solver.c:678-695): iteration it belongs to,
+    // which product of the iteration (1 / 2), and what inside the product (0 the rows / everything, 1 halo exchange, 2 halo-touching rows)
+    std::vector<int> sec_k;
+    std::vector<unsigned char> sec_sub;
+    int cur_k = 0, cur_prod = 0, cur_sub = 0;
+    bool sec_dump = false;                 // BICG_SECTION_TIME=2: the per-iteration table of DISPLAY_SECTION_TIME
+    double switch_sec = 0.0;               // host time spent in seed switches
     int sec_used = 0, sec_cur = 255;
     double sec_ms[4] = {0, 0, 0, 0};
     int sec_iters = 0;
@@ -348,9 +355,23 @@ void sec_mark(bicg_ctx *c, int label)
         return;
     }
     BICG_HIP(hipEventRecord(c->sec_ev[c->sec_used], c->sc));
+    c->sec_k[c->sec_used] = c->cur_k; c->sec_sub[c->sec_used] = (unsigned char)((c->cur_prod << 4) | c->cur_sub);
     c->sec_lab[c->sec_used++] = (unsigned char)label;
     c->sec_cur = label;
 }
+// a mark although the label stays: a new iteration, or another part of the same product
+void sec_remark(bicg_ctx *c)
+{
+    if (!c->time_sections || c->sec_cur == SEC_STOP) return;
+    const int label = c->sec_cur;
+    c->sec_cur = -1;
+    sec_mark(c, label);
+}
+struct SubSection {    // the enclosed launches are part `sub` of the current product
+    bicg_ctx *c; int prev;
+    SubSection(bicg_ctx *ctx, int sub) : c(ctx), prev(ctx->cur_sub) { c->cur_sub = sub; sec_remark(c); }
+    ~SubSection() { c->cur_sub = prev; sec_remark(c); }
+};
 struct Section {       // the enclosed launches belong to `label`; afterwards the enclosing section continues
     bicg_ctx *c; int prev;
     Section(bicg_ctx *ctx, int label) : c(ctx), prev(ctx->sec_cur) { if (prev != SEC_STOP) sec_mark(c, label); }
@@ -360,10 +381,12 @@ void sec_begin(bicg_ctx *c, bool on)
 {
     c->time_sections = on; c->sec_exhausted = false;
     c->sec_used = 0; c->sec_cur = SEC_STOP; c->sec_iters = 0;
+    c->cur_k = 0; c->cur_prod = 0; c->cur_sub = 0; c->switch_sec = 0.0;
     for (double &m : c->sec_ms) m = 0.0;
     if (on && c->sec_ev.empty()) {
         c->sec_ev.resize(kMaxSectionMarks);
         c->sec_lab.resize(kMaxSectionMarks);
+        c->sec_k.resize(kMaxSectionMarks); c->sec_sub.resize(kMaxSectionMarks);
         for (auto &e : c->sec_ev) BICG_HIP(hipEventCreate(&e));
     }
 }
@@ -674,9 +697,10 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             c->halo_unsynced = 0;
         }
     } else {
-        launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, Sh, c->sc);
         const bool two_streams = c->comm->stream_ordered() && c->overlap;
         hipEvent_t eh = nullptr;
+        c->cur_sub = 1; sec_remark(c);          // the exchange: the reference's "agv" section (src/matrix.c:432)
+        launch_halo_pack(xin, c->send_idx, c->nsend, c->sendbuf, Sh, c->sc);
         if (two_streams) {
             hipEvent_t ep = c->ev_pack[c->i_pack++ % kEvRing];
             BICG_HIP(hipEventRecord(ep, c->sc));
@@ -687,6 +711,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         } else {
             c->comm->exchange(c->sendbuf, c->scnt.data(), c->sdsp.data(), xin + c->n_loc, c->rcnt.data(), c->rdsp.data(), c->sc);
         }
+        c->cur_sub = 0; sec_remark(c);
         bool joined_pending = false;
         if (c->pend) {   // start the deferred all-reduce behind the halo traffic
             hipEvent_t after = c->pend_ev;
@@ -706,7 +731,9 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         } else {
             interior();
             if (eh) BICG_HIP(hipStreamWaitEvent(c->sc, eh, 0));
+            c->cur_sub = 2; sec_remark(c);      // the rows that touch the halo: the reference's second mult() (src/matrix.c:440)
             boundary();
+            c->cur_sub = 0; sec_remark(c);
         }
         if (joined_pending && c->pend_ev) {
             BICG_HIP(hipStreamWaitEvent(c->sc, c->pend_ev, 0));
@@ -1291,7 +1318,7 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     const size_t st = c->stride;
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = (o.time_kernels & 1) != 0;
-    sec_begin(c, (o.time_kernels & 2) != 0);
+    sec_begin(c, (o.time_kernels & 2) != 0); c->sec_dump = (o.time_kernels & 4) != 0;
     c->tev_used = 0; c->spmv_calls_timed = 0;
     if (c->time_kernels && c->tev.empty()) {
         c->tev.resize(kMaxTimed);
@@ -1545,6 +1572,49 @@ void print_sections(const bicg_ctx *c, double total_seconds)
     printf("Shift time   : %e [sec.]\n", shift);
 }
 
+// BICG_SECTION_TIME=2 (bicg_options.time_kernels & 4) on the switching solvers: the reference's DISPLAY_SECTION_TIME table
+// (src/shifted_switching_solver.c:884-892: one line per iteration) and the ten totals it prints at the end (:994-1005), on the
+// device clock. Mapping: agv = halo pack + exchange (host / RCCL transports; with the peer-to-peer path the exchange is inside the
+// product's launch and shows under mult_diag), mult_diag = the rows without halo entries (one rank: every row), mult_offd = the
+// halo-touching rows (their diag AND offd part: one kernel), ared = the hand-over of the dot groups, shift = the batched pass
+// over the shifted systems, seed = everything of the iteration except shift, switch = host time spent in seed switches.
+void print_section_table(bicg_ctx *c, int its, int nsig, const int *unsolved, double total_seconds)
+{
+    if (c->sec_used == 0 || its <= 0) return;
+    enum { AGV1, DIAG1, OFFD1, AGV2, DIAG2, OFFD2, ARED, SHIFT, SEED, NCOL };
+    std::vector<double> t((size_t)(its + 1) * NCOL, 0.0);
+    for (int i = 0; i + 1 < c->sec_used; ++i) {
+        if (c->sec_lab[i] == SEC_STOP) continue;
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, c->sec_ev[i], c->sec_ev[i + 1]) != hipSuccess) continue;
+        const int k = std::min(std::max(c->sec_k[i], 0), its), prod = c->sec_sub[i] >> 4, sub = c->sec_sub[i] & 15;
+        double *row = t.data() + (size_t)k * NCOL;
+        const double sec = 1.0e-3 * ms;
+        if (c->sec_lab[i] == SEC_SHIFT) { row[SHIFT] += sec; continue; }
+        row[SEED] += sec;
+        if (c->sec_lab[i] == SEC_REDUCE) row[ARED] += sec;
+        else if (c->sec_lab[i] == SEC_SPMV && (prod == 1 || prod == 2)) row[(prod == 1 ? AGV1 : AGV2) + (sub == 1 ? 0 : sub == 2 ? 2 : 1)] += sec;
+    }
+    printf("iter, unsolved, seed, agv_1, mult_diag_1, mult_offd_1, agv_2, mult_diag_2, mult_offd_2, ared, shift\n");
+    double tot[NCOL] = {0};
+    for (int k = 1; k <= its; ++k) {
+        const double *r = t.data() + (size_t)k * NCOL;
+        printf("%d, %d, %e, %e, %e, %e, %e, %e, %e, %e, %e\n", k, unsolved ? unsolved[k] : nsig, r[SEED], r[AGV1], r[DIAG1], r[OFFD1], r[AGV2], r[DIAG2],
+               r[OFFD2], r[ARED], r[SHIFT]);
+        for (int q = 0; q < NCOL; ++q) tot[q] += r[q];
+    }
+    printf("Seed time    : %e [sec.]\n", total_seconds - tot[SHIFT] - c->switch_sec);
+    printf(" 1 Agv time   : %e [sec.]\n", tot[AGV1]);
+    printf(" 1 Mult_diag  : %e [sec.]\n", tot[DIAG1]);
+    printf(" 1 Mult_offd  : %e [sec.]\n", tot[OFFD1]);
+    printf(" 2 Agv time   : %e [sec.]\n", tot[AGV2]);
+    printf(" 2 Mult_diag  : %e [sec.]\n", tot[DIAG2]);
+    printf(" 2 Mult_offd  : %e [sec.]\n", tot[OFFD2]);
+    printf(" Ared time    : %e [sec.]\n", tot[ARED]);
+    printf("Shift time   : %e [sec.]\n", tot[SHIFT]);
+    printf("Switch time  : %e [sec.]\n", c->switch_sec);
+}
+
 int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
                   const bicg_options *opt_in, bicg_result *res)
 {
@@ -1569,7 +1639,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
         c->sh_cap = nsig;
     }
     const int L = o.max_iter + 2;                                    // archive entries 0 .. max_iter + 1
-    const size_t nd = 3 * (size_t)L + (size_t)nsig * L, ni = 2 * (size_t)nsig;
+    const size_t nd = 3 * (size_t)L + (size_t)nsig * L, ni = 2 * (size_t)nsig + (size_t)L;     // (+ the systems still running, per iteration)
     const size_t need = nd * sizeof(double) + ni * sizeof(int);
     if (c->sw_cap < need) {
         if (c->sw_buf) BICG_HIP(hipFree(c->sw_buf));
@@ -1582,7 +1652,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     double **arr[12] = {&h.sigma, &h.alpha, &h.beta, &h.omega, &h.eta, &h.zeta, &h.pi_old, &h.pi_new, &h.cp, &h.cx, &h.c1, &h.c2};
     for (int i = 0; i < 12; ++i) *arr[i] = c->sh_arrays + (size_t)i * nsig;
     h.a_arc = c->sw_buf; h.b_arc = h.a_arc + L; h.w_arc = h.b_arc + L; h.pi_arc = h.w_arc + L;
-    h.stop = (int *)(c->sw_buf + nd); h.skip = h.stop + nsig;
+    h.stop = (int *)(c->sw_buf + nd); h.skip = h.stop + nsig; h.unsolved_arc = h.skip + nsig;
     BICG_HIP(hipMemcpy(c->sh_dev, &h, sizeof h, hipMemcpyHostToDevice));
     BICG_HIP(hipMemset(c->sh_arrays, 0, sizeof(double) * 12 * (size_t)nsig));
     BICG_HIP(hipMemset(c->sw_buf, 0, need));
@@ -1609,7 +1679,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = false;
-    sec_begin(c, (o.time_kernels & 2) != 0);
+    sec_begin(c, (o.time_kernels & 2) != 0); c->sec_dump = (o.time_kernels & 4) != 0;
     for (int j = 0; j < nsig; ++j)          // p[sigma] <- b for EVERY shift, src/shifted_switching_solver.c:348
         BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
     {   // streaming policy: matrix + 7 work vectors + the two sets
@@ -1630,6 +1700,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     for (;;) {
         fetch_scal(c);
         if (c->hS->paused) {                        // a seed switch happened at the end of iteration hS->k
+            const double t_sw = now_sec();
             ShiftDev now;
             BICG_HIP(hipMemcpy(&now, c->sh_dev, sizeof now, hipMemcpyDeviceToHost));
             launch_scale(v.r, (uint32_t)n, now.r_scale, c->sc);                       // (:499)
@@ -1644,6 +1715,7 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
             if (!finished) BICG_HIP(hipMemcpyAsync(&c->S->done, &zero2[0], sizeof(int), hipMemcpyHostToDevice, c->sc));
             BICG_HIP(hipMemcpyAsync(&c->S->paused, &zero2[1], sizeof(int), hipMemcpyHostToDevice, c->sc));
             BICG_HIP(hipStreamSynchronize(c->sc));
+            c->switch_sec += now_sec() - t_sw;      // the reference's switch_time (src/shifted_switching_solver.c:488-530)
             if (finished) { c->hS->paused = 0; break; }
             continue;
         }
@@ -1653,10 +1725,13 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
         const int chunk = std::min(o.check_every, o.max_iter - c->hS->k);
         sec_mark(c, SEC_VEC);
         for (int j = 0; j < chunk; ++j) {
+            c->cur_k = c->hS->k + j + 1; c->cur_prod = 1; sec_remark(c);
             spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SW_ALPHA, true, 1));           // s = (A + sigma I) p[seed], (r#,s)
             group_now(c, 1, PH_SW_ALPHA);
             launch_sw_q(v, qc, c->S, c->sc);                                          // r_old, q
+            c->cur_prod = 2;
             spmv(c, v.r, v.y, 3, v.r, c->red(0, PH_SW_OMEGA, true, 2));               // y = (A + sigma I) q, (q,y), (q,q)
+            c->cur_prod = 0;
             group_now(c, 2, PH_SW_OMEGA);
             launch_sw_seed(v, x_seed, p_seed, c->S, c->red(0, PH_SW_END, true, 2), c->sc);   // x[seed], r, (r,r), (r#,r)
             group_now(c, 2, PH_SW_END);
@@ -1689,7 +1764,14 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
         if (mode == SH_SWITCH) printf("Total iter   : %d\n", k_ref - 1);
         printf("Total time   : %e [sec.] \n", t1 - t0);
         printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / (k_ref > 0 ? k_ref : 1));
-        print_sections(c, t1 - t0);
+        if (c->sec_dump && c->sec_used > 0) {
+            std::vector<int> unsolved((size_t)L, nsig);
+            BICG_HIP(hipMemcpy(unsolved.data(), h.unsolved_arc, sizeof(int) * (size_t)L, hipMemcpyDeviceToHost));
+            print_section_table(c, its, nsig, unsolved.data(), t1 - t0);
+        } else {
+            print_sections(c, t1 - t0);
+            if (c->sec_used > 0 && mode == SH_SWITCH) printf("Switch time  : %e [sec.]\n", c->switch_sec);      // (src/shifted_switching_solver.c:566)
+        }
         fflush(stdout);
     }
     return k_ref;
@@ -1751,7 +1833,7 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
     BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
     c->time_kernels = false;
-    sec_begin(c, (o.time_kernels & 2) != 0);
+    sec_begin(c, (o.time_kernels & 2) != 0); c->sec_dump = (o.time_kernels & 4) != 0;
     if (mode == SH_XI)                      // p[sigma] <- b for every shift, src/shifted_solver.c:72
         for (int j = 0; j < nsig; ++j)
             BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
@@ -1866,7 +1948,8 @@ void env_options(bicg_options *o)
     if (const char *s = getenv("BICG_CHECK_EVERY")) o->check_every = atoi(s);
     if (const char *s = getenv("BICG_QUIET")) o->quiet = atoi(s);
     if (const char *s = getenv("BICG_RR_DRIFT")) o->rr_drift = atof(s);
-    if (const char *s = getenv("BICG_SECTION_TIME")) o->time_kernels = atoi(s) ? 2 : 0;     // the reference's MEASURE_SECTION_TIME
+    // the reference's MEASURE_SECTION_TIME (1) and DISPLAY_SECTION_TIME (2: the per-iteration table of the switching solvers)
+    if (const char *s = getenv("BICG_SECTION_TIME")) o->time_kernels = atoi(s) >= 2 ? 6 : atoi(s) ? 2 : 0;
 }
 
 // ---------------------------------------------------------------- matrix residency across drop-in calls

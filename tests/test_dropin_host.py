@@ -222,3 +222,42 @@ def test_display_error_lines_of_the_reference_on_the_dropin_path(tmp_path, np_):
         assert ew <= 1e-9 and eg <= 1e-9 and abs(ew - eg) <= 1e-8, (ew, eg)
     silent = subprocess.run([MPIEXEC, "-n", "1", dropin, path], capture_output=True, text=True, timeout=600)
     assert "relative error" not in silent.stdout                      # off unless asked for, like the reference's default build
+
+
+@need
+def test_section_time_table_of_the_reference_on_the_dropin_path(tmp_path):
+    """BICG_SECTION_TIME=2: the reference's DISPLAY_SECTION_TIME table from the drop-in build of main_shifted.c
+    (src/shifted_switching_solver.c:884-892: header, one line per iteration -- iteration, systems still running, seed, the two
+    products' halo / diag / offd parts, the reductions, the shift pass) and the ten totals with "Switch time" (:994-1005), on the
+    device clock; BICG_SECTION_TIME=1: the three lines of MEASURE_SECTION_TIME (:563-566). Two ranks over the host transport so
+    that the exchange and the halo-touching rows are launches of their own."""
+    dropin = os.path.join(REF, "shifted_dropin")
+    if not os.path.exists(dropin):
+        pytest.skip("shifted_dropin not built")
+    path = str(tmp_path / "shifted.mtx")
+    synth.write_mtx(path, synth.from_offsets(20011, (0, 1, -1, 140, -140, 141, -141), diag_base=4.6, seed=5))
+    for np_, extra in ((1, {}), (2, {"BICG_TRANSPORT": "host", "BICG_P2P": "0"})):
+        out = subprocess.run([MPIEXEC, "-n", str(np_), dropin, path], capture_output=True, text=True, timeout=600,
+                             env=dict(os.environ, BICG_CHECK_EVERY="4", BICG_SECTION_TIME="2", **extra))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        k = int(re.search(r"Total iter\s*:\s*(\d+)", out.stdout).group(1))
+        total = float(re.search(r"Total time\s*:\s*(\S+)", out.stdout).group(1))
+        assert "iter, unsolved, seed, agv_1, mult_diag_1, mult_offd_1, agv_2, mult_diag_2, mult_offd_2, ared, shift" in out.stdout
+        rows = [[float(v) for v in m] for m in re.findall(r"^(\d+), (\d+), " + ", ".join([r"(\S+)"] * 9) + "$", out.stdout, flags=re.M)]
+        assert len(rows) == k and [int(r[0]) for r in rows] == list(range(1, k + 1)), (k, len(rows))
+        unsolved = [int(r[1]) for r in rows]
+        assert unsolved[0] <= 512 and all(a >= b for a, b in zip(unsolved, unsolved[1:])) and unsolved[-1] >= 0
+        assert all(r[2] > 0 and r[4] > 0 and r[7] > 0 and r[10] > 0 for r in rows)            # seed, both products, the shift pass
+        if np_ == 2:
+            # the exchange is a section of its own; the halo-touching rows are one only when they are a launch of their own (two-stream
+            # overlap): on this path one launch takes all rows behind the exchange and the column stays 0
+            assert sum(r[3] for r in rows) > 0 and sum(r[6] for r in rows) > 0 and all(r[5] >= 0 and r[8] >= 0 for r in rows)
+        assert sum(r[2] + r[10] for r in rows) <= 1.2 * total
+        for name in ("Seed time", " 1 Agv time", " 1 Mult_diag", " 1 Mult_offd", " 2 Agv time", " 2 Mult_diag", " 2 Mult_offd", " Ared time",
+                     "Shift time", "Switch time"):
+            assert re.search(r"^" + re.escape(name) + r"\s*: \S+ \[sec\.\]$", out.stdout, flags=re.M), name
+    out = subprocess.run([MPIEXEC, "-n", "1", dropin, path], capture_output=True, text=True, timeout=600,
+                         env=dict(os.environ, BICG_CHECK_EVERY="4", BICG_SECTION_TIME="1"))
+    assert out.returncode == 0 and "iter, unsolved" not in out.stdout
+    for name in ("Seed time", "Shift time", "Switch time"):
+        assert re.search(r"^" + re.escape(name) + r"\s*: \S+ \[sec\.\]$", out.stdout, flags=re.M), name
