@@ -83,7 +83,7 @@ void p2p_disable(Comm *c);
 
 Comm *comm_get();                 // process-global communicator (auto-initialised on first use)
 void comm_set(Comm *c);           // takes ownership
-void contexts_orphan();           // bicg_solver.cpp: contexts built on the communicator that is about to go away
+void contexts_orphan();           // bicg_create.cpp: contexts built on the communicator that is about to go away
 Comm *make_single(int device);
 Comm *make_host(int rank, int nranks, bicg_allreduce_fn ar, bicg_alltoallv_fn a2a, void *user, int device);
 Comm *make_rccl(int rank, int nranks, const void *id, int device);

@@ -1,5 +1,5 @@
 // bicg_device.h -- device-side state and kernel launch interface shared by the kernels
-// (bicg_kernels.hip) and the iteration drivers (bicg_solver.cpp). gfx950 only.
+// (bicg_kernels.hip) and the host side (bicg_solver.cpp, bicg_shifted.cpp, bicg_create.cpp: bicg_host.h). gfx950 only.
 #pragma once
 
 #include <hip/hip_runtime.h>

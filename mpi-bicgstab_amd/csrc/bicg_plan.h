@@ -1,4 +1,4 @@
-// bicg_plan.h -- host-only plans shared by bicg_plan.cpp and bicg_solver.cpp (no HIP types).
+// bicg_plan.h -- host-only plans shared by bicg_plan.cpp and bicg_create.cpp (no HIP types).
 #pragma once
 
 #include <cstdint>

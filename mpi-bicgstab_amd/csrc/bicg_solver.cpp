@@ -1,4 +1,5 @@
-// bicg_solver.cpp -- GPU-resident iteration drivers and the C ABI (include/bicgstab_hip.h).
+// bicg_solver.cpp -- GPU-resident iteration drivers behind include/bicgstab_hip.h (the C ABI itself: bicg_api.cpp, bicg_dropin.cpp;
+// contexts and plans: bicg_create.cpp; the shifted family: bicg_shifted.cpp; what they share: bicg_host.h).
 //
 // One context per rank: the rank's diag/offd CSR blocks, the SpMV plan (row blocks, interior /
 // boundary split, halo lists), twelve vectors of rows+halo doubles, and a small device-resident
@@ -7,342 +8,14 @@
 // device, the convergence test of the reference's while loop (src/solver.c:86) is evaluated on the
 // device and turns every later kernel into a no-op, and the host only looks every `check_every`
 // iterations.
-#include <algorithm>
-#include <chrono>
-#include <cmath>
-#include <cstdio>
-#include <cstdlib>
-#include <cstring>
-#include <map>
-#include <tuple>
-#include <vector>
+#include "bicg_host.h"
 
-#include "bicg_comm.h"
-#include "bicg_knobs.h"
-#include "bicg_plan.h"
-#include "bicg_parallel.h"
-#include <memory>
-#include "bicg_device.h"
-
-using namespace bicg;
-
-namespace {
-
-constexpr int kEvRing = 16;
-constexpr int kMaxTimed = 8192;
-constexpr int kPersistChunk = 128;   // iterations per persistent launch, at least (run_iterate)
-
-double now_sec()
-{
-    return std::chrono::duration<double>(std::chrono::steady_clock::now().time_since_epoch()).count();
-}
-
-template <class T> T *dev_alloc(size_t n)
-{
-    T *p = nullptr;
-    BICG_HIP(hipMalloc((void **)&p, sizeof(T) * (n ? n : 1)));
-    return p;
-}
-
-template <class T> T *dev_upload(const T *src, size_t n)
-{
-    T *p = dev_alloc<T>(n);
-    if (n) BICG_HIP(hipMemcpy(p, src, sizeof(T) * n, hipMemcpyHostToDevice));
-    return p;
-}
-
-// n entries followed by `pad` zero entries (16-byte loads may run past the last non-zero)
-template <class T> T *dev_upload_padded(const T *src, size_t n, size_t pad)
-{
-    T *p = dev_alloc<T>(n + pad);
-    BICG_HIP(hipMemset(p + n, 0, sizeof(T) * pad));
-    if (n) BICG_HIP(hipMemcpy(p, src, sizeof(T) * n, hipMemcpyHostToDevice));
-    return p;
-}
-
-}  // namespace
-
-constexpr unsigned kWaitCap = 4096;      // samples per row of PersistArgs::waitlog
-struct bicg_ctx {
-    Comm *comm = nullptr;                  // null once the communicator has been replaced (contexts_orphan)
-    int device = 0;
-    int nranks = 1, rank = 0;
-    uint32_t n_loc = 0, n_glob = 0, halo = 0, stride = 0, nnz_d = 0, nnz_o = 0;
-
-    // matrix + plan (device)
-    double *d_val = nullptr, *o_val = nullptr;
-    uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
-    uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // CSR row-block descriptors: interior / halo-touching
-    FusedWindow fw{};                      // plain BiCGStab with the q / p updates formed in the SpMV's window (fw.ncl > 0: available)
-    bool fuse_plain = false;               // ... use it: BICG_FUSE_PLAIN=1. Off by default -- measured (profiles/NOTES.md, round 3): bit-identical
-                                           // to the five-launch iteration but not faster: forming q / p for the ~5.8 x 256 columns a Transport
-                                           // group touches costs the two products more (+12 us each) than the two launches it removes (8 + 7 us);
-                                           // on a narrow band (redundancy 1.06) it is a tie (146.2 vs 145.9 us)
-    int pl_flip = 0;                       // which of the ping-pong pairs (p | w), (s | z) holds the current p and s
-    bool rowsplit = false;                 // long rows: the row blocks go to k_spmv_rows (a row spread over T lanes)
-    short *d_col16 = nullptr;              // ... with CSR-order 16-bit column offsets when they fit
-    uint32_t nblk = 0, n_int = 0, n_bnd = 0;
-    int sell_gpw = 1, sell_gpw_dots = 1;   // 256-row groups per workgroup: plain SpMV / SpMV with fused dots
-    uint32_t sell_blocked = 0;             // the groups are taken plane block by plane block (sell_order_for_big_grids): block size
-    int spmv_dir = 0;                      // direction of the last sliced-ELL product (SpmvArgs::reverse)
-    int sell_alt = 1;                      // BICG_SELL_ALT=0: every product forward; default: consecutive products alternate direction
-    int sell_xcd = 1;                      // BICG_SELL_XCD=0: round robin; default: XCD-contiguous group order (SpmvArgs::xcd_map)
-    int sell_nt_env = -1;                  // BICG_SELL_NT: force (1) / forbid (0) non-temporal matrix loads
-    bool sell_nt = false;                  // decided per solve from the working-set size (run_begin)
-    uint64_t matrix_bytes = 0;             // bytes one SpMV streams from the matrix arrays
-    uint64_t stencil_matrix_bytes = 0;     // ... when the plane-marching product runs (StencilDev)
-    hipEvent_t region_ev[2] = {nullptr, nullptr};   // bicg_run_iterate_timed
-    unsigned *waitlog = nullptr;           // PersistArgs::waitlog (multi-rank persistent launches), 3 rows of kWaitCap samples
-    double t_enq = 0.0;
-    uint64_t device_matrix_bytes = 0;      // bytes of matrix storage resident on the GPU
-    // sliced-ELL copy of the diag block (rows whose 256-row group pads by < 25 %)
-    double *s_val = nullptr;
-    uint32_t *s_col = nullptr, *s_base = nullptr, *s_len = nullptr, *s_base16 = nullptr;
-    short *s_col16 = nullptr;
-    uint32_t *s_ubase = nullptr;           // uniform slices (SellDev::ubase / uoff): BICG_SELL_UNIFORM=0 switches them off
-    int *s_uoff = nullptr;
-    uint64_t uniform_entries = 0;          // sliced-ELL entries whose columns the SpMV does not read
-    uint32_t far_rows = 0;                 // farthest column distance of a uniform slice, in rows (a grid's plane size)
-    uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_SELL_MASKED=0 switches them off
-    unsigned short *s_rmask = nullptr;
-    uint64_t masked_rows = 0;
-    uint32_t plan_collisions = 0;          // list-driven slices the device plan's verification pass put back (bicg_plan_collisions)
-    int *s_uoff8 = nullptr;                // SellDev::uoff8
-    int sell_ystride = 0;                  // SellDev::ystride (BICG_SELL_YGROUP=1; default: consecutive slices per workgroup)
-    bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
-    StencilDev st{};                       // SellDev::st: the plane-marching product of a 7-point grid stencil (BICG_STENCIL=0: off)
-    uint32_t *st_code = nullptr; StencilTab *st_tab = nullptr; unsigned char *st_cmask = nullptr;
-    bool ca_fuse = true;                   // CA-BiCGStab: q, y and their dots in the epilogue of z = A s (plane-marching product only; BICG_CA_FUSE=0)
-    uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
-    uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
-    double *s_uval = nullptr;
-    uint64_t constant_entries = 0;         // ... whose values it does not read either
-    bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
-    uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
-    uint32_t win_max_runs = 0;             // most runs of one group's window
-    uint2 *win_runs = nullptr;
-    unsigned char *sell_perm = nullptr;    // SellDev::perm
-    unsigned short *lane_info = nullptr;   // SellDev::lane_info
-    bool jagw_fast = true;                 // the three-trip product of bicg_jagw.hip (BICG_JAGW=0: k_spmv_sell's loop)
-    uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
-    uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
-    uint64_t sell_entries = 0, sell_nnz = 0;
-    bool glist_int_identity = false;
-    bool glist_all = false;        // every 256-row group is on the sliced-ELL path (one merged launch possible)
-
-    // halo exchange
-    std::vector<int> scnt, sdsp, rcnt, rdsp;
-    uint32_t nsend = 0;
-    uint32_t *send_idx = nullptr;
-    double *sendbuf = nullptr;
-    // peer-to-peer transport (comm->p2p): landing ring for incoming halo values and, per entry of
-    // the send list, where it goes in the ring of the rank that needs it
-    P2p *p2p = nullptr;
-    llword *halo_ring = nullptr;                              // [kHaloRing][halo][2]
-    unsigned long long *push_dst0 = nullptr, *push_stride = nullptr;
-    std::vector<void *> ring_mapped;
-    unsigned halo_seq = 0;          // exchanges started (sequence number of the last one)
-    int halo_unsynced = 0;          // exchanges since the last all-reduce or barrier (flow control)
-    unsigned pend_seq = 0;
-    bool comm_failed = false;       // a peer-to-peer wait timed out (BICG_P2P_SOFT_FAIL)
-    bool soft_fail = false;         // ... report it through comm_failed instead of ending the program (drop-in fallback)
-    // Exchange folded into the SpMV launch (HaloLL): possible when every halo-touching row is on the
-    // sliced-ELL path. One launch covers push + interior + halo-touching groups (listed in that order).
-    bool ll_fused = false;
-    uint32_t *glist_ll = nullptr;
-    bool inline_apply = true;       // BICG_P2P_INLINE_APPLY=0: always use the separate apply kernel
-    int fault_after = 0;            // BICG_P2P_FAULT_AFTER=n (tests): from the n-th exchange on this rank sends nothing
-
-    // vectors and scalars
-    double *slab = nullptr;
-    Vecs v{};
-    Scal *S = nullptr;           // the scalar block kernels enqueued from now on read (= Sbuf + cur)
-    Scal *Sbuf = nullptr;        // two blocks: a kernel that finishes a dot group reads one and writes the other
-    int cur = 0;
-    Scal *hS = nullptr;          // pinned mirror
-    // consumer-side finish of dot groups (struct Finish, bicg_device.h): the four solvers of src/solver.c
-    struct Group {
-        bool active = false;     // produced, not yet consumed
-        bool deferred = false;   // may ride across the next SpMV (pipelined variants, src/solver.c:363-367)
-        bool staged = false;     // an SpMV launch has already summed the shards / pushed the sums to the peers
-        unsigned seq = 0, mail_seq = 0, nparts = 0;
-        int n = 0, off = 0, phase = 0, buf = 0;
-    } grp;
-    bool wave_mode = false;      // this call uses consumer-side finish (run_begin); false: ticket reductions
-    bool spmm_ok = false;        // spmm_possible() on every rank (the SpMM exchanges the halos of all its vectors at once)
-    bool fuse_plan_ok = false;   // every row on the sliced-ELL path and one launch per SpMV -- ON EVERY RANK (the fused and the
-                                 // separate flow exchange their dot groups differently: the choice is collective)
-    bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues (BICG_FUSE_PIPE=0/1 overrides)
-    bool fuse_small = true;      // ... the average block has < 6 M non-zeros: fused whatever the layout
-    int  pipe_probe = 0;         // BICG_PIPE_PROBE=1: the first pipelined solve TIMES both forms on this matrix and keeps the faster
-    bool pipe_probed = false;    // ... done (the choice holds for the life of the context)
-    double probe_ms[2] = {0, 0}; // ... ms per iteration measured for {separate kernels, phases in the SpMV epilogues}
-    bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
-    // persistent pipelined iteration (bicg_persist.hip, struct PersistArgs): plan + LL buffers; persist.nwg == 0: not available
-    PersistArgs persist{};
-    bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0/1 overrides
-    bool persist_plain = true;   // ... and for plain BiCGStab (BICG_PERSIST_PLAIN=0: the five-launch iteration)
-    bool last_shifted_persist = false;   // the last shifted solve ran as persistent launches (bicg_result.flags of bicg_solve_shifted)
-    unsigned persist_seq = 0;    // LL tags used so far (dot tables)
-    unsigned persist_vseq = 0;   // ... by the pipelined kernel's vector images
-    std::vector<void *> persist_mem;
-    unsigned wg_cap = 0;         // ranks sharing this GPU (tests): workgroups per launch that may wait for another rank
-    double *wpart[2] = {nullptr, nullptr};   // per-wavefront partial sums, alternating between groups
-    llword *shard_ll = nullptr;  // 2 x [kShards][kRedSlots][2], alternating like wpart
-    int *alarm = nullptr, *h_alarm = nullptr;
-    unsigned grp_seq = 0;
-    unsigned long long spin_ticks = 2000;   // 20 us before a workgroup sums a missing shard itself (BICG_SPIN_TICKS)
-    double *partial = nullptr, *shard_tot = nullptr;
-    unsigned *counter = nullptr;
-    // tail finish of ticket-mode dot groups (struct Reduce): LL table + shard totals; BICG_TAIL_FINISH=0: arrival tickets
-    llword *tail_tab = nullptr, *tail_shard = nullptr;
-    mutable unsigned tail_seq = 0;
-    bool tail_finish = true;
-    unsigned nslots = 0;
-    double *trace = nullptr;     // 4 * trace_cap
-    int trace_cap = 0;
-    int last_iters = 0;
-
-    hipStream_t sc = nullptr, sm = nullptr;   // compute, communication
-    hipEvent_t ev_pack[kEvRing] = {}, ev_halo[kEvRing] = {}, ev_dots[kEvRing] = {}, ev_red[kEvRing] = {};
-    unsigned i_pack = 0, i_halo = 0, i_dots = 0, i_red = 0;
-
-    // deferred dot group (pipelined variant: all-reduce overlaps the next SpMV)
-    bool pend = false;
-    int pend_n = 0, pend_phase = 0, pend_off = 0;
-    hipEvent_t pend_ev = nullptr;
-
-    // shifted solver (bicg_solve_shifted): per-shift scalar state and the two vector sets
-    double *sw_buf = nullptr;        // seed-switching variants: archives (doubles) followed by the flag arrays
-    size_t sw_cap = 0;
-    ShiftDev *sh_dev = nullptr;
-    double *sh_arrays = nullptr, *p_set = nullptr, *x_set = nullptr;
-    int sh_cap = 0;
-    double cur_shift = 0.0;
-    bool cur_has_shift = false;
-
-    // SpMM (bicg_spmm, bicg_shifted_residuals): kSpmmCols shift-major vectors with halo tails, their row-major
-    // image [rows + halo][kSpmmCols], the row-major result and the per-workgroup column sums
-    double *mm_in = nullptr, *mm_xt = nullptr, *mm_yt = nullptr, *mm_part = nullptr, *mm_out = nullptr, *mm_sigma = nullptr;
-    bool mm_xcd = true;          // XCD-contiguous row groups in the SpMM (BICG_SPMM_XCD=0: round robin like the SpMV)
-    // A rank WITHOUT rows (more ranks than rows, or an empty block of a non-zero balanced partition; the reference's loops simply
-    // run over zero rows there, src/matrix.c:295-298) holds ONE phantom row here -- the 1 x 1 block [1.0], decoupled from every
-    // other row, with x = b = 0: all its vector entries stay 0, it adds 0.0 to every dot sum, sends and receives nothing, and so
-    // takes part in every exchange and every launch path without a zero-row form of any kernel. The caller's vectors are empty:
-    // host reads come from / host writes go to a scratch (host_in / host_out below).
-    bool phantom = false;
-    std::vector<double> ph_scratch;
-    bool mm_win = false;         // the last SpMM pass ran the windowed kernel (vectors stay shift-major, X staged in LDS)
-    int  mm_win_env = 1;         // BICG_SPMM_WIN=0: the row-major kernel
-
-    // state of the solve in progress (run_begin / run_iterate / run_end)
-    bicg_options opt{};
-    int method = 0, it = 0, printed = 0, adaptive_rr = 0;
-    double t_begin = 0.0, t_init = 0.0, t_iter = 0.0;
-
-    // per-SpMV timing
-    bool time_kernels = false;
-    std::vector<hipEvent_t> tev;
-    int tev_used = 0, spmv_calls_timed = 0;
-
-    // section timing (bicg_options.time_kernels & 2): an event on the compute stream wherever the kind of work
-    // changes; the time between two marks belongs to the section the first one opened. The counterpart of the
-    // reference's MEASURE_SECTION_TIME (src/shifted_switching_solver.c:77-81, 132-154, 230-247: MPI_Wtime around the
-    // shift loops, seed = total - shift), on the device's clock instead of the host's.
-    bool time_sections = false, sec_exhausted = false;
-    std::vector<hipEvent_t> sec_ev;
-    std::vector<unsigned char> sec_lab;
-    // finer attribution of a mark (the reference's ten sections, src/shifted_switching_solver.c:678-695): iteration it belongs to,
-    // which product of the iteration (1 / 2), and what inside the product (0 the rows / everything, 1 halo exchange, 2 halo-touching rows)
-    std::vector<int> sec_k;
-    std::vector<unsigned char> sec_sub;
-    int cur_k = 0, cur_prod = 0, cur_sub = 0;
-    bool sec_dump = false;                 // BICG_SECTION_TIME=2: the per-iteration table of DISPLAY_SECTION_TIME
-    double switch_sec = 0.0;               // host time spent in seed switches
-    int sec_used = 0, sec_cur = 255;
-    double sec_ms[4] = {0, 0, 0, 0};
-    int sec_iters = 0;
-
-    // BICG_FORCE_COMM=1 (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
-    // apply kernels, two streams) even with one rank, so that it can be exercised on a one-GPU box
-    bool force_comm = false;
-    bool single() const { return nranks == 1 && !force_comm; }
-
-    // Use the second (communication) stream to overlap the halo exchange with the interior rows and
-    // the pipelined variant's all-reduces with the next SpMV (reference src/matrix.c:432-440,
-    // src/solver.c:363-367). A cross-stream hand-off costs ~7 us each way, the interior SpMV of a
-    // 200 k-row rank only ~6 us, so below ~6 M local non-zeros everything is enqueued in order on
-    // the compute stream instead. BICG_OVERLAP=0/1 overrides.
-    bool overlap = false;
-
-    // hipGraph replay of the iteration body (BICG_GRAPH): one captured iteration per method
-    int graph_mode = -1;                 // -1 auto, 0 off, 1 on
-    hipGraphExec_t graph_exec[4] = {nullptr, nullptr, nullptr, nullptr};
-    int graph_warm[4] = {0, 0, 0, 0};    // eager iterations done since the context was created
-    bool graph_nt[4] = {false, false, false, false};
-    // now_n > 0: the group is closed by group_now(now_n, phase) right after this producer (not
-    // deferred); with the peer-to-peer transport the producer's finishing workgroup then collects
-    // and applies it in-kernel and group_now launches nothing.
-    mutable bool open_inline = false;
-    Reduce red(int off, int phase, bool apply_single = true, int now_n = 0) const
-    {
-        Reduce r{};
-        r.partial = partial; r.shard_tot = shard_tot; r.counter = counter; r.expected = 0; r.slot_base = 0;
-        r.red_off = off; r.phase = phase;
-        r.apply_now = (single() && apply_single) ? 1 : 0;
-        r.p2p = P2pRed{};
-        r.tail_tab = tail_tab; r.tail_shard = tail_shard;
-        // (not under hipGraph replay: a captured launch would meet its own earlier words under the same tag)
-        r.tail_seq = (tail_finish && !p2p && tail_tab && graph_mode != 1) ? ++tail_seq : 0u;
-        if (p2p) {
-            r.p2p = p2p->red_desc(p2p->red_seq);   // the group being produced; closed by group_now/defer
-            if (apply_single && now_n > 0 && inline_apply) {
-                r.apply_now = 1; r.p2p.n_collect = now_n;
-                open_inline = true;
-            }
-        }
-        return r;
-    }
-};
-
-namespace {
-// contexts alive in this process: a context holds pointers into its communicator (transport, peer-to-peer state),
-// so replacing the communicator (bicg_comm_init_*, bicg_comm_finalize) orphans them -- they can still be
-// destroyed, nothing else
-std::vector<bicg_ctx *> g_live;
-
-// host vectors of a rank without rows (bicg_ctx::phantom): `count` zeros to read / a place to write
-const double *host_in(bicg_ctx *c, const double *p, size_t count = 1)
-{
-    if (!c->phantom) return p;
-    c->ph_scratch.assign(std::max<size_t>(count, 1), 0.0);
-    return c->ph_scratch.data();
-}
-double *host_out(bicg_ctx *c, double *p, size_t count = 1)
-{
-    if (!c->phantom || !p) return p;
-    if (c->ph_scratch.size() < count) c->ph_scratch.assign(count, 0.0);
-    return c->ph_scratch.data();
-}
-
-void use_device(const bicg_ctx *c)
-{
-    if (!c->comm)
-        die("bicg_ctx", "the communicator this context was built on has been replaced or finalized; only bicg_destroy is valid now");
-    BICG_HIP(hipSetDevice(c->device));
-}
-}  // namespace
-
-namespace {
 
 // ---------------------------------------------------------------- dot groups: consumer-side finish
 // (the four solvers of reference src/solver.c; struct Finish in bicg_device.h). A group is PRODUCED by
 // one or two kernels (per-wavefront partials), then CONSUMED by the kernel that needs the scalars,
 // by an SpMV that only has to deposit the sums, or by the stand-alone finisher.
 // ---------------------------------------------------------------- section timing
-enum { SEC_VEC = 0, SEC_SPMV = 1, SEC_SHIFT = 2, SEC_REDUCE = 3, SEC_COUNT = 4, SEC_STOP = 255 };
-constexpr int kMaxSectionMarks = 1 << 16;
-
 void sec_mark(bicg_ctx *c, int label)
 {
     if (!c->time_sections || label == c->sec_cur) return;
@@ -367,16 +40,6 @@ void sec_remark(bicg_ctx *c)
     c->sec_cur = -1;
     sec_mark(c, label);
 }
-struct SubSection {    // the enclosed launches are part `sub` of the current product
-    bicg_ctx *c; int prev;
-    SubSection(bicg_ctx *ctx, int sub) : c(ctx), prev(ctx->cur_sub) { c->cur_sub = sub; sec_remark(c); }
-    ~SubSection() { c->cur_sub = prev; sec_remark(c); }
-};
-struct Section {       // the enclosed launches belong to `label`; afterwards the enclosing section continues
-    bicg_ctx *c; int prev;
-    Section(bicg_ctx *ctx, int label) : c(ctx), prev(ctx->sec_cur) { if (prev != SEC_STOP) sec_mark(c, label); }
-    ~Section() { if (prev != SEC_STOP) sec_mark(c, prev); }
-};
 void sec_begin(bicg_ctx *c, bool on)
 {
     c->time_sections = on; c->sec_exhausted = false;
@@ -403,7 +66,7 @@ void sec_collect(bicg_ctx *c, int iters)
     c->sec_iters = iters;
 }
 
-Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg = 0)
+Reduce grp_produce(bicg_ctx *c, int off, int n, int phase, unsigned nwg)
 {
     if (c->grp.active) die("internal", "a dot group was produced while the previous one was still open");
     bicg_ctx::Group &g = c->grp;
@@ -434,7 +97,7 @@ Finish grp_desc(bicg_ctx *c, int roles)
 
 // stand-alone finisher, in place on the current scalar block. local_only: deposit this rank's sums
 // and leave the recurrence to the all-reduce + apply kernel the host enqueues next.
-void grp_close(bicg_ctx *c, bool local_only = false)
+void grp_close(bicg_ctx *c, bool local_only)
 {
     if (!c->grp.active) return;
     Finish f = grp_desc(c, FIN_BLOCK0 | (c->grp.staged ? 0 : FIN_SHARDS | FIN_PUSH) | (local_only ? FIN_LOCAL : 0));
@@ -553,7 +216,7 @@ void group_defer(bicg_ctx *c, int n, int phase)
 }
 
 // one rank, every row on the sliced-ELL path, and the plan found a grid's 7-point stencil (build_stencil_plan)
-static inline bool stencil_product(const bicg_ctx *c)
+bool stencil_product(const bicg_ctx *c)
 {
     return c->st.on && c->single() && c->ng_bnd == 0 && c->nblk == 0 && c->glist_all;      // (whatever order the groups are listed in)
 }
@@ -564,8 +227,8 @@ static inline bool stencil_product(const bicg_ctx *c)
 // blocks that touch the halo run after it has landed. Every row is produced by exactly one
 // workgroup as (0 + sum_diag) + sum_offd, the reference's order.
 // fin: a dot group of earlier kernels that the first kernel launched here finishes (grp_for_spmv).
-void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{}, int epi = 0,
-          Scal *S = nullptr, const FusedWindow *fw = nullptr)
+void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin, int epi,
+          Scal *S, const FusedWindow *fw)
 {
     Section sec(c, SEC_SPMV);      // halo exchange and the joins of deferred all-reduces included
     SpmvArgs a;
@@ -751,7 +414,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 
 // SpMV of the pipelined solvers (consumer-side finish): a deferred group of earlier kernels is staged
 // by this launch; the SpMV's own dots (ndot > 0) open the next group.
-void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int phase = PH_NONE)
+void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, int phase)
 {
     const Finish fin = grp_for_spmv(c);
     Reduce red{};
@@ -875,176 +538,7 @@ void group_flush(bicg_ctx *c)
 }
 
 void fetch_scal(bicg_ctx *c);
-}  // namespace
-// One descriptor per slice (SellDev::sdesc) from the per-slice arrays of the plan: blocks with list-driven slices only
-static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const std::vector<uint4> &d, const std::vector<int> &uoff,
-                               const std::vector<double> &uval, const unsigned short *rmask_host);
-static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const uint32_t *slice_len, const std::vector<uint32_t> &ubase,
-                             const std::vector<uint32_t> &vbase, const std::vector<uint32_t> &mbase, const std::vector<int> &uoff,
-                             const std::vector<double> &uval, const unsigned short *rmask_host)
-{
-    if (vbase.empty() || ubase.empty() || (uint64_t)nrows >= (1ull << 29)) return;
-    if (getenv("BICG_SELL_DESC") && atoi(getenv("BICG_SELL_DESC")) == 0) return;
-    std::vector<uint4> d(nslices);
-    bool all_lists = !(getenv("BICG_SELL_LISTS") && atoi(getenv("BICG_SELL_LISTS")) == 0) && nrows % kGroupRows == 0;
-    for (uint32_t sl = 0; sl < nslices; ++sl) {
-        const uint32_t ub = ubase[sl], vb = vbase[sl], mb = mbase.empty() ? 0xFFFFFFFFu : mbase[sl];
-        uint32_t len = slice_len[sl] & 0xFFFFu, kind = kSliceGeneral, w = 0;
-        if (ub != 0xFFFFFFFFu && slice_len[sl] <= 0xFFFFu) {
-            kind = kSliceUniform;
-            if (vb != 0xFFFFFFFFu) {
-                kind = kSliceConstant;
-                if (mb != 0xFFFFFFFFu) { kind = kSliceMasked; len = mb >> 26; w = mb & 0x03FFFFFFu; }
-            }
-        }
-        d[sl] = make_uint4(len | (kind << 16), kind >= kSliceConstant ? ub : 0u, kind >= kSliceConstant ? vb : 0u, w);
-        if ((uint64_t)sl * kSliceRows < nrows && (kind < kSliceConstant || len == 0 || len > 8u)) all_lists = false;
-    }
-    if (all_lists) {                              // (SellDev::all_lists: the distances once more, as byte offsets)
-        std::vector<int> u8(uoff.size());
-        for (size_t i = 0; i < uoff.size(); ++i) u8[i] = (int)((uint32_t)uoff[i] * 8u);      // (modulo 2^32: the product adds it to the row's byte offset modulo 2^32)
-        c->s_uoff8 = dev_upload(u8.data(), u8.size());
-        c->sell_all_lists = true;
-        // SellDev::ystride from the longest list (the interior's): its second-largest distance is a grid line when it is a multiple
-        // of 64 rows. (Only the speed depends on the guess: any value gives every slice to exactly one wavefront.)
-        uint32_t best_len = 0, best_at = 0;
-        for (uint32_t sl = 0; sl < nslices; ++sl) { const uint32_t l = d[sl].x & 0xFFFFu; if ((d[sl].x >> 16) == kSliceConstant && l > best_len) { best_len = l; best_at = d[sl].y; } }
-        // (measured, 512^3: 0.923 against 0.929 ms per product, 256^3 0.146 against 0.123 ms -- off unless BICG_SELL_YGROUP=1)
-        if (best_len >= 5 && knob_x("BICG_SELL_YGROUP") && atoi(knob_x("BICG_SELL_YGROUP")) != 0) {
-            std::vector<int> dist(uoff.begin() + best_at, uoff.begin() + best_at + best_len);
-            std::sort(dist.begin(), dist.end());
-            const int line = dist[best_len - 2];
-            const uint32_t S = line > 0 ? (uint32_t)line / kSliceRows : 0u;
-            if (S >= 1 && (uint32_t)line % kSliceRows == 0 && (S & (S - 1u)) == 0 && nslices % (4u * S) == 0) c->sell_ystride = (int)S;   // (a power of two: shifts in the kernel)
-        }
-    }
-    c->s_desc = dev_upload(d.data(), d.size());
-    c->matrix_bytes += 8ull * nslices;          // 16 bytes of descriptor per slice where base + length were counted
-    if (all_lists) build_stencil_plan(c, nslices, nrows, d, uoff, uval, rmask_host);
-}
 
-// The plane-marching product (struct StencilDev, bicg_stencil.hip): is this block the 7-point stencil of a grid? Decided from the
-// lists alone -- the interior's list must be (-sz, -sy, -1, 0, +1, +sy, +sz) with sy a multiple of 64 rows, sz a multiple of sy,
-// the rows a multiple of sz, and every other list a sub-sequence of it in the same order. Values may differ from list to list
-// (every (distance list, value list) pair gets a table entry); rows of masked slices get their entries as canonical bits.
-static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const std::vector<uint4> &d, const std::vector<int> &uoff,
-                               const std::vector<double> &uval, const unsigned short *rmask_host)
-{
-    if (getenv("BICG_STENCIL") && atoi(getenv("BICG_STENCIL")) == 0) return;
-    uint32_t best_at = 0, best_len = 0;
-    // the interior's list: the longest one, of a constant slice or (a grid one x segment wide has no other) of a masked one
-    for (uint32_t sl = 0; sl < nslices; ++sl) { const uint32_t l = d[sl].x & 0xFFFFu; if ((d[sl].x >> 16) >= kSliceConstant && l > best_len) { best_len = l; best_at = d[sl].y; } }
-    if (best_len != 7) return;
-    const int *L = uoff.data() + best_at;
-    if (!(L[3] == 0 && L[2] == -1 && L[4] == 1 && L[5] > 1 && L[6] > L[5] && L[1] == -L[5] && L[0] == -L[6])) return;
-    const uint32_t sy = (uint32_t)L[5], sz = (uint32_t)L[6];
-    if (sy % kSliceRows || sz % sy || nrows % sz || sy / kSliceRows > 64u) return;
-    const uint32_t nxs = sy / kSliceRows, ny = sz / sy, nz = nrows / sz;
-    if (ny % 2u) return;
-    const int canon[7] = {-(int)sz, -(int)sy, -1, 0, 1, (int)sy, (int)sz};
-    struct Entry { StencilTab t; signed char pos[8]; };
-    std::map<std::tuple<uint32_t, uint32_t, uint32_t>, uint32_t> pairs;
-    std::vector<Entry> entries;
-    std::vector<uint32_t> code(nslices), which(nslices);
-    unsigned long long mcols = 0;
-    for (uint32_t sl = 0; sl < nslices; ++sl) {
-        const uint32_t kind = d[sl].x >> 16, len = d[sl].x & 0xFFFFu;
-        const auto key = std::make_tuple(d[sl].y, d[sl].z, len);
-        auto it = pairs.find(key);
-        if (it == pairs.end()) {
-            if (entries.size() >= 65536u) return;
-            Entry e;
-            memset(&e, 0, sizeof e);
-            int cpos = -1;
-            for (uint32_t k = 0; k < len; ++k) {
-                int at = -1;
-                for (int q = cpos + 1; q < 7; ++q) if (canon[q] == uoff[d[sl].y + k]) { at = q; break; }
-                if (at < 0) return;                                   // a distance the grid does not have, or out of order: not this product
-                cpos = at;
-                e.t.v[at] = uval[d[sl].z + k];
-                e.t.bits |= 1ull << at;
-                e.pos[k] = (signed char)at;
-            }
-            it = pairs.emplace(key, (uint32_t)entries.size()).first;
-            entries.push_back(e);
-        }
-        const uint32_t xs = sl % nxs, line = sl / nxs, yy = line % ny, zz = line / ny;
-        which[sl] = it->second;
-        code[((size_t)zz * nxs + xs) * ny + yy] = it->second;
-        if (kind == kSliceMasked) mcols |= 1ull << xs;
-    }
-    const uint32_t nmc = (uint32_t)__builtin_popcountll(mcols);
-    std::vector<unsigned char> cmask;
-    if (nmc) {
-        std::vector<unsigned short> rm_dl;
-        if (!rmask_host) {                                            // the device plan wrote the rows' masks on the GPU
-            uint32_t top = 0;
-            for (uint32_t sl = 0; sl < nslices; ++sl) if ((d[sl].x >> 16) == kSliceMasked) top = std::max(top, d[sl].w + 1u);
-            rm_dl.resize((size_t)top * kSliceRows);
-            BICG_HIP(hipMemcpy(rm_dl.data(), c->s_rmask, sizeof(unsigned short) * rm_dl.size(), hipMemcpyDeviceToHost));
-            rmask_host = rm_dl.data();
-        }
-        cmask.assign((size_t)(nslices / nxs) * nmc * kSliceRows, 0);
-        parallel_ranges(nslices, 4096, [&](size_t s0, size_t s1, int) {
-            for (size_t sl = s0; sl < s1; ++sl) {
-                const uint32_t xs = (uint32_t)(sl % nxs);
-                if (!((mcols >> xs) & 1ull)) continue;
-                const uint32_t dense = (uint32_t)__builtin_popcountll(mcols & ((1ull << xs) - 1ull));
-                unsigned char *out = cmask.data() + ((sl / nxs) * nmc + dense) * kSliceRows;
-                const Entry &e = entries[which[sl]];
-                if ((d[sl].x >> 16) == kSliceMasked) {
-                    const unsigned short *pm = rmask_host + (size_t)d[sl].w * kSliceRows;
-                    const uint32_t len = d[sl].x & 0xFFFFu;
-                    for (uint32_t l = 0; l < kSliceRows; ++l) {
-                        unsigned bits = 0;
-                        for (uint32_t k = 0; k < len; ++k) if ((pm[l] >> k) & 1u) bits |= 1u << e.pos[k];
-                        out[l] = (unsigned char)bits;
-                    }
-                } else {
-                    for (uint32_t l = 0; l < kSliceRows; ++l) out[l] = (unsigned char)e.t.bits;
-                }
-            }
-        });
-    }
-    std::vector<StencilTab> tab(entries.size());
-    for (size_t i = 0; i < entries.size(); ++i) tab[i] = entries[i].t;
-    // lines per wavefront and planes per tile: enough workgroups for several rounds of the 1024 a GPU holds, tiles as deep as that allows
-    uint32_t lines = 0, zl = 0;
-    {
-        static const uint32_t cand[][2] = {{4, 32}, {4, 16}, {2, 32}, {2, 16}, {4, 8}, {2, 8}, {2, 4}};
-        uint64_t most = 0;
-        for (auto &cd : cand) {
-            if (ny % cd[0]) continue;
-            const uint64_t wgs = (uint64_t)nxs * ((ny + 4 * cd[0] - 1) / (4 * cd[0])) * ((nz + cd[1] - 1) / cd[1]);
-            if (wgs >= 3000) { lines = cd[0]; zl = cd[1]; break; }
-            if (wgs > most) { most = wgs; lines = cd[0]; zl = cd[1]; }
-        }
-        if (const char *v = getenv("BICG_STENCIL_LINES")) { const uint32_t r = (uint32_t)atoi(v); if ((r == 2 || r == 4) && ny % r == 0) lines = r; }
-        if (const char *v = getenv("BICG_STENCIL_ZL")) { const int z = atoi(v); if (z >= 1) zl = (uint32_t)z; }
-    }
-    c->st_code = dev_upload(code.data(), code.size());
-    c->st_tab = dev_upload(tab.data(), tab.size());
-    if (nmc) c->st_cmask = dev_upload(cmask.data(), cmask.size());
-    // Input + output vector far beyond the 256 MiB Infinity Cache (512^3: 2 x 1 GiB): y is stored non-temporally and the tiles go to
-    // the XCDs round-robin (product 0.480 -> 0.460 ms, CA-BiCGStab 5.40 -> 5.31 ms per iteration); a grid whose vectors the cache
-    // holds (256^3) keeps ordinary stores and the XCD-contiguous order (0.053 against 0.061 ms): profiles/r05/stencil_sweep_xcd_nt.txt
-    const bool st_big = 16.0 * (double)nrows > 2.0 * 256.0 * 1048576.0;
-    const int st_xcd = knob_x("BICG_STENCIL_XCD") ? atoi(knob_x("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
-    const int st_nt = knob_x("BICG_STENCIL_NT") ? atoi(knob_x("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
-    c->st = StencilDev{1, sy, sz, nxs, ny, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
-    if (const char *v = getenv("BICG_CA_FUSE")) c->ca_fuse = atoi(v) != 0;
-    // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
-    c->stencil_matrix_bytes = 4ull * nslices + (uint64_t)cmask.size();
-    if (getenv("BICG_PLAN_TRACE"))
-        fprintf(stderr, "bicgstab_hip: plane-marching product: %u x %u x %u grid (x segments of 64 rows: %u), %zu list pairs, %u masked x segments, %u lines x %u planes per wavefront, %u workgroups\n",
-                sy, ny, nz, nxs, tab.size(), nmc, lines, zl, stencil_grid(c->st));
-}
-
-void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups);
-bool persist_chunk(bicg_ctx *c, int niter);
-bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, int seed, double shift);
-void persist_account(bicg_ctx *c);
-namespace {
 
 // ---------------------------------------------------------------- the four iterations
 struct Driver {
@@ -1550,2287 +1044,3 @@ int run_solver(bicg_ctx *c, int method, const bicg_options *opt_in, bicg_result 
     return run_end(c, res);
 }
 
-// ---------------------------------------------------------------- shifted BiCGStab
-// (A + sigma_j I) x_j = b for all j from ONE Krylov recurrence on the seed system: 2 SpMV per
-// iteration whatever the number of shifts (reference src/shifted_solver.c:182-354). Per iteration:
-// SpMV(+sigma_seed) with (r#,s) | q, r_old | SpMV(+sigma_seed) with (q,y),(q,q) | ONE batched kernel
-// over all shifts (x_seed, r, every p_j and x_j, two dots) | p_seed.  The per-shift scalar
-// recurrences (beta_j, pi_j, eta_j, alpha_j, omega_j, zeta_j) run on the device, one thread per shift.
-// shifted_lopbicg / shifted_lopbicg_switching (+_noovlp), reference src/shifted_switching_solver.c.
-// Per iteration: SpMV (+alpha) ; q ; SpMV (+omega) ; seed update with the (r,r), (r#,r) dots (+beta
-// and every active shift's coefficients) ; ONE batched kernel over all shifts ; a one-workgroup
-// kernel for the stop flags. A seed switch needs new vector pointers and a rescaled r from the
-// host, so the device raises done/paused, the launches already queued fall through, and the host
-// resumes with the new seed (switches are rare: at most one per shift).
-// "Seed time" / "Shift time" as the reference prints them under MEASURE_SECTION_TIME (src/shifted_solver.c:244-247,
-// src/shifted_switching_solver.c:563-...): shift = the passes over the shifted systems, seed = total - shift
-void print_sections(const bicg_ctx *c, double total_seconds)
-{
-    if (c->sec_used == 0) return;
-    const double shift = c->sec_ms[SEC_SHIFT] * 1.0e-3;
-    printf("Seed time    : %e [sec.]\n", total_seconds - shift);
-    printf("Shift time   : %e [sec.]\n", shift);
-}
-
-// BICG_SECTION_TIME=2 (bicg_options.time_kernels & 4) on the switching solvers: the reference's DISPLAY_SECTION_TIME table
-// (src/shifted_switching_solver.c:884-892: one line per iteration) and the ten totals it prints at the end (:994-1005), on the
-// device clock. Mapping: agv = halo pack + exchange (host / RCCL transports; with the peer-to-peer path the exchange is inside the
-// product's launch and shows under mult_diag), mult_diag = the rows without halo entries (one rank: every row), mult_offd = the
-// halo-touching rows (their diag AND offd part: one kernel), ared = the hand-over of the dot groups, shift = the batched pass
-// over the shifted systems, seed = everything of the iteration except shift, switch = host time spent in seed switches.
-void print_section_table(bicg_ctx *c, int its, int nsig, const int *unsolved, double total_seconds)
-{
-    if (c->sec_used == 0 || its <= 0) return;
-    enum { AGV1, DIAG1, OFFD1, AGV2, DIAG2, OFFD2, ARED, SHIFT, SEED, NCOL };
-    std::vector<double> t((size_t)(its + 1) * NCOL, 0.0);
-    for (int i = 0; i + 1 < c->sec_used; ++i) {
-        if (c->sec_lab[i] == SEC_STOP) continue;
-        float ms = 0.f;
-        if (hipEventElapsedTime(&ms, c->sec_ev[i], c->sec_ev[i + 1]) != hipSuccess) continue;
-        const int k = std::min(std::max(c->sec_k[i], 0), its), prod = c->sec_sub[i] >> 4, sub = c->sec_sub[i] & 15;
-        double *row = t.data() + (size_t)k * NCOL;
-        const double sec = 1.0e-3 * ms;
-        if (c->sec_lab[i] == SEC_SHIFT) { row[SHIFT] += sec; continue; }
-        row[SEED] += sec;
-        if (c->sec_lab[i] == SEC_REDUCE) row[ARED] += sec;
-        else if (c->sec_lab[i] == SEC_SPMV && (prod == 1 || prod == 2)) row[(prod == 1 ? AGV1 : AGV2) + (sub == 1 ? 0 : sub == 2 ? 2 : 1)] += sec;
-    }
-    printf("iter, unsolved, seed, agv_1, mult_diag_1, mult_offd_1, agv_2, mult_diag_2, mult_offd_2, ared, shift\n");
-    double tot[NCOL] = {0};
-    for (int k = 1; k <= its; ++k) {
-        const double *r = t.data() + (size_t)k * NCOL;
-        printf("%d, %d, %e, %e, %e, %e, %e, %e, %e, %e, %e\n", k, unsolved ? unsolved[k] : nsig, r[SEED], r[AGV1], r[DIAG1], r[OFFD1], r[AGV2], r[DIAG2],
-               r[OFFD2], r[ARED], r[SHIFT]);
-        for (int q = 0; q < NCOL; ++q) tot[q] += r[q];
-    }
-    printf("Seed time    : %e [sec.]\n", total_seconds - tot[SHIFT] - c->switch_sec);
-    printf(" 1 Agv time   : %e [sec.]\n", tot[AGV1]);
-    printf(" 1 Mult_diag  : %e [sec.]\n", tot[DIAG1]);
-    printf(" 1 Mult_offd  : %e [sec.]\n", tot[OFFD1]);
-    printf(" 2 Agv time   : %e [sec.]\n", tot[AGV2]);
-    printf(" 2 Mult_diag  : %e [sec.]\n", tot[DIAG2]);
-    printf(" 2 Mult_offd  : %e [sec.]\n", tot[OFFD2]);
-    printf(" Ared time    : %e [sec.]\n", tot[ARED]);
-    printf("Shift time   : %e [sec.]\n", tot[SHIFT]);
-    printf("Switch time  : %e [sec.]\n", c->switch_sec);
-}
-
-int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
-                  const bicg_options *opt_in, bicg_result *res)
-{
-    std::vector<double> ph_x, ph_r;      // a rank without rows: the caller's vectors are empty (bicg_ctx::phantom)
-    if (c->phantom && nsig > 0) { ph_x.assign((size_t)nsig, 0.0); ph_r.assign(1, 0.0); x_set_host = ph_x.data(); r_host = ph_r.data(); }
-    bicg_options o;
-    if (opt_in) o = *opt_in; else { bicg_default_options(&o); o.tol = 1.0e-12; }   // EPS of src/shifted_switching_solver.c:5
-    if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
-    if (o.max_iter < 0) o.max_iter = 0;
-    if (o.check_every < 1) o.check_every = 1;
-    use_device(c);
-    c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
-    c->spmv_dir = 0;                     // same first direction for every solve on this context (see run_begin)
-    const size_t st = c->stride, n = c->n_loc;
-
-    if (c->sh_cap < nsig) {
-        for (void *p : {(void *)c->sh_dev, (void *)c->sh_arrays, (void *)c->p_set, (void *)c->x_set}) if (p) BICG_HIP(hipFree(p));
-        c->sh_dev = dev_alloc<ShiftDev>(1);
-        c->sh_arrays = dev_alloc<double>(12 * (size_t)nsig);
-        c->p_set = dev_alloc<double>((size_t)nsig * st);
-        c->x_set = dev_alloc<double>((size_t)nsig * st);
-        c->sh_cap = nsig;
-    }
-    const int L = o.max_iter + 2;                                    // archive entries 0 .. max_iter + 1
-    const size_t nd = 3 * (size_t)L + (size_t)nsig * L, ni = 2 * (size_t)nsig + (size_t)L;     // (+ the systems still running, per iteration)
-    const size_t need = nd * sizeof(double) + ni * sizeof(int);
-    if (c->sw_cap < need) {
-        if (c->sw_buf) BICG_HIP(hipFree(c->sw_buf));
-        BICG_HIP(hipMalloc((void **)&c->sw_buf, need));
-        c->sw_cap = need;
-    }
-    ShiftDev h;
-    memset(&h, 0, sizeof h);
-    h.nsig = nsig; h.seed = seed; h.mode = mode; h.arc_len = L;
-    double **arr[12] = {&h.sigma, &h.alpha, &h.beta, &h.omega, &h.eta, &h.zeta, &h.pi_old, &h.pi_new, &h.cp, &h.cx, &h.c1, &h.c2};
-    for (int i = 0; i < 12; ++i) *arr[i] = c->sh_arrays + (size_t)i * nsig;
-    h.a_arc = c->sw_buf; h.b_arc = h.a_arc + L; h.w_arc = h.b_arc + L; h.pi_arc = h.w_arc + L;
-    h.stop = (int *)(c->sw_buf + nd); h.skip = h.stop + nsig; h.unsolved_arc = h.skip + nsig;
-    BICG_HIP(hipMemcpy(c->sh_dev, &h, sizeof h, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemset(c->sh_arrays, 0, sizeof(double) * 12 * (size_t)nsig));
-    BICG_HIP(hipMemset(c->sw_buf, 0, need));
-    BICG_HIP(hipMemcpy(h.sigma, sigma, sizeof(double) * nsig, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemset(c->p_set, 0, sizeof(double) * (size_t)nsig * st));
-    BICG_HIP(hipMemset(c->x_set, 0, sizeof(double) * (size_t)nsig * st));
-    for (int j = 0; j < nsig; ++j)
-        BICG_HIP(hipMemcpy(c->x_set + (size_t)j * st, x_set_host + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemcpy(c->v.r, r_host, sizeof(double) * n, hipMemcpyHostToDevice));
-    BICG_HIP(hipDeviceSynchronize());
-
-    if (c->trace_cap < o.max_iter) {
-        if (c->trace) BICG_HIP(hipFree(c->trace));
-        c->trace_cap = o.max_iter > 0 ? o.max_iter : 1;
-        c->trace = dev_alloc<double>(4 * (size_t)c->trace_cap);
-    }
-    Scal hs;
-    memset(&hs, 0, sizeof hs);
-    hs.tol2 = o.tol * o.tol; hs.max_iter = o.max_iter;
-    hs.tr_alpha = c->trace; hs.tr_omega = c->trace + c->trace_cap;
-    hs.tr_beta = c->trace + 2 * (size_t)c->trace_cap; hs.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
-    hs.sh = c->sh_dev;
-    BICG_HIP(hipMemcpyAsync(c->S, &hs, sizeof hs, hipMemcpyHostToDevice, c->sc));
-    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
-    BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
-    c->time_kernels = false;
-    sec_begin(c, (o.time_kernels & 2) != 0); c->sec_dump = (o.time_kernels & 4) != 0;
-    for (int j = 0; j < nsig; ++j)          // p[sigma] <- b for EVERY shift, src/shifted_switching_solver.c:348
-        BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
-    {   // streaming policy: matrix + 7 work vectors + the two sets
-        const double ws = (double)c->matrix_bytes + 8.0 * st * (7 + 2.0 * nsig);
-        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
-        if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
-    }
-    BICG_HIP(hipStreamSynchronize(c->sc));
-
-    Vecs &v = c->v;
-    double *qc = v.z;                               // q_copy (:394)
-    const double t0 = now_sec();
-    c->cur_has_shift = false;
-    launch_shift_init(v, c->p_set + (size_t)seed * st, c->S, c->red(0, PH_SW_INIT, true, 1), c->sc);   // r# = r, (r,r)
-    group_now(c, 1, PH_SW_INIT);
-    c->cur_has_shift = true;
-    int switches = 0;
-    for (;;) {
-        fetch_scal(c);
-        if (c->hS->paused) {                        // a seed switch happened at the end of iteration hS->k
-            const double t_sw = now_sec();
-            ShiftDev now;
-            BICG_HIP(hipMemcpy(&now, c->sh_dev, sizeof now, hipMemcpyDeviceToHost));
-            launch_scale(v.r, (uint32_t)n, now.r_scale, c->sc);                       // (:499)
-            seed = now.seed;
-            ++switches;
-            const bool finished = c->hS->paused == 2;
-            // the reference's line at every switch (src/shifted_switching_solver.c:526; its k counts from 1). Its per-shift
-            // "sigma[j] eta: ..." debug lines (:522) are not reproduced.
-            if (c->rank == 0 && !o.quiet && !finished)
-                printf("k: %d, seed: %d, remain: %d\n", c->hS->k + 1, seed, nsig - now.stop_count);
-            const int zero2[2] = {0, 0};
-            if (!finished) BICG_HIP(hipMemcpyAsync(&c->S->done, &zero2[0], sizeof(int), hipMemcpyHostToDevice, c->sc));
-            BICG_HIP(hipMemcpyAsync(&c->S->paused, &zero2[1], sizeof(int), hipMemcpyHostToDevice, c->sc));
-            BICG_HIP(hipStreamSynchronize(c->sc));
-            c->switch_sec += now_sec() - t_sw;      // the reference's switch_time (src/shifted_switching_solver.c:488-530)
-            if (finished) { c->hS->paused = 0; break; }
-            continue;
-        }
-        if (c->hS->done || c->hS->k >= o.max_iter) break;
-        double *p_seed = c->p_set + (size_t)seed * st, *x_seed = c->x_set + (size_t)seed * st;
-        c->cur_shift = sigma[seed];
-        const int chunk = std::min(o.check_every, o.max_iter - c->hS->k);
-        sec_mark(c, SEC_VEC);
-        for (int j = 0; j < chunk; ++j) {
-            c->cur_k = c->hS->k + j + 1; c->cur_prod = 1; sec_remark(c);
-            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SW_ALPHA, true, 1));           // s = (A + sigma I) p[seed], (r#,s)
-            group_now(c, 1, PH_SW_ALPHA);
-            launch_sw_q(v, qc, c->S, c->sc);                                          // r_old, q
-            c->cur_prod = 2;
-            spmv(c, v.r, v.y, 3, v.r, c->red(0, PH_SW_OMEGA, true, 2));               // y = (A + sigma I) q, (q,y), (q,q)
-            c->cur_prod = 0;
-            group_now(c, 2, PH_SW_OMEGA);
-            launch_sw_seed(v, x_seed, p_seed, c->S, c->red(0, PH_SW_END, true, 2), c->sc);   // x[seed], r, (r,r), (r#,r)
-            group_now(c, 2, PH_SW_END);
-            {
-                Section sec(c, SEC_SHIFT);       // the shift loops of src/shifted_switching_solver.c:425-480
-                launch_sw_shifts(v, qc, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->sc);
-            }
-            launch_apply(c->S, PH_SW_STOP, c->sc);                                    // identical on every rank: no sums
-        }
-        sec_mark(c, SEC_STOP);
-    }
-    c->cur_has_shift = false; c->cur_shift = 0.0;
-    const double t1 = now_sec();
-
-    const int its = c->hS->k;
-    c->last_iters = its;
-    sec_collect(c, its);
-    for (int j = 0; j < nsig; ++j)
-        BICG_HIP(hipMemcpy(x_set_host + (size_t)j * n, c->x_set + (size_t)j * st, sizeof(double) * n, hipMemcpyDeviceToHost));
-    BICG_HIP(hipMemcpy(r_host, c->v.r, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (res) {
-        memset(res, 0, sizeof *res);
-        res->iterations = its; res->dot_r = c->hS->dot_r; res->dot_zero = c->hS->dot_zero;
-        res->seconds = t1 - t0; res->iter_seconds = t1 - t0;
-        res->breakdown_iteration = c->hS->breakdown_k;
-        res->adaptive_replacements = switches;      // reused: number of seed switches
-    }
-    const int k_ref = mode == SH_SWITCH ? its + 1 : its;   // the switching variants count from 1 (:295, 536)
-    if (c->rank == 0 && !o.quiet) {   // reference src/shifted_switching_solver.c:228-233 / :556-560
-        if (mode == SH_SWITCH) printf("Total iter   : %d\n", k_ref - 1);
-        printf("Total time   : %e [sec.] \n", t1 - t0);
-        printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / (k_ref > 0 ? k_ref : 1));
-        if (c->sec_dump && c->sec_used > 0) {
-            std::vector<int> unsolved((size_t)L, nsig);
-            BICG_HIP(hipMemcpy(unsolved.data(), h.unsolved_arc, sizeof(int) * (size_t)L, hipMemcpyDeviceToHost));
-            print_section_table(c, its, nsig, unsolved.data(), t1 - t0);
-        } else {
-            print_sections(c, t1 - t0);
-            if (c->sec_used > 0 && mode == SH_SWITCH) printf("Switch time  : %e [sec.]\n", c->switch_sec);      // (src/shifted_switching_solver.c:566)
-        }
-        fflush(stdout);
-    }
-    return k_ref;
-}
-
-int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const double *sigma, int nsig, int seed,
-                const bicg_options *opt_in, bicg_result *res)
-{
-    std::vector<double> ph_x, ph_r;      // a rank without rows: the caller's vectors are empty (bicg_ctx::phantom)
-    if (c->phantom && nsig > 0) { ph_x.assign((size_t)nsig, 0.0); ph_r.assign(1, 0.0); x_set_host = ph_x.data(); r_host = ph_r.data(); }
-    if (mode == SH_FLAG || mode == SH_SWITCH) return run_switching(c, mode, x_set_host, r_host, sigma, nsig, seed, opt_in, res);
-    if (mode < SH_LOP || mode > SH_XI) die("bicg_solve_shifted", "unknown variant");
-    if (mode == SH_XI) seed = 0;          // shifted_bicgstab: the seed system is A itself, shift index 0
-    bicg_options o;
-    if (opt_in) o = *opt_in; else { bicg_default_options(&o); o.tol = 1.0e-12; }   // EPS of src/shifted_solver.c:5
-    if (nsig < 1 || seed < 0 || seed >= nsig) die("bicg_solve_shifted", "seed outside the shift list");
-    if (o.max_iter < 0) o.max_iter = 0;
-    if (o.check_every < 1) o.check_every = 1;
-    use_device(c);
-    c->wave_mode = false;                // the shifted solvers keep the ticket reductions (scalars applied in place)
-    c->spmv_dir = 0;                     // same first direction for every solve on this context (see run_begin)
-    const size_t st = c->stride, n = c->n_loc;
-
-    if (c->sh_cap < nsig) {
-        for (void *p : {(void *)c->sh_dev, (void *)c->sh_arrays, (void *)c->p_set, (void *)c->x_set}) if (p) BICG_HIP(hipFree(p));
-        c->sh_dev = dev_alloc<ShiftDev>(1);
-        c->sh_arrays = dev_alloc<double>(12 * (size_t)nsig);
-        c->p_set = dev_alloc<double>((size_t)nsig * st);
-        c->x_set = dev_alloc<double>((size_t)nsig * st);
-        c->sh_cap = nsig;
-    }
-    ShiftDev h;
-    memset(&h, 0, sizeof h);
-    h.nsig = nsig; h.seed = seed; h.mode = mode;
-    double **arr[12] = {&h.sigma, &h.alpha, &h.beta, &h.omega, &h.eta, &h.zeta, &h.pi_old, &h.pi_new, &h.cp, &h.cx, &h.c1, &h.c2};
-    for (int i = 0; i < 12; ++i) *arr[i] = c->sh_arrays + (size_t)i * nsig;
-    BICG_HIP(hipMemcpy(c->sh_dev, &h, sizeof h, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemset(c->sh_arrays, 0, sizeof(double) * 12 * (size_t)nsig));
-    BICG_HIP(hipMemcpy(h.sigma, sigma, sizeof(double) * nsig, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemset(c->p_set, 0, sizeof(double) * (size_t)nsig * st));        // calloc, src/shifted_solver.c:223
-    BICG_HIP(hipMemset(c->x_set, 0, sizeof(double) * (size_t)nsig * st));
-    for (int j = 0; j < nsig; ++j)
-        BICG_HIP(hipMemcpy(c->x_set + (size_t)j * st, x_set_host + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemcpy(c->v.r, r_host, sizeof(double) * n, hipMemcpyHostToDevice));
-    BICG_HIP(hipDeviceSynchronize());       // the memsets above ran on the null stream; sc does not wait for it
-
-    if (c->trace_cap < o.max_iter) {
-        if (c->trace) BICG_HIP(hipFree(c->trace));
-        c->trace_cap = o.max_iter > 0 ? o.max_iter : 1;
-        c->trace = dev_alloc<double>(4 * (size_t)c->trace_cap);
-    }
-    Scal hs;
-    memset(&hs, 0, sizeof hs);
-    hs.tol2 = o.tol * o.tol; hs.max_iter = o.max_iter;
-    hs.tr_alpha = c->trace; hs.tr_omega = c->trace + c->trace_cap;
-    hs.tr_beta = c->trace + 2 * (size_t)c->trace_cap; hs.tr_dotr = c->trace + 3 * (size_t)c->trace_cap;
-    hs.sh = c->sh_dev;
-    BICG_HIP(hipMemcpyAsync(c->S, &hs, sizeof hs, hipMemcpyHostToDevice, c->sc));
-    BICG_HIP(hipMemsetAsync(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride, c->sc));
-    BICG_HIP(hipMemsetAsync(c->slab + 2 * st, 0, sizeof(double) * 10 * st, c->sc));
-    c->time_kernels = false;
-    sec_begin(c, (o.time_kernels & 2) != 0); c->sec_dump = (o.time_kernels & 4) != 0;
-    if (mode == SH_XI)                      // p[sigma] <- b for every shift, src/shifted_solver.c:72
-        for (int j = 0; j < nsig; ++j)
-            BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
-    {   // streaming policy: matrix + 6 work vectors + the two sets
-        const double ws = (double)c->matrix_bytes + 8.0 * st * ((mode == SH_PIPE ? 10 : 6) + 2.0 * nsig);
-        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
-        if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
-    }
-    BICG_HIP(hipStreamSynchronize(c->sc));
-
-    double *p_seed = c->p_set + (size_t)seed * st;
-    Vecs &v = c->v;
-    const bool shifted_A = mode != SH_XI;       // lop / pipe iterate on A + sigma[seed] I, shifted_bicgstab on A
-    const double t0 = now_sec();
-    c->cur_has_shift = false;
-    launch_shift_init(v, p_seed, c->S, c->red(0, PH_SH_INIT, true, 1), c->sc);
-    group_now(c, 1, PH_SH_INIT);
-    c->cur_shift = sigma[seed]; c->cur_has_shift = shifted_A;
-    if (mode == SH_PIPE) {                                                   // src/shifted_solver.c:764-769, 785-786
-        spmv(c, v.r, v.w, 1, v.r, c->red(0, PH_SHP_INIT_ALPHA));             // w = (A + sigma I) r, (r,w)
-        group_defer(c, 1, PH_SHP_INIT_ALPHA);
-        spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));                   // t = (A + sigma I) w
-        group_flush(c);
-    }
-    fetch_scal(c);
-    int it = 0;
-    // latency-bound ranks: the pipelined shifted iteration as ONE persistent launch per chunk (bicg_persist.hip, k_shpipe_persist);
-    // section timing needs the launch boundaries and keeps the multi-launch form
-    const int persist_shifted_env = getenv("BICG_PERSIST_SHIFTED") ? atoi(getenv("BICG_PERSIST_SHIFTED")) : 1;
-    bool persist = (mode == SH_PIPE || mode == SH_LOP) && c->persist_on && c->persist.rpt == 1u && nsig <= kPersistMaxShifts && persist_shifted_env != 0 &&
-                   !(o.time_kernels & 3) && !c->time_sections;
-    c->last_shifted_persist = false;
-    while (!c->hS->done && it < o.max_iter) {
-        const int persist_chunk_min = getenv("BICG_PERSIST_CHUNK") ? std::max(1, atoi(getenv("BICG_PERSIST_CHUNK"))) : kPersistChunk;
-        const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, o.max_iter - it);
-        sec_mark(c, SEC_VEC);
-        if (persist) {
-            persist = persist_chunk_shifted(c, mode, chunk, it, nsig, seed, sigma[seed]);
-            if (persist) c->last_shifted_persist = true;
-        }
-        for (int j = 0; j < chunk && !persist; ++j) {
-            if (mode == SH_PIPE) {
-                launch_shift_pipe1(v, p_seed, c->S, c->red(0, PH_SHP_OMEGA), c->sc);    // p, s, z, r_old, q, y, 2 dots
-                group_defer(c, 2, PH_SHP_OMEGA);
-                spmv(c, v.z, v.v, 0, nullptr, c->red(0, PH_NONE));                      // v = (A + sigma I) z
-                {   // the shift loops of src/shifted_solver.c:850-905, with the seed system's x / r / w and the five dots in the same pass
-                    Section sec(c, SEC_SHIFT);
-                    launch_shift_pipe2(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SHP_END), c->sc);
-                }
-                group_defer(c, 5, PH_SHP_END);
-                spmv(c, v.w, v.t, 0, nullptr, c->red(0, PH_NONE));                      // t = (A + sigma I) w
-                group_flush(c);
-                continue;
-            }
-            spmv(c, p_seed, v.s, 1, v.rh, c->red(0, PH_SH_ALPHA, true, 1));          // s = (A [+ sigma I]) p[seed], (r#,s)
-            group_now(c, 1, PH_SH_ALPHA);
-            launch_shift_q(v, c->S, c->sc);                                 // r_old = r, q = r - alpha s
-            // lop: (q,y), (q,q) ; shifted_bicgstab: (q,y), (y,y)
-            spmv(c, v.r, v.y, mode == SH_XI ? 2 : 3, v.r, c->red(0, PH_SH_OMEGA, true, 2));
-            group_now(c, 2, PH_SH_OMEGA);
-            {   // the shift loops of src/shifted_solver.c:132-154 and 180-208, with the seed system's x / r and two dots in the same pass
-                Section sec(c, SEC_SHIFT);
-                launch_shift_update(v, c->p_set, c->x_set, (uint32_t)st, seed, c->sh_dev, c->S, c->red(0, PH_SH_END, true, 2), c->sc);
-            }
-            group_now(c, 2, PH_SH_END);
-            launch_shift_pseed(v, p_seed, c->S, c->sc);                     // p[seed] = r + beta (p[seed] - omega s)
-        }
-        it += chunk;
-        sec_mark(c, SEC_STOP);
-        fetch_scal(c);
-        if (persist && mode == SH_PIPE) persist_account(c);
-    }
-    c->cur_has_shift = false; c->cur_shift = 0.0;
-    const double t1 = now_sec();
-
-    const int k = c->hS->k;
-    c->last_iters = k;
-    sec_collect(c, k);
-    for (int j = 0; j < nsig; ++j)
-        BICG_HIP(hipMemcpy(x_set_host + (size_t)j * n, c->x_set + (size_t)j * st, sizeof(double) * n, hipMemcpyDeviceToHost));
-    BICG_HIP(hipMemcpy(r_host, c->v.r, sizeof(double) * n, hipMemcpyDeviceToHost));
-    if (res) {
-        memset(res, 0, sizeof *res);
-        res->iterations = k; res->dot_r = c->hS->dot_r; res->dot_zero = c->hS->dot_zero;
-        res->seconds = t1 - t0; res->iter_seconds = t1 - t0;
-    }
-    if (c->rank == 0 && !o.quiet) {   // reference src/shifted_solver.c:336-343
-        printf("Total iter   : %d\n", k);
-        printf("Final r      : %e\n", sqrt(c->hS->dot_r / c->hS->dot_zero));
-        printf("Total time   : %e [sec.] \n", t1 - t0);
-        printf("Avg time/iter: %e [sec.] \n", (t1 - t0) / k);
-        print_sections(c, t1 - t0);
-        fflush(stdout);
-    }
-    return k;
-}
-
-void check_square(const INFO_Matrix *info)
-{
-    if (info->cols != info->rows) {   // reference src/solver.c:43-46
-        printf("Error: matrix is not square.\n");
-        exit(1);
-    }
-}
-
-void env_options(bicg_options *o)
-{
-    bicg_default_options(o);
-    if (const char *s = getenv("BICG_TOL")) o->tol = atof(s);
-    if (const char *s = getenv("BICG_MAX_ITER")) o->max_iter = atoi(s);
-    if (const char *s = getenv("BICG_OUT_ITER")) o->out_iter = atoi(s);
-    if (const char *s = getenv("BICG_CHECK_EVERY")) o->check_every = atoi(s);
-    if (const char *s = getenv("BICG_QUIET")) o->quiet = atoi(s);
-    if (const char *s = getenv("BICG_RR_DRIFT")) o->rr_drift = atof(s);
-    // the reference's MEASURE_SECTION_TIME (1) and DISPLAY_SECTION_TIME (2: the per-iteration table of the switching solvers)
-    if (const char *s = getenv("BICG_SECTION_TIME")) o->time_kernels = atoi(s) >= 2 ? 6 : atoi(s) ? 2 : 0;
-}
-
-// ---------------------------------------------------------------- matrix residency across drop-in calls
-// The reference's drivers call a solver many times on the same blocks (main_repeat.c:109-132: 10 x,
-// main_seed_diff.c: 28 x); building the SpMV plan and uploading ~700 MB per call would cost more than
-// the solves. The context of the last drop-in call stays resident and is reused when the caller
-// passes the same blocks again: same array addresses, sizes and partition, AND the same contents --
-// every value, column and row pointer goes through a 64-bit hash (one pass at memory speed, ~20 ms per
-// 200 MB against ~1 s for plan + upload), because the caller may have edited the matrix in place
-// between calls (the reference's csr_shift_diagonal does, src/matrix.c:518-531). Hit or miss is agreed
-// by all ranks (bicg_create is collective). BICG_DROPIN_CACHE=0 restores create / destroy per call.
-struct DropinKey {
-    const void *dv, *dc, *dp, *ov, *oc, *op;
-    unsigned rows, nnz_d, nnz_o, n_glob;
-    int nranks, rank, first_row;
-    const Comm *comm;
-    const void *p2p;
-    uint64_t hash;
-    bool operator==(const DropinKey &o) const
-    {
-        return dv == o.dv && dc == o.dc && dp == o.dp && ov == o.ov && oc == o.oc && op == o.op && rows == o.rows &&
-               nnz_d == o.nnz_d && nnz_o == o.nnz_o && n_glob == o.n_glob && nranks == o.nranks && rank == o.rank &&
-               first_row == o.first_row && comm == o.comm && p2p == o.p2p && hash == o.hash;
-    }
-};
-struct DropinCache { bicg_ctx *ctx = nullptr; DropinKey key{}; unsigned hits = 0, misses = 0; } g_dropin;
-
-uint64_t hash_words(uint64_t h, const void *data, size_t bytes)
-{
-    // four independent multiply-xor lanes over 8-byte words: runs at memory speed, order-sensitive
-    const uint64_t *w = (const uint64_t *)data;
-    const size_t n = bytes / 8;
-    uint64_t a = h ^ 0x9E3779B97F4A7C15ull, b = h + 0xBF58476D1CE4E5B9ull, c = ~h, d = h * 0x94D049BB133111EBull + 1;
-    size_t i = 0;
-    for (; i + 4 <= n; i += 4) {
-        a = (a ^ w[i]) * 0x100000001B3ull; b = (b ^ w[i + 1]) * 0x9E3779B97F4A7C15ull;
-        c = (c ^ w[i + 2]) * 0xC2B2AE3D27D4EB4Full; d = (d ^ w[i + 3]) * 0x165667B19E3779F9ull;
-    }
-    for (; i < n; ++i) a = (a ^ w[i]) * 0x100000001B3ull;
-    const unsigned char *t = (const unsigned char *)data + 8 * n;
-    for (size_t k = 0; k < bytes - 8 * n; ++k) b = (b ^ t[k]) * 0x100000001B3ull;
-    return (a ^ (b << 1) ^ (c >> 1) ^ (d << 7)) * 0xFF51AFD7ED558CCDull;
-}
-
-DropinKey dropin_key(const CSR_Matrix *d, const CSR_Matrix *o, const INFO_Matrix *info, Comm *comm)
-{
-    DropinKey k{};
-    k.dv = d->val; k.dc = d->col; k.dp = d->ptr; k.ov = o->val; k.oc = o->col; k.op = o->ptr;
-    k.rows = d->rows; k.nnz_d = d->rows ? d->ptr[d->rows] : 0u; k.n_glob = info->rows;
-    k.nranks = comm->nranks; k.rank = comm->rank; k.comm = comm; k.p2p = comm->p2p;
-    k.nnz_o = (comm->nranks > 1 && o->rows) ? o->ptr[o->rows] : 0u;
-    k.first_row = info->displs ? info->displs[comm->rank] : 0;
-    uint64_t h = 0x243F6A8885A308D3ull;
-    h = hash_words(h, d->ptr, sizeof(unsigned) * ((size_t)d->rows + 1));
-    h = hash_words(h, d->col, sizeof(unsigned) * (size_t)k.nnz_d);
-    h = hash_words(h, d->val, sizeof(double) * (size_t)k.nnz_d);
-    if (comm->nranks > 1) {
-        h = hash_words(h, o->ptr, sizeof(unsigned) * ((size_t)o->rows + 1));
-        h = hash_words(h, o->col, sizeof(unsigned) * (size_t)k.nnz_o);
-        h = hash_words(h, o->val, sizeof(double) * (size_t)k.nnz_o);
-        h = hash_words(h, info->recvcounts, sizeof(int) * (size_t)comm->nranks);
-        h = hash_words(h, info->displs, sizeof(int) * (size_t)comm->nranks);
-    }
-    k.hash = h;
-    return k;
-}
-
-// every rank contributes one flag; true when it is set on all of them
-bool all_ranks(Comm *comm, bool mine)
-{
-    const int P = comm->nranks;
-    if (P == 1) return mine;
-    std::vector<int> cnt(P, (int)sizeof(int)), dsp(P), out(P, mine ? 1 : 0), in(P, 0);
-    for (int p = 0; p < P; ++p) dsp[p] = p * (int)sizeof(int);
-    comm->alltoallv_host(out.data(), cnt.data(), dsp.data(), in.data(), cnt.data(), dsp.data());
-    in[comm->rank] = mine ? 1 : 0;
-    for (int p = 0; p < P; ++p) if (!in[p]) return false;
-    return true;
-}
-
-bool dropin_cache_enabled()
-{
-    static const bool enabled = !(getenv("BICG_DROPIN_CACHE") && atoi(getenv("BICG_DROPIN_CACHE")) == 0);
-    return enabled;
-}
-
-// the resident context for these blocks: reused when nothing changed, rebuilt otherwise (collective)
-bicg_ctx *dropin_context(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
-{
-    Comm *comm = comm_get();
-    if (!dropin_cache_enabled()) {
-        // create / destroy per call, but the library keeps ownership all the same (a caller that asked for the context
-        // through bicg_dropin_context must not be left with one to free, and must not meet a SECOND copy of the matrix
-        // on the GPU when it calls a solver next): the previous context goes before the new one is built
-        if (g_dropin.ctx) { bicg_destroy(g_dropin.ctx); g_dropin.ctx = nullptr; }
-        g_dropin.misses++;
-        g_dropin.ctx = bicg_create(diag, offd, info);
-        g_dropin.key = DropinKey{};
-        return g_dropin.ctx;
-    }
-    const DropinKey key = dropin_key(diag, offd, info, comm);
-    const bool hit = all_ranks(comm, g_dropin.ctx != nullptr && g_dropin.key == key);
-    if (hit) { g_dropin.hits++; return g_dropin.ctx; }
-    if (g_dropin.ctx) { bicg_destroy(g_dropin.ctx); g_dropin.ctx = nullptr; }
-    g_dropin.misses++;
-    g_dropin.ctx = bicg_create(diag, offd, info);
-    g_dropin.key = key;
-    return g_dropin.ctx;
-}
-void dropin_release(bicg_ctx *c)
-{
-    // caching disabled: the context does not outlive the solver call
-    if (c && !dropin_cache_enabled() && c == g_dropin.ctx) { bicg_destroy(c); g_dropin.ctx = nullptr; }
-}
-
-// drop-in fallback from an automatically chosen peer-to-peer path. p2p_guard: arm it for this call (keeps copies of the
-// caller's vectors); p2p_fell_back: collective -- true when some rank timed out; the resident context and the
-// peer-to-peer state are gone then, and the next dropin_context() builds on the transport's collectives.
-bool p2p_guard(bicg_ctx *c, const double *x, const double *r, std::vector<double> &x0, std::vector<double> &b)
-{
-    if (!c->p2p || !c->comm->p2p_auto) return false;
-    c->soft_fail = true;
-    const size_t nuser = c->phantom ? 0 : c->n_loc;      // a rank without rows: the caller's vectors are empty
-    x0.assign(x, x + nuser); b.assign(r, r + nuser);
-    return true;
-}
-bool p2p_fell_back(bicg_ctx *c)
-{
-    Comm *comm = c->comm;
-    const bool failed = !all_ranks(comm, !c->comm_failed);
-    if (!failed) return false;
-    if (comm->rank == 0)
-        fprintf(stderr, "bicgstab_hip: the peer-to-peer data path timed out in a solve although its self-test had passed; "
-                        "repeating the solve with the %s collectives\n", comm->name());
-    bicg_dropin_release();
-    if (!g_live.empty()) die("peer-to-peer transport", "timed out, and other contexts still use it: cannot fall back");
-    p2p_disable(comm);
-    return true;
-}
-
-int dropin(int method, CSR_Matrix *diag, CSR_Matrix *offd, INFO_Matrix *info, double *x, double *r, int krr, int nrr)
-{
-    check_square(info);
-    bicg_options o;
-    env_options(&o);
-    o.krr = krr; o.nrr = nrr;
-    bicg_ctx *c = dropin_context(diag, offd, info);
-    if (!c) die("bicg_create", "failed");
-    bicg_result res;
-    // The peer-to-peer data path is chosen automatically when its self-test passes (bicg_comm_init_mpi "auto"). Should it
-    // fail in a real solve all the same -- a wait for a peer times out -- the solve is repeated on the transport's own
-    // collectives (RCCL / MPI-staged) from the caller's x0 and b instead of ending the program.
-    std::vector<double> x0, b;
-    const bool guarded = p2p_guard(c, x, r, x0, b);
-    int k = bicg_solve(c, method, x, r, &o, &res);
-    if (guarded && p2p_fell_back(c)) {
-        memcpy(x, x0.data(), sizeof(double) * x0.size());
-        memcpy(r, b.data(), sizeof(double) * b.size());
-        c = dropin_context(diag, offd, info);
-        if (!c) die("bicg_create", "failed");
-        k = bicg_solve(c, method, x, r, &o, &res);
-    }
-    dropin_release(c);
-    return k;
-}
-
-}  // namespace
-
-// Very large structured blocks (the 512^3 Laplacian: 524 288 row groups, z neighbours 262 144 rows = 2 MB of x away).
-//  * groups per workgroup: with one 256-row group of 7-entry rows per workgroup the per-workgroup part of a product with dots
-//    (block sum, hand-over of the partials) is a third of the kernel (2.16 ms without dots, 2.76 / 3.13 ms with one / two);
-//    workgroups take ceil(groups / 65536) contiguous groups each.
-//  * order of the groups: an XCD sweeps its eighth of the rows plane by plane, and the three planes a sweep front touches (6 MB
-//    of x) do not fit its 4 MB L2 -- every x value comes from the Infinity Cache three times. The groups of an XCD's share are
-//    therefore taken block by block through the planes: B consecutive groups of plane z, the same B of plane z + 1, ... so that
-//    what a block fetched as its far neighbours is still in the L2 when it becomes the block's own rows. Only the ORDER of the
-//    list changes (SpmvArgs::glist): rows, sums of a row and results are those of the natural order; the dot partials are
-//    added in list order (a different, equally fixed association).
-// BICG_SELL_BLOCK = B (groups, default 256; 0: natural order).
-void sell_order_for_big_grids(bicg_ctx *c, uint32_t ngroups)
-{
-    if (!knob_x("BICG_SELL_GPW") && !knob_x("BICG_SELL_GPW_DOTS")) c->sell_gpw = c->sell_gpw_dots = (int)std::max<uint32_t>(1u, (ngroups + 65535u) / 65536u);
-    if (const char *sv = knob_x("BICG_SELL_GPW")) c->sell_gpw = std::max(1, atoi(sv));
-    if (const char *sv = knob_x("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = std::max(1, atoi(sv));
-    const uint32_t B = knob_x("BICG_SELL_BLOCK") ? (uint32_t)atoi(knob_x("BICG_SELL_BLOCK")) : 256u;
-    const uint32_t P = (c->far_rows + kGroupRows / 2) / kGroupRows;          // groups per plane
-    if (B == 0 || P < 4 * B || c->sell_gpw != c->sell_gpw_dots || (uint64_t)c->far_rows * 24ull <= (3ull << 19)) return;   // three planes fit half an L2
-    const uint32_t nblocks = sell_grid(ngroups, c->sell_gpw), each = (ngroups + nblocks - 1) / nblocks;
-    std::vector<uint32_t> list(ngroups);
-    for (uint32_t x = 0; x <= 8; ++x) {
-        // XCD x's share of the list (the last segment: what the division left over); within it block y of every plane, plane
-        // after plane, then block y + 1 ... -- the order a sort by (block, group) would give, enumerated directly
-        const uint32_t s0 = std::min<uint64_t>(ngroups, (uint64_t)x * (nblocks / 8u) * each);
-        const uint32_t s1 = x == 8 ? ngroups : std::min<uint64_t>(ngroups, (uint64_t)(x + 1) * (nblocks / 8u) * each);
-        uint32_t o = s0;
-        for (uint32_t y0 = 0; y0 < P && o < s1; y0 += B)
-            for (uint64_t z0 = s0; z0 < s1; z0 += P)
-                for (uint64_t g = z0 + y0; g < std::min<uint64_t>({(uint64_t)s1, z0 + y0 + B, z0 + P}); ++g) list[o++] = (uint32_t)g;
-    }
-    if (c->glist_int) BICG_HIP(hipFree(c->glist_int));
-    c->glist_int = dev_upload(list.data(), list.size());
-    c->glist_int_identity = false;
-    c->sell_blocked = B;
-}
-
-// ---------------------------------------------------------------- persistent pipelined iteration: plan
-// Which rows a workgroup owns, its part of the matrix in padded slices (diag entries first, then offd entries in the
-// x_ext numbering [local rows | halo positions]) with window slots instead of columns, the window runs, and -- multi
-// rank -- the send-list entries of every workgroup. Returns false when the block does not qualify.
-bool persist_build(bicg_ctx *c, const CSR_Matrix *diag, const std::vector<uint32_t> &optr, const std::vector<uint32_t> &ocol,
-                   const std::vector<double> &oval, const std::vector<uint32_t> &send_idx, const std::vector<unsigned long long> &dst0,
-                   const std::vector<unsigned long long> &dstride)
-{
-    const uint32_t nrows = c->n_loc;
-    const bool multi = !c->single();
-    if (nrows == 0 || c->fault_after > 0) return false;
-    if (!(c->glist_all && c->nblk == 0 && !c->rowsplit && (c->single() || (c->p2p && c->ll_fused)))) return false;
-    hipDeviceProp_t prop;
-    BICG_HIP(hipGetDeviceProperties(&prop, c->device));
-    const int cus = prop.multiProcessorCount;
-    // one workgroup per CU (its LDS): ranks sharing a GPU (tests) share the CUs; one CU is the helper's
-    const int gmax = cus / std::max(1, c->comm->ranks_on_device) - 1;
-    if (gmax < 1) return false;
-    PersistPlan P;
-    if (!persist_plan_host(diag, multi ? optr.data() : nullptr, multi ? ocol.data() : nullptr, multi ? oval.data() : nullptr, (unsigned)gmax, P))
-        return false;
-    const uint32_t nslices = P.nslices, spw = P.spw, nwg = P.nwg, grows = spw * kSliceRows;
-    const uint32_t slots_used = P.win_slots, max_runs = P.max_runs, max_entries = P.max_entries;
-    const std::vector<uint32_t> &pbase = P.pbase, &wptr = P.wptr;
-    const std::vector<double> &pval = P.pval;
-    const std::vector<unsigned short> &pslot = P.pslot, &rlen = P.rlen, &rdiag = P.rdiag;
-    static_assert(sizeof(uint2) == 2 * sizeof(uint32_t), "run = two 32-bit words");
-    std::vector<uint2> runs(P.runs.size() / 2 + 1);
-    for (size_t i = 0; i < P.runs.size() / 2; ++i) runs[i] = make_uint2(P.runs[2 * i], P.runs[2 * i + 1]);
-    PersistArgs &a = c->persist;
-    a = PersistArgs{};
-    a.nrows = nrows; a.nslices = nslices; a.nwg = nwg; a.spw = P.nrw; a.rpt = P.rpt;
-    a.win_slots = slots_used; a.max_runs = max_runs;
-    // the matrix goes to LDS when everything fits next to the window
-    a.mat_entries = P.rpt == 1 ? max_entries : 0;
-    if (knob_x("BICG_PERSIST_LDSMAT") && atoi(knob_x("BICG_PERSIST_LDSMAT")) == 0) a.mat_entries = 0;
-    // what a workgroup may ask for on THIS device (gfx950: 160 KiB per CU; the static part of the kernels is < 6 KiB)
-    const unsigned lds_max = std::min<unsigned>(kPersistMaxLds, prop.sharedMemPerBlock > 8192 ? (unsigned)prop.sharedMemPerBlock - 6144u : 0u);
-    if (persist_lds_bytes(a) > lds_max) a.mat_entries = 0;
-    if (persist_lds_bytes(a) > lds_max) { a = PersistArgs{}; return false; }
-    auto keep = [&](void *p) { c->persist_mem.push_back(p); return p; };
-    a.pval = (const double *)keep(dev_upload(pval.data(), pval.size()));
-    a.pslot = (const unsigned short *)keep(dev_upload(pslot.data(), pslot.size()));
-    a.pbase = (const uint32_t *)keep(dev_upload(pbase.data(), pbase.size()));
-    a.rlen = (const unsigned short *)keep(dev_upload(rlen.data(), rlen.size()));
-    a.rdiag = (const unsigned short *)keep(dev_upload(rdiag.data(), rdiag.size()));
-    a.win_ptr = (const uint32_t *)keep(dev_upload(wptr.data(), wptr.size()));
-    a.win_runs = (const uint2 *)keep(dev_upload(runs.data(), runs.size()));
-    for (int i = 0; i < 4; ++i) {
-        a.llv[i] = (llword *)keep(dev_alloc<llword>(2 * (size_t)nrows));
-        BICG_HIP(hipMemset(a.llv[i], 0, sizeof(llword) * 2 * (size_t)nrows));
-    }
-    for (int i = 0; i < 2; ++i) {
-        a.dtab[i] = (llword *)keep(dev_alloc<llword>((size_t)nwg * kRedSlots * 2));
-        BICG_HIP(hipMemset(a.dtab[i], 0, sizeof(llword) * (size_t)nwg * kRedSlots * 2));
-        a.arow[i] = (llword *)keep(dev_alloc<llword>(8));
-        BICG_HIP(hipMemset(a.arow[i], 0, sizeof(llword) * 8));
-        a.crow[i] = (llword *)keep(dev_alloc<llword>(6 * kPersistMaxShifts * 2));      // shifted kernel: per-shift coefficients
-        BICG_HIP(hipMemset(a.crow[i], 0, sizeof(llword) * 6 * kPersistMaxShifts * 2));
-    }
-    a.multi = multi ? 1 : 0;
-    if (multi) {
-        // send-list entries by owning workgroup (the list is grouped by destination, a row may go to several ranks)
-        std::vector<uint32_t> sptr(nwg + 1, 0u);
-        for (uint32_t i = 0; i < c->nsend; ++i) sptr[send_idx[i] / grows + 1]++;
-        for (uint32_t g = 0; g < nwg; ++g) sptr[g + 1] += sptr[g];
-        std::vector<uint32_t> fill(sptr.begin(), sptr.end() - 1);
-        std::vector<unsigned short> srow(c->nsend ? c->nsend : 1);
-        std::vector<unsigned long long> sd0(c->nsend ? c->nsend : 1), sst(c->nsend ? c->nsend : 1);
-        for (uint32_t i = 0; i < c->nsend; ++i) {
-            const uint32_t g = send_idx[i] / grows, at = fill[g]++;
-            srow[at] = (unsigned short)(send_idx[i] - g * grows); sd0[at] = dst0[i]; sst[at] = dstride[i];
-        }
-        a.snd_ptr = (const uint32_t *)keep(dev_upload(sptr.data(), sptr.size()));
-        a.snd_row = (const unsigned short *)keep(dev_upload(srow.data(), srow.size()));
-        a.snd_dst0 = (const unsigned long long *)keep(dev_upload(sd0.data(), sd0.size()));
-        a.snd_stride = (const unsigned long long *)keep(dev_upload(sst.data(), sst.size()));
-        a.ring = c->halo_ring; a.halo = c->halo;
-    }
-    a.v = c->v;
-    a.alarm = c->alarm;
-    if (getenv("BICG_DEBUG"))
-        fprintf(stderr, "bicgstab_hip: rank %d: persistent plan: %u workgroups x (%u + 64) threads x %u rows (+1 helper), window %u slots (%u runs at most), "
-                        "matrix %s (%u entries per workgroup), %u bytes of LDS\n", c->rank, nwg, 64 * P.nrw, P.rpt, slots_used, max_runs,
-                a.mat_entries ? "in LDS" : "in memory", max_entries, persist_lds_bytes(a));
-    return true;
-}
-
-// niter iterations of pipe_bicgstab in one launch (the open dot group has been closed: fetch_scal precedes every chunk)
-bool persist_chunk(bicg_ctx *c, int niter)
-{
-    if (c->grp.active) die("internal", "persistent chunk with an open dot group");
-    if (c->f1_done) die("internal", "persistent chunk after phase 1 of the next iteration has run");
-    const bool plain = c->method == BICG_BICGSTAB;
-    const bool pipe = c->method >= BICG_PIPE_BICGSTAB;
-    const unsigned groups = plain ? 3u : 2u;                  // dot groups (tags, mailbox numbers) per iteration
-    PersistArgs a = c->persist;
-    a.v = c->v; a.S = c->S; a.alarm = c->alarm; a.niter = niter;
-    a.seq0 = c->persist_seq;
-    a.vseq0 = c->persist_vseq;
-    // the pipelined kernel numbers hand-offs and groups densely and reports what it used (replacement iterations and drift
-    // checks make the count data dependent): persist_account() advances the counters after the launch
-    if (!pipe) c->persist_seq += groups * (unsigned)niter;
-    a.it0 = c->it;
-    a.krr = c->method == BICG_PIPE_BICGSTAB_RR ? c->opt.krr : 0; a.nrr = c->opt.nrr;
-    a.force_first = 0;
-    a.drift_every = (pipe && c->opt.rr_drift > 0.0) ? c->opt.check_every : 0;
-    a.drift_tol2 = c->opt.rr_drift * c->opt.rr_drift;
-    a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;          // 2 s inside one GPU
-    static const int xcd_map = knob_x("BICG_PERSIST_XCD") ? atoi(knob_x("BICG_PERSIST_XCD")) : 1;
-    a.xcd_map = xcd_map;
-    static const int first_sleep = knob_x("BICG_PERSIST_SLEEP") ? atoi(knob_x("BICG_PERSIST_SLEEP")) : 1;
-    a.first_sleep = (unsigned)first_sleep;
-    if (a.multi) {
-        // every rank advances its exchange and group numbers by the whole chunk, converged early or not
-        a.halo_seq0 = c->halo_seq;
-        a.p2p = c->p2p->red_desc(c->p2p->red_seq);
-        if (!pipe) { c->halo_seq += 2u * (unsigned)niter; c->p2p->red_seq += groups * (unsigned)niter; }
-        a.ring = c->halo_ring;
-        c->halo_unsynced = 0;
-    }
-    if (a.multi) {
-        if (!c->waitlog) { c->waitlog = dev_alloc<unsigned>(3 * (size_t)kWaitCap); BICG_HIP(hipMemsetAsync(c->waitlog, 0, sizeof(unsigned) * 3 * kWaitCap, c->sc)); }
-        a.waitlog = c->waitlog; a.waitcap = kWaitCap;
-    }
-    static const bool want_trace = knob_x("BICG_PERSIST_TRACE") != nullptr;
-    unsigned long long *dbg = nullptr;
-    if (want_trace) {
-        dbg = dev_alloc<unsigned long long>(64 * 16);
-        BICG_HIP(hipMemset(dbg, 0, 64 * 16 * sizeof(unsigned long long)));
-        a.dbg = dbg;
-    }
-    hipError_t err;
-    if (plain) err = launch_plain_persist(a, c->sc);
-    else if (c->method == BICG_CA_BICGSTAB) err = launch_ca_persist(a, c->sc);
-    else err = launch_pipe_persist(a, c->sc);
-    if (err != hipSuccess) {
-        // nothing ran: hand the chunk back to the multi-launch kernels (every rank sees the same failure: same kernel, same
-        // plan limits; the sequence numbers reserved above are simply skipped on all of them)
-        if (dbg) (void)hipFree(dbg);
-        if (c->nranks > 1) die("persistent kernel", "launch failed on a multi-rank run (BICG_PERSIST=0 selects the multi-launch iteration)");
-        fprintf(stderr, "bicgstab_hip: falling back to the multi-launch iteration\n");
-        c->persist_on = false;
-        return false;
-    }
-    if (want_trace && c->method != BICG_PIPE_BICGSTAB) { BICG_HIP(hipStreamSynchronize(c->sc)); BICG_HIP(hipFree(dbg)); }
-    if (want_trace && c->method == BICG_PIPE_BICGSTAB) {
-        // 10 ns ticks of one row workgroup (0 start, 1 z and partials published, 2 window staged, 3 product done, 4 omega here,
-        // 5 w and partials published, 6 window, 7 product, 8 scalars here) and of the helper (10 / 11: group 1 / 2 published)
-        std::vector<unsigned long long> h(64 * 16);
-        BICG_HIP(hipStreamSynchronize(c->sc));
-        BICG_HIP(hipMemcpy(h.data(), dbg, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
-        BICG_HIP(hipFree(dbg));
-        for (int it = std::max(0, std::min(niter, 32) - 5); it < std::min(niter, 32); ++it)
-            for (int who = 0; who < 2; ++who) {
-                const unsigned long long *q = h.data() + (size_t)(it * 2 + who) * 16, *q0 = h.data() + (size_t)(it * 2) * 16;
-                fprintf(stderr, "persist trace it %2d %s:", it, who ? "comm" : "row ");
-                for (int i = 0; i <= 8; ++i) fprintf(stderr, " %d:%+.2f", i, 0.01 * (double)(long long)(q[i] - q0[0]));
-                if (!who) fprintf(stderr, "  helper g1 %+.2f g2 %+.2f", 0.01 * (double)(long long)(q[10] - q0[0]), 0.01 * (double)(long long)(q[11] - q0[0]));
-                else fprintf(stderr, "  helper g1: arrived %+.2f summed %+.2f applied %+.2f", 0.01 * (double)(long long)(q[12] - q0[0]),
-                             0.01 * (double)(long long)(q[13] - q0[0]), 0.01 * (double)(long long)(q[14] - q0[0]));
-                fprintf(stderr, "\n");
-            }
-    }
-    return true;
-}
-
-// niter iterations of shifted_pipe_lopbicgstab (reference src/shifted_solver.c:794-866) in one launch: the seed system's
-// pipelined recurrence with products of A + sigma_seed I, every other shift's p_j / x_j streamed through in phase 2. Sequence
-// numbers as for the pipelined kernel (dense, reported back: persist_account).
-bool persist_chunk_shifted(bicg_ctx *c, int mode, int niter, int it0, int nsig, int seed, double shift)
-{
-    const bool pipe = mode == SH_PIPE;          // else shifted_lopbicgstab: three groups and two products per iteration, numbered
-                                                // like the plain kernel's (fixed counts, advanced here)
-    if (c->grp.active) die("internal", "persistent chunk with an open dot group");
-    const size_t st = c->stride;
-    PersistArgs a = c->persist;
-    a.v = c->v;
-    a.v.x = c->x_set + (size_t)seed * st; a.v.p = c->p_set + (size_t)seed * st;      // x[seed], p[seed]
-    a.S = c->S; a.alarm = c->alarm; a.niter = niter;
-    a.seq0 = c->persist_seq; a.vseq0 = c->persist_vseq;
-    a.it0 = it0; a.krr = 0; a.nrr = 0; a.force_first = 0; a.drift_every = 0; a.drift_tol2 = 0.0;
-    a.pset = c->p_set; a.xset = c->x_set; a.set_stride = (uint32_t)st; a.nsig = nsig; a.seed = seed;
-    a.shift = shift; a.has_shift = 1;
-    {   // the sets stay in the Infinity Cache when they (and the matrix, if it is not in LDS) fit half of it
-        const double ws = 16.0 * (double)nsig * (double)st + (a.mat_entries ? 0.0 : (double)c->matrix_bytes);
-        a.set_nt = ws > 0.5 * 256.0 * 1048576.0;
-        if (const char *e = knob_x("BICG_SHP_NT")) a.set_nt = atoi(e) != 0;
-    }
-    a.timeout_ticks = c->p2p ? c->p2p->timeout_ticks : 200000000ull;
-    static const int xcd_map = knob_x("BICG_PERSIST_XCD") ? atoi(knob_x("BICG_PERSIST_XCD")) : 1;
-    a.xcd_map = xcd_map;
-    static const int first_sleep = knob_x("BICG_PERSIST_SLEEP") ? atoi(knob_x("BICG_PERSIST_SLEEP")) : 1;
-    a.first_sleep = (unsigned)first_sleep;
-    if (!pipe) c->persist_seq += 3u * (unsigned)niter;
-    if (a.multi) {
-        a.halo_seq0 = c->halo_seq;
-        a.p2p = c->p2p->red_desc(c->p2p->red_seq);
-        if (!pipe) { c->halo_seq += 2u * (unsigned)niter; c->p2p->red_seq += 3u * (unsigned)niter; }
-        a.ring = c->halo_ring;
-        c->halo_unsynced = 0;
-    }
-    const hipError_t err = pipe ? launch_shpipe_persist(a, c->sc) : launch_shlop_persist(a, c->sc);
-    if (err != hipSuccess) {
-        if (c->nranks > 1) die("persistent kernel", "launch failed on a multi-rank run (BICG_PERSIST=0 selects the multi-launch iteration)");
-        fprintf(stderr, "bicgstab_hip: falling back to the multi-launch iteration\n");
-        return false;
-    }
-    return true;
-}
-
-// after a pipelined persistent launch (fetch_scal has brought the scalar block back): advance the sequence counters by what
-// the launch consumed. Identical on every rank -- the decisions inside the launch depend on globally reduced sums only.
-void persist_account(bicg_ctx *c)
-{
-    const unsigned nv = (unsigned)c->hS->red[kRedUsedV], ng = (unsigned)c->hS->red[kRedUsedG];
-    c->persist_seq += ng;
-    c->persist_vseq += nv;
-    if (!c->single()) { c->halo_seq += nv; c->p2p->red_seq += ng; }
-    c->adaptive_rr += (int)c->hS->red[kRedAdaptive];
-}
-
-// vectors, reduction scratch and scalar blocks of a context whose plan (n_loc, halo, nblk) is known
-static void ctx_state(bicg_ctx *c, Comm *comm, uint32_t ngroups)
-{
-    // ---- vectors: 12 x (rows + halo), each 256-byte aligned; order x r | rh p s y z w v t ax b
-    c->stride = ((c->n_loc + c->halo + 31u) / 32u) * 32u;
-    // (BICG_STRIDE_PAD = doubles added to the distance between two vectors, a multiple of 32: measurement knob for grids whose
-    // vectors would otherwise lie a power of two bytes apart -- 512^3: exactly 1 GiB)
-    if (const char *sv = knob_x("BICG_STRIDE_PAD")) c->stride += ((uint32_t)std::max(0, atoi(sv)) / 32u) * 32u;
-    c->slab = dev_alloc<double>(12 * (size_t)c->stride);
-    BICG_HIP(hipMemset(c->slab, 0, sizeof(double) * 12 * (size_t)c->stride));
-    double *base = c->slab;
-    double **slots[12] = {&c->v.x, &c->v.r, &c->v.rh, &c->v.p, &c->v.s, &c->v.y, &c->v.z, &c->v.w, &c->v.v, &c->v.t, &c->v.ax, &c->v.b};
-    for (int i = 0; i < 12; ++i) *slots[i] = base + (size_t)i * c->stride;
-    c->v.n = c->n_loc;
-
-    c->nslots = std::max<unsigned>(ngroups + c->nblk, kMaxGrid) + 64;
-    c->partial = dev_alloc<double>((size_t)c->nslots * kPartialStride);
-    c->shard_tot = dev_alloc<double>((size_t)kShards * kPartialStride);
-    c->counter = dev_alloc<unsigned>((kShards + 1) * kCounterStride);
-    BICG_HIP(hipMemset(c->counter, 0, sizeof(unsigned) * (kShards + 1) * kCounterStride));
-    c->tail_tab = dev_alloc<llword>((size_t)c->nslots * kTailStride);
-    BICG_HIP(hipMemset(c->tail_tab, 0, sizeof(llword) * (size_t)c->nslots * kTailStride));
-    c->tail_shard = dev_alloc<llword>((size_t)kShards * kRedSlots * 2);
-    BICG_HIP(hipMemset(c->tail_shard, 0, sizeof(llword) * kShards * kRedSlots * 2));
-    if (const char *sv = knob_x("BICG_TAIL_FINISH")) c->tail_finish = atoi(sv) != 0;
-    c->Sbuf = dev_alloc<Scal>(2);
-    BICG_HIP(hipMemset(c->Sbuf, 0, 2 * sizeof(Scal)));
-    c->S = c->Sbuf;
-    for (int i = 0; i < 2; ++i) {
-        c->wpart[i] = dev_alloc<double>((size_t)c->nslots * (kBlock / 64) * kPartialStride);
-        BICG_HIP(hipMemset(c->wpart[i], 0, sizeof(double) * (size_t)c->nslots * (kBlock / 64) * kPartialStride));
-    }
-    c->shard_ll = dev_alloc<llword>((size_t)2 * kShardLL * kRedSlots * 2);
-    BICG_HIP(hipMemset(c->shard_ll, 0, sizeof(llword) * 2 * kShardLL * kRedSlots * 2));
-    c->alarm = dev_alloc<int>(1);
-    BICG_HIP(hipMemset(c->alarm, 0, sizeof(int)));
-    BICG_HIP(hipHostMalloc((void **)&c->h_alarm, sizeof(int), hipHostMallocDefault));
-    *c->h_alarm = 0;
-    if (comm->ranks_on_device > 1) {
-        // one-GPU box standing in for a node: 1024 = 256 CUs x 4 resident workgroups of the largest kernels
-        c->wg_cap = 1024u / (unsigned)(comm->ranks_on_device + 1);
-        set_vec_grid_cap(c->wg_cap);
-    }
-}
-
-static void ctx_streams(bicg_ctx *c, int P)
-{
-    BICG_HIP(hipStreamCreateWithFlags(&c->sc, hipStreamNonBlocking));
-    if (P > 1 || c->force_comm) BICG_HIP(hipStreamCreateWithFlags(&c->sm, hipStreamNonBlocking));
-    for (int i = 0; i < kEvRing; ++i) {
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_pack[i], hipEventDisableTiming));
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_halo[i], hipEventDisableTiming));
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_dots[i], hipEventDisableTiming));
-        BICG_HIP(hipEventCreateWithFlags(&c->ev_red[i], hipEventDisableTiming));
-    }
-    BICG_HIP(hipDeviceSynchronize());       // uploads and memsets above used the null stream
-}
-
-// =====================================================================================  C ABI
-extern "C" {
-
-int bicg_has_experiments(void) { return kExperiments ? 1 : 0; }
-const char *bicg_version(void) { return "bicgstab_hip 0.1 (gfx950)"; }
-
-void bicg_default_options(bicg_options *o)
-{
-    memset(o, 0, sizeof *o);
-    o->tol = 1.0e-15;      // reference EPS       (src/solver.c:3)
-    o->max_iter = 1000;    // reference MAX_ITER  (src/solver.c:4)
-    o->out_iter = 100;     // reference OUT_ITER  (src/solver.c:9)
-    o->check_every = 16;
-}
-
-// the code objects this context launches from, loaded now (preload_kernels, bicg_kernels.hip)
-static void preload_for(bicg_ctx *c)
-{
-    if (knob_x("BICG_PRELOAD") && atoi(knob_x("BICG_PRELOAD")) == 0) return;
-    SellDev d = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
-    d.vbase = c->s_vbase;
-    preload_kernels(d, c->sell_entries > 0);
-    if (c->persist_on) preload_persist_kernels();
-    if (c->st.on) preload_stencil_kernels();
-    if (c->lane_info && c->jagw_fast) preload_jagw_kernels();
-}
-
-bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
-{
-    Comm *comm = comm_get();
-    BICG_HIP(hipSetDevice(comm->device));
-    if (info->rows != info->cols) { fprintf(stderr, "ERROR: bicg_create: matrix is not square\n"); return nullptr; }
-
-    bicg_ctx *c = new bicg_ctx;
-    c->comm = comm; c->device = comm->device; c->nranks = comm->nranks; c->rank = comm->rank;
-    g_live.push_back(c);
-    // a rank without rows: one phantom row (see bicg_ctx::phantom)
-    static double ph_val[1] = {1.0};
-    static unsigned ph_col[1] = {0u}, ph_ptr1[2] = {0u, 1u}, ph_ptr0[2] = {0u, 0u};
-    CSR_Matrix ph_d, ph_o;
-    if (diag->rows == 0 && info->rows > 0 && comm->nranks > 1) {
-        c->phantom = true;
-        ph_d.val = ph_val; ph_d.col = ph_col; ph_d.ptr = ph_ptr1; ph_d.nz = 1; ph_d.rows = 1; ph_d.cols = 1;
-        ph_o.val = ph_val; ph_o.col = ph_col; ph_o.ptr = ph_ptr0; ph_o.nz = 0; ph_o.rows = 1; ph_o.cols = info->cols;
-        diag = &ph_d; offd = &ph_o;
-    }
-    c->n_loc = diag->rows; c->n_glob = info->rows;
-    c->nnz_d = diag->rows ? diag->ptr[diag->rows] : 0u;
-    const int P = c->nranks;
-
-    bool use_sell = !(knob_x("BICG_NO_SELL") && atoi(knob_x("BICG_NO_SELL")));
-    if (const char *sv = knob_x("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
-    if (const char *sv = knob_x("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
-    if (const char *sv = knob_x("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
-    if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
-    if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
-    uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
-    {   // Every rank learns every rank's (non-zeros, rows). The enqueue mode changes the ORDER of RCCL calls,
-        // so all ranks must take the same decision: it is based on the average number of local non-zeros.
-        // (a rank without rows carries a phantom row and counts as a rank like any other; only an EMPTY MATRIX is refused)
-        uint64_t total = c->nnz_d;
-        bool empty = c->n_loc == 0;
-        if (P > 1) {
-            std::vector<int> cnt(P, 2 * (int)sizeof(uint32_t)), off(P);
-            std::vector<uint32_t> mine(2 * (size_t)P), all(2 * (size_t)P, 0u);
-            for (int p = 0; p < P; ++p) { off[p] = 2 * p * (int)sizeof(uint32_t); mine[2 * p] = c->nnz_d; mine[2 * p + 1] = c->n_loc; }
-            comm->alltoallv_host(mine.data(), cnt.data(), off.data(), all.data(), cnt.data(), off.data());
-            all[2 * c->rank] = c->nnz_d; all[2 * c->rank + 1] = c->n_loc;
-            total = 0;
-            for (int p = 0; p < P; ++p) { total += all[2 * p]; empty = empty || all[2 * p + 1] == 0; }
-        }
-        if (empty) {
-            if (c->rank == 0) fprintf(stderr, "ERROR: bicg_create: empty matrix (%u rows over %d ranks)\n", info->rows, P);
-            bicg_destroy(c);          // nothing is allocated yet; takes the context out of the registry of live ones
-            return nullptr;
-        }
-        nnz_diag_all = total;
-        c->overlap = total / (uint64_t)P >= 6000000u;
-        // two launches per pipelined iteration (phases in the SpMV epilogues): latency on small ranks (200 k rows 26.2
-        // vs 34.1 us), the traffic of v and t on large ones (1.6 M rows 159 vs 163 us, banded b = 8 158 vs 169, the
-        // 16.8 M-row Laplacian share 1.14 vs 1.25 ms) -- except with x windows, whose epilogue kernels at 4 waves per
-        // SIMD lose on large blocks (FEM-like 189 vs 175 us). Like the enqueue mode this changes the sequence of
-        // exchanges, so it is decided from facts all ranks share (see fuse_plan_ok), never from the local block alone.
-        c->fuse_small = total / (uint64_t)P < 6000000u;
-    }
-    if (const char *sv = getenv("BICG_OVERLAP")) c->overlap = atoi(sv) != 0;
-    if (const char *sv = knob_x("BICG_SELL_GPW")) c->sell_gpw = atoi(sv);
-    if (const char *sv = knob_x("BICG_SELL_GPW_DOTS")) c->sell_gpw_dots = atoi(sv);
-
-    // ---- halo plan (multi rank): which of x's remote entries this rank needs, who needs ours
-    std::vector<uint32_t> ocol, optr(c->n_loc + 1, 0u);
-    std::vector<double> oval;
-    std::vector<uint32_t> send_idx;
-    c->scnt.assign(P, 0); c->sdsp.assign(P, 0); c->rcnt.assign(P, 0); c->rdsp.assign(P, 0);
-    if (P > 1) {
-        if (offd->rows != c->n_loc) die("bicg_create", "offd block row count differs from diag block");
-        c->nnz_o = offd->ptr[offd->rows];
-        std::vector<uint32_t> halo_cols(c->nnz_o ? c->nnz_o : 1);
-        ocol.resize(c->nnz_o ? c->nnz_o : 1);
-        c->halo = (uint32_t)bicg_halo_plan(offd, info, P, c->n_loc, halo_cols.data(), c->rcnt.data(), ocol.data());
-        optr.assign(offd->ptr, offd->ptr + c->n_loc + 1);
-        oval.assign(offd->val, offd->val + c->nnz_o);
-        for (int p = 1; p < P; ++p) c->rdsp[p] = c->rdsp[p - 1] + c->rcnt[p - 1];
-        // tell every owner which of its rows we need; learn which of ours the others need
-        auto tramp = [](const void *sbuf, const int *sc, const int *sd, void *rbuf, const int *rc, const int *rd, void *user) {
-            static_cast<Comm *>(user)->alltoallv_host(sbuf, sc, sd, rbuf, rc, rd);
-        };
-        const int total = bicg_halo_send_counts(P, c->rcnt.data(), tramp, comm, c->scnt.data());
-        send_idx.resize(total > 0 ? total : 1);
-        const int got = bicg_halo_send_lists(c->rank, P, info, c->n_loc, halo_cols.data(), c->rcnt.data(), c->scnt.data(),
-                                             tramp, comm, send_idx.data());
-        if (got < 0) die("bicg_create", "halo request outside the owner's rows");
-        c->nsend = (uint32_t)got;
-        for (int p = 1; p < P; ++p) c->sdsp[p] = c->sdsp[p - 1] + c->scnt[p - 1];
-    }
-
-    // (BICG_PLAN_TRACE=1: seconds per part of the plan on stderr, rank 0)
-    const bool plan_trace = getenv("BICG_PLAN_TRACE") && atoi(getenv("BICG_PLAN_TRACE")) != 0 && comm->rank == 0;
-    double plan_t = now_sec();
-    auto plan_mark = [&](const char *what) {
-        if (!plan_trace) return;
-        const double t = now_sec();
-        fprintf(stderr, "bicgstab_hip: plan  %-34s %8.4f s\n", what, t - plan_t);
-        plan_t = t;
-    };
-    plan_mark("state, halo plan");
-    // ---- SpMV plan. Rows are cut into groups of 256 (4 slices of 64 rows = one workgroup, lane = row).
-    // Two layouts of a slice: PADDED to its longest row (banded matrices: nothing to pad, 8-byte loads of four
-    // 16-bit column offsets) or JAGGED (ragged rows: step k stores the rows longer than k only; exactly the CSR's
-    // bytes, lane = row kept). Jagged is chosen for the whole block when padding would add > 2 % entries. Groups
-    // with a very long row go to the CSR row-block kernel (strided workgroup reduction of one row). Either kind
-    // is "boundary" when one of its rows has offd entries (it then runs after the halo has landed).
-    const uint32_t nrows = c->n_loc;
-    const uint32_t nslices = (nrows + kSliceRows - 1) / kSliceRows, ngroups = (nrows + kGroupRows - 1) / kGroupRows;
-    // Long rows: lane = row needs 256 rows per workgroup, so a block of few, long rows (banded, half-bandwidth 512:
-    // 23 k rows of 1025 entries = 92 workgroups for 256 CUs) starves the GPU. Such a block goes to the rows-over-lanes
-    // kernel (k_spmv_rows) as a whole: row blocks of <= 8192 non-zeros, a row spread over 8..64 lanes. The row sums
-    // are then associated differently from mult() (tolerance 1e-13 x sum |a_ij x_j| instead of bit-exact).
-    // Decided from the GLOBAL shape (mean row length, rows per rank) so that all ranks agree.
-    {
-        const uint64_t mean_len = info->rows ? nnz_diag_all / info->rows : 0;     // (INFO_Matrix.nz is not always filled in)
-        const uint64_t groups_per_rank = ((uint64_t)info->rows / (uint64_t)P + kGroupRows - 1) / kGroupRows;
-        c->rowsplit = use_sell && (mean_len >= 256 || (mean_len >= 128 && groups_per_rank < 512));
-        if (const char *sv = knob_x("BICG_ROWSPLIT")) c->rowsplit = atoi(sv) != 0;
-        if (c->rowsplit) use_sell = false;
-    }
-    std::vector<uint32_t> slice_len(nslices, 0u), slice_base(nslices, 0u);
-    for (uint32_t r = 0; r < nrows; ++r)
-        slice_len[r / kSliceRows] = std::max(slice_len[r / kSliceRows], diag->ptr[r + 1] - diag->ptr[r]);
-    std::vector<uint32_t> gl_int, gl_bnd;
-    std::vector<uint4> bint, bbnd;
-    std::vector<char> group_is_sell(ngroups, 0);
-    const uint32_t jag_max_row = std::max<uint64_t>(64, nrows ? 4 * (uint64_t)c->nnz_d / nrows : 0);   // 4 x the average row
-    bool jag = false;
-    {
-        uint64_t padded_rows = 0;
-        for (uint32_t sl = 0; sl < nslices; ++sl)
-            padded_rows += (uint64_t)slice_len[sl] * std::min<uint32_t>(kSliceRows, nrows - sl * kSliceRows);
-        jag = padded_rows > (uint64_t)c->nnz_d + c->nnz_d / 50;
-        if (const char *sv = getenv("BICG_SELL_LAYOUT")) jag = !strcmp(sv, "jag") ? true : !strcmp(sv, "pad") ? false : jag;
-    }
-    // x windows in LDS (SellDev::win_*): wanted for ragged rows, where the x gather of one step touches many cache
-    // lines (FEM-like: 63 -> 58 us per SpMV). With equal rows the gathers are perfectly coalesced and the window
-    // only adds staging loads and two barriers per group (Transport-shaped +2 %, 256^3 Laplacian +9 % although its
-    // columns shrink from 32 to 16 bits), so there it is taken on request only: BICG_SELL_WINDOW = 1 asks for it
-    // whenever it fits, 0 never. It needs the jagged layout.
-    const bool jag_auto = jag;
-    int win_env = -1;
-    if (const char *sv = getenv("BICG_SELL_WINDOW")) win_env = atoi(sv);
-    bool want_win = use_sell && win_env != 0 && (win_env == 1 || jag_auto);
-    if (want_win) jag = true;
-    auto group_fits = [&](uint32_t g, uint64_t *stored_out) {
-        const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
-        const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
-        if (jag) {
-            // a lane walks its row alone: an outlier row would keep its wavefront busy long after the launch's other
-            // rows are done, so it goes to the CSR kernel, which spreads one row over a workgroup
-            *stored_out = nnz_g;
-            for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl)
-                if (slice_len[sl] > jag_max_row) return false;
-            return true;
-        }
-        // storage always covers 64 lanes per slice; the criterion only counts lanes that hold a row, so
-        // that the last, partly filled group of a block does not fall to the CSR kernel (an extra
-        // launch per SpMV for a few dozen rows)
-        uint64_t padded = 0, padded_rows = 0;
-        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) {
-            padded += (uint64_t)slice_len[sl] * kSliceRows;
-            padded_rows += (uint64_t)slice_len[sl] * std::min<uint32_t>(kSliceRows, r1 - sl * kSliceRows);
-        }
-        *stored_out = padded;
-        return padded_rows <= nnz_g + nnz_g / 4 + 2 * kSliceRows;
-    };
-    // (Round 1, before the jagged layout: a ragged matrix left only a few groups under the padding limit; two
-    // kernels per SpMV were then slower than the CSR kernel alone -- synth.fem_like 70 vs 63 us -- and sorting rows
-    // by length inside the groups, SELL-C-sigma, removes the padding but also the coalesced x gather: 66.9 us.)
-    bool sell_worthwhile = use_sell;
-    uint64_t sell_entries = 0;
-    std::vector<uint32_t> win_ptr;
-    std::vector<uint2> win_runs;
-    uint32_t win_slots = 0;
-  select_groups:
-    sell_entries = 0; c->sell_nnz = 0; c->sell_rows = 0;
-    gl_int.clear(); gl_bnd.clear();
-    if (use_sell) {
-        uint64_t rows_fit = 0, dummy;
-        for (uint32_t g = 0; g < ngroups; ++g)
-            if (group_fits(g, &dummy)) rows_fit += std::min(nrows, (g + 1) * (uint32_t)kGroupRows) - g * kGroupRows;
-        sell_worthwhile = 2 * rows_fit >= nrows;
-    }
-    for (uint32_t g = 0; g < ngroups; ++g) {
-        const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
-        const uint64_t nnz_g = diag->ptr[r1] - diag->ptr[r0];
-        uint64_t stored = 0;
-        const bool sell = sell_worthwhile && group_fits(g, &stored) && sell_entries + stored < 0xFFFFFF00ull;
-        group_is_sell[g] = sell;
-        if (!sell) continue;
-        for (uint32_t sl = r0 / kSliceRows; sl * kSliceRows < r1; ++sl) {
-            slice_base[sl] = (uint32_t)sell_entries;
-            if (jag) sell_entries += diag->ptr[std::min(nrows, (sl + 1) * (uint32_t)kSliceRows)] - diag->ptr[sl * kSliceRows];
-            else sell_entries += (uint64_t)slice_len[sl] * kSliceRows;
-        }
-        c->sell_nnz += nnz_g; c->sell_rows += r1 - r0;
-        const bool touches_halo = P > 1 && optr[r1] > optr[r0];
-        (touches_halo ? gl_bnd : gl_int).push_back(g);
-    }
-    if (want_win) {
-        // per group: the columns its rows touch, merged into runs of consecutive columns (bicg_plan.cpp)
-        constexpr uint32_t kWinGap = 8;
-        bool ok = sell_entries > 0;
-        long nruns = ok ? bicg_window_plan(diag->ptr, diag->col, nrows, kGroupRows, group_is_sell.data(), kWinMaxSlots, kWinGap,
-                                           nullptr, nullptr, nullptr) : -1;
-        if (nruns >= 0) {
-            win_ptr.assign(ngroups + 1, 0u);
-            win_runs.assign((size_t)nruns + 1, make_uint2(0u, 0u));
-            static_assert(sizeof(uint2) == 2 * sizeof(unsigned int), "run = two 32-bit words");
-            bicg_window_plan(diag->ptr, diag->col, nrows, kGroupRows, group_is_sell.data(), kWinMaxSlots, kWinGap, win_ptr.data(),
-                             reinterpret_cast<unsigned int *>(win_runs.data()), &win_slots);
-        } else {
-            ok = false;
-        }
-        if (!ok) {                          // some group's window does not fit: no windows for this block
-            want_win = false; win_slots = 0; win_runs.clear(); win_ptr.clear();
-            if (!jag_auto) { jag = false; std::fill(group_is_sell.begin(), group_is_sell.end(), 0); goto select_groups; }
-        }
-    }
-    const bool win = want_win && win_slots > 0;
-    auto slot_of = [&](uint32_t g, uint32_t col) -> uint32_t {
-        return bicg_window_slot(reinterpret_cast<const unsigned int *>(win_runs.data()), win_ptr[g], win_ptr[g + 1], col);
-    };
-    // With windows: deal the rows of every group to the lanes by decreasing length (SellDev::perm). The group's
-    // entries stay where they are as a whole; the slices inside it change length.
-    std::vector<unsigned char> perm;
-    if (win && !(knob_x("BICG_SELL_SORT") && atoi(knob_x("BICG_SELL_SORT")) == 0)) {
-        perm.assign((size_t)ngroups * kGroupRows, 0);
-        std::vector<uint32_t> slice_sum(nslices, 0u);             // entries of a slice after the rows were dealt out
-        parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int) {
-            for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g) {
-                unsigned char *pg = perm.data() + (size_t)g * kGroupRows;
-                for (uint32_t t = 0; t < kGroupRows; ++t) pg[t] = (unsigned char)t;
-                if (!group_is_sell[g]) continue;
-                const uint32_t r0 = g * kGroupRows;
-                auto len_of = [&](unsigned t) -> uint32_t { return r0 + t < nrows ? diag->ptr[r0 + t + 1] - diag->ptr[r0 + t] : 0u; };
-                std::stable_sort(pg, pg + kGroupRows, [&](unsigned char x, unsigned char y) { return len_of(x) > len_of(y); });
-                for (uint32_t w = 0; w < kGroupRows / kSliceRows; ++w) {
-                    const uint32_t sl = g * (kGroupRows / kSliceRows) + w;
-                    if (sl >= nslices) break;
-                    uint32_t longest = 0; uint64_t sum = 0;
-                    for (uint32_t l = 0; l < kSliceRows; ++l) { const uint32_t n = len_of(pg[w * kSliceRows + l]); longest = std::max(longest, n); sum += n; }
-                    slice_len[sl] = longest; slice_sum[sl] = (uint32_t)sum;
-                }
-            }
-        });
-        uint64_t at = 0;
-        for (uint32_t g = 0; g < ngroups; ++g) {
-            if (!group_is_sell[g]) continue;
-            for (uint32_t sl = g * (kGroupRows / kSliceRows); sl < std::min(nslices, (g + 1) * (kGroupRows / kSliceRows)); ++sl) { slice_base[sl] = (uint32_t)at; at += slice_sum[sl]; }
-        }
-        if (at != sell_entries) die("bicg_create", "internal: sorted slices do not add up");
-    }
-    auto row_of = [&](uint32_t sl, uint32_t lane) -> uint32_t {      // the row lane `lane` of slice `sl` works on
-        if (perm.empty()) return sl * kSliceRows + lane;
-        const uint32_t g = sl / (kGroupRows / kSliceRows), w = sl % (kGroupRows / kSliceRows);
-        return g * kGroupRows + perm[(size_t)g * kGroupRows + w * kSliceRows + lane];
-    };
-    plan_mark("groups, windows, row order");
-    c->sell_entries = sell_entries;
-    c->sell_jag = jag && sell_entries > 0;
-    // (allocated without a fill: the threads that write a slice also zero its padding -- 330 MB of zeros from one thread were a
-    // third of this part)
-    std::unique_ptr<double[]> sval_mem(new double[sell_entries ? sell_entries : 1]);
-    double *const sval = sval_mem.get();
-    std::unique_ptr<uint32_t[]> scol_mem;                          // filled once it is known whether the 32-bit columns are uploaded
-    // 16-bit column offsets when every sliced-ELL entry is within +-32767 of its row
-    bool c16 = sell_entries > 0 && (win || !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16"))));
-    std::vector<uint32_t> slice_base16(nslices, 0u);
-    uint64_t n16 = 0;
-    if (jag) n16 = sell_entries;
-    else
-        for (uint32_t sl = 0; sl < nslices; ++sl) {
-            slice_base16[sl] = (uint32_t)n16;
-            if (group_is_sell[sl / (kGroupRows / kSliceRows)]) n16 += (uint64_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows;
-        }
-    if (n16 >= 0xFFFFFF00ull) c16 = false;
-    std::vector<int> offsets_seen;          // distinct column offsets (col - row), while they stay few: the fused-window clusters
-    bool offsets_few = true;
-    if (c16 && !win) {
-        // row ranges on several threads, a map of the offsets seen per thread; merged below (ascending: the order does not matter,
-        // the clusters are formed from the sorted list)
-        std::vector<std::vector<unsigned char>> marks((size_t)plan_threads());
-        std::vector<char> bad((size_t)plan_threads(), 0);
-        const int np = parallel_ranges(nrows, 4096, [&](size_t ra, size_t rb, int part) {
-            std::vector<unsigned char> &mark = marks[(size_t)part];
-            mark.assign(65536, 0);
-            for (uint32_t r = (uint32_t)ra; r < (uint32_t)rb && !bad[(size_t)part]; ++r) {
-                if (!group_is_sell[r / kGroupRows]) continue;
-                for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
-                    const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
-                    if (dlt < -32767 || dlt > 32767) { bad[(size_t)part] = 1; break; }
-                    mark[dlt + 32768] = 1;
-                }
-            }
-        });
-        for (int p = 0; p < np; ++p) if (bad[(size_t)p]) c16 = false;
-        for (int d = 0; c16 && d < 65536; ++d) {
-            bool any = false;
-            for (int p = 0; p < np && !any; ++p) any = marks[(size_t)p][(size_t)d] != 0;
-            if (!any) continue;
-            if (offsets_seen.size() >= 4096) { offsets_few = false; break; }
-            offsets_seen.push_back(d - 32768);
-        }
-    }
-    // Fused-window clusters (struct FusedWindow): the offsets fall into <= 4 clusters (gaps of more than 512 columns separate
-    // them) and a group's window -- 256 + span columns per cluster -- fits 2048 LDS slots. Padded slices with 16-bit offsets,
-    // every row on the sliced-ELL path. (The fused product itself is a one-rank form; the windowed SpMM uses the clusters on every rank.)
-    if (c16 && !jag && !win && offsets_few && sell_entries > 0) {
-        offsets_seen.push_back(0);
-        std::sort(offsets_seen.begin(), offsets_seen.end());
-        FusedWindow f{};
-        int ncl = 0, slots = 0;
-        bool ok = true;
-        for (size_t i = 0; i < offsets_seen.size() && ok;) {
-            size_t k = i;
-            while (k + 1 < offsets_seen.size() && offsets_seen[k + 1] - offsets_seen[k] <= 512) ++k;
-            if (ncl == kFwMaxClusters) { ok = false; break; }
-            f.lo[ncl] = offsets_seen[i]; f.hi[ncl] = offsets_seen[k];
-            f.bias[ncl] = slots - f.lo[ncl];
-            slots += kGroupRows + f.hi[ncl] - f.lo[ncl];
-            ++ncl;
-            i = k + 1;
-        }
-        if (ok && slots <= 2048) { f.ncl = ncl; f.slots = (unsigned)slots; c->fw = f; }
-    }
-    plan_mark("column offsets, clusters");
-    const size_t n16_alloc = c16 ? (size_t)n16 : 1;
-    std::unique_ptr<short[]> scol16_mem(new short[n16_alloc]);
-    short *const scol16 = scol16_mem.get();
-    if (!c16) { scol16[0] = 0; scol_mem.reset(new uint32_t[sell_entries ? sell_entries : 1]); }
-    uint32_t *const scol = scol_mem.get();                        // null with 16-bit offsets: the 32-bit columns are not uploaded
-    if (sell_entries == 0) { sval[0] = 0.0; if (scol) scol[0] = 0u; }
-    // Slices on several threads: a slice's entries (and its padding, zeros) are its own range of the arrays.
-    parallel_ranges(nslices, 256, [&](size_t sa, size_t sb, int) {
-        for (uint32_t sl = (uint32_t)sa; sl < (uint32_t)sb; ++sl) {
-            const uint32_t g = sl / (kGroupRows / kSliceRows);
-            if (!group_is_sell[g]) continue;
-            if (jag) {
-                size_t e = slice_base[sl];
-                for (uint32_t k = 0; k < slice_len[sl]; ++k)
-                    for (uint32_t lane = 0; lane < kSliceRows; ++lane) {
-                        const uint32_t r = row_of(sl, lane);
-                        if (r >= nrows || diag->ptr[r + 1] - diag->ptr[r] <= k) continue;
-                        const uint32_t j = diag->ptr[r] + k;
-                        sval[e] = diag->val[j];
-                        if (scol) scol[e] = diag->col[j];
-                        if (win) scol16[e] = (short)(unsigned short)slot_of(g, diag->col[j]);
-                        else if (c16) scol16[e] = (short)((int64_t)diag->col[j] - (int64_t)r);
-                        ++e;
-                    }
-                continue;
-            }
-            const size_t b0 = slice_base[sl], n = (size_t)slice_len[sl] * kSliceRows;
-            std::fill(sval + b0, sval + b0 + n, 0.0);
-            if (scol) std::fill(scol + b0, scol + b0 + n, 0u);
-            if (c16) std::fill(scol16 + slice_base16[sl], scol16 + slice_base16[sl] + (size_t)((slice_len[sl] + 3) / 4) * 4 * kSliceRows, (short)0);
-            for (uint32_t lane = 0; lane < kSliceRows; ++lane) {
-                const uint32_t r = sl * kSliceRows + lane;
-                if (r >= nrows) break;
-                for (uint32_t j = diag->ptr[r], k = 0; j < diag->ptr[r + 1]; ++j, ++k) {
-                    const size_t e = b0 + (size_t)k * kSliceRows + lane;
-                    sval[e] = diag->val[j];
-                    if (scol) scol[e] = diag->col[j];
-                    if (c16) scol16[(size_t)slice_base16[sl] + ((size_t)(k / 4) * kSliceRows + lane) * 4 + (k % 4)] =
-                                 (short)((int64_t)diag->col[j] - (int64_t)r);
-                }
-            }
-        }
-    });
-
-    plan_mark("sliced-ELL arrays");
-    // Uniform slices (SellDev::ubase): all 64 rows present, equally long, entry k at the same distance from its row in
-    // every row. Lists are shared between slices (a banded matrix has ONE for its whole interior) and padded with zeros.
-    std::vector<uint32_t> ubase, vbase, mbase;
-    std::vector<int> uoff;
-    std::vector<double> uval;
-    std::vector<unsigned short> rmask;
-    uint64_t uniform_entries = 0, constant_entries = 0, masked_rows = 0;
-    const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
-    const bool want_masked = !(getenv("BICG_SELL_MASKED") && atoi(getenv("BICG_SELL_MASKED")) == 0);
-    if (!jag && sell_entries > 0 && !(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
-        ubase.assign(nslices, 0xFFFFFFFFu);
-        std::map<std::vector<int>, uint32_t> lists, vlists;
-        std::vector<int> cur, vkey;
-        // which slices are uniform (1) / uniform and constant (2): 64 rows x length comparisons per slice, on several threads; the
-        // lists themselves are numbered by the pass below, in slice order
-        std::vector<char> cls(nslices, 0);
-        parallel_ranges(nslices, 256, [&](size_t sa, size_t sb, int) {
-            for (uint32_t sl = (uint32_t)sa; sl < (uint32_t)sb; ++sl) {
-                if (!group_is_sell[sl / (kGroupRows / kSliceRows)] || (sl + 1) * kSliceRows > nrows || slice_len[sl] == 0) continue;
-                const uint32_t r0 = sl * kSliceRows, len = slice_len[sl], p0 = diag->ptr[r0];
-                bool uni = true;
-                for (uint32_t l = 0; l < kSliceRows && uni; ++l) uni = diag->ptr[r0 + l + 1] - diag->ptr[r0 + l] == len;
-                for (uint32_t l = 1; l < kSliceRows && uni; ++l)
-                    for (uint32_t k = 0; k < len; ++k)
-                        if ((int64_t)diag->col[diag->ptr[r0 + l] + k] - (int64_t)(r0 + l) != (int64_t)diag->col[p0 + k] - (int64_t)r0) { uni = false; break; }
-                if (!uni) continue;
-                bool con = want_constant;
-                for (uint32_t l = 1; l < kSliceRows && con; ++l) con = memcmp(diag->val + diag->ptr[r0 + l], diag->val + p0, sizeof(double) * len) == 0;
-                cls[sl] = con ? 2 : 1;
-            }
-        });
-        for (uint32_t sl = 0; sl < nslices; ++sl) {
-            if (!group_is_sell[sl / (kGroupRows / kSliceRows)] || (sl + 1) * kSliceRows > nrows || slice_len[sl] == 0) continue;
-            const uint32_t r0 = sl * kSliceRows, len = slice_len[sl];
-            const bool uni = cls[sl] != 0;
-            if (uni) {
-                cur.assign(len, 0);
-                for (uint32_t k = 0; k < len; ++k) cur[k] = (int)((int64_t)diag->col[diag->ptr[r0] + k] - (int64_t)r0);
-            }
-            if (!uni) {
-                // masked slice (SellDev::mbase): the rows are sub-sequences of one ascending list of <= 16 (distance, value) pairs
-                if (!want_constant || !want_masked) continue;
-                std::map<int, long long> un;                                      // distance -> value bits
-                bool ok = true;
-                for (uint32_t l = 0; l < kSliceRows && ok; ++l) {
-                    const uint32_t p0 = diag->ptr[r0 + l], p1 = diag->ptr[r0 + l + 1];
-                    ok = p1 > p0 && p1 - p0 <= 16u;
-                    for (uint32_t j = p0; j < p1 && ok; ++j) {
-                        if (j > p0 && diag->col[j] <= diag->col[j - 1]) { ok = false; break; }      // ascending columns
-                        const int d = (int)((int64_t)diag->col[j] - (int64_t)(r0 + l));
-                        long long b; memcpy(&b, diag->val + j, 8);
-                        auto f = un.find(d);
-                        if (f == un.end()) un.emplace(d, b); else ok = f->second == b;
-                    }
-                    ok = ok && un.size() <= 16u;
-                }
-                if (!ok) continue;
-                const uint32_t ulen = (uint32_t)un.size();
-                cur.clear(); vkey.clear();
-                std::vector<double> uv_list;
-                for (auto &kv : un) { cur.push_back(kv.first); double v; memcpy(&v, &kv.second, 8); uv_list.push_back(v); }
-                vkey.assign(cur.begin(), cur.end());
-                for (auto &kv : un) { vkey.push_back((int)(kv.second & 0xFFFFFFFF)); vkey.push_back((int)(kv.second >> 32)); }
-                auto it = lists.find(cur);
-                if (it == lists.end()) {
-                    if (uoff.size() + ulen + 32 > (1u << 24)) continue;
-                    it = lists.emplace(cur, (uint32_t)uoff.size()).first;
-                    uoff.insert(uoff.end(), cur.begin(), cur.end());
-                    uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);
-                }
-                auto vt = vlists.find(vkey);
-                if (vt == vlists.end()) {
-                    if (uval.size() + ulen + 32 > (1u << 22)) continue;
-                    vt = vlists.emplace(vkey, (uint32_t)uval.size()).first;
-                    uval.insert(uval.end(), uv_list.begin(), uv_list.end());
-                    uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
-                }
-                if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
-                if (mbase.empty()) mbase.assign(nslices, 0xFFFFFFFFu);
-                ubase[sl] = it->second; vbase[sl] = vt->second;
-                mbase[sl] = (ulen << 26) | (uint32_t)(rmask.size() / kSliceRows);
-                for (uint32_t l = 0; l < kSliceRows; ++l) {
-                    unsigned m = 0;
-                    for (uint32_t j = diag->ptr[r0 + l]; j < diag->ptr[r0 + l + 1]; ++j) {
-                        const int d = (int)((int64_t)diag->col[j] - (int64_t)(r0 + l));
-                        m |= 1u << (unsigned)std::distance(un.begin(), un.find(d));
-                    }
-                    rmask.push_back((unsigned short)m);
-                }
-                uniform_entries += (uint64_t)len * kSliceRows; constant_entries += (uint64_t)len * kSliceRows;     // (padded entries the product no longer reads)
-                masked_rows += kSliceRows;
-                continue;
-            }
-            auto it = lists.find(cur);
-            if (it == lists.end()) {
-                if (uoff.size() + len + 32 > (1u << 24)) continue;            // the table stays small (scalar cache)
-                it = lists.emplace(cur, (uint32_t)uoff.size()).first;
-                uoff.insert(uoff.end(), cur.begin(), cur.end());
-                uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);               // batches of up to 16 entries read past the list
-            }
-            ubase[sl] = it->second;
-            uniform_entries += (uint64_t)len * kSliceRows;
-            // constant slice: entry k holds the same value in all 64 rows (SellDev::vbase)
-            if (!want_constant) continue;
-            const double *v0 = diag->val + diag->ptr[r0];
-            if (cls[sl] != 2) continue;
-            vkey.assign(cur.begin(), cur.end());                                  // distances, then the value bits
-            for (uint32_t k = 0; k < len; ++k) { long long b; memcpy(&b, v0 + k, 8); vkey.push_back((int)(b & 0xFFFFFFFF)); vkey.push_back((int)(b >> 32)); }
-            auto vt = vlists.find(vkey);
-            if (vt == vlists.end()) {
-                if (uval.size() + len + 32 > (1u << 22)) continue;
-                vt = vlists.emplace(vkey, (uint32_t)uval.size()).first;
-                uval.insert(uval.end(), v0, v0 + len);
-                uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
-            }
-            if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
-            vbase[sl] = vt->second;
-            constant_entries += (uint64_t)len * kSliceRows;
-        }
-        if (uniform_entries == 0) { ubase.clear(); uoff.clear(); }
-    }
-    c->uniform_entries = uniform_entries;
-    c->constant_entries = constant_entries;
-    c->masked_rows = masked_rows;
-
-    plan_mark("uniform / constant / masked slices");
-    // CSR row blocks over the maximal runs of non-SELL groups
-    std::vector<uint32_t> rb(nrows + 1);
-    for (uint32_t g = 0; g < ngroups;) {
-        if (group_is_sell[g]) { ++g; continue; }
-        uint32_t g1 = g;
-        while (g1 < ngroups && !group_is_sell[g1]) ++g1;
-        const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, g1 * kGroupRows);
-        // bicg_row_blocks works on a ptr array that starts at the run's first row
-        const uint32_t nb = c->rowsplit ? bicg_row_blocks(diag->ptr + r0, r1 - r0, 8192, 256, rb.data())
-                                        : bicg_row_blocks(diag->ptr + r0, r1 - r0, kRowBlockNnz, 1024, rb.data());
-        for (uint32_t b = 0; b < nb; ++b) {
-            const uint32_t a0 = r0 + rb[b], a1 = r0 + rb[b + 1];
-            const bool touches_halo = P > 1 && optr[a1] > optr[a0];
-            (touches_halo ? bbnd : bint).push_back(make_uint4(a0, a1, diag->ptr[a0], diag->ptr[a1]));
-        }
-        g = g1;
-    }
-    c->n_int = (uint32_t)bint.size(); c->n_bnd = (uint32_t)bbnd.size();
-    c->nblk = c->n_int + c->n_bnd;
-    c->ng_int = (uint32_t)gl_int.size(); c->ng_bnd = (uint32_t)gl_bnd.size();
-    c->glist_int_identity = c->ng_int == ngroups;     // every group, in order: index directly
-    c->glist_all = c->ng_int + c->ng_bnd == ngroups;
-
-    plan_mark("row blocks");
-    // ---- upload
-    // Only what some kernel reads goes to the GPU: the CSR val/col arrays when there are row blocks for the
-    // CSR kernel (none for banded matrices: everything is on the sliced-ELL path), the 32-bit sliced-ELL
-    // columns when the 16-bit offsets do not apply. (Round 1 kept all of them: 2.3 x the matrix.)
-    const bool need_csr = c->nblk > 0;
-    bool csr16 = c->rowsplit && need_csr && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
-    std::vector<short> dcol16;
-    if (csr16) {                  // rows-over-lanes kernel: 16-bit column offsets in CSR order when every entry fits
-        dcol16.resize((size_t)c->nnz_d + kPadEntries, 0);
-        for (uint32_t r = 0; csr16 && r < nrows; ++r)
-            for (uint32_t j = diag->ptr[r]; j < diag->ptr[r + 1]; ++j) {
-                const int64_t dlt = (int64_t)diag->col[j] - (int64_t)r;
-                if (dlt < -32767 || dlt > 32767) { csr16 = false; break; }
-                dcol16[j] = (short)dlt;
-            }
-    }
-    c->d_val = dev_upload_padded(diag->val, need_csr ? c->nnz_d : 0, kPadEntries);
-    c->d_col = dev_upload_padded(diag->col, need_csr && !csr16 ? c->nnz_d : 0, kPadEntries);
-    if (csr16) c->d_col16 = dev_upload(dcol16.data(), dcol16.size());
-    c->d_ptr = dev_upload(diag->ptr, (size_t)c->n_loc + 1);
-    c->o_val = dev_upload(oval.data(), c->nnz_o);
-    c->o_col = dev_upload(ocol.data(), c->nnz_o);
-    c->o_ptr = dev_upload(optr.data(), (size_t)c->n_loc + 1);
-    c->desc_int = dev_upload(bint.data(), bint.size());
-    c->desc_bnd = dev_upload(bbnd.data(), bbnd.size());
-    // (jagged slices: lanes whose row has ended read up to one entry past the last -- kPadEntries of slack)
-    c->s_val = dev_upload_padded(sval, (size_t)sell_entries, kPadEntries);
-    c->s_col = dev_upload_padded(scol, c16 ? 0 : (size_t)sell_entries, kPadEntries);
-    c->matrix_bytes = (uint64_t)sell_entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 2ull * masked_rows + 8ull * nslices + 4ull * (nrows + 1) +
-                      (uint64_t)(c->nnz_d - c->sell_nnz) * (csr16 ? 10 : 12) + (uint64_t)c->nnz_o * 12;
-    if (!vbase.empty()) {
-        c->s_vbase = dev_upload(vbase.data(), vbase.size());
-        c->s_uval = dev_upload(uval.data(), uval.size());
-    }
-    if (!mbase.empty()) {
-        c->s_mbase = dev_upload(mbase.data(), mbase.size());
-        c->s_rmask = dev_upload(rmask.data(), rmask.size());
-    }
-    if (!ubase.empty()) {
-        c->s_ubase = dev_upload(ubase.data(), ubase.size());
-        c->s_uoff = dev_upload(uoff.data(), uoff.size());
-    }
-    build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase, uoff, uval, rmask.empty() ? nullptr : rmask.data());
-    c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
-                             8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
-    if (c16) {
-        c->s_col16 = dev_upload_padded(scol16, n16_alloc, kPadEntries);
-        c->s_base16 = dev_upload(slice_base16.data(), slice_base16.size());
-    }
-    if (win) {
-        c->win_ptr = dev_upload(win_ptr.data(), win_ptr.size());
-        c->win_runs = dev_upload(win_runs.data(), win_runs.size());
-        c->win_slots = win_slots;
-        for (uint32_t g = 0; g < ngroups; ++g) c->win_max_runs = std::max(c->win_max_runs, win_ptr[g + 1] - win_ptr[g]);
-        if (!perm.empty()) c->sell_perm = dev_upload(perm.data(), perm.size());
-        // SellDev::lane_info: row in the group + its length per lane, in the order the lanes work (perm or natural)
-        {
-            std::vector<unsigned short> li((size_t)ngroups * kGroupRows, 0);
-            std::vector<char> too_long((size_t)plan_threads(), 0);
-            parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int part) {
-                for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g)
-                    for (uint32_t t = 0; t < kGroupRows; ++t) {
-                        const uint32_t in_group = perm.empty() ? t : perm[(size_t)g * kGroupRows + t], r = g * kGroupRows + in_group;
-                        const uint32_t n = (r < nrows && group_is_sell[g]) ? diag->ptr[r + 1] - diag->ptr[r] : 0u;
-                        if (n > 255u) too_long[(size_t)part] = 1;
-                        li[(size_t)g * kGroupRows + t] = (unsigned short)(in_group | (n << 8));
-                    }
-            });
-            bool ok = true;
-            for (char b : too_long) ok = ok && !b;
-            if (ok) {
-                c->lane_info = dev_upload(li.data(), li.size());
-                c->matrix_bytes += 2ull * li.size();
-                c->device_matrix_bytes += 2ull * li.size();
-            }
-            if (const char *v = getenv("BICG_JAGW")) c->jagw_fast = atoi(v) != 0;
-        }
-        c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
-        c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
-    }
-    c->s_base = dev_upload(slice_base.data(), slice_base.size());
-    c->s_len = dev_upload(slice_len.data(), slice_len.size());
-    c->glist_int = dev_upload(gl_int.data(), gl_int.size());
-    c->glist_bnd = dev_upload(gl_bnd.data(), gl_bnd.size());
-    c->send_idx = dev_upload(send_idx.data(), c->nsend);
-    c->sendbuf = dev_alloc<double>(c->nsend);
-
-    plan_mark("upload");
-    // ---- peer-to-peer transport: publish this rank's halo landing ring, learn where every entry
-    // of the send list lands in the ring of the rank that needs it (collective)
-    c->p2p = comm->p2p;
-    std::vector<unsigned long long> dst0, dstride;
-    if (const char *sv = getenv("BICG_P2P_FAULT_AFTER")) c->fault_after = atoi(sv);
-    // in-kernel collect needs the HEAVY kernel instantiations (occupancy 5 instead of 8 waves per SIMD,
-    // ~3 % per SpMV): worth it unless the local problem is so large that 3 % exceeds the ~10 us per
-    // iteration the separate apply kernels cost
-    c->inline_apply = c->nnz_d < 40000000u;
-    if (const char *sv = knob_x("BICG_P2P_INLINE_APPLY")) c->inline_apply = atoi(sv) != 0;
-    if (c->p2p && !c->single()) {
-        c->halo_ring = (llword *)c->p2p->alloc(sizeof(llword) * 2 * (size_t)kHaloRing * c->halo);
-        std::vector<void *> rings;
-        if (c->p2p->share(c->halo_ring, rings, c->ring_mapped) != 0)
-            die("bicg_create", "could not map the halo rings of the other ranks (peer-to-peer transport)");
-        // to rank p: where ITS values land in my ring, and my ring's slot size
-        std::vector<int> mine(2 * (size_t)P), theirs(2 * (size_t)P, 0), cnt(P, 2 * (int)sizeof(int)), dsp(P);
-        for (int p = 0; p < P; ++p) {
-            mine[2 * p] = c->rdsp[p]; mine[2 * p + 1] = (int)c->halo;
-            dsp[p] = 2 * p * (int)sizeof(int);
-        }
-        comm->alltoallv_host(mine.data(), cnt.data(), dsp.data(), theirs.data(), cnt.data(), dsp.data());
-        dst0.assign(c->nsend ? c->nsend : 1, 0ull); dstride.assign(c->nsend ? c->nsend : 1, 0ull);
-        for (int p = 0; p < P; ++p)
-            for (int j = 0; j < c->scnt[p]; ++j) {
-                const size_t i = (size_t)c->sdsp[p] + j;
-                dst0[i] = (unsigned long long)(uintptr_t)rings[p] + 16ull * ((unsigned long long)theirs[2 * p] + j);
-                dstride[i] = 16ull * (unsigned long long)theirs[2 * p + 1];
-            }
-        c->push_dst0 = dev_upload(dst0.data(), dst0.size());
-        c->push_stride = dev_upload(dstride.data(), dstride.size());
-        c->ll_fused = c->n_bnd == 0 && c->ng_int + c->ng_bnd > 0;
-        if (const char *sv = knob_x("BICG_P2P_FUSED")) c->ll_fused = c->ll_fused && atoi(sv) != 0;
-        if (c->ll_fused) {
-            std::vector<uint32_t> order(gl_int);
-            order.insert(order.end(), gl_bnd.begin(), gl_bnd.end());
-            c->glist_ll = dev_upload(order.data(), order.size());
-        }
-    } else {
-        c->p2p = nullptr;
-    }
-
-    ctx_state(c, comm, ngroups);
-    if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
-    // Round 4: with the products alternating direction and reading no column index in uniform slices, a big block is faster
-    // as two plain products + two element-wise kernels (Transport-shaped, one GPU: 139.0 vs 152.0 us per pipelined iteration;
-    // profiles/NOTES.md): the fused two-launch form stays what it was built for -- the latency-bound ranks.
-    c->fuse_pipe = c->fuse_small;
-    if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
-    else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
-    c->spmm_ok = all_ranks(comm, spmm_possible(c));
-    c->fuse_plan_ok = all_ranks(comm, c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused)));
-    BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
-    memset(c->hS, 0, sizeof(Scal));
-    {   // persistent pipelined iteration for latency-bound ranks: available when the plan fits on EVERY rank
-        const char *pe = getenv("BICG_PERSIST");
-        bool mine = !(pe && atoi(pe) == 0) && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
-        c->persist_on = all_ranks(comm, mine);
-        if (const char *pp = knob_x("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
-        if (const char *pp = knob_x("BICG_FUSE_PLAIN")) c->fuse_plain = atoi(pp) != 0;
-        if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
-    }
-
-    plan_mark("transport, persistent plan");
-    ctx_streams(c, P);
-    plan_mark("streams");
-    preload_for(c);
-    plan_mark("code objects");
-    return c;
-}
-
-// Single rank, the matrix ALREADY in device memory as CSR: the sliced-ELL plan (slice lengths, bases, the column-major
-// padded copy, 16-bit column offsets when they fit) is built by kernels (bicg_plan_device.hip) -- no host copy of the
-// matrix ever exists. This is what makes BASELINE.json configs[3] at its stated size fit a bench run: the 512^3 Laplacian
-// (134 M rows, 938 M non-zeros, 11 GB of CSR) is generated on the GPU (bicg_stencil7_device) and planned in a fraction of
-// a second, where the one-thread host plan of bicg_create would take the better part of a minute after a 15 GB transfer.
-// Blocks whose rows are too ragged for padded slices (or long enough for the rows-over-lanes kernel) are refused: the
-// caller downloads the CSR and takes bicg_create.
-bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d, const unsigned int *ptr_d, unsigned int rows,
-                                 double *plan_seconds)
-{
-    Comm *comm = comm_get();
-    BICG_HIP(hipSetDevice(comm->device));
-    if (comm->nranks != 1) { fprintf(stderr, "ERROR: bicg_create_device_csr: single rank only\n"); return nullptr; }
-    if (rows == 0) { fprintf(stderr, "ERROR: bicg_create_device_csr: empty matrix\n"); return nullptr; }
-    const double t0 = now_sec();
-    unsigned nnz = 0;
-    BICG_HIP(hipMemcpy(&nnz, ptr_d + rows, sizeof(unsigned), hipMemcpyDeviceToHost));
-    const uint32_t nslices = (rows + kSliceRows - 1) / kSliceRows, ngroups = (rows + kGroupRows - 1) / kGroupRows;
-    uint32_t *slen_d = dev_alloc<uint32_t>(nslices);
-    int *far_d = dev_alloc<int>(1);
-    BICG_HIP(hipMemset(slen_d, 0, sizeof(uint32_t) * nslices));
-    BICG_HIP(hipMemset(far_d, 0, sizeof(int)));
-    launch_plan_rowstats(ptr_d, col_d, rows, slen_d, far_d, nullptr);
-    std::vector<uint32_t> slen(nslices), sbase(nslices), sbase16(nslices);
-    int far = 0;
-    BICG_HIP(hipMemcpy(slen.data(), slen_d, sizeof(uint32_t) * nslices, hipMemcpyDeviceToHost));
-    BICG_HIP(hipMemcpy(&far, far_d, sizeof(int), hipMemcpyDeviceToHost));
-    uint64_t entries = 0, n16 = 0, padded_rows = 0;
-    uint32_t longest = 0;
-    for (uint32_t sl = 0; sl < nslices; ++sl) {
-        sbase[sl] = (uint32_t)entries; sbase16[sl] = (uint32_t)n16;
-        entries += (uint64_t)slen[sl] * kSliceRows;
-        n16 += (uint64_t)((slen[sl] + 3) / 4) * 4 * kSliceRows;
-        padded_rows += (uint64_t)slen[sl] * std::min<uint32_t>(kSliceRows, rows - sl * kSliceRows);
-        longest = std::max(longest, slen[sl]);
-    }
-    const bool c16 = !far && n16 < 0xFFFFFF00ull && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
-    const char *why = nullptr;
-    if (entries >= 0xFFFFFF00ull) why = "more than 2^32 sliced-ELL entries";
-    else if (padded_rows > (uint64_t)nnz + nnz / 50) why = "ragged rows (jagged slices are planned on the host)";
-    else if ((uint64_t)nnz / rows >= 128 && ngroups < 512) why = "long rows (the rows-over-lanes plan is built on the host)";
-    else if (longest > std::max<uint64_t>(64, 4 * (uint64_t)nnz / rows)) why = "a row much longer than the average";
-    if (why) {
-        fprintf(stderr, "bicgstab_hip: bicg_create_device_csr: %s -- use bicg_create\n", why);
-        BICG_HIP(hipFree(slen_d)); BICG_HIP(hipFree(far_d));
-        return nullptr;
-    }
-    bicg_ctx *c = new bicg_ctx;
-    c->comm = comm; c->device = comm->device; c->nranks = 1; c->rank = 0;
-    g_live.push_back(c);
-    c->n_loc = rows; c->n_glob = rows; c->nnz_d = nnz;
-    if (const char *sv = knob_x("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
-    if (const char *sv = knob_x("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
-    if (const char *sv = knob_x("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
-    if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
-    if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
-    c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;
-    c->scnt.assign(1, 0); c->sdsp.assign(1, 0); c->rcnt.assign(1, 0); c->rdsp.assign(1, 0);
-    c->sell_entries = entries; c->sell_nnz = nnz; c->sell_rows = rows; c->sell_jag = false;
-    c->s_val = dev_alloc<double>((size_t)entries + kPadEntries);
-    BICG_HIP(hipMemset(c->s_val, 0, sizeof(double) * ((size_t)entries + kPadEntries)));
-    if (c16) {
-        c->s_col16 = dev_alloc<short>((size_t)n16 + kPadEntries);
-        BICG_HIP(hipMemset(c->s_col16, 0, sizeof(short) * ((size_t)n16 + kPadEntries)));
-        c->s_base16 = dev_upload(sbase16.data(), sbase16.size());
-        c->s_col = dev_alloc<uint32_t>(kPadEntries);
-    } else {
-        c->s_col = dev_alloc<uint32_t>((size_t)entries + kPadEntries);
-        BICG_HIP(hipMemset(c->s_col, 0, sizeof(uint32_t) * ((size_t)entries + kPadEntries)));
-    }
-    c->s_base = dev_upload(sbase.data(), sbase.size());
-    c->s_len = slen_d;
-    launch_plan_fill(ptr_d, col_d, val_d, rows, c->s_base, c->s_base16, c->s_val, c16 ? nullptr : c->s_col, c16 ? c->s_col16 : nullptr, nullptr);
-    // uniform slices (SellDev::ubase): found by a kernel, grouped by the hash of their distance lists here; one list per group
-    // is fetched from the CSR (a stencil has a few dozen)
-    uint64_t uniform_entries = 0, constant_entries = 0;
-    uint32_t far_rows = 0;
-    if (!(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
-        const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
-        unsigned long long *uh_d = dev_alloc<unsigned long long>(2 * (size_t)nslices), *vh_d = uh_d + nslices;
-        BICG_HIP(hipMemset(uh_d, 0, sizeof(unsigned long long) * 2 * (size_t)nslices));
-        launch_plan_uniform(ptr_d, col_d, val_d, rows, uh_d, want_constant ? vh_d : nullptr, nullptr);
-        std::vector<unsigned long long> uh(nslices), vh(nslices);
-        BICG_HIP(hipMemcpy(uh.data(), uh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
-        BICG_HIP(hipMemcpy(vh.data(), vh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
-        BICG_HIP(hipFree(uh_d));
-        // tests: every hash lands in one of TWO buckets -- slices with different lists collide in their thousands and
-        // k_plan_verify has to catch each one (tests/test_full_size.py::test_device_plan_survives_hash_collisions)
-        const bool collide = getenv("BICG_PLAN_TEST_COLLIDE") && atoi(getenv("BICG_PLAN_TEST_COLLIDE")) != 0;
-        if (collide) for (uint32_t sl = 0; sl < nslices; ++sl) { if (uh[sl]) uh[sl] = 1ull + (uh[sl] >> 63); if (vh[sl]) vh[sl] = 1ull + (vh[sl] >> 63); }
-        std::vector<uint32_t> vbase, mbase;
-        std::vector<double> uval, vals;
-        std::map<unsigned long long, uint32_t> vlists;
-        std::vector<uint32_t> ubase(nslices, 0xFFFFFFFFu);
-        std::vector<int> uoff;
-        std::map<unsigned long long, uint32_t> lists;
-        std::vector<uint32_t> cols;
-        for (uint32_t sl = 0; sl < nslices; ++sl) {
-            if (!uh[sl]) continue;
-            auto it = lists.find(uh[sl]);
-            if (it == lists.end()) {
-                if (lists.size() >= 4096) continue;                           // not a structured matrix: leave the rest to col / col16
-                const uint32_t r0 = sl * kSliceRows, len = slen[sl];
-                uint32_t p0 = 0;
-                BICG_HIP(hipMemcpy(&p0, ptr_d + r0, sizeof(uint32_t), hipMemcpyDeviceToHost));
-                cols.resize(len);
-                BICG_HIP(hipMemcpy(cols.data(), col_d + p0, sizeof(uint32_t) * len, hipMemcpyDeviceToHost));
-                it = lists.emplace(uh[sl], (uint32_t)uoff.size()).first;
-                for (uint32_t k = 0; k < len; ++k) uoff.push_back((int)((int64_t)cols[k] - (int64_t)r0));
-                uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);
-            }
-            ubase[sl] = it->second;
-            uniform_entries += (uint64_t)slen[sl] * kSliceRows;
-            if (!vh[sl]) continue;                                                // constant slice (SellDev::vbase)
-            auto vt = vlists.find(vh[sl]);
-            if (vt == vlists.end()) {
-                if (vlists.size() >= 4096) continue;
-                const uint32_t r0 = sl * kSliceRows, len = slen[sl];
-                uint32_t p0 = 0;
-                BICG_HIP(hipMemcpy(&p0, ptr_d + r0, sizeof(uint32_t), hipMemcpyDeviceToHost));
-                vals.resize(len);
-                BICG_HIP(hipMemcpy(vals.data(), val_d + p0, sizeof(double) * len, hipMemcpyDeviceToHost));
-                vt = vlists.emplace(vh[sl], (uint32_t)uval.size()).first;
-                uval.insert(uval.end(), vals.begin(), vals.end());
-                uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
-            }
-            if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
-            vbase[sl] = vt->second;
-            constant_entries += (uint64_t)slen[sl] * kSliceRows;
-        }
-        for (int d : uoff) far_rows = std::max<uint32_t>(far_rows, (uint32_t)std::abs(d));      // the farthest distance of a uniform slice
-        // masked slices (SellDev::mbase): the slices next to a grid face. Found by a kernel (hash of the slice's list of
-        // (distance, value) pairs), one representative per hash is fetched and its list rebuilt here, the rows' masks are
-        // written by a second pass over the slices that were kept.
-        if (want_constant && !(getenv("BICG_SELL_MASKED") && atoi(getenv("BICG_SELL_MASKED")) == 0)) {
-            unsigned long long *mh_d = dev_alloc<unsigned long long>(nslices);
-            BICG_HIP(hipMemset(mh_d, 0, sizeof(unsigned long long) * nslices));
-            launch_plan_masked(ptr_d, col_d, val_d, rows, mh_d, nullptr, nullptr, nullptr);
-            std::vector<unsigned long long> mh(nslices);
-            BICG_HIP(hipMemcpy(mh.data(), mh_d, sizeof(unsigned long long) * nslices, hipMemcpyDeviceToHost));
-            BICG_HIP(hipFree(mh_d));
-            if (collide) for (uint32_t sl = 0; sl < nslices; ++sl) if (mh[sl]) mh[sl] = (mh[sl] & 31ull) | (32ull << (mh[sl] >> 63));
-            std::map<unsigned long long, std::pair<uint32_t, uint32_t>> mlists;       // hash -> (position in uoff, position in uval)
-            std::vector<uint32_t> rp(kSliceRows + 1), rc;
-            std::vector<double> rv;
-            uint32_t nmasked = 0;
-            for (uint32_t sl = 0; sl < nslices; ++sl) {
-                if (ubase[sl] != 0xFFFFFFFFu || !mh[sl] || (sl + 1) * kSliceRows > rows) continue;
-                const uint32_t ulen = (uint32_t)(mh[sl] & 31ull);
-                auto it = mlists.find(mh[sl]);
-                if (it == mlists.end()) {
-                    if (mlists.size() >= 4096) continue;
-                    const uint32_t r0 = sl * kSliceRows;
-                    BICG_HIP(hipMemcpy(rp.data(), ptr_d + r0, sizeof(uint32_t) * (kSliceRows + 1), hipMemcpyDeviceToHost));
-                    const uint32_t ne = rp[kSliceRows] - rp[0];
-                    rc.resize(ne); rv.resize(ne);
-                    BICG_HIP(hipMemcpy(rc.data(), col_d + rp[0], sizeof(uint32_t) * ne, hipMemcpyDeviceToHost));
-                    BICG_HIP(hipMemcpy(rv.data(), val_d + rp[0], sizeof(double) * ne, hipMemcpyDeviceToHost));
-                    std::map<int, double> un;
-                    for (uint32_t l = 0; l < kSliceRows; ++l)
-                        for (uint32_t j = rp[l]; j < rp[l + 1]; ++j) un.emplace((int)((int64_t)rc[j - rp[0]] - (int64_t)(r0 + l)), rv[j - rp[0]]);
-                    if (un.size() != ulen) continue;                              // (cannot happen: the kernel built the same list)
-                    it = mlists.emplace(mh[sl], std::make_pair((uint32_t)uoff.size(), (uint32_t)uval.size())).first;
-                    for (auto &kv : un) { uoff.push_back(kv.first); uval.push_back(kv.second); far_rows = std::max<uint32_t>(far_rows, (uint32_t)std::abs(kv.first)); }
-                    uoff.resize((uoff.size() + 7) / 8 * 8 + 16, 0);
-                    uval.resize((uval.size() + 7) / 8 * 8 + 16, 0.0);
-                }
-                if (mbase.empty()) mbase.assign(nslices, 0xFFFFFFFFu);
-                if (vbase.empty()) vbase.assign(nslices, 0xFFFFFFFFu);
-                ubase[sl] = it->second.first; vbase[sl] = it->second.second;
-                mbase[sl] = (ulen << 26) | nmasked++;
-                uniform_entries += (uint64_t)slen[sl] * kSliceRows; constant_entries += (uint64_t)slen[sl] * kSliceRows;
-            }
-            if (nmasked) {
-                c->s_mbase = dev_upload(mbase.data(), mbase.size());
-                c->s_rmask = dev_alloc<unsigned short>((size_t)nmasked * kSliceRows);
-                BICG_HIP(hipMemset(c->s_rmask, 0, sizeof(unsigned short) * (size_t)nmasked * kSliceRows));
-                launch_plan_masked(ptr_d, col_d, val_d, rows, nullptr, c->s_mbase, c->s_rmask, nullptr);
-                BICG_HIP(hipDeviceSynchronize());
-                c->masked_rows = (uint64_t)nmasked * kSliceRows;
-            }
-        }
-        if (uniform_entries) {
-            c->s_ubase = dev_upload(ubase.data(), ubase.size());
-            c->s_uoff = dev_upload(uoff.data(), uoff.size());
-        }
-        if (constant_entries) {
-            c->s_vbase = dev_upload(vbase.data(), vbase.size());
-            c->s_uval = dev_upload(uval.data(), uval.size());
-        }
-        // The groups above are keyed by 64-bit hashes: every list-driven slice is now compared with the list it was given
-        // (k_plan_verify), and a slice that differs -- a collision -- goes back to its stored columns and values, which
-        // launch_plan_fill has written for every slice. (The host plan keys on the full lists and needs no such pass.)
-        if (uniform_entries) {
-            unsigned char *bad_d = dev_alloc<unsigned char>(nslices);
-            BICG_HIP(hipMemset(bad_d, 0, nslices));
-            launch_plan_verify(ptr_d, col_d, val_d, rows, slen_d, c->s_ubase, c->s_vbase, c->s_mbase, c->s_rmask, c->s_uoff, c->s_uval, bad_d, nullptr);
-            std::vector<unsigned char> bad(nslices);
-            BICG_HIP(hipMemcpy(bad.data(), bad_d, nslices, hipMemcpyDeviceToHost));
-            BICG_HIP(hipFree(bad_d));
-            uint32_t nbad = 0;
-            for (uint32_t sl = 0; sl < nslices; ++sl) {
-                if (!bad[sl]) continue;
-                ++nbad;
-                const uint64_t e = (uint64_t)slen[sl] * kSliceRows;
-                uniform_entries -= e;
-                if (!vbase.empty() && vbase[sl] != 0xFFFFFFFFu) { constant_entries -= e; vbase[sl] = 0xFFFFFFFFu; }
-                if (!mbase.empty() && mbase[sl] != 0xFFFFFFFFu) { c->masked_rows -= kSliceRows; mbase[sl] = 0xFFFFFFFFu; }
-                ubase[sl] = 0xFFFFFFFFu;
-            }
-            c->plan_collisions = nbad;
-            if (nbad) {
-                BICG_HIP(hipMemcpy(c->s_ubase, ubase.data(), sizeof(uint32_t) * nslices, hipMemcpyHostToDevice));
-                if (c->s_vbase) BICG_HIP(hipMemcpy(c->s_vbase, vbase.data(), sizeof(uint32_t) * nslices, hipMemcpyHostToDevice));
-                if (c->s_mbase) BICG_HIP(hipMemcpy(c->s_mbase, mbase.data(), sizeof(uint32_t) * nslices, hipMemcpyHostToDevice));
-                if (getenv("BICG_PLAN_TRACE")) fprintf(stderr, "bicgstab_hip: %u list-driven slices did not match their list (hash collision): stored as general slices\n", nbad);
-            }
-        }
-        if (constant_entries) build_slice_desc(c, nslices, rows, slen.data(), ubase, vbase, mbase, uoff, uval, nullptr);
-    }
-    c->uniform_entries = uniform_entries;
-    c->constant_entries = constant_entries;
-    c->far_rows = far_rows;
-    c->d_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
-    BICG_HIP(hipMemcpy(c->d_ptr, ptr_d, sizeof(uint32_t) * ((size_t)rows + 1), hipMemcpyDeviceToDevice));
-    c->d_val = dev_alloc<double>(kPadEntries); c->d_col = dev_alloc<uint32_t>(kPadEntries);
-    c->o_val = dev_alloc<double>(1); c->o_col = dev_alloc<uint32_t>(1);
-    c->o_ptr = dev_alloc<uint32_t>((size_t)rows + 1);
-    BICG_HIP(hipMemset(c->o_ptr, 0, sizeof(uint32_t) * ((size_t)rows + 1)));
-    c->desc_int = dev_alloc<uint4>(1); c->desc_bnd = dev_alloc<uint4>(1);
-    c->glist_int = dev_alloc<uint32_t>(1); c->glist_bnd = dev_alloc<uint32_t>(1);
-    c->send_idx = dev_alloc<uint32_t>(1); c->sendbuf = dev_alloc<double>(1);
-    c->ng_int = ngroups; c->ng_bnd = 0; c->n_int = c->n_bnd = c->nblk = 0;
-    c->glist_int_identity = true; c->glist_all = true;
-    sell_order_for_big_grids(c, ngroups);
-    c->matrix_bytes = entries * (c16 ? 10 : 12) - uniform_entries * (c16 ? 2 : 4) - constant_entries * 8ull + 2ull * c->masked_rows + 8ull * nslices + 4ull * ((uint64_t)rows + 1);
-    if (c->s_desc) c->matrix_bytes += 8ull * nslices;
-    c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
-    BICG_HIP(hipFree(far_d));
-    ctx_state(c, comm, ngroups);
-    if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
-    c->fuse_pipe = c->fuse_small;
-    if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
-    else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
-    c->spmm_ok = spmm_possible(c);
-    c->fuse_plan_ok = true;
-    BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
-    memset(c->hS, 0, sizeof(Scal));
-    ctx_streams(c, 1);
-    preload_for(c);
-    if (plan_seconds) *plan_seconds = now_sec() - t0;
-    return c;
-}
-
-namespace {
-// the halo landing ring lives in the transport's shared memory: give it back while the transport exists
-void release_p2p(bicg_ctx *c)
-{
-    if (!c->p2p) return;
-    (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
-    c->p2p->unmap(c->ring_mapped);
-    c->p2p->release(c->halo_ring);
-    c->ring_mapped.clear(); c->halo_ring = nullptr; c->p2p = nullptr;
-}
-}  // namespace
-
-// called by comm_set() before the communicator goes away (bicg_comm.cpp)
-extern "C++" {
-void bicg::contexts_orphan()
-{
-    for (bicg_ctx *c : g_live) { release_p2p(c); c->comm = nullptr; }
-}
-}
-
-void bicg_destroy(bicg_ctx *c)
-{
-    if (!c) return;
-    g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
-    (void)hipSetDevice(c->device);
-    (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->lane_info, c->waitlog, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
-                    c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
-                    c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
-    for (void *p : ptrs) if (p) (void)hipFree(p);
-    for (void *p : c->persist_mem) if (p) (void)hipFree(p);
-    release_p2p(c);
-    if (c->push_dst0) (void)hipFree(c->push_dst0);
-    if (c->push_stride) (void)hipFree(c->push_stride);
-    if (c->glist_ll) (void)hipFree(c->glist_ll);
-    if (c->hS) (void)hipHostFree(c->hS);
-    if (c->h_alarm) (void)hipHostFree(c->h_alarm);
-    for (int i = 0; i < kEvRing; ++i) {
-        for (hipEvent_t e : {c->ev_pack[i], c->ev_halo[i], c->ev_dots[i], c->ev_red[i]})
-            if (e) (void)hipEventDestroy(e);      // a context that failed early in bicg_create has none
-    }
-    for (auto &e : c->tev) (void)hipEventDestroy(e);
-    for (auto &e : c->region_ev) if (e) (void)hipEventDestroy(e);
-    for (auto &e : c->sec_ev) (void)hipEventDestroy(e);
-    for (auto &ge : c->graph_exec) if (ge) (void)hipGraphExecDestroy(ge);
-    if (c->sc) (void)hipStreamDestroy(c->sc);
-    if (c->sm) (void)hipStreamDestroy(c->sm);
-    delete c;
-}
-
-int bicg_load(bicg_ctx *c, const double *x0, const double *b)
-{
-    use_device(c);
-    x0 = host_in(c, x0); b = host_in(c, b);
-    BICG_HIP(hipMemcpy(c->v.x, x0, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
-    BICG_HIP(hipMemcpy(c->v.r, b, sizeof(double) * c->n_loc, hipMemcpyHostToDevice));
-    return 0;
-}
-
-int bicg_fetch(bicg_ctx *c, double *x, double *r)
-{
-    use_device(c);
-    BICG_HIP(hipStreamSynchronize(c->sc));
-    x = host_out(c, x); r = host_out(c, r);
-    if (x) BICG_HIP(hipMemcpy(x, c->v.x, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
-    if (r) BICG_HIP(hipMemcpy(r, c->v.r, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost));
-    return 0;
-}
-
-int bicg_run(bicg_ctx *c, int method, const bicg_options *opt, bicg_result *res) { return run_solver(c, method, opt, res); }
-int bicg_run_begin(bicg_ctx *c, int method, const bicg_options *opt) { run_begin(c, method, opt); return 0; }
-int bicg_run_iterate(bicg_ctx *c, int nsteps) { return run_iterate(c, nsteps); }
-int bicg_run_iterate_timed(bicg_ctx *c, int nsteps, double ms[3])
-{
-    use_device(c);
-    if (!c->region_ev[0]) for (auto &e : c->region_ev) BICG_HIP(hipEventCreate(&e));
-    c->t_enq = 0.0;
-    const double t0 = now_sec();
-    BICG_HIP(hipEventRecord(c->region_ev[0], c->sc));
-    const int k = run_iterate(c, nsteps);
-    BICG_HIP(hipEventRecord(c->region_ev[1], c->sc));
-    BICG_HIP(hipEventSynchronize(c->region_ev[1]));
-    float dev = 0.f;
-    BICG_HIP(hipEventElapsedTime(&dev, c->region_ev[0], c->region_ev[1]));
-    ms[0] = dev; ms[1] = 1e3 * c->t_enq; ms[2] = 1e3 * (now_sec() - t0);
-    return k;
-}
-int bicg_run_end(bicg_ctx *c, bicg_result *res) { return run_end(c, res); }
-int bicg_sync(bicg_ctx *c)
-{
-    use_device(c);
-    BICG_HIP(hipStreamSynchronize(c->sc));
-    if (c->sm) BICG_HIP(hipStreamSynchronize(c->sm));
-    return 0;
-}
-
-int bicg_solve(bicg_ctx *c, int method, double *x, double *r, const bicg_options *opt, bicg_result *res)
-{
-    bicg_load(c, x, r);
-    const int k = run_solver(c, method, opt, res);
-    bicg_fetch(c, x, r);
-    return k;
-}
-
-int bicg_trace(bicg_ctx *c, double *alpha, double *omega, double *beta, double *dot_r)
-{
-    const int k = c->last_iters;
-    if (k <= 0 || !c->trace) return 0;
-    double *dst[4] = {alpha, omega, beta, dot_r};
-    for (int i = 0; i < 4; ++i)
-        if (dst[i]) BICG_HIP(hipMemcpy(dst[i], c->trace + (size_t)i * c->trace_cap, sizeof(double) * k, hipMemcpyDeviceToHost));
-    return k;
-}
-
-static void reset_scal(bicg_ctx *c) { scal_reset(c); }
-
-int bicg_spmv(bicg_ctx *c, const double *x, double *y)
-{
-    use_device(c);
-    reset_scal(c);
-    x = host_in(c, x); y = host_out(c, y);
-    BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
-    c->time_kernels = false;
-    spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
-    BICG_HIP(hipMemcpyAsync(y, c->v.s, sizeof(double) * c->n_loc, hipMemcpyDeviceToHost, c->sc));
-    if (c->p2p) fetch_scal(c);      // also reports a peer that never delivered its halo values
-    else BICG_HIP(hipStreamSynchronize(c->sc));
-    return 0;
-}
-
-double bicg_dot(bicg_ctx *c, const double *x, const double *y)
-{
-    use_device(c);
-    reset_scal(c);
-    if (c->phantom) { x = host_in(c, x); y = x; }
-    BICG_HIP(hipMemcpyAsync(c->v.p, x, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
-    BICG_HIP(hipMemcpyAsync(c->v.s, y, sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
-    launch_dot(c->v.p, c->v.s, c->n_loc, c->S, c->red(0, PH_NONE, true, 1), c->sc);
-    group_now(c, 1, PH_NONE);
-    fetch_scal(c);
-    return c->hS->red[0];
-}
-
-// Verification loop of the reference's shifted driver (src/test_shifted.c:129-154): for every shift the
-// relative residual || (A + sigma_j I) x_j - b || / || b ||, computed on the device (SpMV with the
-// shift folded into its epilogue + one fused difference/norm kernel per shift). Collective.
-int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b_loc, const double *sigma, int nsig,
-                           double *relres_out)
-{
-    use_device(c);
-    reset_scal(c);
-    x_loc_set = host_in(c, x_loc_set, (size_t)nsig); if (c->phantom) b_loc = x_loc_set;
-    const size_t n = c->n_loc;
-    BICG_HIP(hipMemcpyAsync(c->v.b, b_loc, sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
-    BICG_HIP(hipMemsetAsync(c->v.t, 0, sizeof(double) * c->stride, c->sc));
-    c->time_kernels = false;
-    launch_dot(c->v.b, c->v.b, c->n_loc, c->S, c->red(0, PH_NONE, true, 1), c->sc);
-    group_now(c, 1, PH_NONE);
-    fetch_scal(c);
-    const double bb = c->hS->red[0];
-    if (c->spmm_ok && !(getenv("BICG_NO_SPMM") && atoi(getenv("BICG_NO_SPMM")))) {
-        // every matrix entry is read once for kSpmmCols shifts (the only place where
-        // the reference multiplies A with many vectors is this verification loop, one SpMV per shift)
-        spmm_buffers(c);
-        std::vector<double> sq(kSpmmCols);
-        for (int j0 = 0; j0 < nsig; j0 += kSpmmCols) {
-            const int nv = std::min(kSpmmCols, nsig - j0);
-            for (int j = 0; j < nv; ++j)
-                BICG_HIP(hipMemcpyAsync(c->mm_in + (size_t)j * c->stride, x_loc_set + (size_t)(j0 + j) * n, sizeof(double) * n,
-                                        hipMemcpyHostToDevice, c->sc));
-            spmm_pass(c, nv, sigma + j0, true);
-            BICG_HIP(hipMemcpyAsync(sq.data(), c->mm_out, sizeof(double) * kSpmmCols, hipMemcpyDeviceToHost, c->sc));
-            fetch_scal(c);                                   // synchronises; reports a lost peer
-            if (!c->single()) {                              // sum over ranks (host-side: kSpmmCols doubles)
-                std::vector<int> cnt(c->nranks, (int)(sizeof(double) * kSpmmCols)), dsp(c->nranks);
-                std::vector<double> all((size_t)c->nranks * kSpmmCols), mine((size_t)c->nranks * kSpmmCols);
-                for (int p = 0; p < c->nranks; ++p) { dsp[p] = p * (int)(sizeof(double) * kSpmmCols); std::copy(sq.begin(), sq.end(), mine.begin() + (size_t)p * kSpmmCols); }
-                c->comm->alltoallv_host(mine.data(), cnt.data(), dsp.data(), all.data(), cnt.data(), dsp.data());
-                std::copy(sq.begin(), sq.end(), all.begin() + (size_t)c->rank * kSpmmCols);
-                for (int j = 0; j < kSpmmCols; ++j) { double t = 0.0; for (int p = 0; p < c->nranks; ++p) t += all[(size_t)p * kSpmmCols + j]; sq[j] = t; }
-            }
-            for (int j = 0; j < nv; ++j) relres_out[j0 + j] = bb > 0.0 ? sqrt(sq[j] / bb) : sqrt(sq[j]);
-        }
-        return 0;
-    }
-    Vecs w = c->v;
-    w.r = c->v.t;                               // zero vector: FDrift then yields || b - A x ||^2
-    for (int j = 0; j < nsig; ++j) {
-        BICG_HIP(hipMemcpyAsync(c->v.p, x_loc_set + (size_t)j * n, sizeof(double) * n, hipMemcpyHostToDevice, c->sc));
-        c->cur_shift = sigma[j]; c->cur_has_shift = true;
-        spmv(c, c->v.p, c->v.ax, 0, nullptr, c->red(0, PH_NONE));
-        c->cur_has_shift = false; c->cur_shift = 0.0;
-        launch_drift(w, Launch{c->S, Finish{}, c->sc}, c->red(0, PH_NONE, true, 2));
-        group_now(c, 2, PH_NONE);
-        fetch_scal(c);
-        relres_out[j] = bb > 0.0 ? sqrt(c->hS->red[0] / bb) : sqrt(c->hS->red[0]);
-    }
-    return 0;
-}
-
-// Y_j = (A + sigma_j I) X_j, j < nvec, with A read once per kSpmmCols vectors ("batched SpMV", BASELINE.json configs[4]);
-// x_loc_set / y_loc_set shift-major like the shifted solvers' x_loc_set; sigma may be NULL. Returns 1 (nothing done)
-// when the matrix is not entirely on the sliced-ELL path. ms_out (optional): device time of the passes.
-int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nvec, double *y_loc_set, double *ms_out)
-{
-    use_device(c);
-    if (!c->spmm_ok) return 1;
-    reset_scal(c);
-    spmm_buffers(c);
-    std::vector<double> ph_y;
-    if (c->phantom) { x_loc_set = host_in(c, x_loc_set, (size_t)nvec); ph_y.assign((size_t)nvec, 0.0); y_loc_set = ph_y.data(); }
-    const size_t n = c->n_loc;
-    hipEvent_t e0, e1;
-    BICG_HIP(hipEventCreate(&e0)); BICG_HIP(hipEventCreate(&e1));
-    float total = 0.f;
-    for (int j0 = 0; j0 < nvec; j0 += kSpmmCols) {
-        const int nv = std::min(kSpmmCols, nvec - j0);
-        for (int j = 0; j < nv; ++j)
-            BICG_HIP(hipMemcpyAsync(c->mm_in + (size_t)j * c->stride, x_loc_set + (size_t)(j0 + j) * n, sizeof(double) * n,
-                                    hipMemcpyHostToDevice, c->sc));
-        BICG_HIP(hipEventRecord(e0, c->sc));
-        spmm_pass(c, nv, sigma ? sigma + j0 : nullptr, false);
-        BICG_HIP(hipEventRecord(e1, c->sc));
-        if (!c->mm_win) launch_vectors_from_rows(c->mm_yt, c->stride, nv, c->n_loc, c->mm_in, c->sc);     // result back to shift-major (reuses mm_in)
-        const double *ysrc = c->mm_win ? c->mm_yt : c->mm_in;
-        for (int j = 0; j < nv; ++j)
-            BICG_HIP(hipMemcpyAsync(y_loc_set + (size_t)(j0 + j) * n, ysrc + (size_t)j * c->stride, sizeof(double) * n,
-                                    hipMemcpyDeviceToHost, c->sc));
-        fetch_scal(c);
-        float ms = 0.f;
-        BICG_HIP(hipEventElapsedTime(&ms, e0, e1));
-        total += ms;
-    }
-    (void)hipEventDestroy(e0); (void)hipEventDestroy(e1);
-    if (ms_out) *ms_out = (double)total;
-    return 0;
-}
-
-int bicg_spmv_bench(bicg_ctx *c, int reps, double *ms_per_spmv)
-{
-    use_device(c);
-    reset_scal(c);
-    std::vector<double> ones(c->n_loc, 1.0);
-    BICG_HIP(hipMemcpyAsync(c->v.p, ones.data(), sizeof(double) * c->n_loc, hipMemcpyHostToDevice, c->sc));
-    BICG_HIP(hipStreamSynchronize(c->sc));
-    c->time_kernels = false;
-    for (int i = 0; i < 3; ++i) spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
-    hipEvent_t a, b;
-    BICG_HIP(hipEventCreate(&a)); BICG_HIP(hipEventCreate(&b));
-    BICG_HIP(hipEventRecord(a, c->sc));
-    for (int i = 0; i < reps; ++i) spmv(c, c->v.p, c->v.s, 0, nullptr, c->red(0, PH_NONE));
-    BICG_HIP(hipEventRecord(b, c->sc));
-    BICG_HIP(hipEventSynchronize(b));
-    float ms = 0.f;
-    BICG_HIP(hipEventElapsedTime(&ms, a, b));
-    (void)hipEventDestroy(a); (void)hipEventDestroy(b);
-    if (c->p2p) fetch_scal(c);
-    *ms_per_spmv = (double)ms / (reps > 0 ? reps : 1);
-    return 0;
-}
-
-int bicg_comm_failed(bicg_ctx *c) { return c->comm_failed ? 1 : 0; }
-
-int bicg_section_times(bicg_ctx *c, double ms[4], int *iterations, int *marks)
-{
-    if (!c) return 1;
-    for (int i = 0; i < SEC_COUNT; ++i) ms[i] = c->sec_ms[i];
-    if (iterations) *iterations = c->sec_iters;
-    if (marks) *marks = c->sec_exhausted ? -c->sec_used : c->sec_used;
-    return c->sec_used > 0 ? 0 : 2;
-}
-
-int bicg_plan_info(bicg_ctx *c, unsigned int out[8])
-{
-    out[0] = c->n_loc; out[1] = c->nnz_d; out[2] = c->nnz_o; out[3] = c->halo;
-    out[4] = c->nblk + c->ng_int + c->ng_bnd;       // workgroups per SpMV
-    out[5] = c->n_bnd + c->ng_bnd;                  // of which halo-touching
-    out[6] = c->sell_rows;                          // rows on the sliced-ELL path
-    out[7] = (unsigned)(c->sell_entries > c->sell_nnz ? c->sell_entries - c->sell_nnz : 0);   // padding entries
-    return 0;
-}
-
-bicg_ctx *bicg_dropin_context(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO_Matrix *info)
-{
-    return dropin_context(diag, offd, info);
-}
-void bicg_dropin_release(void)
-{
-    if (g_dropin.ctx) { bicg_destroy(g_dropin.ctx); g_dropin.ctx = nullptr; }
-}
-unsigned long long bicg_device_matrix_bytes(bicg_ctx *c) { return c->device_matrix_bytes; }
-unsigned long long bicg_uniform_entries(bicg_ctx *c) { return c->uniform_entries; }
-unsigned long long bicg_constant_entries(bicg_ctx *c) { return c->constant_entries; }
-unsigned long long bicg_masked_rows(bicg_ctx *c) { return c->masked_rows; }
-// out = {mailbox all-reduce p50, p99, hand-off wait p50, p99 (microseconds), samples of the former, of the latter}; returns 0 when
-// the last solve recorded something (multi-rank persistent launches only)
-int bicg_comm_wait_stats(bicg_ctx *c, double out[6])
-{
-    for (int i = 0; i < 6; ++i) out[i] = 0.0;
-    if (!c->waitlog) return 1;
-    use_device(c);
-    std::vector<unsigned> h(3 * (size_t)kWaitCap);
-    BICG_HIP(hipMemcpy(h.data(), c->waitlog, sizeof(unsigned) * h.size(), hipMemcpyDeviceToHost));
-    auto pct = [](std::vector<unsigned> &v, double q) -> double {
-        if (v.empty()) return 0.0;
-        std::sort(v.begin(), v.end());
-        return 0.01 * (double)v[std::min(v.size() - 1, (size_t)(q * (double)(v.size() - 1) + 0.5))];      // 100 MHz ticks -> us
-    };
-    std::vector<unsigned> mail, hand[2];
-    for (size_t i = 0; i < kWaitCap; ++i) {
-        if (h[i]) mail.push_back(h[i]);
-        if (h[kWaitCap + i]) hand[0].push_back(h[kWaitCap + i]);
-        if (h[2 * kWaitCap + i]) hand[1].push_back(h[2 * kWaitCap + i]);
-    }
-    // the row workgroup that borders another rank waits for halo values, the other one only for its own GPU: report the slower
-    std::vector<unsigned> &hw = pct(hand[0], 0.5) >= pct(hand[1], 0.5) ? hand[0] : hand[1];
-    out[0] = pct(mail, 0.5); out[1] = pct(mail, 0.99); out[2] = pct(hw, 0.5); out[3] = pct(hw, 0.99);
-    out[4] = (double)mail.size(); out[5] = (double)hw.size();
-    return mail.empty() && hw.empty() ? 1 : 0;
-}
-int bicg_stencil_info(bicg_ctx *c, unsigned int out[8])
-{
-    const bool on = stencil_product(c);
-    const StencilDev &t = c->st;
-    const unsigned int v[8] = {on ? 1u : 0u, t.sy, t.ny, t.nz, t.lines, t.zl, on ? stencil_grid(t) : 0u, t.nmc};
-    for (int i = 0; i < 8; ++i) out[i] = v[i];
-    return on ? 1 : 0;
-}
-unsigned int bicg_plan_collisions(bicg_ctx *c) { return c->plan_collisions; }
-unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return stencil_product(c) ? c->stencil_matrix_bytes : c->matrix_bytes; }
-int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
-int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }
-
-void bicg_dropin_stats(unsigned int *hits, unsigned int *misses)
-{
-    if (hits) *hits = g_dropin.hits;
-    if (misses) *misses = g_dropin.misses;
-}
-
-unsigned int bicg_ctx_flags(bicg_ctx *c)
-{
-    unsigned f = 0;
-    if (c->p2p) f |= BICG_FLAG_P2P;
-    if (c->ll_fused) f |= BICG_FLAG_LL_FUSED;
-    if (c->overlap) f |= BICG_FLAG_OVERLAP;
-    if (c->s_col16) f |= BICG_FLAG_COL16;
-    if (c->sell_jag) f |= BICG_FLAG_JAGGED;
-    if (c->win_slots) f |= BICG_FLAG_WINDOW;
-    if (c->spmm_ok) f |= BICG_FLAG_SPMM;
-    if (c->glist_all) f |= BICG_FLAG_ALL_SELL;
-    if (c->rowsplit) f |= BICG_FLAG_ROWSPLIT;
-    if (c->persist_on) f |= BICG_FLAG_PERSIST;
-    if (c->fuse_pipe && c->fuse_plan_ok && !hosted(c)) f |= BICG_FLAG_FUSE_PIPE;
-    if (c->pipe_probed && (c->probe_ms[0] > 0.0 || c->probe_ms[1] > 0.0)) f |= BICG_FLAG_PIPE_PROBED;
-    if (c->uniform_entries) f |= BICG_FLAG_UNIFORM;
-    if (c->constant_entries) f |= BICG_FLAG_CONSTANT;
-    return f;
-}
-
-int bicg_solve_shifted(bicg_ctx *c, int variant, double *x_loc_set, double *r_loc, const double *sigma, int sigma_len,
-                       int seed, const bicg_options *opt, bicg_result *res)
-{
-    return run_shifted(c, variant, x_loc_set, r_loc, sigma, sigma_len, seed, opt, res);
-}
-
-// BICG_DISPLAY_ERROR=1: what the reference prints when it is compiled with -DDISPLAY_ERROR (src/shifted_switching_solver.c:327-335,
-// 570-598): the right-hand side is formed once more as ans = (A + sigma[seed] I) 1 -- what its drivers pass as b, src/main_shifted.c
-// -- and every system's || (A + sigma_i I) x_i - ans || / || ans || is printed for the seed ("0, ...") and every tenth shift
-// ("1, ..."). Here: one product on the device for ans, then the batched residuals of bicg_shifted_residuals (the matrix read once
-// per 16 shifts). Collective like the solve itself.
-static void display_error(bicg_ctx *c, const double *x_set, const double *sigma, int nsig, int seed)
-{
-    const size_t n = c->phantom ? 0 : c->n_loc;
-    std::vector<double> ones(std::max<size_t>(n, 1), 1.0), ans(std::max<size_t>(n, 1), 0.0), err((size_t)nsig, 0.0);
-    bicg_spmv(c, ones.data(), ans.data());
-    for (size_t j = 0; j < n; ++j) ans[j] += sigma[seed] * ones[j];                        // my_daxpy(sigma[seed], temp, ans_loc)
-    bicg_shifted_residuals(c, x_set, ans.data(), sigma, nsig, err.data());
-    if (c->rank != 0) return;
-    printf("seed(0:seed, 1:shift), sigma, relative error\n");
-    for (int i = 0; i < nsig; ++i) {
-        if (i == seed) printf("0, %e, %e\n", sigma[i], err[i]);
-        else if (i % 10 == 0) printf("1, %e, %e\n", sigma[i], err[i]);
-    }
-    fflush(stdout);
-}
-
-static int dropin_shifted(int mode, CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x_set, double *r, double *sigma, int nsig, int seed)
-{
-    check_square(i);
-    bicg_options opt;
-    env_options(&opt);
-    if (!getenv("BICG_TOL")) opt.tol = 1.0e-12;      // EPS of reference src/shifted_solver.c:5
-    bicg_ctx *c = dropin_context(d, o, i);
-    if (!c) die("bicg_create", "failed");
-    bicg_result res;
-    std::vector<double> x0, b, xs0;
-    const bool guarded = p2p_guard(c, x_set, r, x0, b);
-    if (guarded) xs0.assign(x_set, x_set + (size_t)nsig * c->n_loc);
-    int k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
-    if (guarded && p2p_fell_back(c)) {
-        memcpy(x_set, xs0.data(), sizeof(double) * xs0.size());
-        memcpy(r, b.data(), sizeof(double) * b.size());
-        c = dropin_context(d, o, i);
-        if (!c) die("bicg_create", "failed");
-        k = run_shifted(c, mode, x_set, r, sigma, nsig, seed, &opt, &res);
-    }
-    if (getenv("BICG_DISPLAY_ERROR") && atoi(getenv("BICG_DISPLAY_ERROR")) != 0) display_error(c, x_set, sigma, nsig, mode == SH_XI ? 0 : seed);
-    dropin_release(c);
-    return k;
-}
-
-// ---- shifted drop-ins: reference src/shifted_solver.h:17-19. The three reference functions perform
-// the same arithmetic in a different order (their outputs are bit-identical to each other).
-int shifted_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_LOP, d, o, i, x, r, sigma, n, seed); }
-int shifted_lopbicgstab_v2(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_LOP, d, o, i, x, r, sigma, n, seed); }
-int shifted_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_LOP, d, o, i, x, r, sigma, n, seed); }
-// src/shifted_solver.h:20-21 (the two reference functions are bit-identical to each other)
-int shifted_pipe_lopbicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_PIPE, d, o, i, x, r, sigma, n, seed); }
-int shifted_pipe_lopbicgstab_nooverlap(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_PIPE, d, o, i, x, r, sigma, n, seed); }
-// src/shifted_solver.h:16 (seed system = A, shift index 0)
-int shifted_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n) { return dropin_shifted(SH_XI, d, o, i, x, r, sigma, n, 0); }
-// reference src/shifted_switching_solver.h:10-12
-int shifted_lopbicg(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_FLAG, d, o, i, x, r, sigma, n, seed); }
-int shifted_lopbicg_switching(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_SWITCH, d, o, i, x, r, sigma, n, seed); }
-int shifted_lopbicg_switching_noovlp(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, double *sigma, int n, int seed) { return dropin_shifted(SH_SWITCH, d, o, i, x, r, sigma, n, seed); }
-
-// ---- drop-in entry points: reference src/solver.h:10-13
-int bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_BICGSTAB, d, o, i, x, r, 0, 0); }
-int ca_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_CA_BICGSTAB, d, o, i, x, r, 0, 0); }
-int pipe_bicgstab(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r) { return dropin(BICG_PIPE_BICGSTAB, d, o, i, x, r, 0, 0); }
-int pipe_bicgstab_rr(CSR_Matrix *d, CSR_Matrix *o, INFO_Matrix *i, double *x, double *r, int krr, int nrr)
-{
-    return dropin(BICG_PIPE_BICGSTAB_RR, d, o, i, x, r, krr, nrr);
-}
-
-}  // extern "C"

@@ -1,6 +1,6 @@
 #!/bin/bash
 # PMC passes over 20 products back to back (tools/spmv_only.py; SPMV_KIND=fem_like for the FEM-like matrix), one small counter
-# set per pass. Usage: bash tools/r5/pmc_spmv.sh <output directory under gpurun_out> [ENV=V ...]
+# set per pass. Usage: bash tools/pmc_spmv.sh <output directory under gpurun_out> [ENV=V ...]
 cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
