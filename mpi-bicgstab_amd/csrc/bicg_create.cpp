@@ -171,7 +171,7 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
     const bool st_big = 16.0 * (double)nrows > 2.0 * 256.0 * 1048576.0;
     const int st_xcd = knob_x("BICG_STENCIL_XCD") ? atoi(knob_x("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
     const int st_nt = knob_x("BICG_STENCIL_NT") ? atoi(knob_x("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
-    c->st = StencilDev{1, sy, sz, nxs, ny, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
+    c->st = StencilDev{1, sy, sz, nxs, ny, nz, 0u, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
     if (const char *v = getenv("BICG_CA_FUSE")) c->ca_fuse = atoi(v) != 0;
     // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
     c->stencil_matrix_bytes = 4ull * nslices + (uint64_t)cmask.size();
@@ -1090,6 +1090,24 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->s_uoff = dev_upload(uoff.data(), uoff.size());
     }
     build_slice_desc(c, nslices, nrows, slice_len.data(), ubase, vbase, mbase, uoff, uval, rmask.empty() ? nullptr : rmask.data());
+    if (P > 1) {
+        // Across ranks (a z-slab of BASELINE.json configs[3]: 64 planes of 512^2 per GPU) the plane-marching product takes the
+        // planes without halo entries; the halo-touching planes go through the slice-by-slice kernel behind the exchange. That
+        // needs the two sets to BE whole planes: every group of a plane with a halo-touching group is halo-touching, and the
+        // others form one range of planes.
+        const uint32_t gpp = (c->st.on && c->st.sz % kGroupRows == 0) ? c->st.sz / kGroupRows : 0u;
+        std::vector<char> bnd_plane(c->st.on ? c->st.nz : 1u, 0);
+        bool ok = gpp > 0 && c->glist_all && c->nblk == 0;
+        for (uint32_t g : gl_bnd) if (ok) bnd_plane[(size_t)g / gpp] = 1;
+        uint32_t nb = 0, lo = c->st.nz, hi = 0;
+        for (uint32_t z = 0; ok && z < c->st.nz; ++z) { if (bnd_plane[z]) ++nb; else { lo = std::min(lo, z); hi = std::max(hi, z + 1); } }
+        ok = ok && (uint64_t)nb * gpp == gl_bnd.size() && lo < hi;
+        for (uint32_t z = lo; ok && z < hi; ++z) ok = !bnd_plane[z];
+        ok = all_ranks(comm, ok);       // (every rank takes the same form of the exchange: collective)
+        if (ok) { c->st.z_lo = lo; c->st.z_hi = hi; c->st_multi = true; }
+        if (getenv("BICG_PLAN_TRACE") && c->rank == 0)
+            fprintf(stderr, "bicgstab_hip: plane-marching product across ranks: %s (planes %u .. %u of %u without halo entries)\n", ok ? "yes" : "no", lo, hi, c->st.nz);
+    }
     c->device_matrix_bytes = (need_csr ? (csr16 ? 10ull : 12ull) * c->nnz_d : 0ull) + 4ull * (c->n_loc + 1) + 12ull * c->nnz_o + 4ull * (c->n_loc + 1) +
                              8ull * sell_entries + (c16 ? 2ull * n16 : 4ull * sell_entries) + 12ull * nslices;
     if (c16) {

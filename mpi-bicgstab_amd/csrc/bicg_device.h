@@ -234,6 +234,7 @@ struct StencilDev {
     int on;
     uint32_t sy, sz;                // distances in rows
     uint32_t nxs, ny, nz;           // x segments (sy / 64), lines per plane (sz / sy), planes (rows / sz)
+    uint32_t z_lo, z_hi;            // the planes this product takes (one rank: all; across ranks: the planes without halo entries)
     uint32_t zl;                    // planes per wavefront tile
     uint32_t lines;                 // lines per wavefront (2, 4 or 8)
     uint32_t nmc;                   // x segments with masked slices

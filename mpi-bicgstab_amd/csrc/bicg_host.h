@@ -111,6 +111,7 @@ struct bicg_ctx {
     bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
     StencilDev st{};                       // SellDev::st: the plane-marching product of a 7-point grid stencil (BICG_STENCIL=0: off)
     uint32_t *st_code = nullptr; StencilTab *st_tab = nullptr; unsigned char *st_cmask = nullptr;
+    bool st_multi = false;                 // several ranks: the halo-free rows of this rank are the whole planes z_lo .. z_hi - 1 of its grid
     bool ca_fuse = true;                   // CA-BiCGStab: q, y and their dots in the epilogue of z = A s (plane-marching product only; BICG_CA_FUSE=0)
     uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
     uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off

@@ -215,10 +215,11 @@ void group_defer(bicg_ctx *c, int n, int phase)
     c->pend = true; c->pend_n = n; c->pend_off = 0; c->pend_phase = phase; c->pend_ev = e;
 }
 
-// one rank, every row on the sliced-ELL path, and the plan found a grid's 7-point stencil (build_stencil_plan)
+// every row on the sliced-ELL path, and the plan found a grid's 7-point stencil (build_stencil_plan)
 bool stencil_product(const bicg_ctx *c)
 {
-    return c->st.on && c->single() && c->ng_bnd == 0 && c->nblk == 0 && c->glist_all;      // (whatever order the groups are listed in)
+    // (whatever order the groups are listed in; across ranks: the halo-free rows are whole planes, StencilDev::z_lo / z_hi)
+    return c->st.on && c->nblk == 0 && c->glist_all && (c->single() ? c->ng_bnd == 0 : c->st_multi);
 }
 
 // ---------------------------------------------------------------- distributed SpMV
@@ -260,16 +261,17 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // evict it just before it is needed. Rows, hence results of the product, are unaffected; the dot partials of a
     // reversed launch land in mirrored slots (a different, equally fixed association).
     a.reverse = (c->sell_alt && c->single() && !fw) ? (c->spmv_dir ^= 1) : 0;
-    const unsigned g_si = sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
+    // the plane-marching product (bicg_stencil.hip) takes the rank's halo-free planes in one launch of its own tiling; across ranks
+    // the halo-touching planes follow behind the exchange through the slice-by-slice kernel, as separate launches (never the
+    // launch with the exchange inside)
+    const bool stencil = stencil_product(c) && !fw && (epi == 0 || epi == 3) && !a.has_shift;
+    if (epi == 3 && !(stencil && c->single())) die("internal", "CA-BiCGStab's fused q / y epilogue without the plane-marching product");
+    const unsigned g_si = stencil ? stencil_grid(c->st) : sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
-    const bool fused = c->p2p && c->ll_fused;
-    const bool merged = !c->single() && (fused || (!c->p2p && !(c->comm->stream_ordered() && c->overlap) && c->glist_all));
+    const bool fused = c->p2p && c->ll_fused && !stencil;
+    const bool merged = !c->single() && !stencil && (fused || (!c->p2p && !(c->comm->stream_ordered() && c->overlap) && c->glist_all));
     const unsigned g_sall = sell_grid(c->ng_int + c->ng_bnd, a.groups_per_wg);
     red.expected = merged ? g_sall + g_ci + g_cb : g_si + g_ci + g_sb + g_cb;
-    // the plane-marching product (bicg_stencil.hip) takes the whole block in one launch of its own tiling
-    const bool stencil = stencil_product(c) && !fw && (epi == 0 || epi == 3) && !a.has_shift;
-    if (epi == 3 && !stencil) die("internal", "CA-BiCGStab's fused q / y epilogue without the plane-marching product");
-    if (stencil) red.expected = stencil_grid(c->st);
     red.slot_base = 0;
     a.red = red;
     if (red.wave && (ndot > 0 || epi)) c->grp.nparts = red.expected * (kBlock / 64);   // one partial per wavefront
@@ -285,7 +287,8 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 
     auto interior = [&]() {
         a.glist = c->glist_int_identity ? nullptr : c->glist_int; a.nlist = c->ng_int; a.red.slot_base = 0;
-        took(launch_spmv_sell(a, ndot, false, c->sc, ev(0), ev(1)));
+        if (stencil) took(launch_spmv_stencil(a, ndot, epi == 3 ? 1 : 0, c->sc, ev(0), ev(1)));
+        else took(launch_spmv_sell(a, ndot, false, c->sc, ev(0), ev(1)));
         a.desc = c->desc_int; a.nlist = c->n_int; a.red.slot_base = g_si;
         took(launch_spmv(a, ndot, false, c->sc, ev(0), ev(1)));
     };
@@ -309,11 +312,8 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         a.red.expected = red.expected;
         c->grp.nparts = red.expected * (kBlock / 64);
     }
-    if (stencil) {
-        a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
-        took(launch_spmv_stencil(a, ndot, epi == 3 ? 1 : 0, c->sc, ev(0), ev(1)));
-    } else if (c->single()) {
-        if (epi) {
+    if (c->single()) {
+        if (epi && !stencil) {
             a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
             took(launch_spmv_sell_epi(a, epi, false, c->sc, ev(0), ev(1)));
         } else if (fw) {
@@ -382,7 +382,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
             group_enqueue(c, c->pend_n, c->pend_phase, after);
             joined_pending = true;
         }
-        if (!two_streams && c->glist_all) {
+        if (!two_streams && c->glist_all && !stencil) {
             // nothing overlaps the exchange: one launch over ALL sliced-ELL groups (rows without offd
             // entries simply find an empty offd range) instead of an interior + a boundary launch
             a.glist = nullptr; a.nlist = c->ng_int + c->ng_bnd; a.red.slot_base = 0;
@@ -629,7 +629,7 @@ struct Driver {
     void iter_ca()      // reference src/solver.c:217-251
     {
         launch_ca_ps(v, here());                                // p, s recurrences
-        if (c->ca_fuse && stencil_product(c) && !c->cur_has_shift) {
+        if (c->ca_fuse && c->single() && stencil_product(c) && !c->cur_has_shift) {
             // z = A s with q = r - alpha s, y = w - alpha z, (q,y), (y,y) on the product's own rows: s_i and z_i are registers there
             spmv(c, v.s, v.z, 2, nullptr, c->red(0, PH_OMEGA, true, 2), Finish{}, 3);
         } else {

@@ -275,7 +275,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_stencil(SpmvArgs a)
     const unsigned nyw = (g.ny + 4u * (unsigned)R - 1u) / (4u * (unsigned)R);
     const unsigned xs = vb % g.nxs, yw = (vb / g.nxs) % nyw, zb = vb / (g.nxs * nyw);
     const unsigned y0 = (yw * 4u + wave) * (unsigned)R;
-    const unsigned z0 = zb * g.zl, z1 = z0 + g.zl < g.nz ? z0 + g.zl : g.nz;
+    const unsigned z0 = g.z_lo + zb * g.zl, z1 = z0 + g.zl < g.z_hi ? z0 + g.zl : g.z_hi;
     if (!done && y0 < g.ny) {              // (done: nothing is stored and nothing published)
         if ((g.mcols >> xs) & 1ull) stencil_tile<NDOT, R, EPI, true>(a, xs, y0, z0, z1, lane, acc);
         else stencil_tile<NDOT, R, EPI, false>(a, xs, y0, z0, z1, lane, acc);
@@ -289,7 +289,7 @@ __global__ void __launch_bounds__(kBlock) k_spmv_stencil(SpmvArgs a)
 unsigned stencil_grid(const StencilDev &st)
 {
     if (!st.on) return 0u;
-    const unsigned nyw = (st.ny + 4u * st.lines - 1u) / (4u * st.lines), nzb = (st.nz + st.zl - 1u) / st.zl;
+    const unsigned nyw = (st.ny + 4u * st.lines - 1u) / (4u * st.lines), nzb = (st.z_hi - st.z_lo + st.zl - 1u) / st.zl;
     return st.nxs * nyw * nzb;
 }
 

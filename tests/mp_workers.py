@@ -305,6 +305,10 @@ def fullsize_worker(rank, world, port, kind, outdir):
         assert flags["p2p"] == p2p
         if p2p:
             assert flags["ll_fused"], "banded slab: the halo exchange must be folded into the SpMV launch"
+        if grid:
+            # a z-slab of the grid: the planes without halo entries go to the plane-marching product (csrc/bicg_stencil.hip), the two
+            # (one, at either end of the grid) halo-touching planes to the slice-by-slice kernel behind the exchange
+            assert ctx.stencil_info()["on"] == 1, ctx.stencil_info()
         if "expect_persist" in ref and int(ref["expect_persist"]):
             # ranks small enough for one persistent launch per chunk of iterations (bicg_persist.hip) AND with neighbours:
             # halo pushes by the communication wavefronts, window loads from the landing ring, sums through the mailboxes
