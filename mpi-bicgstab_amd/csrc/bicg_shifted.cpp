@@ -136,8 +136,10 @@ int run_switching(bicg_ctx *c, int mode, double *x_set_host, double *r_host, con
     for (int j = 0; j < nsig; ++j)          // p[sigma] <- b for EVERY shift, src/shifted_switching_solver.c:348
         BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
     {   // streaming policy: matrix + 7 work vectors + the two sets
-        const double ws = (double)c->matrix_bytes + 8.0 * st * (7 + 2.0 * nsig);
-        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
+        // (the two sets are streamed past the cache by their own kernels: what competes with the matrix for it are the work vectors.
+        // 16 shifts, Transport-shaped: 250 against 276 us per iteration with ordinary loads -- profiles/r05/ab_matrix_stream_policy.txt)
+        const double ws = (double)c->matrix_bytes + 8.0 * st * 7;
+        c->sell_nt = ws > 2.5 * 256.0 * 1048576.0;
         if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
     }
     BICG_HIP(hipStreamSynchronize(c->sc));
@@ -291,8 +293,9 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
         for (int j = 0; j < nsig; ++j)
             BICG_HIP(hipMemcpyAsync(c->p_set + (size_t)j * st, c->v.r, sizeof(double) * n, hipMemcpyDeviceToDevice, c->sc));
     {   // streaming policy: matrix + 6 work vectors + the two sets
-        const double ws = (double)c->matrix_bytes + 8.0 * st * ((mode == SH_PIPE ? 10 : 6) + 2.0 * nsig);
-        c->sell_nt = ws > 1.25 * 256.0 * 1048576.0;
+        // (as in run_switching: the sets are streamed, the work vectors compete with the matrix)
+        const double ws = (double)c->matrix_bytes + 8.0 * st * (mode == SH_PIPE ? 10 : 6);
+        c->sell_nt = ws > 2.5 * 256.0 * 1048576.0;
         if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
     }
     BICG_HIP(hipStreamSynchronize(c->sc));

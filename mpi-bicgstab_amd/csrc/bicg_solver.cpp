@@ -784,7 +784,10 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
         const double ws = (double)c->matrix_bytes + 8.0 * c->stride * nvec[method];
         // (round 4: with the products alternating direction, ordinary loads pay up to 35 % over the cache -- CA-BiCGStab
         // 166.9 -> 150.6 us per iteration; the pipelined solvers' ten vectors are past that: 157.2 vs 160.9)
-        c->sell_nt = ws > (c->sell_alt ? 1.35 : 1.25) * 256.0 * 1048576.0;
+        // (round 5, the products of rounds 4-5 and an irregular matrix: ordinary loads win far beyond that -- FEM-like, 1.6 M rows,
+        // pipelined, 1.42 x the cache: 161 against 180 us; 2.4 M rows plain 1.85 x: 220 against 239; 3.2 M rows plain 2.47 x: 294
+        // against 306, pipelined 2.85 x: 338 against 325 -- the cross-over is near 2.5 x: profiles/r05/ab_matrix_stream_policy.txt)
+        c->sell_nt = ws > (c->sell_alt ? 2.5 : 1.25) * 256.0 * 1048576.0;
         if (c->sell_nt_env >= 0) c->sell_nt = c->sell_nt_env != 0;
     }
 
