@@ -2474,7 +2474,10 @@ void set_vec_grid_cap(unsigned cap) { g_vec_grid_cap = cap; }
 static unsigned vec_ppt(uint32_t n)
 {
     static const int ppt_env = [] { const char *v = knob_x("BICG_VEC_PPT"); return v ? atoi(v) : -1; }();
-    return ppt_env >= 0 ? (unsigned)ppt_env : (n >= (1u << 26) ? (unsigned)kVecTile : 0u);
+    // (tiles from 2^24 rows = 128 MiB per vector: 256^3 plain 0.512 -> 0.442, CA 0.662 -> 0.573 ms per iteration; at 6.4 M rows --
+    // 49 MiB per vector, what one kernel writes the next still finds in the Infinity Cache -- plain loses 3.6 %, pipelined gains 1.7 %;
+    // at Transport size plain loses 7 %: profiles/r05/ab_vec_tile_sizes.txt)
+    return ppt_env >= 0 ? (unsigned)ppt_env : (n >= (1u << 24) ? (unsigned)kVecTile : 0u);
 }
 // ... as contiguous tiles with non-temporal accesses (k_vec<.., TILE>; BICG_VEC_TILE=0: the strided form of round 4)
 static bool vec_tiled(uint32_t n)
@@ -2490,7 +2493,7 @@ unsigned vec_grid(uint32_t n)
         const int g = v ? atoi(v) : kMaxGrid;
         return (unsigned)(g >= 1 && g <= kMaxGrid ? g : kMaxGrid);
     }();
-    // Vectors far beyond the caches (>= 64 M rows): one workgroup per tile of 4 element pairs per thread (16 KiB per stream)
+    // Vectors far beyond the caches (>= 16.8 M rows): one workgroup per tile of 4 element pairs per thread (16 KiB per stream)
     // instead of <= 2048 persistent workgroups striding through the vectors -- short workgroups stream faster (STREAM read:
     // +12 %, profiles/NOTES.md; 512^3 Laplacian: plain 9.12 -> 8.65 ms, CA 10.86 -> 10.10 ms per iteration, round 4). At
     // 16.8 M rows (256^3) and at Transport size the two forms tie. BICG_VEC_PPT=p forces p pairs per thread everywhere
