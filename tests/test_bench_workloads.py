@@ -112,7 +112,10 @@ def test_laplace7_256_as_benchmarked():
     ctx = H.Context(H.single_rank_blocks(A))
     assert ctx.plan_info()["sell_rows"] == A.rows
     _spmv_check(ctx, A, coo, seed=4)
-    _trajectory_check(ctx, A, coo, ("ca_bicgstab", "bicgstab"), k=8)
+    # (round 5: at this size the element-wise phases run as contiguous non-temporal tiles -- k_vec<.., TILE> -- in all three
+    # reduction modes: ticket (plain, CA) and consumer-side finish (the pipelined solvers, incl. a replacement step)
+    assert ctx.stencil_info()["on"] == 1
+    _trajectory_check(ctx, A, coo, ("ca_bicgstab", "bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"), k=8)
     ctx.close()
 
 
