@@ -304,7 +304,7 @@ def main():
                 rc_p2p = int(L.bicg_comm_enable_p2p())      # collective; leaves the transport as it is when the self-test fails
                 comm_info["p2p_selftest"] = "passed" if rc_p2p == 0 and int(L.bicg_comm_p2p_active()) else f"failed (code {rc_p2p})"
         elif a.force_comm:
-            os.environ["BICG_FORCE_COMM"] = "1"
+            H.switches(force_comm=1)
             buf = (C.c_char * H_UNIQUE)()
             L.bicg_comm_unique_id(buf)
             L.bicg_comm_init_rccl(0, 1, buf.raw, device)
@@ -573,20 +573,20 @@ def main():
     # ------------------------------------------------------------------ how much of the headline is the synthetic's structure?
     # The Transport-SHAPED matrix has 15 constant diagonals: its slices are "uniform" (one shared list of distances, no column
     # index read: 8 instead of 10 bytes per non-zero). Transport.mtx itself (FEM) would not qualify. The same matrix once more
-    # with that layout switched off (BICG_SELL_UNIFORM=0: 16-bit column offsets for every entry) puts a number on the difference.
+    # with that layout switched off (BICG_PLAN="uniform=0": 16-bit column offsets for every entry) puts a number on the difference.
     structure = None
     if world == 1 and not a.inner and not a.no_variants and a.workload == "transport" and not a.matrix:
         stage[0] = "headline without uniform slices"
-        os.environ["BICG_SELL_UNIFORM"] = "0"
+        H.switches(uniform=0)
         try:
             lg = Leg(wl)
         finally:
-            os.environ.pop("BICG_SELL_UNIFORM", None)
+            H.switches(uniform=None)
         dtu, _ = lg.best(a.method)
         _, rese = lg.timed(a.method, kernel_events=True)
         sp_u = rese.spmv_ms_total / max(rese.spmv_launches, 1)
         fb_u = lg.ctx.spmv_matrix_bytes() + 16 * lg.plan["rows"]
-        structure = dict(setting="BICG_SELL_UNIFORM=0: every slice reads its 16-bit column offsets (10 bytes per non-zero)",
+        structure = dict(setting="BICG_PLAN=uniform=0: every slice reads its 16-bit column offsets (10 bytes per non-zero)",
                          flags=[k for k, v in lg.ctx.flags().items() if v],
                          ms_per_iteration=1e3 * dtu / K, ms_per_iteration_default=ms_step,
                          spmv_avg_launch_ms=sp_u, spmv_avg_launch_ms_default=spmv_ms,

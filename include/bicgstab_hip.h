@@ -325,7 +325,7 @@ enum { BICG_FLAG_P2P = 1, BICG_FLAG_LL_FUSED = 2, BICG_FLAG_OVERLAP = 4, BICG_FL
                                      matrix slices and x window in LDS, vectors in registers; bicg_persist.hip) */,
        BICG_FLAG_FUSE_PIPE = 1024 /* multi-launch pipelined iterations run their element-wise phases in the SpMV epilogues (two
                                      launches per iteration) rather than as separate kernels */,
-       BICG_FLAG_PIPE_PROBED = 2048 /* ... and that was MEASURED on this matrix by the first pipelined solve (BICG_PIPE_PROBE=1)
+       BICG_FLAG_PIPE_PROBED = 2048 /* ... and that was MEASURED on this matrix by the first pipelined solve (BICG_PLAN="pipe-probe")
                                      instead of decided by the size / layout rule of bicg_create */,
        BICG_FLAG_UNIFORM = 4096   /* some 64-row slices are UNIFORM -- all rows present, equally long, entry k at the same distance
                                      from its row in every row (the interior of a banded or stencil matrix): the SpMV takes their
@@ -344,26 +344,26 @@ unsigned long long bicg_uniform_entries(bicg_ctx *ctx);
 unsigned long long bicg_constant_entries(bicg_ctx *ctx);
 /* rows of MASKED slices: slices next to a grid face, whose rows are sub-sequences of one list of <= 16 (distance, value) pairs;
  * the product reads one 16-bit word per row for them (which pairs the row has) instead of values and columns. Counted in
- * bicg_uniform_entries / bicg_constant_entries too (with their padded entries). BICG_SELL_MASKED=0 switches them off */
+ * bicg_uniform_entries / bicg_constant_entries too (with their padded entries). BICG_PLAN="masked=0" switches them off */
 unsigned long long bicg_masked_rows(bicg_ctx *ctx);
 /* The plane-marching product (csrc/bicg_stencil.hip): when the plan finds the 7-point stencil of a grid in the lists of a block
  * whose slices are all list-driven -- the interior's distances are (-sz, -sy, -1, 0, +1, +sy, +sz) with sy a multiple of 64 rows,
  * sz a multiple of sy, the rows a multiple of sz, and every other list a sub-sequence of that one -- y = A x runs with every
  * wavefront marching through the planes of its own grid lines (BASELINE.json configs[3]); same sums in the same order as
  * mult() (reference src/matrix.c:506-515). out = {in use (0/1), sy, sz / sy, rows / sz, lines per wavefront, planes per tile,
- * workgroups per product, x segments with masked slices}. BICG_STENCIL=0 switches it off (slice-by-slice product);
- * BICG_STENCIL_LINES=2|4, BICG_STENCIL_ZL=n set the tile; BICG_CA_FUSE=0 keeps CA-BiCGStab's q / y phase a kernel of its own */
+ * workgroups per product, x segments with masked slices}. BICG_PLAN="stencil=0" switches it off (slice-by-slice product);
+ * BICG_PLAN="lines=2|4,planes=n" sets the tile; BICG_PLAN="ca-fuse=0" keeps CA-BiCGStab's q / y phase a kernel of its own */
 int bicg_stencil_info(bicg_ctx *ctx, unsigned int out[8]);
 /* bicg_create_device_csr groups its list-driven slices by 64-bit hashes of their lists and then compares every slice with the
  * list it was given: the number of slices that did NOT match (hash collisions) and were put back on their stored columns and
  * values. 0 for contexts built by bicg_create (the host plan keys on the full lists). */
 unsigned int bicg_plan_collisions(bicg_ctx *ctx);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
- * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST_SHIFTED=0 keeps the multi-launch form) */
+ * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST="shifted=0" keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);
 /* 1 when the last bicg_spmm / bicg_shifted_residuals pass on this context ran the windowed kernel (k_spmm_win: the vectors stay
  * shift-major, the x values a 256-row group touches are staged in LDS for up to 16 vectors at a time and X is read once;
- * BICG_SPMM_WIN=0 selects the row-major kernel k_spmm_sell, which is also what layouts without cluster or window runs take) */
+ * BICG_PLAN="spmm-window=0" selects the row-major kernel k_spmm_sell, which is also what layouts without cluster or window runs take) */
 int bicg_last_spmm_windowed(bicg_ctx *ctx);
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *ctx);
 
@@ -465,6 +465,10 @@ const char *bicg_version(void);
 /* 1: the library was built with `make EXPERIMENTS=1` and reads the measurement knobs of the development rounds (csrc/bicg_knobs.h;
  * the negative results they select -- window-fused plain iteration, direct SpMM -- are compiled in); 0: the default build */
 int bicg_has_experiments(void);
+/* What the library reads from one of its token-list variables (BICG_PLAN, BICG_PERSIST, BICG_TEST: comma-separated `name` or
+ * `name=value` tokens): copies the value of token `name` in $set to out ("1" for a bare token) and returns
+ * its length, -1 when the variable or the token is absent. No device needed. */
+int bicg_switch_value(const char *set, const char *name, char *out, int cap);
 
 #ifdef __cplusplus
 }

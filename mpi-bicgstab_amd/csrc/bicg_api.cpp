@@ -114,7 +114,7 @@ int bicg_shifted_residuals(bicg_ctx *c, const double *x_loc_set, const double *b
     group_now(c, 1, PH_NONE);
     fetch_scal(c);
     const double bb = c->hS->red[0];
-    if (c->spmm_ok && !(getenv("BICG_NO_SPMM") && atoi(getenv("BICG_NO_SPMM")))) {
+    if (c->spmm_ok && !plan_off("spmm")) {
         // every matrix entry is read once for kSpmmCols shifts (the only place where
         // the reference multiplies A with many vectors is this verification loop, one SpMV per shift)
         spmm_buffers(c);

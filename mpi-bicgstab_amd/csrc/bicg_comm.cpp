@@ -2,6 +2,7 @@
 // host-staged callbacks. See bicg_comm.h.
 #include "bicg_comm.h"
 #include "bicg_parallel.h"
+#include "bicg_knobs.h"
 
 #include <dlfcn.h>
 #include <rccl/rccl.h>   // types and enums only; the functions are resolved with dlsym
@@ -283,7 +284,7 @@ int bicg_comm_rccl_loadable(void) { return rccl_loadable(); }
 
 int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device)
 {
-    const char *force = getenv("BICG_FORCE_COMM");     // tests: a real 1-rank RCCL communicator
+    const char *force = test_tok("force-comm");     // tests: a real 1-rank RCCL communicator
     Comm *c = nranks > 1 || (force && atoi(force)) ? make_rccl(rank, nranks, id, device) : make_single(device);
     if (!c) return 1;                                  // BICG_COMM_SOFT_FAIL: no communicator was installed
     comm_set(c);

@@ -24,9 +24,9 @@ static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, cons
                              const std::vector<double> &uval, const unsigned short *rmask_host)
 {
     if (vbase.empty() || ubase.empty() || (uint64_t)nrows >= (1ull << 29)) return;
-    if (getenv("BICG_SELL_DESC") && atoi(getenv("BICG_SELL_DESC")) == 0) return;
+    if (plan_off("desc")) return;
     std::vector<uint4> d(nslices);
-    bool all_lists = !(getenv("BICG_SELL_LISTS") && atoi(getenv("BICG_SELL_LISTS")) == 0) && nrows % kGroupRows == 0;
+    bool all_lists = !plan_off("lists") && nrows % kGroupRows == 0;
     for (uint32_t sl = 0; sl < nslices; ++sl) {
         const uint32_t ub = ubase[sl], vb = vbase[sl], mb = mbase.empty() ? 0xFFFFFFFFu : mbase[sl];
         uint32_t len = slice_len[sl] & 0xFFFFu, kind = kSliceGeneral, w = 0;
@@ -70,7 +70,7 @@ static void build_slice_desc(bicg_ctx *c, uint32_t nslices, uint32_t nrows, cons
 static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, const std::vector<uint4> &d, const std::vector<int> &uoff,
                                const std::vector<double> &uval, const unsigned short *rmask_host)
 {
-    if (getenv("BICG_STENCIL") && atoi(getenv("BICG_STENCIL")) == 0) return;
+    if (plan_off("stencil")) return;
     uint32_t best_at = 0, best_len = 0;
     // the interior's list: the longest one, of a constant slice or (a grid one x segment wide has no other) of a masked one
     for (uint32_t sl = 0; sl < nslices; ++sl) { const uint32_t l = d[sl].x & 0xFFFFu; if ((d[sl].x >> 16) >= kSliceConstant && l > best_len) { best_len = l; best_at = d[sl].y; } }
@@ -159,8 +159,8 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
             if (wgs >= 3000) { lines = cd[0]; zl = cd[1]; break; }
             if (wgs > most) { most = wgs; lines = cd[0]; zl = cd[1]; }
         }
-        if (const char *v = getenv("BICG_STENCIL_LINES")) { const uint32_t r = (uint32_t)atoi(v); if ((r == 2 || r == 4) && ny % r == 0) lines = r; }
-        if (const char *v = getenv("BICG_STENCIL_ZL")) { const int z = atoi(v); if (z >= 1) zl = (uint32_t)z; }
+        if (const char *v = plan_tok("lines")) { const uint32_t r = (uint32_t)atoi(v); if ((r == 2 || r == 4) && ny % r == 0) lines = r; }
+        if (const char *v = plan_tok("planes")) { const int z = atoi(v); if (z >= 1) zl = (uint32_t)z; }
     }
     c->st_code = dev_upload(code.data(), code.size());
     c->st_tab = dev_upload(tab.data(), tab.size());
@@ -172,7 +172,7 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
     const int st_xcd = knob_x("BICG_STENCIL_XCD") ? atoi(knob_x("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
     const int st_nt = knob_x("BICG_STENCIL_NT") ? atoi(knob_x("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
     c->st = StencilDev{1, sy, sz, nxs, ny, nz, 0u, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
-    if (const char *v = getenv("BICG_CA_FUSE")) c->ca_fuse = atoi(v) != 0;
+    if (const char *v = plan_tok("ca-fuse")) c->ca_fuse = atoi(v) != 0;
     // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
     c->stencil_matrix_bytes = 4ull * nslices + (uint64_t)cmask.size();
     if (getenv("BICG_PLAN_TRACE"))
@@ -502,6 +502,13 @@ static void ctx_streams(bicg_ctx *c, int P)
 extern "C" {
 
 int bicg_has_experiments(void) { return kExperiments ? 1 : 0; }
+int bicg_switch_value(const char *set, const char *name, char *out, int cap)
+{
+    const char *v = set && name ? knob_tok(set, name) : nullptr;
+    if (!v) return -1;
+    if (out && cap > 0) { strncpy(out, v, (size_t)cap - 1); out[cap - 1] = 0; }
+    return (int)strlen(v);
+}
 const char *bicg_version(void) { return "bicgstab_hip 0.1 (gfx950)"; }
 
 void bicg_default_options(bicg_options *o)
@@ -552,7 +559,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     if (const char *sv = knob_x("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = knob_x("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
     if (const char *sv = knob_x("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
-    if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
+    if (const char *sv = test_tok("force-comm")) c->force_comm = atoi(sv) != 0;
     if (const char *sv = getenv("BICG_GRAPH")) c->graph_mode = atoi(sv);
     uint64_t nnz_diag_all = c->nnz_d;      // diag non-zeros of all ranks
     {   // Every rank learns every rank's (non-zeros, rows). The enqueue mode changes the ORDER of RCCL calls,
@@ -657,16 +664,16 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         for (uint32_t sl = 0; sl < nslices; ++sl)
             padded_rows += (uint64_t)slice_len[sl] * std::min<uint32_t>(kSliceRows, nrows - sl * kSliceRows);
         jag = padded_rows > (uint64_t)c->nnz_d + c->nnz_d / 50;
-        if (const char *sv = getenv("BICG_SELL_LAYOUT")) jag = !strcmp(sv, "jag") ? true : !strcmp(sv, "pad") ? false : jag;
+        if (const char *sv = plan_tok("layout")) jag = !strcmp(sv, "jag") ? true : !strcmp(sv, "pad") ? false : jag;
     }
     // x windows in LDS (SellDev::win_*): wanted for ragged rows, where the x gather of one step touches many cache
     // lines (FEM-like: 63 -> 58 us per SpMV). With equal rows the gathers are perfectly coalesced and the window
     // only adds staging loads and two barriers per group (Transport-shaped +2 %, 256^3 Laplacian +9 % although its
-    // columns shrink from 32 to 16 bits), so there it is taken on request only: BICG_SELL_WINDOW = 1 asks for it
+    // columns shrink from 32 to 16 bits), so there it is taken on request only: BICG_PLAN="window=1" asks for it
     // whenever it fits, 0 never. It needs the jagged layout.
     const bool jag_auto = jag;
     int win_env = -1;
-    if (const char *sv = getenv("BICG_SELL_WINDOW")) win_env = atoi(sv);
+    if (const char *sv = plan_tok("window")) win_env = atoi(sv);
     bool want_win = use_sell && win_env != 0 && (win_env == 1 || jag_auto);
     if (want_win) jag = true;
     auto group_fits = [&](uint32_t g, uint64_t *stored_out) {
@@ -792,7 +799,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     double *const sval = sval_mem.get();
     std::unique_ptr<uint32_t[]> scol_mem;                          // filled once it is known whether the 32-bit columns are uploaded
     // 16-bit column offsets when every sliced-ELL entry is within +-32767 of its row
-    bool c16 = sell_entries > 0 && (win || !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16"))));
+    bool c16 = sell_entries > 0 && (win || !plan_off("col16"));
     std::vector<uint32_t> slice_base16(nslices, 0u);
     uint64_t n16 = 0;
     if (jag) n16 = sell_entries;
@@ -904,9 +911,9 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     std::vector<double> uval;
     std::vector<unsigned short> rmask;
     uint64_t uniform_entries = 0, constant_entries = 0, masked_rows = 0;
-    const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
-    const bool want_masked = !(getenv("BICG_SELL_MASKED") && atoi(getenv("BICG_SELL_MASKED")) == 0);
-    if (!jag && sell_entries > 0 && !(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
+    const bool want_constant = !plan_off("constant");
+    const bool want_masked = !plan_off("masked");
+    if (!jag && sell_entries > 0 && !plan_off("uniform")) {
         ubase.assign(nslices, 0xFFFFFFFFu);
         std::map<std::vector<int>, uint32_t> lists, vlists;
         std::vector<int> cur, vkey;
@@ -1052,7 +1059,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // CSR kernel (none for banded matrices: everything is on the sliced-ELL path), the 32-bit sliced-ELL
     // columns when the 16-bit offsets do not apply. (Round 1 kept all of them: 2.3 x the matrix.)
     const bool need_csr = c->nblk > 0;
-    bool csr16 = c->rowsplit && need_csr && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
+    bool csr16 = c->rowsplit && need_csr && !plan_off("col16");
     std::vector<short> dcol16;
     if (csr16) {                  // rows-over-lanes kernel: 16-bit column offsets in CSR order when every entry fits
         dcol16.resize((size_t)c->nnz_d + kPadEntries, 0);
@@ -1140,7 +1147,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
                 c->matrix_bytes += 2ull * li.size();
                 c->device_matrix_bytes += 2ull * li.size();
             }
-            if (const char *v = getenv("BICG_JAGW")) c->jagw_fast = atoi(v) != 0;
+            if (const char *v = plan_tok("jagw")) c->jagw_fast = atoi(v) != 0;
         }
         c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
         c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
@@ -1157,7 +1164,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     // of the send list lands in the ring of the rank that needs it (collective)
     c->p2p = comm->p2p;
     std::vector<unsigned long long> dst0, dstride;
-    if (const char *sv = getenv("BICG_P2P_FAULT_AFTER")) c->fault_after = atoi(sv);
+    if (const char *sv = test_tok("p2p-fault-after")) c->fault_after = atoi(sv);
     // in-kernel collect needs the HEAVY kernel instantiations (occupancy 5 instead of 8 waves per SIMD,
     // ~3 % per SpMV): worth it unless the local problem is so large that 3 % exceeds the ~10 us per
     // iteration the separate apply kernels cost
@@ -1196,20 +1203,20 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     }
 
     ctx_state(c, comm, ngroups);
-    if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
+    if (const char *sv = test_tok("spin-ticks")) c->spin_ticks = strtoull(sv, nullptr, 10);
     // Round 4: with the products alternating direction and reading no column index in uniform slices, a big block is faster
     // as two plain products + two element-wise kernels (Transport-shaped, one GPU: 139.0 vs 152.0 us per pipelined iteration;
     // profiles/NOTES.md): the fused two-launch form stays what it was built for -- the latency-bound ranks.
     c->fuse_pipe = c->fuse_small;
-    if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
-    else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
+    if (const char *sv = plan_tok("fuse-pipe")) c->fuse_pipe = atoi(sv) != 0;
+    else if (const char *pv = plan_tok("pipe-probe")) c->pipe_probe = atoi(pv);
     c->spmm_ok = all_ranks(comm, spmm_possible(c));
     c->fuse_plan_ok = all_ranks(comm, c->glist_all && c->nblk == 0 && (c->single() || (c->p2p && c->ll_fused)));
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));
     memset(c->hS, 0, sizeof(Scal));
     {   // persistent pipelined iteration for latency-bound ranks: available when the plan fits on EVERY rank
-        const char *pe = getenv("BICG_PERSIST");
-        bool mine = !(pe && atoi(pe) == 0) && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
+        const bool off = knob_tok("BICG_PERSIST", "0") || knob_tok("BICG_PERSIST", "off");
+        bool mine = !off && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
         c->persist_on = all_ranks(comm, mine);
         if (const char *pp = knob_x("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
         if (const char *pp = knob_x("BICG_FUSE_PLAIN")) c->fuse_plain = atoi(pp) != 0;
@@ -1260,7 +1267,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         padded_rows += (uint64_t)slen[sl] * std::min<uint32_t>(kSliceRows, rows - sl * kSliceRows);
         longest = std::max(longest, slen[sl]);
     }
-    const bool c16 = !far && n16 < 0xFFFFFF00ull && !(getenv("BICG_NO_COL16") && atoi(getenv("BICG_NO_COL16")));
+    const bool c16 = !far && n16 < 0xFFFFFF00ull && !plan_off("col16");
     const char *why = nullptr;
     if (entries >= 0xFFFFFF00ull) why = "more than 2^32 sliced-ELL entries";
     else if (padded_rows > (uint64_t)nnz + nnz / 50) why = "ragged rows (jagged slices are planned on the host)";
@@ -1278,8 +1285,8 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     if (const char *sv = knob_x("BICG_SELL_NT")) c->sell_nt_env = atoi(sv);
     if (const char *sv = knob_x("BICG_SELL_ALT")) c->sell_alt = atoi(sv);
     if (const char *sv = knob_x("BICG_SELL_XCD")) c->sell_xcd = atoi(sv);
-    if (const char *sv = getenv("BICG_FORCE_COMM")) c->force_comm = atoi(sv) != 0;
-    if (c->force_comm) die("bicg_create_device_csr", "BICG_FORCE_COMM is not supported on this path");
+    if (const char *sv = test_tok("force-comm")) c->force_comm = atoi(sv) != 0;
+    if (c->force_comm) die("bicg_create_device_csr", "BICG_TEST=force-comm is not supported on this path");
     c->overlap = nnz >= 6000000u; c->fuse_small = nnz < 6000000u;
     c->scnt.assign(1, 0); c->sdsp.assign(1, 0); c->rcnt.assign(1, 0); c->rdsp.assign(1, 0);
     c->sell_entries = entries; c->sell_nnz = nnz; c->sell_rows = rows; c->sell_jag = false;
@@ -1301,8 +1308,8 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     // is fetched from the CSR (a stencil has a few dozen)
     uint64_t uniform_entries = 0, constant_entries = 0;
     uint32_t far_rows = 0;
-    if (!(getenv("BICG_SELL_UNIFORM") && atoi(getenv("BICG_SELL_UNIFORM")) == 0)) {
-        const bool want_constant = !(getenv("BICG_SELL_CONSTANT") && atoi(getenv("BICG_SELL_CONSTANT")) == 0);
+    if (!plan_off("uniform")) {
+        const bool want_constant = !plan_off("constant");
         unsigned long long *uh_d = dev_alloc<unsigned long long>(2 * (size_t)nslices), *vh_d = uh_d + nslices;
         BICG_HIP(hipMemset(uh_d, 0, sizeof(unsigned long long) * 2 * (size_t)nslices));
         launch_plan_uniform(ptr_d, col_d, val_d, rows, uh_d, want_constant ? vh_d : nullptr, nullptr);
@@ -1312,7 +1319,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         BICG_HIP(hipFree(uh_d));
         // tests: every hash lands in one of TWO buckets -- slices with different lists collide in their thousands and
         // k_plan_verify has to catch each one (tests/test_full_size.py::test_device_plan_survives_hash_collisions)
-        const bool collide = getenv("BICG_PLAN_TEST_COLLIDE") && atoi(getenv("BICG_PLAN_TEST_COLLIDE")) != 0;
+        const bool collide = test_tok("plan-collide") != nullptr;
         if (collide) for (uint32_t sl = 0; sl < nslices; ++sl) { if (uh[sl]) uh[sl] = 1ull + (uh[sl] >> 63); if (vh[sl]) vh[sl] = 1ull + (vh[sl] >> 63); }
         std::vector<uint32_t> vbase, mbase;
         std::vector<double> uval, vals;
@@ -1358,7 +1365,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
         // masked slices (SellDev::mbase): the slices next to a grid face. Found by a kernel (hash of the slice's list of
         // (distance, value) pairs), one representative per hash is fetched and its list rebuilt here, the rows' masks are
         // written by a second pass over the slices that were kept.
-        if (want_constant && !(getenv("BICG_SELL_MASKED") && atoi(getenv("BICG_SELL_MASKED")) == 0)) {
+        if (want_constant && !plan_off("masked")) {
             unsigned long long *mh_d = dev_alloc<unsigned long long>(nslices);
             BICG_HIP(hipMemset(mh_d, 0, sizeof(unsigned long long) * nslices));
             launch_plan_masked(ptr_d, col_d, val_d, rows, mh_d, nullptr, nullptr, nullptr);
@@ -1464,10 +1471,10 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     c->device_matrix_bytes = 8ull * ((uint64_t)rows + 1) + 8ull * entries + (c16 ? 2ull * n16 : 4ull * entries) + 12ull * nslices;
     BICG_HIP(hipFree(far_d));
     ctx_state(c, comm, ngroups);
-    if (const char *sv = getenv("BICG_SPIN_TICKS")) c->spin_ticks = strtoull(sv, nullptr, 10);
+    if (const char *sv = test_tok("spin-ticks")) c->spin_ticks = strtoull(sv, nullptr, 10);
     c->fuse_pipe = c->fuse_small;
-    if (const char *sv = getenv("BICG_FUSE_PIPE")) c->fuse_pipe = atoi(sv) != 0;
-    else if (const char *pv = getenv("BICG_PIPE_PROBE")) c->pipe_probe = atoi(pv);
+    if (const char *sv = plan_tok("fuse-pipe")) c->fuse_pipe = atoi(sv) != 0;
+    else if (const char *pv = plan_tok("pipe-probe")) c->pipe_probe = atoi(pv);
     c->spmm_ok = spmm_possible(c);
     c->fuse_plan_ok = true;
     BICG_HIP(hipHostMalloc((void **)&c->hS, sizeof(Scal), hipHostMallocDefault));

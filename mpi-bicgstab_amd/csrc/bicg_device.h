@@ -301,7 +301,7 @@ struct SellDev {
     //   x = length | kind << 16   (kSliceGeneral: columns and values streamed, kSliceUniform: values streamed,
     //                               kSliceConstant: y = position in uoff, z = position in uval,
     //                               kSliceMasked: the same + w = index of the slice in rmask; length = the LIST's length)
-    // null: no descriptors (BICG_SELL_DESC=0, or 2^29 rows and more: the fast paths address x by 32-bit byte offsets).
+    // null: no descriptors (BICG_PLAN="desc=0", or 2^29 rows and more: the fast paths address x by 32-bit byte offsets).
     const uint4 *sdesc;
     // whole 256-row groups only, and every slice is constant or masked with a list of at most 8 entries (a constant-coefficient stencil: the
     // 7-point Laplacian of BASELINE.json configs[3]): the product runs a loop of its own over the descriptors -- list lengths

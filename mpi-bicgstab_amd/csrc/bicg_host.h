@@ -98,23 +98,23 @@ struct bicg_ctx {
     double *s_val = nullptr;
     uint32_t *s_col = nullptr, *s_base = nullptr, *s_len = nullptr, *s_base16 = nullptr;
     short *s_col16 = nullptr;
-    uint32_t *s_ubase = nullptr;           // uniform slices (SellDev::ubase / uoff): BICG_SELL_UNIFORM=0 switches them off
+    uint32_t *s_ubase = nullptr;           // uniform slices (SellDev::ubase / uoff): BICG_PLAN="uniform=0" switches them off
     int *s_uoff = nullptr;
     uint64_t uniform_entries = 0;          // sliced-ELL entries whose columns the SpMV does not read
     uint32_t far_rows = 0;                 // farthest column distance of a uniform slice, in rows (a grid's plane size)
-    uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_SELL_MASKED=0 switches them off
+    uint32_t *s_mbase = nullptr;           // masked slices (SellDev::mbase / rmask): BICG_PLAN="masked=0" switches them off
     unsigned short *s_rmask = nullptr;
     uint64_t masked_rows = 0;
     uint32_t plan_collisions = 0;          // list-driven slices the device plan's verification pass put back (bicg_plan_collisions)
     int *s_uoff8 = nullptr;                // SellDev::uoff8
     int sell_ystride = 0;                  // SellDev::ystride (BICG_SELL_YGROUP=1; default: consecutive slices per workgroup)
-    bool sell_all_lists = false;           // SellDev::all_lists (BICG_SELL_LISTS=0 switches the loop of its own off)
-    StencilDev st{};                       // SellDev::st: the plane-marching product of a 7-point grid stencil (BICG_STENCIL=0: off)
+    bool sell_all_lists = false;           // SellDev::all_lists (BICG_PLAN="lists=0" switches the loop of its own off)
+    StencilDev st{};                       // SellDev::st: the plane-marching product of a 7-point grid stencil (BICG_PLAN="stencil=0": off)
     uint32_t *st_code = nullptr; StencilTab *st_tab = nullptr; unsigned char *st_cmask = nullptr;
     bool st_multi = false;                 // several ranks: the halo-free rows of this rank are the whole planes z_lo .. z_hi - 1 of its grid
-    bool ca_fuse = true;                   // CA-BiCGStab: q, y and their dots in the epilogue of z = A s (plane-marching product only; BICG_CA_FUSE=0)
-    uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_SELL_DESC=0 switches them off
-    uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_SELL_CONSTANT=0 switches them off
+    bool ca_fuse = true;                   // CA-BiCGStab: q, y and their dots in the epilogue of z = A s (plane-marching product only; BICG_PLAN="ca-fuse=0")
+    uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_PLAN="desc=0" switches them off
+    uint32_t *s_vbase = nullptr;           // constant slices (SellDev::vbase / uval): BICG_PLAN="constant=0" switches them off
     double *s_uval = nullptr;
     uint64_t constant_entries = 0;         // ... whose values it does not read either
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
@@ -123,7 +123,7 @@ struct bicg_ctx {
     uint2 *win_runs = nullptr;
     unsigned char *sell_perm = nullptr;    // SellDev::perm
     unsigned short *lane_info = nullptr;   // SellDev::lane_info
-    bool jagw_fast = true;                 // the three-trip product of bicg_jagw.hip (BICG_JAGW=0: k_spmv_sell's loop)
+    bool jagw_fast = true;                 // the three-trip product of bicg_jagw.hip (BICG_PLAN="jagw=0": k_spmv_sell's loop)
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
     uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;
     uint64_t sell_entries = 0, sell_nnz = 0;
@@ -151,7 +151,7 @@ struct bicg_ctx {
     bool ll_fused = false;
     uint32_t *glist_ll = nullptr;
     bool inline_apply = true;       // BICG_P2P_INLINE_APPLY=0: always use the separate apply kernel
-    int fault_after = 0;            // BICG_P2P_FAULT_AFTER=n (tests): from the n-th exchange on this rank sends nothing
+    int fault_after = 0;            // BICG_TEST="p2p-fault-after=n" (tests): from the n-th exchange on this rank sends nothing
 
     // vectors and scalars
     double *slab = nullptr;
@@ -172,9 +172,9 @@ struct bicg_ctx {
     bool spmm_ok = false;        // spmm_possible() on every rank (the SpMM exchanges the halos of all its vectors at once)
     bool fuse_plan_ok = false;   // every row on the sliced-ELL path and one launch per SpMV -- ON EVERY RANK (the fused and the
                                  // separate flow exchange their dot groups differently: the choice is collective)
-    bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues (BICG_FUSE_PIPE=0/1 overrides)
+    bool fuse_pipe = true;       // pipelined solvers: element-wise phases in the SpMV epilogues (BICG_PLAN="fuse-pipe=0|1" overrides)
     bool fuse_small = true;      // ... the average block has < 6 M non-zeros: fused whatever the layout
-    int  pipe_probe = 0;         // BICG_PIPE_PROBE=1: the first pipelined solve TIMES both forms on this matrix and keeps the faster
+    int  pipe_probe = 0;         // BICG_PLAN="pipe-probe": the first pipelined solve TIMES both forms on this matrix and keeps the faster
     bool pipe_probed = false;    // ... done (the choice holds for the life of the context)
     double probe_ms[2] = {0, 0}; // ... ms per iteration measured for {separate kernels, phases in the SpMV epilogues}
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
@@ -191,7 +191,7 @@ struct bicg_ctx {
     llword *shard_ll = nullptr;  // 2 x [kShards][kRedSlots][2], alternating like wpart
     int *alarm = nullptr, *h_alarm = nullptr;
     unsigned grp_seq = 0;
-    unsigned long long spin_ticks = 2000;   // 20 us before a workgroup sums a missing shard itself (BICG_SPIN_TICKS)
+    unsigned long long spin_ticks = 2000;   // 20 us before a workgroup sums a missing shard itself (BICG_TEST="spin-ticks=n")
     double *partial = nullptr, *shard_tot = nullptr;
     unsigned *counter = nullptr;
     // tail finish of ticket-mode dot groups (struct Reduce): LL table + shard totals; BICG_TAIL_FINISH=0: arrival tickets
@@ -233,7 +233,7 @@ struct bicg_ctx {
     bool phantom = false;
     std::vector<double> ph_scratch;
     bool mm_win = false;         // the last SpMM pass ran the windowed kernel (vectors stay shift-major, X staged in LDS)
-    int  mm_win_env = 1;         // BICG_SPMM_WIN=0: the row-major kernel
+    int  mm_win_env = 1;         // BICG_PLAN="spmm-window=0": the row-major kernel
 
     // state of the solve in progress (run_begin / run_iterate / run_end)
     bicg_options opt{};
@@ -263,7 +263,7 @@ struct bicg_ctx {
     double sec_ms[4] = {0, 0, 0, 0};
     int sec_iters = 0;
 
-    // BICG_FORCE_COMM=1 (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
+    // BICG_TEST="force-comm" (tests): run the multi-rank code path (pack, exchange, packed all-reduce,
     // apply kernels, two streams) even with one rank, so that it can be exercised on a one-GPU box
     bool force_comm = false;
     bool single() const { return nranks == 1 && !force_comm; }

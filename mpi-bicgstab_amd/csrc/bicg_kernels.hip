@@ -1859,7 +1859,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
 // wavefront's gather is four or five cache lines, not sixty-four as in the row-major kernel, there is no LDS window to stage,
 // no barrier, and two vectors' gathers are in flight per lane. The matrix is read once, X once per row that touches it through
 // the caches, Y written once; per row and vector the sum runs in stored order like mult() (reference src/matrix.c:506-515):
-// every column is bit-identical to bicg_spmv of that vector. (BICG_SPMM_WIN=2; rows longer than 16 stream their tail per vector.)
+// every column is bit-identical to bicg_spmv of that vector. (BICG_PLAN="spmm-window=2"; rows longer than 16 stream their tail per vector.)
 // ------------------------------------------------------------------------------------------
 template <bool C16, bool OFFD>
 __global__ void __launch_bounds__(kBlock) k_spmm_dir(SpmmArgs a)

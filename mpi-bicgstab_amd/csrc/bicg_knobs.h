@@ -1,5 +1,10 @@
-// bicg_knobs.h -- the library's run-time switches come in two kinds.
-//   getenv("BICG_...") directly: switches for users and for the tests (tabled in INTEGRATION.md section 6).
+// bicg_knobs.h -- the library's run-time switches come in three kinds.
+//   getenv("BICG_...") directly: switches for users (tabled in INTEGRATION.md section 6).
+//   knob_tok(set, "name"):       the forms of the plan and the hooks of the tests, gathered in three variables that hold
+//                                comma-separated `name` / `name=value` tokens: BICG_PLAN (which layouts and products the plan may
+//                                use: "stencil=0,lines=2,planes=8"), BICG_PERSIST ("0", or "chunk=64,shifted=0") and BICG_TEST
+//                                (fault injection and forced paths: "force-comm,spin-ticks=0"). Every form gives the same bits or
+//                                is covered by a test that says what differs; the table is in INTEGRATION.md section 6.
 //   knob_x("BICG_..."):          measurement knobs of the development rounds -- A/B settings whose outcome is on record in
 //                                profiles/NOTES.md, negative results kept for reference. They are read only by a library built
 //                                with `make EXPERIMENTS=1` (-DBICG_EXPERIMENTS); the default build has their defaults compiled in
@@ -7,8 +12,39 @@
 #pragma once
 
 #include <cstdlib>
+#include <cstring>
 
 namespace bicg {
+
+// Value of token `name` in the comma-separated list $set ("1" for a bare token), nullptr when the variable or the token is
+// absent. The text lives in one of four per-thread buffers, so a caller may hold a few values at a time.
+inline const char *knob_tok(const char *set, const char *name)
+{
+    const char *s = getenv(set);
+    if (!s) return nullptr;
+    static thread_local char buf[4][48];
+    static thread_local unsigned turn = 0;
+    const size_t ln = strlen(name);
+    while (*s) {
+        while (*s == ',' || *s == ' ') ++s;
+        const char *e = s;
+        while (*e && *e != ',' && *e != ' ') ++e;
+        if ((size_t)(e - s) >= ln && !strncmp(s, name, ln) && (s + ln == e || s[ln] == '=')) {
+            char *out = buf[turn++ & 3];
+            if (s + ln == e) { out[0] = '1'; out[1] = 0; return out; }
+            size_t lv = (size_t)(e - s) - ln - 1;
+            if (lv > sizeof(buf[0]) - 1) lv = sizeof(buf[0]) - 1;
+            memcpy(out, s + ln + 1, lv);
+            out[lv] = 0;
+            return out;
+        }
+        s = e;
+    }
+    return nullptr;
+}
+inline const char *plan_tok(const char *name) { return knob_tok("BICG_PLAN", name); }
+inline const char *test_tok(const char *name) { return knob_tok("BICG_TEST", name); }
+inline bool plan_off(const char *name) { const char *v = plan_tok(name); return v && atoi(v) == 0; }     // "name=0"
 
 #ifdef BICG_EXPERIMENTS
 inline const char *knob_x(const char *name) { return getenv(name); }

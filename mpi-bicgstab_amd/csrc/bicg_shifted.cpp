@@ -318,12 +318,12 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     int it = 0;
     // latency-bound ranks: the pipelined shifted iteration as ONE persistent launch per chunk (bicg_persist.hip, k_shpipe_persist);
     // section timing needs the launch boundaries and keeps the multi-launch form
-    const int persist_shifted_env = getenv("BICG_PERSIST_SHIFTED") ? atoi(getenv("BICG_PERSIST_SHIFTED")) : 1;
+    const int persist_shifted_env = knob_tok("BICG_PERSIST", "shifted") ? atoi(knob_tok("BICG_PERSIST", "shifted")) : 1;
     bool persist = (mode == SH_PIPE || mode == SH_LOP) && c->persist_on && c->persist.rpt == 1u && nsig <= kPersistMaxShifts && persist_shifted_env != 0 &&
                    !(o.time_kernels & 3) && !c->time_sections;
     c->last_shifted_persist = false;
     while (!c->hS->done && it < o.max_iter) {
-        const int persist_chunk_min = getenv("BICG_PERSIST_CHUNK") ? std::max(1, atoi(getenv("BICG_PERSIST_CHUNK"))) : kPersistChunk;
+        const int persist_chunk_min = knob_tok("BICG_PERSIST", "chunk") ? std::max(1, atoi(knob_tok("BICG_PERSIST", "chunk"))) : kPersistChunk;
         const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, o.max_iter - it);
         sec_mark(c, SEC_VEC);
         if (persist) {

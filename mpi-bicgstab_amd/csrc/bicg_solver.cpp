@@ -332,7 +332,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         }
         const unsigned seq = ++c->halo_seq;
         c->halo_unsynced++;
-        const bool lose = c->fault_after > 0 && seq >= (unsigned)c->fault_after;   // BICG_P2P_FAULT_AFTER (tests)
+        const bool lose = c->fault_after > 0 && seq >= (unsigned)c->fault_after;   // BICG_TEST="p2p-fault-after=n" (tests)
         if (fused) {
             // ONE launch: leading workgroups push, the others multiply; halo-touching groups come last
             // and read the landing ring directly
@@ -455,7 +455,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
     // the windowed form (k_spmm_win) reads the shift-major vectors directly and writes Y shift-major into mm_yt
     const unsigned wslots = c->win_slots ? c->win_slots : (c->s_col16 && !c->sell_jag && c->fw.ncl > 0 ? c->fw.slots : 0u);
-    // (BICG_SPMM_WIN=2: the direct form for padded slices -- row heads in registers, gathers from the shift-major vectors)
+    // (BICG_PLAN="spmm-window=2": the direct form for padded slices -- row heads in registers, gathers from the shift-major vectors)
     const bool direct = c->mm_win_env == 2 && !c->sell_jag && !c->win_slots;
     c->mm_win = direct || (c->mm_win_env != 0 && spmm_win_vectors(wslots) > 0);
     if (!c->mm_win) launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
@@ -478,7 +478,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     } else if (c->mm_win) {
         a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
         if (!c->win_slots) a.cl = c->fw;
-        if (launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_SPMM_WIN=0 selects the row-major form)");
+        if (launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
     } else {
         launch_spmm_sell(a, !c->single(), c->sc);
     }
@@ -505,7 +505,7 @@ void spmm_buffers(bicg_ctx *c)
     BICG_HIP(hipMemset(c->mm_in, 0, sizeof(double) * kSpmmCols * st));
     BICG_HIP(hipDeviceSynchronize());      // the memset ran on the null stream: c->sc does not wait for it
     c->mm_xcd = !(knob_x("BICG_SPMM_XCD") && atoi(knob_x("BICG_SPMM_XCD")) == 0);
-    c->mm_win_env = getenv("BICG_SPMM_WIN") ? atoi(getenv("BICG_SPMM_WIN")) : 1;
+    c->mm_win_env = plan_tok("spmm-window") ? atoi(plan_tok("spmm-window")) : 1;
     if (!kExperiments && c->mm_win_env == 2) c->mm_win_env = 1;      // (2 = the direct form: builds with EXPERIMENTS=1 only)
 }
 
@@ -892,7 +892,7 @@ int run_iterate(bicg_ctx *c, int nsteps)
         // A persistent launch costs ~27 us of set-up (matrix slices and x window into LDS) and stops by itself at
         // convergence: it covers at least kPersistChunk iterations whatever the host check interval (200 k-row rank,
         // pipelined: 12.5 us per iteration at 16 per launch, 11.0 at 128, 10.9 at 512 -- tools/persist_chunk_times.py)
-        const int persist_chunk_min = getenv("BICG_PERSIST_CHUNK") ? std::max(1, atoi(getenv("BICG_PERSIST_CHUNK"))) : kPersistChunk;
+        const int persist_chunk_min = knob_tok("BICG_PERSIST", "chunk") ? std::max(1, atoi(knob_tok("BICG_PERSIST", "chunk"))) : kPersistChunk;
         const int chunk = std::min(persist ? std::max(o.check_every, persist_chunk_min) : o.check_every, stop - c->it);
         bool force = false;
         // (the persistent kernel checks the drift itself, every check_every iterations inside the launch)
@@ -973,7 +973,7 @@ int run_end(bicg_ctx *c, bicg_result *res)
 
 // Which pipelined form? By default a constant decides (fuse_small / x windows, set in bicg_create): the same program then
 // takes the same form on every run, which keeps results bit-reproducible from run to run -- the two forms associate the dot
-// sums differently. BICG_PIPE_PROBE=1 measures instead: the first pipelined solve on a context runs 2 + 6 iterations of each
+// sums differently. BICG_PLAN="pipe-probe" measures instead: the first pipelined solve on a context runs 2 + 6 iterations of each
 // form on the system A x = A 1, x0 = 0 (the caller's x0 / b are restored afterwards), all ranks agree on the slower rank's times, the
 // faster form stays. The extra solves advance the exchange sequence numbers: a probed solve is not bit-identical to an unprobed one
 // whenever the chosen form differs from the rule's (probing trades away that reproducibility; it is opt-in).

@@ -61,7 +61,7 @@ EXPORTS = [
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
-    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_has_experiments", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
+    "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_has_experiments", "bicg_switch_value", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
 ]
 
 _lib = None
@@ -84,6 +84,7 @@ def lib():
         L.bicg_run_begin.argtypes = [C.c_void_p, C.c_int, C.POINTER(Options)]
         L.bicg_run_iterate.argtypes = [C.c_void_p, C.c_int]
         L.bicg_run_iterate_timed.argtypes = [C.c_void_p, C.c_int, _dp]
+        L.bicg_switch_value.argtypes = [C.c_char_p, C.c_char_p, C.c_char_p, C.c_int]
         L.bicg_run_end.argtypes = [C.c_void_p, C.POINTER(Result)]
         L.bicg_sync.argtypes = [C.c_void_p]
         L.bicg_load.argtypes = [C.c_void_p, _dp, _dp]
@@ -142,6 +143,44 @@ def lib():
                                        C.c_int, C.c_int]
         _lib = L
     return _lib
+
+
+# The library's token-list variables (csrc/bicg_knobs.h): keyword -> (variable, token). INTEGRATION.md section 6 says what each does.
+SWITCHES = {k: ("BICG_PLAN", k.replace("_", "-")) for k in (
+    "stencil", "lines", "planes", "ca_fuse", "layout", "window", "col16", "uniform", "constant", "masked", "desc", "lists", "jagw",
+    "spmm", "spmm_window", "fuse_pipe", "pipe_probe")}
+SWITCHES.update(persist=("BICG_PERSIST", "0"), persist_chunk=("BICG_PERSIST", "chunk"), persist_shifted=("BICG_PERSIST", "shifted"),
+                force_comm=("BICG_TEST", "force-comm"), spin_ticks=("BICG_TEST", "spin-ticks"),
+                p2p_fault_after=("BICG_TEST", "p2p-fault-after"), plan_collide=("BICG_TEST", "plan-collide"))
+SWITCH_VARS = ("BICG_PLAN", "BICG_PERSIST", "BICG_TEST")
+
+
+def switches(env=None, **kw):
+    """Set (value) or clear (None) tokens of BICG_PLAN / BICG_PERSIST / BICG_TEST in `env` (default: this process's environment),
+    the other tokens stay: switches(stencil=0, lines=2) -> BICG_PLAN="stencil=0,lines=2"; switches(force_comm=1) ->
+    BICG_TEST="force-comm=1"; switches(persist=0) -> BICG_PERSIST="0" beside its chunk= / shifted= tokens, persist=1 or None
+    takes the "0" away. Contexts read the variables when they are created."""
+    env = os.environ if env is None else env
+    for k, v in kw.items():
+        var, tok = SWITCHES[k]
+        toks = [t for t in env.get(var, "").split(",") if t and t.split("=")[0] != tok and not (k == "persist" and t in ("1", "off"))]
+        if k == "persist":
+            if v is not None and int(v) == 0:
+                toks.insert(0, "0")
+        elif v is not None:
+            toks.append(f"{tok}={v}")
+        if toks:
+            env[var] = ",".join(toks)
+        else:
+            env.pop(var, None)
+    return env
+
+
+def switch_value(var: str, name: str):
+    """what the LIBRARY reads for token `name` of BICG_PLAN / BICG_PERSIST / BICG_TEST (bicg_switch_value): its text, None if absent"""
+    buf = C.create_string_buffer(64)
+    n = lib().bicg_switch_value(var.encode(), name.encode(), buf, 64)
+    return None if n < 0 else buf.value.decode()
 
 
 def _d(a):

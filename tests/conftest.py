@@ -20,3 +20,20 @@ def pytest_sessionstart(session):
         subprocess.call(["make", "-j", "8", "-C", os.path.join(ROOT, "mpi-bicgstab_amd"), "all"])
     if not os.path.exists(os.path.join(ROOT, "oracle", "liboracle.so")):
         subprocess.call(["make", "-C", os.path.join(ROOT, "oracle"), "all"])
+
+
+import pytest
+
+
+@pytest.fixture(autouse=True)
+def _switch_variables_restored():
+    """the library's token-list variables (BICG_PLAN / BICG_PERSIST / BICG_TEST, csrc/bicg_knobs.h) are put back after every test:
+    tests change single tokens with hipsolver.switches() and need not undo them"""
+    names = ("BICG_PLAN", "BICG_PERSIST", "BICG_TEST")
+    saved = {k: os.environ.get(k) for k in names}
+    yield
+    for k, v in saved.items():
+        if v is None:
+            os.environ.pop(k, None)
+        else:
+            os.environ[k] = v

@@ -170,9 +170,9 @@ def gpu_worker(rank, world, port, kind, outdir):
             # every rank), two launches per iteration, separate kernels -- same answer up to the association of the dot sums
             fl = ctx.flags()
             orcs = {m: O.solve(m, A.rows, row, col, val, b_full, nranks=world, tol=1e-9) for m in ("pipe_bicgstab", "bicgstab", "ca_bicgstab")}
-            for name, env in (("persistent", {"BICG_PERSIST": "1"}), ("two-launch", {"BICG_PERSIST": "0", "BICG_FUSE_PIPE": "1"}),
-                              ("separate", {"BICG_PERSIST": "0", "BICG_FUSE_PIPE": "0"})):
-                os.environ.update(env)
+            for name, env in (("persistent", dict(persist=1, fuse_pipe=None)), ("two-launch", dict(persist=0, fuse_pipe=1)),
+                              ("separate", dict(persist=0, fuse_pipe=0))):
+                H.switches(**env)
                 c2 = H.Context(H.HostBlocks(diag, offd, A.rows, counts, displs))
                 if name == "persistent" and kind in ("offsets", "stencil", "laplace"):      # (a block with a 700-entry row does not qualify)
                     assert c2.flags()["persist"], c2.flags()
@@ -185,8 +185,7 @@ def gpu_worker(rank, world, port, kind, outdir):
                     g3 = c2.solve(m, b, tol=1e-9, check_every=4)          # run to run: same bits
                     assert g3["k"] == g2["k"] and np.array_equal(g3["x"], g2["x"]), (name, m)
                 c2.close()
-            for k_ in ("BICG_PERSIST", "BICG_FUSE_PIPE"):
-                os.environ.pop(k_, None)
+            H.switches(persist=None, fuse_pipe=None)
         # shifted systems, 5 shifts, seed 2 (reference src/test_shifted.c:95-111 set-up)
         sigma, seed = 0.01 * (np.arange(5) + 1.0), 2
         bs_full = b_full + sigma[seed] * np.ones(A.rows)

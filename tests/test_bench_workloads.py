@@ -173,7 +173,7 @@ def test_shifted_on_a_rank_of_8_is_one_persistent_launch(which):
     shifted_lopbicgstab run as persistent launches (k_shpipe_persist / k_shlop_persist: seed vectors in registers, the 15 other
     shifts' p_j / x_j streamed through while the last dot group travels, the per-shift coefficients published by the helper
     workgroup with omega) -- asserted --, the first K iterations against the oracle's trajectory, the converged solve beside the
-    multi-launch form (BICG_PERSIST_SHIFTED=0), run-to-run bit-identical (reference src/shifted_solver.c:257-319, 794-866)."""
+    multi-launch form (BICG_PERSIST="shifted=0"), run-to-run bit-identical (reference src/shifted_solver.c:257-319, 794-866)."""
     import os
     H.lib().bicg_comm_init_single(0)
     n8 = (synth.TRANSPORT_N + 7) // 8
@@ -201,7 +201,7 @@ def test_shifted_on_a_rank_of_8_is_one_persistent_launch(which):
     assert ctx.last_shifted_persistent() and 100 < full["k"] < 600
     rel = ctx.shifted_residuals(full["x"], b, sigma)
     assert rel.max() < 1e-4, rel
-    os.environ["BICG_PERSIST_SHIFTED"] = "0"
+    H.switches(persist_shifted=0)
     try:
         ref = H.Context(H.single_rank_blocks(A))
         multi = ref.solve_shifted(b, sigma, seed, tol=1e-5, max_iter=600, which=which)
@@ -209,7 +209,7 @@ def test_shifted_on_a_rank_of_8_is_one_persistent_launch(which):
         ref_rel = ref.shifted_residuals(multi["x"], b, sigma)
         ref.close()
     finally:
-        os.environ.pop("BICG_PERSIST_SHIFTED")
+        H.switches(persist_shifted=None)
     # (the iterates themselves are not comparable at this tolerance: residual 1e-5 on a matrix scaled over two decades leaves
     # errors of several per cent in x -- in both forms)
     assert abs(full["k"] - multi["k"]) <= 0.1 * multi["k"], (full["k"], multi["k"])

@@ -1,4 +1,4 @@
-"""The multi-rank machinery on ONE GPU (`-m gpu`): BICG_FORCE_COMM=1 makes a single rank take the
+"""The multi-rank machinery on ONE GPU (`-m gpu`): BICG_TEST=force-comm makes a single rank take the
 N>1 code path -- halo pack/exchange calls, packed all-reduce of every dot group on the
 communication stream, 1-thread apply kernels, event joins -- with either the trivial transport or a
 REAL one-rank RCCL communicator, eagerly and as a replayed hipGraph. Every combination must
@@ -22,9 +22,11 @@ def _solve_all(A, b, **env):
     import os
     # bit equality across transports is a statement about identical kernels: the persistent one-launch form of
     # pipe_bicgstab (bicg_persist.hip) associates the dot sums differently and is compared on its own below
-    env.setdefault("BICG_PERSIST", 0)
-    saved = {k: os.environ.get(k) for k in env}
-    os.environ.update({k: str(v) for k, v in env.items()})
+    # (lower-case keywords are tokens of BICG_PLAN / BICG_PERSIST / BICG_TEST -- hipsolver.switches --, the rest are variables)
+    env.setdefault("persist", 0)
+    saved = {k: os.environ.get(k) for k in list(H.SWITCH_VARS) + [k for k in env if k not in H.SWITCHES]}
+    H.switches(**{k: v for k, v in env.items() if k in H.SWITCHES})
+    os.environ.update({k: str(v) for k, v in env.items() if k not in H.SWITCHES})
     try:
         ctx = H.Context(H.single_rank_blocks(A))
         out = {}
@@ -52,10 +54,10 @@ def problem():
     ctx = H.Context(H.single_rank_blocks(A))
     b = ctx.spmv(np.ones(A.rows))
     ctx.close()
-    # BICG_FUSE_PIPE=0: a small single rank runs the pipelined phases in the SpMV epilogues (two launches per iteration),
+    # BICG_PLAN="fuse-pipe=0": a small single rank runs the pipelined phases in the SpMV epilogues (two launches per iteration),
     # the host-enqueued transports keep them as separate kernels; same arithmetic per element, but the dot sums are then
     # associated differently -- bit equality across transports is a statement about identical kernels
-    return A, b, _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=0)
+    return A, b, _solve_all(A, b, BICG_GRAPH=0, fuse_pipe=0)
 
 
 def _same(got, ref):
@@ -66,7 +68,7 @@ def _same(got, ref):
 
 def test_graph_replay_single_rank(problem):
     A, b, ref = problem
-    _same(_solve_all(A, b, BICG_GRAPH=1, BICG_FUSE_PIPE=0), ref)
+    _same(_solve_all(A, b, BICG_GRAPH=1, fuse_pipe=0), ref)
 
 
 @pytest.mark.parametrize("overlap", [0, 1])
@@ -74,21 +76,21 @@ def test_graph_replay_single_rank(problem):
 def test_forced_comm_trivial_transport(problem, graph, overlap):
     A, b, ref = problem
     H.lib().bicg_comm_init_single(0)
-    _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph, BICG_OVERLAP=overlap), ref)
+    _same(_solve_all(A, b, force_comm=1, BICG_GRAPH=graph, BICG_OVERLAP=overlap), ref)
 
 
 @pytest.mark.parametrize("overlap", [0, 1])      # 1 = two-stream mode: halo / all-reduce on the communication stream
 @pytest.mark.parametrize("graph", [0, 1])
 def test_forced_comm_one_rank_rccl(problem, graph, overlap, monkeypatch):
     A, b, ref = problem
-    monkeypatch.setenv("BICG_FORCE_COMM", "1")
+    H.switches(force_comm=1)
     buf = (C.c_char * 128)()
     H.lib().bicg_comm_unique_id(buf)
     H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
     try:
-        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=graph, BICG_OVERLAP=overlap), ref)
+        _same(_solve_all(A, b, force_comm=1, BICG_GRAPH=graph, BICG_OVERLAP=overlap), ref)
     finally:
-        monkeypatch.delenv("BICG_FORCE_COMM")
+        H.switches(force_comm=None)
         H.lib().bicg_comm_init_single(0)
 
 
@@ -96,16 +98,16 @@ def test_forced_comm_peer_to_peer_one_rank(problem, monkeypatch):
     """The peer-to-peer data path (bicg_p2p.cpp) with one rank: dot groups go through the LL mailbox
     and k_apply_p2p, SpMVs through the (empty) push / unpack kernels -- same bits as single rank."""
     A, b, ref = problem
-    monkeypatch.setenv("BICG_FORCE_COMM", "1")
+    H.switches(force_comm=1)
     buf = (C.c_char * 128)()
     H.lib().bicg_comm_unique_id(buf)
     H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
     try:
         assert H.lib().bicg_comm_enable_p2p() == 0
         assert H.lib().bicg_comm_p2p_active() > 0
-        _same(_solve_all(A, b, BICG_FORCE_COMM=1, BICG_GRAPH=0, BICG_FUSE_PIPE=0), ref)
+        _same(_solve_all(A, b, force_comm=1, BICG_GRAPH=0, fuse_pipe=0), ref)
     finally:
-        monkeypatch.delenv("BICG_FORCE_COMM")
+        H.switches(force_comm=None)
         H.lib().bicg_comm_init_single(0)
 
 
@@ -113,7 +115,7 @@ def test_fused_pipelined_iteration_matches_separate_kernels(problem):
     """k_spmv_sell_epi (phases in the SpMV epilogues) against the four-kernel iteration: same iteration count, same
     solution to rounding (only the association of the dot sums differs)"""
     A, b, ref = problem
-    got = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1)
+    got = _solve_all(A, b, BICG_GRAPH=0, fuse_pipe=1)
     for m in ("pipe_bicgstab", "pipe_bicgstab_rr"):
         assert abs(got[m][0] - ref[m][0]) <= 1, m
         assert np.abs(got[m][1] - ref[m][1]).max() <= 1e-9 * np.abs(ref[m][1]).max(), m
@@ -133,14 +135,10 @@ def test_persistent_iterations(problem, monkeypatch):
     tols = dict(METHODS)
     methods = ("pipe_bicgstab", "bicgstab", "ca_bicgstab")
     runs = []
-    # (BICG_PERSIST_CHUNK: a persistent launch covers at least that many iterations whatever check_every says -- 128 by
+    # (BICG_PERSIST="chunk=n": a persistent launch covers at least that many iterations whatever check_every says -- 128 by
     # default; 1 = exactly check_every, the last run takes the default)
     for check_every, least in ((5, 1), (5, 1), (1, 1), (64, 1), (5, None)):
-        monkeypatch.setenv("BICG_PERSIST", "1")
-        if least is None:
-            monkeypatch.delenv("BICG_PERSIST_CHUNK", raising=False)
-        else:
-            monkeypatch.setenv("BICG_PERSIST_CHUNK", str(least))
+        H.switches(persist=1, persist_chunk=least)
         ctx = H.Context(H.single_rank_blocks(A))
         assert ctx.flags()["persist"], ctx.flags()
         out = {}
@@ -161,7 +159,7 @@ def test_persistent_iterations(problem, monkeypatch):
             k, x, r, a, d = other[m]
             assert k == k0 and np.array_equal(x, x0) and np.array_equal(r, r0) and np.array_equal(a, a0) and np.array_equal(d, d0), m
     # through the peer-to-peer transport, one rank: dot groups via the mailboxes, (empty) halo pushes
-    monkeypatch.setenv("BICG_FORCE_COMM", "1")
+    H.switches(force_comm=1)
     buf = (C.c_char * 128)()
     H.lib().bicg_comm_unique_id(buf)
     H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
@@ -175,18 +173,18 @@ def test_persistent_iterations(problem, monkeypatch):
             assert r["k"] == k0 and np.array_equal(r["x"], x0) and np.array_equal(r["r"], r0), m
         ctx.close()
     finally:
-        monkeypatch.delenv("BICG_FORCE_COMM")
+        H.switches(force_comm=None)
         H.lib().bicg_comm_init_single(0)
 
 
 def test_fused_pipelined_iteration_is_bit_reproducible(problem, monkeypatch):
-    """the two-launch form (k_spmv_sell_epi) twice, and once more with BICG_SPIN_TICKS=0 -- every workgroup then sums
+    """the two-launch form (k_spmv_sell_epi) twice, and once more with BICG_TEST="spin-ticks=0" -- every workgroup then sums
     the shards it is waiting for itself (same partials, same order): same bits whoever computes a shard"""
     A, b, ref = problem
     H.lib().bicg_comm_init_single(0)
-    a1 = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1)
-    a2 = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1)
-    a3 = _solve_all(A, b, BICG_GRAPH=0, BICG_FUSE_PIPE=1, BICG_SPIN_TICKS=0)
+    a1 = _solve_all(A, b, BICG_GRAPH=0, fuse_pipe=1)
+    a2 = _solve_all(A, b, BICG_GRAPH=0, fuse_pipe=1)
+    a3 = _solve_all(A, b, BICG_GRAPH=0, fuse_pipe=1, spin_ticks=0)
     for m in ("pipe_bicgstab", "pipe_bicgstab_rr"):
         for other in (a2, a3):
             assert other[m][0] == a1[m][0] and np.array_equal(other[m][1], a1[m][1]) and np.array_equal(other[m][2], a1[m][2]), m
@@ -216,7 +214,8 @@ def test_section_times_on_the_multi_rank_path(problem, overlap, monkeypatch):
     src/shifted_switching_solver.c:884-892); the marks must not change a bit of the result."""
     A, b, ref = problem
     H.lib().bicg_comm_init_single(0)
-    for k, v in dict(BICG_FORCE_COMM=1, BICG_GRAPH=0, BICG_OVERLAP=overlap, BICG_PERSIST=0).items():
+    H.switches(force_comm=1, persist=0)
+    for k, v in dict(BICG_GRAPH=0, BICG_OVERLAP=overlap).items():
         monkeypatch.setenv(k, str(v))
     ctx = H.Context(H.single_rank_blocks(A))
     for m, tol in METHODS:
@@ -233,15 +232,13 @@ def test_section_times_on_the_multi_rank_path(problem, overlap, monkeypatch):
 
 
 def test_pipelined_form_chosen_by_measurement(monkeypatch):
-    """BICG_PIPE_PROBE=1: the first pipelined solve on a context times both multi-launch forms (phases as separate kernels /
+    """BICG_PLAN=pipe-probe: the first pipelined solve on a context times both multi-launch forms (phases as separate kernels /
     in the SpMV epilogues) on the caller's own system and keeps the faster one -- instead of the size / layout rule of
     bicg_create. The probe must leave x0 and b untouched: the solve that follows is bit for bit the solve of a context
-    pinned to the chosen form (BICG_FUSE_PIPE), also for a second call and for the replacement variant."""
+    pinned to the chosen form (BICG_PLAN="fuse-pipe=0|1"), also for a second call and for the replacement variant."""
     H.lib().bicg_comm_init_single(0)
     A = synth.fem_like(300_000, scale_decades=1.0)
-    monkeypatch.setenv("BICG_PERSIST", "0")
-    monkeypatch.delenv("BICG_FUSE_PIPE", raising=False)
-    monkeypatch.setenv("BICG_PIPE_PROBE", "1")
+    H.switches(persist=0, fuse_pipe=None, pipe_probe=1)
     ctx = H.Context(H.single_rank_blocks(A))
     b = ctx.spmv(np.ones(A.rows))
     x0 = np.random.default_rng(2).standard_normal(A.rows) * 1e-3
@@ -253,8 +250,7 @@ def test_pipelined_form_chosen_by_measurement(monkeypatch):
     rr = ctx.solve("pipe_bicgstab_rr", b, x0=x0, tol=0.0, max_iter=40, check_every=8, krr=10, nrr=2)
     assert ctx.flags()["fuse_pipe"] == fl["fuse_pipe"]          # decided once per context
     ctx.close()
-    monkeypatch.delenv("BICG_PIPE_PROBE")
-    monkeypatch.setenv("BICG_FUSE_PIPE", "1" if fl["fuse_pipe"] else "0")
+    H.switches(pipe_probe=None, fuse_pipe=1 if fl["fuse_pipe"] else 0)
     pinned = H.Context(H.single_rank_blocks(A))
     assert not pinned.flags()["pipe_probed"] and pinned.flags()["fuse_pipe"] == fl["fuse_pipe"]
     want = pinned.solve("pipe_bicgstab", b, x0=x0, tol=0.0, max_iter=40, check_every=8)

@@ -139,10 +139,10 @@ def test_c_host_two_ranks_peer_to_peer_over_mpi(mtx, tmp_path):
 @need
 def test_c_host_falls_back_when_the_peer_to_peer_path_fails_in_a_solve(mtx, tmp_path):
     """the automatically chosen peer-to-peer path is a bet on its self-test: when a wait for a peer times out in a
-    real solve (here: rank 1 stops sending halo values from its 7th exchange on, BICG_P2P_FAULT_AFTER) the drop-in
+    real solve (here: rank 1 stops sending halo values from its 7th exchange on, BICG_TEST="p2p-fault-after=7") the drop-in
     entry point repeats the solve on the transport's own collectives instead of ending the program with a time-out"""
     env = dict(os.environ, BICG_CHECK_EVERY="4", BICG_TRANSPORT="p2p", BICG_P2P_FALLBACK="1", BICG_P2P_TIMEOUT_MS="1500",
-               BICG_P2P_FAULT_AFTER="7")
+               BICG_TEST="p2p-fault-after=7")
     prefix = str(tmp_path / "fb")
     out = subprocess.run([MPIEXEC, "-n", "2", HOST, mtx, "bicgstab", "--dump", prefix], capture_output=True, text=True,
                          timeout=300, env=env)

@@ -163,7 +163,7 @@ def test_jagged_slices_on_fem_like_rows(monkeypatch):
         assert abs(got["k"] - orc["k"]) <= 2, (method, got["k"], orc["k"])
         assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max(), method
     ctx.close()
-    monkeypatch.setenv("BICG_SELL_WINDOW", "0")       # jagged slices, x gathered from memory (16-bit offsets)
+    H.switches(window=0)       # jagged slices, x gathered from memory (16-bit offsets)
     ctx = H.Context(H.single_rank_blocks(A))
     assert ctx.flags()["jagged"] and ctx.flags()["col16"] and not ctx.flags()["window"]
     assert np.array_equal(ctx.spmv(x), y_orc)
@@ -171,14 +171,14 @@ def test_jagged_slices_on_fem_like_rows(monkeypatch):
     orc = O.solve("pipe_bicgstab", A.rows, row, col, val, b)
     assert abs(got["k"] - orc["k"]) <= 2
     ctx.close()
-    monkeypatch.setenv("BICG_NO_COL16", "1")          # 32-bit columns in jagged slices
+    H.switches(col16=0)          # 32-bit columns in jagged slices
     ctx = H.Context(H.single_rank_blocks(A))
     assert ctx.flags()["jagged"] and not ctx.flags()["col16"]
     assert np.array_equal(ctx.spmv(x), y_orc)
     ctx.close()
-    monkeypatch.delenv("BICG_NO_COL16")
-    monkeypatch.delenv("BICG_SELL_WINDOW")
-    monkeypatch.setenv("BICG_SELL_LAYOUT", "pad")     # padded slices: most groups fall to the CSR kernel
+    H.switches(col16=None)
+    H.switches(window=None)
+    H.switches(layout="pad")     # padded slices: most groups fall to the CSR kernel
     ctx = H.Context(H.single_rank_blocks(A))
     assert not ctx.flags()["jagged"]
     assert np.array_equal(ctx.spmv(x), y_orc)
@@ -188,7 +188,7 @@ def test_jagged_slices_on_fem_like_rows(monkeypatch):
 def test_ragged_rows_product_with_the_short_chain_gives_the_same_bits(monkeypatch):
     """k_spmv_jagw (csrc/bicg_jagw.hip: window bounds + one 16-bit word per lane, then every run descriptor and the first two
     batches of entries, then the whole window -- three dependent trips per 256-row group) against k_spmv_sell's loop over the same
-    jagged slices (BICG_JAGW=0): the product, the solvers' scalars (same partial-sum slots, same order) and a shifted solve are
+    jagged slices (BICG_PLAN="jagw=0"): the product, the solvers' scalars (same partial-sum slots, same order) and a shifted solve are
     identical in every bit; the product equals the oracle's mult() (reference src/matrix.c:506-515). Three shapes: FEM-like rows
     (3 runs per group, rows not a multiple of 256), columns in seven separate runs per group, a Transport-sized one."""
     H.lib().bicg_comm_init_single(0)
@@ -212,9 +212,9 @@ def test_ragged_rows_product_with_the_short_chain_gives_the_same_bits(monkeypatc
         b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
         results = []
         for fast in ("0", "1"):
-            monkeypatch.setenv("BICG_JAGW", fast)
+            H.switches(jagw=fast)
             if name == "scattered":
-                monkeypatch.setenv("BICG_SELL_WINDOW", "1")
+                H.switches(window=1)
             ctx = H.Context(H.single_rank_blocks(A))
             fl = ctx.flags()
             assert fl["jagged"] and fl["window"], (name, fl)
@@ -228,19 +228,19 @@ def test_ragged_rows_product_with_the_short_chain_gives_the_same_bits(monkeypatc
             sh = ctx.solve_shifted(b, np.array([0.0, 0.02, 0.05]), 1, tol=0.0, max_iter=6, check_every=6)
             results.append((y, traces, sh["x"].copy()))
             ctx.close()
-            monkeypatch.delenv("BICG_SELL_WINDOW", raising=False)
+            H.switches(window=None)
         (y0, t0, s0), (y1, t1, s1) = results
         assert np.array_equal(y0, y1), name
         for a_, b_ in zip(t0, t1):
             assert np.array_equal(a_, b_), name
         assert np.array_equal(s0, s1), name
-    monkeypatch.delenv("BICG_JAGW")
+    H.switches(jagw=None)
 
 
 def test_x_window_for_columns_far_from_the_row(monkeypatch):
     """columns further than 32767 from the row (a 3-D stencil's z neighbours at full size): 16-bit offsets do not
     apply, the x window in LDS would -- 16-bit slots, 10 bytes per non-zero, SpMV bit-identical -- but with equal
-    rows it is only taken on request (BICG_SELL_WINDOW=1; measured slower on the 256^3 Laplacian: as many staging
+    rows it is only taken on request (BICG_PLAN="window=1"; measured slower on the 256^3 Laplacian: as many staging
     loads as gathers); a group whose window would not fit LDS switches the whole block back to memory gathers."""
     H.lib().bicg_comm_init_single(0)
     A = synth.from_offsets(150000, (0, 1, -1, 300, -300, 40000, -40000), diag_base=9.0, seed=3)
@@ -250,7 +250,7 @@ def test_x_window_for_columns_far_from_the_row(monkeypatch):
     ctx = H.Context(H.single_rank_blocks(A))      # equal rows, perfectly coalesced gathers: padded slices, 32-bit columns
     assert not ctx.flags()["window"] and not ctx.flags()["col16"] and not ctx.flags()["jagged"]
     ctx.close()
-    monkeypatch.setenv("BICG_SELL_WINDOW", "1")   # on request
+    H.switches(window=1)   # on request
     ctx = H.Context(H.single_rank_blocks(A))
     fl = ctx.flags()
     assert fl["window"] and fl["jagged"] and fl["col16"] and fl["all_sell"]
@@ -262,12 +262,12 @@ def test_x_window_for_columns_far_from_the_row(monkeypatch):
         got = ctx.solve(method, b)
         assert abs(got["k"] - orc["k"]) <= 2 and np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max(), method
     ctx.close()
-    monkeypatch.setenv("BICG_SELL_WINDOW", "0")
+    H.switches(window=0)
     ctx = H.Context(H.single_rank_blocks(A))
     assert not ctx.flags()["window"] and not ctx.flags()["col16"]
     assert np.array_equal(ctx.spmv(x), y_orc)
     ctx.close()
-    monkeypatch.delenv("BICG_SELL_WINDOW")
+    H.switches(window=None)
     # 40 scattered columns per row: a 256-row group touches > 4096 distinct x values
     B = synth.random_rows(20000, 40, seed=11)
     ctx = H.Context(H.single_rank_blocks(B))
@@ -344,7 +344,7 @@ def test_device_side_plan_matches_host_plan():
 def test_device_plan_survives_hash_collisions(monkeypatch):
     """bicg_create_device_csr groups uniform / constant / masked slices by a 64-bit hash of their lists and fetches ONE
     representative per hash (nothing compared a slice with the list it got). k_plan_verify now does, and a
-    slice that differs goes back to its stored columns and values. BICG_PLAN_TEST_COLLIDE=1 throws every hash into one of two
+    slice that differs goes back to its stored columns and values. BICG_TEST=plan-collide throws every hash into one of two
     buckets: thousands of slices get a foreign list, every one has to be caught -- the product stays bit-exact."""
     H.lib().bicg_comm_init_single(0)
     weights = (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)
@@ -353,13 +353,13 @@ def test_device_plan_survives_hash_collisions(monkeypatch):
         row, col, val = A.to_coo()
         x = np.random.default_rng(m).standard_normal(A.rows)
         want = O.spmv(A.rows, row, col, val, x)
-        monkeypatch.delenv("BICG_PLAN_TEST_COLLIDE", raising=False)
+        H.switches(plan_collide=None)
         ctx, _, _, _ = H.Context.stencil7_on_device(m, weights)
         assert ctx.plan_collisions() == 0 and ctx.constant_entries() > 0
         clean_constant = ctx.constant_entries()
         assert np.array_equal(ctx.spmv(x), want)
         ctx.close()
-        monkeypatch.setenv("BICG_PLAN_TEST_COLLIDE", "1")
+        H.switches(plan_collide=1)
         ctx, _, _, _ = H.Context.stencil7_on_device(m, weights)
         assert ctx.plan_collisions() > 0 and ctx.constant_entries() < clean_constant
         assert np.array_equal(ctx.spmv(x), want)
@@ -371,8 +371,8 @@ def test_device_plan_survives_hash_collisions(monkeypatch):
 
 def test_list_driven_slices_same_bits_whichever_loop_runs(monkeypatch):
     """Constant / masked slices (SellDev::vbase / mbase) have three forms of the product: the general loop of sell_row
-    (BICG_SELL_DESC=0), sell_row with one descriptor per slice and the next slices' metadata requested ahead
-    (BICG_SELL_LISTS=0), and the loop of its own for blocks whose slices are ALL list-driven (default; 64^3 and 96^3 qualify,
+    (BICG_PLAN="desc=0"), sell_row with one descriptor per slice and the next slices' metadata requested ahead
+    (BICG_PLAN="lists=0"), and the loop of its own for blocks whose slices are ALL list-driven (default; 64^3 and 96^3 qualify,
     33^3 -- rows not a multiple of 256 -- does not). Same sums in the same order (reference src/matrix.c:506-515): SpMV, the
     SpMV with fused dots inside the solvers (alpha / omega / (r,r) of 12 iterations) and the shifted product are bit-identical."""
     H.lib().bicg_comm_init_single(0)
@@ -382,13 +382,10 @@ def test_list_driven_slices_same_bits_whichever_loop_runs(monkeypatch):
         x = np.random.default_rng(m).standard_normal(A.rows)
         b = None
         results = []
-        # (BICG_STENCIL=0: the 64^3 grid would otherwise go to the plane-marching product, whose dot sums are tiled differently --
+        # (BICG_PLAN="stencil=0": the 64^3 grid would otherwise go to the plane-marching product, whose dot sums are tiled differently --
         # tests/test_stencil.py compares that one)
-        for env in ({"BICG_SELL_DESC": "0"}, {"BICG_SELL_LISTS": "0"}, {"BICG_STENCIL": "0"}):
-            for k in ("BICG_SELL_DESC", "BICG_SELL_LISTS", "BICG_STENCIL"):
-                monkeypatch.delenv(k, raising=False)
-            for k, v in env.items():
-                monkeypatch.setenv(k, v)
+        for env in ({"desc": 0}, {"lists": 0}, {"stencil": 0}):
+            H.switches(**{k: env.get(k) for k in ("desc", "lists", "stencil")})
             ctx = H.Context(H.single_rank_blocks(A))
             assert ctx.flags()["constant"] and ctx.masked_rows() > 0
             y = ctx.spmv(x)

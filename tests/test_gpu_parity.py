@@ -388,7 +388,7 @@ def test_section_times_account_for_the_iteration(capfd):
 def test_uniform_slices_give_the_same_bits():
     """Uniform slices (BICG_FLAG_UNIFORM, SellDev::ubase): in the interior of a banded / stencil matrix the SpMV takes the columns
     of a 64-row slice from ONE shared list of distances instead of reading col / col16 -- fewer bytes, the same arithmetic in the
-    same order: y is bit-identical to the oracle AND to a context planned without them (BICG_SELL_UNIFORM=0), 16- and 32-bit
+    same order: y is bit-identical to the oracle AND to a context planned without them (BICG_PLAN="uniform=0"), 16- and 32-bit
     column layouts, boundary slices (clipped bands, grid faces) stay on the column arrays; the solver trajectories of the two
     contexts are identical to the last bit (reference src/matrix.c:498-516)."""
     import os
@@ -405,21 +405,21 @@ def test_uniform_slices_give_the_same_bits():
             A = synth.CSR(A.rows, A.rows, ptr, A.col[keep], A.val[keep])
         row, col, val = A.to_coo()
         ctx = H.Context(H.single_rank_blocks(A))
-        os.environ["BICG_SELL_UNIFORM"] = "0"
+        H.switches(uniform=0)
         try:
             ref = H.Context(H.single_rank_blocks(A))
         finally:
-            os.environ.pop("BICG_SELL_UNIFORM")
+            H.switches(uniform=None)
         assert ctx.flags()["uniform"] and not ref.flags()["uniform"], name
         # constant slices (round 4): a stencil with one weight per direction repeats its VALUES in every row of an interior
         # slice as well -- those come from a shared list too (no matrix stream at all); random values never qualify
         if name.startswith("stencil"):
             assert ctx.flags()["constant"] and 0 < ctx.constant_entries() <= ctx.uniform_entries(), name
-            os.environ["BICG_SELL_CONSTANT"] = "0"
+            H.switches(constant=0)
             try:
                 noc = H.Context(H.single_rank_blocks(A))
             finally:
-                os.environ.pop("BICG_SELL_CONSTANT")
+                H.switches(constant=None)
             xx = np.random.default_rng(12).standard_normal(A.rows)
             assert noc.flags()["uniform"] and not noc.flags()["constant"] and noc.constant_entries() == 0
             assert ctx.spmv_matrix_bytes() <= noc.spmv_matrix_bytes() - 8 * ctx.constant_entries() + 2 * ctx.masked_rows() + 64, name
@@ -427,11 +427,11 @@ def test_uniform_slices_give_the_same_bits():
             # (distance, value) pairs -- keep one 16-bit word per row: with them (almost) the whole stencil streams no values and no
             # columns; switched off, the same bits
             assert ctx.masked_rows() > 0 and ctx.masked_rows() % 64 == 0 and ctx.constant_entries() > 0.8 * A.nnz, (name, ctx.masked_rows(), ctx.constant_entries(), A.nnz)
-            os.environ["BICG_SELL_MASKED"] = "0"
+            H.switches(masked=0)
             try:
                 nom = H.Context(H.single_rank_blocks(A))
             finally:
-                os.environ.pop("BICG_SELL_MASKED")
+                H.switches(masked=None)
             assert nom.masked_rows() == 0 and nom.constant_entries() < ctx.constant_entries()
             assert np.array_equal(ctx.spmv(xx), nom.spmv(xx)), name
             nom.close()

@@ -451,3 +451,44 @@ def test_stencil7_closed_form_is_the_oracles_spmv():
             assert np.array_equal(synth.stencil7_matvec(m, w, x), O.spmv(A.rows, row, col, val, x))
         ones = synth.stencil7_matvec(m, synth.LAPLACE_WEIGHTS, np.ones(m ** 3)).reshape(m, m, m)
         assert np.all(ones[1:-1, 1:-1, 1:-1] == 0.0) and ones[0, 0, 0] == 3.0      # b = A 1: zero in the interior
+
+
+def test_switch_variables_as_the_library_reads_them():
+    """BICG_PLAN / BICG_PERSIST / BICG_TEST hold comma-separated `name` / `name=value` tokens (csrc/bicg_knobs.h): what
+    hipsolver.switches() writes is what the library reads (bicg_switch_value, no device needed) -- whole names only, a bare token
+    reads as "1", the last of the three stays readable while a caller holds the first."""
+    from mpi_bicgstab_amd import hipsolver as H
+    H.switches(stencil=0, lines=2, planes=64, layout="pad", persist=0, persist_chunk=17, force_comm=1, spin_ticks=0)
+    assert os.environ["BICG_PLAN"] == "stencil=0,lines=2,planes=64,layout=pad" and os.environ["BICG_PERSIST"] == "0,chunk=17"
+    assert H.switch_value("BICG_PLAN", "stencil") == "0" and H.switch_value("BICG_PLAN", "lines") == "2"
+    assert H.switch_value("BICG_PLAN", "planes") == "64" and H.switch_value("BICG_PLAN", "layout") == "pad"
+    assert H.switch_value("BICG_PLAN", "line") is None and H.switch_value("BICG_PLAN", "plane") is None      # prefixes are not names
+    assert H.switch_value("BICG_PLAN", "ca-fuse") is None
+    assert H.switch_value("BICG_PERSIST", "0") == "1" and H.switch_value("BICG_PERSIST", "chunk") == "17"
+    assert H.switch_value("BICG_TEST", "force-comm") == "1" and H.switch_value("BICG_TEST", "spin-ticks") == "0"
+    H.switches(persist=1, lines=None)
+    assert H.switch_value("BICG_PERSIST", "0") is None and H.switch_value("BICG_PERSIST", "chunk") == "17"
+    assert H.switch_value("BICG_PLAN", "lines") is None and H.switch_value("BICG_PLAN", "planes") == "64"
+    os.environ["BICG_TEST"] = " plan-collide , p2p-fault-after=7,"            # written by hand: blanks, a bare token, a trailing comma
+    assert H.switch_value("BICG_TEST", "plan-collide") == "1" and H.switch_value("BICG_TEST", "p2p-fault-after") == "7"
+    H.switches(stencil=None, planes=None, layout=None, persist_chunk=None)
+    assert "BICG_PLAN" not in os.environ and "BICG_PERSIST" not in os.environ
+    assert H.switch_value("BICG_PLAN", "stencil") is None
+
+
+def test_the_default_build_reads_at_most_thirty_variables_and_the_manual_lists_them():
+    """every variable the default build reads (getenv directly, or one of the three token lists) is in INTEGRATION.md section 6;
+    the measurement knobs of the development rounds (knob_x) are not read without -DBICG_EXPERIMENTS (csrc/bicg_knobs.h)"""
+    import glob
+    import re
+    pkg = os.path.join(ROOT, "mpi-bicgstab_amd")
+    names = set()
+    for path in glob.glob(os.path.join(pkg, "csrc", "*")) + glob.glob(os.path.join(pkg, "host", "*.c")) + glob.glob(os.path.join(pkg, "host", "*.h")):
+        text = open(path, errors="replace").read()
+        names.update(re.findall(r'[^_a-z]getenv\("(BICG_[A-Z0-9_]+)"\)', text))
+        names.update(re.findall(r'knob_tok\("(BICG_[A-Z0-9_]+)"', text))
+    assert {"BICG_PLAN", "BICG_PERSIST", "BICG_TEST"} <= names
+    assert len(names) <= 30, sorted(names)
+    manual = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    missing = [n for n in sorted(names) if f"`{n}`" not in manual and f"`{n}=" not in manual]
+    assert not missing, missing

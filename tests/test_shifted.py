@@ -119,7 +119,7 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
     H.lib().bicg_comm_init_single(0)
     A = synth.from_offsets(30011, (0, 1, -1, 37, -37, 2999, -2999), diag_base=9.0, seed=5)
     ctx = H.Context(H.single_rank_blocks(A))
-    os.environ["BICG_SPMM_WIN"] = "0"                 # the row-major kernel (round 2) beside the windowed one (round 4)
+    H.switches(spmm_window=0)                 # the row-major kernel (round 2) beside the windowed one (round 4)
     try:
         rowmajor = H.Context(H.single_rank_blocks(A))
         Xr = np.random.default_rng(3).standard_normal((16, A.rows))
@@ -127,15 +127,15 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
         assert not rowmajor.last_spmm_windowed()
         rowmajor.close()
     finally:
-        del os.environ["BICG_SPMM_WIN"]
-    os.environ["BICG_SPMM_WIN"] = "2"                 # the direct kernel (row heads in registers, gathers from the shift-major vectors)
+        H.switches(spmm_window=None)
+    H.switches(spmm_window=2)                 # the direct kernel (row heads in registers, gathers from the shift-major vectors)
     try:
         direct = H.Context(H.single_rank_blocks(A))
         Yd, _ = direct.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
         assert direct.last_spmm_windowed() and np.array_equal(Yd, Yr)
         direct.close()
     finally:
-        del os.environ["BICG_SPMM_WIN"]
+        H.switches(spmm_window=None)
     Yw, _ = ctx.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
     assert ctx.last_spmm_windowed() and np.array_equal(Yw, Yr)      # three clusters of offsets: staged per 256-row group in LDS
     rng = np.random.default_rng(8)
@@ -151,11 +151,11 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
         assert np.array_equal(Y0[0], ctx.spmv(X[0]))
         b = rng.standard_normal(A.rows)
         r1 = ctx.shifted_residuals(X, b, sigma)
-        os.environ["BICG_NO_SPMM"] = "1"
+        H.switches(spmm=0)
         try:
             r2 = ctx.shifted_residuals(X, b, sigma)    # one SpMV + one fused norm kernel per shift
         finally:
-            del os.environ["BICG_NO_SPMM"]
+            H.switches(spmm=None)
         np.testing.assert_allclose(r1, r2, rtol=1e-13)
         want = [np.linalg.norm(b - (ctx.spmv(X[j]) + sigma[j] * X[j])) / np.linalg.norm(b) for j in range(nvec)]
         np.testing.assert_allclose(r1, want, rtol=1e-12)

@@ -1,7 +1,7 @@
 """The plane-marching product (csrc/bicg_stencil.hip, `-m gpu`): blocks in whose lists the plan finds the 7-point stencil of a
 grid (BASELINE.json configs[3]) are multiplied by wavefronts that march through the planes of their own grid lines. Same sums in
 the same order as mult() (reference src/matrix.c:506-515): every product here is compared bit for bit with the CPU oracle and
-with the slice-by-slice product (BICG_STENCIL=0); the dot sums are associated differently (another tiling), so the solvers'
+with the slice-by-slice product (BICG_PLAN="stencil=0"); the dot sums are associated differently (another tiling), so the solvers'
 scalars agree to rounding, not in bits. CA-BiCGStab's q / y phase (reference src/solver.c:225-232) in the epilogue of z = A s:
 same expressions, checked against the unfused iteration."""
 import numpy as np
@@ -16,14 +16,11 @@ pytestmark = pytest.mark.gpu
 W = (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.3)          # every position its own weight: a swapped neighbour shows
 W2 = (7.25, -0.7, -1.4, -0.6, -1.5, -0.9, -1.1)
 
-KNOBS = ("BICG_STENCIL", "BICG_STENCIL_LINES", "BICG_STENCIL_ZL", "BICG_CA_FUSE")
+KNOBS = ("stencil", "lines", "planes", "ca_fuse")          # tokens of BICG_PLAN (csrc/bicg_knobs.h)
 
 
 def _ctx(monkeypatch, A, **env):
-    for k in KNOBS:
-        monkeypatch.delenv(k, raising=False)
-    for k, v in env.items():
-        monkeypatch.setenv(k, str(v))
+    H.switches(**{k: env.get(k) for k in KNOBS})
     return H.Context(H.single_rank_blocks(A))
 
 
@@ -41,20 +38,20 @@ def test_plane_marching_product_bit_for_bit(monkeypatch, shape, kw):
     row, col, val = A.to_coo()
     x = np.random.default_rng(nx + ny + nz).standard_normal(A.rows)
     want = O.spmv(A.rows, row, col, val, x)
-    tiles = [{}, {"BICG_STENCIL_LINES": 2, "BICG_STENCIL_ZL": 3}, {"BICG_STENCIL_LINES": 2, "BICG_STENCIL_ZL": 64},
-             {"BICG_STENCIL_LINES": 4, "BICG_STENCIL_ZL": 1}, {"BICG_STENCIL_LINES": 4, "BICG_STENCIL_ZL": 5}]
+    tiles = [{}, {"lines": 2, "planes": 3}, {"lines": 2, "planes": 64},
+             {"lines": 4, "planes": 1}, {"lines": 4, "planes": 5}]
     for env in tiles:
-        if env.get("BICG_STENCIL_LINES") == 4 and ny % 4:
+        if env.get("lines") == 4 and ny % 4:
             continue
         ctx = _ctx(monkeypatch, A, **env)
         info = ctx.stencil_info()
         assert info["on"] == 1 and info["sy"] == nx and info["ny"] == ny and info["nz"] == nz, (env, info)
-        if "BICG_STENCIL_LINES" in env:
-            assert info["lines"] == env["BICG_STENCIL_LINES"] and info["planes"] == env["BICG_STENCIL_ZL"]
+        if "lines" in env:
+            assert info["lines"] == env["lines"] and info["planes"] == env["planes"]
         assert np.array_equal(ctx.spmv(x), want), env
         assert np.array_equal(ctx.spmv(x), want), env             # the reversed direction of the second product
         ctx.close()
-    ctx = _ctx(monkeypatch, A, BICG_STENCIL=0)
+    ctx = _ctx(monkeypatch, A, stencil=0)
     assert ctx.stencil_info()["on"] == 0
     assert np.array_equal(ctx.spmv(x), want)
     ctx.close()
@@ -92,8 +89,8 @@ def test_solvers_on_the_plane_marching_product(monkeypatch):
     row, col, val = A.to_coo()
     b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
     runs = {}
-    for name, env in (("slices", {"BICG_STENCIL": 0}), ("planes", {}), ("planes_unfused", {"BICG_CA_FUSE": 0}),
-                      ("planes_2x3", {"BICG_STENCIL_LINES": 2, "BICG_STENCIL_ZL": 3})):
+    for name, env in (("slices", {"stencil": 0}), ("planes", {}), ("planes_unfused", {"ca_fuse": 0}),
+                      ("planes_2x3", {"lines": 2, "planes": 3})):
         ctx = _ctx(monkeypatch, A, **env)
         assert ctx.stencil_info()["on"] == (0 if name == "slices" else 1)
         runs[name] = _traces(ctx, b)
@@ -118,7 +115,7 @@ def test_ca_epilogue_leaves_the_vectors_of_the_unfused_iteration(monkeypatch):
     b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
     res = {}
     for fuse in (1, 0):
-        ctx = _ctx(monkeypatch, A, BICG_CA_FUSE=fuse)
+        ctx = _ctx(monkeypatch, A, ca_fuse=fuse)
         assert ctx.stencil_info()["on"] == 1
         out = ctx.solve("ca_bicgstab", b, tol=0.0, max_iter=5, check_every=5)
         res[fuse] = (out["x"].copy(), out["r"].copy())

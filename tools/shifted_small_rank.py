@@ -15,7 +15,7 @@ A = synth.transport_like(n=rows, scale_decades=2.0)
 sigma = (np.arange(nsh) + 1.0) * 0.01 / nsh
 ones = np.ones(A.rows)
 for env, label in (("1", "persistent"), ("0", "multi-launch")):
-    os.environ["BICG_PERSIST_SHIFTED"] = env
+    H.switches(persist_shifted=env)
     ctx = H.Context(H.single_rank_blocks(A))
     b = ctx.spmv(ones) + sigma[seed] * ones
     for which in ("shifted_pipe_lopbicgstab", "shifted_lopbicgstab"):

@@ -15,5 +15,5 @@ done
 # the multi-launch forms of the pipelined iteration (the default above is ONE persistent launch per chunk, bicg_persist.hip)
 BICG_PERSIST=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, two launches per iteration   pipe_bicgstab"
 BICG_PERSIST=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, two launches per iteration      pipe_bicgstab"
-BICG_PERSIST=0 BICG_FUSE_PIPE=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, phases as separate kernels  pipe_bicgstab"
-BICG_PERSIST=0 BICG_FUSE_PIPE=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, phases as separate kernels     pipe_bicgstab"
+BICG_PERSIST=0 BICG_PLAN=fuse-pipe=0 timeout 100 $B --method pipe_bicgstab 2>/dev/null | show "single, phases as separate kernels  pipe_bicgstab"
+BICG_PERSIST=0 BICG_PLAN=fuse-pipe=0 timeout 100 $B --method pipe_bicgstab --force-comm --transport auto 2>/dev/null | show "p2p, phases as separate kernels     pipe_bicgstab"

@@ -1,7 +1,8 @@
 #!/usr/bin/env python3
 """The m^3 7-point Laplacian (BASELINE.json configs[3] for m = 512) generated and planned on the device, once per setting of the
 plane-marching product's knobs: product back to back, plain and CA-BiCGStab per iteration.
-    python tools/stencil_sweep.py m "ENV=V ENV=V" "ENV=V" ...      ("" = defaults)"""
+    python tools/stencil_sweep.py m "lines=2 planes=8" "stencil=0" "BICG_SELL_XCD=0" ...      ("" = defaults; lower case:
+tokens of BICG_PLAN, upper case: variables -- the measurement knobs need a library built with make EXPERIMENTS=1)"""
 import os, sys, time
 import numpy as np
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
@@ -9,13 +10,16 @@ from mpi_bicgstab_amd import hipsolver as H, synth
 H.lib().bicg_comm_init_single(0)
 m = int(sys.argv[1])
 n = m ** 3
-KNOBS = ("BICG_STENCIL", "BICG_STENCIL_LINES", "BICG_STENCIL_ZL", "BICG_CA_FUSE", "BICG_SELL_XCD", "BICG_SELL_ALT")
+KNOBS = ("BICG_PLAN", "BICG_SELL_XCD", "BICG_SELL_ALT", "BICG_STENCIL_XCD", "BICG_STENCIL_NT")
 for setting in sys.argv[2:] or [""]:
     for k in KNOBS:
         os.environ.pop(k, None)
     for kv in setting.split():
         k, v = kv.split("=")
-        os.environ[k] = v
+        if k in H.SWITCHES:
+            H.switches(**{k: v})
+        else:
+            os.environ[k] = v
     ctx, nnz, ps, gs = H.Context.stencil7_on_device(m, synth.LAPLACE_WEIGHTS)
     info = ctx.stencil_info()
     b = ctx.spmv(np.ones(n))
