@@ -259,6 +259,9 @@ def main():
     def p2p_label(mode, base):
         """what the peer-to-peer data path crossed: xGMI links only when every rank has a GPU of its own"""
         mem = "uncached" if mode == 2 else "device"
+        if world == 1:      # --force-comm: one rank drives the whole path, its mailboxes are its own memory
+            return (f"peer-to-peer LL stores of ONE rank into its own mailboxes ({mem} memory; no peer, no xGMI link involved; "
+                    f"bootstrap {base})")
         if world > torch.cuda.device_count():
             return (f"peer-to-peer LL stores between processes SHARING one device (HIP IPC, {mem} memory; no xGMI link involved; "
                     f"bootstrap {base})")
