@@ -66,8 +66,12 @@ __device__ __forceinline__ double jag_use(const JagBatch &B, uint32_t k0, uint32
     return sum;
 }
 
+// Registers: 97 without dots, 102-104 with them -- one above the step at 96 where a SIMD holds five wavefronts instead of four.
+// The product without dots fits into 96 without scratch and runs 6 % faster with the fifth wavefront (45.1 -> 42.3 us back to back,
+// pipelined iteration 0.160 -> 0.155 ms); the variants with dots would spill five words per lane, and a kernel that needs scratch at
+// all starts its wavefronts slower: plain 0.141 -> 0.166 ms (profiles/r05/fem_like_waves_per_simd.txt) -- they keep four.
 template <int NDOT, bool NT, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 8))) k_spmv_jagw(SpmvArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NDOT == 0 ? 5 : 4, 8))) k_spmv_jagw(SpmvArgs a)
 {
     constexpr int ND = NDOT > 0 ? NDOT : 1;
     const int done = a.S->done;
