@@ -66,12 +66,14 @@ __device__ __forceinline__ double jag_use(const JagBatch &B, uint32_t k0, uint32
     return sum;
 }
 
-// Registers: 97 without dots, 102-104 with them -- one above the step at 96 where a SIMD holds five wavefronts instead of four.
-// The product without dots fits into 96 without scratch and runs 6 % faster with the fifth wavefront (45.1 -> 42.3 us back to back,
-// pipelined iteration 0.160 -> 0.155 ms); the variants with dots would spill five words per lane, and a kernel that needs scratch at
-// all starts its wavefronts slower: plain 0.141 -> 0.166 ms (profiles/r05/fem_like_waves_per_simd.txt) -- they keep four.
+// Registers and occupancy (profiles/r05/fem_like_waves_per_simd.txt). The kernel used 97 registers without dots and 102-104 with
+// them: just above the step at 96 where a SIMD holds five wavefronts instead of four. Forced below it the variants with dots
+// spilled five words per lane, and a kernel that needs scratch at all starts its wavefronts slower (plain 0.141 -> 0.166 ms).
+// Seven of those registers held tid + 256 k, hoisted out of the group loop; re-formed per group (an opaque copy of tid) every
+// variant fits into 89-95 registers without scratch: product back to back 45.1 -> 42.3 us, plain iteration 0.141 -> 0.134 ms,
+// CA 0.154 -> 0.151, pipelined 0.160 -> 0.155 on the FEM-like matrix.
 template <int NDOT, bool NT, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NDOT == 0 ? 5 : 4, 8))) k_spmv_jagw(SpmvArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) k_spmv_jagw(SpmvArgs a)
 {
     constexpr int ND = NDOT > 0 ? NDOT : 1;
     const int done = a.S->done;
@@ -124,26 +126,28 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(NDO
         const uint32_t total = nruns ? (lrun_y >> 16) + (lrun_y & 0xFFFFu) : 0u;
         double xw[kJagSlots];
         uint32_t col[kJagSlots];
+        uint32_t ts = tid;
+        asm volatile("" : "+v"(ts));       // (the slots tid + 256 k are re-formed per group: hoisted out of the loop they hold seven registers)
 #pragma unroll
-        for (int k = 0; k < kJagSlots; ++k) col[k] = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, 0) + tid + (uint32_t)k * kBlock;
+        for (int k = 0; k < kJagSlots; ++k) col[k] = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, 0) + ts + (uint32_t)k * kBlock;
         for (uint32_t r = 1; r < nruns; ++r) {                    // wave-uniform: runs are in ascending slot order
             const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, (int)r);
             const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)myrun.y, (int)r) >> 16;
 #pragma unroll
             for (int k = 0; k < kJagSlots; ++k) {
-                const uint32_t s = tid + (uint32_t)k * kBlock;
+                const uint32_t s = ts + (uint32_t)k * kBlock;
                 if (s >= slot0) col[k] = first + (s - slot0);
             }
         }
 #pragma unroll
         for (int k = 0; k < kJagSlots; ++k) {
-            const uint32_t s = tid + (uint32_t)k * kBlock;
+            const uint32_t s = ts + (uint32_t)k * kBlock;
             xw[k] = x[s < total ? col[k] : row < a.nrows ? row : 0u];       // (unconditional: a slot past the window reads a value that exists)
         }
         __syncthreads();                                          // the previous group's reads of the window are done
 #pragma unroll
         for (int k = 0; k < kJagSlots; ++k) {
-            const uint32_t s = tid + (uint32_t)k * kBlock;
+            const uint32_t s = ts + (uint32_t)k * kBlock;
             if (s < total) win[s] = xw[k];
         }
         __syncthreads();
