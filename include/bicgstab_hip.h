@@ -469,6 +469,9 @@ int bicg_has_experiments(void);
  * `name=value` tokens): copies the value of token `name` in $set to out ("1" for a bare token) and returns
  * its length, -1 when the variable or the token is absent. No device needed. */
 int bicg_switch_value(const char *set, const char *name, char *out, int cap);
+/* Tokens of $set that are none of the names the library knows for it (a typing error selects nothing): copies the first one to out
+ * and returns their number. bicg_create prints one line per list on rank 0 when there are any. */
+int bicg_switch_unknown(const char *set, char *out, int cap);
 
 #ifdef __cplusplus
 }

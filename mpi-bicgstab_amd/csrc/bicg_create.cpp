@@ -502,6 +502,19 @@ static void ctx_streams(bicg_ctx *c, int P)
 extern "C" {
 
 int bicg_has_experiments(void) { return kExperiments ? 1 : 0; }
+int bicg_switch_unknown(const char *set, char *out, int cap) { return set ? knob_unknown(set, out, cap > 0 ? (size_t)cap : 0) : 0; }
+// once per process, from bicg_create: a token none of the lists knows is reported, not obeyed
+static void warn_unknown_switches()
+{
+    static bool done = false;
+    if (done) return;
+    done = true;
+    for (const char *set : {"BICG_PLAN", "BICG_PERSIST", "BICG_TEST"}) {
+        char first[64];
+        const int n = knob_unknown(set, first, sizeof first);
+        if (n) fprintf(stderr, "bicgstab_hip: %s has %d token%s this library does not know (first: \"%s\"); see INTEGRATION.md section 6\n", set, n, n == 1 ? "" : "s", first);
+    }
+}
 int bicg_switch_value(const char *set, const char *name, char *out, int cap)
 {
     const char *v = set && name ? knob_tok(set, name) : nullptr;
@@ -536,6 +549,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
 {
     Comm *comm = comm_get();
     BICG_HIP(hipSetDevice(comm->device));
+    if (comm->rank == 0) warn_unknown_switches();
     if (info->rows != info->cols) { fprintf(stderr, "ERROR: bicg_create: matrix is not square\n"); return nullptr; }
 
     bicg_ctx *c = new bicg_ctx;
@@ -1244,6 +1258,7 @@ bicg_ctx *bicg_create_device_csr(const double *val_d, const unsigned int *col_d,
     Comm *comm = comm_get();
     BICG_HIP(hipSetDevice(comm->device));
     if (comm->nranks != 1) { fprintf(stderr, "ERROR: bicg_create_device_csr: single rank only\n"); return nullptr; }
+    warn_unknown_switches();
     if (rows == 0) { fprintf(stderr, "ERROR: bicg_create_device_csr: empty matrix\n"); return nullptr; }
     const double t0 = now_sec();
     unsigned nnz = 0;

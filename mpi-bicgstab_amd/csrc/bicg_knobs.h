@@ -42,6 +42,37 @@ inline const char *knob_tok(const char *set, const char *name)
     }
     return nullptr;
 }
+// The names each list knows. A token that is none of them is a typing error that would otherwise
+// pass silently -- "stencil=O" selects nothing --: knob_unknown copies the first such token to out and returns how many there are.
+inline const char *const *knob_names(const char *set)
+{
+    static const char *const plan[] = {"stencil", "lines", "planes", "ca-fuse", "layout", "window", "col16", "uniform", "constant", "masked",
+                                       "desc", "lists", "jagw", "spmm", "spmm-window", "fuse-pipe", "pipe-probe", nullptr};
+    static const char *const persist[] = {"0", "1", "off", "on", "chunk", "shifted", nullptr};
+    static const char *const test[] = {"force-comm", "spin-ticks", "p2p-fault-after", "plan-collide", nullptr};
+    static const char *const none[] = {nullptr};
+    return !strcmp(set, "BICG_PLAN") ? plan : !strcmp(set, "BICG_PERSIST") ? persist : !strcmp(set, "BICG_TEST") ? test : none;
+}
+inline int knob_unknown(const char *set, char *out, size_t cap)
+{
+    const char *s = getenv(set);
+    int n = 0;
+    if (out && cap) out[0] = 0;
+    if (!s) return 0;
+    const char *const *names = knob_names(set);
+    while (*s) {
+        while (*s == ',' || *s == ' ') ++s;
+        const char *e = s, *q = s;
+        while (*e && *e != ',' && *e != ' ') ++e;
+        while (q < e && *q != '=') ++q;
+        if (e == s) break;
+        bool known = false;
+        for (int i = 0; names[i]; ++i) known = known || (strlen(names[i]) == (size_t)(q - s) && !strncmp(names[i], s, (size_t)(q - s)));
+        if (!known && n++ == 0 && out && cap) { const size_t l = (size_t)(e - s) < cap - 1 ? (size_t)(e - s) : cap - 1; memcpy(out, s, l); out[l] = 0; }
+        s = e;
+    }
+    return n;
+}
 inline const char *plan_tok(const char *name) { return knob_tok("BICG_PLAN", name); }
 inline const char *test_tok(const char *name) { return knob_tok("BICG_TEST", name); }
 inline bool plan_off(const char *name) { const char *v = plan_tok(name); return v && atoi(v) == 0; }     // "name=0"

@@ -471,7 +471,19 @@ def test_switch_variables_as_the_library_reads_them():
     assert H.switch_value("BICG_PLAN", "lines") is None and H.switch_value("BICG_PLAN", "planes") == "64"
     os.environ["BICG_TEST"] = " plan-collide , p2p-fault-after=7,"            # written by hand: blanks, a bare token, a trailing comma
     assert H.switch_value("BICG_TEST", "plan-collide") == "1" and H.switch_value("BICG_TEST", "p2p-fault-after") == "7"
-    H.switches(stencil=None, planes=None, layout=None, persist_chunk=None)
+    # a token the library does not know is counted (bicg_create says so on rank 0) -- every keyword of hipsolver.switches is known
+    buf = C.create_string_buffer(64)
+    for var in H.SWITCH_VARS:
+        assert H.lib().bicg_switch_unknown(var.encode(), buf, 64) == 0, (var, os.environ.get(var), buf.value)
+    everything = {k: 1 for k in H.SWITCHES}
+    H.switches(**everything)
+    for var in H.SWITCH_VARS:
+        assert H.lib().bicg_switch_unknown(var.encode(), buf, 64) == 0, (var, os.environ.get(var), buf.value)
+    H.switches(**{k: None for k in H.SWITCHES})
+    os.environ["BICG_PLAN"] = "stencil=0,stencl=0,no-window"
+    assert H.lib().bicg_switch_unknown(b"BICG_PLAN", buf, 64) == 2 and buf.value == b"stencl=0"
+    os.environ["BICG_PLAN"] = "lines=2"
+    H.switches(stencil=None, lines=None, planes=None, layout=None, persist_chunk=None)
     assert "BICG_PLAN" not in os.environ and "BICG_PERSIST" not in os.environ
     assert H.switch_value("BICG_PLAN", "stencil") is None
 
