@@ -104,6 +104,109 @@ def roof(alg_bytes, seconds, csr_bytes, spmv_stream_bytes, nspmv, rows, nvec, fl
     return dict(out, bound="hbm", peak=HBM_PEAK_GBS, frac=fgb / HBM_PEAK_GBS)
 
 
+def _r(v, nd=6):
+    """numbers of the compact line: 6 significant digits are more than any clock here resolves"""
+    if isinstance(v, bool) or v is None or isinstance(v, (int, str)):
+        return v
+    if isinstance(v, float):
+        return float(f"{v:.{nd}g}") if v == v and abs(v) != float("inf") else None
+    if isinstance(v, dict):
+        return {k: _r(x, nd) for k, x in v.items()}
+    if isinstance(v, (list, tuple)):
+        return [_r(x, nd) for x in v]
+    return v
+
+
+COMPACT_LIMIT = 8192      # bytes; the driver's capture parsed a 16 KB line and lost a 27 KB one (round 5) -- stay well below
+ROOF_KEYS = ("kernel", "bound", "peak", "unit", "achieved", "frac", "frac_basis", "survey_8d_frac", "algorithmic_bytes_per_launch",
+             "avg_launch_ms", "traffic", "frac_of_measured_copy")
+
+
+def compact(full):
+    """The ONE line rank 0 prints on stdout, formed from the complete record (which goes to bench_full.json and stderr).
+    Contract keys + roofline + cpu_baseline + one {ms_per_iteration, bound, frac} per extra leg; long texts are cut."""
+    def cut(s, n):
+        return s if not isinstance(s, str) or len(s) <= n else s[:n - 1] + "~"
+
+    def roofline(r, kernel_chars=96):
+        if not r:
+            return None
+        out = {k: r.get(k) for k in ROOF_KEYS}
+        out["kernel"] = cut(out["kernel"], kernel_chars)
+        out["frac_basis"] = cut(out["frac_basis"], 96)
+        if out["algorithmic_bytes_per_launch"] is None:
+            out["algorithmic_bytes_per_launch"] = r.get("format_bytes_per_launch")
+        sd = r.get("structure_dependence")
+        if sd:
+            out["structure_dependence"] = {"ms_per_iteration": sd.get("ms_per_iteration"), "frac": sd.get("frac_of_format_bytes", sd.get("frac"))}
+        if isinstance(r.get("ms_per_iteration"), dict):
+            out["ms_per_iteration"] = r["ms_per_iteration"]
+        for k in ("numbering", "window"):
+            if k in r:
+                out[k] = r[k]
+        st = r.get("stream_measured_gbps")
+        if isinstance(st, dict):
+            out["stream_measured_gbps"] = {k: v for k, v in st.items() if k != "note"}
+        return out
+
+    def leg(e):
+        """an extra workload: one {ms_per_iteration, bound, frac} per method it ran"""
+        if not isinstance(e, dict):
+            return e
+        if "error" in e:
+            return {"error": cut(e["error"], 120)}
+        out = {}
+        for k, v in e.items():
+            if isinstance(v, dict) and "ms_per_iteration" in v:
+                out[k] = {"ms_per_iteration": v["ms_per_iteration"], "bound": v.get("bound"), "frac": v.get("frac")}
+                if v.get("iterations_genuine") is False:
+                    out[k]["iterations_genuine"] = False
+            elif isinstance(v, dict) and "ms" in v and "bound" in v:       # spmv_back_to_back / spmm legs
+                out[k] = {"ms": v["ms"], "bound": v.get("bound"), "frac": v.get("frac")}
+        if "ms_per_iteration" in e:
+            out.update(ms_per_iteration=e["ms_per_iteration"], bound=e.get("bound"), frac=e.get("frac"))
+        return out
+
+    cfg = full.get("config", {})
+    cpu, cpu_all = full.get("cpu_baseline"), full.get("cpu_baseline_multicore")
+    cm = full.get("comm") or {}
+    line = {k: full.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                     "vs_baseline", "dtype", "data")}
+    line["metric"] = cut(line["metric"], 140)
+    line["config"] = {k: cfg.get(k) for k in ("workload", "rows", "nnz", "method", "transport", "iterations_genuine", "halo")}
+    line["config"]["workload"] = cut(line["config"]["workload"], 140)
+    line["config"]["transport"] = cut(line["config"]["transport"], 120)
+    line["roofline"] = roofline(full.get("roofline"))
+    line["roofline_unstructured"] = roofline(full.get("roofline_unstructured"))
+    if isinstance(cpu, dict):
+        line["cpu_baseline"] = {k: cut(cpu.get(k), 140) for k in ("value", "unit", "cores", "kind", "sample", "flags", "error") if k in cpu}
+    else:
+        line["cpu_baseline"] = cpu
+    if isinstance(cpu_all, dict):
+        line["cpu_baseline_multicore"] = {k: cut(cpu_all.get(k), 120) for k in ("value", "unit", "cores", "kind", "error") if k in cpu_all}
+    else:
+        line["cpu_baseline_multicore"] = cpu_all
+    rl = cm.get("rccl_leg")
+    if isinstance(rl, dict):
+        rl = {k: cut(v, 160) for k, v in rl.items() if k in ("ms_per_iteration", "unavailable", "rccl_nranks", "iterations_genuine", "note", "attempt")}
+    line["comm"] = {"world": cm.get("world"), "p2p_selftest": cm.get("p2p_selftest"), "rccl_nranks": cm.get("rccl_nranks"),
+                    "transport_used": cut(cm.get("transport_used"), 120), "fallback_reason": cut(cm.get("fallback_reason"), 160),
+                    "wait_us": cm.get("wait_us"), "rccl_leg": rl}
+    line["variants_ms_per_iteration"] = full.get("variants_ms_per_iteration")
+    line["variants_frac"] = {k: v.get("frac") for k, v in (full.get("variant_rooflines") or {}).items()}
+    line["extras"] = {k: leg(v) for k, v in (full.get("extras") or {}).items()}
+    line["full_record"] = full.get("full_record")
+    line = _r(line)
+    text = json.dumps(line, separators=(",", ":"))
+    if len(text) >= COMPACT_LIMIT:        # never expected: drop the optional blocks rather than lose the whole line
+        for k in ("extras", "variants_frac", "variants_ms_per_iteration"):
+            line[k] = None
+            text = json.dumps(line, separators=(",", ":"))
+            if len(text) < COMPACT_LIMIT:
+                break
+    return text
+
+
 def measure_traffic(argv_inner, note):
     """HBM bytes per SpMV launch of THIS run's kernel, from rocprofv3 PMC counters collected now: two
     separate passes (--pmc FETCH_SIZE, --pmc WRITE_SIZE; the TCC block cannot hold both) over a short
@@ -192,6 +295,16 @@ def main():
     ap.add_argument("--inner", action="store_true", help=argparse.SUPPRESS)   # the run rocprofv3 wraps for roofline.traffic
     a = ap.parse_args()
 
+    if a.gpus > 1 and "WORLD_SIZE" not in os.environ and "RANK" not in os.environ:
+        # `python bench.py --gpus N` without a launcher: become the launcher (one rank per GPU, the command the driver uses)
+        import socket
+        sk = socket.socket(); sk.bind(("127.0.0.1", 0)); port = sk.getsockname()[1]; sk.close()
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={a.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        print(f"bench.py: --gpus {a.gpus} without a launcher: re-executing under torch.distributed.run", file=sys.stderr, flush=True)
+        sys.stdout.flush()
+        os.execv(sys.executable, cmd)
+
     rank = int(os.environ.get("RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
@@ -203,7 +316,8 @@ def main():
 
     def note(msg):
         if rank == 0:
-            print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+            msg = str(msg)       # stderr shares the driver's bounded capture with the result line: notes stay short
+            print(f"[bench {time.strftime('%H:%M:%S')}] {msg if len(msg) <= 400 else msg[:399] + '~'}", file=sys.stderr, flush=True)
 
     # A hung collective must not hang the driver: after BENCH_WATCHDOG_S seconds every rank gives up.
     import threading
@@ -885,7 +999,20 @@ def main():
             "timed_regions_ms": regions_ms,
             "timed_region_clocks": region_clocks,
         }
-        print(json.dumps(line), file=result_out, flush=True)
+        # the complete record (every timed region with its clocks, plans, flags, notes): a side file and stderr. stdout gets
+        # ONE compact line (< 8 KB) formed from it -- the driver's capture could not hold the 27 KB line of round 5
+        full_path = os.environ.get("BENCH_FULL_JSON", os.path.join(ROOT, "bench_full.json"))
+        line["full_record"] = os.path.basename(full_path)
+        try:
+            with open(full_path, "w") as f:
+                json.dump(line, f, indent=1)
+            out_dir = os.path.join(ROOT, "gpurun_out")
+            if os.path.isdir(out_dir) and "BENCH_FULL_JSON" not in os.environ:
+                shutil.copy(full_path, os.path.join(out_dir, "bench_full.json"))
+        except OSError as e:
+            note(f"bench_full.json not written: {e!r}")
+        # (not echoed to stderr: the driver keeps a bounded tail of stdout + stderr TOGETHER, a 27 KB echo would push the line out)
+        print(compact(line), file=result_out, flush=True)
 
     dog.cancel()
     if dist is not None:

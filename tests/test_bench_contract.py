@@ -70,6 +70,65 @@ def test_bench_names_the_bound_of_every_leg():
     assert "SHARING one device" in src             # two ranks on one GPU are not "over xGMI"
 
 
+COMPACT_KEYS = ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling", "vs_baseline",
+                "dtype", "data", "config", "roofline", "roofline_unstructured", "cpu_baseline", "cpu_baseline_multicore", "comm",
+                "variants_ms_per_iteration", "extras", "full_record")
+ROOFLINE_KEYS = ("kernel", "bound", "peak", "unit", "achieved", "frac", "frac_basis", "survey_8d_frac", "algorithmic_bytes_per_launch",
+                 "avg_launch_ms", "traffic", "frac_of_measured_copy")
+
+
+def test_the_stdout_line_is_compact():
+    """Round 5's 27 KB line did not fit the driver's capture (BENCH_r05.json: parsed null). The line on stdout is now formed from
+    the complete record by bench.compact(): < 8 KB, the contract's keys, roofline and cpu_baseline with the keys the review
+    named, one {ms_per_iteration, bound, frac} per extra leg. Checked on the recorded complete lines of rounds 4-5 and on a record
+    inflated with long texts."""
+    import glob
+    import json
+    sys.path.insert(0, ROOT)
+    import bench
+    recs = sorted(glob.glob(os.path.join(ROOT, "profiles", "r0[45]", "bench_n1_driver_flags*.json")) + glob.glob(os.path.join(ROOT, "profiles", "r06", "bench_full*.json")))
+    assert recs
+    for path in recs:
+        full = json.load(open(path))
+        text = bench.compact(full)
+        assert len(text) < bench.COMPACT_LIMIT == 8192 and "\n" not in text, (path, len(text))
+        line = json.loads(text)
+        assert set(COMPACT_KEYS) <= set(line), (path, set(COMPACT_KEYS) - set(line))
+        assert set(ROOFLINE_KEYS) <= set(line["roofline"])
+        assert {"workload", "rows", "nnz", "method", "transport", "iterations_genuine"} <= set(line["config"])
+        assert line["value"] == float(f"{full['value']:.6g}") and line["roofline"]["bound"] == "hbm"
+        if full.get("cpu_baseline"):
+            assert {"value", "unit", "cores", "kind", "sample"} <= set(line["cpu_baseline"])
+        for name, e in line["extras"].items():
+            for leg in ([e] if "ms_per_iteration" in e else [v for v in e.values() if isinstance(v, dict)]):
+                assert set(leg) <= {"ms_per_iteration", "ms", "bound", "frac", "iterations_genuine", "error"}, (name, leg)
+    # texts of any length cannot push the line over the limit
+    full = json.load(open(recs[-1]))
+    full["config"]["workload"] = "w" * 5000
+    full["config"]["transport"] = "t" * 5000
+    full["roofline"]["kernel"] = "k" * 5000
+    full["roofline"]["frac_basis"] = "f" * 5000
+    full["cpu_baseline"] = dict(full.get("cpu_baseline") or {}, sample="s" * 5000, flags="g" * 5000)
+    assert len(bench.compact(full)) < 8192
+    full["extras"] = {f"leg{i}": {"bicgstab": {"ms_per_iteration": 1.0, "bound": "hbm", "frac": 0.5}} for i in range(400)}
+    text = bench.compact(full)
+    assert len(text) < 8192 and json.loads(text)["roofline"]["frac"] is not None
+
+
+def test_bench_relaunches_itself_for_more_than_one_gpu():
+    """`python bench.py --gpus N` with no launcher around it re-executes under torch.distributed.run (one rank per GPU) instead of
+    exiting 2; here, without a GPU, every rank then fails loudly"""
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    assert "torch.distributed.run" in src and "os.execv(sys.executable" in src
+    import torch
+    if torch.cuda.is_available():
+        return
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2"], capture_output=True, text=True, timeout=300,
+                         env={k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK")})
+    assert "re-executing under torch.distributed.run" in out.stderr and out.returncode != 0
+    assert out.stderr.count("needs a GPU") >= 2 and out.stdout.strip() == ""
+
+
 def test_graft_entry_has_build_and_smoke():
     sys.path.insert(0, ROOT)
     import __graft_entry__ as g

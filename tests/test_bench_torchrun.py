@@ -38,11 +38,36 @@ def run_bench(n, extra=()):
     cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={n}", "--master-addr", "127.0.0.1",
            "--master-port", str(_free_port()), os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "20", "--warmup", "5",
            "--no-cpu-baseline", "--no-variants", *extra]
-    env = dict(os.environ, BENCH_WATCHDOG_S="240", OMP_NUM_THREADS="2")
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=400, cwd=ROOT, env=env)
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
-    return json.loads(lines[0])
+    return _run(cmd, 400, dict(BENCH_WATCHDOG_S="240", OMP_NUM_THREADS="2"))
+
+
+def _run(cmd, timeout, env_extra):
+    """-> the COMPLETE record (bench_full.json); the one stdout line must be its compact form: < 8 KB, contract keys, same numbers"""
+    import tempfile
+    with tempfile.TemporaryDirectory() as tmp:
+        full_path = os.path.join(tmp, "bench_full.json")
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout, cwd=ROOT,
+                             env=dict(os.environ, BENCH_FULL_JSON=full_path, **env_extra))
+        assert out.returncode == 0 and out.stdout.count("\n") == 1 and out.stdout.startswith("{"), out.stdout[-2000:] + out.stderr[-4000:]
+        assert len(out.stdout) < 8192, len(out.stdout)
+        assert len(out.stderr) < 12000, len(out.stderr)      # the driver keeps a bounded tail of both streams together
+        line = json.loads(out.stdout)
+        full = json.load(open(full_path))
+    check_compact(line, full)
+    return full
+
+
+def check_compact(line, full):
+    from test_bench_contract import COMPACT_KEYS, ROOFLINE_KEYS
+    assert set(COMPACT_KEYS) <= set(line), set(COMPACT_KEYS) - set(line)
+    assert set(ROOFLINE_KEYS) <= set(line["roofline"]), set(ROOFLINE_KEYS) - set(line["roofline"])
+    for k in ("value", "ms_per_step"):
+        assert abs(line[k] - full[k]) <= 1e-5 * full[k]
+    for k in ("unit", "n_gpus", "steps", "warmup", "higher_is_better", "scaling", "vs_baseline", "dtype", "data"):
+        assert line[k] == full[k], k
+    assert abs(line["roofline"]["frac"] - full["roofline"]["frac"]) < 1e-5
+    assert line["config"]["iterations_genuine"] == full["config"]["iterations_genuine"]
+    assert line["full_record"] == "bench_full.json"
 
 
 @pytest.mark.parametrize("n,transport,extras", [(2, "host-p2p", True), (4, "host-p2p", False), (2, "host", False)])
@@ -82,10 +107,7 @@ def test_bench_single_gpu_line_has_every_leg():
     """the N = 1 line the driver records: headline unchanged, plus roofline fractions of every variant, the banded /
     FEM-like / 256^3-Laplacian legs and the HBM traffic measured in this run (rocprofv3 PMC passes)"""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "20", "--warmup", "5", "--no-cpu-baseline"]
-    out = subprocess.run(cmd, capture_output=True, text=True, timeout=900, cwd=ROOT, env=dict(os.environ, BENCH_WATCHDOG_S="800"))
-    lines = [ln for ln in out.stdout.splitlines() if ln.startswith("{")]
-    assert out.returncode == 0 and len(lines) == 1, out.stdout[-2000:] + out.stderr[-4000:]
-    d = json.loads(lines[0])
+    d = _run(cmd, 900, dict(BENCH_WATCHDOG_S="800"))
     assert d["n_gpus"] == 1 and d["config"]["iterations_genuine"] is True and "configs[1]" in d["config"]["workload"]
     for m in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr", "shifted_lopbicgstab_16shifts", "shifted_pipe_lopbicgstab_16shifts"):
         r = d["variant_rooflines"][m]
