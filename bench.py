@@ -141,9 +141,13 @@ def compact(full):
             out["structure_dependence"] = {"ms_per_iteration": sd.get("ms_per_iteration"), "frac": sd.get("frac_of_format_bytes", sd.get("frac"))}
         if isinstance(r.get("ms_per_iteration"), dict):
             out["ms_per_iteration"] = r["ms_per_iteration"]
-        for k in ("numbering", "window"):
+        for k in ("numbering", "product_kernels", "survey_8d_frac_of_measured_copy"):
             if k in r:
                 out[k] = r[k]
+        if isinstance(r.get("other_numberings"), dict):
+            out["other_numberings"] = {kind: {k: cut(u.get(k), 160) for k in ("product_kernels", "avg_launch_ms", "frac", "survey_8d_frac",
+                                                                              "survey_8d_frac_of_measured_copy", "ms_per_iteration", "bottleneck") if k in u}
+                                       for kind, u in r["other_numberings"].items()}
         st = r.get("stream_measured_gbps")
         if isinstance(st, dict):
             out["stream_measured_gbps"] = {k: v for k, v in st.items() if k != "note"}
@@ -248,7 +252,7 @@ def measure_traffic(argv_inner, note):
         return (1024.0 * sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
     # the in-solver SpMV with its dot epilogue (sliced-ELL kernel, or the ragged-rows product of bicg_jagw.hip)
-    dots = lambda nm: any(k in nm for k in ("k_spmv_sell<1", "k_spmv_sell<2", "k_spmv_jagw<1", "k_spmv_jagw<2"))
+    dots = lambda nm: any(k in nm for k in ("k_spmv_sell<1", "k_spmv_sell<2", "k_spmv_jagw<1", "k_spmv_jagw<2", "k_spmv_jagd<1", "k_spmv_jagd<2"))
     fetch, nf = per_launch("FETCH_SIZE", dots)
     write, nw = per_launch("WRITE_SIZE", dots)
     qf, _ = per_launch("FETCH_SIZE", lambda nm: "FPlainQ" in nm)
@@ -267,11 +271,14 @@ def main():
     ap.add_argument("--method", default="bicgstab", choices=list(ITER_VECTOR_BYTES_PER_ROW))
     ap.add_argument("--rows", dest="n", type=int, default=0, help="rows (default: 1602111; banded: ~24 M non-zeros)")
     ap.add_argument("--scale-decades", type=float, default=2.0)
-    ap.add_argument("--workload", default="transport", choices=["transport", "laplace7", "banded", "fem_like"],
+    ap.add_argument("--numbering", default="rcm", choices=["generator", "rcm", "random"], help="--workload mesh: the node numbering")
+    ap.add_argument("--workload", default="transport", choices=["transport", "laplace7", "banded", "fem_like", "mesh"],
                     help="transport: BASELINE configs[1] (default, the headline). banded: dense band, --half-bandwidth b "
                          "(SURVEY 8d synthetic input ii). fem_like: irregular rows (3..27 per row) on the Transport node "
                          "numbering. laplace7: 7-point Laplacian on an m^3 grid (configs[3] is m = 512 over 8 GPUs = 64 "
-                         "planes of 512^2 per GPU)")
+                         "planes of 512^2 per GPU). mesh: the unstructured FEM matrix of mpi_bicgstab_amd.mesh (P1 elements on a "
+                         "Delaunay tetrahedralisation of 117^3 jittered points: 1 601 613 rows, 26.0 M non-zeros, symmetric pattern, "
+                         "unsymmetric values -- the stand-in for Transport.mtx) in the numbering --numbering")
     ap.add_argument("--half-bandwidth", type=int, default=64)
     ap.add_argument("--grid", dest="m", type=int, default=256, help="grid edge for --workload laplace7")
     ap.add_argument("--matrix", default=None, help="Matrix-Market file (coordinate real general) instead of the "
@@ -472,7 +479,21 @@ def main():
     K, W = a.steps, a.warmup
 
     # ------------------------------------------------------------------ workloads: this rank's row slab
-    def build(workload, n=0, half_bw=64, m=256, matrix=None):
+    mesh_cache = os.path.join(tempfile.gettempdir(), "bicg_mesh_cache")
+
+    def mesh_slab(kind, lo_hi):
+        """this rank's rows of the unstructured FEM matrix; rank 0 generates (or finds) the assembled matrix first, the other ranks
+        of the host read its files"""
+        from mpi_bicgstab_amd import mesh
+        os.makedirs(mesh_cache, exist_ok=True)
+        if rank == 0:
+            slab = mesh.fem_unstructured(117, kind, a.scale_decades, rows=lo_hi, cache_dir=mesh_cache)
+        barrier()
+        if rank != 0:
+            slab = mesh.fem_unstructured(117, kind, a.scale_decades, rows=lo_hi, cache_dir=mesh_cache)
+        return slab
+
+    def build(workload, n=0, half_bw=64, m=256, matrix=None, numbering="rcm"):
         """-> dict(name, rows, nnz, blocks, lo, hi, note): this rank's blocks of the global matrix"""
         mtx = matrix or (os.path.join(ROOT, "data", "Transport.mtx") if workload == "transport" and not n and
                          os.path.exists(os.path.join(ROOT, "data", "Transport.mtx")) else None)
@@ -493,6 +514,12 @@ def main():
             desc = (f"synthetic banded CSR (SURVEY.md 8d input ii): half-bandwidth {half_bw}, {rows} rows, value law of the "
                     f"Transport-shaped synthetic scaled over {a.scale_decades} decades, b = A*1, x0 = 0")
             gen = lambda lo, hi: synth.banded(rows, half_bw, rows=(lo, hi), scale_decades=a.scale_decades)
+        elif workload == "mesh":
+            rows = 117 ** 3
+            nnz = None
+            desc = (f"unstructured FEM matrix (mesh.py: P1 convection-diffusion on a Delaunay tetrahedralisation of 117^3 jittered points, "
+                    f"symmetric pattern, unsymmetric values), numbering '{numbering}', values scaled over {a.scale_decades} decades, b = A*1, x0 = 0")
+            gen = lambda lo, hi: mesh_slab(numbering, (lo, hi))
         elif workload == "fem_like":
             rows = n or synth.TRANSPORT_N
             nnz = None
@@ -592,7 +619,7 @@ def main():
 
     # ------------------------------------------------------------------ headline workload
     stage[0] = "matrix generation / upload"
-    wl = build(a.workload, a.n, a.half_bandwidth, a.m, a.matrix)
+    wl = build(a.workload, a.n, a.half_bandwidth, a.m, a.matrix, a.numbering)
     leg = Leg(wl)
     n, nnz_global, plan = wl["rows"], wl["nnz"], leg.plan
     note(f"matrix resident: {plan}")
@@ -754,6 +781,7 @@ def main():
             lg = Leg(wl2)
             out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v],
                        setup_seconds=lg.setup_s)
+            H.product_kernels()
             mbytes = lg.ctx.spmv_matrix_bytes()
             for m in methods:
                 dtv, rv = lg.best(m, steps=steps, warm=min(W, 10))
@@ -765,6 +793,7 @@ def main():
                               iterations=int(rv.iterations),
                               iterations_genuine=bool(int(rv.iterations) == steps + min(W, 10) and rv.breakdown_iteration == 0
                                                       and np.isfinite(rv.dot_r) and rv.dot_r > 0.0))
+            out["product_kernels"] = H.product_kernels()       # which product kernels the solves of this leg launched (rank 0)
             sp = lg.ctx.spmv_bench(100)
             bs = spmv_bytes(lg.plan["nnz_diag"] + lg.plan["nnz_offd"], lg.plan["rows"], lg.plan["halo"])
             out["spmv_back_to_back"] = dict(ms=sp, gbps=bs / (sp * 1e-3) / 1e9, algorithmic_bytes_rank0=bs,
@@ -835,10 +864,13 @@ def main():
                    "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "2", "--rows", str(nrows), "--method", "pipe_bicgstab",
                    "--steps", "400", "--warmup", "40", "--transport", "host-p2p", "--no-cpu-baseline", "--no-variants", "--no-extras",
                    "--no-traffic", "--no-stream", "--no-rccl-leg", "--scale-decades", str(a.scale_decades)]
+            child_full = tempfile.mktemp(prefix="bicg_bench_child_", suffix=".json", dir="/tmp")
             try:
                 r = subprocess.run(cmd, capture_output=True, text=True, timeout=300, cwd=ROOT,
-                                   env=dict(os.environ, BENCH_WATCHDOG_S="240", OMP_NUM_THREADS="2"))
-                d = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+                                   env=dict(os.environ, BENCH_WATCHDOG_S="240", OMP_NUM_THREADS="2", BENCH_FULL_JSON=child_full))
+                assert r.stdout.startswith("{"), r.stderr[-300:]
+                d = json.load(open(child_full))           # the child's complete record (its stdout line is the compact form)
+                os.unlink(child_full)
                 out = dict(ranks=2, rows_per_rank=nrows // 2, ms_per_iteration=d["value"], bound="latency", frac=None,
                            transport=d["config"]["transport"], flags=d["config"].get("flags"), halo=d["config"].get("halo"),
                            comm_wait_us=d.get("comm", {}).get("wait_us"),
@@ -852,6 +884,9 @@ def main():
         ke = min(K, 100)
         for hb in (8, 64, 512):
             extras[f"banded_b{hb}"] = extra(f"banded b={hb}", build("banded", 0, hb), ("bicgstab", "pipe_bicgstab"), ke)
+        if world > 1:
+            # the unstructured matrix (RCM numbering) in the reference's row partition, whatever the number of GPUs
+            extras["mesh_rcm"] = extra("mesh rcm", build("mesh", numbering="rcm"), ("bicgstab", "pipe_bicgstab"), ke)
         if world == 1:
             # what ONE of 8 GPUs does in BASELINE.json configs[2]: a 200 k-row rank (1/8 of the Transport-shaped matrix, the
             # reference's partition) -- latency-bound, the pipelined solver runs it as one persistent launch per chunk of
@@ -861,7 +896,9 @@ def main():
             wl8 = dict(build("transport", n=n8), desc=f"1/8 of the Transport-shaped matrix as one rank holds it at 8 GPUs ({n8} rows)")
             extras["transport_rank_of_8"] = extra("1/8 Transport rank", wl8, ("pipe_bicgstab", "bicgstab"), max(ke, 200))
             extras["small_rank_with_halo"] = small_rank_with_halo(n8)
-            extras["fem_like"] = extra("fem_like", build("fem_like"), ("bicgstab", "pipe_bicgstab"), ke, kernel_roofline=True)
+            # the stand-in for Transport.mtx where nothing is regular: the unstructured FEM matrix in three numberings
+            for kind in ("rcm", "generator", "random"):
+                extras[f"mesh_{kind}"] = extra(f"mesh {kind}", build("mesh", numbering=kind), ("bicgstab", "pipe_bicgstab"), ke, kernel_roofline=True)
             extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
             extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "
                                                  "= 16.8 M rows per GPU), CA-BiCGStab")
@@ -886,31 +923,54 @@ def main():
                                   caveat="the x2 is stated by the guide for wide coalesced reads and re-checked here on the element-wise "
                                          "kernel; the SpMV issues 8- and 16-byte loads")
 
-    # the same counters for the product of the FEM-like matrix (jagged slices with the x window in LDS): the second headline
-    roofline_unstructured = None
-    if "fem_like" in extras and "kernel_roofline" in extras.get("fem_like", {}):
-        kr = extras["fem_like"]["kernel_roofline"]
+    # the product of the UNSTRUCTURED matrix as the second headline: the mesh matrix in RCM numbering (what a bandwidth-reducing
+    # pre-pass of a FEM code hands over), with the generator order and the random permutation beside it
+    KERNEL_TEXT = {"jagw": "k_spmv_jagw (csrc/bicg_jagw.hip: jagged slices, x window of each 256-row group in LDS, three dependent trips per group)",
+                   "jagd": "k_spmv_jagd (csrc/bicg_jagw.hip: jagged slices, x gathered through the caches by 16-bit offsets / 32-bit columns, three trips)",
+                   "sell_jagged": "k_spmv_sell on jagged slices", "sell_window_loop": "k_spmv_sell's window loop", "csr": "k_spmv (CSR row blocks)"}
+
+    def unstructured(kind, with_traffic):
+        e = extras.get(f"mesh_{kind}")
+        if not e or "kernel_roofline" not in e:
+            return None
+        kr = e["kernel_roofline"]
         t_un, t_un_detail = None, None
-        if rank == 0 and world == 1 and not a.no_traffic:
-            stage[0] = "rocprofv3 counter passes, FEM-like matrix"
-            m = measure_traffic(["--inner", "--workload", "fem_like", "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-variants", "--no-extras",
-                                 "--no-traffic", "--no-stream", "--method", "bicgstab", "--scale-decades", str(a.scale_decades)], note)
+        if with_traffic and rank == 0 and world == 1 and not a.no_traffic:
+            stage[0] = f"rocprofv3 counter passes, mesh matrix ({kind})"
+            m = measure_traffic(["--inner", "--workload", "mesh", "--numbering", kind, "--steps", "30", "--warmup", "5", "--no-cpu-baseline", "--no-variants",
+                                 "--no-extras", "--no-traffic", "--no-stream", "--method", "bicgstab", "--scale-decades", str(a.scale_decades)], note)
             if m:
                 t_un = 2.0 * m["fetch_counter_bytes"] + m["write_counter_bytes"]
                 t_un_detail = dict(fetch_bytes_x2=2.0 * m["fetch_counter_bytes"], write_bytes=m["write_counter_bytes"], launches=m["launches"])
-        roofline_unstructured = dict(
-            kernel="k_spmv_jagw (csrc/bicg_jagw.hip: jagged slices, x window of each 256-row group staged in LDS, three dependent trips "
-                   "per group, fused dot epilogue) on the FEM-like matrix: ragged rows (6..27), no shared lists -- the layout a real "
-                   "FEM matrix such as Transport.mtx gets",
+        kern = [k for k in e.get("product_kernels", []) if k in KERNEL_TEXT]
+        return dict(
+            kernel="; ".join(KERNEL_TEXT[k] for k in kern) + f" on the unstructured FEM matrix, numbering '{kind}'",
+            product_kernels=e.get("product_kernels"), numbering=kind,
             bound="hbm", peak=HBM_PEAK_GBS, unit="GB/s",
-            achieved=kr["format_gbps"], frac=kr["format_frac"], frac_basis="format bytes (values + 16-bit window slots + window runs + x + y)",
+            achieved=kr["format_gbps"], frac=kr["format_frac"], frac_basis="format bytes (values + 16-bit offsets or slots / 32-bit columns + per-lane words + x + y)",
             avg_launch_ms=kr["avg_launch_ms"], launches_timed=kr["launches_timed"],
-            format_bytes_per_launch=kr["format_bytes_per_launch"],
+            format_bytes_per_launch=kr["format_bytes_per_launch"], algorithmic_bytes_per_launch=kr["format_bytes_per_launch"],
             survey_8d_bytes_per_launch=kr["survey_8d_bytes_per_launch"], survey_8d_gbps=kr["survey_8d_gbps"], survey_8d_frac=kr["survey_8d_frac"],
             traffic=t_un, traffic_detail=t_un_detail,
-            ms_per_iteration={m: extras["fem_like"][m]["ms_per_iteration"] for m in ("bicgstab", "pipe_bicgstab") if m in extras["fem_like"]},
-            back_to_back_spmv_ms=extras["fem_like"]["spmv_back_to_back"]["ms"],
-            frac_of_measured_copy=(kr["format_gbps"] / stream["copy"]) if stream and "copy" in stream else None)
+            ms_per_iteration={m: e[m]["ms_per_iteration"] for m in ("bicgstab", "pipe_bicgstab") if m in e},
+            back_to_back_spmv_ms=e["spmv_back_to_back"]["ms"],
+            frac_of_measured_copy=(kr["format_gbps"] / stream["copy"]) if stream and "copy" in stream else None,
+            survey_8d_frac_of_measured_copy=(kr["survey_8d_gbps"] / stream["copy"]) if stream and "copy" in stream else None)
+
+    roofline_unstructured = unstructured("rcm", True)
+    if roofline_unstructured:
+        others = {}
+        for kind in ("generator", "random"):
+            u = unstructured(kind, kind == "random")
+            if u:
+                others[kind] = {k: u[k] for k in ("product_kernels", "avg_launch_ms", "frac", "survey_8d_frac", "survey_8d_frac_of_measured_copy", "traffic",
+                                                  "format_bytes_per_launch", "ms_per_iteration")}
+        # the adversarial numbering: every gather of x pulls a whole cache line out of the Infinity Cache for 8 useful bytes -- the
+        # counters say how many bytes the product moved for the bytes its layout holds
+        if "random" in others and others["random"]["traffic"]:
+            others["random"]["bottleneck"] = ("x gathers: one cache line per entry from the Infinity Cache (x itself is 12.8 MB); fabric traffic = "
+                                              f"{others['random']['traffic'] / others['random']['format_bytes_per_launch']:.1f} x the layout's bytes")
+        roofline_unstructured["other_numberings"] = others
 
     cpu = None
     cpu_all = None
@@ -941,7 +1001,7 @@ def main():
         iter_bytes = iteration_bytes(a.method, nnz_global, n)
         iter_fmt_bytes = min(iter_bytes, iter_bytes - 2 * world * max(0, b_spmv - fmt_spmv))
         shape = {"transport": "Transport-shaped CSR", "laplace7": f"7-point Laplacian {a.m}^3", "banded": f"banded CSR b={a.half_bandwidth}",
-                 "fem_like": "FEM-like irregular CSR"}[a.workload]
+                 "fem_like": "FEM-like irregular CSR", "mesh": f"unstructured FEM CSR ({a.numbering} numbering)"}[a.workload]
         line = {
             "metric": f"ms/iteration, {a.method}, {shape} ({n} rows, {nnz_global} nnz), strong scaling over GPUs",
             "value": ms_step, "unit": "ms/iteration", "n_gpus": world, "steps": K, "warmup": W,

@@ -358,6 +358,13 @@ int bicg_stencil_info(bicg_ctx *ctx, unsigned int out[8]);
  * list it was given: the number of slices that did NOT match (hash collisions) and were put back on their stored columns and
  * values. 0 for contexts built by bicg_create (the host plan keys on the full lists). */
 unsigned int bicg_plan_collisions(bicg_ctx *ctx);
+/* Which product kernels this process has launched since the last call with reset != 0 (bit mask): 1 k_spmv_sell on padded slices,
+ * 2 k_spmv_sell on jagged slices (columns gathered through the caches), 4 k_spmv_sell's loop over jagged slices with the x window
+ * in LDS, 8 k_spmv_jagw (the three-trip form of that product, csrc/bicg_jagw.hip), 16 k_spmv_stencil, 32 k_spmv (CSR row blocks),
+ * 64 k_spmv_rows (a row over several lanes), 128 a product with a pipelined phase in its epilogue, 256 the window-fused product,
+ * 512 k_spmv_jagd (the three-trip product of jagged slices without a window: x gathered through the caches). Tests and bench.py
+ * assert on the kernel a matrix gets. */
+unsigned int bicg_product_kernels(int reset);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
  * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST="shifted=0" keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);

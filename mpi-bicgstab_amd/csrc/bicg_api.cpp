@@ -275,6 +275,12 @@ int bicg_stencil_info(bicg_ctx *c, unsigned int out[8])
     return on ? 1 : 0;
 }
 unsigned int bicg_plan_collisions(bicg_ctx *c) { return c->plan_collisions; }
+unsigned int bicg_product_kernels(int reset)
+{
+    const unsigned m = g_product_kernels;
+    if (reset) g_product_kernels = 0;
+    return m;
+}
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return stencil_product(c) ? c->stencil_matrix_bytes : c->matrix_bytes; }
 int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
 int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }

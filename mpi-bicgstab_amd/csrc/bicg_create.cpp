@@ -760,6 +760,17 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         } else {
             ok = false;
         }
+        // The window pays through k_spmv_jagw only (three dependent trips per group, bicg_jagw.hip): at most kJagwMaxRuns runs per
+        // group and kJagwMaxSlots slots. A numbering whose groups touch MANY short runs (reverse Cuthill-McKee of a tetrahedral
+        // mesh: up to 170 runs, 2 657 slots) would go through k_spmv_sell's window loop, which stages run after run: 169 us per
+        // product on the 1.6 M-row mesh matrix against 56.5 us for the same jagged slices with 16-bit offsets gathered through
+        // the caches (profiles/r06/mesh_probe_baseline.txt, mesh_probe_plans.txt). Unless BICG_PLAN="window=1" insists, such a
+        // block keeps its jagged slices and drops the window.
+        if (ok && win_env != 1) {
+            uint32_t most_runs = 0;
+            for (uint32_t g = 0; g < ngroups; ++g) most_runs = std::max(most_runs, win_ptr[g + 1] - win_ptr[g]);
+            if (most_runs > kJagwMaxRuns || win_slots > kJagwMaxSlots) ok = false;
+        }
         if (!ok) {                          // some group's window does not fit: no windows for this block
             want_win = false; win_slots = 0; win_runs.clear(); win_ptr.clear();
             if (!jag_auto) { jag = false; std::fill(group_is_sell.begin(), group_is_sell.end(), 0); goto select_groups; }
@@ -1141,30 +1152,35 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->win_slots = win_slots;
         for (uint32_t g = 0; g < ngroups; ++g) c->win_max_runs = std::max(c->win_max_runs, win_ptr[g + 1] - win_ptr[g]);
         if (!perm.empty()) c->sell_perm = dev_upload(perm.data(), perm.size());
-        // SellDev::lane_info: row in the group + its length per lane, in the order the lanes work (perm or natural)
-        {
-            std::vector<unsigned short> li((size_t)ngroups * kGroupRows, 0);
-            std::vector<char> too_long((size_t)plan_threads(), 0);
-            parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int part) {
-                for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g)
-                    for (uint32_t t = 0; t < kGroupRows; ++t) {
-                        const uint32_t in_group = perm.empty() ? t : perm[(size_t)g * kGroupRows + t], r = g * kGroupRows + in_group;
-                        const uint32_t n = (r < nrows && group_is_sell[g]) ? diag->ptr[r + 1] - diag->ptr[r] : 0u;
-                        if (n > 255u) too_long[(size_t)part] = 1;
-                        li[(size_t)g * kGroupRows + t] = (unsigned short)(in_group | (n << 8));
-                    }
-            });
-            bool ok = true;
-            for (char b : too_long) ok = ok && !b;
-            if (ok) {
-                c->lane_info = dev_upload(li.data(), li.size());
-                c->matrix_bytes += 2ull * li.size();
-                c->device_matrix_bytes += 2ull * li.size();
-            }
-            if (const char *v = plan_tok("jagw")) c->jagw_fast = atoi(v) != 0;
-        }
         c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
         c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
+    }
+    if (jag && sell_entries > 0) {
+    // (with or without a window: the three-trip products of bicg_jagw.hip read one word per lane instead of two row pointers)
+    // SellDev::lane_info: row in the group + its length per lane, in the order the lanes work (perm or natural)
+    {
+        std::vector<unsigned short> li((size_t)ngroups * kGroupRows, 0);
+        std::vector<char> too_long((size_t)plan_threads(), 0);
+        parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int part) {
+            for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g)
+                for (uint32_t t = 0; t < kGroupRows; ++t) {
+                    const uint32_t in_group = perm.empty() ? t : perm[(size_t)g * kGroupRows + t], r = g * kGroupRows + in_group;
+                    const uint32_t n = (r < nrows && group_is_sell[g]) ? diag->ptr[r + 1] - diag->ptr[r] : 0u;
+                    if (n > 255u) too_long[(size_t)part] = 1;
+                    li[(size_t)g * kGroupRows + t] = (unsigned short)(in_group | (n << 8));
+                }
+        });
+        bool ok = true;
+        for (char b : too_long) ok = ok && !b;
+        if (ok) {
+            c->lane_info = dev_upload(li.data(), li.size());
+            c->matrix_bytes += 2ull * li.size();
+            c->device_matrix_bytes += 2ull * li.size();
+            // (one rank: every product goes through the three-trip kernels, which do not read the row pointers)
+            if (P == 1 && c->matrix_bytes > 4ull * (nrows + 1)) c->matrix_bytes -= 4ull * (nrows + 1);
+        }
+        if (const char *v = plan_tok("jagw")) c->jagw_fast = atoi(v) != 0;
+    }
     }
     c->s_base = dev_upload(slice_base.data(), slice_base.size());
     c->s_len = dev_upload(slice_len.data(), slice_len.size());

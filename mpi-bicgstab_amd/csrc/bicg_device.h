@@ -318,6 +318,8 @@ enum SliceKind { kSliceGeneral = 0, kSliceUniform = 1, kSliceConstant = 2, kSlic
 // the registers it took, 45 -> 56 us on Transport)
 enum SellLayout { LAY_PAD32 = 0, LAY_PAD16 = 1, LAY_JAG32 = 2, LAY_JAG16 = 3, LAY_JAGW = 4, LAY_PAD32C = 6, LAY_PAD16C = 7 };
 constexpr uint32_t kWinMaxSlots = 4096;      // 32 KB of LDS per workgroup: 4 workgroups per CU
+constexpr uint32_t kJagwMaxRuns = 64;        // k_spmv_jagw: run descriptors one wavefront holds (lane r = run r) ...
+constexpr uint32_t kJagwMaxSlots = 2048;     // ... and window values it stages (8 per thread)
 
 // Peer-to-peer halo exchange folded into the sliced-ELL SpMV launch: the first `npush` workgroups
 // store this rank's send list into the landing rings of the ranks that need it, the others
@@ -490,6 +492,12 @@ struct SpmmArgs {
 };
 
 
+// which product kernels have been launched since the last reset (bicg_product_kernels: tests and bench.py assert on the kernel
+// a matrix gets, not only on the plan's flags)
+enum ProductKernel : unsigned { PK_SELL_PAD = 1, PK_SELL_JAG = 2, PK_SELL_WINLOOP = 4, PK_JAGW = 8, PK_STENCIL = 16, PK_CSR = 32, PK_ROWS = 64,
+                                PK_SELL_EPI = 128, PK_SELL_FW = 256, PK_JAGD = 512 };
+extern unsigned g_product_kernels;
+
 // ---- launch wrappers (bicg_kernels.hip) ----
 // Both return false when there was nothing to launch. e0/e1 (optional): start/stop events bound to
 // this one kernel (hipExtLaunchKernelGGL) -- the per-kernel durations bench.py's roofline uses.
@@ -502,6 +510,9 @@ bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t
 // the ragged-rows product with three dependent trips per group (bicg_jagw.hip); jagw_fast_ok: this launch qualifies
 bool jagw_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo);
 bool launch_spmv_jagw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// ... and its form for jagged slices WITHOUT a window (x gathered through the caches: 16-bit offsets or 32-bit columns)
+bool jagd_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo);
+bool launch_spmv_jagd(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void preload_jagw_kernels();
 unsigned stencil_grid(const StencilDev &st);
 bool launch_spmv_stencil(const SpmvArgs &a, int ndot, int epi, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);

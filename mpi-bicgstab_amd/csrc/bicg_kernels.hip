@@ -446,9 +446,12 @@ static bool launch_spmv_rows(const SpmvArgs &a, int ndot, bool with_offd, hipStr
     return true;
 }
 
+unsigned g_product_kernels = 0;
+
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.nlist == 0) return false;
+    g_product_kernels |= a.rowsplit ? PK_ROWS : PK_CSR;
     if (a.rowsplit) return launch_spmv_rows(a, ndot, with_offd, st, e0, e1);
     if (with_offd) {
         if (ndot == 0) launch_spmv_var<0, true>(a, st, e0, e1); else if (ndot == 1) launch_spmv_var<1, true>(a, st, e0, e1);
@@ -1389,10 +1392,20 @@ void preload_kernels(const SellDev &d, bool sell)
 #if PART_IS(0)
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
 {
+    if (a.nlist) {
+        const int lay = sell_layout(a.sell);
+        g_product_kernels |= lay == LAY_JAGW ? (jagw_fast_ok(a, with_offd, fused_halo) ? 0u : (unsigned)PK_SELL_WINLOOP)
+                             : (lay == LAY_JAG32 || lay == LAY_JAG16) ? (jagd_fast_ok(a, with_offd, fused_halo) ? 0u : (unsigned)PK_SELL_JAG)
+                             : (unsigned)PK_SELL_PAD;
+    }
     switch (sell_layout(a.sell)) {
     case LAY_PAD16: return launch_spmv_sell_pad16(a, ndot, with_offd, st, e0, e1, fused_halo);
-    case LAY_JAG32: return launch_spmv_sell_jag32(a, ndot, with_offd, st, e0, e1, fused_halo);
-    case LAY_JAG16: return launch_spmv_sell_jag16(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAG32:
+        if (jagd_fast_ok(a, with_offd, fused_halo)) return launch_spmv_jagd(a, ndot, st, e0, e1);
+        return launch_spmv_sell_jag32(a, ndot, with_offd, st, e0, e1, fused_halo);
+    case LAY_JAG16:
+        if (jagd_fast_ok(a, with_offd, fused_halo)) return launch_spmv_jagd(a, ndot, st, e0, e1);
+        return launch_spmv_sell_jag16(a, ndot, with_offd, st, e0, e1, fused_halo);
     case LAY_JAGW:
         if (jagw_fast_ok(a, with_offd, fused_halo)) return launch_spmv_jagw(a, ndot, st, e0, e1);
         return launch_spmv_sell_jagw(a, ndot, with_offd, st, e0, e1, fused_halo);
@@ -1404,6 +1417,7 @@ bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t s
 
 bool launch_spmv_sell_epi(const SpmvArgs &a, int epi, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1, bool fused_halo)
 {
+    if (a.nlist) g_product_kernels |= PK_SELL_EPI;
     switch (sell_layout(a.sell)) {
     case LAY_PAD16: return launch_spmv_sell_epi_pad16(a, epi, with_offd, st, e0, e1, fused_halo);
     case LAY_JAG32: return launch_spmv_sell_epi_jag32(a, epi, with_offd, st, e0, e1, fused_halo);

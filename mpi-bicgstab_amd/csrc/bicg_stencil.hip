@@ -329,6 +329,7 @@ static bool stencil_launch_lines(const SpmvArgs &a, int ndot, int epi, hipStream
 bool launch_spmv_stencil(const SpmvArgs &a, int ndot, int epi, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (!a.sell.st.on || a.has_shift) return false;      // (shifted products: the slice-by-slice loop)
+    if (a.sell.st.lines == 2 || a.sell.st.lines == 4) g_product_kernels |= PK_STENCIL;
     switch (a.sell.st.lines) {
     case 2: return stencil_launch_lines<2>(a, ndot, epi, st, e0, e1);
     case 4: return stencil_launch_lines<4>(a, ndot, epi, st, e0, e1);

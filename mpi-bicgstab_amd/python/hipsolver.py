@@ -60,7 +60,7 @@ EXPORTS = [
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_product_kernels", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_has_experiments", "bicg_switch_value", "bicg_switch_unknown", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
 ]
 
@@ -111,6 +111,7 @@ def lib():
         for fn in (L.bicg_uniform_entries, L.bicg_constant_entries, L.bicg_masked_rows, L.bicg_spmv_matrix_bytes):
             fn.argtypes = [C.c_void_p]; fn.restype = C.c_ulonglong
         L.bicg_plan_collisions.argtypes = [C.c_void_p]; L.bicg_plan_collisions.restype = C.c_uint
+        L.bicg_product_kernels.argtypes = [C.c_int]; L.bicg_product_kernels.restype = C.c_uint
         L.bicg_last_shifted_persistent.argtypes = [C.c_void_p]
         L.bicg_last_spmm_windowed.argtypes = [C.c_void_p]
         L.bicg_shifted_residuals.argtypes = [C.c_void_p, _dp, _dp, _dp, C.c_int, _dp]
@@ -480,6 +481,16 @@ class Context:
         lib().bicg_plan_info(self.h, out)
         return dict(zip(("rows", "nnz_diag", "nnz_offd", "halo", "row_blocks", "boundary_blocks", "sell_rows",
                          "sell_padding"), list(out)))
+
+
+PRODUCT_KERNELS = {"sell_padded": 1, "sell_jagged": 2, "sell_window_loop": 4, "jagw": 8, "stencil": 16, "csr": 32, "rows": 64, "sell_epilogue": 128,
+                   "sell_window_fused": 256, "jagd": 512}
+
+
+def product_kernels(reset: bool = True):
+    """names of the product kernels launched since the last reset (bicg_product_kernels)"""
+    m = int(lib().bicg_product_kernels(1 if reset else 0))
+    return sorted(k for k, v in PRODUCT_KERNELS.items() if m & v)
 
 
 STREAM_KINDS = {"copy": 0, "triad": 1, "read8": 2, "read16": 3}

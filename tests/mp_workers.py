@@ -292,17 +292,23 @@ def fullsize_worker(rank, world, port, kind, outdir):
         counts, displs = synth.partition(n, world)
         lo, nl = int(displs[rank]), int(counts[rank])
         grid = int(ref["grid"]) if "grid" in ref else 0
+        mesh_kind = str(ref["mesh_numbering"]) if "mesh_numbering" in ref else ""
         if grid:      # BASELINE.json configs[3] family: z-slabs of the 7-point Laplacian (64 planes per GPU at 512^3 / 8 GPUs)
             slab = synth.stencil7(grid, synth.LAPLACE_WEIGHTS, rows=(lo, lo + nl))
+        elif mesh_kind:   # the unstructured FEM matrix (the parent left the assembled matrix in str(ref["mesh_cache"]))
+            from mpi_bicgstab_amd import mesh
+            slab = mesh.fem_unstructured(int(ref["mesh_m"]), mesh_kind, float(ref["scale_decades"]), rows=(lo, lo + nl), cache_dir=str(ref["mesh_cache"]))
         else:
             slab = synth.transport_like(n=n, rows=(lo, lo + nl), scale_decades=float(ref["scale_decades"]))
         diag, offd = synth.split_row_slab(slab, lo)
         ctx = H.Context(H.HostBlocks(diag, offd, n, counts, displs))
         info, flags = ctx.plan_info(), ctx.flags()
         assert info["halo"] > 0 and info["boundary_blocks"] > 0
-        assert info["sell_rows"] == nl and flags["all_sell"] and (flags["col16"] or grid)
+        assert info["sell_rows"] == nl and flags["all_sell"] and (flags["col16"] or grid or mesh_kind == "random")
         assert flags["p2p"] == p2p
-        if p2p:
+        if mesh_kind:
+            assert flags["jagged"] and info["sell_padding"] == 0, (flags, info)       # ragged rows across ranks: jagged slices, no padding
+        if p2p and not mesh_kind:
             assert flags["ll_fused"], "banded slab: the halo exchange must be folded into the SpMV launch"
         if grid:
             # a z-slab of the grid: the planes without halo entries go to the plane-marching product (csrc/bicg_stencil.hip), the two

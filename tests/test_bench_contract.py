@@ -39,7 +39,7 @@ def test_bench_json_keys_are_the_contract():
     assert "6290.0" not in src and "rccl_leg" in src
     for key in ("laplace7_512_ca", "transport_rank_of_8", "plan_seconds", "generate_seconds"):
         assert key in src, key
-    for wl in ("banded", "fem_like", "laplace7"):
+    for wl in ("banded", "fem_like", "laplace7", "mesh"):
         assert f'"{wl}"' in src
     assert "--half-bandwidth" in src and "--no-extras" in src and "--no-traffic" in src
     for key in ("value", "unit", "cores", "kind", "sample"):

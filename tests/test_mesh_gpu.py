@@ -1,0 +1,74 @@
+"""`-m gpu`: the unstructured FEM matrix (mpi_bicgstab_amd.mesh, 1 601 613 rows, 26.0 M non-zeros -- the stand-in for
+Transport.mtx, reference README.md:32-42) in its three numberings on one rank: which product kernel each gets (asserted), y = A x
+bit for bit against the oracle (reference src/matrix.c:498-516), the first 12 iterations of the four solvers against the oracle's
+alpha / omega / beta / (r,r) (src/solver.c:35-576)."""
+import numpy as np
+import pytest
+
+import oracle_lib as O
+from mpi_bicgstab_amd import hipsolver as H
+from mpi_bicgstab_amd import mesh
+
+pytestmark = pytest.mark.gpu
+
+K_FIX = 12
+# the kernel a numbering must get (hipsolver.product_kernels): generator order -- a few long runs of columns per 256-row group -- the
+# three-trip product with the x window in LDS; reverse Cuthill-McKee (up to 170 short runs per group) and the random permutation the
+# three-trip product that gathers x through the caches (16-bit offsets / 32-bit columns)
+EXPECT = {"generator": ("jagw", dict(window=True, col16=True)), "rcm": ("jagd", dict(window=False, col16=True)),
+          "random": ("jagd", dict(window=False, col16=False))}
+
+
+@pytest.fixture(scope="module", params=["generator", "rcm", "random"])
+def case(request, tmp_path_factory):
+    H.lib().bicg_comm_init_single(0)
+    cache = tmp_path_factory.getbasetemp() / "mesh_cache"
+    cache.mkdir(exist_ok=True)
+    A = mesh.fem_unstructured(117, request.param, scale_decades=2.0, cache_dir=str(cache))
+    ctx = H.Context(H.single_rank_blocks(A))
+    yield request.param, A, A.to_coo(), ctx
+    ctx.close()
+
+
+def test_kernel_and_plan(case):
+    kind, A, _, ctx = case
+    assert A.rows == 117 ** 3 and 25_500_000 < A.nnz < 26_500_000
+    fl, info = ctx.flags(), ctx.plan_info()
+    kernel, want = EXPECT[kind]
+    assert fl["jagged"] and fl["all_sell"] and info["sell_rows"] == A.rows and info["sell_padding"] == 0, (fl, info)
+    for k, v in want.items():
+        assert fl[k] == v, (kind, k, fl)
+    H.product_kernels()
+    ctx.spmv_bench(3)
+    assert H.product_kernels() == [kernel], kind
+    # the stored layout: 8-byte values + 2-byte offsets or slots (4-byte columns for the random numbering), no padding
+    per_nnz = ctx.spmv_matrix_bytes() / A.nnz
+    assert per_nnz < (12.5 if kind == "random" else 10.6), per_nnz
+
+
+def test_spmv_bitexact_and_linear(case):
+    kind, A, (row, col, val), ctx = case
+    rng = np.random.default_rng(5)
+    x, z = rng.standard_normal(A.rows), rng.standard_normal(A.rows)
+    y = ctx.spmv(x)
+    assert np.array_equal(y, O.spmv(A.rows, row, col, val, x)), kind          # 1.6 M ragged rows, bit for bit
+    lhs = ctx.spmv(2.5 * x - 0.75 * z)
+    rhs = 2.5 * y - 0.75 * ctx.spmv(z)
+    scale = np.abs(A.val).max() * 30 * (np.abs(x).max() + np.abs(z).max())
+    assert np.abs(lhs - rhs).max() <= 1e-13 * scale
+
+
+def test_first_iterations_against_the_oracle(case):
+    kind, A, (row, col, val), ctx = case
+    b = ctx.spmv(np.ones(A.rows))
+    assert np.array_equal(b, O.spmv(A.rows, row, col, val, np.ones(A.rows)))
+    for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
+        H.product_kernels()
+        got = ctx.solve(method, b, tol=0.0, max_iter=K_FIX, krr=5, nrr=1, check_every=K_FIX)
+        orc = O.solve(method, A.rows, row, col, val, b, tol=0.0, max_iter=K_FIX, krr=5, nrr=1)
+        assert got["k"] == orc["k"] == K_FIX
+        assert EXPECT[kind][0] in H.product_kernels(), (kind, method)
+        tr = ctx.trace(K_FIX)
+        for key in ("alpha", "omega", "beta", "dotr"):
+            np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=f"{kind} {method} {key}")
+        assert np.abs(got["x"] - orc["x"]).max() <= 1e-8 * np.abs(orc["x"]).max(), (kind, method)

@@ -98,6 +98,36 @@ def test_fullsize_partition_against_oracle(matrix, world, kind):
         assert len(glob.glob(os.path.join(td, "ok*"))) == world
 
 
+@pytest.mark.parametrize("numbering,world,kind", [("rcm", 8, "host-p2p"), ("rcm", 8, "host"), ("random", 4, "host-p2p")])
+def test_unstructured_mesh_partition_against_oracle(numbering, world, kind, tmp_path_factory):
+    """The unstructured FEM matrix (mpi_bicgstab_amd.mesh: 1 601 613 ragged rows, the stand-in for Transport.mtx) in the reference's
+    row partition (src/matrix.c:295-308) across ranks sharing the GPU: RCM numbering at 8 ranks through both transports (halo = the
+    neighbouring level sets), the random permutation at 4 (every rank needs nearly all of x: the halo IS the vector). Distributed
+    SpMV bit-exact against the oracle at the same P (src/matrix.c:428-441), first 12 iterations of the four solvers against its
+    alpha / omega / beta / (r,r)."""
+    from mpi_bicgstab_amd import mesh
+    cache = tmp_path_factory.getbasetemp() / "mesh_cache"
+    cache.mkdir(exist_ok=True)
+    A = mesh.fem_unstructured(117, numbering, scale_decades=SCALE_DECADES, cache_dir=str(cache))
+    row, col, val = A.to_coo()
+    out = dict(n=A.rows, k_fix=K_FIX, scale_decades=SCALE_DECADES, mesh_numbering=numbering, mesh_m=117, mesh_cache=str(cache))
+    out["x_in"] = np.random.default_rng(99).standard_normal(A.rows)
+    out["y"] = O.spmv(A.rows, row, col, val, out["x_in"], nranks=world)
+    out["b"] = O.spmv(A.rows, row, col, val, np.ones(A.rows), nranks=world)
+    for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
+        orc = O.solve(method, A.rows, row, col, val, out["b"], nranks=world, tol=0.0, max_iter=K_FIX, krr=5, nrr=1)
+        assert orc["k"] == K_FIX
+        for key in ("alpha", "omega", "beta", "dotr", "x"):
+            out[f"{method}_{key}"] = orc[key]
+    del A, row, col, val
+    with tempfile.TemporaryDirectory() as td:
+        np.savez(os.path.join(td, "oracle.npz"), **out)
+        mp.start_processes(W.fullsize_worker, args=(world, _free_port(), kind, td), nprocs=world, join=True, start_method="spawn")
+        fails = glob.glob(os.path.join(td, "fail*"))
+        assert not fails, open(fails[0]).read()
+        assert len(glob.glob(os.path.join(td, "ok*"))) == world
+
+
 def test_laplace7_slabs_8_ranks_ca_bicgstab():
     """BASELINE.json configs[3] (7-point Laplacian 512^3 over 8 GPUs = 64 planes of 512^2 each, CA-BiCGStab) at 128^3:
     8 ranks x 16-plane z-slabs in the reference's row partition, peer-to-peer data path (halo = one plane per neighbour,
