@@ -254,6 +254,14 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // Up to four launches share one dot group (one partial slot per workgroup, numbered in launch
     // order): {sliced-ELL groups, CSR row blocks} x {interior, halo-touching}.
     a.groups_per_wg = ndot > 0 ? c->sell_gpw_dots : c->sell_gpw;
+    // Ranks SHARING a GPU (tests; bicg_ctx::wg_cap): a launch with the halo exchange inside may consist of workgroups that ALL wait
+    // for another rank's values (a numbering without locality: every 256-row group touches the halo). The first rank's launch would
+    // fill the device with waiting workgroups and keep the launches that hold the awaited pushes out until the time-out; every
+    // rank's launch, pushing workgroups included, has to fit beside the others'.
+    if (c->wg_cap && c->p2p && c->ll_fused) {
+        const unsigned room = c->wg_cap > 80u ? c->wg_cap - 64u : 16u, ng = c->ng_int + c->ng_bnd;
+        a.groups_per_wg = std::max<int>(a.groups_per_wg, (int)((ng + room - 1) / room));
+    }
     a.xcd_map = c->sell_xcd;
     // Consecutive products of a solve run over the matrix in alternating directions (BICG_SELL_ALT=0: always forward): matrix +
     // vectors of a Transport-sized system exceed the 256 MiB Infinity Cache by a quarter, so a product that starts where the

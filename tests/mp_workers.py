@@ -331,14 +331,15 @@ def fullsize_worker(rank, world, port, kind, outdir):
         b = ctx.spmv(np.ones(nl))
         assert np.array_equal(b, ref["b"][lo:lo + nl])
         methods = [str(m) for m in ref["methods"]] if "methods" in ref else ["bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"]
+        rtol = float(ref["rtol"]) if "rtol" in ref else 1e-7          # (the mesh matrix: see tests/test_mesh_gpu.py)
         for method in methods:
             got = ctx.solve(method, b, tol=0.0, max_iter=k_fix, krr=5, nrr=1, check_every=k_fix)
             assert got["k"] == k_fix, (method, got["k"])
             tr = ctx.trace(k_fix)
             for key in ("alpha", "omega", "beta", "dotr"):
-                np.testing.assert_allclose(tr[key], ref[f"{method}_{key}"], rtol=1e-7, err_msg=f"{method} {key}")
+                np.testing.assert_allclose(tr[key], ref[f"{method}_{key}"], rtol=rtol, err_msg=f"{method} {key}")
             xo = ref[f"{method}_x"]
-            assert np.abs(got["x"] - xo[lo:lo + nl]).max() <= 1e-8 * np.abs(xo).max(), method
+            assert np.abs(got["x"] - xo[lo:lo + nl]).max() <= 0.1 * rtol * np.abs(xo).max(), method
         # ... and all the way to convergence (oracle run at the same rank count, tolerance in ref): the iteration count
         # within the spread the dot-sum association causes, the manufactured solution x = 1 reached
         for method in ([str(m) for m in ref["converge_methods"]] if "converge_methods" in ref else []):

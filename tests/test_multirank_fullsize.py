@@ -98,25 +98,29 @@ def test_fullsize_partition_against_oracle(matrix, world, kind):
         assert len(glob.glob(os.path.join(td, "ok*"))) == world
 
 
-@pytest.mark.parametrize("numbering,world,kind", [("rcm", 8, "host-p2p"), ("rcm", 8, "host"), ("random", 4, "host-p2p")])
+@pytest.mark.parametrize("numbering,world,kind", [("rcm", 8, "host-p2p"), ("rcm", 8, "host"), ("random", 8, "host-p2p"), ("random", 8, "host"),
+                                                  ("generator", 8, "host-p2p")])
 def test_unstructured_mesh_partition_against_oracle(numbering, world, kind, tmp_path_factory):
     """The unstructured FEM matrix (mpi_bicgstab_amd.mesh: 1 601 613 ragged rows, the stand-in for Transport.mtx) in the reference's
     row partition (src/matrix.c:295-308) across ranks sharing the GPU: RCM numbering at 8 ranks through both transports (halo = the
-    neighbouring level sets), the random permutation at 4 (every rank needs nearly all of x: the halo IS the vector). Distributed
-    SpMV bit-exact against the oracle at the same P (src/matrix.c:428-441), first 12 iterations of the four solvers against its
+    neighbouring level sets), the random permutation likewise (every rank needs nearly all of x: the halo IS the vector). Distributed
+    SpMV bit-exact against the oracle at the same P (src/matrix.c:428-441), first 8 iterations of the four solvers against its
     alpha / omega / beta / (r,r)."""
     from mpi_bicgstab_amd import mesh
     cache = tmp_path_factory.getbasetemp() / "mesh_cache"
     cache.mkdir(exist_ok=True)
     A = mesh.fem_unstructured(117, numbering, scale_decades=SCALE_DECADES, cache_dir=str(cache))
     row, col, val = A.to_coo()
-    out = dict(n=A.rows, k_fix=K_FIX, scale_decades=SCALE_DECADES, mesh_numbering=numbering, mesh_m=117, mesh_cache=str(cache))
+    # (8 iterations at rtol 1e-6: the reference's own scalars spread by a factor of ten per iteration on this matrix when only the
+    # association of the dot sums changes, tests/test_mesh_gpu.py)
+    k_fix = 8
+    out = dict(n=A.rows, k_fix=k_fix, rtol=1e-6, scale_decades=SCALE_DECADES, mesh_numbering=numbering, mesh_m=117, mesh_cache=str(cache))
     out["x_in"] = np.random.default_rng(99).standard_normal(A.rows)
     out["y"] = O.spmv(A.rows, row, col, val, out["x_in"], nranks=world)
     out["b"] = O.spmv(A.rows, row, col, val, np.ones(A.rows), nranks=world)
     for method in ("bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"):
-        orc = O.solve(method, A.rows, row, col, val, out["b"], nranks=world, tol=0.0, max_iter=K_FIX, krr=5, nrr=1)
-        assert orc["k"] == K_FIX
+        orc = O.solve(method, A.rows, row, col, val, out["b"], nranks=world, tol=0.0, max_iter=k_fix, krr=5, nrr=1)
+        assert orc["k"] == k_fix
         for key in ("alpha", "omega", "beta", "dotr", "x"):
             out[f"{method}_{key}"] = orc[key]
     del A, row, col, val
