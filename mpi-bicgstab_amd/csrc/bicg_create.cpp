@@ -160,7 +160,15 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
             if (wgs > most) { most = wgs; lines = cd[0]; zl = cd[1]; }
         }
         if (const char *v = plan_tok("lines")) { const uint32_t r = (uint32_t)atoi(v); if ((r == 2 || r == 4) && ny % r == 0) lines = r; }
-        if (const char *v = plan_tok("planes")) { const int z = atoi(v); if (z >= 1) zl = (uint32_t)z; }
+        if (const char *v = plan_tok("planes")) {
+            // every workgroup of the product publishes one row of partial sums: the tiling must not need more rows than the table
+            // has (ctx_state: max(256-row groups, kMaxGrid) + 64) -- thin grids with few planes per tile would
+            const int z = atoi(v);
+            const uint64_t wgs = z >= 1 ? (uint64_t)nxs * ((ny + 4 * lines - 1) / (4 * lines)) * ((nz + (uint32_t)z - 1) / (uint32_t)z) : 0;
+            const uint64_t room = std::max<uint64_t>(((uint64_t)nrows + kGroupRows - 1) / kGroupRows, (uint64_t)kMaxGrid);
+            if (z >= 1 && wgs <= room) zl = (uint32_t)z;
+            else if (c->rank == 0) fprintf(stderr, "bicgstab_hip: BICG_PLAN planes=%s ignored (%llu workgroups, room for %llu partial-sum rows)\n", v, (unsigned long long)wgs, (unsigned long long)room);
+        }
     }
     c->st_code = dev_upload(code.data(), code.size());
     c->st_tab = dev_upload(tab.data(), tab.size());

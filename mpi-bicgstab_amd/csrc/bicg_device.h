@@ -236,7 +236,7 @@ struct StencilDev {
     uint32_t nxs, ny, nz;           // x segments (sy / 64), lines per plane (sz / sy), planes (rows / sz)
     uint32_t z_lo, z_hi;            // the planes this product takes (one rank: all; across ranks: the planes without halo entries)
     uint32_t zl;                    // planes per wavefront tile
-    uint32_t lines;                 // lines per wavefront (2, 4 or 8)
+    uint32_t lines;                 // lines per wavefront (2 or 4: the instantiations of k_spmv_stencil)
     uint32_t nmc;                   // x segments with masked slices
     int xcd;                        // XCD-contiguous order of the tiles (measurement knob BICG_STENCIL_XCD)
     int nt_store;                   // y (and the epilogue's vectors) stored non-temporally (measurement knob BICG_STENCIL_NT)
@@ -489,6 +489,7 @@ struct SpmmArgs {
     int nvec;
     FusedWindow cl;
     unsigned wslots;        // LDS doubles per vector
+    int dbg;                // BICG_TEST="spmm-skip=n" (measurement only, results are wrong): 1 no staging loads, 2 no products, 4 no row heads
 };
 
 

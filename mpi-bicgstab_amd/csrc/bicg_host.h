@@ -180,7 +180,7 @@ struct bicg_ctx {
     bool f1_done = false;        // phase 1 of the NEXT iteration has already run in the previous launch's epilogue
     // persistent pipelined iteration (bicg_persist.hip, struct PersistArgs): plan + LL buffers; persist.nwg == 0: not available
     PersistArgs persist{};
-    bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0/1 overrides
+    bool persist_on = false;     // use it for pipe_bicgstab (every rank agrees); BICG_PERSIST=0 (or off) keeps the multi-launch iteration
     bool persist_plain = true;   // ... and for plain BiCGStab (BICG_PERSIST_PLAIN=0: the five-launch iteration)
     bool last_shifted_persist = false;   // the last shifted solve ran as persistent launches (bicg_result.flags of bicg_solve_shifted)
     unsigned persist_seq = 0;    // LL tags used so far (dot tables)

@@ -1688,7 +1688,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
         return (unsigned)((int)tid + d + bias);               // padding: distance 0, the row's own column
     };
     const i16x4 *const q16 = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + lane);
-    if (WIN) {
+    if (a.dbg & 4) {
+#pragma unroll
+        for (int e = 0; e < K; ++e) { hs[e] = tid; hv[e] = 1.0; hon |= 1u << e; }
+    } else if (WIN) {
 #pragma unroll
         for (int e = 0; e < K; ++e) {
             hs[e] = 0u; hv[e] = 0.0;
@@ -1749,7 +1752,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
 #pragma unroll
             for (int j = 0; j < JB; ++j) {
 #pragma unroll
-                for (int v = 0; v < NV; ++v) t[j][v] = (c[j] >= 0 && v < nv) ? a.xs[(size_t)(v0 + v) * a.vstride + (unsigned)c[j]] : 0.0;
+                for (int v = 0; v < NV; ++v) t[j][v] = (c[j] >= 0 && v < nv && !(a.dbg & 1)) ? a.xs[(size_t)(v0 + v) * a.vstride + (unsigned)c[j]] : 0.0;
             }
 #pragma unroll
             for (int j = 0; j < JB; ++j) {
@@ -1788,10 +1791,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
                 if ((e & 1) == 1) __builtin_amdgcn_sched_barrier(0);
             }
         };
+        if (!(a.dbg & 2)) {
         half(0);
         if (len > (uint32_t)(K / 2)) half(K / 2);
+        }
         pos = pos_tail;
-        for (uint32_t k0 = K; k0 < len; k0 += U) {
+        for (uint32_t k0 = K; k0 < len && !(a.dbg & 2); k0 += U) {
             double val[U];
             unsigned sl[U];
             bool on[U];

@@ -36,6 +36,9 @@ inline const char *knob_tok(const char *set, const char *name)
             if (lv > sizeof(buf[0]) - 1) lv = sizeof(buf[0]) - 1;
             memcpy(out, s + ln + 1, lv);
             out[lv] = 0;
+            // switches may be spelled out: on / true / yes read as 1, off / false / no as 0 (callers use atoi)
+            for (const char *w : {"on", "true", "yes"}) if (!strcmp(out, w)) { out[0] = '1'; out[1] = 0; }
+            for (const char *w : {"off", "false", "no"}) if (!strcmp(out, w)) { out[0] = '0'; out[1] = 0; }
             return out;
         }
         s = e;
@@ -44,12 +47,25 @@ inline const char *knob_tok(const char *set, const char *name)
 }
 // The names each list knows. A token that is none of them is a typing error that would otherwise
 // pass silently -- "stencil=O" selects nothing --: knob_unknown copies the first such token to out and returns how many there are.
+// A known name with a value that cannot be read counts too: values are integers or on / off / true / false / yes / no ("layout":
+// jag or pad), so "lines=2;planes=8" (one token whose value is "2;planes=8") and "stencil = 0" (three tokens) are reported.
+inline bool knob_value_ok(const char *name, size_t name_len, const char *v, size_t lv)
+{
+    auto is = [&](const char *w) { return strlen(w) == lv && !strncmp(v, w, lv); };
+    if (name_len == 6 && !strncmp(name, "layout", 6)) return is("jag") || is("pad");
+    if (is("on") || is("off") || is("true") || is("false") || is("yes") || is("no")) return true;
+    if (lv == 0) return false;
+    size_t i = (v[0] == '-' || v[0] == '+') ? 1 : 0;
+    if (i == lv) return false;
+    for (; i < lv; ++i) if (v[i] < '0' || v[i] > '9') return false;
+    return true;
+}
 inline const char *const *knob_names(const char *set)
 {
     static const char *const plan[] = {"stencil", "lines", "planes", "ca-fuse", "layout", "window", "col16", "uniform", "constant", "masked",
                                        "desc", "lists", "jagw", "spmm", "spmm-window", "fuse-pipe", "pipe-probe", nullptr};
-    static const char *const persist[] = {"0", "1", "off", "on", "chunk", "shifted", nullptr};
-    static const char *const test[] = {"force-comm", "spin-ticks", "p2p-fault-after", "plan-collide", nullptr};
+    static const char *const persist[] = {"0", "off", "chunk", "shifted", nullptr};      // (the persistent forms are the default: there is no "on")
+    static const char *const test[] = {"force-comm", "spin-ticks", "p2p-fault-after", "plan-collide", "spmm-skip", nullptr};
     static const char *const none[] = {nullptr};
     return !strcmp(set, "BICG_PLAN") ? plan : !strcmp(set, "BICG_PERSIST") ? persist : !strcmp(set, "BICG_TEST") ? test : none;
 }
@@ -68,6 +84,7 @@ inline int knob_unknown(const char *set, char *out, size_t cap)
         if (e == s) break;
         bool known = false;
         for (int i = 0; names[i]; ++i) known = known || (strlen(names[i]) == (size_t)(q - s) && !strncmp(names[i], s, (size_t)(q - s)));
+        if (known && q < e && !knob_value_ok(s, (size_t)(q - s), q + 1, (size_t)(e - q - 1))) known = false;
         if (!known && n++ == 0 && out && cap) { const size_t l = (size_t)(e - s) < cap - 1 ? (size_t)(e - s) : cap - 1; memcpy(out, s, l); out[l] = 0; }
         s = e;
     }

@@ -321,6 +321,13 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
     const int persist_shifted_env = knob_tok("BICG_PERSIST", "shifted") ? atoi(knob_tok("BICG_PERSIST", "shifted")) : 1;
     bool persist = (mode == SH_PIPE || mode == SH_LOP) && c->persist_on && c->persist.rpt == 1u && nsig <= kPersistMaxShifts && persist_shifted_env != 0 &&
                    !(o.time_kernels & 3) && !c->time_sections;
+    // BICG_DISPLAY_RESIDUAL=1: the progress line the reference prints when it is compiled with -DDISPLAY_RESIDUAL
+    // (src/shifted_solver.c:151-155, 325-329, 500-504, 672-676, 870-874, 1061-1065: every OUT_ITER iterations the relative
+    // residual and the largest |xi tau| / |1 / (zeta pi)| over the shifts). The host looks at the scalars every out_iter
+    // iterations then (the largest ratio lives in the device's ShiftDev), in the multi-launch form.
+    const char *show_env = getenv("BICG_DISPLAY_RESIDUAL");
+    const bool show = show_env && atoi(show_env) != 0 && o.out_iter > 0;
+    if (show) { o.check_every = o.out_iter; persist = false; }
     c->last_shifted_persist = false;
     while (!c->hS->done && it < o.max_iter) {
         const int persist_chunk_min = knob_tok("BICG_PERSIST", "chunk") ? std::max(1, atoi(knob_tok("BICG_PERSIST", "chunk"))) : kPersistChunk;
@@ -361,6 +368,13 @@ int run_shifted(bicg_ctx *c, int mode, double *x_set_host, double *r_host, const
         sec_mark(c, SEC_STOP);
         fetch_scal(c);
         if (persist && mode == SH_PIPE) persist_account(c);
+        if (show && c->hS->k == it && it % o.out_iter == 0) {       // (a solve that stopped inside the chunk has printed its last line)
+            ShiftDev now;
+            BICG_HIP(hipMemcpy(&now, c->sh_dev, sizeof now, hipMemcpyDeviceToHost));
+            if (c->rank == 0 && !o.quiet)
+                printf("Iteration: %d, Residual: %e, %s: %e\n", it, sqrt(c->hS->dot_r / c->hS->dot_zero), mode == SH_XI ? "Max_Xi" : "Max_Zeta_Pi",
+                       now.max_zeta_pi);
+        }
     }
     c->cur_has_shift = false; c->cur_shift = 0.0;
     const double t1 = now_sec();

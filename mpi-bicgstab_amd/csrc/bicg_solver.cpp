@@ -295,8 +295,15 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 
     auto interior = [&]() {
         a.glist = c->glist_int_identity ? nullptr : c->glist_int; a.nlist = c->ng_int; a.red.slot_base = 0;
-        if (stencil) took(launch_spmv_stencil(a, ndot, epi == 3 ? 1 : 0, c->sc, ev(0), ev(1)));
-        else took(launch_spmv_sell(a, ndot, false, c->sc, ev(0), ev(1)));
+        if (stencil) {
+            // (the plan only selects tilings the kernel is built for, and the epilogue only with ticket reductions: a launch that
+            // is declined here would leave y unwritten and a ticket group waiting for partial sums that never come)
+            if (!launch_spmv_stencil(a, ndot, epi == 3 ? 1 : 0, c->sc, ev(0), ev(1)))
+                die("internal", "the plane-marching product declined a launch its plan had selected (lines per wavefront / reduction mode)");
+            took(true);
+        } else {
+            took(launch_spmv_sell(a, ndot, false, c->sc, ev(0), ev(1)));
+        }
         a.desc = c->desc_int; a.nlist = c->n_int; a.red.slot_base = g_si;
         took(launch_spmv(a, ndot, false, c->sc, ev(0), ev(1)));
     };
@@ -485,6 +492,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
         if (launch_spmm_dir(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the direct kernel could not be launched");
     } else if (c->mm_win) {
         a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
+        if (const char *sv = test_tok("spmm-skip")) a.dbg = atoi(sv);
         if (!c->win_slots) a.cl = c->fw;
         if (launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
     } else {

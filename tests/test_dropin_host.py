@@ -225,6 +225,38 @@ def test_display_error_lines_of_the_reference_on_the_dropin_path(tmp_path, np_):
 
 
 @need
+@pytest.mark.parametrize("np_", [1, 2])
+def test_display_residual_lines_of_the_reference_on_the_dropin_path(tmp_path, np_):
+    """BICG_DISPLAY_RESIDUAL=1: the progress line of the reference's shifted solvers (src/shifted_solver.c:151-155 "Iteration: %d,
+    Residual: %e, Max_Xi: %e", and :325-329, 500-504, 672-676, 870-874, 1061-1065 with Max_Zeta_Pi) from the drop-in build of the
+    reference's own driver test_shifted.c (shifted_pipe_lopbicgstab_nooverlap on 5 shifts, then shifted_lopbicgstab once per
+    shift, src/test_shifted.c:127, 157-166), against the reference compiled with -DDISPLAY_RESIDUAL and OUT_ITER 5
+    (oracle/_ref/test_shifted_ref_res): the same lines at the same iterations, residuals and ratios within 1e-4 (six printed digits
+    of two trajectories that differ in the association of their dot sums), every solve of the driver."""
+    dropin, ref = os.path.join(REF, "test_shifted_dropin"), os.path.join(REF, "test_shifted_ref_res")
+    if not (os.path.exists(dropin) and os.path.exists(ref)):
+        pytest.skip("test_shifted_dropin / test_shifted_ref_res not built")
+    path = str(tmp_path / "shifted.mtx")
+    synth.write_mtx(path, synth.from_offsets(20011, (0, 1, -1, 140, -140, 141, -141), diag_base=4.6, seed=5))
+
+    def run(binary, **env):
+        out = subprocess.run([MPIEXEC, "-n", str(np_), binary, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+        assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
+        lines = re.findall(r"^Iteration: (\d+), Residual: (\S+), (Max_Xi|Max_Zeta_Pi): (\S+)$", out.stdout, flags=re.M)
+        return [(int(k), float(r), name, float(m)) for k, r, name, m in lines], [int(k) for k in re.findall(r"Total iter\s*:\s*(\d+)", out.stdout)]
+
+    want, kw = run(ref)
+    got, kg = run(dropin, BICG_DISPLAY_RESIDUAL="1", BICG_OUT_ITER="5")
+    assert len(want) >= 30 and len(kw) >= 6 and len(kg) == len(kw), (len(want), kw, kg)      # six solves, eight lines each
+    assert all(abs(a - b) <= 1 for a, b in zip(kw, kg)), (kw, kg)
+    assert [(w[0], w[2]) for w in want] == [(g[0], g[2]) for g in got], (want[:10], got[:10])
+    for (k, rw, _, mw), (_, rg, _, mg) in zip(want, got):
+        assert abs(rw - rg) <= 1e-4 * rw and abs(mw - mg) <= 1e-4 * mw, (k, rw, rg, mw, mg)
+    silent = subprocess.run([MPIEXEC, "-n", "1", dropin, path], capture_output=True, text=True, timeout=600)
+    assert "Iteration:" not in silent.stdout                         # off unless asked for, like the reference's default build
+
+
+@need
 def test_section_time_table_of_the_reference_on_the_dropin_path(tmp_path):
     """BICG_SECTION_TIME=2: the reference's DISPLAY_SECTION_TIME table from the drop-in build of main_shifted.c
     (src/shifted_switching_solver.c:884-892: header, one line per iteration -- iteration, systems still running, seed, the two

@@ -476,12 +476,30 @@ def test_switch_variables_as_the_library_reads_them():
     for var in H.SWITCH_VARS:
         assert H.lib().bicg_switch_unknown(var.encode(), buf, 64) == 0, (var, os.environ.get(var), buf.value)
     everything = {k: 1 for k in H.SWITCHES}
+    everything["layout"] = "jag"
     H.switches(**everything)
     for var in H.SWITCH_VARS:
         assert H.lib().bicg_switch_unknown(var.encode(), buf, 64) == 0, (var, os.environ.get(var), buf.value)
     H.switches(**{k: None for k in H.SWITCHES})
     os.environ["BICG_PLAN"] = "stencil=0,stencl=0,no-window"
     assert H.lib().bicg_switch_unknown(b"BICG_PLAN", buf, 64) == 2 and buf.value == b"stencl=0"
+    # ... and so is a known name with a value that cannot be read: values are integers or on / off / true / false / yes / no
+    # (layout: jag / pad); a switch spelled out reads as 1 / 0
+    os.environ["BICG_PLAN"] = "stencil=on,jagw=false,ca-fuse=yes,window=-1,layout=pad"
+    assert H.lib().bicg_switch_unknown(b"BICG_PLAN", buf, 64) == 0, buf.value
+    assert H.switch_value("BICG_PLAN", "stencil") == "1" and H.switch_value("BICG_PLAN", "jagw") == "0" and H.switch_value("BICG_PLAN", "ca-fuse") == "1"
+    for text, n, first in (("lines=2;planes=8", 1, b"lines=2;planes=8"), ("stencil = 0", 2, b"="), ("stencil=O", 1, b"stencil=O"),
+                           ("layout=jagged,planes=", 2, b"layout=jagged"), ("lines=2.5", 1, b"lines=2.5")):
+        os.environ["BICG_PLAN"] = text
+        assert H.lib().bicg_switch_unknown(b"BICG_PLAN", buf, 64) == n and buf.value == first, (text, buf.value)
+    # the persistent forms are the default: BICG_PERSIST knows "0" / "off" and its two valued tokens, nothing that would switch them "on"
+    os.environ["BICG_PERSIST"] = "1"
+    assert H.lib().bicg_switch_unknown(b"BICG_PERSIST", buf, 64) == 1
+    os.environ["BICG_PERSIST"] = "off,chunk=64"
+    assert H.lib().bicg_switch_unknown(b"BICG_PERSIST", buf, 64) == 0
+    manual = open(os.path.join(ROOT, "INTEGRATION.md")).read()
+    assert "`0` (or `off`)" in manual and "BICG_PERSIST=1" not in manual and "BICG_PERSIST=on" not in manual
+    del os.environ["BICG_PERSIST"]
     os.environ["BICG_PLAN"] = "lines=2"
     H.switches(stencil=None, lines=None, planes=None, layout=None, persist_chunk=None)
     assert "BICG_PLAN" not in os.environ and "BICG_PERSIST" not in os.environ
