@@ -150,6 +150,10 @@ int bicg_comm_p2p_active(void);
 void bicg_comm_finalize(void);
 /* 1 when librccl and every entry point the RCCL transport uses resolve (dies with a message otherwise); no device call */
 int bicg_comm_rccl_loadable(void);
+/* Why the last bicg_comm_init_rccl of this process failed: RCCL's result string and, where the library has it, its own last
+ * error text ("" after a success). Returns the text's length. With BICG_COMM_SOFT_FAIL=1 a refused communicator is reported
+ * this way instead of ending the process (bench.py records RCCL's refusal of two ranks on one device verbatim). */
+int bicg_comm_last_error(char *out, int cap);
 /* one-rank RCCL round trip (library load, communicator, all-reduce); 0 = ok. Needs a GPU. */
 int bicg_comm_selftest_rccl(int device);
 int bicg_comm_rank(void);
@@ -368,9 +372,12 @@ unsigned int bicg_product_kernels(int reset);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
  * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST="shifted=0" keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);
-/* 1 when the last bicg_spmm / bicg_shifted_residuals pass on this context ran the windowed kernel (k_spmm_win: the vectors stay
- * shift-major, the x values a 256-row group touches are staged in LDS for up to 16 vectors at a time and X is read once;
- * BICG_PLAN="spmm-window=0" selects the row-major kernel k_spmm_sell, which is also what layouts without cluster or window runs take) */
+/* Which kernel the last bicg_spmm / bicg_shifted_residuals pass on this context ran: 2 the pipelined one (k_spmm_dma,
+ * csrc/bicg_spmm.hip: the x window of the next step copied global -> LDS by the DMA path while the current step multiplies,
+ * persistent workgroups; padded 16-bit layouts whose distances fall into clusters), 1 the windowed one (k_spmm_win: the x values a
+ * 256-row group touches staged in LDS through registers; BICG_PLAN="spmm-window=1" selects it everywhere, and layouts with x-window
+ * runs take it), 0 the row-major kernel k_spmm_sell (BICG_PLAN="spmm-window=0", and layouts without clusters or window runs).
+ * In all three the vectors' columns are bit-identical to bicg_spmv of each vector. */
 int bicg_last_spmm_windowed(bicg_ctx *ctx);
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *ctx);
 

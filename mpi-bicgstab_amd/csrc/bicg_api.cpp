@@ -174,8 +174,9 @@ int bicg_spmm(bicg_ctx *c, const double *x_loc_set, const double *sigma, int nve
         for (int j = 0; j < nv; ++j)
             BICG_HIP(hipMemcpyAsync(c->mm_in + (size_t)j * c->stride, x_loc_set + (size_t)(j0 + j) * n, sizeof(double) * n,
                                     hipMemcpyHostToDevice, c->sc));
+        if (sigma) spmm_stage_sigma(c, nv, sigma + j0);
         BICG_HIP(hipEventRecord(e0, c->sc));
-        spmm_pass(c, nv, sigma ? sigma + j0 : nullptr, false);
+        spmm_pass(c, nv, sigma ? sigma + j0 : nullptr, false, true);
         BICG_HIP(hipEventRecord(e1, c->sc));
         if (!c->mm_win) launch_vectors_from_rows(c->mm_yt, c->stride, nv, c->n_loc, c->mm_in, c->sc);     // result back to shift-major (reuses mm_in)
         const double *ysrc = c->mm_win ? c->mm_yt : c->mm_in;
@@ -283,7 +284,7 @@ unsigned int bicg_product_kernels(int reset)
 }
 unsigned long long bicg_spmv_matrix_bytes(bicg_ctx *c) { return stencil_product(c) ? c->stencil_matrix_bytes : c->matrix_bytes; }
 int bicg_last_shifted_persistent(bicg_ctx *c) { return c->last_shifted_persist ? 1 : 0; }
-int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? 1 : 0; }
+int bicg_last_spmm_windowed(bicg_ctx *c) { return c->mm_win ? (c->mm_dma ? 2 : 1) : 0; }      // 2: the pipelined kernel (bicg_spmm.hip)
 
 unsigned int bicg_ctx_flags(bicg_ctx *c)
 {

@@ -121,7 +121,9 @@ struct RcclApi {
     ncclResult_t (*GroupStart)() = nullptr;
     ncclResult_t (*GroupEnd)() = nullptr;
     const char *(*GetErrorString)(ncclResult_t) = nullptr;
+    const char *(*GetLastError)(ncclComm_t) = nullptr;       // optional (RCCL >= 2.13): the library's own text of what went wrong
 };
+static char g_rccl_error[512] = "";     // why the last ncclCommInitRank of this process failed (bicg_comm_last_error)
 
 static RcclApi &rccl()
 {
@@ -152,6 +154,7 @@ static RcclApi &rccl()
     SYM(GroupEnd, "ncclGroupEnd");
     SYM(GetErrorString, "ncclGetErrorString");
 #undef SYM
+    *(void **)(&api.GetLastError) = dlsym(api.handle, "ncclGetLastError");
     return api;
 }
 
@@ -233,7 +236,11 @@ Comm *make_rccl(int rank, int nranks, const void *id, int device)
     ncclUniqueId uid;
     memcpy(&uid, id, sizeof uid);
     const ncclResult_t r = rccl().CommInitRank(&c->comm, nranks, uid, rank);
+    g_rccl_error[0] = 0;
     if (r != ncclSuccess) {
+        const char *last = rccl().GetLastError ? rccl().GetLastError(nullptr) : nullptr;
+        snprintf(g_rccl_error, sizeof g_rccl_error, "ncclCommInitRank(nranks %d, rank %d, device %d): %s%s%s", nranks, rank, c->device,
+                 rccl().GetErrorString(r), last && last[0] ? " -- " : "", last && last[0] ? last : "");
         // BICG_COMM_SOFT_FAIL=1 (bench.py): report instead of exiting, so that the caller can fall back to
         // another transport collectively
         const char *soft = getenv("BICG_COMM_SOFT_FAIL");
@@ -281,6 +288,11 @@ extern "C" {
 
 int bicg_comm_unique_id(void *id_out) { return rccl_unique_id(id_out); }
 int bicg_comm_rccl_loadable(void) { return rccl_loadable(); }
+int bicg_comm_last_error(char *out, int cap)
+{
+    if (out && cap > 0) { strncpy(out, g_rccl_error, (size_t)cap - 1); out[cap - 1] = 0; }
+    return (int)strlen(g_rccl_error);
+}
 
 int bicg_comm_init_rccl(int rank, int nranks, const void *id, int device)
 {

@@ -233,7 +233,8 @@ struct bicg_ctx {
     bool phantom = false;
     std::vector<double> ph_scratch;
     bool mm_win = false;         // the last SpMM pass ran the windowed kernel (vectors stay shift-major, X staged in LDS)
-    int  mm_win_env = 1;         // BICG_PLAN="spmm-window=0": the row-major kernel
+    int  mm_win_env = 3;         // BICG_PLAN="spmm-window=0": the row-major kernel, 1: k_spmm_win everywhere, 3 (default): k_spmm_dma where the block qualifies
+    bool mm_dma = false;         // the last SpMM pass ran the pipelined kernel (bicg_spmm.hip)
 
     // state of the solve in progress (run_begin / run_iterate / run_end)
     bicg_options opt{};
@@ -366,7 +367,8 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int phase = PH_NONE);
 void spmv_epi(bicg_ctx *c, double *xin, double *yout, int epi, int nd, int phase);
 void halo_only(bicg_ctx *c, double *xin);
-void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b);
+void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, bool sigma_staged = false);
+void spmm_stage_sigma(bicg_ctx *c, int nvec, const double *sigma_host);
 bool spmm_possible(const bicg_ctx *c);
 void spmm_buffers(bicg_ctx *c);
 void scal_reset(bicg_ctx *c);

@@ -464,7 +464,17 @@ void halo_only(bicg_ctx *c, double *xin)
 
 // Y_j = (A + sigma_j I) X_j for nvec <= kSpmmCols vectors that sit shift-major in c->mm_in: one pass over A.
 // with_b: c->v.b holds b, c->mm_out receives || b - Y_j ||^2 (this rank's rows); otherwise c->mm_yt receives Y.
-void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
+// the shifts of a pass go to the device BEFORE the pass is timed: the upload ends in a host-side wait (the values live on the
+// caller's stack frame), which used to sit inside bicg_spmm's event bracket -- 30-40 us of an idle GPU counted as kernel time
+void spmm_stage_sigma(bicg_ctx *c, int nvec, const double *sigma_host)
+{
+    double sg[kSpmmCols] = {0};
+    for (int j = 0; j < nvec; ++j) sg[j] = sigma_host[j];
+    BICG_HIP(hipMemcpyAsync(c->mm_sigma, sg, sizeof sg, hipMemcpyHostToDevice, c->sc));
+    BICG_HIP(hipStreamSynchronize(c->sc));     // sg lives on this stack frame
+}
+
+void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, bool sigma_staged)
 {
     const size_t st = c->stride;
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
@@ -481,10 +491,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
     a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
     a.xcd_map = c->mm_xcd ? 1 : 0;
     if (sigma_host) {
-        double sg[kSpmmCols] = {0};
-        for (int j = 0; j < nvec; ++j) sg[j] = sigma_host[j];
-        BICG_HIP(hipMemcpyAsync(c->mm_sigma, sg, sizeof sg, hipMemcpyHostToDevice, c->sc));
-        BICG_HIP(hipStreamSynchronize(c->sc));     // sg lives on this stack frame
+        if (!sigma_staged) spmm_stage_sigma(c, nvec, sigma_host);
         a.sigma = c->mm_sigma;
     }
     if (direct) {
@@ -494,7 +501,9 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b)
         a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
         if (const char *sv = test_tok("spmm-skip")) a.dbg = atoi(sv);
         if (!c->win_slots) a.cl = c->fw;
-        if (launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
+        // the pipelined form where the block qualifies (BICG_PLAN="spmm-window=1": k_spmm_win everywhere)
+        c->mm_dma = c->mm_win_env == 3 && !a.dbg && launch_spmm_dma(a, !c->single(), c->sc) == hipSuccess;
+        if (!c->mm_dma && launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
     } else {
         launch_spmm_sell(a, !c->single(), c->sc);
     }
@@ -512,7 +521,7 @@ void spmm_buffers(bicg_ctx *c)
 {
     if (c->mm_in) return;
     const size_t st = c->stride, ngroups = c->ng_int + c->ng_bnd;
-    c->mm_in = dev_alloc<double>((size_t)kSpmmCols * st);
+    c->mm_in = dev_alloc<double>((size_t)kSpmmCols * st + 64);      // (+64: k_spmm_dma copies 16-byte pairs, the last one may reach one column past a vector)
     c->mm_xt = dev_alloc<double>((size_t)kSpmmCols * st);
     c->mm_yt = dev_alloc<double>((size_t)kSpmmCols * st);
     c->mm_part = dev_alloc<double>((ngroups + 8) * kSpmmCols);
@@ -521,7 +530,7 @@ void spmm_buffers(bicg_ctx *c)
     BICG_HIP(hipMemset(c->mm_in, 0, sizeof(double) * kSpmmCols * st));
     BICG_HIP(hipDeviceSynchronize());      // the memset ran on the null stream: c->sc does not wait for it
     c->mm_xcd = !(knob_x("BICG_SPMM_XCD") && atoi(knob_x("BICG_SPMM_XCD")) == 0);
-    c->mm_win_env = plan_tok("spmm-window") ? atoi(plan_tok("spmm-window")) : 1;
+    c->mm_win_env = plan_tok("spmm-window") ? atoi(plan_tok("spmm-window")) : 3;      // 3: pipelined form where possible, else windowed
     if (!kExperiments && c->mm_win_env == 2) c->mm_win_env = 1;      // (2 = the direct form: builds with EXPERIMENTS=1 only)
 }
 

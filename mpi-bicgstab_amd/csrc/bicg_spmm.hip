@@ -1,0 +1,405 @@
+// bicg_spmm.hip -- Y_j = (A + sigma_j I) X_j for up to 16 vectors with the matrix read once (the per-shift verification loop of the
+// reference's shifted driver, src/test_shifted.c:129-154: BASELINE.json configs[4] "batched SpMV"), as a PIPELINE:
+// k_spmm_dma. Padded slices with 16-bit column offsets whose distances fall into clusters (struct FusedWindow: banded and
+// stencil-like matrices, the Transport-shaped one among them).
+//
+// What k_spmm_win (bicg_kernels.hip) did with its time (profiles/r06/spmm_skip.txt: the kernel with parts switched off):
+// of 320 us, 135 remained with no staging loads, no products and no row heads at all -- a workgroup's life was a chain of
+// dependent trips (slice metadata, row heads, staging of pass 1, sigma, staging of pass 2, ...) with two workgroups per CU to
+// overlap them; the staging loads themselves were 54 us, the products 85, the row heads 40, one after the other.
+// Here nothing waits for the memory it asked for in the same step:
+//   * the x window of a step (one 256-row group x 4 vectors) is copied global -> LDS by the DMA path
+//     (__builtin_amdgcn_global_load_lds, 16 bytes per lane, no staging registers, no ds_write pass) into the OTHER of two LDS
+//     buffers while the current step multiplies out of its own: a cluster's run of a group is one contiguous piece of every
+//     vector, laid out contiguously in LDS (runs start at even columns and even slots: 16-byte lanes);
+//   * a workgroup is persistent over consecutive groups; the head of the NEXT group's rows (first 16 entries: all of a
+//     Transport-shaped row) is loaded while the last pass of the current group multiplies;
+//   * a step's results are stored at the beginning of the next step, so that the one `s_waitcnt vmcnt(0)` per step (in front of
+//     the barrier that hands the buffers over) finds the stores long acknowledged;
+//   * the step's shifts are requested at its beginning (scalar loads), used behind its products.
+// Arithmetic: per row and vector the products are added in stored order, one rounding per product and per sum, y = 0 + that sum,
+// then the offd part, then sigma_j x_j -- bit for bit k_spmm_win's, i.e. bicg_spmv's column by column (tests/test_full_size.py,
+// tests/test_shifted.py).
+#include "bicg_device.h"
+#include "bicg_devfn.h"
+#include "bicg_reduce.h"
+#include "bicg_knobs.h"
+
+#include <cstdio>
+#include <cstdlib>
+
+namespace bicg {
+
+extern __shared__ double spmm_lds[];
+typedef short spmm_i16x4 __attribute__((ext_vector_type(4)));
+
+constexpr int kDmaNV = 4;          // vectors per step: two buffers of 4 x 1 246 slots = 80 KB, two workgroups per CU
+constexpr int kDmaHead = 16;       // entries of a row kept in registers across the passes of its group
+
+// what a group's rows need before their entries can be asked for (loaded a whole group ahead) ...
+#define BICG_KCONST __attribute__((address_space(4)))
+struct SpmmMeta { uint32_t p0, p1, len, base, base16, oa, ob; double bi; };      // (p1 - p0: the row's length -- subtracted where it is used)
+// ... and the head of the rows: the first 16 entries (value, LDS slot, "counts" bit)
+struct SpmmHead { double v[kDmaHead]; unsigned s8[kDmaHead]; };      // s8: BYTE offset of the entry's slot in a vector's window
+
+// LDS slot of the entry at distance d from the row of thread tid (padding: distance 0, the row's own column)
+__device__ __forceinline__ unsigned dma_slot(const FusedWindow &cl, unsigned tid, int d)
+{
+    int bias = cl.bias[0];
+    if (cl.ncl > 1 && d >= cl.lo[1]) bias = cl.bias[1];
+    if (cl.ncl > 2 && d >= cl.lo[2]) bias = cl.bias[2];
+    if (cl.ncl > 3 && d >= cl.lo[3]) bias = cl.bias[3];
+    return (unsigned)((int)tid + d + bias);
+}
+
+template <bool OFFD>
+__device__ __forceinline__ void dma_meta(const SpmmArgs &a, unsigned g, unsigned tid, unsigned wave, SpmmMeta &M)
+{
+    const uint32_t row = g * kGroupRows + tid;
+    const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g * (kGroupRows / kSliceRows) + wave));     // scalar loads below
+    const bool live = row < a.nrows;
+    M.base = 0u; M.len = 0u; M.base16 = 0u;
+    if (slice * kSliceRows < a.nrows) {       // (scalar loads: they do not take part in the vector memory counter the DMA copies use)
+        M.base = *((const BICG_KCONST uint32_t *)a.sell.slice_base + slice);
+        M.len = *((const BICG_KCONST uint32_t *)a.sell.slice_len + slice);
+        M.base16 = *((const BICG_KCONST uint32_t *)a.sell.slice_base16 + slice);
+    }
+    M.p0 = 0u; M.p1 = 0u;
+    if (live) { M.p0 = a.dptr[row]; M.p1 = a.dptr[row + 1]; }
+    M.oa = 0u; M.ob = 0u;
+    if (OFFD && live) { M.oa = a.offd.ptr[row]; M.ob = a.offd.ptr[row + 1]; }
+    M.bi = (a.b && live) ? a.b[row] : 0.0;
+}
+
+// the raw head of a group's rows as it comes from memory: NOTHING is computed from it where it is requested (an instruction that
+// uses a loaded word makes the wavefront wait for it -- and, the counter being in order, for the DMA copies issued before)
+struct SpmmRaw { double v[kDmaHead]; spmm_i16x4 q[kDmaHead / 4]; };
+__device__ __forceinline__ void dma_vals(const SpmmArgs &a, const SpmmMeta &M, unsigned lane, SpmmRaw &R)
+{
+    const spmm_i16x4 *const q16 = reinterpret_cast<const spmm_i16x4 *>(a.sell.col16) + ((size_t)M.base16 / 4 + lane);
+#pragma unroll
+    for (int q = 0; q < kDmaHead / 4; ++q) {
+        R.q[q] = (spmm_i16x4)(0);
+        if ((uint32_t)(4 * q) < M.len) R.q[q] = q16[(size_t)q * kSliceRows];       // wave-uniform test; the quad is padded
+    }
+#pragma unroll
+    for (int e = 0; e < kDmaHead; ++e) R.v[e] = (uint32_t)e < M.len ? a.sell.val[M.base + (uint32_t)e * kSliceRows + lane] : 0.0;
+}
+// An entry the row does not have (padding of the slice, or past the head of a shorter row) becomes value 0.0 at the window's ZERO
+// slot (the last slot of every vector's window holds 0.0): the products need no per-entry predicate then -- acc + 0.0 * 0.0 is
+// acc (a sum of -0.0 would turn +0.0: y = 0.0 + sum gives +0.0 either way, reference src/matrix.c:434-437).
+__device__ __forceinline__ void dma_finish(const SpmmArgs &a, const SpmmMeta &M, const SpmmRaw &R, unsigned tid, SpmmHead &H)
+{
+    const unsigned zero8 = (a.wslots - 1u) * 8u, mylen = M.p1 - M.p0;
+#pragma unroll
+    for (int q = 0; q < kDmaHead / 4; ++q) {
+        H.s8[4 * q + 0] = dma_slot(a.cl, tid, R.q[q].x) * 8u; H.s8[4 * q + 1] = dma_slot(a.cl, tid, R.q[q].y) * 8u;
+        H.s8[4 * q + 2] = dma_slot(a.cl, tid, R.q[q].z) * 8u; H.s8[4 * q + 3] = dma_slot(a.cl, tid, R.q[q].w) * 8u;
+    }
+#pragma unroll
+    for (int e = 0; e < kDmaHead; ++e) {
+        const bool on = (uint32_t)e < mylen;
+        H.v[e] = on ? R.v[e] : 0.0;
+        H.s8[e] = on ? H.s8[e] : zero8;
+    }
+}
+
+// the window of group g for vectors v0 .. v0 + 3 -> dst[v * W + slot], copied by the DMA path: 16 bytes (two columns) per lane,
+// LDS destination = wave-uniform base + 16 x lane. Cluster k's run starts at the even column g0 + lo_k (lo_k even: launch_spmm_dma)
+// and holds an even number of columns; lanes whose pair lies outside the vector do nothing (no entry refers to their slots).
+__device__ __forceinline__ void dma_issue(const SpmmArgs &a, unsigned g, int v0, double *dst, unsigned tid, unsigned wave, unsigned lane)
+{
+    const unsigned W = a.wslots;
+    const int g0 = (int)(g * kGroupRows), last = (int)a.nrows;           // (one column past the block may be read: the vectors have slack)
+#pragma unroll
+    for (int v = 0; v < kDmaNV; ++v) {
+        if (v0 + v >= a.nvec) break;
+        const double *xv = a.xs + (size_t)(v0 + v) * a.vstride;
+        for (int k = 0; k < a.cl.ncl; ++k) {
+            const int lo = a.cl.lo[k], pairs = (kGroupRows + a.cl.hi[k] - lo) / 2;
+            const unsigned s0 = (unsigned)(a.cl.bias[k] + lo);                           // first slot of the run (even)
+            for (int c0 = 0; c0 < pairs; c0 += kBlock) {
+                const int c = c0 + (int)(wave * 64u + lane);
+                const int col = g0 + lo + 2 * c;
+                double *base = dst + (size_t)v * W + s0 + 2u * (unsigned)(c0 + (int)(wave * 64u));      // wave-uniform
+                if (c < pairs && col >= 0 && col < last)
+                    __builtin_amdgcn_global_load_lds(const_cast<double *>(xv + col), (__attribute__((address_space(3))) void *)base, 16, 0, 0);
+            }
+        }
+    }
+}
+
+template <bool OFFD>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_dma(SpmmArgs a)
+{
+    constexpr int NV = kDmaNV, K = kDmaHead, U = 8;
+    __shared__ double sm[(kBlock / 64) * NV];
+    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
+    const unsigned W = a.wslots;
+    double *const buf0 = spmm_lds, *const buf1 = spmm_lds + (size_t)NV * W;
+    // Which groups: workgroup b runs on XCD b % 8. gstep > 0: consecutive groups floor(vb gstep) ..., XCD-contiguous ranges.
+    // gstep == 0 (default): every XCD owns an eighth of the groups and its workgroups take them CYCLICALLY -- at any time the
+    // workgroups of an XCD work on neighbouring groups, whose windows overlap: what one of them fetched the others find in the L2.
+    const unsigned nwg = gridDim.x;
+    unsigned gfirst, gend, gstride;
+    if (a.gstep > 0.0) {
+        unsigned vb = blockIdx.x;
+        if (a.xcd_map && nwg % 8u == 0u) vb = (blockIdx.x % 8u) * (nwg / 8u) + blockIdx.x / 8u;
+        gfirst = (unsigned)((double)vb * a.gstep);
+        const double upto = (double)(vb + 1u) * a.gstep;
+        gend = upto >= (double)a.ngroups ? a.ngroups : (unsigned)upto;      // (the grid is padded to a multiple of 8: the last few own nothing)
+        gstride = 1u;
+    } else {
+        const unsigned per = (a.ngroups + 7u) / 8u, xcd = blockIdx.x % 8u, j = blockIdx.x / 8u;
+        gstride = nwg / 8u;
+        gfirst = xcd * per + j;
+        gend = (xcd + 1u) * per < a.ngroups ? (xcd + 1u) * per : a.ngroups;
+    }
+    const int npass = (a.nvec + NV - 1) / NV;
+    if (a.b) {      // columns past the last vector (rows past the last group: launch_spmm_dma)
+        for (unsigned g = gfirst; g < gend; g += gstride)
+            if (tid < (unsigned)kSpmmCols && (int)tid >= a.nvec) a.partial[(size_t)g * kSpmmCols + tid] = 0.0;
+    }
+    if (gfirst >= gend) return;
+
+    // In-order memory counters: whatever a step WAITS for must have been asked for before the step's DMA copies, or the wait covers
+    // those too. A group's metadata is loaded a pair of groups ahead (pass 0, in front of the copies), its row heads in the last
+    // step that uses the head they replace (again in front of the copies; converted behind that step's hand-over barrier).
+    //
+    // Order of the steps: the workgroup's groups are taken in PAIRS (g0, g1 = its next group: one stride of the XCD's workgroups
+    // further on), passes outermost inside a pair: (g0, p0) (g1, p0) (g0, p1) (g1, p1) ... A pair is about one cluster distance
+    // apart when an XCD's workgroups cover 64 consecutive groups per round (Transport-shaped: 53.7 groups), so the far window of
+    // one is the near window of the other for the SAME vectors one step later -- an L2 hit instead of a trip to the Infinity Cache
+    // (with the passes innermost the same columns came back 4 steps = 10 MB of other traffic later: profiles/r06/spmm_notes.txt).
+    if (tid < 2u * NV) spmm_lds[(size_t)tid * W + (W - 1u)] = 0.0;      // the ZERO slot of every vector's window, both buffers (dma_finish)
+    const unsigned ncount = (gend - gfirst + gstride - 1u) / gstride;
+    SpmmMeta M0, M1, MN0, MN1;
+    SpmmHead H0, H1;
+    SpmmRaw N;
+    dma_meta<OFFD>(a, gfirst, tid, wave, M0);
+    dma_vals(a, M0, lane, N);
+    dma_issue(a, gfirst, 0, buf0, tid, wave, lane);
+    dma_finish(a, M0, N, tid, H0);
+    M1 = M0; H1 = H0;
+    if (ncount > 1u) {
+        dma_meta<OFFD>(a, gfirst + gstride, tid, wave, M1);
+        dma_vals(a, M1, lane, N);
+        dma_finish(a, M1, N, tid, H1);
+    }
+    MN0 = M0; MN1 = M1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    double yprev[NV];
+    uint32_t prev_row = 0xFFFFFFFFu;
+    int prev_v0 = 0;
+    unsigned step = 0;
+    // one step: group g, pass p out of the current buffer; (ng, np): the step after it (ng = ~0u: none); rawm: the metadata of the
+    // group whose row heads are to be requested in this step (want_raw)
+    auto run = [&](SpmmHead &H, const SpmmMeta M, unsigned g, int p, unsigned ng, int np, bool want_raw, const SpmmMeta rawm) {
+        const uint32_t row = g * kGroupRows + tid;
+        const bool live = row < a.nrows;
+        const int v0 = p * NV, nv = a.nvec - v0 < NV ? a.nvec - v0 : NV;
+        double *const cur = (step & 1u) ? buf1 : buf0, *const nxt = (step & 1u) ? buf0 : buf1;
+        ++step;
+        double sg[NV];                                                // the step's shifts: requested now, used behind the products
+#pragma unroll
+        for (int v = 0; v < NV; ++v) sg[v] = (a.sigma && v < nv) ? a.sigma[v0 + v] : 0.0;
+        // ---- what later steps need: row heads (raw), then the next step's window
+        if (want_raw) dma_vals(a, rawm, lane, N);
+        if (ng != 0xFFFFFFFFu) dma_issue(a, ng, np * NV, nxt, tid, wave, lane);
+        // ---- the previous step's results
+        if (prev_row != 0xFFFFFFFFu && a.ys) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v)
+                if (prev_v0 + v < a.nvec) a.ys[(size_t)(prev_v0 + v) * a.vstride + prev_row] = yprev[v];
+        }
+        // ---- this step: NV sums per lane out of the current buffer, the head from registers, whatever follows streamed
+        double acc[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) acc[v] = 0.0;
+#pragma unroll
+        for (int e = 0; e < K; ++e) asm volatile("" : "+v"(H.s8[e]));     // (keeps the 16 x NV LDS addresses out of loop-invariant registers)
+        const char *const cb = reinterpret_cast<const char *>(cur);
+        auto half = [&](int e0) {       // four entries' reads (16) in flight, then their products in stored order
+#pragma unroll
+            for (int e4 = e0; e4 < e0 + K / 2; e4 += 4) {
+                double xr[4][NV];
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) xr[i][v] = *reinterpret_cast<const double *>(cb + (size_t)v * W * 8u + H.s8[e4 + i]);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int i = 0; i < 4; ++i)
+#pragma unroll
+                    for (int v = 0; v < NV; ++v) acc[v] = acc[v] + H.v[e4 + i] * xr[i][v];       // an absent entry adds 0.0 * 0.0
+                __builtin_amdgcn_sched_barrier(0);
+            }
+        };
+        half(0);
+        if (M.len > (uint32_t)(K / 2)) half(K / 2);
+        for (uint32_t k0 = K; k0 < M.len; k0 += U) {                  // rows longer than the head: streamed per pass
+            const spmm_i16x4 *const q16 = reinterpret_cast<const spmm_i16x4 *>(a.sell.col16) + ((size_t)M.base16 / 4 + lane);
+            double val[U];
+            unsigned sl[U];
+#pragma unroll
+            for (int q = 0; q < U / 4; ++q) {
+                spmm_i16x4 dq = (spmm_i16x4)(0);
+                if (k0 + 4 * q < M.len) dq = q16[(size_t)(k0 / 4 + q) * kSliceRows];
+                sl[4 * q + 0] = dma_slot(a.cl, tid, dq.x); sl[4 * q + 1] = dma_slot(a.cl, tid, dq.y);
+                sl[4 * q + 2] = dma_slot(a.cl, tid, dq.z); sl[4 * q + 3] = dma_slot(a.cl, tid, dq.w);
+            }
+#pragma unroll
+            for (int e = 0; e < U; ++e) val[e] = k0 + e < M.len ? a.sell.val[M.base + (k0 + e) * kSliceRows + lane] : 0.0;
+#pragma unroll
+            for (int e = 0; e < U; ++e) {
+                const bool on = k0 + e < M.p1 - M.p0;
+#pragma unroll
+                for (int v = 0; v < NV; ++v) {
+                    const double t = acc[v] + val[e] * cur[(unsigned)v * W + sl[e]];
+                    acc[v] = on ? t : acc[v];
+                }
+            }
+        }
+        double r2[NV];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+            r2[v] = 0.0;
+            yprev[v] = 0.0;
+            if (v < nv && live) {
+                double y = 0.0 + acc[v];                              // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
+                if (OFFD) {
+                    const double *xv = a.xs + (size_t)(v0 + v) * a.vstride;
+                    double so = 0.0;
+                    for (uint32_t k = M.oa; k < M.ob; ++k) so += a.offd.val[k] * xv[a.offd.col[k]];
+                    y += so;                                          // second mult() call, src/matrix.c:440
+                }
+                // += sigma_j x_j (src/test_shifted.c:133): the row's own column is in the window (distance 0 belongs to a cluster)
+                if (a.sigma) y += sg[v] * cur[(unsigned)v * W + dma_slot(a.cl, tid, 0)];
+                yprev[v] = y;
+                if (a.b) { const double dd = (M.bi + (-1.0) * y) - 0.0; r2[v] = dd * dd; }
+            }
+        }
+        prev_row = live ? row : 0xFFFFFFFFu; prev_v0 = v0;
+        if (a.b) {
+#pragma unroll
+            for (int v = 0; v < NV; ++v) {
+                const double t = wave_sum(r2[v]);
+                if (lane == 0) sm[wave * NV + v] = t;
+            }
+            __syncthreads();
+            if ((int)tid < nv) {
+                double t = sm[tid];
+                for (int w = 1; w < kBlock / 64; ++w) t += sm[w * NV + tid];
+                a.partial[(size_t)g * kSpmmCols + v0 + tid] = t;
+            }
+        }
+        // ---- hand-over: the next step's window has landed, nobody reads this step's buffer any more
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    };
+
+    const unsigned none = 0xFFFFFFFFu;
+    for (unsigned i = 0; i < ncount; i += 2u) {
+        const unsigned g0 = gfirst + i * gstride, g1 = g0 + gstride;
+        const bool two = i + 1u < ncount, next0 = i + 2u < ncount, next1 = i + 3u < ncount;
+        for (int p = 0; p < npass; ++p) {
+            const bool last = p + 1 == npass;
+            if (p == 0) {       // the next pair's metadata, in front of everything this step asks for
+                if (next0) dma_meta<OFFD>(a, g0 + 2u * gstride, tid, wave, MN0);
+                if (next1) dma_meta<OFFD>(a, g0 + 3u * gstride, tid, wave, MN1);
+            }
+            // (g0, p); then (g1, p) or, for a last single group, (g0, p + 1)
+            {
+                const unsigned ng = two ? g1 : (!last ? g0 : (next0 ? g0 + 2u * gstride : none));
+                const int np = two ? p : (!last ? p + 1 : 0);
+                run(H0, M0, g0, p, ng, np, last && next0, MN0);
+                if (last && next0) { M0 = MN0; dma_finish(a, M0, N, tid, H0); }
+            }
+            if (two) {
+                const unsigned ng = !last ? g0 : (next0 ? g0 + 2u * gstride : none);
+                const int np = !last ? p + 1 : 0;
+                run(H1, M1, g1, p, ng, np, last && next1, MN1);
+                if (last && next1) { M1 = MN1; dma_finish(a, M1, N, tid, H1); }
+            }
+        }
+    }
+    if (prev_row != 0xFFFFFFFFu && a.ys) {
+#pragma unroll
+        for (int v = 0; v < NV; ++v)
+            if (prev_v0 + v < a.nvec) a.ys[(size_t)(prev_v0 + v) * a.vstride + prev_row] = yprev[v];
+    }
+}
+
+// Padded slices with 16-bit offsets in clusters, slices that stream their columns (no uniform / constant lists needed: col16 is
+// complete), and a window that fits two buffers of 4 vectors. The clusters are re-laid for the DMA copy: every run starts at an
+// even distance and an even slot and holds an even number of columns.
+bool spmm_dma_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
+{
+    if (a.cl.ncl <= 0 || a.sell.jag || a.sell.win_slots || !a.sell.col16 || !a.sell.slice_base16) return false;
+    FusedWindow f = a.cl;
+    int slots = 0;
+    for (int k = 0; k < f.ncl; ++k) {
+        // the run of cluster k covers the distances lo .. hi for rows 0 .. 255 of the group: columns g0 + lo .. g0 + 255 + hi, i.e.
+        // 256 + hi - lo of them -- even when lo and hi are
+        f.lo[k] = a.cl.lo[k] & ~1;                       // rounds towards minus infinity (two's complement)
+        f.hi[k] = (a.cl.hi[k] + 1) & ~1;
+        if (k > 0 && f.lo[k] <= f.hi[k - 1] + kGroupRows) return false;
+        f.bias[k] = slots - f.lo[k];
+        slots += kGroupRows + f.hi[k] - f.lo[k];
+    }
+    slots += 2;                                          // the last slot of a window holds 0.0 (dma_finish); even count
+    if ((size_t)2 * kDmaNV * (size_t)slots * 8u > 158u * 1024u) return false;
+    f.slots = (unsigned)slots;
+    out = f; wslots = (unsigned)slots;
+    return true;
+}
+
+// Two workgroups per CU are resident (80 KB of LDS each): 512, all of them from the start. Marching through consecutive groups in
+// step with a workgroup one cluster distance ahead (so that its near window is this one's far window) was tried and measured
+// no gain (profiles/r06/spmm_notes.txt); the cyclic order within an XCD is what the kernel uses.
+static void spmm_dma_shape(const SpmmArgs &a, unsigned &grid, double &gstep)
+{
+    grid = a.ngroups <= 512u ? ((a.ngroups + 7u) & ~7u) : 512u;
+    gstep = 0.0;                                                               // cyclic within the XCD's eighth
+    if (const char *v = test_tok("spmm-gstep")) {                              // (measurement: consecutive groups per workgroup, in thousandths)
+        const double s = 1e-3 * atof(v), ng = (double)a.ngroups;
+        if (s >= 1.0) {
+            unsigned g = (unsigned)(ng / s) + 1u;
+            while ((double)(g - 1u) * s >= ng) --g;
+            grid = (g + 7u) & ~7u; gstep = s;
+        }
+    }
+}
+
+hipError_t launch_spmm_dma(const SpmmArgs &a0, bool with_offd, hipStream_t st)
+{
+    if (a0.ngroups == 0) return hipSuccess;
+    SpmmArgs a = a0;
+    FusedWindow f;
+    unsigned W = 0;
+    if (!spmm_dma_plan(a0, f, W)) return hipErrorInvalidValue;
+    a.cl = f; a.wslots = W;
+    unsigned grid = 0;
+    spmm_dma_shape(a, grid, a.gstep);
+    const unsigned lds = 2u * (unsigned)kDmaNV * W * 8u;
+    // one row of partial sums per GROUP (not per workgroup); the column sums run over spmm_grid() rows: the few beyond the last group are zero
+    if (a.b) (void)hipMemsetAsync(a.partial + (size_t)a.ngroups * kSpmmCols, 0, sizeof(double) * 8 * kSpmmCols, st);
+    auto go = [&](auto kernel) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+        (void)hipGetLastError();
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, a);
+        return hipGetLastError();
+    };
+    return with_offd ? go(k_spmm_dma<true>) : go(k_spmm_dma<false>);
+}
+
+void preload_spmm_kernels()
+{
+    hipFuncAttributes at;
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_dma<false>));
+    (void)hipGetLastError();
+}
+
+}  // namespace bicg

@@ -58,7 +58,7 @@ EXPORTS = [
     "bicg_partition_nnz", "bicg_mtx_load_block_part", "bicg_mtx_parse_double", "bicg_mtx_cache_save", "bicg_mtx_cache_load",
     "bicg_coo_to_blocks_device", "bicg_mtx_set_block_builder",
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
-    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
+    "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_comm_last_error", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
     "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_product_kernels", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_has_experiments", "bicg_switch_value", "bicg_switch_unknown", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
@@ -469,6 +469,10 @@ class Context:
 
     def last_spmm_windowed(self) -> bool:
         return bool(lib().bicg_last_spmm_windowed(self.h))
+
+    def last_spmm_kind(self) -> str:
+        """which SpMM kernel the last pass ran: "pipelined" (k_spmm_dma), "windowed" (k_spmm_win) or "rowmajor" (k_spmm_sell)"""
+        return ("rowmajor", "windowed", "pipelined")[int(lib().bicg_last_spmm_windowed(self.h))]
 
     def last_shifted_persistent(self) -> bool:
         return bool(lib().bicg_last_shifted_persistent(self.h))

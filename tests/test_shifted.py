@@ -136,8 +136,17 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
         direct.close()
     finally:
         H.switches(spmm_window=None)
+    H.switches(spmm_window=1)                 # the windowed kernel (round 4: x staged through registers, one group per workgroup)
+    try:
+        windowed = H.Context(H.single_rank_blocks(A))
+        Yw1, _ = windowed.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
+        assert windowed.last_spmm_kind() == "windowed" and np.array_equal(Yw1, Yr)
+        windowed.close()
+    finally:
+        H.switches(spmm_window=None)
     Yw, _ = ctx.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
-    assert ctx.last_spmm_windowed() and np.array_equal(Yw, Yr)      # three clusters of offsets: staged per 256-row group in LDS
+    # three clusters of offsets: the pipelined kernel (round 6, csrc/bicg_spmm.hip: windows copied by the DMA path a step ahead)
+    assert ctx.last_spmm_kind() == "pipelined" and np.array_equal(Yw, Yr)
     rng = np.random.default_rng(8)
     for nvec in (1, 5, 16, 21):                       # less than, exactly and more than one pass of 16
         X = rng.standard_normal((nvec, A.rows))

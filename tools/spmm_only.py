@@ -1,17 +1,30 @@
 #!/usr/bin/env python3
-"""SpMM of 16 vectors on the bench matrix, a few times (for rocprofv3 kernel stats)."""
+"""SpMM of 16 vectors on the bench matrix: the pipelined kernel (k_spmm_dma) against the windowed one (BICG_PLAN=spmm-window=1),
+columns compared bit for bit with each other and with 16 single products; a few more launches for rocprofv3 kernel stats."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mpi_bicgstab_amd import hipsolver as H, synth
 H.lib().bicg_comm_init_single(0)
 A = synth.transport_like(scale_decades=2.0)
-ctx = H.Context(H.single_rank_blocks(A))
 X = np.random.default_rng(0).standard_normal((16, A.rows))
 sg = (np.arange(16) + 1.0) * 0.01 / 16
-for _ in range(5):
-    Y, ms = ctx.spmm(X, sg)
-print("spmm ms", ms, "spmv ms", ctx.spmv_bench(50))
-b = np.random.default_rng(1).standard_normal(A.rows)
-for _ in range(3):
-    r = ctx.shifted_residuals(X, b, sg)
+out = {}
+for name, tok in (("windowed", 1), ("pipelined", 3)):
+    H.switches(spmm_window=tok)
+    ctx = H.Context(H.single_rank_blocks(A))
+    for _ in range(5):
+        Y, ms = ctx.spmm(X, sg)
+    out[name] = Y
+    print(name, "kind", int(H.lib().bicg_last_spmm_windowed(ctx.h)), "spmm ms", round(ms, 4), "spmv ms", round(ctx.spmv_bench(50), 4), flush=True)
+    if name == "pipelined":
+        y3 = ctx.spmv(X[3]) + sg[3] * X[3]
+        print("column 3 equals the single product + shift:", bool(np.array_equal(Y[3], y3)))
+        Y5, _ = ctx.spmm(X[:5], sg[:5])
+        print("5 vectors:", bool(np.array_equal(Y5, Y[:5])))
+        b = np.random.default_rng(1).standard_normal(A.rows)
+        r = ctx.shifted_residuals(X, b, sg)
+        ref = np.array([np.linalg.norm(b - Y[j]) / np.linalg.norm(b) for j in range(16)])
+        print("residual norms max rel diff", float(np.abs(np.asarray(r) - ref).max() / ref.max()))
+    ctx.close()
+print("bit-identical columns:", bool(np.array_equal(out["windowed"], out["pipelined"])))
