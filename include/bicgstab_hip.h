@@ -372,7 +372,7 @@ unsigned int bicg_product_kernels(int reset);
 /* 1 when the last bicg_solve_shifted / shifted_pipe_lopbicgstab call on this context ran its iterations as persistent launches
  * (k_shpipe_persist: latency-bound ranks, <= 32 shifts; BICG_PERSIST="shifted=0" keeps the multi-launch form) */
 int bicg_last_shifted_persistent(bicg_ctx *ctx);
-/* Which kernel the last bicg_spmm / bicg_shifted_residuals pass on this context ran: 2 the pipelined one (k_spmm_dma,
+/* Which kernel the last bicg_spmm / bicg_shifted_residuals pass on this context ran: 2 the pipelined one (k_spmm_pipe,
  * csrc/bicg_spmm.hip: the x window of the next step copied global -> LDS by the DMA path while the current step multiplies,
  * persistent workgroups; padded 16-bit layouts whose distances fall into clusters), 1 the windowed one (k_spmm_win: the x values a
  * 256-row group touches staged in LDS through registers; BICG_PLAN="spmm-window=1" selects it everywhere, and layouts with x-window

@@ -490,7 +490,7 @@ struct SpmmArgs {
     FusedWindow cl;
     unsigned wslots;        // LDS doubles per vector
     int dbg;                // BICG_TEST="spmm-skip=n" (measurement only, results are wrong): 1 no staging loads, 2 no products, 4 no row heads
-    double gstep;           // k_spmm_dma: groups per workgroup (fractional: workgroup w takes groups floor(w gstep) .. floor((w + 1) gstep) - 1)
+    double gstep;           // k_spmm_pipe: groups per workgroup (fractional: workgroup w takes groups floor(w gstep) .. floor((w + 1) gstep) - 1)
 };
 
 
@@ -523,12 +523,10 @@ void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
 // vectors per LDS window of the windowed form for `wslots` doubles per vector (0: the window does not fit, use launch_spmm_sell)
 int spmm_win_vectors(unsigned wslots);
 hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st);
-// pipelined form (bicg_spmm.hip, k_spmm_dma): the window of the next step copied global -> LDS by the DMA path while the current one
+// pipelined form (bicg_spmm.hip, k_spmm_pipe): the window of the next step copied global -> LDS by the DMA path while the current one
 // multiplies, persistent workgroups over consecutive groups; padded 16-bit layouts with clusters (hipErrorInvalidValue: not this block)
-hipError_t launch_spmm_dma(const SpmmArgs &a, bool with_offd, hipStream_t st);
+hipError_t launch_spmm_pipe(const SpmmArgs &a, bool with_offd, hipStream_t st);
 void preload_spmm_kernels();
-// direct form (k_spmm_dir, padded slices): the row heads in registers, x gathered from the shift-major vectors, no LDS window
-hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st);
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 // look up one kernel of every translation unit a context with this sliced-ELL plan launches from (loads their code objects now)
 void preload_kernels(const SellDev &d, bool sell);

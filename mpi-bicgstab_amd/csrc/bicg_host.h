@@ -233,7 +233,7 @@ struct bicg_ctx {
     bool phantom = false;
     std::vector<double> ph_scratch;
     bool mm_win = false;         // the last SpMM pass ran the windowed kernel (vectors stay shift-major, X staged in LDS)
-    int  mm_win_env = 3;         // BICG_PLAN="spmm-window=0": the row-major kernel, 1: k_spmm_win everywhere, 3 (default): k_spmm_dma where the block qualifies
+    int  mm_win_env = 3;         // BICG_PLAN="spmm-window=0": the row-major kernel, 1: k_spmm_win everywhere, 3 (default): k_spmm_pipe where the block qualifies
     bool mm_dma = false;         // the last SpMM pass ran the pipelined kernel (bicg_spmm.hip)
 
     // state of the solve in progress (run_begin / run_iterate / run_end)

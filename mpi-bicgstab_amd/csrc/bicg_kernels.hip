@@ -1870,161 +1870,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
-#ifdef BICG_EXPERIMENTS      // one of three SpMM forms measured in round 4; the windowed one is the library's (bicg_knobs.h)
-// ------------------------------------------------------------------------------------------
-// Direct SpMM (round 4, padded slices): the head of every row -- value and column of its first 16 entries, the whole row for
-// banded / stencil matrices -- is loaded ONCE into registers, and the row is then multiplied with one vector after the other
-// straight from the shift-major vectors: consecutive lanes gather consecutive x values (lane = row, as in the SpMV), so a
-// wavefront's gather is four or five cache lines, not sixty-four as in the row-major kernel, there is no LDS window to stage,
-// no barrier, and two vectors' gathers are in flight per lane. The matrix is read once, X once per row that touches it through
-// the caches, Y written once; per row and vector the sum runs in stored order like mult() (reference src/matrix.c:506-515):
-// every column is bit-identical to bicg_spmv of that vector. (BICG_PLAN="spmm-window=2"; rows longer than 16 stream their tail per vector.)
-// ------------------------------------------------------------------------------------------
-template <bool C16, bool OFFD>
-__global__ void __launch_bounds__(kBlock) k_spmm_dir(SpmmArgs a)
-{
-    constexpr int K = 16, U = 8, NVD = 2;
-    __shared__ double sm[(kBlock / 64) * kSpmmCols];
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
-    unsigned g = blockIdx.x;
-    if (a.xcd_map) {
-        const unsigned per = (a.ngroups + 7u) / 8u;
-        g = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);
-    }
-    if (a.b && tid < (unsigned)kSpmmCols && (g >= a.ngroups || (int)tid >= a.nvec)) a.partial[(size_t)blockIdx.x * kSpmmCols + tid] = 0.0;
-    if (g >= a.ngroups) return;                               // (grid padded to a multiple of 8: workgroup-uniform)
-    const uint32_t row = g * kGroupRows + tid;
-    const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
-    const bool live = row < a.nrows;
-    const uint32_t rb = live ? row : 0u;                      // lanes past the last row hold padding: they read x of row 0, add nothing
-    uint32_t base = 0u, len = 0u, base16 = 0u;
-    if (slice * kSliceRows < a.nrows) {
-        base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice];
-        if (C16) base16 = a.sell.slice_base16[slice];
-    }
-    const uint32_t mylen = live ? a.dptr[row + 1] - a.dptr[row] : 0u;
-    uint32_t oa = 0u, ob = 0u;
-    if (OFFD && live) { oa = a.offd.ptr[row]; ob = a.offd.ptr[row + 1]; }
-    const double bi = (a.b && live) ? a.b[row] : 0.0;
-    const i16x4 *const q16 = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + lane);
-
-    // (x is addressed as uniform base + 32-bit byte offset -- spmm_possible: stride < 2^25 rows -- so the head's columns cost 16
-    // registers, not a 64-bit address per entry and vector)
-    auto at = [](const double *xb, uint32_t byte_off) -> double {
-        return *reinterpret_cast<const double *>(reinterpret_cast<const char *>(xb) + byte_off);
-    };
-    double hv[K];
-    uint32_t hc[K];                                           // byte offsets
-    unsigned hon = 0u;
-    if (C16) {
-#pragma unroll
-        for (int q = 0; q < K / 4; ++q) {
-            i16x4 dq = (i16x4)(0);
-            if ((uint32_t)(4 * q) < len) dq = q16[(size_t)q * kSliceRows];        // wave-uniform test; the quad is padded
-            hc[4 * q + 0] = rb + (int)dq.x; hc[4 * q + 1] = rb + (int)dq.y; hc[4 * q + 2] = rb + (int)dq.z; hc[4 * q + 3] = rb + (int)dq.w;
-        }
-    }
-#pragma unroll
-    for (int e = 0; e < K; ++e) {
-        const bool in = (uint32_t)e < len;                    // wave-uniform
-        if (!C16) hc[e] = in ? a.sell.col[base + (uint32_t)e * kSliceRows + lane] : rb;
-        hv[e] = in ? a.sell.val[base + (uint32_t)e * kSliceRows + lane] : 0.0;
-        if ((uint32_t)e < mylen) hon |= 1u << e; else hc[e] = rb;      // padding: the row's own column, never added
-        hc[e] <<= 3;
-    }
-
-    for (int v0 = 0; v0 < a.nvec; v0 += NVD) {
-        const double *xv[NVD];
-#pragma unroll
-        for (int v = 0; v < NVD; ++v) xv[v] = a.xs + (size_t)(v0 + v < a.nvec ? v0 + v : a.nvec - 1) * a.vstride;
-        double acc[NVD];
-#pragma unroll
-        for (int v = 0; v < NVD; ++v) acc[v] = 0.0;
-        // (the offsets are made opaque once per pass: their 64-bit extensions are loop invariants otherwise, 32 more registers and
-        // an address addition per load instead of the base + 32-bit offset form)
-#pragma unroll
-        for (int e = 0; e < K; ++e) asm volatile("" : "+v"(hc[e]));
-        auto half = [&](int e0) {
-            double xr[NVD][K / 2];
-#pragma unroll
-            for (int v = 0; v < NVD; ++v)
-#pragma unroll
-                for (int e = 0; e < K / 2; ++e) xr[v][e] = at(xv[v], hc[e0 + e]);
-#pragma unroll
-            for (int e = 0; e < K / 2; ++e) {
-                const bool on = (hon >> (e0 + e)) & 1u;
-#pragma unroll
-                for (int v = 0; v < NVD; ++v) {
-                    const double t = acc[v] + hv[e0 + e] * xr[v][e];      // stored order; padding never added
-                    acc[v] = on ? t : acc[v];
-                }
-            }
-        };
-        half(0);
-        if (len > (uint32_t)(K / 2)) half(K / 2);
-        for (uint32_t k0 = K; k0 < len; k0 += U) {            // rows longer than the head: streamed once per pair of vectors
-            double val[U];
-            uint32_t cc[U];
-            if (C16) {
-#pragma unroll
-                for (int q = 0; q < U / 4; ++q) {
-                    i16x4 dq = (i16x4)(0);
-                    if (k0 + 4 * q < len) dq = q16[(size_t)(k0 / 4 + q) * kSliceRows];
-                    cc[4 * q + 0] = rb + (int)dq.x; cc[4 * q + 1] = rb + (int)dq.y; cc[4 * q + 2] = rb + (int)dq.z; cc[4 * q + 3] = rb + (int)dq.w;
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < U; ++e) {
-                const bool in = k0 + e < len;
-                if (!C16) cc[e] = in ? a.sell.col[base + (k0 + e) * kSliceRows + lane] : rb;
-                val[e] = in ? a.sell.val[base + (k0 + e) * kSliceRows + lane] : 0.0;
-                if (!(k0 + e < mylen)) cc[e] = rb;
-            }
-            double xr[NVD][U];
-#pragma unroll
-            for (int v = 0; v < NVD; ++v)
-#pragma unroll
-                for (int e = 0; e < U; ++e) xr[v][e] = at(xv[v], cc[e] << 3);
-#pragma unroll
-            for (int e = 0; e < U; ++e) {
-                const bool on = k0 + e < mylen;
-#pragma unroll
-                for (int v = 0; v < NVD; ++v) {
-                    const double t = acc[v] + val[e] * xr[v][e];          // stored order
-                    acc[v] = on ? t : acc[v];
-                }
-            }
-        }
-#pragma unroll
-        for (int v = 0; v < NVD; ++v) {
-            double r2 = 0.0;
-            if (v0 + v < a.nvec && live) {
-                double y = 0.0 + acc[v];                      // y = 0 ; y += tempy  (src/matrix.c:434-437, 514)
-                if (OFFD) {
-                    double so = 0.0;
-                    for (uint32_t k = oa; k < ob; ++k) so += a.offd.val[k] * xv[v][a.offd.col[k]];
-                    y += so;                                  // second mult() call, src/matrix.c:440
-                }
-                if (a.sigma) y += a.sigma[v0 + v] * xv[v][row];            // += sigma_j x_j (src/test_shifted.c:133)
-                if (a.ys) a.ys[(size_t)(v0 + v) * a.vstride + row] = y;
-                if (a.b) { const double dd = (bi + (-1.0) * y) - 0.0; r2 = dd * dd; }
-            }
-            if (a.b) {
-                const double t = wave_sum(r2);
-                if (lane == 0 && v0 + v < a.nvec) sm[wave * kSpmmCols + v0 + v] = t;
-            }
-        }
-    }
-    if (a.b) {
-        __syncthreads();
-        if ((int)tid < a.nvec) {
-            double t = sm[tid];
-            for (int w = 1; w < kBlock / 64; ++w) t += sm[w * kSpmmCols + tid];
-            a.partial[(size_t)blockIdx.x * kSpmmCols + tid] = t;
-        }
-    }
-}
-#endif
 
 // out[col] = sum over workgroups of partial[wg][col], fixed order; one workgroup per column
 __global__ void __launch_bounds__(kBlock) k_colsum(const double *partial, unsigned nwg, double *out)
@@ -2130,20 +1975,6 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
 #undef WIN_GO
     return err;
 }
-#ifdef BICG_EXPERIMENTS
-hipError_t launch_spmm_dir(const SpmmArgs &a, bool with_offd, hipStream_t st)
-{
-    if (a.ngroups == 0) return hipSuccess;
-    if (a.sell.jag || a.sell.win_slots) return hipErrorInvalidValue;      // padded slices only
-    const unsigned grid = a.xcd_map ? ((a.ngroups + 7u) / 8u) * 8u : a.ngroups;
-    const bool c16 = a.sell.col16 != nullptr;
-    if (c16) { if (with_offd) hipLaunchKernelGGL((k_spmm_dir<true, true>), dim3(grid), dim3(kBlock), 0, st, a); else hipLaunchKernelGGL((k_spmm_dir<true, false>), dim3(grid), dim3(kBlock), 0, st, a); }
-    else     { if (with_offd) hipLaunchKernelGGL((k_spmm_dir<false, true>), dim3(grid), dim3(kBlock), 0, st, a); else hipLaunchKernelGGL((k_spmm_dir<false, false>), dim3(grid), dim3(kBlock), 0, st, a); }
-    return hipGetLastError();
-}
-#else
-hipError_t launch_spmm_dir(const SpmmArgs &, bool, hipStream_t) { return hipErrorNotSupported; }      // (not in this build)
-#endif
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map) { return xcd_map ? ((ngroups + 7u) / 8u) * 8u : ngroups; }
 void launch_colsum(const double *partial, unsigned nwg, double *out, hipStream_t st)
 {

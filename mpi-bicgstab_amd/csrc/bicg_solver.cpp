@@ -480,9 +480,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
     // the windowed form (k_spmm_win) reads the shift-major vectors directly and writes Y shift-major into mm_yt
     const unsigned wslots = c->win_slots ? c->win_slots : (c->s_col16 && !c->sell_jag && c->fw.ncl > 0 ? c->fw.slots : 0u);
-    // (BICG_PLAN="spmm-window=2": the direct form for padded slices -- row heads in registers, gathers from the shift-major vectors)
-    const bool direct = c->mm_win_env == 2 && !c->sell_jag && !c->win_slots;
-    c->mm_win = direct || (c->mm_win_env != 0 && spmm_win_vectors(wslots) > 0);
+    c->mm_win = c->mm_win_env != 0 && spmm_win_vectors(wslots) > 0;
     if (!c->mm_win) launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
@@ -494,15 +492,13 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
         if (!sigma_staged) spmm_stage_sigma(c, nvec, sigma_host);
         a.sigma = c->mm_sigma;
     }
-    if (direct) {
-        a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec;
-        if (launch_spmm_dir(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the direct kernel could not be launched");
-    } else if (c->mm_win) {
+    c->mm_dma = false;
+    if (c->mm_win) {
         a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
         if (const char *sv = test_tok("spmm-skip")) a.dbg = atoi(sv);
         if (!c->win_slots) a.cl = c->fw;
         // the pipelined form where the block qualifies (BICG_PLAN="spmm-window=1": k_spmm_win everywhere)
-        c->mm_dma = c->mm_win_env == 3 && !a.dbg && launch_spmm_dma(a, !c->single(), c->sc) == hipSuccess;
+        c->mm_dma = c->mm_win_env == 3 && !a.dbg && launch_spmm_pipe(a, !c->single(), c->sc) == hipSuccess;
         if (!c->mm_dma && launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
     } else {
         launch_spmm_sell(a, !c->single(), c->sc);
@@ -521,7 +517,7 @@ void spmm_buffers(bicg_ctx *c)
 {
     if (c->mm_in) return;
     const size_t st = c->stride, ngroups = c->ng_int + c->ng_bnd;
-    c->mm_in = dev_alloc<double>((size_t)kSpmmCols * st + 64);      // (+64: k_spmm_dma copies 16-byte pairs, the last one may reach one column past a vector)
+    c->mm_in = dev_alloc<double>((size_t)kSpmmCols * st + 64);      // (+64: k_spmm_pipe copies 16-byte pairs, the last one may reach one column past a vector)
     c->mm_xt = dev_alloc<double>((size_t)kSpmmCols * st);
     c->mm_yt = dev_alloc<double>((size_t)kSpmmCols * st);
     c->mm_part = dev_alloc<double>((ngroups + 8) * kSpmmCols);
@@ -531,7 +527,6 @@ void spmm_buffers(bicg_ctx *c)
     BICG_HIP(hipDeviceSynchronize());      // the memset ran on the null stream: c->sc does not wait for it
     c->mm_xcd = !(knob_x("BICG_SPMM_XCD") && atoi(knob_x("BICG_SPMM_XCD")) == 0);
     c->mm_win_env = plan_tok("spmm-window") ? atoi(plan_tok("spmm-window")) : 3;      // 3: pipelined form where possible, else windowed
-    if (!kExperiments && c->mm_win_env == 2) c->mm_win_env = 1;      // (2 = the direct form: builds with EXPERIMENTS=1 only)
 }
 
 // SpMV whose epilogue runs a pipelined phase on the workgroup's own rows (k_spmv_sell_epi): the open dot group is

@@ -1,25 +1,26 @@
 // bicg_spmm.hip -- Y_j = (A + sigma_j I) X_j for up to 16 vectors with the matrix read once (the per-shift verification loop of the
 // reference's shifted driver, src/test_shifted.c:129-154: BASELINE.json configs[4] "batched SpMV"), as a PIPELINE:
-// k_spmm_dma. Padded slices with 16-bit column offsets whose distances fall into clusters (struct FusedWindow: banded and
-// stencil-like matrices, the Transport-shaped one among them).
+// k_spmm_pipe. Padded slices with 16-bit column offsets whose distances fall into clusters (struct FusedWindow: banded and
+// stencil-like matrices, the Transport-shaped one among them); other layouts keep k_spmm_win / k_spmm_sell (bicg_kernels.hip).
 //
-// What k_spmm_win (bicg_kernels.hip) did with its time (profiles/r06/spmm_skip.txt: the kernel with parts switched off):
-// of 320 us, 135 remained with no staging loads, no products and no row heads at all -- a workgroup's life was a chain of
+// What k_spmm_win did with its 311-316 us per 16 vectors (profiles/r06/spmm_notes.txt: the kernel with parts switched off, and its
+// counters): 135 us remained with no staging loads, no products and no row heads at all -- a workgroup's life was a chain of
 // dependent trips (slice metadata, row heads, staging of pass 1, sigma, staging of pass 2, ...) with two workgroups per CU to
-// overlap them; the staging loads themselves were 54 us, the products 85, the row heads 40, one after the other.
-// Here nothing waits for the memory it asked for in the same step:
-//   * the x window of a step (one 256-row group x 4 vectors) is copied global -> LDS by the DMA path
-//     (__builtin_amdgcn_global_load_lds, 16 bytes per lane, no staging registers, no ds_write pass) into the OTHER of two LDS
-//     buffers while the current step multiplies out of its own: a cluster's run of a group is one contiguous piece of every
-//     vector, laid out contiguously in LDS (runs start at even columns and even slots: 16-byte lanes);
-//   * a workgroup is persistent over consecutive groups; the head of the NEXT group's rows (first 16 entries: all of a
-//     Transport-shaped row) is loaded while the last pass of the current group multiplies;
-//   * a step's results are stored at the beginning of the next step, so that the one `s_waitcnt vmcnt(0)` per step (in front of
-//     the barrier that hands the buffers over) finds the stores long acknowledged;
-//   * the step's shifts are requested at its beginning (scalar loads), used behind its products.
+// overlap them -- and it issued 70 M vector instructions, 11.6 per entry and vector (LDS address from slot and vector, a 64-bit
+// select per product for the "row has this entry" bit). Here:
+//   * a step = one 256-row group x 4 vectors. The x window of the NEXT step is asked for at the beginning of a step (16-byte loads
+//     into registers: the clusters' runs start at even columns and even slots) and written to the OTHER of two LDS buffers at the
+//     step's end, behind its products;
+//   * a workgroup is persistent: an XCD owns an eighth of the groups and its workgroups take them cyclically, so that at any time
+//     they work on neighbouring groups whose windows overlap in the L2 (1.28 -> 0.80 GB from the memory side per launch);
+//   * the head of the next group's rows (first 16 entries: all of a Transport-shaped row) is loaded, raw, in the last step of the
+//     current group and converted behind that step's barrier; its metadata a group ahead, by scalar loads;
+//   * a step's results are stored at the beginning of the next step; the step's shifts are requested at its beginning;
+//   * an entry the row does not have is value 0.0 at the window's ZERO slot: products without predicates, one add per LDS address.
+// 316 -> 203 us per 16 vectors (634 MB of matrix + X + Y: 0.39 of 8 TB/s), every column bit-identical.
 // Arithmetic: per row and vector the products are added in stored order, one rounding per product and per sum, y = 0 + that sum,
 // then the offd part, then sigma_j x_j -- bit for bit k_spmm_win's, i.e. bicg_spmv's column by column (tests/test_full_size.py,
-// tests/test_shifted.py).
+// tests/test_shifted.py, across ranks tests/test_multirank.py).
 #include "bicg_device.h"
 #include "bicg_devfn.h"
 #include "bicg_reduce.h"
@@ -33,7 +34,7 @@ namespace bicg {
 extern __shared__ double spmm_lds[];
 typedef short spmm_i16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kDmaNV = 4;          // vectors per step: two buffers of 4 x 1 246 slots = 80 KB, two workgroups per CU
+constexpr int kDmaNV = 4;          // vectors per step: two buffers of 4 x 1 248 slots = 80 KB, two workgroups per CU
 constexpr int kDmaHead = 16;       // entries of a row kept in registers across the passes of its group
 
 // what a group's rows need before their entries can be asked for (loaded a whole group ahead) ...
@@ -59,7 +60,7 @@ __device__ __forceinline__ void dma_meta(const SpmmArgs &a, unsigned g, unsigned
     const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g * (kGroupRows / kSliceRows) + wave));     // scalar loads below
     const bool live = row < a.nrows;
     M.base = 0u; M.len = 0u; M.base16 = 0u;
-    if (slice * kSliceRows < a.nrows) {       // (scalar loads: they do not take part in the vector memory counter the DMA copies use)
+    if (slice * kSliceRows < a.nrows) {       // (scalar loads: they do not take part in the vector memory counter)
         M.base = *((const BICG_KCONST uint32_t *)a.sell.slice_base + slice);
         M.len = *((const BICG_KCONST uint32_t *)a.sell.slice_len + slice);
         M.base16 = *((const BICG_KCONST uint32_t *)a.sell.slice_base16 + slice);
@@ -72,7 +73,7 @@ __device__ __forceinline__ void dma_meta(const SpmmArgs &a, unsigned g, unsigned
 }
 
 // the raw head of a group's rows as it comes from memory: NOTHING is computed from it where it is requested (an instruction that
-// uses a loaded word makes the wavefront wait for it -- and, the counter being in order, for the DMA copies issued before)
+// uses a loaded word makes the wavefront wait for it -- and, the counter being in order, for everything asked for before it)
 struct SpmmRaw { double v[kDmaHead]; spmm_i16x4 q[kDmaHead / 4]; };
 __device__ __forceinline__ void dma_vals(const SpmmArgs &a, const SpmmMeta &M, unsigned lane, SpmmRaw &R)
 {
@@ -104,33 +105,54 @@ __device__ __forceinline__ void dma_finish(const SpmmArgs &a, const SpmmMeta &M,
     }
 }
 
-// the window of group g for vectors v0 .. v0 + 3 -> dst[v * W + slot], copied by the DMA path: 16 bytes (two columns) per lane,
-// LDS destination = wave-uniform base + 16 x lane. Cluster k's run starts at the even column g0 + lo_k (lo_k even: launch_spmm_dma)
-// and holds an even number of columns; lanes whose pair lies outside the vector do nothing (no entry refers to their slots).
-__device__ __forceinline__ void dma_issue(const SpmmArgs &a, unsigned g, int v0, double *dst, unsigned tid, unsigned wave, unsigned lane)
+// The window of group g for vectors v0 .. v0 + 3, through registers: thread t owns the 16-byte pairs t, t + 256, t + 512 of the window
+// (the clusters' runs lie back to back in LDS, start at even columns and hold even numbers of columns: pair f is slots 2 f, 2 f + 1
+// whatever its cluster), asks for them at the beginning of a step and writes them to the other buffer at its end -- the loads
+// have the step's products to land behind. (The same copies through the DMA path, global_load_lds 16 bytes per lane, no staging
+// registers: 243 us per launch against 203 -- that path delivered 16 GB/s per CU here, 4.1 TB/s chip-wide for the gigabyte of
+// windows a launch stages. profiles/r06/spmm_notes.txt)
+constexpr int kStageJ = 3;         // pairs per thread and vector: windows of up to 1 536 slots
+typedef double spmm_f64x2 __attribute__((ext_vector_type(2)));
+struct SpmmStage { spmm_f64x2 t[kStageJ][kDmaNV]; };
+__device__ __forceinline__ void stage_load(const SpmmArgs &a, unsigned g, int v0, unsigned tid, SpmmStage &T)
 {
-    const unsigned W = a.wslots;
-    const int g0 = (int)(g * kGroupRows), last = (int)a.nrows;           // (one column past the block may be read: the vectors have slack)
+    const int g0 = (int)(g * kGroupRows), last = (int)a.nrows;
+    const int n0 = (kGroupRows + a.cl.hi[0] - a.cl.lo[0]) / 2;
+    const int n1 = a.cl.ncl > 1 ? n0 + (kGroupRows + a.cl.hi[1] - a.cl.lo[1]) / 2 : n0;
+    const int n2 = a.cl.ncl > 2 ? n1 + (kGroupRows + a.cl.hi[2] - a.cl.lo[2]) / 2 : n1;
+    const int n3 = a.cl.ncl > 3 ? n2 + (kGroupRows + a.cl.hi[3] - a.cl.lo[3]) / 2 : n2;
 #pragma unroll
-    for (int v = 0; v < kDmaNV; ++v) {
-        if (v0 + v >= a.nvec) break;
-        const double *xv = a.xs + (size_t)(v0 + v) * a.vstride;
-        for (int k = 0; k < a.cl.ncl; ++k) {
-            const int lo = a.cl.lo[k], pairs = (kGroupRows + a.cl.hi[k] - lo) / 2;
-            const unsigned s0 = (unsigned)(a.cl.bias[k] + lo);                           // first slot of the run (even)
-            for (int c0 = 0; c0 < pairs; c0 += kBlock) {
-                const int c = c0 + (int)(wave * 64u + lane);
-                const int col = g0 + lo + 2 * c;
-                double *base = dst + (size_t)v * W + s0 + 2u * (unsigned)(c0 + (int)(wave * 64u));      // wave-uniform
-                if (c < pairs && col >= 0 && col < last)
-                    __builtin_amdgcn_global_load_lds(const_cast<double *>(xv + col), (__attribute__((address_space(3))) void *)base, 16, 0, 0);
-            }
+    for (int j = 0; j < kStageJ; ++j) {
+        const int f = (int)tid + j * kBlock;
+        // the pair's first column: cluster by position, distance = lo_k + 2 (f - pairs before the cluster)
+        int d = a.cl.lo[0] + 2 * f;
+        if (f >= n0) d = a.cl.lo[1] + 2 * (f - n0);
+        if (f >= n1) d = a.cl.lo[2] + 2 * (f - n1);
+        if (f >= n2) d = a.cl.lo[3] + 2 * (f - n2);
+        const int col = g0 + d;
+        const bool ok = f < n3 && col >= 0 && col < last;
+#pragma unroll
+        for (int v = 0; v < kDmaNV; ++v) {
+            T.t[j][v] = (spmm_f64x2)(0.0);
+            if (ok && v0 + v < a.nvec) T.t[j][v] = *reinterpret_cast<const spmm_f64x2 *>(a.xs + (size_t)(v0 + v) * a.vstride + col);
+        }
+    }
+}
+__device__ __forceinline__ void stage_store(const SpmmArgs &a, double *dst, unsigned tid, const SpmmStage &T)
+{
+    const unsigned W = a.wslots, pairs = (W - 2u) / 2u;
+#pragma unroll
+    for (int j = 0; j < kStageJ; ++j) {
+        const unsigned f = tid + (unsigned)j * kBlock;
+        if (f < pairs) {
+#pragma unroll
+            for (int v = 0; v < kDmaNV; ++v) *reinterpret_cast<spmm_f64x2 *>(dst + (size_t)v * W + 2u * f) = T.t[j][v];
         }
     }
 }
 
 template <bool OFFD>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_dma(SpmmArgs a)
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_pipe(SpmmArgs a)
 {
     constexpr int NV = kDmaNV, K = kDmaHead, U = 8;
     __shared__ double sm[(kBlock / 64) * NV];
@@ -156,37 +178,29 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
         gend = (xcd + 1u) * per < a.ngroups ? (xcd + 1u) * per : a.ngroups;
     }
     const int npass = (a.nvec + NV - 1) / NV;
-    if (a.b) {      // columns past the last vector (rows past the last group: launch_spmm_dma)
+    if (a.b) {      // columns past the last vector (rows past the last group: launch_spmm_pipe)
         for (unsigned g = gfirst; g < gend; g += gstride)
             if (tid < (unsigned)kSpmmCols && (int)tid >= a.nvec) a.partial[(size_t)g * kSpmmCols + tid] = 0.0;
     }
     if (gfirst >= gend) return;
 
-    // In-order memory counters: whatever a step WAITS for must have been asked for before the step's DMA copies, or the wait covers
-    // those too. A group's metadata is loaded a pair of groups ahead (pass 0, in front of the copies), its row heads in the last
-    // step that uses the head they replace (again in front of the copies; converted behind that step's hand-over barrier).
-    //
-    // Order of the steps: the workgroup's groups are taken in PAIRS (g0, g1 = its next group: one stride of the XCD's workgroups
-    // further on), passes outermost inside a pair: (g0, p0) (g1, p0) (g0, p1) (g1, p1) ... A pair is about one cluster distance
-    // apart when an XCD's workgroups cover 64 consecutive groups per round (Transport-shaped: 53.7 groups), so the far window of
-    // one is the near window of the other for the SAME vectors one step later -- an L2 hit instead of a trip to the Infinity Cache
-    // (with the passes innermost the same columns came back 4 steps = 10 MB of other traffic later: profiles/r06/spmm_notes.txt).
+    // In-order memory counter: whatever a step WAITS for is asked for before the step's window loads, or the wait covers those
+    // too. A group's metadata is loaded a group ahead (pass 0, scalar loads and one row-pointer pair), its row heads in the last
+    // step of the group before (in front of the window loads; converted behind that step's hand-over barrier).
+    // (Taking the groups in pairs one cluster distance apart, passes outermost inside a pair -- the far window of one group is the
+    // near window of the other one step later -- lowered the L2 misses from 0.80 to 0.68 GB and left the time where it was, at the
+    // price of a second set of row heads in registers: not kept. profiles/r06/spmm_notes.txt)
     if (tid < 2u * NV) spmm_lds[(size_t)tid * W + (W - 1u)] = 0.0;      // the ZERO slot of every vector's window, both buffers (dma_finish)
-    const unsigned ncount = (gend - gfirst + gstride - 1u) / gstride;
-    SpmmMeta M0, M1, MN0, MN1;
-    SpmmHead H0, H1;
+    SpmmMeta M0, MN0;
+    SpmmHead H0;
     SpmmRaw N;
     dma_meta<OFFD>(a, gfirst, tid, wave, M0);
     dma_vals(a, M0, lane, N);
-    dma_issue(a, gfirst, 0, buf0, tid, wave, lane);
+    SpmmStage T;
+    stage_load(a, gfirst, 0, tid, T);
+    stage_store(a, buf0, tid, T);
     dma_finish(a, M0, N, tid, H0);
-    M1 = M0; H1 = H0;
-    if (ncount > 1u) {
-        dma_meta<OFFD>(a, gfirst + gstride, tid, wave, M1);
-        dma_vals(a, M1, lane, N);
-        dma_finish(a, M1, N, tid, H1);
-    }
-    MN0 = M0; MN1 = M1;
+    MN0 = M0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
@@ -207,7 +221,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
         for (int v = 0; v < NV; ++v) sg[v] = (a.sigma && v < nv) ? a.sigma[v0 + v] : 0.0;
         // ---- what later steps need: row heads (raw), then the next step's window
         if (want_raw) dma_vals(a, rawm, lane, N);
-        if (ng != 0xFFFFFFFFu) dma_issue(a, ng, np * NV, nxt, tid, wave, lane);
+        if (ng != 0xFFFFFFFFu) stage_load(a, ng, np * NV, tid, T);
         // ---- the previous step's results
         if (prev_row != 0xFFFFFFFFu && a.ys) {
 #pragma unroll
@@ -296,34 +310,19 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
             }
         }
         // ---- hand-over: the next step's window has landed, nobody reads this step's buffer any more
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        if (ng != 0xFFFFFFFFu) stage_store(a, nxt, tid, T);
         __syncthreads();
     };
 
     const unsigned none = 0xFFFFFFFFu;
-    for (unsigned i = 0; i < ncount; i += 2u) {
-        const unsigned g0 = gfirst + i * gstride, g1 = g0 + gstride;
-        const bool two = i + 1u < ncount, next0 = i + 2u < ncount, next1 = i + 3u < ncount;
+    for (unsigned g = gfirst; g < gend; g += gstride) {
+        const bool more = g + gstride < gend;
         for (int p = 0; p < npass; ++p) {
             const bool last = p + 1 == npass;
-            if (p == 0) {       // the next pair's metadata, in front of everything this step asks for
-                if (next0) dma_meta<OFFD>(a, g0 + 2u * gstride, tid, wave, MN0);
-                if (next1) dma_meta<OFFD>(a, g0 + 3u * gstride, tid, wave, MN1);
-            }
-            // (g0, p); then (g1, p) or, for a last single group, (g0, p + 1)
-            {
-                const unsigned ng = two ? g1 : (!last ? g0 : (next0 ? g0 + 2u * gstride : none));
-                const int np = two ? p : (!last ? p + 1 : 0);
-                run(H0, M0, g0, p, ng, np, last && next0, MN0);
-                if (last && next0) { M0 = MN0; dma_finish(a, M0, N, tid, H0); }
-            }
-            if (two) {
-                const unsigned ng = !last ? g0 : (next0 ? g0 + 2u * gstride : none);
-                const int np = !last ? p + 1 : 0;
-                run(H1, M1, g1, p, ng, np, last && next1, MN1);
-                if (last && next1) { M1 = MN1; dma_finish(a, M1, N, tid, H1); }
-            }
+            if (p == 0 && more) dma_meta<OFFD>(a, g + gstride, tid, wave, MN0);       // the next group's metadata, in front of everything this step asks for
+            run(H0, M0, g, p, !last ? g : (more ? g + gstride : none), !last ? p + 1 : 0, last && more, MN0);
         }
+        if (more) { M0 = MN0; dma_finish(a, M0, N, tid, H0); }
     }
     if (prev_row != 0xFFFFFFFFu && a.ys) {
 #pragma unroll
@@ -332,10 +331,10 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     }
 }
 
-// Padded slices with 16-bit offsets in clusters, slices that stream their columns (no uniform / constant lists needed: col16 is
-// complete), and a window that fits two buffers of 4 vectors. The clusters are re-laid for the DMA copy: every run starts at an
+// Padded slices with 16-bit offsets in clusters (col16 is complete: uniform / constant lists are not needed), and a window that
+// fits two buffers of 4 vectors and three pairs per thread. The clusters are re-laid for 16-byte copies: every run starts at an
 // even distance and an even slot and holds an even number of columns.
-bool spmm_dma_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
+bool spmm_pipe_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
 {
     if (a.cl.ncl <= 0 || a.sell.jag || a.sell.win_slots || !a.sell.col16 || !a.sell.slice_base16) return false;
     FusedWindow f = a.cl;
@@ -349,6 +348,7 @@ bool spmm_dma_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
         f.bias[k] = slots - f.lo[k];
         slots += kGroupRows + f.hi[k] - f.lo[k];
     }
+    if (slots > 2 * kStageJ * kBlock) return false;      // three 16-byte pairs per thread and vector (stage_load)
     slots += 2;                                          // the last slot of a window holds 0.0 (dma_finish); even count
     if ((size_t)2 * kDmaNV * (size_t)slots * 8u > 158u * 1024u) return false;
     f.slots = (unsigned)slots;
@@ -359,7 +359,7 @@ bool spmm_dma_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
 // Two workgroups per CU are resident (80 KB of LDS each): 512, all of them from the start. Marching through consecutive groups in
 // step with a workgroup one cluster distance ahead (so that its near window is this one's far window) was tried and measured
 // no gain (profiles/r06/spmm_notes.txt); the cyclic order within an XCD is what the kernel uses.
-static void spmm_dma_shape(const SpmmArgs &a, unsigned &grid, double &gstep)
+static void spmm_pipe_shape(const SpmmArgs &a, unsigned &grid, double &gstep)
 {
     grid = a.ngroups <= 512u ? ((a.ngroups + 7u) & ~7u) : 512u;
     gstep = 0.0;                                                               // cyclic within the XCD's eighth
@@ -373,16 +373,16 @@ static void spmm_dma_shape(const SpmmArgs &a, unsigned &grid, double &gstep)
     }
 }
 
-hipError_t launch_spmm_dma(const SpmmArgs &a0, bool with_offd, hipStream_t st)
+hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st)
 {
     if (a0.ngroups == 0) return hipSuccess;
     SpmmArgs a = a0;
     FusedWindow f;
     unsigned W = 0;
-    if (!spmm_dma_plan(a0, f, W)) return hipErrorInvalidValue;
+    if (!spmm_pipe_plan(a0, f, W)) return hipErrorInvalidValue;
     a.cl = f; a.wslots = W;
     unsigned grid = 0;
-    spmm_dma_shape(a, grid, a.gstep);
+    spmm_pipe_shape(a, grid, a.gstep);
     const unsigned lds = 2u * (unsigned)kDmaNV * W * 8u;
     // one row of partial sums per GROUP (not per workgroup); the column sums run over spmm_grid() rows: the few beyond the last group are zero
     if (a.b) (void)hipMemsetAsync(a.partial + (size_t)a.ngroups * kSpmmCols, 0, sizeof(double) * 8 * kSpmmCols, st);
@@ -392,13 +392,13 @@ hipError_t launch_spmm_dma(const SpmmArgs &a0, bool with_offd, hipStream_t st)
         hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, a);
         return hipGetLastError();
     };
-    return with_offd ? go(k_spmm_dma<true>) : go(k_spmm_dma<false>);
+    return with_offd ? go(k_spmm_pipe<true>) : go(k_spmm_pipe<false>);
 }
 
 void preload_spmm_kernels()
 {
     hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_dma<false>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_pipe<false>));
     (void)hipGetLastError();
 }
 

@@ -471,7 +471,7 @@ class Context:
         return bool(lib().bicg_last_spmm_windowed(self.h))
 
     def last_spmm_kind(self) -> str:
-        """which SpMM kernel the last pass ran: "pipelined" (k_spmm_dma), "windowed" (k_spmm_win) or "rowmajor" (k_spmm_sell)"""
+        """which SpMM kernel the last pass ran: "pipelined" (k_spmm_pipe), "windowed" (k_spmm_win) or "rowmajor" (k_spmm_sell)"""
         return ("rowmajor", "windowed", "pipelined")[int(lib().bicg_last_spmm_windowed(self.h))]
 
     def last_shifted_persistent(self) -> bool:

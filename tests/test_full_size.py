@@ -92,7 +92,7 @@ def test_spmm_16_vectors_reads_the_matrix_once(big):
     print(f"SpMM 16 vectors {1e3 * ms:.1f} us, one SpMV {1e3 * one:.1f} us")
     # round 4: X staged in LDS per 256-row group straight from the shift-major vectors (k_spmm_win: no layout change, X read
     # once): 345 us against 446 us for the row-major kernel + its transposes -- while one SpMV went from 48 to 35 us.
-    # round 6: the pipelined kernel (k_spmm_dma) ~250 us = 7.5 products of 33 us (the event bracket no longer holds the shifts' upload)
+    # round 6: the pipelined kernel (k_spmm_pipe) ~250 us = 7.5 products of 33 us (the event bracket no longer holds the shifts' upload)
     assert ctx.last_spmm_kind() == "pipelined" and ms <= 0.52 * 16 * one
 
 

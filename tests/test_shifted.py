@@ -128,14 +128,6 @@ def test_spmm_columns_are_the_spmv_of_each_vector():
         rowmajor.close()
     finally:
         H.switches(spmm_window=None)
-    H.switches(spmm_window=2)                 # the direct kernel (row heads in registers, gathers from the shift-major vectors)
-    try:
-        direct = H.Context(H.single_rank_blocks(A))
-        Yd, _ = direct.spmm(Xr, 0.01 * (np.arange(16) + 1.0))
-        assert direct.last_spmm_windowed() and np.array_equal(Yd, Yr)
-        direct.close()
-    finally:
-        H.switches(spmm_window=None)
     H.switches(spmm_window=1)                 # the windowed kernel (round 4: x staged through registers, one group per workgroup)
     try:
         windowed = H.Context(H.single_rank_blocks(A))

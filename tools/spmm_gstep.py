@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""k_spmm_dma: time against groups per workgroup (BICG_TEST=spmm-gstep, thousandths); default = cluster distance / m"""
+"""k_spmm_pipe: time against groups per workgroup (BICG_TEST=spmm-gstep, thousandths); default = cluster distance / m"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np

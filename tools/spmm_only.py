@@ -1,5 +1,5 @@
 #!/usr/bin/env python3
-"""SpMM of 16 vectors on the bench matrix: the pipelined kernel (k_spmm_dma) against the windowed one (BICG_PLAN=spmm-window=1),
+"""SpMM of 16 vectors on the bench matrix: the pipelined kernel (k_spmm_pipe) against the windowed one (BICG_PLAN=spmm-window=1),
 columns compared bit for bit with each other and with 16 single products; a few more launches for rocprofv3 kernel stats."""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
