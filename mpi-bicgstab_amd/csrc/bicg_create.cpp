@@ -1230,6 +1230,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->push_dst0 = dev_upload(dst0.data(), dst0.size());
         c->push_stride = dev_upload(dstride.data(), dstride.size());
         c->ll_fused = c->n_bnd == 0 && c->ng_int + c->ng_bnd > 0;
+        // Ragged rows (jagged slices): the launch with the exchange inside runs k_spmv_sell's loop over EVERY group, the rank's
+        // halo-free groups included; as separate launches -- push, interior, unpack, boundary -- the interior goes through the
+        // three-trip products of bicg_jagw.hip. Worth two more launches when the interior is large (measured with two 800 k-row
+        // ranks of the RCM-numbered mesh matrix sharing a GPU: profiles/r06/ragged_ranks_fused_or_split.txt); BICG_PLAN="halo-fused=0|1" decides.
+        if (c->ll_fused && c->sell_jag && c->lane_info && c->jagw_fast && (uint64_t)c->nnz_d >= 4000000ull) c->ll_fused = false;
+        if (const char *sv = plan_tok("halo-fused")) c->ll_fused = c->n_bnd == 0 && c->ng_int + c->ng_bnd > 0 && atoi(sv) != 0;
         if (const char *sv = knob_x("BICG_P2P_FUSED")) c->ll_fused = c->ll_fused && atoi(sv) != 0;
         if (c->ll_fused) {
             std::vector<uint32_t> order(gl_int);
