@@ -227,33 +227,43 @@ def test_display_error_lines_of_the_reference_on_the_dropin_path(tmp_path, np_):
 @need
 @pytest.mark.parametrize("np_", [1, 2])
 def test_display_residual_lines_of_the_reference_on_the_dropin_path(tmp_path, np_):
-    """BICG_DISPLAY_RESIDUAL=1: the progress line of the reference's shifted solvers (src/shifted_solver.c:151-155 "Iteration: %d,
-    Residual: %e, Max_Xi: %e", and :325-329, 500-504, 672-676, 870-874, 1061-1065 with Max_Zeta_Pi) from the drop-in build of the
-    reference's own driver test_shifted.c (shifted_pipe_lopbicgstab_nooverlap on 5 shifts, then shifted_lopbicgstab once per
-    shift, src/test_shifted.c:127, 157-166), against the reference compiled with -DDISPLAY_RESIDUAL and OUT_ITER 5
-    (oracle/_ref/test_shifted_ref_res): the same lines at the same iterations, residuals and ratios within 1e-4 (six printed digits
-    of two trajectories that differ in the association of their dot sums), every solve of the driver."""
-    dropin, ref = os.path.join(REF, "test_shifted_dropin"), os.path.join(REF, "test_shifted_ref_res")
+    """BICG_DISPLAY_RESIDUAL=1: the progress line of the reference's shifted solvers -- "Iteration: %d, Residual: %e, Max_Xi: %e"
+    (src/shifted_solver.c:151-155) and the same with Max_Zeta_Pi (:325-329, 500-504, 672-676, 870-874, 1061-1065) -- from all six
+    entry points of src/shifted_solver.h:16-21 in libbicgstab_hip.so, against the reference compiled with -DDISPLAY_RESIDUAL and
+    OUT_ITER 5 under the same driver (oracle/ref_dump_shifted_main.c: b = (A + sigma_seed I) 1, five shifts): the same lines at the
+    same iterations; residuals and ratios within 1e-4 while the residual is above 1e-9 (six printed digits of two trajectories that
+    differ in the association of their dot sums), within a factor of ten below (round-off decides there), iteration counts +-4."""
+    dropin, ref = os.path.join(REF, "ref_dump_shifted_dropin"), os.path.join(REF, "ref_dump_shifted_res")
     if not (os.path.exists(dropin) and os.path.exists(ref)):
-        pytest.skip("test_shifted_dropin / test_shifted_ref_res not built")
+        pytest.skip("ref_dump_shifted_dropin / ref_dump_shifted_res not built")
     path = str(tmp_path / "shifted.mtx")
     synth.write_mtx(path, synth.from_offsets(20011, (0, 1, -1, 140, -140, 141, -141), diag_base=4.6, seed=5))
+    sigmas = ["0.01", "0.02", "0.03", "0.04", "0.05"]
 
-    def run(binary, **env):
-        out = subprocess.run([MPIEXEC, "-n", str(np_), binary, path], capture_output=True, text=True, timeout=600, env=dict(os.environ, **env))
+    def run(binary, fn, **env):
+        out = subprocess.run([MPIEXEC, "-n", str(np_), binary, path, fn, str(tmp_path / "dump"), "2", *sigmas], capture_output=True, text=True,
+                             timeout=600, env=dict(os.environ, **env))
         assert out.returncode == 0, out.stdout[-3000:] + out.stderr[-3000:]
         lines = re.findall(r"^Iteration: (\d+), Residual: (\S+), (Max_Xi|Max_Zeta_Pi): (\S+)$", out.stdout, flags=re.M)
-        return [(int(k), float(r), name, float(m)) for k, r, name, m in lines], [int(k) for k in re.findall(r"Total iter\s*:\s*(\d+)", out.stdout)]
+        k = int(re.search(r"Total iter\s*:\s*(\d+)", out.stdout).group(1))
+        return [(int(it), float(r), name, float(m)) for it, r, name, m in lines], k, out.stdout
 
-    want, kw = run(ref)
-    got, kg = run(dropin, BICG_DISPLAY_RESIDUAL="1", BICG_OUT_ITER="5")
-    assert len(want) >= 30 and len(kw) >= 6 and len(kg) == len(kw), (len(want), kw, kg)      # six solves, eight lines each
-    assert all(abs(a - b) <= 1 for a, b in zip(kw, kg)), (kw, kg)
-    assert [(w[0], w[2]) for w in want] == [(g[0], g[2]) for g in got], (want[:10], got[:10])
-    for (k, rw, _, mw), (_, rg, _, mg) in zip(want, got):
-        assert abs(rw - rg) <= 1e-4 * rw and abs(mw - mg) <= 1e-4 * mw, (k, rw, rg, mw, mg)
-    silent = subprocess.run([MPIEXEC, "-n", "1", dropin, path], capture_output=True, text=True, timeout=600)
-    assert "Iteration:" not in silent.stdout                         # off unless asked for, like the reference's default build
+    for fn, label in (("shifted_bicgstab", "Max_Xi"), ("shifted_lopbicgstab", "Max_Zeta_Pi"), ("shifted_lopbicgstab_v2", "Max_Zeta_Pi"),
+                      ("shifted_lopbicgstab_nooverlap", "Max_Zeta_Pi"), ("shifted_pipe_lopbicgstab", "Max_Zeta_Pi"),
+                      ("shifted_pipe_lopbicgstab_nooverlap", "Max_Zeta_Pi")):
+        want, kw, _ = run(ref, fn)
+        got, kg, _ = run(dropin, fn, BICG_DISPLAY_RESIDUAL="1", BICG_OUT_ITER="5")
+        assert len(want) >= 4 and all(w[2] == label for w in want), (fn, want[:3])
+        assert abs(kw - kg) <= 4, (fn, kw, kg)
+        n = min(len(want), len(got))
+        assert n >= len(want) - 1 and [(w[0], w[2]) for w in want[:n]] == [(g[0], g[2]) for g in got[:n]], (fn, want, got)
+        for (it, rw, _, mw), (_, rg, _, mg) in zip(want[:n], got[:n]):
+            if rw > 1e-9:
+                assert abs(rw - rg) <= 1e-4 * rw and abs(mw - mg) <= 1e-4 * mw, (fn, it, rw, rg, mw, mg)
+            else:
+                assert rw / 10 <= rg <= rw * 10 and abs(mw - mg) <= 1e-3 * mw, (fn, it, rw, rg, mw, mg)
+    _, _, silent = run(dropin, "shifted_lopbicgstab")
+    assert "Iteration:" not in silent                                # off unless asked for, like the reference's default build
 
 
 @need
