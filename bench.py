@@ -947,6 +947,7 @@ def main():
     # the product of the UNSTRUCTURED matrix as the second headline: the mesh matrix in RCM numbering (what a bandwidth-reducing
     # pre-pass of a FEM code hands over), with the generator order and the random permutation beside it
     KERNEL_TEXT = {"jagw": "k_spmv_jagw (csrc/bicg_jagw.hip: jagged slices, x window of each 256-row group in LDS, three dependent trips per group)",
+                   "jagw_list": "k_spmv_jagl (csrc/bicg_jagw.hip: jagged slices, LIST-driven x window of each 256-row group in LDS, three trips)",
                    "jagd": "k_spmv_jagd (csrc/bicg_jagw.hip: jagged slices, x gathered through the caches by 16-bit offsets / 32-bit columns, three trips)",
                    "sell_jagged": "k_spmv_sell on jagged slices", "sell_window_loop": "k_spmv_sell's window loop", "csr": "k_spmv (CSR row blocks)"}
 

@@ -728,6 +728,7 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     std::vector<uint32_t> win_ptr;
     std::vector<uint2> win_runs;
     uint32_t win_slots = 0;
+    bool win_list_mode = false;
   select_groups:
     sell_entries = 0; c->sell_nnz = 0; c->sell_rows = 0;
     gl_int.clear(); gl_bnd.clear();
@@ -778,6 +779,30 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
             uint32_t most_runs = 0;
             for (uint32_t g = 0; g < ngroups; ++g) most_runs = std::max(most_runs, win_ptr[g + 1] - win_ptr[g]);
             if (most_runs > kJagwMaxRuns || win_slots > kJagwMaxSlots) ok = false;
+            // ... unless the group's DISTINCT columns fit the window one by one (no gaps merged): the list-driven window of
+            // k_spmv_jagw<.., LIST> (SellDev::win_list). One rank only -- launches with offd entries or the exchange inside go
+            // through k_spmv_sell's loop, which would have to stage hundreds of runs -- and not for blocks whose pipelined
+            // phases ride in the products' epilogues (the same loop). BICG_PLAN="window-list=0" keeps the gathers.
+            if (!ok && P == 1 && !c->fuse_small && sell_entries > 0 && !plan_off("window-list")) {
+                long nr = bicg_window_plan(diag->ptr, diag->col, nrows, kGroupRows, group_is_sell.data(), kJagwMaxSlots, 0u, nullptr, nullptr, nullptr);
+                bool near = nr >= 0;
+                for (uint32_t g = 0; near && g < ngroups; ++g) {      // 16-bit list entries: distance from the group's first row
+                    if (!group_is_sell[g]) continue;
+                    const uint32_t r0 = g * kGroupRows, r1 = std::min(nrows, r0 + kGroupRows);
+                    for (uint32_t j = diag->ptr[r0]; j < diag->ptr[r1]; ++j) {
+                        const long d = (long)diag->col[j] - (long)r0;
+                        if (d < -32768 || d > 32767) { near = false; break; }
+                    }
+                }
+                if (near) {
+                    win_ptr.assign(ngroups + 1, 0u);
+                    win_runs.assign((size_t)nr + 1, make_uint2(0u, 0u));
+                    bicg_window_plan(diag->ptr, diag->col, nrows, kGroupRows, group_is_sell.data(), kJagwMaxSlots, 0u, win_ptr.data(),
+                                     reinterpret_cast<unsigned int *>(win_runs.data()), &win_slots);
+                    win_list_mode = true;
+                    ok = true;
+                }
+            }
         }
         if (!ok) {                          // some group's window does not fit: no windows for this block
             want_win = false; win_slots = 0; win_runs.clear(); win_ptr.clear();
@@ -1159,9 +1184,39 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->win_runs = dev_upload(win_runs.data(), win_runs.size());
         c->win_slots = win_slots;
         for (uint32_t g = 0; g < ngroups; ++g) c->win_max_runs = std::max(c->win_max_runs, win_ptr[g + 1] - win_ptr[g]);
+        if (win_list_mode) {
+            // the runs spelled out, 16 bits per column (distance from the group's first row), two slots per word: word j of thread t
+            // (at lptr[g] + 256 j + t) holds slots t + 512 j (low half) and t + 512 j + 256 -- the slots thread t stages
+            std::vector<uint32_t> lptr(ngroups + 1, 0u);
+            std::vector<uint32_t> total(ngroups, 0u);
+            for (uint32_t g = 0; g < ngroups; ++g) {
+                uint32_t n = 0;
+                for (uint32_t r = win_ptr[g]; r < win_ptr[g + 1]; ++r) n += win_runs[r].y & 0xFFFFu;
+                total[g] = n;
+                lptr[g + 1] = lptr[g] + kGroupRows * ((n + 2u * kGroupRows - 1u) / (2u * kGroupRows));
+            }
+            std::vector<uint32_t> list((size_t)lptr[ngroups] + 8, 0u);
+            parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int) {
+                for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g) {
+                    uint32_t s = 0;
+                    for (uint32_t r = win_ptr[g]; r < win_ptr[g + 1]; ++r)
+                        for (uint32_t k = 0; k < (win_runs[r].y & 0xFFFFu); ++k, ++s) {
+                            const uint32_t d = (uint32_t)((int)(win_runs[r].x + k) - (int)(g * kGroupRows)) & 0xFFFFu;
+                            const uint32_t j = s / (2u * kGroupRows), rest = s % (2u * kGroupRows);
+                            uint32_t &w = list[(size_t)lptr[g] + (size_t)j * kGroupRows + rest % kGroupRows];
+                            w |= rest < kGroupRows ? d : d << 16;
+                        }
+                }
+            });
+            c->win_list = dev_upload(list.data(), list.size());
+            c->win_lptr = dev_upload(lptr.data(), lptr.size());
+            c->win_ltotal = dev_upload(total.data(), total.size());
+            c->device_matrix_bytes += 4ull * list.size() + 8ull * lptr.size();
+            c->matrix_bytes += 4ull * list.size() + 8ull * lptr.size();
+        }
         if (!perm.empty()) c->sell_perm = dev_upload(perm.data(), perm.size());
         c->device_matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
-        c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();
+        if (!win_list_mode) c->matrix_bytes += 4ull * win_ptr.size() + 8ull * win_runs.size();      // (the list-driven product reads the list, not the runs)
     }
     if (jag && sell_entries > 0) {
     // (with or without a window: the three-trip products of bicg_jagw.hip read one word per lane instead of two row pointers)
@@ -1557,7 +1612,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->sell_perm, c->lane_info, c->waitlog, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->win_list, c->win_lptr, c->win_ltotal, c->sell_perm, c->lane_info, c->waitlog, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);

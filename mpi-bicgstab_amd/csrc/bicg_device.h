@@ -274,6 +274,15 @@ struct SellDev {
     // runs any group's window has. Null when some row of a sliced group has more than 255 entries.
     const unsigned short *lane_info;
     uint32_t win_max_runs;
+    // List-driven window (one rank, round 6): the group's distinct columns one by one -- for numberings whose groups touch many
+    // SHORT runs (reverse Cuthill-McKee of a tetrahedral mesh: 59-170 runs of ~25 columns, too many descriptors to search per slot).
+    // 16 bits per column (distance from the group's first row), two slots per word: word win_list[win_lptr[g] + 256 j + t] holds
+    // the columns of slots t + 512 j (low half) and t + 512 j + 256 -- the slots thread t stages; win_ltotal[g] slots in all.
+    // k_spmv_jagw<.., LIST> loads its slots' columns instead of searching the runs; the runs (merged with gap 0) stay for
+    // k_spmv_sell's loop. Null: no list.
+    const uint32_t *win_list;
+    const uint32_t *win_lptr;
+    const uint32_t *win_ltotal;
     // Uniform slices (padded layouts): when all 64 rows of a slice are present, equally long and entry k of every row sits at
     // the SAME distance from its row -- every interior slice of a banded or stencil matrix -- the slice's columns are the list
     // uoff[ubase[slice] + k] (shared by all slices with the same list) and the SpMV does not read its col / col16 entries at
@@ -497,7 +506,7 @@ struct SpmmArgs {
 // which product kernels have been launched since the last reset (bicg_product_kernels: tests and bench.py assert on the kernel
 // a matrix gets, not only on the plan's flags)
 enum ProductKernel : unsigned { PK_SELL_PAD = 1, PK_SELL_JAG = 2, PK_SELL_WINLOOP = 4, PK_JAGW = 8, PK_STENCIL = 16, PK_CSR = 32, PK_ROWS = 64,
-                                PK_SELL_EPI = 128, PK_SELL_FW = 256, PK_JAGD = 512 };
+                                PK_SELL_EPI = 128, PK_SELL_FW = 256, PK_JAGD = 512, PK_JAGW_LIST = 1024 };
 extern unsigned g_product_kernels;
 
 // ---- launch wrappers (bicg_kernels.hip) ----

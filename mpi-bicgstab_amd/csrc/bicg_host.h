@@ -123,6 +123,7 @@ struct bicg_ctx {
     uint2 *win_runs = nullptr;
     unsigned char *sell_perm = nullptr;    // SellDev::perm
     unsigned short *lane_info = nullptr;   // SellDev::lane_info
+    uint32_t *win_list = nullptr, *win_lptr = nullptr, *win_ltotal = nullptr;     // list-driven window (SellDev::win_list)
     bool jagw_fast = true;                 // the three-trip product of bicg_jagw.hip (BICG_PLAN="jagw=0": k_spmv_sell's loop)
     uint32_t *glist_int = nullptr, *glist_bnd = nullptr;
     uint32_t ng_int = 0, ng_bnd = 0, sell_rows = 0;

@@ -73,8 +73,8 @@ __device__ __forceinline__ double jag_use(const JagBatch &B, uint32_t k0, uint32
 // Seven of those registers held tid + 256 k, hoisted out of the group loop; re-formed per group (an opaque copy of tid) every
 // variant fits into 89-95 registers without scratch: product back to back 45.1 -> 42.3 us, plain iteration 0.141 -> 0.134 ms,
 // CA 0.154 -> 0.151, pipelined 0.160 -> 0.155 on the FEM-like matrix.
-template <int NDOT, bool NT, int MODE>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) k_spmv_jagw(SpmvArgs a)
+template <int NDOT, bool NT, int MODE, bool LIST>
+__device__ __forceinline__ void jagw_body(const SpmvArgs &a)
 {
     constexpr int ND = NDOT > 0 ? NDOT : 1;
     const int done = a.S->done;
@@ -101,8 +101,8 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
     for (unsigned gq = gfirst; gq < gend && !done; ++gq) {
         const unsigned gi = a.reverse ? gfirst + (gend - 1u - gq) : gq;
         const unsigned g = a.glist ? a.glist[gi] : gi;
-        // ---- trip 1
-        const uint32_t w0 = a.sell.win_ptr[g], w1 = a.sell.win_ptr[g + 1];
+        // ---- trip 1 (LIST: the group's slots are positions in the list of its distinct columns, SellDev::win_list)
+        const uint32_t w0 = LIST ? a.sell.win_lptr[g] : a.sell.win_ptr[g], w1 = LIST ? a.sell.win_ltotal[g] : a.sell.win_ptr[g + 1];
         // (the block's last group may lack its last slices: their metadata does not exist -- no rows, no entries)
         const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
         const bool has_slice = slice * (uint32_t)kSliceRows < a.nrows;
@@ -111,9 +111,17 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
         const uint32_t row = g * kGroupRows + (info & 0xFFu), mylen = info >> 8;          // (rows past the block's last: length 0)
         const bool live = row < a.nrows;
         // ---- trip 2
-        const uint32_t nruns = w1 - w0;
+        const uint32_t nruns = LIST ? 0u : w1 - w0;
         uint2 myrun = make_uint2(0u, 0u);
-        if (lane < nruns) myrun = a.sell.win_runs[w0 + lane];
+        if (!LIST && lane < nruns) myrun = a.sell.win_runs[w0 + lane];
+        uint32_t lcol[LIST ? kJagSlots / 2 : 1];                   // LIST: the columns of this thread's slots, two 16-bit distances per word
+        if (LIST) {
+#pragma unroll
+            for (int j = 0; j < kJagSlots / 2; ++j) {
+                lcol[j] = 0u;
+                if (tid + (uint32_t)(2 * j) * kBlock < w1) lcol[j] = a.sell.win_list[w0 + (uint32_t)j * kBlock + tid];
+            }
+        }
         uint32_t pos = base;
         JagBatch A, B;
         jag_load<NT>(a, 0u, mylen, pos, A);
@@ -124,13 +132,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
         // ---- trip 3: the window. Thread t stages slots t, t + 256, ...; slot -> column over the run descriptors
         const uint32_t last = nruns ? nruns - 1u : 0u;
         const uint32_t lrun_y = (uint32_t)__builtin_amdgcn_readlane((int)myrun.y, (int)last);
-        const uint32_t total = nruns ? (lrun_y >> 16) + (lrun_y & 0xFFFFu) : 0u;
+        const uint32_t total = LIST ? w1 : (nruns ? (lrun_y >> 16) + (lrun_y & 0xFFFFu) : 0u);
         double xw[kJagSlots];
         uint32_t col[kJagSlots];
         uint32_t ts = tid;
         asm volatile("" : "+v"(ts));       // (the slots tid + 256 k are re-formed per group: hoisted out of the loop they hold seven registers)
 #pragma unroll
-        for (int k = 0; k < kJagSlots; ++k) col[k] = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, 0) + ts + (uint32_t)k * kBlock;
+        for (int k = 0; k < kJagSlots; ++k)
+            col[k] = LIST ? g * kGroupRows + (uint32_t)(int)(short)((k & 1) ? lcol[LIST ? k / 2 : 0] >> 16 : lcol[LIST ? k / 2 : 0] & 0xFFFFu)
+                          : (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, 0) + ts + (uint32_t)k * kBlock;
         for (uint32_t r = 1; r < nruns; ++r) {                    // wave-uniform: runs are in ascending slot order
             const uint32_t first = (uint32_t)__builtin_amdgcn_readlane((int)myrun.x, (int)r);
             const uint32_t slot0 = (uint32_t)__builtin_amdgcn_readlane((int)myrun.y, (int)r) >> 16;
@@ -176,6 +186,15 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 
         else reduce_publish<ND, MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + vb, sm, a.red.slot_base + bid);
     }
 }
+
+template <int NDOT, bool NT, int MODE>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(5, 8))) k_spmv_jagw(SpmvArgs a) { jagw_body<NDOT, NT, MODE, false>(a); }
+#ifndef JAGL_WAVES
+#define JAGL_WAVES 5
+#endif
+// the list-driven window holds its slots' columns (four registers: two 16-bit distances each) while the first batches are in flight
+template <int NDOT, bool NT, int MODE>
+__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JAGL_WAVES, 8))) k_spmv_jagl(SpmvArgs a) { jagw_body<NDOT, NT, MODE, true>(a); }
 
 // ---- the same product WITHOUT a window: x gathered through the caches ----------------------------------------------------------
 // For numberings whose 256-row groups touch many short runs of columns (reverse Cuthill-McKee of a tetrahedral mesh: up to 170 runs
@@ -400,7 +419,8 @@ bool launch_spmv_jagd(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0
 bool jagw_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo)
 {
     return a.sell.win_slots > 0 && a.sell.lane_info != nullptr && !with_offd && !fused_halo && a.fw.wf == 0 &&
-           a.sell.win_slots <= (uint32_t)(kBlock * kJagSlots) && a.sell.win_max_runs >= 1 && a.sell.win_max_runs <= kJagMaxRuns;
+           a.sell.win_slots <= (uint32_t)(kBlock * kJagSlots) && a.sell.win_max_runs >= 1 &&
+           (a.sell.win_max_runs <= kJagMaxRuns || a.sell.win_list != nullptr);
 }
 
 template <class K>
@@ -420,12 +440,14 @@ static void jagw_go(K kernel, const SpmvArgs &a, hipStream_t st, hipEvent_t e0, 
 bool launch_spmv_jagw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.nlist == 0) return false;
-    g_product_kernels |= PK_JAGW;
+    const bool list = a.sell.win_list != nullptr;
+    g_product_kernels |= list ? PK_JAGW_LIST : PK_JAGW;
     const bool nt = a.nt != 0;
     const int mode = red_mode(a.red, a.fin, ndot > 0);
 #define JAGW_MODE(ND, MD)                                                                 \
     do {                                                                                  \
-        if (nt) jagw_go(k_spmv_jagw<ND, true, MD>, a, st, e0, e1);                        \
+        if (list) { if (nt) jagw_go(k_spmv_jagl<ND, true, MD>, a, st, e0, e1); else jagw_go(k_spmv_jagl<ND, false, MD>, a, st, e0, e1); } \
+        else if (nt) jagw_go(k_spmv_jagw<ND, true, MD>, a, st, e0, e1);                   \
         else jagw_go(k_spmv_jagw<ND, false, MD>, a, st, e0, e1);                          \
     } while (0)
 #define JAGW_CASE(ND)                                                                     \

@@ -241,6 +241,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     a.sell.sdesc = c->s_desc; a.sell.all_lists = c->sell_all_lists ? 1 : 0; a.sell.uoff8 = c->s_uoff8; a.sell.ystride = c->sell_ystride;
     a.sell.st = c->st;
     a.sell.lane_info = c->jagw_fast ? c->lane_info : nullptr; a.sell.win_max_runs = c->win_max_runs;
+    a.sell.win_list = c->win_list; a.sell.win_lptr = c->win_lptr; a.sell.win_ltotal = c->win_ltotal;
     a.glist = nullptr;
     a.nrows = c->n_loc;
     a.diag = {c->d_val, c->d_col, c->d_ptr};

@@ -150,7 +150,7 @@ def lib():
 # The library's token-list variables (csrc/bicg_knobs.h): keyword -> (variable, token). INTEGRATION.md section 6 says what each does.
 SWITCHES = {k: ("BICG_PLAN", k.replace("_", "-")) for k in (
     "stencil", "lines", "planes", "ca_fuse", "layout", "window", "col16", "uniform", "constant", "masked", "desc", "lists", "jagw",
-    "spmm", "spmm_window", "fuse_pipe", "pipe_probe", "halo_fused")}
+    "spmm", "spmm_window", "fuse_pipe", "pipe_probe", "halo_fused", "window_list")}
 SWITCHES.update(persist=("BICG_PERSIST", "0"), persist_chunk=("BICG_PERSIST", "chunk"), persist_shifted=("BICG_PERSIST", "shifted"),
                 force_comm=("BICG_TEST", "force-comm"), spin_ticks=("BICG_TEST", "spin-ticks"),
                 p2p_fault_after=("BICG_TEST", "p2p-fault-after"), plan_collide=("BICG_TEST", "plan-collide"))
@@ -488,7 +488,7 @@ class Context:
 
 
 PRODUCT_KERNELS = {"sell_padded": 1, "sell_jagged": 2, "sell_window_loop": 4, "jagw": 8, "stencil": 16, "csr": 32, "rows": 64, "sell_epilogue": 128,
-                   "sell_window_fused": 256, "jagd": 512}
+                   "sell_window_fused": 256, "jagd": 512, "jagw_list": 1024}
 
 
 def product_kernels(reset: bool = True):

@@ -148,7 +148,7 @@ def test_bench_single_gpu_line_has_every_leg():
     # the product of the UNSTRUCTURED matrix (mesh.py, RCM numbering) as a second headline: per-kernel time by events, both byte
     # bases, counters; the kernel it ran on is on record, and so are the generator order and the random permutation
     ru = d["roofline_unstructured"]
-    assert ru and ru["numbering"] == "rcm" and ru["product_kernels"] == ["jagd"], ru
+    assert ru and ru["numbering"] == "rcm" and ru["product_kernels"] == ["jagw_list"], ru
     assert 0.45 < ru["frac"] < 1.0 and ru["survey_8d_frac"] > ru["frac"] and ru["traffic"] is not None, ru
     assert 0.85 * ru["format_bytes_per_launch"] < ru["traffic"] < 1.6 * ru["format_bytes_per_launch"], ru
     # north_star's bar on the stand-in for Transport.mtx: the product at >= 60 % of this GPU's measured copy rate on SURVEY 8d bytes
