@@ -1,0 +1,30 @@
+#!/bin/bash
+# Round 6's evidence from ONE build (the caller names the commit): kernel statistics of the headline, the three numberings of the mesh
+# matrix, the 512^3 Laplacian and the SpMM (rocprofv3 --kernel-trace --stats, one workload each), the bench line with the driver's
+# flags, the GPU suite. Run on the GPU box: gpurun -- 'bash tools/r6_evidence.sh'. Outputs under gpurun_out/r06/.
+cd /tmp && export TMPDIR=/tmp
+R=${GRAFT_REPO_ROOT:-/root/repo}
+OUT=$R/gpurun_out/r06
+rm -rf $OUT; mkdir -p $OUT
+QUIET="--steps 60 --warmup 10 --no-cpu-baseline --no-variants --no-extras --no-traffic --no-stream --regions 1"
+stats() {   # name, command...
+  local name=$1; shift
+  rm -rf /tmp/prof_$name
+  timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/prof_$name -o s --output-format csv -- "$@" > $OUT/$name.log 2>&1
+  f=$(find /tmp/prof_$name -name "*kernel_stats.csv" | head -1)
+  [ -n "$f" ] && cp $f $OUT/${name}_kernel_stats.csv
+}
+stats headline_plain python $R/bench.py $QUIET
+stats mesh_rcm_plain python $R/bench.py $QUIET --workload mesh --numbering rcm
+stats mesh_generator_plain python $R/bench.py $QUIET --workload mesh --numbering generator
+stats mesh_random_plain python $R/bench.py $QUIET --workload mesh --numbering random
+stats laplace512 python $R/tools/lap512_only.py
+stats spmm python $R/tools/spmm_only.py
+cd $R
+s=$(date +%s)
+python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
+echo "bench.py wall seconds: $(( $(date +%s) - s ))" >> $OUT/bench_stderr.txt
+cp bench_full.json $OUT/bench_full.json
+python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -12 > $OUT/gpu_suite.txt
+wc -c $OUT/bench_line.json; tail -2 $OUT/bench_stderr.txt; cat $OUT/gpu_suite.txt
+for f in $OUT/*_kernel_stats.csv; do echo "== $f"; head -6 $f | cut -c1-150; done
