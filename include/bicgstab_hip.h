@@ -365,7 +365,7 @@ unsigned int bicg_plan_collisions(bicg_ctx *ctx);
 /* Which product kernels this process has launched since the last call with reset != 0 (bit mask): 1 k_spmv_sell on padded slices,
  * 2 k_spmv_sell on jagged slices (columns gathered through the caches), 4 k_spmv_sell's loop over jagged slices with the x window
  * in LDS, 8 k_spmv_jagw (the three-trip form of that product, csrc/bicg_jagw.hip), 16 k_spmv_stencil, 32 k_spmv (CSR row blocks),
- * 64 k_spmv_rows (a row over several lanes), 128 a product with a pipelined phase in its epilogue, 256 the window-fused product,
+ * 64 k_spmv_rows (a row over several lanes), 128 a product with a pipelined phase in its epilogue,
  * 512 k_spmv_jagd (the three-trip product of jagged slices without a window: x gathered through the caches), 1024 k_spmv_jagw with a
  * list-driven window (the group's distinct columns one by one). Tests and bench.py assert on the kernel a matrix gets. */
 unsigned int bicg_product_kernels(int reset);

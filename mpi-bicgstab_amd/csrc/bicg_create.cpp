@@ -1318,7 +1318,6 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         bool mine = !off && persist_build(c, diag, optr, ocol, oval, send_idx, dst0, dstride);
         c->persist_on = all_ranks(comm, mine);
         if (const char *pp = knob_x("BICG_PERSIST_PLAIN")) c->persist_plain = atoi(pp) != 0;
-        if (const char *pp = knob_x("BICG_FUSE_PLAIN")) c->fuse_plain = atoi(pp) != 0;
         if (!c->persist_on && mine) { for (void *p : c->persist_mem) (void)hipFree(p); c->persist_mem.clear(); c->persist = PersistArgs{}; }
     }
 

@@ -353,26 +353,19 @@ struct Vecs {
     uint32_t n;
 };
 
-// Window-fused SpMV of plain BiCGStab on padded slices with 16-bit column offsets (k_spmv_sell_fw): the input vector is
-// not read from memory but FORMED while the columns a 256-row group touches are staged in LDS --
-//   wf 1:  q  = r - alpha s            (the my_daxpy of reference src/solver.c:94, then y = A q)
-//   wf 2:  p' = beta p + r - beta omega s   (src/solver.c:117-119, then s = A p')
-// which removes the two element-wise launches of the iteration, their vector traffic, and (wf 1) the read of the dot
-// operand. The columns of a group are g0 + row-in-group + d with d from a small set of offsets that falls into a few
-// clusters (Transport: {-13807..-13689}, {-118..118}, {13689..13807}); cluster k of every group is the window run
-// [g0 + lo_k, g0 + 255 + hi_k], so the LDS slot of an entry is  thread + d + bias_k  -- no per-group plan.
+// Clusters of column distances of a padded 16-bit block: the columns of a 256-row group are g0 + row-in-group + d with d from a
+// small set of offsets that falls into a few clusters (Transport: {-13807..-13689}, {-118..118}, {13689..13807}); cluster k of every
+// group is the window run [g0 + lo_k, g0 + 255 + hi_k], so the LDS slot of an entry is  thread + d + bias_k  -- no per-group plan.
+// Used by the SpMM kernels (k_spmm_win MODE 0, k_spmm_pipe). (Round 3's window-fused product of plain BiCGStab, which formed q and p
+// in such windows, was a negative result and left the tree in round 6: profiles/NOTES.md.)
 constexpr int kFwMaxClusters = 4;
 struct FusedWindow {
-    int wf;                          // 0: not fused
-    int ncl;                         // clusters of column offsets, ascending
+    int ncl;                         // clusters of column offsets, ascending (0: none)
     int lo[kFwMaxClusters], hi[kFwMaxClusters], bias[kFwMaxClusters];   // bias_k = slot0_k - lo_k
     unsigned slots;                  // LDS doubles of a window
-    const double *v0, *v1, *v2;      // wf 1: r, s ; wf 2: p, r, s
-    double *wout;                    // the formed vector (own rows): q / p'
 };
 
 struct SpmvArgs {
-    FusedWindow fw;
     SellDev sell;
     const uint32_t *glist;  // SELL launch: 256-row groups to process (null = groups 0..nlist-1)
     uint32_t nrows;         // local rows
@@ -506,7 +499,7 @@ struct SpmmArgs {
 // which product kernels have been launched since the last reset (bicg_product_kernels: tests and bench.py assert on the kernel
 // a matrix gets, not only on the plan's flags)
 enum ProductKernel : unsigned { PK_SELL_PAD = 1, PK_SELL_JAG = 2, PK_SELL_WINLOOP = 4, PK_JAGW = 8, PK_STENCIL = 16, PK_CSR = 32, PK_ROWS = 64,
-                                PK_SELL_EPI = 128, PK_SELL_FW = 256, PK_JAGD = 512, PK_JAGW_LIST = 1024 };
+                                PK_SELL_EPI = 128, PK_JAGD = 512, PK_JAGW_LIST = 1024 };
 extern unsigned g_product_kernels;
 
 // ---- launch wrappers (bicg_kernels.hip) ----
@@ -515,7 +508,6 @@ extern unsigned g_product_kernels;
 bool launch_spmv(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);        // CSR row-block stream
 bool launch_spmv_sell(const SpmvArgs &a, int ndot, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr,
                       bool fused_halo = false);   // sliced ELL; fused_halo: a.ll describes the in-kernel exchange
-bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // a.fw.wf = 1 / 2
 // plane-marching product of a 7-point grid stencil (bicg_stencil.hip; a.sell.st.on). epi = 1: CA-BiCGStab's q = r - alpha s,
 // y = w - alpha z, (q,y), (y,y) (reference src/solver.c:225-232) on the wavefront's own rows behind z = A s (a.epi.r / a.epi.w)
 // the ragged-rows product with three dependent trips per group (bicg_jagw.hip); jagw_fast_ok: this launch qualifies

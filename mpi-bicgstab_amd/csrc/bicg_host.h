@@ -72,12 +72,7 @@ struct bicg_ctx {
     double *d_val = nullptr, *o_val = nullptr;
     uint32_t *d_col = nullptr, *d_ptr = nullptr, *o_col = nullptr, *o_ptr = nullptr;
     uint4 *desc_int = nullptr, *desc_bnd = nullptr;   // CSR row-block descriptors: interior / halo-touching
-    FusedWindow fw{};                      // plain BiCGStab with the q / p updates formed in the SpMV's window (fw.ncl > 0: available)
-    bool fuse_plain = false;               // ... use it: BICG_FUSE_PLAIN=1. Off by default -- measured (profiles/NOTES.md, round 3): bit-identical
-                                           // to the five-launch iteration but not faster: forming q / p for the ~5.8 x 256 columns a Transport
-                                           // group touches costs the two products more (+12 us each) than the two launches it removes (8 + 7 us);
-                                           // on a narrow band (redundancy 1.06) it is a tie (146.2 vs 145.9 us)
-    int pl_flip = 0;                       // which of the ping-pong pairs (p | w), (s | z) holds the current p and s
+    FusedWindow fw{};                      // clusters of column distances of a padded 16-bit block (fw.ncl > 0): the windows of the SpMM kernels
     bool rowsplit = false;                 // long rows: the row blocks go to k_spmv_rows (a row spread over T lanes)
     short *d_col16 = nullptr;              // ... with CSR-order 16-bit column offsets when they fit
     uint32_t nblk = 0, n_int = 0, n_bnd = 0;
@@ -364,7 +359,7 @@ void group_flush(bicg_ctx *c);
 bool stencil_product(const bicg_ctx *c);
 bool hosted(const bicg_ctx *c);      // several ranks whose collectives the host enqueues (RCCL / host transports)
 void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin = Finish{}, int epi = 0,
-          Scal *S = nullptr, const FusedWindow *fw = nullptr);
+          Scal *S = nullptr);
 void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int phase = PH_NONE);
 void spmv_epi(bicg_ctx *c, double *xin, double *yout, int epi, int nd, int phase);
 void halo_only(bicg_ctx *c, double *xin);

@@ -370,7 +370,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(JAG
 bool jagd_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo)
 {
     // (x is addressed by 32-bit byte offsets: fewer than 2^28 rows)
-    return a.sell.jag && a.sell.win_slots == 0 && a.sell.lane_info != nullptr && !with_offd && !fused_halo && a.fw.wf == 0 &&
+    return a.sell.jag && a.sell.win_slots == 0 && a.sell.lane_info != nullptr && !with_offd && !fused_halo &&
            (a.sell.col16 != nullptr || a.sell.col != nullptr) && a.nrows < (1u << 28);
 }
 
@@ -418,7 +418,7 @@ bool launch_spmv_jagd(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0
 // can this launch go to k_spmv_jagw? (one rank's halo-free rows, the plan's per-lane words present, the window small enough)
 bool jagw_fast_ok(const SpmvArgs &a, bool with_offd, bool fused_halo)
 {
-    return a.sell.win_slots > 0 && a.sell.lane_info != nullptr && !with_offd && !fused_halo && a.fw.wf == 0 &&
+    return a.sell.win_slots > 0 && a.sell.lane_info != nullptr && !with_offd && !fused_halo &&
            a.sell.win_slots <= (uint32_t)(kBlock * kJagSlots) && a.sell.win_max_runs >= 1 &&
            (a.sell.win_max_runs <= kJagMaxRuns || a.sell.win_list != nullptr);
 }

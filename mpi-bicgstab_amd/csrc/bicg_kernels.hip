@@ -1078,123 +1078,6 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(4, 
     else if (!have && !done) wave_publish<ND>(acc, a.red.partial, a.red.slot_base + slot);
 }
 
-#ifdef BICG_EXPERIMENTS      // negative result of round 3, kept for reference (bicg_knobs.h; make EXPERIMENTS=1)
-// ------------------------------------------------------------------------------------------
-// Window-fused SpMV of plain BiCGStab (struct FusedWindow, bicg_device.h): padded slices, 16-bit offsets, single rank.
-// The row product and the fused dot epilogue are those of k_spmv_sell (same per-lane order, same partial per
-// workgroup), the formed vector is computed with the expressions of FPlainQ / FPlainP: results are bit-identical to
-// the five-launch iteration.
-// ------------------------------------------------------------------------------------------
-template <int WF>
-__device__ __forceinline__ double fw_value(const FusedWindow &f, uint32_t c, double alpha, double beta, double cbo)
-{
-    if (WF == 1) return f.v0[c] + (-alpha) * f.v1[c];                 // q = r - alpha s
-    double pp = beta * f.v0[c];                                       // p = beta p ; p += r ; p += (-beta omega) s
-    pp = pp + 1.0 * f.v1[c];
-    return pp + cbo * f.v2[c];
-}
-
-template <int NDOT, bool NT, int WF, int MODE>
-__global__ void __launch_bounds__(kBlock) k_spmv_sell_fw(SpmvArgs a)
-{
-    constexpr int U = 8;
-    const int done = a.S->done;
-    const double alpha = a.S->alpha, beta = a.S->beta, cbo = -a.S->beta * a.S->omega;
-    __shared__ double sm[5 * (NDOT > 0 ? NDOT : 1)];
-    double *win = dyn_lds;
-    const unsigned tid = threadIdx.x, lane = tid & 63u, wave = tid >> 6;
-    const FusedWindow &f = a.fw;
-    double acc[NDOT > 0 ? NDOT : 1];
-#pragma unroll
-    for (int d = 0; d < (NDOT > 0 ? NDOT : 1); ++d) acc[d] = 0.0;
-    for (unsigned g = blockIdx.x; g < a.nlist; g += gridDim.x) {
-        const long long g0 = (long long)g * kGroupRows;
-        __syncthreads();                                              // the previous group's reads of the window are done
-        {
-            // window slot w -> column g0 + w - bias_k of its cluster; every load of the (up to 8) slots of a thread is in
-            // flight before the first value is formed (slot by slot it was one memory round trip per slot and vector)
-            constexpr int SW = 8;                                     // 2048 slots / 256 threads
-            double t0[SW], t1[SW], t2[SW];
-            bool in[SW];
-#pragma unroll
-            for (int j = 0; j < SW; ++j) {
-                const int w = (int)tid + j * kBlock;
-                int b = f.bias[0];
-                if (f.ncl > 1 && w >= f.bias[1] + f.lo[1]) b = f.bias[1];
-                if (f.ncl > 2 && w >= f.bias[2] + f.lo[2]) b = f.bias[2];
-                if (f.ncl > 3 && w >= f.bias[3] + f.lo[3]) b = f.bias[3];
-                const long long c = g0 + (w - b);
-                in[j] = w < (int)f.slots && c >= 0 && c < (long long)a.nrows;
-                const uint32_t cc = in[j] ? (uint32_t)c : 0u;
-                t0[j] = f.v0[cc]; t1[j] = f.v1[cc];
-                t2[j] = WF == 2 ? f.v2[cc] : 0.0;
-            }
-#pragma unroll
-            for (int j = 0; j < SW; ++j) {
-                double val;
-                if (WF == 1) val = t0[j] + (-alpha) * t1[j];                           // q = r - alpha s
-                else { val = beta * t0[j]; val = val + 1.0 * t1[j]; val = val + cbo * t2[j]; }   // p = beta p ; += r ; += (-beta omega) s
-                if (in[j]) win[(int)tid + j * kBlock] = val;
-            }
-        }
-        __syncthreads();
-        const uint32_t row = (uint32_t)g0 + tid;
-        const bool live = row < a.nrows;
-        const uint32_t slice = g * (kGroupRows / kSliceRows) + wave;
-        uint32_t base = 0u, len = 0u, base16 = 0u;
-        if (slice * kSliceRows < a.nrows) { base = a.sell.slice_base[slice]; len = a.sell.slice_len[slice]; base16 = a.sell.slice_base16[slice]; }
-        const uint32_t mylen = live ? a.diag.ptr[row + 1] - a.diag.ptr[row] : 0u;
-        double sum = 0.0;
-        for (uint32_t k0 = 0; k0 < len; k0 += U) {
-            int sl[U];
-            double v[U];
-#pragma unroll
-            for (int q = 0; q < U / 4; ++q) {
-                const bool ok = k0 + 4 * q < len;                     // wave-uniform; the quad is padded
-                const i16x4 *p = reinterpret_cast<const i16x4 *>(a.sell.col16) + ((size_t)base16 / 4 + (size_t)((k0 / 4) + q) * kSliceRows + lane);
-                i16x4 dq = (i16x4)(0);
-                if (ok) dq = NT ? __builtin_nontemporal_load(p) : *p;
-                const int dd[4] = {(int)dq.x, (int)dq.y, (int)dq.z, (int)dq.w};
-#pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    int b = f.bias[0];
-                    if (f.ncl > 1 && dd[e] >= f.lo[1]) b = f.bias[1];
-                    if (f.ncl > 2 && dd[e] >= f.lo[2]) b = f.bias[2];
-                    if (f.ncl > 3 && dd[e] >= f.lo[3]) b = f.bias[3];
-                    sl[4 * q + e] = (int)tid + dd[e] + b;              // padding (d = 0) reads this thread's own column
-                }
-            }
-#pragma unroll
-            for (int e = 0; e < U; ++e) {
-                const bool ok = k0 + e < len;
-                const uint32_t j = base + (k0 + e) * kSliceRows + lane;
-                v[e] = ok ? (NT ? __builtin_nontemporal_load(a.sell.val + j) : a.sell.val[j]) : 0.0;
-            }
-            double xv[U];
-#pragma unroll
-            for (int e = 0; e < U; ++e) xv[e] = win[sl[e]];
-#pragma unroll
-            for (int e = 0; e < U; ++e)
-                if (k0 + e < mylen) sum += v[e] * xv[e];              // stored order; padding never added
-        }
-        const double yi = 0.0 + sum;
-        if (live) {
-            int b0 = f.bias[0];                                        // offset 0 is always inside a cluster
-            if (f.ncl > 1 && 0 >= f.lo[1]) b0 = f.bias[1];
-            if (f.ncl > 2 && 0 >= f.lo[2]) b0 = f.bias[2];
-            if (f.ncl > 3 && 0 >= f.lo[3]) b0 = f.bias[3];
-            const double me = win[(int)tid + b0];                      // the formed vector at this row (kept: x / r update, next products)
-            if (!done) { a.y[row] = yi; f.wout[row] = me; }
-            if (NDOT >= 1) {
-                const double ume = WF == 1 ? me : a.u[row];           // (q,y): the operand was just formed
-                acc[0] += ume * yi;
-                if (NDOT == 2) acc[NDOT >= 2 ? 1 : 0] += yi * yi;
-            }
-        }
-    }
-    if (NDOT > 0 && !done) reduce_publish<(NDOT > 0 ? NDOT : 1), MODE == RED_TICKET_HEAVY>(acc, a.S, a.red, a.red.slot_base + blockIdx.x, sm);
-}
-#endif
 
 static inline int sell_layout(const SellDev &d)
 {
@@ -1291,26 +1174,6 @@ bool launch_spmv_sell_pad32(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD3
 bool launch_spmv_sell_epi_pad32(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD32>(a, n, with_offd, st, e0, e1, fused_halo); }
 #endif
 #if PART_IS(2)
-#ifdef BICG_EXPERIMENTS
-bool launch_spmv_sell_fw(const SpmvArgs &a, int ndot, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
-{
-    if (a.nlist == 0 || a.fw.wf == 0) return false;
-    dim3 g(sell_grid(a.nlist, a.groups_per_wg)), b(kBlock);
-    const unsigned lds = a.fw.slots * (unsigned)sizeof(double);
-    const bool nt = a.nt != 0;
-#define FW_GO(ND, WFV)                                                                                         \
-    do {                                                                                                       \
-        if (nt) launch_timed_lds(k_spmv_sell_fw<ND, true, WFV, RED_TICKET>, g, b, lds, st, e0, e1, a);        \
-        else launch_timed_lds(k_spmv_sell_fw<ND, false, WFV, RED_TICKET>, g, b, lds, st, e0, e1, a);          \
-    } while (0)
-    if (a.fw.wf == 1) { if (ndot == 2) FW_GO(2, 1); else if (ndot == 1) FW_GO(1, 1); else FW_GO(0, 1); }
-    else { if (ndot == 2) FW_GO(2, 2); else if (ndot == 1) FW_GO(1, 2); else FW_GO(0, 2); }
-#undef FW_GO
-    return true;
-}
-#else
-bool launch_spmv_sell_fw(const SpmvArgs &, int, hipStream_t, hipEvent_t, hipEvent_t) { return false; }      // (not in this build)
-#endif
 bool launch_spmv_sell_pad16(SELL_PART_ARGS) { return sell_launch_layout<LAY_PAD16>(a, n, with_offd, st, e0, e1, fused_halo); }
 bool launch_spmv_sell_epi_pad16(SELL_PART_ARGS) { return sell_epi_launch_layout<LAY_PAD16>(a, n, with_offd, st, e0, e1, fused_halo); }
 #endif

@@ -7,8 +7,7 @@
 //                                is covered by a test that says what differs; the table is in INTEGRATION.md section 6.
 //   knob_x("BICG_..."):          measurement knobs of the development rounds -- A/B settings whose outcome is on record in
 //                                profiles/NOTES.md, negative results kept for reference. They are read only by a library built
-//                                with `make EXPERIMENTS=1` (-DBICG_EXPERIMENTS); the default build has their defaults compiled in
-//                                and does not contain the kernel only they can select (k_spmv_sell_fw).
+//                                with `make EXPERIMENTS=1` (-DBICG_EXPERIMENTS); the default build has their defaults compiled in.
 #pragma once
 
 #include <cstdlib>

@@ -229,11 +229,10 @@ bool stencil_product(const bicg_ctx *c)
 // workgroup as (0 + sum_diag) + sum_offd, the reference's order.
 // fin: a dot group of earlier kernels that the first kernel launched here finishes (grp_for_spmv).
 void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Reduce red, Finish fin, int epi,
-          Scal *S, const FusedWindow *fw)
+          Scal *S)
 {
     Section sec(c, SEC_SPMV);      // halo exchange and the joins of deferred all-reduces included
     SpmvArgs a;
-    a.fw = fw ? *fw : FusedWindow{};
     a.fin = fin;
     a.epi = c->v;
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
@@ -269,11 +268,11 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
     // previous one ended finds the most recently streamed part of the matrix still cached, while cyclic forward passes
     // evict it just before it is needed. Rows, hence results of the product, are unaffected; the dot partials of a
     // reversed launch land in mirrored slots (a different, equally fixed association).
-    a.reverse = (c->sell_alt && c->single() && !fw) ? (c->spmv_dir ^= 1) : 0;
+    a.reverse = (c->sell_alt && c->single()) ? (c->spmv_dir ^= 1) : 0;
     // the plane-marching product (bicg_stencil.hip) takes the rank's halo-free planes in one launch of its own tiling; across ranks
     // the halo-touching planes follow behind the exchange through the slice-by-slice kernel, as separate launches (never the
     // launch with the exchange inside)
-    const bool stencil = stencil_product(c) && !fw && (epi == 0 || epi == 3) && !a.has_shift;
+    const bool stencil = stencil_product(c) && (epi == 0 || epi == 3) && !a.has_shift;
     if (epi == 3 && !(stencil && c->single())) die("internal", "CA-BiCGStab's fused q / y epilogue without the plane-marching product");
     const unsigned g_si = stencil ? stencil_grid(c->st) : sell_grid(c->ng_int, a.groups_per_wg), g_ci = spmv_grid(c->n_int);
     const unsigned g_sb = sell_grid(c->ng_bnd, a.groups_per_wg), g_cb = spmv_grid(c->n_bnd);
@@ -332,9 +331,6 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
         if (epi && !stencil) {
             a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
             took(launch_spmv_sell_epi(a, epi, false, c->sc, ev(0), ev(1)));
-        } else if (fw) {
-            a.glist = nullptr; a.nlist = c->ng_int; a.red.slot_base = 0;
-            took(launch_spmv_sell_fw(a, ndot, c->sc, ev(0), ev(1)));
         } else {
             interior();
         }
@@ -609,34 +605,8 @@ struct Driver {
         group_flush(c);
     }
 
-    // plain BiCGStab with q = r - alpha s and p = r + beta (p - omega s) formed in the windows of the two products (struct
-    // FusedWindow): three launches per iteration. p and s alternate between two buffers each (a workgroup forms the values
-    // of rows other workgroups own, so nothing it reads may be overwritten by the launch), q has its own.
-    bool fused_plain() const
-    {
-        return c->fuse_plain && c->fw.ncl > 0 && c->single() && c->glist_all && c->nblk == 0 && c->glist_int_identity && c->sell_gpw_dots == 1;
-    }
-    void iter_plain_fused()
-    {
-        double *pa = c->pl_flip ? v.w : v.p, *pb = c->pl_flip ? v.p : v.w;
-        double *sa = c->pl_flip ? v.z : v.s, *sb = c->pl_flip ? v.s : v.z;
-        FusedWindow f = c->fw;
-        f.wf = 2; f.v0 = pa; f.v1 = v.r; f.v2 = sa; f.wout = pb;
-        spmv(c, pb, sb, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1), Finish{}, 0, nullptr, &f);   // p', s = A p', (r#,s) -> alpha
-        group_now(c, 1, PH_PLAIN_ALPHA);
-        f.wf = 1; f.v0 = v.r; f.v1 = sb; f.v2 = nullptr; f.wout = v.t;
-        spmv(c, v.t, v.y, 2, v.t, c->red(0, PH_OMEGA, true, 2), Finish{}, 0, nullptr, &f);         // q, y = A q, (q,y), (y,y) -> omega
-        group_now(c, 2, PH_OMEGA);
-        Vecs vv = v;
-        vv.p = pb;
-        launch_plain_xr(vv, here(), c->red(0, PH_PLAIN_END, true, 2), v.t);                        // x, r, (r,r), (r#,r) -> beta, k++
-        group_now(c, 2, PH_PLAIN_END);
-        c->pl_flip ^= 1;
-    }
-
     void iter_plain()   // reference src/solver.c:88-119
     {
-        if (fused_plain()) { iter_plain_fused(); return; }
         spmv(c, v.p, v.s, 1, v.rh, c->red(0, PH_PLAIN_ALPHA, true, 1));   // s = A p, (r#,s) -> alpha
         group_now(c, 1, PH_PLAIN_ALPHA);
         launch_plain_q(v, here());                              // q = r - alpha s
@@ -792,7 +762,6 @@ void run_begin(bicg_ctx *c, int method, const bicg_options *opt_in)
     c->wave_mode = method >= BICG_PIPE_BICGSTAB;
     c->grp = bicg_ctx::Group{};
     c->f1_done = false;
-    c->pl_flip = 0;
     c->spmv_dir = 0;             // every solve starts in the same direction (its first product toggles this to 1 = reversed):
                                  // run-to-run bit reproducibility, also with several groups per workgroup
     // Matrix stream policy. The Infinity Cache (256 MiB) is shared by the matrix stream and the

@@ -488,7 +488,7 @@ class Context:
 
 
 PRODUCT_KERNELS = {"sell_padded": 1, "sell_jagged": 2, "sell_window_loop": 4, "jagw": 8, "stencil": 16, "csr": 32, "rows": 64, "sell_epilogue": 128,
-                   "sell_window_fused": 256, "jagd": 512, "jagw_list": 1024}
+                   "jagd": 512, "jagw_list": 1024}
 
 
 def product_kernels(reset: bool = True):

@@ -307,34 +307,6 @@ def test_device_ingest_matches_host():
         assert d.cols == hi - lo and o.cols == A.cols
 
 
-@pytest.mark.gpu
-def test_window_fused_plain_iteration_is_bit_identical(monkeypatch):
-    """BICG_FUSE_PLAIN=1: q = r - alpha s and p = r + beta (p - omega s) are formed while the SpMV stages the columns of a
-    256-row group in LDS (k_spmv_sell_fw: three launches per iteration instead of five; off by default, it is not faster --
-    profiles/NOTES.md). Same expressions, same row sums, same dot partials: x, r and the alpha / omega / beta / (r,r) trace
-    are bit-identical to the five-launch iteration, also across chunk boundaries."""
-    from mpi_bicgstab_amd import hipsolver as H
-    if not H.lib().bicg_has_experiments():
-        pytest.skip("a negative result kept for reference: compiled in by `make EXPERIMENTS=1` only (csrc/bicg_knobs.h)")
-    H.lib().bicg_comm_init_single(0)
-    A = synth.from_offsets(300007, (0, 1, -1, 117, -117, 118, -118, 13689, -13689, 13807, -13807), diag_base=14.0, seed=6)
-    out = {}
-    for fuse in ("0", "1"):
-        monkeypatch.setenv("BICG_FUSE_PLAIN", fuse)
-        monkeypatch.setenv("BICG_PERSIST", "0")
-        ctx = H.Context(H.single_rank_blocks(A))
-        assert ctx.flags()["col16"] and ctx.flags()["all_sell"] and not ctx.flags()["jagged"]
-        b = ctx.spmv(np.ones(A.rows))
-        got = ctx.solve("bicgstab", b, tol=1e-12, check_every=3)
-        out[fuse] = (got["k"], got["x"].copy(), got["r"].copy(), ctx.trace(got["k"]))
-        ctx.close()
-    assert out["0"][0] == out["1"][0] > 5
-    assert np.array_equal(out["0"][1], out["1"][1]) and np.array_equal(out["0"][2], out["1"][2])
-    for key in ("alpha", "omega", "beta", "dotr"):
-        assert np.array_equal(out["0"][3][key], out["1"][3][key]), key
-    assert np.abs(out["1"][1] - 1.0).max() <= 1e-8
-
-
 def test_section_times_account_for_the_iteration(capfd):
     """bicg_options.time_kernels & 2 -- the reference's MEASURE_SECTION_TIME (src/shifted_solver.c:77-81, 132-154, 230-247;
     src/shifted_switching_solver.c:9) on the device clock. Timing must not change the arithmetic (same kernels: the

@@ -240,8 +240,14 @@ def test_hot_kernels_stay_lean():
     assert len(rows) >= 12, len(rows)
     for k in rows:
         assert kernels[k]["VGPRs"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] == 8 and kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
-    for k in [k for k in kernels if "k_spmv_sell_fw" in k]:
-        assert kernels[k]["VGPRs"] <= 88 and kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
+    # round 6: the three-trip ragged products at five wavefronts per SIMD without scratch (run-driven and list-driven windows, no window)
+    for name in ("k_spmv_jagwI", "k_spmv_jaglI", "k_spmv_jagdI"):
+        ks = [k for k in kernels if name in k]
+        assert len(ks) >= 12, (name, len(ks))
+        for k in ks:
+            assert kernels[k]["VGPRs"] <= 96 and kernels[k]["ScratchSize [bytes/lane]"] == 0 and kernels[k]["Occupancy [waves/SIMD]"] >= 5, (k, kernels[k])
+    pipe = [k for k in kernels if "k_spmm_pipeI" in k]
+    assert len(pipe) == 2 and all(kernels[k]["ScratchSize [bytes/lane]"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] >= 2 for k in pipe), pipe
 
 
 def test_window_plan_does_not_depend_on_the_number_of_threads():
