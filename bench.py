@@ -252,7 +252,7 @@ def measure_traffic(argv_inner, note):
         return (1024.0 * sum(vals) / len(vals), len(vals)) if vals else (None, 0)
 
     # the in-solver SpMV with its dot epilogue (sliced-ELL kernel, or the ragged-rows product of bicg_jagw.hip)
-    dots = lambda nm: any(k in nm for k in ("k_spmv_sell<1", "k_spmv_sell<2", "k_spmv_jagw<1", "k_spmv_jagw<2", "k_spmv_jagd<1", "k_spmv_jagd<2"))
+    dots = lambda nm: any(k in nm for k in ("k_spmv_sell<1", "k_spmv_sell<2", "k_spmv_jagw<1", "k_spmv_jagw<2", "k_spmv_jagd<1", "k_spmv_jagd<2", "k_spmv_jagl<1", "k_spmv_jagl<2"))
     fetch, nf = per_launch("FETCH_SIZE", dots)
     write, nw = per_launch("WRITE_SIZE", dots)
     qf, _ = per_launch("FETCH_SIZE", lambda nm: "FPlainQ" in nm)

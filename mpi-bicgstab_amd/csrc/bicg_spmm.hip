@@ -53,11 +53,11 @@ __device__ __forceinline__ unsigned dma_slot(const FusedWindow &cl, unsigned tid
     return (unsigned)((int)tid + d + bias);
 }
 
-template <bool OFFD>
+template <bool OFFD, int TR>
 __device__ __forceinline__ void dma_meta(const SpmmArgs &a, unsigned g, unsigned tid, unsigned wave, SpmmMeta &M)
 {
-    const uint32_t row = g * kGroupRows + tid;
-    const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g * (kGroupRows / kSliceRows) + wave));     // scalar loads below
+    const uint32_t row = g * (uint32_t)TR + tid;
+    const uint32_t slice = (uint32_t)__builtin_amdgcn_readfirstlane((int)(g * (uint32_t)(TR / kSliceRows) + wave));     // scalar loads below
     const bool live = row < a.nrows;
     M.base = 0u; M.len = 0u; M.base16 = 0u;
     if (slice * kSliceRows < a.nrows) {       // (scalar loads: they do not take part in the vector memory counter)
@@ -111,19 +111,20 @@ __device__ __forceinline__ void dma_finish(const SpmmArgs &a, const SpmmMeta &M,
 // have the step's products to land behind. (The same copies through the DMA path, global_load_lds 16 bytes per lane, no staging
 // registers: 243 us per launch against 203 -- that path delivered 16 GB/s per CU here, 4.1 TB/s chip-wide for the gigabyte of
 // windows a launch stages. profiles/r06/spmm_notes.txt)
-constexpr int kStageJ = 3;         // pairs per thread and vector: windows of up to 1 536 slots
+template <int TR> struct StageShape { static constexpr int J = TR == 256 ? 3 : 2; };      // pairs per thread and vector: windows of up to 1 536 (2 048) slots
 typedef double spmm_f64x2 __attribute__((ext_vector_type(2)));
-struct SpmmStage { spmm_f64x2 t[kStageJ][kDmaNV]; };
-__device__ __forceinline__ void stage_load(const SpmmArgs &a, unsigned g, int v0, unsigned tid, SpmmStage &T)
+template <int TR> struct SpmmStage { spmm_f64x2 t[StageShape<TR>::J][kDmaNV]; };
+template <int TR>
+__device__ __forceinline__ void stage_load(const SpmmArgs &a, unsigned g, int v0, unsigned tid, SpmmStage<TR> &T)
 {
-    const int g0 = (int)(g * kGroupRows), last = (int)a.nrows;
-    const int n0 = (kGroupRows + a.cl.hi[0] - a.cl.lo[0]) / 2;
-    const int n1 = a.cl.ncl > 1 ? n0 + (kGroupRows + a.cl.hi[1] - a.cl.lo[1]) / 2 : n0;
-    const int n2 = a.cl.ncl > 2 ? n1 + (kGroupRows + a.cl.hi[2] - a.cl.lo[2]) / 2 : n1;
-    const int n3 = a.cl.ncl > 3 ? n2 + (kGroupRows + a.cl.hi[3] - a.cl.lo[3]) / 2 : n2;
+    const int g0 = (int)(g * (unsigned)TR), last = (int)a.nrows;
+    const int n0 = (TR + a.cl.hi[0] - a.cl.lo[0]) / 2;
+    const int n1 = a.cl.ncl > 1 ? n0 + (TR + a.cl.hi[1] - a.cl.lo[1]) / 2 : n0;
+    const int n2 = a.cl.ncl > 2 ? n1 + (TR + a.cl.hi[2] - a.cl.lo[2]) / 2 : n1;
+    const int n3 = a.cl.ncl > 3 ? n2 + (TR + a.cl.hi[3] - a.cl.lo[3]) / 2 : n2;
 #pragma unroll
-    for (int j = 0; j < kStageJ; ++j) {
-        const int f = (int)tid + j * kBlock;
+    for (int j = 0; j < StageShape<TR>::J; ++j) {
+        const int f = (int)tid + j * TR;
         // the pair's first column: cluster by position, distance = lo_k + 2 (f - pairs before the cluster)
         int d = a.cl.lo[0] + 2 * f;
         if (f >= n0) d = a.cl.lo[1] + 2 * (f - n0);
@@ -138,12 +139,13 @@ __device__ __forceinline__ void stage_load(const SpmmArgs &a, unsigned g, int v0
         }
     }
 }
-__device__ __forceinline__ void stage_store(const SpmmArgs &a, double *dst, unsigned tid, const SpmmStage &T)
+template <int TR>
+__device__ __forceinline__ void stage_store(const SpmmArgs &a, double *dst, unsigned tid, const SpmmStage<TR> &T)
 {
     const unsigned W = a.wslots, pairs = (W - 2u) / 2u;
 #pragma unroll
-    for (int j = 0; j < kStageJ; ++j) {
-        const unsigned f = tid + (unsigned)j * kBlock;
+    for (int j = 0; j < StageShape<TR>::J; ++j) {
+        const unsigned f = tid + (unsigned)j * (unsigned)TR;
         if (f < pairs) {
 #pragma unroll
             for (int v = 0; v < kDmaNV; ++v) *reinterpret_cast<spmm_f64x2 *>(dst + (size_t)v * W + 2u * f) = T.t[j][v];
@@ -151,11 +153,11 @@ __device__ __forceinline__ void stage_store(const SpmmArgs &a, double *dst, unsi
     }
 }
 
-template <bool OFFD>
-__global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_pipe(SpmmArgs a)
+template <bool OFFD, int TR>
+__global__ void __launch_bounds__(TR) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_pipe(SpmmArgs a)
 {
     constexpr int NV = kDmaNV, K = kDmaHead, U = 8;
-    __shared__ double sm[(kBlock / 64) * NV];
+    __shared__ double sm[(TR / 64) * NV];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
     const unsigned W = a.wslots;
     double *const buf0 = spmm_lds, *const buf1 = spmm_lds + (size_t)NV * W;
@@ -194,11 +196,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     SpmmMeta M0, MN0;
     SpmmHead H0;
     SpmmRaw N;
-    dma_meta<OFFD>(a, gfirst, tid, wave, M0);
+    dma_meta<OFFD, TR>(a, gfirst, tid, wave, M0);
     dma_vals(a, M0, lane, N);
-    SpmmStage T;
-    stage_load(a, gfirst, 0, tid, T);
-    stage_store(a, buf0, tid, T);
+    SpmmStage<TR> T;
+    stage_load<TR>(a, gfirst, 0, tid, T);
+    stage_store<TR>(a, buf0, tid, T);
     dma_finish(a, M0, N, tid, H0);
     MN0 = M0;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -211,7 +213,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     // one step: group g, pass p out of the current buffer; (ng, np): the step after it (ng = ~0u: none); rawm: the metadata of the
     // group whose row heads are to be requested in this step (want_raw)
     auto run = [&](SpmmHead &H, const SpmmMeta M, unsigned g, int p, unsigned ng, int np, bool want_raw, const SpmmMeta rawm) {
-        const uint32_t row = g * kGroupRows + tid;
+        const uint32_t row = g * (uint32_t)TR + tid;
         const bool live = row < a.nrows;
         const int v0 = p * NV, nv = a.nvec - v0 < NV ? a.nvec - v0 : NV;
         double *const cur = (step & 1u) ? buf1 : buf0, *const nxt = (step & 1u) ? buf0 : buf1;
@@ -221,7 +223,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
         for (int v = 0; v < NV; ++v) sg[v] = (a.sigma && v < nv) ? a.sigma[v0 + v] : 0.0;
         // ---- what later steps need: row heads (raw), then the next step's window
         if (want_raw) dma_vals(a, rawm, lane, N);
-        if (ng != 0xFFFFFFFFu) stage_load(a, ng, np * NV, tid, T);
+        if (ng != 0xFFFFFFFFu) stage_load<TR>(a, ng, np * NV, tid, T);
         // ---- the previous step's results
         if (prev_row != 0xFFFFFFFFu && a.ys) {
 #pragma unroll
@@ -305,12 +307,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
             __syncthreads();
             if ((int)tid < nv) {
                 double t = sm[tid];
-                for (int w = 1; w < kBlock / 64; ++w) t += sm[w * NV + tid];
+                for (int w = 1; w < TR / 64; ++w) t += sm[w * NV + tid];
                 a.partial[(size_t)g * kSpmmCols + v0 + tid] = t;
             }
         }
         // ---- hand-over: the next step's window has landed, nobody reads this step's buffer any more
-        if (ng != 0xFFFFFFFFu) stage_store(a, nxt, tid, T);
+        if (ng != 0xFFFFFFFFu) stage_store<TR>(a, nxt, tid, T);
         __syncthreads();
     };
 
@@ -319,7 +321,7 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
         const bool more = g + gstride < gend;
         for (int p = 0; p < npass; ++p) {
             const bool last = p + 1 == npass;
-            if (p == 0 && more) dma_meta<OFFD>(a, g + gstride, tid, wave, MN0);       // the next group's metadata, in front of everything this step asks for
+            if (p == 0 && more) dma_meta<OFFD, TR>(a, g + gstride, tid, wave, MN0);       // the next group's metadata, in front of everything this step asks for
             run(H0, M0, g, p, !last ? g : (more ? g + gstride : none), !last ? p + 1 : 0, last && more, MN0);
         }
         if (more) { M0 = MN0; dma_finish(a, M0, N, tid, H0); }
@@ -332,23 +334,23 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
 }
 
 // Padded slices with 16-bit offsets in clusters (col16 is complete: uniform / constant lists are not needed), and a window that
-// fits two buffers of 4 vectors and three pairs per thread. The clusters are re-laid for 16-byte copies: every run starts at an
-// even distance and an even slot and holds an even number of columns.
-bool spmm_pipe_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
+// fits two buffers of 4 vectors and the pairs a thread stages. The clusters are re-laid for 16-byte copies: every run starts at an
+// even distance and an even slot and holds an even number of columns. `tile` rows per workgroup (= its threads): 256 or 512.
+bool spmm_pipe_plan(const SpmmArgs &a, int tile, FusedWindow &out, unsigned &wslots)
 {
     if (a.cl.ncl <= 0 || a.sell.jag || a.sell.win_slots || !a.sell.col16 || !a.sell.slice_base16) return false;
     FusedWindow f = a.cl;
     int slots = 0;
     for (int k = 0; k < f.ncl; ++k) {
-        // the run of cluster k covers the distances lo .. hi for rows 0 .. 255 of the group: columns g0 + lo .. g0 + 255 + hi, i.e.
-        // 256 + hi - lo of them -- even when lo and hi are
+        // the run of cluster k covers the distances lo .. hi for rows 0 .. tile - 1 of the workgroup: columns g0 + lo .. g0 + tile - 1
+        // + hi, i.e. tile + hi - lo of them -- even when lo and hi are
         f.lo[k] = a.cl.lo[k] & ~1;                       // rounds towards minus infinity (two's complement)
         f.hi[k] = (a.cl.hi[k] + 1) & ~1;
-        if (k > 0 && f.lo[k] <= f.hi[k - 1] + kGroupRows) return false;
+        if (k > 0 && f.lo[k] <= f.hi[k - 1] + tile) return false;
         f.bias[k] = slots - f.lo[k];
-        slots += kGroupRows + f.hi[k] - f.lo[k];
+        slots += tile + f.hi[k] - f.lo[k];
     }
-    if (slots > 2 * kStageJ * kBlock) return false;      // three 16-byte pairs per thread and vector (stage_load)
+    if (slots > 2 * (tile == 256 ? 3 : 2) * tile) return false;      // the 16-byte pairs a thread stages per vector (StageShape)
     slots += 2;                                          // the last slot of a window holds 0.0 (dma_finish); even count
     if ((size_t)2 * kDmaNV * (size_t)slots * 8u > 158u * 1024u) return false;
     f.slots = (unsigned)slots;
@@ -356,15 +358,15 @@ bool spmm_pipe_plan(const SpmmArgs &a, FusedWindow &out, unsigned &wslots)
     return true;
 }
 
-// Two workgroups per CU are resident (80 KB of LDS each): 512, all of them from the start. Marching through consecutive groups in
-// step with a workgroup one cluster distance ahead (so that its near window is this one's far window) was tried and measured
-// no gain (profiles/r06/spmm_notes.txt); the cyclic order within an XCD is what the kernel uses.
-static void spmm_pipe_shape(const SpmmArgs &a, unsigned &grid, double &gstep)
+// Resident workgroups: two per CU with 256-row tiles (80 KB of LDS each), one with 512-row tiles (129 KB): all of them from the
+// start, an XCD's workgroups taking its tiles cyclically. (Marching through consecutive groups in step with a workgroup one cluster
+// distance ahead was tried and measured no gain: profiles/r06/spmm_notes.txt.)
+static void spmm_pipe_shape(const SpmmArgs &a, unsigned ntiles, unsigned resident, unsigned &grid, double &gstep)
 {
-    grid = a.ngroups <= 512u ? ((a.ngroups + 7u) & ~7u) : 512u;
+    grid = ntiles <= resident ? ((ntiles + 7u) & ~7u) : resident;
     gstep = 0.0;                                                               // cyclic within the XCD's eighth
-    if (const char *v = test_tok("spmm-gstep")) {                              // (measurement: consecutive groups per workgroup, in thousandths)
-        const double s = 1e-3 * atof(v), ng = (double)a.ngroups;
+    if (const char *v = test_tok("spmm-gstep")) {                              // (measurement: consecutive tiles per workgroup, in thousandths)
+        const double s = 1e-3 * atof(v), ng = (double)ntiles;
         if (s >= 1.0) {
             unsigned g = (unsigned)(ng / s) + 1u;
             while ((double)(g - 1u) * s >= ng) --g;
@@ -379,26 +381,34 @@ hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st)
     SpmmArgs a = a0;
     FusedWindow f;
     unsigned W = 0;
-    if (!spmm_pipe_plan(a0, f, W)) return hipErrorInvalidValue;
+    // 512-row tiles (BICG_TEST="spmm-tile=512") stage 3.9 x the vectors instead of 4.9 x -- the clusters' spans are shared by twice
+    // the rows -- but one 129 KB workgroup per CU has nobody to take turns with: 217 us against 203 (profiles/r06/spmm_notes.txt)
+    int tile = 256;
+    if (const char *v = test_tok("spmm-tile")) tile = atoi(v) == 512 ? 512 : 256;
+    if (tile == 512 && !spmm_pipe_plan(a0, 512, f, W)) tile = 256;
+    if (tile == 256 && !spmm_pipe_plan(a0, 256, f, W)) return hipErrorInvalidValue;
     a.cl = f; a.wslots = W;
+    const unsigned ntiles = (a0.nrows + (unsigned)tile - 1u) / (unsigned)tile, ngroups_all = a0.ngroups;
+    a.ngroups = ntiles;                                                         // the kernel counts tiles
     unsigned grid = 0;
-    spmm_pipe_shape(a, grid, a.gstep);
+    spmm_pipe_shape(a, ntiles, tile == 256 ? 512u : 256u, grid, a.gstep);
     const unsigned lds = 2u * (unsigned)kDmaNV * W * 8u;
-    // one row of partial sums per GROUP (not per workgroup); the column sums run over spmm_grid() rows: the few beyond the last group are zero
-    if (a.b) (void)hipMemsetAsync(a.partial + (size_t)a.ngroups * kSpmmCols, 0, sizeof(double) * 8 * kSpmmCols, st);
+    // one row of partial sums per TILE (not per workgroup); the column sums run over spmm_grid(groups) rows: those beyond the last tile are zero
+    if (a.b) (void)hipMemsetAsync(a.partial + (size_t)ntiles * kSpmmCols, 0, sizeof(double) * ((size_t)ngroups_all + 8 - ntiles) * kSpmmCols, st);
     auto go = [&](auto kernel) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         (void)hipGetLastError();
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, a);
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3((unsigned)tile), lds, st, a);
         return hipGetLastError();
     };
-    return with_offd ? go(k_spmm_pipe<true>) : go(k_spmm_pipe<false>);
+    if (tile == 512) return with_offd ? go(k_spmm_pipe<true, 512>) : go(k_spmm_pipe<false, 512>);
+    return with_offd ? go(k_spmm_pipe<true, 256>) : go(k_spmm_pipe<false, 256>);
 }
 
 void preload_spmm_kernels()
 {
     hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_pipe<false>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_pipe<false, 256>));
     (void)hipGetLastError();
 }
 
