@@ -247,7 +247,7 @@ def test_hot_kernels_stay_lean():
         for k in ks:
             assert kernels[k]["VGPRs"] <= 96 and kernels[k]["ScratchSize [bytes/lane]"] == 0 and kernels[k]["Occupancy [waves/SIMD]"] >= 5, (k, kernels[k])
     pipe = [k for k in kernels if "k_spmm_pipeI" in k]
-    assert len(pipe) == 2 and all(kernels[k]["ScratchSize [bytes/lane]"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] >= 2 for k in pipe), pipe
+    assert len(pipe) == 4 and all(kernels[k]["ScratchSize [bytes/lane]"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] >= 2 for k in pipe), pipe
 
 
 def test_window_plan_does_not_depend_on_the_number_of_threads():
