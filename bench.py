@@ -169,6 +169,8 @@ def compact(full):
                 out[k] = {"ms": v["ms"], "bound": v.get("bound"), "frac": v.get("frac")}
         if "ms_per_iteration" in e:
             out.update(ms_per_iteration=e["ms_per_iteration"], bound=e.get("bound"), frac=e.get("frac"))
+        elif "ms" in e and "bound" in e:        # a leg that is one kernel (the SpMM)
+            out.update(ms=e["ms"], bound=e.get("bound"), frac=e.get("frac"))
         return out
 
     cfg = full.get("config", {})
@@ -702,7 +704,26 @@ def main():
             gb = ib / (variants[key] * 1e-3) / 1e9
             variant_roof[key] = dict(ms_per_iteration=variants[key], algorithmic_bytes=ib, gbps=gb,
                                      **roof(ib, variants[key] * 1e-3, csr_bytes(nnz_global, n), leg.ctx.spmv_matrix_bytes(), 2, plan["rows"], 2 * nsh + 6, [], stream, world))
+    # BASELINE.json configs[4] "batched SpMV": Y_j = (A + sigma_j I) X_j for 16 vectors in one pass over the matrix (the reference's
+    # per-shift verification loop, src/test_shifted.c:129-154), device time of the pass
+    spmm_leg = None
+    if world == 1 and not a.no_variants and not a.inner and leg.ctx.flags().get("spmm"):
+        stage[0] = "SpMM leg"
+        nsh = 16
+        X = np.random.default_rng(16).standard_normal((nsh, plan["rows"]))
+        sg = (np.arange(nsh) + 1.0) * 0.01 / nsh
+        leg.ctx.spmm(X, sg)
+        ms_mm = min(leg.ctx.spmm(X, sg)[1] for _ in range(3))
+        b8d = csr_bytes(nnz_global, n) + 2 * nsh * 8 * n
+        bfmt = leg.ctx.spmv_matrix_bytes() + 2 * nsh * 8 * n
+        spmm_leg = dict(ms=ms_mm, vectors=nsh, kernel=leg.ctx.last_spmm_kind(), bound="hbm", peak=HBM_PEAK_GBS,
+                        frac=bfmt / (ms_mm * 1e-3) / 1e9 / HBM_PEAK_GBS, format_bytes=bfmt, survey_8d_bytes=b8d,
+                        survey_8d_frac=b8d / (ms_mm * 1e-3) / 1e9 / HBM_PEAK_GBS, spmv_equivalents=None)
+        del X
     spmv_alone_ms = leg.ctx.spmv_bench(200)
+    if spmm_leg:
+        spmm_leg["spmv_equivalents"] = spmm_leg["ms"] / spmv_alone_ms
+        note(f"SpMM of 16 vectors: {1e3 * spmm_leg['ms']:.1f} us ({spmm_leg['kernel']}), {spmm_leg['spmv_equivalents']:.1f} x one product")
     # roofline leg: the same K iterations, every SpMV kernel launched with its own start/stop HIP events
     # (hipExtLaunchKernelGGL on the library's compute stream): kernel durations, no launch gaps. It comes after
     # the other timed legs of this matrix: event-timed launches put the queue into a profiling mode whose switch
@@ -796,6 +817,8 @@ def main():
 
     # ------------------------------------------------------------------ the other workloads north_star names
     extras = {}
+    if spmm_leg:
+        extras["spmm_16_vectors"] = spmm_leg
     if not a.no_extras and a.workload == "transport" and not a.n and not a.matrix:
         def extra(name, wl2, methods, steps, kernel_roofline=False):
             stage[0] = f"extra workload {name}"

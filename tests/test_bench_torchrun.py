@@ -157,6 +157,9 @@ def test_bench_single_gpu_line_has_every_leg():
     assert on["generator"]["product_kernels"] == ["jagw"] and on["generator"]["avg_launch_ms"] < ru["avg_launch_ms"] * 1.05, on
     assert on["random"]["product_kernels"] == ["jagd"] and on["random"]["avg_launch_ms"] > 3 * ru["avg_launch_ms"], on
     assert on["random"]["traffic"] > 3 * on["random"]["format_bytes_per_launch"] and "cache line" in on["random"]["bottleneck"], on
+    # BASELINE.json configs[4] "batched SpMV": 16 vectors through the pipelined SpMM, well below 16 single products
+    mm = d["extras"]["spmm_16_vectors"]
+    assert mm["kernel"] == "pipelined" and mm["vectors"] == 16 and 0.25 < mm["frac"] < 1.0 and mm["spmv_equivalents"] < 8.5, mm
     assert d["extras"]["laplace7_512_ca"]["plane_marching_product"]["on"] == 1
     assert math.isfinite(d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["true_relres_after_timed_region"])
     for key in ("banded_b8", "banded_b64", "banded_b512", "mesh_rcm", "mesh_generator", "mesh_random", "laplace7_256_ca", "laplace7_512_ca", "transport_rank_of_8"):
