@@ -717,7 +717,7 @@ def main():
         b8d = csr_bytes(nnz_global, n) + 2 * nsh * 8 * n
         bfmt = leg.ctx.spmv_matrix_bytes() + 2 * nsh * 8 * n
         spmm_leg = dict(ms=ms_mm, vectors=nsh, kernel=leg.ctx.last_spmm_kind(), bound="hbm", peak=HBM_PEAK_GBS,
-                        frac=bfmt / (ms_mm * 1e-3) / 1e9 / HBM_PEAK_GBS, format_bytes=bfmt, survey_8d_bytes=b8d,
+                        frac=bfmt / (ms_mm * 1e-3) / 1e9 / HBM_PEAK_GBS, format_bytes=bfmt, algorithmic_bytes=b8d, survey_8d_bytes=b8d,
                         survey_8d_frac=b8d / (ms_mm * 1e-3) / 1e9 / HBM_PEAK_GBS, spmv_equivalents=None)
         del X
     spmv_alone_ms = leg.ctx.spmv_bench(200)
