@@ -308,6 +308,15 @@ def fullsize_worker(rank, world, port, kind, outdir):
         assert flags["p2p"] == p2p
         if mesh_kind:
             assert flags["jagged"] and info["sell_padding"] == 0, (flags, info)       # ragged rows across ranks: jagged slices, no padding
+            if p2p:
+                # ranks of 4 M non-zeros and more take the exchange as separate launches: their halo-free rows go through the
+                # three-trip products (csrc/bicg_jagw.hip); smaller ranks keep the launch with the exchange inside
+                big = info["nnz_diag"] >= 4_000_000
+                assert flags["ll_fused"] == (not big), (flags, info["nnz_diag"])
+                H.product_kernels()
+                ctx.spmv(np.ones(nl))
+                ran = H.product_kernels()
+                assert (("jagd" in ran or "jagw" in ran) == big), (ran, info["nnz_diag"])
         if p2p and not mesh_kind:
             assert flags["ll_fused"], "banded slab: the halo exchange must be folded into the SpMV launch"
         if grid:

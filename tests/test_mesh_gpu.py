@@ -91,3 +91,23 @@ def test_first_iterations_against_the_oracle(case):
         for key in ("alpha", "omega", "beta", "dotr"):
             np.testing.assert_allclose(tr[key], orc[key], rtol=1e-6, err_msg=f"{kind} {method} {key}")
         assert np.abs(got["x"] - orc["x"]).max() <= 1e-6 * np.abs(orc["x"]).max(), (kind, method)
+
+
+def test_shifted_solve_on_the_list_driven_window(case):
+    """the shifted products (A + sigma_seed I) x of src/shifted_solver.c:259-260 through the same kernels: 4 shifts, 6 iterations of
+    shifted_lopbicgstab against the oracle's seed scalars and two of its solutions (RCM numbering: the list-driven window)"""
+    kind, A, (row, col, val), ctx = case
+    if kind != "rcm":
+        pytest.skip("one numbering is enough: the shift rides in the product's epilogue whatever the layout")
+    sigma, seed = np.array([0.01, 0.02, 0.03, 0.04]), 1
+    b = ctx.spmv(np.ones(A.rows)) + sigma[seed] * np.ones(A.rows)
+    H.product_kernels()
+    got = ctx.solve_shifted(b, sigma, seed, tol=0.0, max_iter=6, check_every=6, which="shifted_lopbicgstab")
+    assert "jagw_list" in H.product_kernels()
+    orc = O.solve_shifted(A.rows, row, col, val, b, sigma, seed, tol=0.0, max_iter=6, which="shifted_lopbicgstab")
+    assert got["k"] == orc["k"] == 6
+    tr = ctx.trace(6)
+    for key in ("alpha", "omega", "beta", "dotr"):
+        np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=key)
+    for j in (0, 3):
+        assert np.abs(got["x"][j] - orc["x"][j]).max() <= 1e-8 * np.abs(orc["x"][j]).max(), j

@@ -99,11 +99,12 @@ def test_fullsize_partition_against_oracle(matrix, world, kind):
 
 
 @pytest.mark.parametrize("numbering,world,kind", [("rcm", 8, "host-p2p"), ("rcm", 8, "host"), ("random", 8, "host-p2p"), ("random", 8, "host"),
-                                                  ("generator", 8, "host-p2p")])
+                                                  ("generator", 8, "host-p2p"), ("rcm", 2, "host-p2p"), ("generator", 2, "host-p2p")])
 def test_unstructured_mesh_partition_against_oracle(numbering, world, kind, tmp_path_factory):
     """The unstructured FEM matrix (mpi_bicgstab_amd.mesh: 1 601 613 ragged rows, the stand-in for Transport.mtx) in the reference's
     row partition (src/matrix.c:295-308) across ranks sharing the GPU: RCM numbering at 8 ranks through both transports (halo = the
-    neighbouring level sets), the random permutation likewise (every rank needs nearly all of x: the halo IS the vector). Distributed
+    neighbouring level sets), the random permutation likewise (every rank needs nearly all of x: the halo IS the vector); at 2 ranks
+    (800 k rows each) the exchange runs as separate launches and the halo-free rows go through k_spmv_jagd / k_spmv_jagw (asserted). Distributed
     SpMV bit-exact against the oracle at the same P (src/matrix.c:428-441), first 8 iterations of the four solvers against its
     alpha / omega / beta / (r,r)."""
     from mpi_bicgstab_amd import mesh
