@@ -537,7 +537,12 @@ static int parse_threaded(const char *p, const char *end, mtx_header *h, unsigne
                 jobs[t].max_entries = (unsigned long)(h->nz - before);
                 parse_job_run(&jobs[t]);
             }
-            if (jobs[t].rc) { rc = jobs[t].rc; fputs(jobs[t].h.err, stderr); break; }
+            if (jobs[t].rc) {     /* (a byte range of the MPI mode, nz unknown: the caller decides whether the line counts -- it may lie behind the nz-th) */
+                rc = jobs[t].rc;
+                if (h->nz != (unsigned long)-1) fputs(jobs[t].h.err, stderr);
+                memcpy(h->err, jobs[t].h.err, sizeof h->err);
+                break;
+            }
             before += jobs[t].h.lines;
         }
         if (!rc && h->nz != (unsigned long)-1 && before < h->nz) { fprintf(stderr, "ERROR: reading matrix data.\n"); rc = 6; }     /* the reference's message, src/matrix.c:318 */
@@ -788,9 +793,25 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
     {   /* A malformed range must stop every rank, not leave the others in the collectives below; so must a file with FEWER
          * entry lines than its banner says (the reference's error, src/matrix.c:315-318). MORE lines: the reference reads the
          * first nz and never looks at the rest -- a prefix sum of the ranks' line counts finds the rank whose range holds the
-         * nz-th line (it reads its range again up to that line); the ranks behind it drop theirs. (A malformed line behind the
-         * nz-th one is still refused in this mode: a range that failed does not know how many lines it held.) */
-        unsigned long long mine = rc ? 0ull : h.lines, before = 0, lines = 0;
+         * nz-th line (it reads its range again up to that line); the ranks behind it drop theirs. That includes lines that do
+         * not parse: the FIRST range that failed knows how many entries lie in front of it (every earlier range parsed) -- if
+         * those are nz or more, it and everything behind it is never looked at, like in the reference; otherwise it reads its
+         * range again up to the nz-th entry, and only a failure of THAT is an error. */
+        int first_fail = rc ? me : np;
+        MPI_Allreduce(MPI_IN_PLACE, &first_fail, 1, MPI_INT, MPI_MIN, MPI_COMM_WORLD);
+        unsigned long long mine = me < first_fail ? h.lines : 0ull, before = 0, lines = 0;
+        MPI_Allreduce(&mine, &lines, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);      /* entries in front of the first failed range */
+        if (first_fail < np && me >= first_fail) {
+            for (int i = 0; i < nseg; ++i) free(segs[i].t);
+            free(segs); segs = NULL; nseg = 0;
+            h.emitted = 0; h.lines = 0; rc = 0;
+            if (me == first_fail && lines < (unsigned long long)banner_nz) {
+                h.nz = (unsigned long)((unsigned long long)banner_nz - lines);
+                rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);
+                h.nz = banner_nz;
+                mine = rc ? 0ull : h.lines;
+            }
+        }
         MPI_Exscan(&mine, &before, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
         if (me == 0) before = 0;
         MPI_Allreduce(&mine, &lines, 1, MPI_UNSIGNED_LONG_LONG, MPI_SUM, MPI_COMM_WORLD);
@@ -800,17 +821,20 @@ int bicg_mtx_load_block_mpi_part(const char *path, int part, CSR_Matrix *diag, C
             if (me == 0) fprintf(stderr, "ERROR: reading matrix data: %llu entry lines, the banner says %lu.\n", lines, (unsigned long)h.nz);
             any = 6;
         }
+        int again = 0;
         if (!any && lines > (unsigned long long)h.nz && before + mine > (unsigned long long)h.nz) {
             for (int i = 0; i < nseg; ++i) free(segs[i].t);
             free(segs); segs = NULL; nseg = 0;
             h.emitted = 0; h.lines = 0;
             if (before < (unsigned long long)h.nz) {
                 h.nz = (unsigned long)((unsigned long long)banner_nz - before);
-                rc = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);   /* lines it has read once already */
+                again = parse_threaded(p, q, &h, 0u, (unsigned)h.m, nt, &segs, &nseg);   /* lines it has read once already */
                 h.nz = banner_nz;
-                if (rc) { fprintf(stderr, "ERROR: reading matrix data (second pass of rank %d).\n", me); MPI_Abort(MPI_COMM_WORLD, 1); }
+                if (again) fprintf(stderr, "ERROR: reading matrix data (second pass of rank %d).\n", me);
             }
         }
+        MPI_Allreduce(MPI_IN_PLACE, &again, 1, MPI_INT, MPI_MAX, MPI_COMM_WORLD);      /* every rank returns the error, none is left in a collective */
+        if (!any && again) any = again;
         free(buf);
         if (any) { for (int i = 0; i < nseg; ++i) free(segs[i].t); free(segs); return any; }
     }

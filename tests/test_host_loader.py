@@ -320,6 +320,20 @@ def test_entry_count_and_index_range_do_not_depend_on_threads(tmp_path):
             rows, ncols, d, o = _read(str(tmp_path / "o"), rank)
             ed, eo, counts, _ = _expected(A.rows, row, col, val, 2, rank)
             assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[2], ed.val) and np.array_equal(o[2], eo.val), threads
+    # ... and in the byte-range (MPI) mode: the first range that does not parse knows how many entries lie in front
+    # of it; nz or more, and it is never looked at
+    for world, threads in ((2, "2"), (3, "1"), (4, "3"), (8, "1")):
+        out = run(junk, world, "mpi", threads)
+        assert out.returncode == 0 and "ERROR" not in out.stderr, (world, threads, out.stderr)
+        for rank in range(world):
+            rows, ncols, d, o = _read(str(tmp_path / "o"), rank)
+            ed, eo, counts, _ = _expected(A.rows, row, col, val, world, rank)
+            assert np.array_equal(d[0], ed.ptr) and np.array_equal(d[2], ed.val) and np.array_equal(o[2], eo.val), (world, threads)
+    # a malformed line among the FIRST nz entries is an error in every mode, on every rank (no rank left behind in a collective)
+    broken = write("broken.mtx", lines[:200] + ["this is not an entry\n"] + lines[200:])
+    for mode, world in (("serial", 2), ("mpi", 2), ("mpi", 5)):
+        out = run(broken, world, mode, "2")
+        assert out.returncode != 0 and "ERROR: reading matrix data" in out.stderr, (mode, world, out.stderr)
     short = write("short.mtx", lines[:-5])
     for mode, threads in (("serial", "1"), ("serial", "4"), ("mpi", "2")):
         out = run(short, 2, mode, threads)
