@@ -8,16 +8,16 @@
 // dependent trips (slice metadata, row heads, staging of pass 1, sigma, staging of pass 2, ...) with two workgroups per CU to
 // overlap them -- and it issued 70 M vector instructions, 11.6 per entry and vector (LDS address from slot and vector, a 64-bit
 // select per product for the "row has this entry" bit). Here:
-//   * a step = one 256-row group x 4 vectors. The x window of the NEXT step is asked for at the beginning of a step (16-byte loads
-//     into registers: the clusters' runs start at even columns and even slots) and written to the OTHER of two LDS buffers at the
+//   * a step = one tile of 512 (or 256) rows x 2 vectors; two (three) workgroups per CU take turns. The x window of the NEXT step is asked for at the
+//     beginning of a step (16-byte loads into registers: the clusters' runs start at even columns and even slots) and written to the OTHER of two LDS buffers at the
 //     step's end, behind its products;
 //   * a workgroup is persistent: an XCD owns an eighth of the groups and its workgroups take them cyclically, so that at any time
 //     they work on neighbouring groups whose windows overlap in the L2 (1.28 -> 0.80 GB from the memory side per launch);
-//   * the head of the next group's rows (first 16 entries: all of a Transport-shaped row) is loaded, raw, in the last step of the
-//     current group and converted behind that step's barrier; its metadata a group ahead, by scalar loads;
+//   * the head of a group's rows (first 16 entries: all of a Transport-shaped row) stays in registers across the group's 8 steps; its
+//     metadata is loaded a group ahead, by scalar loads (prefetching the heads too costs the registers of the third workgroup);
 //   * a step's results are stored at the beginning of the next step; the step's shifts are requested at its beginning;
 //   * an entry the row does not have is value 0.0 at the window's ZERO slot: products without predicates, one add per LDS address.
-// 316 -> 203 us per 16 vectors (634 MB of matrix + X + Y: 0.39 of 8 TB/s), every column bit-identical.
+// 316 -> 175 us per 16 vectors (634 MB of matrix + X + Y: 0.45 of 8 TB/s), every column bit-identical.
 // Arithmetic: per row and vector the products are added in stored order, one rounding per product and per sum, y = 0 + that sum,
 // then the offd part, then sigma_j x_j -- bit for bit k_spmm_win's, i.e. bicg_spmv's column by column (tests/test_full_size.py,
 // tests/test_shifted.py, across ranks tests/test_multirank.py).
@@ -34,7 +34,30 @@ namespace bicg {
 extern __shared__ double spmm_lds[];
 typedef short spmm_i16x4 __attribute__((ext_vector_type(4)));
 
-constexpr int kDmaNV = 4;          // vectors per step: two buffers of 4 x 1 248 slots = 80 KB, two workgroups per CU
+// Shape of a step (compile-time; measured with 16 vectors on the Transport-shaped matrix, kernel time by rocprofv3,
+// profiles/r06/spmm_notes.txt): vectors per step x resident workgroups per CU x next group's row heads prefetched or not
+//   4 x 2 x yes  203-206 us (225 registers)      4 x 2 x no  208 us
+//   2 x 3 x no   184-186 us (145 registers, 40 KB of LDS per workgroup)   <- 256-row tiles
+//   2 x 2 workgroups of 512 rows: 175 us (128 registers + 20 bytes of scratch, 64 KB of LDS)   <- the default where the window fits
+//   2 x 3 x yes  spills (168 registers + 60 bytes)      2 x 4 x no  218 us (128 registers + 60 bytes of scratch)      1 x 4 x no  219 us
+// Smaller steps let a third workgroup per CU take turns with the other two; without the prefetch the heads of a group's rows are
+// waited for once per 8 steps.
+#ifndef SPMM_NV
+#define SPMM_NV 2
+#endif
+#ifndef SPMM_RESIDENT
+#define SPMM_RESIDENT 768
+#endif
+#ifndef SPMM_WAVES
+#define SPMM_WAVES 3
+#endif
+#ifndef SPMM_PREFETCH_HEAD
+#define SPMM_PREFETCH_HEAD 0
+#endif
+#ifndef SPMM_RESIDENT512
+#define SPMM_RESIDENT512 512
+#endif
+constexpr int kDmaNV = SPMM_NV;    // vectors per step: two buffers of 2 x 1 248 slots = 40 KB, three workgroups per CU
 constexpr int kDmaHead = 16;       // entries of a row kept in registers across the passes of its group
 
 // what a group's rows need before their entries can be asked for (loaded a whole group ahead) ...
@@ -154,7 +177,7 @@ __device__ __forceinline__ void stage_store(const SpmmArgs &a, double *dst, unsi
 }
 
 template <bool OFFD, int TR>
-__global__ void __launch_bounds__(TR) __attribute__((amdgpu_waves_per_eu(2, 4))) k_spmm_pipe(SpmmArgs a)
+__global__ void __launch_bounds__(TR) __attribute__((amdgpu_waves_per_eu(TR == 512 ? 4 : SPMM_WAVES, 4))) k_spmm_pipe(SpmmArgs a)
 {
     constexpr int NV = kDmaNV, K = kDmaHead, U = 8;
     __shared__ double sm[(TR / 64) * NV];
@@ -322,9 +345,13 @@ __global__ void __launch_bounds__(TR) __attribute__((amdgpu_waves_per_eu(2, 4)))
         for (int p = 0; p < npass; ++p) {
             const bool last = p + 1 == npass;
             if (p == 0 && more) dma_meta<OFFD, TR>(a, g + gstride, tid, wave, MN0);       // the next group's metadata, in front of everything this step asks for
-            run(H0, M0, g, p, !last ? g : (more ? g + gstride : none), !last ? p + 1 : 0, last && more, MN0);
+            run(H0, M0, g, p, !last ? g : (more ? g + gstride : none), !last ? p + 1 : 0, SPMM_PREFETCH_HEAD && last && more, MN0);
         }
-        if (more) { M0 = MN0; dma_finish(a, M0, N, tid, H0); }
+        if (more) {
+            M0 = MN0;
+            if (!SPMM_PREFETCH_HEAD) dma_vals(a, M0, lane, N);       // (waited for right here: once per group)
+            dma_finish(a, M0, N, tid, H0);
+        }
     }
     if (prev_row != 0xFFFFFFFFu && a.ys) {
 #pragma unroll
@@ -358,7 +385,7 @@ bool spmm_pipe_plan(const SpmmArgs &a, int tile, FusedWindow &out, unsigned &wsl
     return true;
 }
 
-// Resident workgroups: two per CU with 256-row tiles (80 KB of LDS each), one with 512-row tiles (129 KB): all of them from the
+// Resident workgroups: three per CU with 256-row tiles (40 KB of LDS, 145 registers each), one with 512-row tiles: all of them from the
 // start, an XCD's workgroups taking its tiles cyclically. (Marching through consecutive groups in step with a workgroup one cluster
 // distance ahead was tried and measured no gain: profiles/r06/spmm_notes.txt.)
 static void spmm_pipe_shape(const SpmmArgs &a, unsigned ntiles, unsigned resident, unsigned &grid, double &gstep)
@@ -381,23 +408,28 @@ hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st)
     SpmmArgs a = a0;
     FusedWindow f;
     unsigned W = 0;
-    // 512-row tiles (BICG_TEST="spmm-tile=512") stage 3.9 x the vectors instead of 4.9 x -- the clusters' spans are shared by twice
-    // the rows -- but one 129 KB workgroup per CU has nobody to take turns with: 217 us against 203 (profiles/r06/spmm_notes.txt)
-    int tile = 256;
-    if (const char *v = test_tok("spmm-tile")) tile = atoi(v) == 512 ? 512 : 256;
+    // 512-row tiles stage 3.9 x the vectors instead of 4.9 x (the clusters' spans are shared by twice the rows); with two vectors per
+    // step two such workgroups (64 KB of LDS, 128 registers, 8 wavefronts each) are resident per CU: 175 us against 185 for three
+    // 256-row workgroups. BICG_TEST="spmm-tile=256" selects the latter; a window too long for 512-row tiles falls back to it.
+    int tile = 512;
+    if (const char *v = test_tok("spmm-tile")) tile = atoi(v) == 256 ? 256 : 512;
     if (tile == 512 && !spmm_pipe_plan(a0, 512, f, W)) tile = 256;
     if (tile == 256 && !spmm_pipe_plan(a0, 256, f, W)) return hipErrorInvalidValue;
     a.cl = f; a.wslots = W;
     const unsigned ntiles = (a0.nrows + (unsigned)tile - 1u) / (unsigned)tile, ngroups_all = a0.ngroups;
     a.ngroups = ntiles;                                                         // the kernel counts tiles
     unsigned grid = 0;
-    spmm_pipe_shape(a, ntiles, tile == 256 ? 512u : 256u, grid, a.gstep);
+    spmm_pipe_shape(a, ntiles, tile == 256 ? (unsigned)SPMM_RESIDENT : (unsigned)SPMM_RESIDENT512, grid, a.gstep);
     const unsigned lds = 2u * (unsigned)kDmaNV * W * 8u;
     // one row of partial sums per TILE (not per workgroup); the column sums run over spmm_grid(groups) rows: those beyond the last tile are zero
     if (a.b) (void)hipMemsetAsync(a.partial + (size_t)ntiles * kSpmmCols, 0, sizeof(double) * ((size_t)ngroups_all + 8 - ntiles) * kSpmmCols, st);
     auto go = [&](auto kernel) {
-        (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
-        (void)hipGetLastError();
+        static bool raised = false;       // (one flag per instantiation of this lambda's call operator: the attribute call is a host round trip)
+        if (!raised) {
+            (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
+            (void)hipGetLastError();
+            raised = true;
+        }
         hipLaunchKernelGGL(kernel, dim3(grid), dim3((unsigned)tile), lds, st, a);
         return hipGetLastError();
     };
@@ -408,7 +440,7 @@ hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st)
 void preload_spmm_kernels()
 {
     hipFuncAttributes at;
-    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_pipe<false, 256>));
+    (void)hipFuncGetAttributes(&at, reinterpret_cast<const void *>(k_spmm_pipe<false, 512>));
     (void)hipGetLastError();
 }
 
