@@ -38,7 +38,9 @@ typedef short spmm_i16x4 __attribute__((ext_vector_type(4)));
 // profiles/r06/spmm_notes.txt): vectors per step x resident workgroups per CU x next group's row heads prefetched or not
 //   4 x 2 x yes  203-206 us (225 registers)      4 x 2 x no  208 us
 //   2 x 3 x no   184-186 us (145 registers, 40 KB of LDS per workgroup)   <- 256-row tiles
-//   2 x 2 workgroups of 512 rows: 175 us (128 registers + 20 bytes of scratch, 64 KB of LDS)   <- the default where the window fits
+//   2 x 2 workgroups of 512 rows: 175 us (128 registers + 20 bytes of scratch, 64 KB of LDS)
+//   ... and the next group's metadata asked for after the last step instead of in front of the first (SPMM_PREFETCH_META 0: 127
+//   registers, no scratch): 155-156 us   <- the default where the window fits
 //   2 x 3 x yes  spills (168 registers + 60 bytes)      2 x 4 x no  218 us (128 registers + 60 bytes of scratch)      1 x 4 x no  219 us
 // Smaller steps let a third workgroup per CU take turns with the other two; without the prefetch the heads of a group's rows are
 // waited for once per 8 steps.
@@ -53,6 +55,9 @@ typedef short spmm_i16x4 __attribute__((ext_vector_type(4)));
 #endif
 #ifndef SPMM_PREFETCH_HEAD
 #define SPMM_PREFETCH_HEAD 0
+#endif
+#ifndef SPMM_PREFETCH_META
+#define SPMM_PREFETCH_META 0
 #endif
 #ifndef SPMM_RESIDENT512
 #define SPMM_RESIDENT512 512
@@ -344,10 +349,11 @@ __global__ void __launch_bounds__(TR) __attribute__((amdgpu_waves_per_eu(TR == 5
         const bool more = g + gstride < gend;
         for (int p = 0; p < npass; ++p) {
             const bool last = p + 1 == npass;
-            if (p == 0 && more) dma_meta<OFFD, TR>(a, g + gstride, tid, wave, MN0);       // the next group's metadata, in front of everything this step asks for
+            if (SPMM_PREFETCH_META && p == 0 && more) dma_meta<OFFD, TR>(a, g + gstride, tid, wave, MN0);       // the next group's metadata, in front of everything this step asks for
             run(H0, M0, g, p, !last ? g : (more ? g + gstride : none), !last ? p + 1 : 0, SPMM_PREFETCH_HEAD && last && more, MN0);
         }
         if (more) {
+            if (!SPMM_PREFETCH_META) dma_meta<OFFD, TR>(a, g + gstride, tid, wave, MN0);
             M0 = MN0;
             if (!SPMM_PREFETCH_HEAD) dma_vals(a, M0, lane, N);       // (waited for right here: once per group)
             dma_finish(a, M0, N, tid, H0);
