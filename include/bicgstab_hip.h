@@ -358,6 +358,11 @@ unsigned long long bicg_masked_rows(bicg_ctx *ctx);
  * workgroups per product, x segments with masked slices}. BICG_PLAN="stencil=0" switches it off (slice-by-slice product);
  * BICG_PLAN="lines=2|4,planes=n" sets the tile; BICG_PLAN="ca-fuse=0" keeps CA-BiCGStab's q / y phase a kernel of its own */
 int bicg_stencil_info(bicg_ctx *ctx, unsigned int out[8]);
+/* Rows per lane of the plane-marching product: 1 (k_spmv_stencil), 2 or 4 (k_spmv_stencil_w: a wavefront's line is 128 / 256 rows,
+ * one pair of edge lines per line instead of one per 64 rows; taken when every list of the block has the same value per distance --
+ * constant-coefficient stencils -- and the vectors exceed the Infinity Cache, or BICG_PLAN="wide=2|4" asks for it; "wide=0" keeps
+ * one row per lane). 0 when the product is not in use. Same sums as mult(), reference src/matrix.c:506-515. */
+unsigned int bicg_stencil_rows_per_lane(bicg_ctx *ctx);
 /* bicg_create_device_csr groups its list-driven slices by 64-bit hashes of their lists and then compares every slice with the
  * list it was given: the number of slices that did NOT match (hash collisions) and were put back on their stored columns and
  * values. 0 for contexts built by bicg_create (the host plan keys on the full lists). */

@@ -275,6 +275,7 @@ int bicg_stencil_info(bicg_ctx *c, unsigned int out[8])
     for (int i = 0; i < 8; ++i) out[i] = v[i];
     return on ? 1 : 0;
 }
+unsigned int bicg_stencil_rows_per_lane(bicg_ctx *c) { return stencil_product(c) ? (c->st.wide ? c->st.wide : 1u) : 0u; }
 unsigned int bicg_plan_collisions(bicg_ctx *c) { return c->plan_collisions; }
 unsigned int bicg_product_kernels(int reset)
 {

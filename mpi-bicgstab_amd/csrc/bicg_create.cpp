@@ -148,15 +148,34 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
     }
     std::vector<StencilTab> tab(entries.size());
     for (size_t i = 0; i < entries.size(); ++i) tab[i] = entries[i].t;
+    // The wide form (bicg_stencil.hip, k_spmv_stencil_w): 2 or 4 rows per lane. It needs ONE value per canonical position -- every
+    // table entry agrees with the full one wherever it has an entry -- and whole groups of x segments per line.
+    uint32_t wide = 0, ref = 0;
+    {
+        bool have = false, same = true;
+        for (size_t i = 0; i < tab.size() && !have; ++i) if ((tab[i].bits & 0x7Full) == 0x7Full) { ref = (uint32_t)i; have = true; }
+        for (size_t i = 0; have && i < tab.size(); ++i)
+            for (int k = 0; k < 7; ++k)
+                if (((tab[i].bits >> k) & 1ull) && memcmp(&tab[i].v[k], &tab[ref].v[k], sizeof(double)) != 0) same = false;
+        // two rows per lane wherever the grid is large enough for the traffic to matter (512^3: product 0.461 -> 0.423 ms, 256^3:
+        // 0.0535 -> 0.052 ms, plain iteration 0.441 -> 0.424 ms; four rows per lane need 200-256 registers and lose what two gain:
+        // profiles/r06/stencil_notes.txt)
+        uint32_t want = nrows >= (1u << 22) ? 2u : 0u;
+        if (const char *v = plan_tok("wide")) want = (uint32_t)atoi(v);
+        if (have && same && (want == 2u || want == 4u) && nxs % want == 0) wide = want;
+        else if (want && c->rank == 0 && plan_tok("wide")) fprintf(stderr, "bicgstab_hip: BICG_PLAN wide=%u not taken (%s)\n", want, !(want == 2u || want == 4u) ? "2 or 4 rows per lane" : nxs % want ? "the lines are not whole groups of segments" : "values differ between the lists of the block");
+    }
     // lines per wavefront and planes per tile: enough workgroups for several rounds of the 1024 a GPU holds, tiles as deep as that allows
     uint32_t lines = 0, zl = 0;
+    const uint32_t nxt = wide ? nxs / wide : nxs;          // tiles per line
     {
-        static const uint32_t cand[][2] = {{4, 32}, {4, 16}, {2, 32}, {2, 16}, {4, 8}, {2, 8}, {2, 4}};
+        static const uint32_t cand[][2] = {{4, 64}, {4, 32}, {4, 16}, {2, 32}, {2, 16}, {4, 8}, {2, 8}, {2, 4}};
+        const uint64_t enough = wide ? 1000 : 3000;        // (the wide form keeps fewer, larger workgroups resident)
         uint64_t most = 0;
         for (auto &cd : cand) {
-            if (ny % cd[0]) continue;
-            const uint64_t wgs = (uint64_t)nxs * ((ny + 4 * cd[0] - 1) / (4 * cd[0])) * ((nz + cd[1] - 1) / cd[1]);
-            if (wgs >= 3000) { lines = cd[0]; zl = cd[1]; break; }
+            if (ny % cd[0] || (!wide && cd[1] > 32)) continue;
+            const uint64_t wgs = (uint64_t)nxt * ((ny + 4 * cd[0] - 1) / (4 * cd[0])) * ((nz + cd[1] - 1) / cd[1]);
+            if (wgs >= enough) { lines = cd[0]; zl = cd[1]; break; }
             if (wgs > most) { most = wgs; lines = cd[0]; zl = cd[1]; }
         }
         if (const char *v = plan_tok("lines")) { const uint32_t r = (uint32_t)atoi(v); if ((r == 2 || r == 4) && ny % r == 0) lines = r; }
@@ -164,11 +183,23 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
             // every workgroup of the product publishes one row of partial sums: the tiling must not need more rows than the table
             // has (ctx_state: max(256-row groups, kMaxGrid) + 64) -- thin grids with few planes per tile would
             const int z = atoi(v);
-            const uint64_t wgs = z >= 1 ? (uint64_t)nxs * ((ny + 4 * lines - 1) / (4 * lines)) * ((nz + (uint32_t)z - 1) / (uint32_t)z) : 0;
+            const uint64_t wgs = z >= 1 ? (uint64_t)nxt * ((ny + 4 * lines - 1) / (4 * lines)) * ((nz + (uint32_t)z - 1) / (uint32_t)z) : 0;
             const uint64_t room = std::max<uint64_t>(((uint64_t)nrows + kGroupRows - 1) / kGroupRows, (uint64_t)kMaxGrid);
             if (z >= 1 && wgs <= room) zl = (uint32_t)z;
             else if (c->rank == 0) fprintf(stderr, "bicgstab_hip: BICG_PLAN planes=%s ignored (%llu workgroups, room for %llu partial-sum rows)\n", v, (unsigned long long)wgs, (unsigned long long)room);
         }
+    }
+    if (wide) {
+        std::vector<uint32_t> wb((size_t)nz * nxt * ny);
+        parallel_ranges(wb.size(), 65536, [&](size_t i0, size_t i1, int) {
+            for (size_t i = i0; i < i1; ++i) {
+                const size_t yy = i % ny, xw = (i / ny) % nxt, zz = i / ((size_t)ny * nxt);
+                uint32_t word = 0;
+                for (uint32_t q = 0; q < wide; ++q) word |= (uint32_t)(tab[code[(zz * nxs + xw * wide + q) * ny + yy]].bits & 0x7Full) << (8u * q);
+                wb[i] = word;
+            }
+        });
+        c->st_wbits = dev_upload(wb.data(), wb.size());
     }
     c->st_code = dev_upload(code.data(), code.size());
     c->st_tab = dev_upload(tab.data(), tab.size());
@@ -177,15 +208,19 @@ static void build_stencil_plan(bicg_ctx *c, uint32_t nslices, uint32_t nrows, co
     // the XCDs round-robin (product 0.480 -> 0.460 ms, CA-BiCGStab 5.40 -> 5.31 ms per iteration); a grid whose vectors the cache
     // holds (256^3) keeps ordinary stores and the XCD-contiguous order (0.053 against 0.061 ms): profiles/r05/stencil_sweep_xcd_nt.txt
     const bool st_big = 16.0 * (double)nrows > 2.0 * 256.0 * 1048576.0;
-    const int st_xcd = knob_x("BICG_STENCIL_XCD") ? atoi(knob_x("BICG_STENCIL_XCD")) : (st_big ? 0 : 1);
+    // ... and since round 6 (the wide form) in the sweep order: an XCD takes its own eighth of the line blocks plane block by plane
+    // block (0.428 -> 0.423 ms; L2 misses 13.9 M -> 12.8 M per product)
+    int st_xcd = knob_x("BICG_STENCIL_XCD") ? atoi(knob_x("BICG_STENCIL_XCD")) : (st_big ? (wide ? 2 : 0) : 1);
+    if (st_xcd == 2 && ((ny + 4 * lines - 1) / (4 * lines)) % 8u) st_xcd = st_big ? 0 : 1;       // (the sweep order deals whole line blocks to the XCDs)
     const int st_nt = knob_x("BICG_STENCIL_NT") ? atoi(knob_x("BICG_STENCIL_NT")) : (st_big ? 1 : 0);
-    c->st = StencilDev{1, sy, sz, nxs, ny, nz, 0u, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask};
+    c->st = StencilDev{1, sy, sz, nxs, ny, nz, 0u, nz, zl, lines, nmc, st_xcd, st_nt, mcols, c->st_code, c->st_tab, c->st_cmask, wide, ref, c->st_wbits};
     if (const char *v = plan_tok("ca-fuse")) c->ca_fuse = atoi(v) != 0;
     // what this product streams from the matrix side: 4 bytes per slice, one byte per row of the masked x segments
-    c->stencil_matrix_bytes = 4ull * nslices + (uint64_t)cmask.size();
+    // (the wide form: 4 bytes per `wide` slices)
+    c->stencil_matrix_bytes = 4ull * nslices / (wide ? wide : 1u) + (uint64_t)cmask.size();
     if (getenv("BICG_PLAN_TRACE"))
-        fprintf(stderr, "bicgstab_hip: plane-marching product: %u x %u x %u grid (x segments of 64 rows: %u), %zu list pairs, %u masked x segments, %u lines x %u planes per wavefront, %u workgroups\n",
-                sy, ny, nz, nxs, tab.size(), nmc, lines, zl, stencil_grid(c->st));
+        fprintf(stderr, "bicgstab_hip: plane-marching product: %u x %u x %u grid (x segments of 64 rows: %u), %zu list pairs, %u masked x segments, %u lines x %u planes per wavefront, %u rows per lane, %u workgroups\n",
+                sy, ny, nz, nxs, tab.size(), nmc, lines, zl, wide ? wide : 1u, stencil_grid(c->st));
 }
 
 
@@ -1611,7 +1646,7 @@ void bicg_destroy(bicg_ctx *c)
     g_live.erase(std::remove(g_live.begin(), g_live.end(), c), g_live.end());
     (void)hipSetDevice(c->device);
     (void)hipDeviceSynchronize();
-    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->d_col16, c->win_ptr, c->win_runs, c->win_list, c->win_lptr, c->win_ltotal, c->sell_perm, c->lane_info, c->waitlog, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
+    void *ptrs[] = {c->d_val, c->d_col, c->d_ptr, c->o_val, c->o_col, c->o_ptr, c->desc_int, c->desc_bnd, c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->s_ubase, c->s_uoff, c->s_vbase, c->s_uval, c->s_mbase, c->s_rmask, c->s_desc, c->s_uoff8, c->st_code, c->st_tab, c->st_cmask, c->st_wbits, c->d_col16, c->win_ptr, c->win_runs, c->win_list, c->win_lptr, c->win_ltotal, c->sell_perm, c->lane_info, c->waitlog, c->sh_dev, c->sh_arrays, c->p_set, c->x_set, c->glist_int, c->glist_bnd,
                     c->send_idx, c->sendbuf, c->slab, c->partial, c->shard_tot, c->counter, c->Sbuf, c->trace, c->sw_buf,
                     c->wpart[0], c->wpart[1], c->shard_ll, c->tail_tab, c->tail_shard, c->alarm, c->mm_in, c->mm_xt, c->mm_yt, c->mm_part, c->mm_out, c->mm_sigma};
     for (void *p : ptrs) if (p) (void)hipFree(p);

@@ -244,6 +244,10 @@ struct StencilDev {
     const uint32_t *code;
     const StencilTab *tab;
     const unsigned char *cmask;
+    // the wide form (k_spmv_stencil_w): rows per lane (0: the narrow form, 2 or 4), the table entry with all seven values, and one
+    // word per wavefront line ((z nxs/wide + segment group) ny + y) with the presence bits of its `wide` segments, a byte each
+    uint32_t wide, ref;
+    const uint32_t *wbits;
 };
 struct SellDev {
     const double   *val;

@@ -105,7 +105,7 @@ struct bicg_ctx {
     int sell_ystride = 0;                  // SellDev::ystride (BICG_SELL_YGROUP=1; default: consecutive slices per workgroup)
     bool sell_all_lists = false;           // SellDev::all_lists (BICG_PLAN="lists=0" switches the loop of its own off)
     StencilDev st{};                       // SellDev::st: the plane-marching product of a 7-point grid stencil (BICG_PLAN="stencil=0": off)
-    uint32_t *st_code = nullptr; StencilTab *st_tab = nullptr; unsigned char *st_cmask = nullptr;
+    uint32_t *st_code = nullptr; StencilTab *st_tab = nullptr; unsigned char *st_cmask = nullptr; uint32_t *st_wbits = nullptr;
     bool st_multi = false;                 // several ranks: the halo-free rows of this rank are the whole planes z_lo .. z_hi - 1 of its grid
     bool ca_fuse = true;                   // CA-BiCGStab: q, y and their dots in the epilogue of z = A s (plane-marching product only; BICG_PLAN="ca-fuse=0")
     uint4 *s_desc = nullptr;               // one descriptor per slice (SellDev::sdesc): BICG_PLAN="desc=0" switches them off

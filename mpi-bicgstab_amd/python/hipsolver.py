@@ -60,7 +60,7 @@ EXPORTS = [
     "bicg_comm_unique_id", "bicg_comm_init_rccl", "bicg_comm_init_host", "bicg_comm_init_mpi",
     "bicg_comm_init_single", "bicg_comm_finalize", "bicg_comm_selftest_rccl", "bicg_comm_rccl_loadable", "bicg_comm_last_error", "bicg_section_times", "bicg_comm_rank", "bicg_comm_size",
     "bicg_default_options", "bicg_create", "bicg_destroy", "bicg_solve", "bicg_load", "bicg_run", "bicg_fetch",
-    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_product_kernels", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
+    "bicg_run_begin", "bicg_run_iterate", "bicg_run_iterate_timed", "bicg_run_end", "bicg_sync", "bicg_trace", "bicg_spmv", "bicg_dot", "bicg_spmv_bench", "bicg_plan_info", "bicg_ctx_flags", "bicg_spmm", "bicg_device_matrix_bytes", "bicg_uniform_entries", "bicg_constant_entries", "bicg_masked_rows", "bicg_stencil_info", "bicg_stencil_rows_per_lane", "bicg_comm_wait_stats", "bicg_plan_collisions", "bicg_product_kernels", "bicg_spmv_matrix_bytes", "bicg_last_shifted_persistent", "bicg_last_spmm_windowed", "bicg_dropin_context", "bicg_dropin_release", "bicg_dropin_stats",
     "bicg_mtx_load_block", "bicg_mtx_free", "bicg_partition", "bicg_halo_plan", "bicg_halo_send_counts", "bicg_halo_send_lists", "bicg_row_blocks", "bicg_window_plan", "bicg_window_slot", "bicg_version", "bicg_has_experiments", "bicg_switch_value", "bicg_switch_unknown", "bicg_stream_bench", "bicg_create_device_csr", "bicg_stencil7_device", "bicg_device_free", "bicg_persist_plan", "bicg_set_plan_threads",
 ]
 
@@ -97,6 +97,7 @@ def lib():
         L.bicg_spmv_bench.argtypes = [C.c_void_p, C.c_int, _dp]
         L.bicg_plan_info.argtypes = [C.c_void_p, _up]
         L.bicg_stencil_info.argtypes = [C.c_void_p, _up]
+        L.bicg_stencil_rows_per_lane.argtypes = [C.c_void_p]; L.bicg_stencil_rows_per_lane.restype = C.c_uint
         L.bicg_comm_wait_stats.argtypes = [C.c_void_p, _dp]
         L.bicg_section_times.argtypes = [C.c_void_p, C.POINTER(C.c_double), C.POINTER(C.c_int), C.POINTER(C.c_int)]
         L.bicg_comm_failed.argtypes = [C.c_void_p]
@@ -150,7 +151,7 @@ def lib():
 # The library's token-list variables (csrc/bicg_knobs.h): keyword -> (variable, token). INTEGRATION.md section 6 says what each does.
 SWITCHES = {k: ("BICG_PLAN", k.replace("_", "-")) for k in (
     "stencil", "lines", "planes", "ca_fuse", "layout", "window", "col16", "uniform", "constant", "masked", "desc", "lists", "jagw",
-    "spmm", "spmm_window", "fuse_pipe", "pipe_probe", "halo_fused", "window_list")}
+    "spmm", "spmm_window", "fuse_pipe", "pipe_probe", "halo_fused", "window_list", "wide")}
 SWITCHES.update(persist=("BICG_PERSIST", "0"), persist_chunk=("BICG_PERSIST", "chunk"), persist_shifted=("BICG_PERSIST", "shifted"),
                 force_comm=("BICG_TEST", "force-comm"), spin_ticks=("BICG_TEST", "spin-ticks"),
                 p2p_fault_after=("BICG_TEST", "p2p-fault-after"), plan_collide=("BICG_TEST", "plan-collide"))
@@ -462,7 +463,9 @@ class Context:
         """The plane-marching product of a 7-point grid stencil (csrc/bicg_stencil.hip): is it in use, and its tiling."""
         out = (C.c_uint * 8)()
         lib().bicg_stencil_info(self.h, out)
-        return dict(zip(("on", "sy", "ny", "nz", "lines", "planes", "workgroups", "masked_segments"), list(out)))
+        info = dict(zip(("on", "sy", "ny", "nz", "lines", "planes", "workgroups", "masked_segments"), list(out)))
+        info["rows_per_lane"] = int(lib().bicg_stencil_rows_per_lane(self.h))
+        return info
 
     def plan_collisions(self) -> int:
         return int(lib().bicg_plan_collisions(self.h))

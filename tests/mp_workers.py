@@ -301,6 +301,9 @@ def fullsize_worker(rank, world, port, kind, outdir):
         else:
             slab = synth.transport_like(n=n, rows=(lo, lo + nl), scale_decades=float(ref["scale_decades"]))
         diag, offd = synth.split_row_slab(slab, lo)
+        wide = int(ref["stencil_wide"]) if "stencil_wide" in ref else 0
+        if wide:
+            H.switches(wide=wide)
         ctx = H.Context(H.HostBlocks(diag, offd, n, counts, displs))
         info, flags = ctx.plan_info(), ctx.flags()
         assert info["halo"] > 0 and info["boundary_blocks"] > 0
@@ -323,6 +326,7 @@ def fullsize_worker(rank, world, port, kind, outdir):
             # a z-slab of the grid: the planes without halo entries go to the plane-marching product (csrc/bicg_stencil.hip), the two
             # (one, at either end of the grid) halo-touching planes to the slice-by-slice kernel behind the exchange
             assert ctx.stencil_info()["on"] == 1, ctx.stencil_info()
+            assert ctx.stencil_info()["rows_per_lane"] == (wide or 1), ctx.stencil_info()      # (slabs of < 4 M rows keep one row per lane unless asked)
         if "expect_persist" in ref and int(ref["expect_persist"]):
             # ranks small enough for one persistent launch per chunk of iterations (bicg_persist.hip) AND with neighbours:
             # halo pushes by the communication wavefronts, window loads from the landing ring, sums through the mailboxes

@@ -421,6 +421,8 @@ def test_laplace512_device_plan_at_bench_size():
     w = (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.0)
     ctx, nnz, plan_s, gen_s = H.Context.stencil7_on_device(m, w)
     assert nnz == synth.stencil7_nnz(m) and ctx.plan_info()["sell_rows"] == n and not ctx.flags()["col16"]
+    st = ctx.stencil_info()          # one value per distance, vectors beyond the Infinity Cache: two rows per lane, 128 x 16 x 64 tiles
+    assert st["on"] == 1 and st["rows_per_lane"] == 2 and st["lines"] == 4 and st["planes"] == 64 and st["workgroups"] == 1024, st
     x = np.random.default_rng(512).standard_normal(n)
     assert np.array_equal(ctx.spmv(x), synth.stencil7_matvec(m, w, x))           # 134 M rows, bit for bit
     ctx.close()

@@ -213,10 +213,15 @@ def test_hot_kernels_stay_lean():
         assert r["ScratchSize [bytes/lane]"] == 0 and r["Occupancy [waves/SIMD]"] >= 2, (k, r)
     # ... and the plane-marching product (bicg_stencil.hip): four sets of plane registers, never scratch, four wavefronts per SIMD
     # with four lines per wavefront
-    st = [k for k in kernels if "k_spmv_stencil" in k]
+    st = [k for k in kernels if "k_spmv_stencilI" in k]
     assert len(st) >= 28
     for k in st:
         assert kernels[k]["ScratchSize [bytes/lane]"] == 0 and kernels[k]["Occupancy [waves/SIMD]"] >= 4, (k, kernels[k])
+    # ... its wide form (2 / 4 rows per lane: the plane registers are 16 / 32 bytes each): never scratch
+    stw = [k for k in kernels if "k_spmv_stencil_wI" in k]
+    assert len(stw) >= 28
+    for k in stw:
+        assert kernels[k]["ScratchSize [bytes/lane]"] == 0, (k, kernels[k])
     # the fused pipelined iteration: a 200k-row rank is 783 workgroups x 4 wavefronts = 3.06 per SIMD, so a
     # fifth VGPR over 128 (occupancy 3) buys a second round of workgroups: +5 us per iteration, measured
     epi = [k for k in kernels if "k_spmv_sell_epi" in k]

@@ -133,15 +133,19 @@ def test_unstructured_mesh_partition_against_oracle(numbering, world, kind, tmp_
         assert len(glob.glob(os.path.join(td, "ok*"))) == world
 
 
-def test_laplace7_slabs_8_ranks_ca_bicgstab():
+@pytest.mark.parametrize("wide", [0, 2])
+def test_laplace7_slabs_8_ranks_ca_bicgstab(wide):
     """BASELINE.json configs[3] (7-point Laplacian 512^3 over 8 GPUs = 64 planes of 512^2 each, CA-BiCGStab) at 128^3:
     8 ranks x 16-plane z-slabs in the reference's row partition, peer-to-peer data path (halo = one plane per neighbour,
     exchanged inside the SpMV launch): distributed SpMV bit-exact, first 12 iterations of ca_bicgstab and bicgstab against
-    the oracle at 8 ranks (src/solver.c:160-278)."""
+    the oracle at 8 ranks (src/solver.c:160-278). wide = 2: the halo-free planes through the two-rows-per-lane form of the
+    plane-marching product (what a 64-plane slab of 512^2 takes by default)."""
     m, world = 128, 8
     A = synth.stencil7(m, synth.LAPLACE_WEIGHTS)
     row, col, val = A.to_coo()
     out = dict(n=A.rows, k_fix=K_FIX, scale_decades=0.0, grid=m, methods=np.array(["ca_bicgstab", "bicgstab"]))
+    if wide:
+        out["stencil_wide"] = wide
     out["x_in"] = np.random.default_rng(77).standard_normal(A.rows)
     out["y"] = O.spmv(A.rows, row, col, val, out["x_in"], nranks=world)
     out["b"] = O.spmv(A.rows, row, col, val, np.ones(A.rows), nranks=world)

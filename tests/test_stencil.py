@@ -16,7 +16,7 @@ pytestmark = pytest.mark.gpu
 W = (6.5, -1.2, -0.8, -1.1, -0.9, -1.0, -1.3)          # every position its own weight: a swapped neighbour shows
 W2 = (7.25, -0.7, -1.4, -0.6, -1.5, -0.9, -1.1)
 
-KNOBS = ("stencil", "lines", "planes", "ca_fuse")          # tokens of BICG_PLAN (csrc/bicg_knobs.h)
+KNOBS = ("stencil", "lines", "planes", "ca_fuse", "wide")          # tokens of BICG_PLAN (csrc/bicg_knobs.h)
 
 
 def _ctx(monkeypatch, A, **env):
@@ -30,6 +30,9 @@ def _ctx(monkeypatch, A, **env):
     ((192, 4, 9), {"upper_weights": W2}),                    # two value lists for the interior's distances
     ((64, 6, 6), {"wrap_y": True}),                          # a plane's first / last line keeps its -sy / +sy entry
     ((256, 16, 16), {"upper_weights": W2, "wrap_y": True}),
+    ((256, 8, 6), {"wrap_y": True}),                         # one wavefront line of four segments, both face segments in it
+    ((512, 8, 5), {}),                                       # BASELINE.json configs[3]'s line length
+    ((384, 4, 4), {}),                                       # six segments: pairs, not fours
 ])
 def test_plane_marching_product_bit_for_bit(monkeypatch, shape, kw):
     H.lib().bicg_comm_init_single(0)
@@ -40,6 +43,9 @@ def test_plane_marching_product_bit_for_bit(monkeypatch, shape, kw):
     want = O.spmv(A.rows, row, col, val, x)
     tiles = [{}, {"lines": 2, "planes": 3}, {"lines": 2, "planes": 64},
              {"lines": 4, "planes": 1}, {"lines": 4, "planes": 5}]
+    # the wide form (2 / 4 rows per lane): taken when the lines are whole groups of 2 / 4 x segments and the block has one value
+    # per distance -- two value lists (upper_weights) keep one row per lane whatever is asked for
+    tiles += [dict(t, wide=w) for w in (2, 4) for t in ({"lines": 2, "planes": 3}, {"lines": 4, "planes": 5}, {"lines": 2, "planes": 64})]
     for env in tiles:
         if env.get("lines") == 4 and ny % 4:
             continue
@@ -48,6 +54,8 @@ def test_plane_marching_product_bit_for_bit(monkeypatch, shape, kw):
         assert info["on"] == 1 and info["sy"] == nx and info["ny"] == ny and info["nz"] == nz, (env, info)
         if "lines" in env:
             assert info["lines"] == env["lines"] and info["planes"] == env["planes"]
+        wide = env.get("wide", 1)
+        assert info["rows_per_lane"] == (wide if (nx // 64) % wide == 0 and "upper_weights" not in kw else 1), (env, info)
         assert np.array_equal(ctx.spmv(x), want), env
         assert np.array_equal(ctx.spmv(x), want), env             # the reversed direction of the second product
         ctx.close()
@@ -90,12 +98,14 @@ def test_solvers_on_the_plane_marching_product(monkeypatch):
     b = O.spmv(A.rows, row, col, val, np.ones(A.rows))
     runs = {}
     for name, env in (("slices", {"stencil": 0}), ("planes", {}), ("planes_unfused", {"ca_fuse": 0}),
-                      ("planes_2x3", {"lines": 2, "planes": 3})):
+                      ("planes_2x3", {"lines": 2, "planes": 3}), ("planes_wide", {"wide": 2}),
+                      ("planes_wide_unfused", {"wide": 2, "ca_fuse": 0, "lines": 2, "planes": 5})):
         ctx = _ctx(monkeypatch, A, **env)
         assert ctx.stencil_info()["on"] == (0 if name == "slices" else 1)
+        assert ctx.stencil_info()["rows_per_lane"] == (0 if name == "slices" else 2 if "wide" in name else 1)
         runs[name] = _traces(ctx, b)
         ctx.close()
-    for name in ("planes", "planes_unfused", "planes_2x3"):
+    for name in ("planes", "planes_unfused", "planes_2x3", "planes_wide", "planes_wide_unfused"):
         for (t, x), (t0, x0) in zip(runs[name], runs["slices"]):
             np.testing.assert_allclose(t, t0, rtol=1e-8, atol=0.0)
             np.testing.assert_allclose(x, x0, rtol=1e-8, atol=1e-12)
