@@ -28,6 +28,29 @@ stats mesh_generator_plain python $R/bench.py $QUIET --workload mesh --numbering
 stats mesh_random_plain python $R/bench.py $QUIET --workload mesh --numbering random
 stats laplace512 python $R/tools/lap512_only.py
 stats spmm python $R/tools/spmm_only.py
+# counters (their own passes, kernel trace only): what the SpMM and the 512^3 product move
+pmc() {   # name, counter set, command...
+  local name=$1 set=$2; shift 2
+  rm -rf /tmp/pmc_$name
+  timeout 300 rocprofv3 --kernel-trace --pmc $set -d /tmp/pmc_$name -o p --output-format csv -- "$@" > /dev/null 2>&1
+  python - "$name" "$set" $(find /tmp/pmc_$name -name "p_counter_collection.csv" | head -1) >> $OUT/counters.txt <<PY
+import csv, sys, collections
+name, cset, path = sys.argv[1], sys.argv[2], sys.argv[3]
+acc = collections.defaultdict(list)
+for r in csv.DictReader(open(path)):
+    k = r["Kernel_Name"]
+    if "k_spmm" in k or "k_spmv_stencil" in k:
+        acc[(k.split("(")[0][:60], r["Counter_Name"])].append(float(r["Counter_Value"]))
+for (k, cn), v in sorted(acc.items()):
+    v = v[2:] if len(v) > 4 else v
+    print(f"{name:10s} {k:62s} {cn:24s} mean per launch {sum(v)/len(v):16.1f}  ({len(v)} launches)")
+PY
+}
+: > $OUT/counters.txt
+for set in FETCH_SIZE WRITE_SIZE "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
+  pmc spmm "$set" python $R/tools/spmm_only.py
+  pmc laplace512 "$set" python $R/tools/lap512_spmv.py
+done
 cd $R
 s=$(date +%s)
 python bench.py --gpus 1 --steps 20 --warmup 5 > $OUT/bench_line.json 2> $OUT/bench_stderr.txt
@@ -35,4 +58,5 @@ echo "bench.py wall seconds: $(( $(date +%s) - s ))" >> $OUT/bench_stderr.txt
 cp bench_full.json $OUT/bench_full.json
 python -m pytest tests -m gpu -q 2>&1 | grep -E "passed|failed|Error|error|assert" | tail -12 > $OUT/gpu_suite.txt
 wc -c $OUT/bench_line.json; tail -2 $OUT/bench_stderr.txt; cat $OUT/gpu_suite.txt
+cat $OUT/counters.txt
 for f in $OUT/*_kernel_stats.csv; do echo "== $f"; head -6 $f | cut -c1-150; done

@@ -6,7 +6,15 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from mpi_bicgstab_amd import hipsolver as H, synth
 H.lib().bicg_comm_init_single(0)
-A = synth.transport_like(scale_decades=2.0)
+kind = os.environ.get("SPMM_MATRIX", "transport")          # transport | fem_like | mesh_rcm | mesh_generator
+if kind.startswith("mesh_"):
+    from mpi_bicgstab_amd import mesh
+    A = mesh.fem_unstructured(117, kind[5:], 2.0)
+elif kind == "fem_like":
+    A = synth.fem_like(scale_decades=2.0)
+else:
+    A = synth.transport_like(scale_decades=2.0)
+print("matrix", kind, A.rows, "rows", A.nnz if hasattr(A, "nnz") else len(A.val), "non-zeros", flush=True)
 X = np.random.default_rng(0).standard_normal((16, A.rows))
 sg = (np.arange(16) + 1.0) * 0.01 / 16
 out = {}
