@@ -1127,6 +1127,141 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
 }
 
 
+// Plain BiCGStab with R rows per thread (round 6: ranks of 4 GPUs -- 400 k rows of Transport = 1 565 rows per CU -- ran the
+// five-launch iteration at 46.5 us where the pipelined method's persistent kernel took 25.1). The protocol, tags, tables and the
+// helper are k_plain_persist's, operation for operation; a thread keeps x, r, p, s, y, q, r# of its R rows in registers (thread
+// (wavefront w, lane l) owns rows (s0 + j nrw + w) 64 + l, position j nrt + tid of the workgroup's range, like k_pipe_persist),
+// the matrix slices are streamed from memory. Dot partials: a thread adds its rows' products in row order before the wavefront
+// sum -- an association of its own, like every tiling's.
+template <int R, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_plain_persist_r(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wg = persist_wg(a);
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            const unsigned s1 = a.seq0 + 3u * (unsigned)it + 1u, m1 = a.p2p.seq + 3u * (unsigned)it;
+            if (!helper_group<1>(a, a.dtab[0], a.arow[0], s1, m1, PH_PLAIN_ALPHA, L, nullptr)) break;
+            if (!helper_group<2>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_OMEGA, L, nullptr)) break;
+            if (!helper_group<2>(a, a.dtab[0], a.arow[0], s1 + 2u, m1 + 2u, PH_PLAIN_END, L, nullptr)) break;
+        }
+        helper_finish(a, L);
+        return;
+    }
+
+    WgCtx W;
+    RowState<R> rs;
+    wg_setup<R, false, MULTI>(a, wg, dyn, W, rs);
+    const bool comm = W.comm;
+    const Vecs &e = a.v;
+    double x[R], r[R], p[R], s[R], y[R], q[R], h[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t at = rs.live[j] ? rs.row[j] : 0u;
+        x[j] = e.x[at]; r[j] = e.r[at]; p[j] = e.p[at]; s[j] = e.s[at]; h[j] = e.rh[at];
+        y[j] = 0.0; q[j] = 0.0;
+    }
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    // every row publishes val (LL image buf, tag seq; the workgroup's own copy in zs), then the product out = A val
+    auto product = [&](const double (&val)[R], unsigned buf, unsigned seq, unsigned hseq, double (&out)[R]) {
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (rs.live[j]) ll_store16_agent(a.llv[buf] + 2 * (size_t)rs.row[j], val[j], seq);
+                W.zs[(unsigned)j * W.nrt + tid] = val[j];
+            }
+        }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, W.zs, hseq, W.ns0, W.ns1);
+        else stage_window<MULTI>(a, W.runs, W.nruns, W.nslots, a.llv[buf], seq, hseq, W.win, W.nrt, L, W.zs, W.row0, W.nmine);
+        lds_barrier();
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                out[j] = persist_row<MULTI, 8>(a.pval + rs.sbase[j], a.pslot + rs.sbase[j], rs.slen[j], rs.lens[j] & 0xFFFFu, rs.lens[j] >> 16, W.win);
+        }
+    };
+    for (int it = 0; it < a.niter && !done; ++it) {
+        const unsigned g1 = a.seq0 + 3u * (unsigned)it + 1u, g2 = g1 + 1u, g3 = g1 + 2u;
+        const unsigned hp = a.halo_seq0 + 2u * (unsigned)it + 1u, hq = hp + 1u;
+        // ---- s = A p ; (r#,s) -> alpha                                               (src/solver.c:88-93)
+        product(p, 0u, g1, hp, s);
+        if (!comm) {
+            double acc[1] = {0.0};
+#pragma unroll
+            for (int j = 0; j < R; ++j) acc[0] += rs.live[j] ? h[j] * s[j] : 0.0;
+            hand_over<1>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<1>(lane, W.nrw, tab0, g1, L); comm_scalars(a, lane, a.arow[0], g1, L); }
+        lds_barrier();
+        if (L.fail) break;
+        alpha = L.sc[0];
+        // ---- q = r - alpha s ; y = A q ; (q,y), (y,y) -> omega                       (src/solver.c:94-104)
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) q[j] = r[j] + (-alpha) * s[j];
+        }
+        product(q, 1u, g2, hq, y);
+        if (!comm) {
+            double acc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < R; ++j) { acc[0] += rs.live[j] ? q[j] * y[j] : 0.0; acc[1] += rs.live[j] ? y[j] * y[j] : 0.0; }
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, W.nrw, tab1, g2, L); comm_scalars(a, lane, a.arow[1], g2, L); }
+        lds_barrier();
+        if (L.fail) break;
+        omega = L.sc[2];
+        // ---- x += alpha p + omega q ; r = q - omega y ; (r,r), (r#,r) -> beta, k++   (src/solver.c:105-116)
+        if (!comm) {
+            double acc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                double xx = x[j] + alpha * p[j];
+                xx = xx + omega * q[j];
+                x[j] = xx;
+                r[j] = q[j] + (-omega) * y[j];
+                acc[0] += rs.live[j] ? r[j] * r[j] : 0.0;
+                acc[1] += rs.live[j] ? h[j] * r[j] : 0.0;
+            }
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, W.nrw, tab0, g3, L); comm_scalars(a, lane, a.arow[0], g3, L); }
+        lds_barrier();
+        if (L.fail) break;
+        beta = L.sc[1]; done = L.sc[3] != 0.0 ? 1 : 0;
+        // ---- p = beta p ; p += r ; p += (-beta omega) s                              (src/solver.c:117-119)
+        if (!comm && !done) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                double pp = beta * p[j];
+                pp = pp + 1.0 * r[j];
+                pp = pp + (-beta * omega) * s[j];
+                p[j] = pp;
+            }
+        }
+        lds_barrier();                        // L.sc is rewritten by the next group
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (rs.live[j]) { const uint32_t row = rs.row[j]; e.x[row] = x[j]; e.r[row] = r[j]; e.p[row] = p[j]; e.s[row] = s[j]; e.y[row] = y[j]; }
+}
+
+
 // ------------------------------------------------------------------------------------------------------------------
 // shifted_lopbicgstab (reference src/shifted_solver.c:257-319) in the persistent form: the SEED system's iteration is plain
 // BiCGStab on A + sigma_seed I -- three exposed groups, PH_SH_ALPHA / PH_SH_OMEGA / PH_SH_END, numbered like the plain kernel's
@@ -1345,6 +1480,124 @@ __global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4)
     if (live) { e.x[row] = x; e.r[row] = r; e.p[row] = p; e.s[row] = s; e.z[row] = z; e.w[row] = w; }
 }
 
+
+// CA-BiCGStab with R rows per thread: k_ca_persist's protocol, tags and helper; rows and registers as in k_plain_persist_r.
+template <int R, bool MULTI>
+__global__ void __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(4, 4))) k_ca_persist_r(PersistArgs a)
+{
+    extern __shared__ double dyn[];
+    __shared__ PersistLds L;
+    const unsigned tid = threadIdx.x, lane = tid & 63u;
+    const unsigned wg = persist_wg(a);
+    if (tid == 0) { L.priv = *a.S; L.fail = 0; L.drift_flag = 0; L.adaptive = 0; }
+    lds_barrier();
+
+    if (wg == a.nwg) {
+        for (int it = 0; it < a.niter; ++it) {
+            if (L.priv.done) break;
+            const unsigned s1 = a.seq0 + 2u * (unsigned)it + 1u, m1 = a.p2p.seq + 2u * (unsigned)it;
+            if (!helper_group<2>(a, a.dtab[0], a.arow[0], s1, m1, PH_OMEGA, L, nullptr)) break;
+            if (!helper_group<5>(a, a.dtab[1], a.arow[1], s1 + 1u, m1 + 1u, PH_RECUR_END, L, nullptr)) break;
+        }
+        helper_finish(a, L);
+        return;
+    }
+
+    WgCtx W;
+    RowState<R> rs;
+    wg_setup<R, false, MULTI>(a, wg, dyn, W, rs);
+    const bool comm = W.comm;
+    const Vecs &e = a.v;
+    double x[R], r[R], p[R], s[R], z[R], w[R], h[R];
+#pragma unroll
+    for (int j = 0; j < R; ++j) {
+        const uint32_t at = rs.live[j] ? rs.row[j] : 0u;
+        x[j] = e.x[at]; r[j] = e.r[at]; p[j] = e.p[at]; s[j] = e.s[at]; z[j] = e.z[at]; w[j] = e.w[at]; h[j] = e.rh[at];
+    }
+    double alpha = L.priv.alpha, beta = L.priv.beta, omega = L.priv.omega;
+    int done = L.priv.done;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    lds_barrier();
+
+    llword *const tab0 = a.dtab[0] + (size_t)wg * kRedSlots * 2, *const tab1 = a.dtab[1] + (size_t)wg * kRedSlots * 2;
+    auto product = [&](const double (&val)[R], unsigned buf, unsigned seq, unsigned hseq, double (&out)[R]) {
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                if (rs.live[j]) ll_store16_agent(a.llv[buf] + 2 * (size_t)rs.row[j], val[j], seq);
+                W.zs[(unsigned)j * W.nrt + tid] = val[j];
+            }
+        }
+        lds_barrier();
+        if (comm) comm_halo<MULTI>(a, lane, W.zs, hseq, W.ns0, W.ns1);
+        else stage_window<MULTI>(a, W.runs, W.nruns, W.nslots, a.llv[buf], seq, hseq, W.win, W.nrt, L, W.zs, W.row0, W.nmine);
+        lds_barrier();
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                out[j] = persist_row<MULTI, 8>(a.pval + rs.sbase[j], a.pslot + rs.sbase[j], rs.slen[j], rs.lens[j] & 0xFFFFu, rs.lens[j] >> 16, W.win);
+        }
+    };
+    for (int it = 0; it < a.niter && !done; ++it) {
+        const unsigned g1 = a.seq0 + 2u * (unsigned)it + 1u, g2 = g1 + 1u;
+        const unsigned hs = a.halo_seq0 + 2u * (unsigned)it + 1u, hr = hs + 1u;
+        // ---- p = r + beta (p - omega s) ; s = w + beta (s - omega z) ; z = A s      (src/solver.c:217-224)
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                p[j] = recur3<double>(p[j], s[j], r[j], omega, beta);
+                s[j] = recur3<double>(s[j], z[j], w[j], omega, beta);
+            }
+        }
+        product(s, 0u, g1, hs, z);
+        // ---- q = r - alpha s (in r) ; y = w - alpha z (in w) ; (q,y), (y,y) -> omega   (src/solver.c:225-232)
+        if (!comm) {
+            double acc[2] = {0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                r[j] = r[j] + (-alpha) * s[j];
+                w[j] = w[j] + (-alpha) * z[j];
+                acc[0] += rs.live[j] ? r[j] * w[j] : 0.0;
+                acc[1] += rs.live[j] ? w[j] * w[j] : 0.0;
+            }
+            hand_over<2>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<2>(lane, W.nrw, tab0, g1, L); comm_scalars(a, lane, a.arow[0], g1, L); }
+        lds_barrier();
+        if (L.fail) break;
+        omega = L.sc[2];
+        // ---- x += alpha p + omega q ; r = q - omega y ; w = A r                       (src/solver.c:233-239)
+        if (!comm) {
+#pragma unroll
+            for (int j = 0; j < R; ++j) {
+                double xx = x[j] + alpha * p[j];
+                xx = xx + omega * r[j];
+                x[j] = xx;
+                r[j] = r[j] + (-omega) * w[j];
+            }
+        }
+        product(r, 1u, g2, hr, w);
+        // ---- (r,r), (r#,r), (r#,w), (r#,s), (r#,z) -> beta, alpha, k++                 (src/solver.c:240-251)
+        if (!comm) {
+            double acc[5] = {0.0, 0.0, 0.0, 0.0, 0.0};
+#pragma unroll
+            for (int j = 0; j < R; ++j)
+                if (rs.live[j]) { acc[0] += r[j] * r[j]; acc[1] += h[j] * r[j]; acc[2] += h[j] * w[j]; acc[3] += h[j] * s[j]; acc[4] += h[j] * z[j]; }
+            hand_over<5>(0.0, acc, nullptr, L, nullptr, 0u);
+        }
+        lds_barrier();
+        if (comm) { comm_partials<5>(lane, W.nrw, tab1, g2, L); comm_scalars(a, lane, a.arow[1], g2, L); }
+        lds_barrier();
+        if (L.fail) break;
+        alpha = L.sc[0]; beta = L.sc[1]; omega = L.sc[2]; done = L.sc[3] != 0.0 ? 1 : 0;
+        lds_barrier();                        // L.sc is rewritten by the next group
+    }
+#pragma unroll
+    for (int j = 0; j < R; ++j)
+        if (rs.live[j]) { const uint32_t row = rs.row[j]; e.x[row] = x[j]; e.r[row] = r[j]; e.p[row] = p[j]; e.s[row] = s[j]; e.z[row] = z[j]; e.w[row] = w[j]; }
+}
+
 }  // namespace
 
 unsigned persist_lds_bytes(const PersistArgs &a)
@@ -1388,7 +1641,11 @@ static hipError_t launch_persist(const PersistArgs &a, hipStream_t st, int metho
         return hipGetLastError();
     };
     hipError_t err;
-    if (method != 0 && a.rpt != 1u) return hipErrorInvalidValue;      // several rows per thread: the pipelined kernel only
+    if (method == 1 && a.rpt == 2u && !a.mat_entries)                // plain BiCGStab, two rows per thread (400 k-row ranks)
+        return a.multi ? go(k_plain_persist_r<2, true>, 5) : go(k_plain_persist_r<2, false>, 5);
+    if (method == 2 && a.rpt == 2u && !a.mat_entries)                // CA-BiCGStab, likewise
+        return a.multi ? go(k_ca_persist_r<2, true>, 6) : go(k_ca_persist_r<2, false>, 6);
+    if (method != 0 && a.rpt != 1u) return hipErrorInvalidValue;      // several rows per thread otherwise: the pipelined kernel only
     if (method == 0) {
         if (a.rpt == 1u) {
             if (a.mat_entries) { err = a.multi ? go(k_pipe_persist<1, true, true>, 0) : go(k_pipe_persist<1, true, false>, 0); }

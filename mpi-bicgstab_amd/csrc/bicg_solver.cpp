@@ -878,7 +878,8 @@ int run_iterate(bicg_ctx *c, int nsteps)
         // (section marks are host-side events between launches: the multi-launch forms are what they can time)
         bool persist = c->persist_on && !c->time_kernels && !c->time_sections && !c->sec_exhausted &&
                              ((c->method >= BICG_PIPE_BICGSTAB && (c->persist.rpt == 1u || (c->method == BICG_PIPE_BICGSTAB && o.rr_drift <= 0.0))) ||
-                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain && c->persist.rpt == 1u));
+                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain && c->persist.rpt == 1u) ||
+                              ((c->method == BICG_BICGSTAB || c->method == BICG_CA_BICGSTAB) && c->persist_plain && c->persist.rpt == 2u && !c->persist.mat_entries));
         // A persistent launch costs ~27 us of set-up (matrix slices and x window into LDS) and stops by itself at
         // convergence: it covers at least kPersistChunk iterations whatever the host check interval (200 k-row rank,
         // pipelined: 12.5 us per iteration at 16 per launch, 11.0 at 128, 10.9 at 512 -- tools/persist_chunk_times.py)

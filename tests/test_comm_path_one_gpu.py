@@ -177,6 +177,67 @@ def test_persistent_iterations(problem, monkeypatch):
         H.lib().bicg_comm_init_single(0)
 
 
+@pytest.mark.parametrize("method", ["bicgstab", "ca_bicgstab"])
+def test_persistent_plain_two_rows_per_thread(method):
+    """A rank of the headline matrix at 4 GPUs (400 528 rows of the Transport-shaped matrix: 1 565 rows per CU) takes plain BiCGStab
+    and CA-BiCGStab as ONE persistent launch per chunk with two rows per thread (k_plain_persist_r / k_ca_persist_r, round 6;
+    reference src/solver.c:86-121, 217-251):
+    no product kernel is launched during the solve, the first 12 iterations follow the oracle's scalars, the result equals the
+    five-launch iteration's to rounding, run to run and chunk length to chunk length in bits, and the same bits come through the
+    peer-to-peer transport driven by one rank (the MULTI instantiation: sums through the mailboxes)."""
+    import oracle_lib as O
+    H.lib().bicg_comm_init_single(0)
+    n = (synth.TRANSPORT_N + 3) // 4
+    A = synth.transport_like(n=n, scale_decades=2.0)
+    row, col, val = A.to_coo()
+    b = O.spmv(n, row, col, val, np.ones(n))
+    orc = O.solve(method, n, row, col, val, b, tol=0.0, max_iter=12)
+    want = np.concatenate([orc[key][:12] for key in ("alpha", "omega", "beta", "dotr")])
+
+    def run(check_every, **sw):
+        H.switches(**sw)
+        try:
+            ctx = H.Context(H.single_rank_blocks(A))
+            ctx.load(np.zeros(n), b)
+            ctx.run_begin(method, tol=0.0, max_iter=12, check_every=check_every)      # (r = b - A x0 [, w = A r]: product kernels)
+            ctx.sync()
+            H.product_kernels()
+            ctx.run_iterate(12)
+            ctx.sync()
+            ran = H.product_kernels()
+            assert ctx.run_end().iterations == 12
+            x, r = ctx.fetch()
+            tr = ctx.trace(12)
+            out = (np.concatenate([tr[key] for key in ("alpha", "omega", "beta", "dotr")]), x, r, ran, ctx.flags())
+            ctx.close()
+            return out
+        finally:
+            H.switches(**{k: None for k in sw})
+
+    multi = run(12, persist=0)
+    assert multi[3] and not multi[4]["persist"], (multi[3], multi[4])
+    one = run(12, persist_chunk=1)
+    assert one[4]["persist"] and not one[3], ("a product kernel ran: the persistent form was not taken", one[3], one[4])
+    np.testing.assert_allclose(one[0], want, rtol=1e-8, atol=0.0)
+    np.testing.assert_allclose(one[0], multi[0], rtol=1e-8, atol=0.0)
+    np.testing.assert_allclose(one[1], multi[1], rtol=1e-8, atol=1e-12)
+    for other in (run(12, persist_chunk=1), run(4, persist_chunk=1), run(1, persist_chunk=1)):
+        assert not other[3]
+        assert np.array_equal(other[0], one[0]) and np.array_equal(other[1], one[1]) and np.array_equal(other[2], one[2])
+    H.switches(force_comm=1)
+    buf = (C.c_char * 128)()
+    H.lib().bicg_comm_unique_id(buf)
+    H.lib().bicg_comm_init_rccl(0, 1, buf.raw, 0)
+    try:
+        assert H.lib().bicg_comm_enable_p2p() == 0
+        p2p = run(6, persist_chunk=1)
+        assert p2p[4]["persist"] and p2p[4]["p2p"] and not p2p[3], (p2p[3], p2p[4])
+        assert np.array_equal(p2p[0], one[0]) and np.array_equal(p2p[1], one[1]) and np.array_equal(p2p[2], one[2])
+    finally:
+        H.switches(force_comm=None)
+        H.lib().bicg_comm_init_single(0)
+
+
 def test_fused_pipelined_iteration_is_bit_reproducible(problem, monkeypatch):
     """the two-launch form (k_spmv_sell_epi) twice, and once more with BICG_TEST="spin-ticks=0" -- every workgroup then sums
     the shards it is waiting for itself (same partials, same order): same bits whoever computes a shard"""
