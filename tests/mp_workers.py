@@ -345,6 +345,16 @@ def fullsize_worker(rank, world, port, kind, outdir):
         assert np.array_equal(b, ref["b"][lo:lo + nl])
         methods = [str(m) for m in ref["methods"]] if "methods" in ref else ["bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"]
         rtol = float(ref["rtol"]) if "rtol" in ref else 1e-7          # (the mesh matrix: see tests/test_mesh_gpu.py)
+        for method in ([str(m) for m in ref["expect_no_product_kernels"]] if "expect_no_product_kernels" in ref else []):
+            # the iterations of these methods run inside persistent launches: no product kernel between run_begin and run_end
+            ctx.load(np.zeros(nl), b)
+            ctx.run_begin(method, tol=0.0, max_iter=k_fix, check_every=k_fix)
+            ctx.sync()
+            H.product_kernels()
+            ctx.run_iterate(k_fix)
+            ctx.sync()
+            ran = H.product_kernels()
+            assert ctx.run_end().iterations == k_fix and not ran, (method, ran)
         for method in methods:
             got = ctx.solve(method, b, tol=0.0, max_iter=k_fix, krr=5, nrr=1, check_every=k_fix)
             assert got["k"] == k_fix, (method, got["k"])

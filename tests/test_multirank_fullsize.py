@@ -161,19 +161,25 @@ def test_laplace7_slabs_8_ranks_ca_bicgstab(wide):
         assert len(glob.glob(os.path.join(td, "ok*"))) == world
 
 
-def test_two_small_ranks_persistent_with_halo():
+@pytest.mark.parametrize("share", [8, 4])
+def test_two_small_ranks_persistent_with_halo(share):
     """The form an 8-GPU run of BASELINE.json configs[2] takes -- ONE persistent launch per chunk of iterations with the
     neighbours' halo values arriving as LL words in the landing ring and the dot sums crossing the mailboxes -- at a rank size
     the one-GPU box can hold TWICE: two processes x 100 132 rows of a 200 264-row Transport-shaped matrix (each fits the 127
     workgroups a rank gets when two share the 256 CUs; the 8-rank full-size tests above get 31 and fall back to the two-launch
     form). `persist` AND halo > 0 asserted on both ranks; distributed SpMV bit-exact, the first 12 iterations of all four
     solvers and of the two 16-shift solvers against the oracle at P = 2 (reference src/matrix.c:428-441, src/solver.c:351-398,
-    src/shifted_solver.c:257-319)."""
+    src/shifted_solver.c:257-319). share = 4: two processes x 200 264 rows -- 1 577 rows per CU of a rank's 127, the rank size of
+    the headline at 4 GPUs: TWO rows per thread in the persistent kernels of all three methods (round 6: plain and CA-BiCGStab
+    too), asserted by the absence of product kernels during their iterations; the shifted solvers (one row per thread only) keep
+    their launches there."""
     world = 2
-    n = (synth.TRANSPORT_N + 7) // 8
+    n = (synth.TRANSPORT_N + share - 1) // share
     A = synth.transport_like(n=n, scale_decades=SCALE_DECADES)
     row, col, val = A.to_coo()
     out = dict(n=n, k_fix=K_FIX, scale_decades=SCALE_DECADES, expect_persist=1)
+    if share == 4:
+        out["expect_no_product_kernels"] = np.array(["bicgstab", "ca_bicgstab", "pipe_bicgstab"])
     out["x_in"] = np.random.default_rng(31).standard_normal(n)
     out["y"] = O.spmv(n, row, col, val, out["x_in"], nranks=world)
     out["b"] = O.spmv(n, row, col, val, np.ones(n), nranks=world)
