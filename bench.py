@@ -940,6 +940,13 @@ def main():
             wl8 = dict(build("transport", n=n8), desc=f"1/8 of the Transport-shaped matrix as one rank holds it at 8 GPUs ({n8} rows)")
             extras["transport_rank_of_8"] = extra("1/8 Transport rank", wl8, ("pipe_bicgstab", "bicgstab"), max(ke, 200))
             extras["small_rank_with_halo"] = small_rank_with_halo(n8)
+            # ... and ONE of 4 / of 2 GPUs: 400 k rows (persistent launches with two rows per thread for all three methods since
+            # round 6) and 800 k rows (the multi-launch iteration). Single rank, no link latency: the compute side of the strong-
+            # scaling curve the driver measures with real GPUs.
+            for parts in (4, 2):
+                npart = (synth.TRANSPORT_N + parts - 1) // parts
+                wlp = dict(build("transport", n=npart), desc=f"1/{parts} of the Transport-shaped matrix as one rank holds it at {parts} GPUs ({npart} rows)")
+                extras[f"transport_rank_of_{parts}"] = extra(f"1/{parts} Transport rank", wlp, ("bicgstab", "pipe_bicgstab", "ca_bicgstab"), max(ke, 200))
             # the stand-in for Transport.mtx where nothing is regular: the unstructured FEM matrix in three numberings
             for kind in ("rcm", "generator", "random"):
                 extras[f"mesh_{kind}"] = extra(f"mesh {kind}", build("mesh", numbering=kind), ("bicgstab", "pipe_bicgstab"), ke, kernel_roofline=True)

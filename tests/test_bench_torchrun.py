@@ -176,6 +176,12 @@ def test_bench_single_gpu_line_has_every_leg():
     # the rank one of 8 GPUs holds (configs[2]): the pipelined solver takes it as one persistent launch per chunk
     r8 = d["extras"]["transport_rank_of_8"]
     assert "persist" in r8["flags"] and r8["pipe_bicgstab"]["ms_per_iteration"] < 0.020, r8
+    # ... one of 4 (two rows per thread in the persistent kernels of all three methods: the plain iteration below the five-launch
+    # form's 46 us) and one of 2 (multi-launch), every leg a genuine iteration
+    r4, r2 = d["extras"]["transport_rank_of_4"], d["extras"]["transport_rank_of_2"]
+    assert "persist" in r4["flags"] and r4["bicgstab"]["ms_per_iteration"] < 0.043 and r4["ca_bicgstab"]["ms_per_iteration"] < 0.043, r4
+    assert all(r[m]["iterations_genuine"] is True for r in (r4, r2) for m in ("bicgstab", "pipe_bicgstab", "ca_bicgstab")), (r4, r2)
+    assert r4["bicgstab"]["ms_per_iteration"] < r2["bicgstab"]["ms_per_iteration"] < d["value"], (r4, r2, d["value"])
     assert "rowsplit" in d["extras"]["banded_b512"]["flags"] and d["extras"]["banded_b512"]["spmv_back_to_back"]["frac"] > 0.6
     rf = d["roofline"]
     st = rf["stream_measured_gbps"]
