@@ -527,10 +527,10 @@ void preload_stencil_kernels();
 void launch_spmm_sell(const SpmmArgs &a, bool with_offd, hipStream_t st);
 // vectors per LDS window of the windowed form for `wslots` doubles per vector (0: the window does not fit, use launch_spmm_sell)
 int spmm_win_vectors(unsigned wslots);
-hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st);
+hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);   // e0 / e1: stamped at the kernel's start / end
 // pipelined form (bicg_spmm.hip, k_spmm_pipe): the window of the next step copied global -> LDS by the DMA path while the current one
 // multiplies, persistent workgroups over consecutive groups; padded 16-bit layouts with clusters (hipErrorInvalidValue: not this block)
-hipError_t launch_spmm_pipe(const SpmmArgs &a, bool with_offd, hipStream_t st);
+hipError_t launch_spmm_pipe(const SpmmArgs &a, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void preload_spmm_kernels();
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 // look up one kernel of every translation unit a context with this sliced-ELL plan launches from (loads their code objects now)

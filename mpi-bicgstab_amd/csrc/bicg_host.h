@@ -363,7 +363,7 @@ void spmv(bicg_ctx *c, double *xin, double *yout, int ndot, const double *u, Red
 void spmv_grp(bicg_ctx *c, double *xin, double *yout, int ndot = 0, const double *u = nullptr, int phase = PH_NONE);
 void spmv_epi(bicg_ctx *c, double *xin, double *yout, int epi, int nd, int phase);
 void halo_only(bicg_ctx *c, double *xin);
-void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, bool sigma_staged = false);
+void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, bool sigma_staged = false, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void spmm_stage_sigma(bicg_ctx *c, int nvec, const double *sigma_host);
 bool spmm_possible(const bicg_ctx *c);
 void spmm_buffers(bicg_ctx *c);

@@ -1816,7 +1816,7 @@ int spmm_win_vectors(unsigned wslots)
     for (int nv : {8, 4}) if ((size_t)nv * wslots * 8u <= 156u * 1024u) return nv;
     return 0;
 }
-hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
+hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (a.ngroups == 0) return hipSuccess;
     const int nv = spmm_win_vectors(a.wslots);
@@ -1828,7 +1828,8 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st)
         // (the runtime answers "invalid argument" and launches with > 64 KiB of dynamic LDS all the same: bicg_persist.hip)
         (void)hipFuncSetAttribute(reinterpret_cast<const void *>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 159 * 1024);
         (void)hipGetLastError();
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, a);
+        if (e0 && e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(kernel, dim3(grid), dim3(kBlock), lds, st, a);
         return hipGetLastError();
     };
 #define WIN_GO(NVV)                                                                                                   \

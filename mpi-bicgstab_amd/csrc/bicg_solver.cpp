@@ -471,7 +471,9 @@ void spmm_stage_sigma(bicg_ctx *c, int nvec, const double *sigma_host)
     BICG_HIP(hipStreamSynchronize(c->sc));     // sg lives on this stack frame
 }
 
-void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, bool sigma_staged)
+// e0 / e1 (optional): stamped at the start / end of the SpMM KERNEL where the launch can carry them (the windowed and the pipelined
+// form), else around the pass
+void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, bool sigma_staged, hipEvent_t e0, hipEvent_t e1)
 {
     const size_t st = c->stride;
     for (int j = 0; j < nvec; ++j) halo_only(c, c->mm_in + (size_t)j * st);
@@ -495,10 +497,12 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
         if (const char *sv = test_tok("spmm-skip")) a.dbg = atoi(sv);
         if (!c->win_slots) a.cl = c->fw;
         // the pipelined form where the block qualifies (BICG_PLAN="spmm-window=1": k_spmm_win everywhere)
-        c->mm_dma = c->mm_win_env == 3 && !a.dbg && launch_spmm_pipe(a, !c->single(), c->sc) == hipSuccess;
-        if (!c->mm_dma && launch_spmm_win(a, !c->single(), c->sc) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
+        c->mm_dma = c->mm_win_env == 3 && !a.dbg && launch_spmm_pipe(a, !c->single(), c->sc, e0, e1) == hipSuccess;
+        if (!c->mm_dma && launch_spmm_win(a, !c->single(), c->sc, e0, e1) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
     } else {
+        if (e0) BICG_HIP(hipEventRecord(e0, c->sc));
         launch_spmm_sell(a, !c->single(), c->sc);
+        if (e1) BICG_HIP(hipEventRecord(e1, c->sc));
     }
     if (with_b) launch_colsum(c->mm_part, spmm_grid(a.ngroups, a.xcd_map != 0), c->mm_out, c->sc);
 }

@@ -22,6 +22,7 @@
 // then the offd part, then sigma_j x_j -- bit for bit k_spmm_win's, i.e. bicg_spmv's column by column (tests/test_full_size.py,
 // tests/test_shifted.py, across ranks tests/test_multirank.py).
 #include "bicg_device.h"
+#include <hip/hip_ext.h>
 #include "bicg_devfn.h"
 #include "bicg_reduce.h"
 #include "bicg_knobs.h"
@@ -408,7 +409,7 @@ static void spmm_pipe_shape(const SpmmArgs &a, unsigned ntiles, unsigned residen
     }
 }
 
-hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st)
+hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st, hipEvent_t e0, hipEvent_t e1)
 {
     if (a0.ngroups == 0) return hipSuccess;
     SpmmArgs a = a0;
@@ -436,7 +437,8 @@ hipError_t launch_spmm_pipe(const SpmmArgs &a0, bool with_offd, hipStream_t st)
             (void)hipGetLastError();
             raised = true;
         }
-        hipLaunchKernelGGL(kernel, dim3(grid), dim3((unsigned)tile), lds, st, a);
+        if (e0 && e1) hipExtLaunchKernelGGL(kernel, dim3(grid), dim3((unsigned)tile), lds, st, e0, e1, 0, a);
+        else hipLaunchKernelGGL(kernel, dim3(grid), dim3((unsigned)tile), lds, st, a);
         return hipGetLastError();
     };
     if (tile == 512) return with_offd ? go(k_spmm_pipe<true, 512>) : go(k_spmm_pipe<false, 512>);
