@@ -1530,7 +1530,11 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
     const unsigned short *const slots16 = reinterpret_cast<const unsigned short *>(a.sell.col16);
     __shared__ uint2 wruns[WIN ? 64 : 1];                    // the group's window runs (spmm_possible: at most 64)
     unsigned nwr = 0;
-    if (WIN) {
+    // (round 6) LIST: the group's window is a list of its distinct columns (SellDev::win_list, the layout k_spmv_jagl stages from):
+    // slot s = position in the list, column = the group's first row + a 16-bit distance -- no runs, any number of them
+    const bool LIST = WIN && a.sell.win_list != nullptr;
+    const uint32_t lbase = LIST ? a.sell.win_lptr[g] : 0u, ltotal = LIST ? a.sell.win_ltotal[g] : 0u;
+    if (WIN && !LIST) {
         const uint32_t r0 = a.sell.win_ptr[g];
         nwr = a.sell.win_ptr[g + 1] - r0;
         if (tid < nwr && tid < 64u) wruns[tid] = a.sell.win_runs[r0 + tid];
@@ -1595,7 +1599,12 @@ __global__ void __launch_bounds__(kBlock) __attribute__((amdgpu_waves_per_eu(2, 
                 const unsigned sl = s0 + (unsigned)j * kBlock + tid;
                 c[j] = -1;
                 if (sl < W) {
-                    if (WIN) {
+                    if (LIST) {
+                        if (sl < ltotal) {
+                            const uint32_t word = a.sell.win_list[lbase + (sl >> 9) * (unsigned)kGroupRows + (sl & 255u)];
+                            c[j] = (int)g0 + (int)(short)((sl & 256u) ? word >> 16 : word & 0xFFFFu);
+                        }
+                    } else if (WIN) {
                         unsigned r = 0;
                         while (r + 1 < nwr && (wruns[r + 1].y >> 16) <= sl) ++r;      // runs are few and ordered by slot
                         const unsigned off = sl - (wruns[r].y >> 16);

@@ -483,6 +483,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
     if (!c->mm_win) launch_rows_from_vectors(c->mm_in, st, nvec, c->n_loc + c->halo, c->mm_xt, c->sc);
     SpmmArgs a{};
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
+    a.sell.win_list = c->win_list; a.sell.win_lptr = c->win_lptr; a.sell.win_ltotal = c->win_ltotal;
     a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.nrows = c->n_loc; a.ngroups = c->ng_int + c->ng_bnd;
     a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
@@ -510,8 +511,8 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
 // every row on the sliced-ELL path, and 32-bit byte offsets into the row-major X (128 B per row) suffice
 bool spmm_possible(const bicg_ctx *c)
 {
-    // (x windows: the kernel keeps a group's runs in 64 LDS entries)
-    return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && c->win_max_runs <= 64 && (uint64_t)c->stride < (1ull << 25);
+    // (x windows: the kernel keeps a group's runs in 64 LDS entries -- or reads the group's column list, round 6)
+    return c->glist_all && c->nblk == 0 && c->sell_entries > 0 && (c->win_max_runs <= 64 || c->win_list) && (uint64_t)c->stride < (1ull << 25);
 }
 
 void spmm_buffers(bicg_ctx *c)

@@ -111,3 +111,24 @@ def test_shifted_solve_on_the_list_driven_window(case):
         np.testing.assert_allclose(tr[key], orc[key], rtol=1e-7, err_msg=key)
     for j in (0, 3):
         assert np.abs(got["x"][j] - orc["x"][j]).max() <= 1e-8 * np.abs(orc["x"][j]).max(), j
+
+
+def test_spmm_on_the_unstructured_matrix(case):
+    """Y_j = (A + sigma_j I) X_j for 16 vectors with the matrix read once (the reference's verification loop, src/test_shifted.c:
+    129-154) on layouts with an x window: generator order (runs) and RCM (round 6: the window read from the group's column list --
+    before, this layout had no SpMM and took one product per shift). Every column bit for bit the single product + shift; the
+    residual norms of bicg_shifted_residuals against numpy on those columns. The random permutation (no window) keeps the
+    row-major kernel: same bits."""
+    kind, A, (row, col, val), ctx = case
+    rng = np.random.default_rng(16)
+    X = rng.standard_normal((16, A.rows))
+    sg = (np.arange(16) + 1.0) * 0.01 / 16
+    assert ctx.flags()["spmm"], ctx.flags()
+    Y, ms = ctx.spmm(X, sg)
+    assert ctx.last_spmm_kind() == ("rowmajor" if kind == "random" else "windowed"), (kind, ctx.last_spmm_kind())
+    for j in (0, 7, 15):
+        assert np.array_equal(Y[j], ctx.spmv(X[j]) + sg[j] * X[j]), (kind, j)
+    b = rng.standard_normal(A.rows)
+    got = np.asarray(ctx.shifted_residuals(X, b, sg))
+    want = np.array([np.linalg.norm(b - Y[j]) / np.linalg.norm(b) for j in range(16)])
+    np.testing.assert_allclose(got, want, rtol=1e-12)
