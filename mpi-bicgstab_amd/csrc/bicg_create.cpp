@@ -1219,6 +1219,12 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
         c->win_runs = dev_upload(win_runs.data(), win_runs.size());
         c->win_slots = win_slots;
         for (uint32_t g = 0; g < ngroups; ++g) c->win_max_runs = std::max(c->win_max_runs, win_ptr[g + 1] - win_ptr[g]);
+        c->win_near16 = true;
+        for (uint32_t g = 0; g < ngroups && c->win_near16; ++g)
+            for (uint32_t r = win_ptr[g]; r < win_ptr[g + 1]; ++r) {
+                const long lo = (long)win_runs[r].x - (long)(g * kGroupRows), hi = lo + (long)(win_runs[r].y & 0xFFFFu) - 1;
+                if (lo < -32767 || hi > 32767) { c->win_near16 = false; break; }
+            }
         if (win_list_mode) {
             // the runs spelled out, 16 bits per column (distance from the group's first row), two slots per word: word j of thread t
             // (at lptr[g] + 256 j + t) holds slots t + 512 j (low half) and t + 512 j + 256 -- the slots thread t stages
@@ -1259,17 +1265,24 @@ bicg_ctx *bicg_create(const CSR_Matrix *diag, const CSR_Matrix *offd, const INFO
     {
         std::vector<unsigned short> li((size_t)ngroups * kGroupRows, 0);
         std::vector<char> too_long((size_t)plan_threads(), 0);
+        std::vector<uint32_t> tail_most((size_t)plan_threads(), 0u);      // entries behind the 16th of its rows, per slice (k_spmm_jpipe keeps them in LDS)
         parallel_ranges(ngroups, 64, [&](size_t ga, size_t gb, int part) {
-            for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g)
+            for (uint32_t g = (uint32_t)ga; g < (uint32_t)gb; ++g) {
+                uint32_t tail = 0;
                 for (uint32_t t = 0; t < kGroupRows; ++t) {
                     const uint32_t in_group = perm.empty() ? t : perm[(size_t)g * kGroupRows + t], r = g * kGroupRows + in_group;
                     const uint32_t n = (r < nrows && group_is_sell[g]) ? diag->ptr[r + 1] - diag->ptr[r] : 0u;
                     if (n > 255u) too_long[(size_t)part] = 1;
                     li[(size_t)g * kGroupRows + t] = (unsigned short)(in_group | (n << 8));
+                    if (t % kSliceRows == 0) tail = 0;
+                    tail += n > 16u ? n - 16u : 0u;
+                    tail_most[(size_t)part] = std::max(tail_most[(size_t)part], tail);
                 }
+            }
         });
         bool ok = true;
         for (char b : too_long) ok = ok && !b;
+        for (uint32_t t : tail_most) c->jag_tail16_max = std::max(c->jag_tail16_max, t);
         if (ok) {
             c->lane_info = dev_upload(li.data(), li.size());
             c->matrix_bytes += 2ull * li.size();

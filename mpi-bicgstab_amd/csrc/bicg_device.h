@@ -496,6 +496,7 @@ struct SpmmArgs {
     FusedWindow cl;
     unsigned wslots;        // LDS doubles per vector
     int dbg;                // BICG_TEST="spmm-skip=n" (measurement only, results are wrong): 1 no staging loads, 2 no products, 4 no row heads
+    unsigned tail_most;     // k_spmm_jpipe: most entries one jagged slice holds behind the 16th entry of its rows (the plan's count)
     double gstep;           // k_spmm_pipe: groups per workgroup (fractional: workgroup w takes groups floor(w gstep) .. floor((w + 1) gstep) - 1)
 };
 
@@ -531,6 +532,8 @@ hipError_t launch_spmm_win(const SpmmArgs &a, bool with_offd, hipStream_t st, hi
 // pipelined form (bicg_spmm.hip, k_spmm_pipe): the window of the next step copied global -> LDS by the DMA path while the current one
 // multiplies, persistent workgroups over consecutive groups; padded 16-bit layouts with clusters (hipErrorInvalidValue: not this block)
 hipError_t launch_spmm_pipe(const SpmmArgs &a, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
+// the same pipeline on jagged slices with x windows (bicg_spmm_jag.hip, k_spmm_jpipe); hipErrorInvalidValue: the block does not qualify
+hipError_t launch_spmm_jpipe(const SpmmArgs &a, bool with_offd, hipStream_t st, hipEvent_t e0 = nullptr, hipEvent_t e1 = nullptr);
 void preload_spmm_kernels();
 unsigned spmm_grid(uint32_t ngroups, bool xcd_map);
 // look up one kernel of every translation unit a context with this sliced-ELL plan launches from (loads their code objects now)

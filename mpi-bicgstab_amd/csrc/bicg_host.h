@@ -115,6 +115,8 @@ struct bicg_ctx {
     bool sell_jag = false;                 // jagged slices (ragged rows: no padding stored), SellDev::jag
     uint32_t *win_ptr = nullptr, win_slots = 0;   // x windows in LDS (SellDev::win_*)
     uint32_t win_max_runs = 0;             // most runs of one group's window
+    uint32_t jag_tail16_max = 0;           // most entries one jagged slice holds behind the 16th entry of its rows
+    bool win_near16 = false;               // every window column lies within 16 bits of its group's first row (k_spmm_jpipe packs them)
     uint2 *win_runs = nullptr;
     unsigned char *sell_perm = nullptr;    // SellDev::perm
     unsigned short *lane_info = nullptr;   // SellDev::lane_info

@@ -64,7 +64,7 @@ inline const char *const *knob_names(const char *set)
     static const char *const plan[] = {"stencil", "lines", "planes", "ca-fuse", "layout", "window", "col16", "uniform", "constant", "masked",
                                        "desc", "lists", "jagw", "spmm", "spmm-window", "fuse-pipe", "pipe-probe", "halo-fused", "window-list", "wide", nullptr};
     static const char *const persist[] = {"0", "off", "chunk", "shifted", nullptr};      // (the persistent forms are the default: there is no "on")
-    static const char *const test[] = {"force-comm", "spin-ticks", "p2p-fault-after", "plan-collide", "spmm-skip", "spmm-gstep", "spmm-tile", nullptr};
+    static const char *const test[] = {"force-comm", "spin-ticks", "p2p-fault-after", "plan-collide", "spmm-skip", "spmm-gstep", "spmm-tile", "spmm-jres", nullptr};
     static const char *const none[] = {nullptr};
     return !strcmp(set, "BICG_PLAN") ? plan : !strcmp(set, "BICG_PERSIST") ? persist : !strcmp(set, "BICG_TEST") ? test : none;
 }

@@ -484,6 +484,7 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
     SpmmArgs a{};
     a.sell = {c->s_val, c->s_col, c->s_base, c->s_len, c->s_col16, c->s_base16, c->sell_jag ? 1 : 0, c->win_ptr, c->win_runs, c->win_slots, c->sell_perm};
     a.sell.win_list = c->win_list; a.sell.win_lptr = c->win_lptr; a.sell.win_ltotal = c->win_ltotal;
+    a.sell.lane_info = c->lane_info; a.sell.win_max_runs = c->win_max_runs;
     a.dptr = c->d_ptr; a.offd = {c->o_val, c->o_col, c->o_ptr};
     a.nrows = c->n_loc; a.ngroups = c->ng_int + c->ng_bnd;
     a.xt = c->mm_xt; a.yt = with_b ? nullptr : c->mm_yt; a.b = with_b ? c->v.b : nullptr; a.partial = c->mm_part;
@@ -495,10 +496,13 @@ void spmm_pass(bicg_ctx *c, int nvec, const double *sigma_host, bool with_b, boo
     c->mm_dma = false;
     if (c->mm_win) {
         a.xs = c->mm_in; a.ys = with_b ? nullptr : c->mm_yt; a.vstride = st; a.nvec = nvec; a.wslots = wslots;
+        a.tail_most = c->jag_tail16_max;
         if (const char *sv = test_tok("spmm-skip")) a.dbg = atoi(sv);
         if (!c->win_slots) a.cl = c->fw;
         // the pipelined form where the block qualifies (BICG_PLAN="spmm-window=1": k_spmm_win everywhere)
         c->mm_dma = c->mm_win_env == 3 && !a.dbg && launch_spmm_pipe(a, !c->single(), c->sc, e0, e1) == hipSuccess;
+        // ... and its form for ragged rows (jagged slices with x windows: bicg_spmm_jag.hip)
+        if (!c->mm_dma && c->mm_win_env == 3 && c->win_slots && c->win_near16) c->mm_dma = launch_spmm_jpipe(a, !c->single(), c->sc, e0, e1) == hipSuccess;
         if (!c->mm_dma && launch_spmm_win(a, !c->single(), c->sc, e0, e1) != hipSuccess) die("bicg_spmm", "the windowed kernel could not be launched (BICG_PLAN=spmm-window=0 selects the row-major form)");
     } else {
         if (e0) BICG_HIP(hipEventRecord(e0, c->sc));
