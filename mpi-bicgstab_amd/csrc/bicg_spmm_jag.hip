@@ -38,6 +38,14 @@ extern __shared__ double spmm_lds[];
 #ifndef JPIPE_WAVES
 #define JPIPE_WAVES 3
 #endif
+// (measured, tools/jpipe_variants.sh: eight entries per trip behind the heads 342 against 331 us, eight LDS reads in flight 334, two
+// wavefronts per SIMD without spills 401; groups drawn from a counter per XCD instead of dealt 340 against 333)
+#ifndef JPIPE_U
+#define JPIPE_U 4
+#endif
+#ifndef JPIPE_XR
+#define JPIPE_XR 4
+#endif
 constexpr int kJpNV = 2;          // vectors per step
 constexpr int kJpHead = 16;       // entries of a row kept in registers across the steps of its group
 #define BICG_KCONST __attribute__((address_space(4)))
@@ -168,7 +176,7 @@ __device__ __forceinline__ void jp_stage_store(const SpmmArgs &a, double *dst, u
 template <bool OFFD, int JJ>
 __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JPIPE_WAVES, 4))) k_spmm_jpipe(SpmmArgs a, unsigned tq)
 {
-    constexpr int NV = kJpNV, K = kJpHead, U = 4, NW = kGroupRows / 64;
+    constexpr int NV = kJpNV, K = kJpHead, U = JPIPE_U, XR = JPIPE_XR, NW = kGroupRows / 64;
     __shared__ double sm[NW * NV];
     __shared__ uint2 wruns[64];
     const unsigned tid = threadIdx.x, lane = tid & 63u, wave = (unsigned)__builtin_amdgcn_readfirstlane((int)(tid >> 6));
@@ -271,15 +279,15 @@ __global__ void __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(JPIPE_
             const char *const cb = reinterpret_cast<const char *>(win);
             auto half = [&](int e0) {       // four entries' reads in flight, then their products in stored order
 #pragma unroll
-                for (int e4 = e0; e4 < e0 + K / 2; e4 += 4) {
-                    double xr[4][NV];
+                for (int e4 = e0; e4 < e0 + K / 2; e4 += XR) {
+                    double xr[XR][NV];
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < XR; ++i)
 #pragma unroll
                         for (int v = 0; v < NV; ++v) xr[i][v] = *reinterpret_cast<const double *>(cb + (size_t)v * W * 8u + H.s8[e4 + i]);
                     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-                    for (int i = 0; i < 4; ++i)
+                    for (int i = 0; i < XR; ++i)
 #pragma unroll
                         for (int v = 0; v < NV; ++v) acc[v] = acc[v] + H.v[e4 + i] * xr[i][v];       // an absent entry adds 0.0 * 0.0
                     __builtin_amdgcn_sched_barrier(0);

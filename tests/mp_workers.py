@@ -343,6 +343,17 @@ def fullsize_worker(rank, world, port, kind, outdir):
                 np.testing.assert_allclose(y, ref["y"][lo:lo + nl] * (1.0 + 0.125 * rep), rtol=1e-12, atol=1e-9)
         b = ctx.spmv(np.ones(nl))
         assert np.array_equal(b, ref["b"][lo:lo + nl])
+        if mesh_kind and flags["spmm"]:      # (the same on every rank: the SpMM exchanges halos)
+            # BASELINE.json configs[4] "batched SpMV" across ranks on ragged rows (reference src/test_shifted.c:129-154, one product per
+            # shift): 5 vectors, every column bit for bit the distributed product (checked against the oracle above) + shift. A block
+            # that kept its x windows (generator order) goes through k_spmm_jpipe with the offd part per column (csrc/bicg_spmm_jag.hip)
+            X = np.stack([ref["x_in"][lo:lo + nl] * (1.0 + 0.25 * j) for j in range(5)])
+            sg = 0.01 * (np.arange(5) + 1.0)
+            Y, _ = ctx.spmm(X, sg)
+            if flags["window"] and flags["jagged"]:
+                assert ctx.last_spmm_kind() == "pipelined", ctx.last_spmm_kind()
+            for j in range(5):
+                assert np.array_equal(Y[j], ctx.spmv(X[j]) + sg[j] * X[j]), f"SpMM column {j} ({ctx.last_spmm_kind()})"
         methods = [str(m) for m in ref["methods"]] if "methods" in ref else ["bicgstab", "ca_bicgstab", "pipe_bicgstab", "pipe_bicgstab_rr"]
         rtol = float(ref["rtol"]) if "rtol" in ref else 1e-7          # (the mesh matrix: see tests/test_mesh_gpu.py)
         for method in ([str(m) for m in ref["expect_no_product_kernels"]] if "expect_no_product_kernels" in ref else []):

@@ -254,6 +254,9 @@ def test_hot_kernels_stay_lean():
             assert kernels[k]["VGPRs"] <= 96 and kernels[k]["ScratchSize [bytes/lane]"] == 0 and kernels[k]["Occupancy [waves/SIMD]"] >= 5, (k, kernels[k])
     pipe = [k for k in kernels if "k_spmm_pipeI" in k]
     assert len(pipe) == 4 and all(kernels[k]["ScratchSize [bytes/lane]"] <= 64 and kernels[k]["Occupancy [waves/SIMD]"] >= 2 for k in pipe), pipe
+    # ... and its form for ragged rows: three workgroups of four wavefronts per CU, nothing in scratch (csrc/bicg_spmm_jag.hip)
+    jpipe = [k for k in kernels if "k_spmm_jpipeI" in k]
+    assert len(jpipe) == 6 and all(kernels[k]["ScratchSize [bytes/lane]"] == 0 and kernels[k]["Occupancy [waves/SIMD]"] >= 3 for k in jpipe), jpipe
 
 
 def test_window_plan_does_not_depend_on_the_number_of_threads():

@@ -116,18 +116,32 @@ def test_shifted_solve_on_the_list_driven_window(case):
 def test_spmm_on_the_unstructured_matrix(case):
     """Y_j = (A + sigma_j I) X_j for 16 vectors with the matrix read once (the reference's verification loop, src/test_shifted.c:
     129-154) on layouts with an x window: generator order (runs) and RCM (round 6: the window read from the group's column list --
-    before, this layout had no SpMM and took one product per shift). Every column bit for bit the single product + shift; the
-    residual norms of bicg_shifted_residuals against numpy on those columns. The random permutation (no window) keeps the
-    row-major kernel: same bits."""
+    before, this layout had no SpMM and took one product per shift), both through the pipeline for ragged rows (k_spmm_jpipe,
+    csrc/bicg_spmm_jag.hip) and, with BICG_PLAN=spmm-window=1, through k_spmm_win: the same bits. Every column bit for bit the single
+    product + shift, 16 vectors and 5 (an odd number: the last step holds one); the residual norms of bicg_shifted_residuals against
+    numpy on those columns. The random permutation (no window) keeps the row-major kernel: same bits."""
     kind, A, (row, col, val), ctx = case
     rng = np.random.default_rng(16)
     X = rng.standard_normal((16, A.rows))
     sg = (np.arange(16) + 1.0) * 0.01 / 16
     assert ctx.flags()["spmm"], ctx.flags()
     Y, ms = ctx.spmm(X, sg)
-    assert ctx.last_spmm_kind() == ("rowmajor" if kind == "random" else "windowed"), (kind, ctx.last_spmm_kind())
+    assert ctx.last_spmm_kind() == ("rowmajor" if kind == "random" else "pipelined"), (kind, ctx.last_spmm_kind())
     for j in (0, 7, 15):
         assert np.array_equal(Y[j], ctx.spmv(X[j]) + sg[j] * X[j]), (kind, j)
+    Y5, _ = ctx.spmm(X[:5], sg[:5])
+    assert np.array_equal(Y5, Y[:5]), kind
+    Y0, _ = ctx.spmm(X[:3])                                    # no shifts: plain A X
+    assert np.array_equal(Y0[2], ctx.spmv(X[2])), kind
+    if kind != "random":
+        H.switches(spmm_window=1)                              # (read when a context's SpMM buffers are set up: a second context)
+        try:
+            other = H.Context(H.single_rank_blocks(A))
+            Yw, _ = other.spmm(X, sg)
+            assert other.last_spmm_kind() == "windowed" and np.array_equal(Yw, Y), kind
+            other.close()
+        finally:
+            H.switches(spmm_window=None)
     b = rng.standard_normal(A.rows)
     got = np.asarray(ctx.shifted_residuals(X, b, sg))
     want = np.array([np.linalg.norm(b - Y[j]) / np.linalg.norm(b) for j in range(16)])
