@@ -820,7 +820,7 @@ def main():
     if spmm_leg:
         extras["spmm_16_vectors"] = spmm_leg
     if not a.no_extras and a.workload == "transport" and not a.n and not a.matrix:
-        def extra(name, wl2, methods, steps, kernel_roofline=False):
+        def extra(name, wl2, methods, steps, kernel_roofline=False, spmm=False):
             stage[0] = f"extra workload {name}"
             lg = Leg(wl2)
             out = dict(rows=wl2["rows"], nnz=wl2["nnz"], workload=wl2["desc"], plan=lg.plan, flags=[k for k, v in lg.ctx.flags().items() if v],
@@ -851,8 +851,22 @@ def main():
                                               survey_8d_bytes_per_launch=bs, survey_8d_gbps=bs / (kms * 1e-3) / 1e9, survey_8d_frac=bs / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS,
                                               format_bytes_per_launch=fb, format_gbps=fb / (kms * 1e-3) / 1e9, format_frac=fb / (kms * 1e-3) / 1e9 / HBM_PEAK_GBS)
                 lg.timed(methods[0], steps=4, warm=0)
+            if spmm and lg.ctx.flags().get("spmm"):
+                # BASELINE.json configs[4] "batched SpMV" on this matrix: 16 vectors in one pass over it (src/test_shifted.c:129-154)
+                nsh = 16
+                Xm = np.random.default_rng(16).standard_normal((nsh, lg.plan["rows"]))
+                sgm = (np.arange(nsh) + 1.0) * 0.01 / nsh
+                lg.ctx.spmm(Xm, sgm)
+                msm = min(lg.ctx.spmm(Xm, sgm)[1] for _ in range(3))
+                b8 = csr_bytes(wl2["nnz"], wl2["rows"]) + 2 * nsh * 8 * wl2["rows"]
+                bf = mbytes + 2 * nsh * 8 * wl2["rows"]
+                out["spmm_16_vectors"] = dict(ms=msm, vectors=nsh, kernel=lg.ctx.last_spmm_kind(), bound="hbm", peak=HBM_PEAK_GBS,
+                                              frac=bf / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, format_bytes=bf, survey_8d_bytes=b8,
+                                              survey_8d_frac=b8 / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, spmv_equivalents=msm / sp)
+                del Xm
             lg.close()
-            note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods))
+            note(f"{name}: " + ", ".join(f"{m} {out[m]['ms_per_iteration']:.4f} ms" for m in methods)
+                 + (f", SpMM of 16 vectors {1e3 * out['spmm_16_vectors']['ms']:.0f} us ({out['spmm_16_vectors']['kernel']})" if "spmm_16_vectors" in out else ""))
             return out
         def laplace512():
             """BASELINE.json configs[3] at its stated size on ONE GPU (the N = 1 anchor of the 8-GPU configuration): 134 M rows,
@@ -949,7 +963,7 @@ def main():
                 extras[f"transport_rank_of_{parts}"] = extra(f"1/{parts} Transport rank", wlp, ("bicgstab", "pipe_bicgstab", "ca_bicgstab"), max(ke, 200))
             # the stand-in for Transport.mtx where nothing is regular: the unstructured FEM matrix in three numberings
             for kind in ("rcm", "generator", "random"):
-                extras[f"mesh_{kind}"] = extra(f"mesh {kind}", build("mesh", numbering=kind), ("bicgstab", "pipe_bicgstab"), ke, kernel_roofline=True)
+                extras[f"mesh_{kind}"] = extra(f"mesh {kind}", build("mesh", numbering=kind), ("bicgstab", "pipe_bicgstab"), ke, kernel_roofline=True, spmm=kind != "random")
             extras["laplace7_256_ca"] = extra("laplace7 256^3", build("laplace7", m=256), ("ca_bicgstab", "bicgstab"), min(K, 50))
             extras["laplace7_256_ca"]["note"] = ("one GPU's share of BASELINE.json configs[3] (512^3 over 8 GPUs = 64 planes of 512^2 "
                                                  "= 16.8 M rows per GPU), CA-BiCGStab")
