@@ -28,6 +28,8 @@ stats mesh_generator_plain python $R/bench.py $QUIET --workload mesh --numbering
 stats mesh_random_plain python $R/bench.py $QUIET --workload mesh --numbering random
 stats laplace512 python $R/tools/lap512_only.py
 stats spmm python $R/tools/spmm_only.py
+stats spmm_mesh_rcm env SPMM_MATRIX=mesh_rcm python $R/tools/spmm_only.py
+stats spmm_fem_like env SPMM_MATRIX=fem_like python $R/tools/spmm_only.py
 # counters (their own passes, kernel trace only): what the SpMM and the 512^3 product move
 pmc() {   # name, counter set, command...
   local name=$1 set=$2; shift 2
@@ -50,6 +52,7 @@ PY
 for set in FETCH_SIZE WRITE_SIZE "TCP_TCC_READ_REQ_sum TCC_EA0_RDREQ_sum TCC_HIT_sum TCC_MISS_sum"; do
   pmc spmm "$set" python $R/tools/spmm_only.py
   pmc laplace512 "$set" python $R/tools/lap512_spmv.py
+  pmc spmm_rcm "$set" env SPMM_MATRIX=mesh_rcm python $R/tools/spmm_only.py
 done
 cd $R
 s=$(date +%s)
