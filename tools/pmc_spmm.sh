@@ -5,11 +5,19 @@ cd /tmp && export TMPDIR=/tmp
 R=${GRAFT_REPO_ROOT:-/root/repo}
 OUT=$R/gpurun_out/$1; shift
 rm -rf $OUT; mkdir -p $OUT
+# the assembled mesh matrix first, OUTSIDE the profiler (its generation forks workers: minutes under rocprofv3)
+python - <<PY
+import sys, tempfile, os
+sys.path.insert(0, "$R")
+from mpi_bicgstab_amd import mesh
+d = os.path.join(tempfile.gettempdir(), "bicg_mesh_cache"); os.makedirs(d, exist_ok=True)
+mesh.fem_unstructured(117, "generator", cache_dir=d)
+PY
 i=0
 while read -r set; do
   [ -z "$set" ] && continue
   i=$((i+1))
-  env "$@" timeout 120 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p --output-format csv -- python $R/tools/spmm_only.py > $OUT/p$i.log 2>&1
+  env "$@" timeout 200 rocprofv3 --kernel-trace --pmc $set -d $OUT/p$i -o p --output-format csv -- python $R/tools/spmm_only.py > $OUT/p$i.log 2>&1
 done <<SETS
 GRBM_GUI_ACTIVE SQ_WAVES SQ_BUSY_CU_CYCLES SQ_WAVE_CYCLES SQ_WAIT_INST_ANY SQ_WAIT_ANY
 SQ_INSTS_VALU SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_LDS SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR

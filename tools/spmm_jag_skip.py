@@ -10,7 +10,10 @@ H.lib().bicg_comm_init_single(0)
 kind = os.environ.get("SPMM_MATRIX", "mesh_rcm")
 if kind.startswith("mesh_"):
     from mpi_bicgstab_amd import mesh
-    A = mesh.fem_unstructured(117, kind[5:], 2.0)
+    import tempfile
+    cache = os.path.join(tempfile.gettempdir(), "bicg_mesh_cache")      # (bench.py's: generating the mesh under rocprofv3 takes minutes)
+    os.makedirs(cache, exist_ok=True)
+    A = mesh.fem_unstructured(117, kind[5:], 2.0, cache_dir=cache)
 elif kind == "fem_like":
     A = synth.fem_like(scale_decades=2.0)
 else:
