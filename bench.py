@@ -861,7 +861,7 @@ def main():
                 b8 = csr_bytes(wl2["nnz"], wl2["rows"]) + 2 * nsh * 8 * wl2["rows"]
                 bf = mbytes + 2 * nsh * 8 * wl2["rows"]
                 out["spmm_16_vectors"] = dict(ms=msm, vectors=nsh, kernel=lg.ctx.last_spmm_kind(), bound="hbm", peak=HBM_PEAK_GBS,
-                                              frac=bf / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, format_bytes=bf, survey_8d_bytes=b8,
+                                              frac=bf / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, format_bytes=bf, algorithmic_bytes=b8, survey_8d_bytes=b8,
                                               survey_8d_frac=b8 / (msm * 1e-3) / 1e9 / HBM_PEAK_GBS, spmv_equivalents=msm / sp)
                 del Xm
             lg.close()

@@ -160,6 +160,10 @@ def test_bench_single_gpu_line_has_every_leg():
     # BASELINE.json configs[4] "batched SpMV": 16 vectors through the pipelined SpMM, well below 16 single products
     mm = d["extras"]["spmm_16_vectors"]
     assert mm["kernel"] == "pipelined" and mm["vectors"] == 16 and 0.25 < mm["frac"] < 1.0 and mm["spmv_equivalents"] < 8.5, mm
+    # ... and on ragged rows (the mesh matrix, x windows by lists / by runs): the pipeline of csrc/bicg_spmm_jag.hip
+    for key in ("mesh_rcm", "mesh_generator"):
+        mj = d["extras"][key]["spmm_16_vectors"]
+        assert mj["kernel"] == "pipelined" and mj["vectors"] == 16 and 0.15 < mj["frac"] < 1.0 and mj["spmv_equivalents"] < 9.0, (key, mj)
     assert d["extras"]["laplace7_512_ca"]["plane_marching_product"]["on"] == 1
     assert math.isfinite(d["extras"]["laplace7_512_ca"]["ca_bicgstab"]["true_relres_after_timed_region"])
     for key in ("banded_b8", "banded_b64", "banded_b512", "mesh_rcm", "mesh_generator", "mesh_random", "laplace7_256_ca", "laplace7_512_ca", "transport_rank_of_8"):
